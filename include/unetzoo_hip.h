@@ -1,0 +1,173 @@
+/*
+ * unetzoo_hip.h — C ABI of libunetzoo_hip.so, the MI355X (gfx950) kernel library behind the
+ * unet_zoo encoder/decoder hot path.
+ *
+ * The reference (irfanfadhullah/unet_zoo) has no FFI: every primitive below replaces an ATen op
+ * that the reference reaches through torch.nn.  Each entry point cites
+ * the reference call site it stands in for.  Conventions:
+ *   - plain pointers + ints, no torch types, no allocation inside, no exceptions;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (caller passes torch's current stream);
+ *   - activations are NHWC ("pixel-major"): element (pixel p, channel c) of a tensor lives at
+ *     base[p * ld + c]; `ld` (elements) lets a tensor be a channel slice of a wider buffer, which
+ *     is how skip-concats are never materialised (reference: torch.cat, common_layers.py:115);
+ *   - dtype: UZ_F32 = IEEE fp32 storage + exact-fp32 MFMA (parity mode),
+ *            UZ_BF16 = bf16 storage + bf16 MFMA with fp32 accumulate (throughput mode);
+ *   - return 0 on success, otherwise a negative UZ_E* code or a positive hipError_t;
+ *     uz_last_error_string() describes the last failure on the calling thread.
+ * All functions are re-entrant; there is no process-global mutable state except the
+ * thread-local error string.
+ */
+#ifndef UNETZOO_HIP_H
+#define UNETZOO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UZ_ABI_VERSION 1
+
+enum { UZ_F32 = 0, UZ_BF16 = 1 };
+
+enum {
+  UZ_OK = 0,
+  UZ_EINVAL = -1,   /* bad shape / alignment / unsupported combination */
+  UZ_ENOTIMPL = -2
+};
+
+/* tap geometry of an implicit-GEMM convolution */
+enum {
+  UZ_TAPS_CONV = 0,     /* ntaps = 1 (1x1) or 9 (3x3, dilation `dil`, zero padding `dil`) */
+  UZ_TAPS_GATHER2X2 = 1 /* ntaps = 4: input pixel (2h+a, 2w+b), tap = 2a+b (ConvTranspose k2s2 dgrad) */
+};
+enum {
+  UZ_STORE_PLAIN = 0,    /* y[p*ldy + n] */
+  UZ_STORE_SHUFFLE2X2 = 1 /* n = (2a+b)*Co + co  ->  y[pix(2h+a,2w+b)*ldy + co] (ConvTranspose k2s2 fwd) */
+};
+
+int uz_abi_version(void);
+const char* uz_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the matrix cores.
+ *   y[p, n] = bias[n] + sum_{tap, c} x[pix(p, tap), c] * w[n, tap*Cin + c]
+ * Replaces: nn.Conv2d k3 p1 (common_layers.py:28,31,47,52,71; u2net.py:10 with dilation),
+ *           nn.Conv2d k1 (attention_unet.py:11,18,25), their input-gradients (autograd, a19),
+ *           nn.ConvTranspose2d k2 s2 forward and input-gradient (common_layers.py:104).
+ * Optionally emits per-channel partial sums (sum, sum of squares) of the stored value for the
+ * train-mode BatchNorm that follows (common_layers.py:29,32): stats_partial[g][0][n], [g][1][n]
+ * for g < *grid_m as returned by uz_conv_igemm_grid_m(); reduced by uz_bn_finalize().
+ * Requirements: Cin % (16/sizeof(T)*8) == 0 (bf16: 64, fp32: 32), K = ntaps*Cin,
+ *               x, w, y 16-byte aligned, ldx % (16/sizeof(T)) == 0.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct uz_conv_desc {
+  int dtype;
+  int N, H, W;     /* output pixel grid */
+  int Hin, Win;    /* input pixel grid (== H, W for UZ_TAPS_CONV; 2H, 2W for GATHER2X2) */
+  int Cin, ldx;    /* channels per tap, input pixel stride */
+  int Nout, ldy;   /* GEMM N (rows of w), output pixel stride */
+  int ntaps, taps_mode, dil;
+  int store_mode, Co; /* Co: channels per sub-pixel for UZ_STORE_SHUFFLE2X2 (Nout = 4*Co) */
+} uz_conv_desc;
+
+int uz_conv_igemm_grid_m(const uz_conv_desc* d); /* number of stats partial rows; <0 on error */
+int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                  void* y, float* stats_partial, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient (reduction over pixels), fp32 output in the reference's parameter layout.
+ *   out[i, j, tap] (+)= sum_p L[p, i] * R[pix(p, tap), j]
+ * conv k3/k1:  L = dy (i = c_out), R = x (j = c_in)   -> out is OIHW        (nn.Conv2d.weight)
+ * convT k2s2:  L = x  (i = c_in),  R = dy (j = c_out) -> out is (Cin,Cout,2,2) (ConvTranspose2d.weight)
+ * Replaces the weight-gradient half of autograd for the call sites above.
+ * `out` must be zero-filled by the caller when uz_wgrad_split() > 1 (atomic accumulation).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct uz_wgrad_desc {
+  int dtype;
+  int N, H, W;     /* pixel grid of L */
+  int Hr, Wr;      /* pixel grid of R */
+  int Ci, ldl;     /* channels / pixel stride of L */
+  int Cj, ldr;     /* channels / pixel stride of R */
+  int ntaps, taps_mode, dil;
+} uz_wgrad_desc;
+
+int uz_wgrad_split(const uz_wgrad_desc* d);
+int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight re-packing: fp32 master parameters in the reference layout -> kernel layout in run dtype.
+ *   UZ_PACK_CONV_FWD : w[Co][Ci][T] (OIHW)     -> dst[Co][t*Ci + ci]
+ *   UZ_PACK_CONV_DGRAD: w[Co][Ci][T]           -> dst[Ci][(T-1-t)*Co + co]   (flipped taps)
+ *   UZ_PACK_CONVT_FWD : w[Ci][Co][4]           -> dst[t*Co + co][ci]
+ *   UZ_PACK_CONVT_DGRAD: w[Ci][Co][4]          -> dst[ci][t*Co + co]
+ *   UZ_PACK_IM2COL    : w[Co][Ci][T], K=T*Ci   -> dst[Co][Kpad], k = t*Ci + ci, zero padded
+ * ------------------------------------------------------------------------------------------- */
+enum { UZ_PACK_CONV_FWD = 0, UZ_PACK_CONV_DGRAD = 1, UZ_PACK_CONVT_FWD = 2, UZ_PACK_CONVT_DGRAD = 3,
+       UZ_PACK_IM2COL = 4 };
+int uz_pack_weights(int dtype, int mode, const float* w, int Co, int Ci, int T, int Kpad, void* dst,
+                    void* stream);
+
+/* im2col of a small-channel NCHW fp32 input (the network input, unet.py:31 first conv):
+ *   dst[p][t*C + c] = x[n, c, h+dy, w+dx] (zero padded), dst row length Kpad, k >= 9C zero. */
+int uz_im2col3x3_nchw(int dtype, const float* x_nchw, int N, int C, int H, int W, int Kpad, void* dst,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d (train): finalize statistics.  nn.BatchNorm2d, common_layers.py:29,32.
+ *   mean = S1/count, var = S2/count - mean^2 (biased), invstd = 1/sqrt(var+eps)
+ *   scale = gamma*invstd, shift = beta - mean*scale
+ *   running_mean = (1-m)*rm + m*mean ; running_var = (1-m)*rv + m*var*count/(count-1)
+ * stats_partial as written by uz_conv_igemm ([grid_m][2][C]).
+ * ------------------------------------------------------------------------------------------- */
+int uz_bn_finalize(const float* stats_partial, int grid_m, int C, double count, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean,
+                   float* running_var, float* scale, float* shift, float* mean, float* invstd,
+                   void* stream);
+/* eval mode: scale/shift from running statistics (SURVEY §2.3 "BatchNorm2d (eval)") */
+int uz_bn_eval_scale(int C, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, float* scale, float* shift, void* stream);
+
+/* act = relu(scale*y + shift) written to `act` (ld = lda), and optionally its MaxPool2d(2,2)
+ * (floor mode; common_layers.py:90) to `pooled`.  BN-apply + ReLU + pool in one pass. */
+int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                     int N, int H, int W, int C, void* act, int lda, void* pooled, int ldp,
+                     void* stream);
+
+/* Backward of (BN train -> ReLU [-> MaxPool2d(2,2)]) in two passes.
+ * The gradient arriving at the activation is
+ *     g = g0[p] + g1[p] + (p is the first max of its 2x2 window ? gpool[window] : 0)
+ * (any of g0/g1/gpool may be NULL).  Pass 1 accumulates sums[0][c] = sum g*mask,
+ * sums[1][c] = sum g*mask*xhat (double, caller zero-fills).  Pass 2 writes
+ *     dy = scale * (g*mask - sums0/count - xhat*sums1/count)
+ * and dgamma = sums1, dbeta = sums0 (fp32). */
+typedef struct uz_bnbwd_desc {
+  int dtype;
+  int N, H, W, C;
+  int ldy, ldg0, ldg1, ldgp, lddy;
+} uz_bnbwd_desc;
+int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, const void* g0,
+                          const void* g1, const void* gpool, double* sums, void* stream);
+int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const void* g0,
+                         const void* g1, const void* gpool, const double* sums, double count,
+                         void* dy, float* dgamma, float* dbeta, void* stream);
+
+/* 1x1 convolution with few outputs (OutConv, common_layers.py:125), NCHW fp32 logits.
+ *   out[n, k, h, w] = b[k] + sum_c x[p, c] * w[k, c],  k < Kout <= 8 */
+int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,
+                   const float* b, int Kout, float* out_nchw, void* stream);
+/* dx[p,c] = sum_k g[n,k,hw] * w[k,c];  dw[k,c] += sum_p g*x;  db[k] += sum_p g (dw, db zeroed by caller) */
+int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w, int Kout,
+                   const float* g_nchw, void* dx, int lddx, float* dw, float* db, void* stream);
+
+/* out[c] = sum_p x[p*ld + c] (fp32; out zeroed by caller). ConvTranspose2d bias gradient. */
+int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETZOO_HIP_H */

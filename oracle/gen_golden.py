@@ -1,0 +1,132 @@
+"""Generate tests/golden/* by IMPORTING the reference's own model files (run in the build
+container only: /root/reference does not exist on the GPU box).
+
+    python oracle/gen_golden.py
+
+TEST INFRASTRUCTURE — see oracle/__init__.py.  Nothing is copied from the reference: its
+``unet_zoo/models/{common_layers,unet}.py`` are loaded with importlib under a synthetic parent
+package (``import unet_zoo`` itself fails on the absent torchvision) and executed
+on CPU in fp32; only inputs-by-formula digests and OUTPUT numbers are written.
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference/unet_zoo/models"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle.torch_ref import synthetic_batch  # noqa: E402
+
+
+def load_reference(*files: str):
+    pkg = types.ModuleType("refzoo")
+    pkg.__path__ = [os.path.dirname(REF)]
+    sub = types.ModuleType("refzoo.models")
+    sub.__path__ = [REF]
+    sys.modules["refzoo"], sys.modules["refzoo.models"] = pkg, sub
+    mods = {}
+    for f in files:
+        name = f"refzoo.models.{f}"
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, f + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        mods[f] = m
+    return mods
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def sample_idx(n: int, k: int) -> np.ndarray:
+    rng = np.random.RandomState(12345)
+    return np.sort(rng.choice(n, size=min(k, n), replace=False))
+
+
+def run_case(model, B, H, W, tag, full_logits: bool):
+    x, mask = synthetic_batch(B, 3, H, W, seed=1)
+    model.train()
+    logits = model(x)
+    loss = F.binary_cross_entropy_with_logits(logits, mask)
+    model.zero_grad()
+    loss.backward()
+    named = list(model.named_parameters())
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)).item()
+    arrays = {}
+    meta = {
+        "model": "unet", "B": B, "H": H, "W": W, "input_sha256": sha(x), "mask_sha256": sha(mask),
+        "loss": loss.item(), "global_grad_norm": gnorm,
+        "train_logits_mean": logits.mean().item(), "train_logits_std": logits.std().item(),
+        "train_positive_pixels": int((logits > 0).sum().item()),
+        "grad_l2": {n: p.grad.double().norm().item() for n, p in named},
+    }
+    flat = logits.detach().flatten()
+    idx = sample_idx(flat.numel(), 4096)
+    arrays["logit_idx"] = idx
+    arrays["train_logits_sampled"] = flat[idx].numpy()
+    if full_logits:
+        arrays["train_logits"] = logits.detach().numpy()
+        for n, p in named:  # 64 sampled gradient values per parameter
+            gi = sample_idx(p.numel(), 64)
+            arrays["gidx/" + n] = gi
+            arrays["gval/" + n] = p.grad.flatten()[gi].numpy()
+    # running statistics after the single train-mode forward
+    sd = model.state_dict()
+    for k in ("down_convolution_1.conv.conv_op.1", "bottle_neck.conv_op.4", "up_convolution_4.conv.conv_op.4"):
+        arrays["rm/" + k] = sd[k + ".running_mean"].numpy()
+        arrays["rv/" + k] = sd[k + ".running_var"].numpy()
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)
+    meta.update(eval_logits_mean=ev.mean().item(), eval_logits_std=ev.std().item(),
+                eval_positive_pixels=int((ev > 0).sum().item()))
+    arrays["eval_logits_sampled"] = ev.flatten()[idx].numpy()
+    if full_logits:
+        arrays["eval_logits"] = ev.numpy()
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **arrays)
+    with open(os.path.join(OUT, f"{tag}.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(tag, "loss", meta["loss"], "gnorm", gnorm, "train mean", meta["train_logits_mean"])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    mods = load_reference("common_layers", "unet")
+    RefUNet = mods["unet"].UNet
+
+    torch.manual_seed(0)
+    model = RefUNet(in_channels=3, num_classes=1)
+    sd = model.state_dict()
+    manifest = {
+        "model": "unet", "seed": 0, "n_params": sum(p.numel() for p in model.parameters()),
+        "entries": [[k, list(v.shape), str(v.dtype).replace("torch.", ""), sha(v)] for k, v in sd.items()],
+    }
+    allbytes = hashlib.sha256()
+    for k, v in sd.items():
+        allbytes.update(v.detach().contiguous().numpy().tobytes())
+    manifest["state_digest"] = allbytes.hexdigest()
+    with open(os.path.join(OUT, "unet_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0)
+    print("manifest", manifest["n_params"], len(manifest["entries"]), manifest["state_digest"][:16])
+
+    # case A: small, every number kept
+    run_case(model, 2, 64, 64, "unet_b2_64", full_logits=True)
+    # case B: BASELINE configs[0] (B=2, 256x256): fresh seed-0 model
+    torch.manual_seed(0)
+    model = RefUNet(in_channels=3, num_classes=1)
+    run_case(model, 2, 256, 256, "unet_b2_256", full_logits=False)
+
+
+if __name__ == "__main__":
+    main()

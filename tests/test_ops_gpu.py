@@ -1,0 +1,228 @@
+"""GPU: every C-ABI kernel against the plain-PyTorch fp32 CPU restatement of the same op
+(torch.nn.functional — what the reference itself calls), on seeded inputs, ragged sizes included.
+fp32 run dtype must agree to 1e-4 (north-star tolerance is 1e-3 relative); bf16 is checked
+against the same fp32 math fed bf16-rounded operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from unet_zoo_amd import _lib as L
+from unet_zoo_amd import ops
+from unet_zoo_amd.ops import Act, act_from_nchw
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-4 if dt == torch.float32 else 2e-2
+
+
+def rnd(dt, t):
+    """round through the run dtype so both sides see identical operands"""
+    return t.to(dt).float()
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+def bk(dt):
+    return 32 if dt == torch.float32 else 64
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [
+    (2, 12, 20, 64, 64, 1),      # M = 480: ragged last tile
+    (1, 16, 16, 128, 192, 1),    # Nout tail inside a 128-wide tile
+    (3, 9, 7, 64, 128, 2),       # odd sizes, dilation 2
+    (1, 33, 5, 64, 32, 4),       # dilation larger than W
+])
+def test_conv3x3_fwd_bias_stats(dt, N, H, W, Cin, Cout, dil):
+    g = torch.Generator().manual_seed(0)
+    x = rnd(dt, torch.randn(N, Cin, H, W, generator=g))
+    w = rnd(dt, torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=dil, dilation=dil)
+    xa = act_from_nchw(x.to(DEV), dt)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt)
+    y = ops.new_act(N, H, W, Cout, dt, DEV)
+    stats = ops.conv_igemm(xa, wp, b.to(DEV), y, ntaps=9, dil=dil, want_stats=True)
+    got = y.dense().cpu()
+    assert relerr(got, ref) < tol(dt)
+    # statistics are of the STORED (rounded) value
+    s = stats.double().sum(0).cpu()
+    stored = got.double()
+    assert relerr(s[0], stored.sum((0, 2, 3))) < 1e-4 + tol(dt) * 0.1
+    assert relerr(s[1], (stored ** 2).sum((0, 2, 3))) < 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [(2, 12, 20, 64, 128, 1), (1, 10, 14, 128, 64, 2)])
+def test_conv3x3_dgrad_and_wgrad(dt, N, H, W, Cin, Cout, dil):
+    g = torch.Generator().manual_seed(1)
+    x = rnd(dt, torch.randn(N, Cin, H, W, generator=g)).requires_grad_(True)
+    w = rnd(dt, torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    dy = rnd(dt, torch.randn(N, Cout, H, W, generator=g))
+    F.conv2d(x, w, None, padding=dil, dilation=dil).backward(dy)
+    dya = act_from_nchw(dy.to(DEV), dt)
+    xa = act_from_nchw(x.detach().to(DEV), dt)
+    wd = ops.pack_weights(w.detach().to(DEV), L.PACK_CONV_DGRAD, dt)
+    dx = ops.new_act(N, H, W, Cin, dt, DEV)
+    ops.conv_igemm(dya, wd, None, dx, ntaps=9, dil=dil)
+    assert relerr(dx.dense().cpu(), x.grad) < tol(dt)
+    dw = ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9, dil=dil)
+    assert relerr(dw.cpu(), w.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_wgrad_split_k_large_pixel_count(dt):
+    """many pixels, few channels: the split-K / atomic path"""
+    g = torch.Generator().manual_seed(2)
+    N, H, W, C = 2, 64, 96, 64
+    x = rnd(dt, torch.randn(N, C, H, W, generator=g))
+    dy = rnd(dt, torch.randn(N, C, H, W, generator=g))
+    w = torch.zeros(C, C, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    dw = ops.wgrad(act_from_nchw(dy.to(DEV), dt), act_from_nchw(x.to(DEV), dt), (C, C, 3, 3), ntaps=9)
+    assert relerr(dw.cpu(), w.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_reads_and_writes_channel_windows(dt):
+    """input and output may be channel slices of wider buffers (virtual concat)"""
+    g = torch.Generator().manual_seed(3)
+    N, H, W, Cin, Cout = 1, 8, 8, 64, 64
+    x = rnd(dt, torch.randn(N, Cin, H, W, generator=g))
+    w = rnd(dt, torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05)
+    ref = F.conv2d(x, w, None, padding=1)
+    wide_in = torch.full((N * H * W, 3 * Cin), 7.0, dtype=dt, device=DEV)
+    wide_in[:, Cin:2 * Cin] = act_from_nchw(x.to(DEV), dt).buf
+    xin = Act(wide_in, Cin, Cin, N, H, W)
+    wide_out = torch.full((N * H * W, 2 * Cout), -3.0, dtype=dt, device=DEV)
+    yout = Act(wide_out, Cout, Cout, N, H, W)
+    ops.conv_igemm(xin, ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt), None, yout, ntaps=9)
+    assert relerr(yout.dense().cpu(), ref) < tol(dt)
+    assert torch.all(wide_out[:, :Cout].float() == -3.0)  # neighbours untouched
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 10, 128, 64), (1, 4, 4, 256, 128)])
+def test_conv_transpose2x2_fwd_dgrad_wgrad(dt, N, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(4)
+    x = rnd(dt, torch.randn(N, Cin, H, W, generator=g)).requires_grad_(True)
+    w = rnd(dt, torch.randn(Cin, Cout, 2, 2, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).requires_grad_(True)
+    dy = rnd(dt, torch.randn(N, Cout, 2 * H, 2 * W, generator=g))
+    ref = F.conv_transpose2d(x, w, b, stride=2)
+    ref.backward(dy)
+    xa = act_from_nchw(x.detach().to(DEV), dt)
+    y = ops.new_act(N, 2 * H, 2 * W, Cout, dt, DEV)
+    wp = ops.pack_weights(w.detach().to(DEV), L.PACK_CONVT_FWD, dt)
+    ops.conv_igemm(xa, wp, b.detach().to(DEV).repeat(4), y, ntaps=1, store_mode=L.STORE_SHUFFLE2X2,
+                   nout=4 * Cout, co=Cout)
+    assert relerr(y.dense().cpu(), ref.detach()) < tol(dt)
+    dya = act_from_nchw(dy.to(DEV), dt)
+    dx = ops.new_act(N, H, W, Cin, dt, DEV)
+    ops.conv_igemm(dya, ops.pack_weights(w.detach().to(DEV), L.PACK_CONVT_DGRAD, dt), None, dx, ntaps=4,
+                   taps_mode=L.TAPS_GATHER2X2)
+    assert relerr(dx.dense().cpu(), x.grad) < tol(dt)
+    dw = ops.wgrad(xa, dya, (Cin, Cout, 2, 2), ntaps=4, taps_mode=L.TAPS_GATHER2X2)
+    assert relerr(dw.cpu(), w.grad) < tol(dt)
+    assert relerr(ops.colsum(dya).cpu(), b.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_im2col_first_conv(dt):
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W, Cout = 2, 3, 10, 12, 64
+    x = torch.randn(N, C, H, W, generator=g)
+    w = rnd(dt, torch.randn(Cout, C, 3, 3, generator=g) * 0.2)
+    ref = F.conv2d(rnd(dt, x), w, None, padding=1)
+    a = ops.im2col3x3_nchw(x.to(DEV), bk(dt), dt)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_IM2COL, dt, bk(dt))
+    y = ops.new_act(N, H, W, Cout, dt, DEV)
+    ops.conv_igemm(a, wp, None, y, ntaps=1)
+    assert relerr(y.dense().cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 64), (1, 6, 6, 256)])
+def test_bn_relu_pool_forward_backward(dt, pool, N, H, W, C):
+    """train-mode BatchNorm2d + ReLU (+ MaxPool2d(2,2)) forward, running stats and backward with a
+    direct gradient, a second direct gradient and a pooled gradient"""
+    g = torch.Generator().manual_seed(6)
+    y = rnd(dt, torch.randn(N, C, H, W, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    act_ref = F.relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    g0 = rnd(dt, torch.randn(N, C, H, W, generator=g))
+    g1 = rnd(dt, torch.randn(N, C, H, W, generator=g))
+    loss = (act_ref * (g0 + g1)).sum()
+    if pool:
+        p_ref = F.max_pool2d(act_ref, 2, 2)
+        gp = rnd(dt, torch.randn(N, C, H // 2, W // 2, generator=g))
+        loss = loss + (p_ref * gp).sum()
+    loss.backward()
+
+    ya = act_from_nchw(y.detach().to(DEV), dt)
+    # statistics exactly as the conv epilogue would deliver them: one partial row
+    yd = ya.buf.double()
+    stats = torch.stack([yd.sum(0), (yd ** 2).sum(0)]).float().reshape(1, 2, C)
+    rm_d, rv_d = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    vec = ops.bn_finalize(stats, N * H * W, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, rm_d, rv_d)
+    assert relerr(rm_d.cpu(), rm) < 1e-5 and relerr(rv_d.cpu(), rv) < 1e-5
+    act = ops.new_act(N, H, W, C, dt, DEV)
+    pooled = ops.new_act(N, H // 2, W // 2, C, dt, DEV) if pool else None
+    ops.bn_relu_apply(ya, vec[0], vec[1], act, pooled)
+    assert relerr(act.dense().cpu(), act_ref.detach()) < tol(dt)
+    if pool:
+        assert relerr(pooled.dense().cpu(), p_ref.detach()) < tol(dt)
+
+    sums = torch.zeros(2, C, dtype=torch.float64, device=DEV)
+    dy = ops.new_act(N, H, W, C, dt, DEV)
+    dgb = torch.empty(2, C, device=DEV)
+    ops.bn_relu_bwd(ya, vec, act_from_nchw(g0.to(DEV), dt), act_from_nchw(g1.to(DEV), dt),
+                    act_from_nchw(gp.to(DEV), dt) if pool else None, sums, dy, dgb[0], dgb[1])
+    t = tol(dt) * (5 if dt == torch.bfloat16 else 1)
+    assert relerr(dy.dense().cpu(), y.grad) < t
+    assert relerr(dgb[0].cpu(), gamma.grad) < t
+    assert relerr(dgb[1].cpu(), beta.grad) < t
+
+
+def test_bn_eval_scale():
+    g = torch.Generator().manual_seed(7)
+    C = 96
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.1
+    vec = ops.bn_eval_scale(gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5)
+    x = torch.randn(4, C, 3, 3, generator=g)
+    ref = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    got = x * vec[0].cpu().view(1, C, 1, 1) + vec[1].cpu().view(1, C, 1, 1)
+    assert relerr(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("K", [1, 3])
+def test_outconv_fwd_bwd(dt, K):
+    g = torch.Generator().manual_seed(8)
+    N, H, W, C = 2, 9, 11, 64
+    x = rnd(dt, torch.randn(N, C, H, W, generator=g)).requires_grad_(True)
+    w = (torch.randn(K, C, 1, 1, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(K, generator=g).requires_grad_(True)
+    gl = torch.randn(N, K, H, W, generator=g)
+    ref = F.conv2d(x, w, b)
+    ref.backward(gl)
+    xa = act_from_nchw(x.detach().to(DEV), dt)
+    wd = w.detach().reshape(K, C).to(DEV)
+    out = ops.outconv_fwd(xa, wd, b.detach().to(DEV))
+    assert relerr(out.cpu(), ref.detach()) < 1e-5
+    dx = ops.new_act(N, H, W, C, dt, DEV)
+    dw, db = ops.outconv_bwd(xa, wd, gl.to(DEV), dx)
+    assert relerr(dx.dense().cpu(), x.grad) < tol(dt)
+    assert relerr(dw.cpu(), w.grad.reshape(K, C)) < 1e-4
+    assert relerr(db.cpu(), b.grad) < 1e-4

@@ -1,0 +1,155 @@
+"""GPU: the whole UNet hot path (forward + backward through the C ABI) against the golden vectors
+generated from the reference and against the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import unet_zoo_amd
+from oracle import torch_ref
+
+DEV = "cuda"
+
+
+def _golden(golden_dir, tag):
+    with open(os.path.join(golden_dir, tag + ".json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(golden_dir, tag + ".npz"))
+
+
+def _model(dtype):
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=1)
+    m.run_dtype = dtype
+    return m.to(DEV)
+
+
+def _step(m, x, mask):
+    m.train()
+    m.zero_grad()
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, mask.to(DEV))
+    loss.backward()
+    return logits.detach().cpu(), loss.item()
+
+
+def test_fp32_step_matches_reference_golden(golden_dir):
+    """B=2, 64x64, fp32 run dtype: logits, loss, every parameter gradient, running statistics and
+    the following eval-mode forward, all within the north-star tolerance (1e-3 relative)."""
+    meta, arr = _golden(golden_dir, "unet_b2_64")
+    x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=1)
+    m = _model(torch.float32)
+    logits, loss = _step(m, x, mask)
+    ref = torch.from_numpy(arr["train_logits"])
+    assert (logits - ref).abs().max() <= 1e-3 * ref.abs().max()
+    assert torch.equal(logits > 0, ref > 0) or ((logits > 0) != (ref > 0)).sum() == 0
+    assert abs(loss - meta["loss"]) < 1e-5
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())).item()
+    assert abs(gn - meta["global_grad_norm"]) < 1e-3 * meta["global_grad_norm"]
+    for name, p in m.named_parameters():
+        rn = meta["grad_l2"][name]
+        got = p.grad.double().norm().item()
+        if name.endswith("conv_op.0.bias") or name.endswith("conv_op.3.bias"):
+            assert got <= 1e-5          # analytically zero under train-mode BN; reference = rounding noise
+            assert rn <= 1e-5
+            continue
+        assert abs(got - rn) <= 2e-3 * rn + 1e-7, (name, got, rn)
+        idx = arr["gidx/" + name]
+        gv = p.grad.flatten()[torch.from_numpy(idx).to(DEV)].cpu().numpy()
+        scale = np.abs(arr["gval/" + name]).max() + 1e-12
+        assert np.abs(gv - arr["gval/" + name]).max() <= 2e-3 * scale + 1e-7, name
+    sd = m.state_dict()
+    for k in ("down_convolution_1.conv.conv_op.1", "bottle_neck.conv_op.4", "up_convolution_4.conv.conv_op.4"):
+        np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), arr["rm/" + k], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), arr["rv/" + k], rtol=1e-3, atol=1e-5)
+        assert int(sd[k + ".num_batches_tracked"]) == 1
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(DEV)).cpu()
+    evr = torch.from_numpy(arr["eval_logits"])
+    assert (ev - evr).abs().max() <= 1e-3 * evr.abs().max()
+
+
+def test_fp32_config0_b2_256_matches_reference_golden(golden_dir):
+    """BASELINE.json configs[0] shape (B=2, 3x256x256)."""
+    meta, arr = _golden(golden_dir, "unet_b2_256")
+    x, mask = torch_ref.synthetic_batch(2, 3, 256, 256, seed=1)
+    m = _model(torch.float32)
+    logits, loss = _step(m, x, mask)
+    flat = logits.flatten()
+    ref = torch.from_numpy(arr["train_logits_sampled"])
+    got = flat[torch.from_numpy(arr["logit_idx"])]
+    assert (got - ref).abs().max() <= 1e-3 * ref.abs().max()
+    assert abs(loss - meta["loss"]) < 1e-5
+    assert int((logits > 0).sum()) == meta["train_positive_pixels"]   # bit-exact mask
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())).item()
+    assert abs(gn - meta["global_grad_norm"]) < 1e-3 * meta["global_grad_norm"]
+
+
+def test_bf16_step_close_to_reference_with_margin_aware_mask(golden_dir):
+    """bf16 throughput mode: logits within a bf16-sized tolerance; masks must agree wherever the
+    reference logit is not within that tolerance of the threshold."""
+    meta, arr = _golden(golden_dir, "unet_b2_64")
+    x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=1)
+    m = _model(torch.bfloat16)
+    logits, loss = _step(m, x, mask)
+    ref = torch.from_numpy(arr["train_logits"])
+    tol = 0.06 * ref.abs().max()
+    assert (logits - ref).abs().max() <= tol
+    safe = ref.abs() > tol
+    assert torch.equal((logits > 0)[safe], (ref > 0)[safe])
+    assert abs(loss - meta["loss"]) < 2e-2
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())).item()
+    assert abs(gn - meta["global_grad_norm"]) < 0.1 * meta["global_grad_norm"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_against_oracle_on_other_shape_and_classes(dtype):
+    """non-square input, 2 classes, different seed: HIP path vs the CPU oracle on the same state"""
+    torch.manual_seed(11)
+    m = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=2)
+    m.run_dtype = dtype
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, 32, 48, generator=g)
+    t = (torch.rand(1, 2, 32, 48, generator=g) > 0.5).float()
+    logits = m(x.to(DEV))
+    F.binary_cross_entropy_with_logits(logits, t.to(DEV)).backward()
+    st = torch_ref.clone_state(sd, requires_grad=True)
+    ref = torch_ref.unet_forward(st, x, True)
+    F.binary_cross_entropy_with_logits(ref, t).backward()
+    rel = 1e-3 if dtype == torch.float32 else 8e-2
+    assert (logits.detach().cpu() - ref.detach()).abs().max() <= rel * ref.detach().abs().max()
+    for name, p in m.named_parameters():
+        rg = st[name].grad
+        if rg.abs().max() < 1e-6:
+            continue
+        err = (p.grad.cpu() - rg).abs().max() / rg.abs().max()
+        assert err <= (5e-3 if dtype == torch.float32 else 0.25), (name, err.item())
+
+
+def test_full_size_properties_bf16():
+    """BASELINE configs[1] size (B=16, 256x256, bf16): size-independent properties — finite
+    outputs, BN invariants (per-channel mean of the BN output gradient is ~0 so conv-bias grads
+    vanish), running stats moved, deterministic forward."""
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("unet").to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(16, 3, 256, 256, seed=2)
+    x, mask = x.to(DEV), mask.to(DEV)
+    a = m(x)
+    loss = F.binary_cross_entropy_with_logits(a, mask)
+    loss.backward()
+    assert a.shape == (16, 1, 256, 256) and torch.isfinite(a).all()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    assert 0.5 < loss.item() < 1.0
+    rm = m.state_dict()["down_convolution_1.conv.conv_op.1.running_mean"]
+    assert rm.abs().max() > 0
+    with torch.no_grad():
+        b = m(x)
+    assert torch.equal(a.detach(), b)   # same batch statistics -> identical forward

@@ -1,0 +1,129 @@
+"""ctypes binding of libunetzoo_hip.so (C ABI declared in include/unetzoo_hip.h).
+
+The product path has no CPU or PyTorch fallback: if the shared library is missing, or an op is
+handed a non-CUDA tensor, it raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C unet_zoo_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_void_p
+
+import torch
+
+UZ_F32, UZ_BF16 = 0, 1
+TAPS_CONV, TAPS_GATHER2X2 = 0, 1
+STORE_PLAIN, STORE_SHUFFLE2X2 = 0, 1
+PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD, PACK_IM2COL = range(5)
+
+LIB_NAME = "libunetzoo_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+# every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "uz_abi_version", "uz_last_error_string", "uz_conv_igemm_grid_m", "uz_conv_igemm",
+    "uz_wgrad_split", "uz_wgrad", "uz_pack_weights", "uz_im2col3x3_nchw", "uz_bn_finalize",
+    "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
+    "uz_outconv_fwd", "uz_outconv_bwd", "uz_colsum",
+)
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in (
+        "dtype", "N", "H", "W", "Hin", "Win", "Cin", "ldx", "Nout", "ldy", "ntaps", "taps_mode",
+        "dil", "store_mode", "Co")]
+
+
+class WgradDesc(Structure):
+    _fields_ = [(n, c_int) for n in (
+        "dtype", "N", "H", "W", "Hr", "Wr", "Ci", "ldl", "Cj", "ldr", "ntaps", "taps_mode", "dil")]
+
+
+class BnBwdDesc(Structure):
+    _fields_ = [(n, c_int) for n in (
+        "dtype", "N", "H", "W", "C", "ldy", "ldg0", "ldg1", "ldgp", "lddy")]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the kernel library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP kernel library is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` from the repo root. "
+            "unet_zoo_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.uz_abi_version.restype = c_int
+    lib.uz_last_error_string.restype = c_char_p
+    vp, ip, fp = c_void_p, c_int, c_float
+    lib.uz_conv_igemm_grid_m.argtypes = [POINTER(ConvDesc)]
+    lib.uz_conv_igemm.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    lib.uz_wgrad_split.argtypes = [POINTER(WgradDesc)]
+    lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp]
+    lib.uz_pack_weights.argtypes = [ip, ip, vp, ip, ip, ip, ip, vp, vp]
+    lib.uz_im2col3x3_nchw.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp]
+    lib.uz_bn_finalize.argtypes = [vp, ip, ip, c_double, vp, vp, fp, fp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_bn_eval_scale.argtypes = [ip, vp, vp, vp, vp, fp, vp, vp, vp]
+    lib.uz_bn_relu_apply.argtypes = [ip, vp, ip, vp, vp, ip, ip, ip, ip, vp, ip, vp, ip, vp]
+    lib.uz_bn_relu_bwd_reduce.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_bn_relu_bwd_apply.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                         c_double, vp, vp, vp, vp]
+    lib.uz_outconv_fwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
+    lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp]
+    lib.uz_colsum.argtypes = [ip, vp, ip, ip, ip, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("uz_last_error_string",):
+            fn.restype = c_int
+    if lib.uz_abi_version() != 1:
+        raise HipLibraryError("libunetzoo_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def _fail(rc: int, what: str):
+    msg = load().uz_last_error_string().decode("utf-8", "replace")
+    raise HipLibraryError(f"{what} failed (code {rc}): {msg}")
+
+
+def check(rc: int, what: str) -> None:
+    """Status-returning entry points: anything but 0 is an error."""
+    if rc != 0:
+        _fail(rc, what)
+
+
+def check_count(rc: int, what: str) -> int:
+    """Count-returning entry points (grid_m, split): negative is an error."""
+    if rc < 0:
+        _fail(rc, what)
+    return rc
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return UZ_F32
+    if dt == torch.bfloat16:
+        return UZ_BF16
+    raise ValueError(f"unsupported run dtype {dt}; use torch.float32 or torch.bfloat16")
+
+
+def require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError(
+                "unet_zoo_amd kernels run on an MI355X only: got a CPU tensor. Move the model and "
+                "inputs to 'cuda' (there is no CPU fallback in the product path).")

@@ -1,0 +1,63 @@
+// Internal helpers shared by the gfx950 kernels of libunetzoo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/unetzoo_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+#define UZ_WAVE 64
+#define UZ_NUM_CU 256
+#define UZ_NUM_XCD 8
+
+void uz_set_error(const char* fmt, ...);
+
+#define UZ_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      uz_set_error(__VA_ARGS__);         \
+      return UZ_EINVAL;                  \
+    }                                    \
+  } while (0)
+
+#define UZ_LAUNCH_CHECK(name)                                               \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      uz_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));  \
+      return (int)e__;                                                      \
+    }                                                                       \
+  } while (0)
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int VEC = 4;  // elements per 16 bytes
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int VEC = 8;
+};
+
+// 16-byte vector of T, loaded/stored as one dwordx4.
+template <typename T> struct alignas(16) Vec16 {
+  T v[ElemTraits<T>::VEC];
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+  return *reinterpret_cast<const Vec16<T>*>(p);
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<Vec16<T>*>(p) = v;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+  Vec16<T> z;
+#pragma unroll
+  for (int i = 0; i < ElemTraits<T>::VEC; ++i) z.v[i] = (T)0.0f;
+  return z;
+}
+
+static inline int uz_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,805 @@
+// Bandwidth-bound kernels of the UNet hot path for gfx950 (MI355X): BatchNorm statistics
+// finalisation, BN-apply + ReLU (+ 2x2 max-pool) forward, its two-pass backward, the 1x1 output
+// convolution, weight re-packing and the input im2col.  All activations NHWC with 16-byte
+// (8 x bf16 / 4 x fp32) accesses per lane; per-channel reductions go wave-shuffle -> LDS -> one
+// atomic per block and channel.
+//
+// Reference call sites replaced: nn.BatchNorm2d / nn.ReLU / nn.MaxPool2d in DoubleConv and
+// DownSample (unet_zoo/models/common_layers.py:29-33, 90-95), OutConv (:125), and their
+// autograd backward (unet_zoo/utils/training_loop.py:119).
+#include "uz_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void load_f(const T* p, float* f) {
+  const Vec16<T> v = ld16(p);
+#pragma unroll
+  for (int i = 0; i < ElemTraits<T>::VEC; ++i) f[i] = (float)v.v[i];
+}
+template <typename T> __device__ __forceinline__ void store_f(T* p, const float* f) {
+  Vec16<T> v;
+#pragma unroll
+  for (int i = 0; i < ElemTraits<T>::VEC; ++i) v.v[i] = (T)f[i];
+  st16(p, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// BN finalize: reduce the conv kernel's partial rows and derive scale/shift + running stats.
+// One block of 1024 threads per 32 channels: thread (c = t & 31, g = t >> 5) sums rows g, g+32, ...
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
+    const float* __restrict__ part, int grid_m, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+    float* running_var, float* scale, float* shift, float* mean, float* invstd) {
+  __shared__ double sh[2][32][33];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    for (int r = g; r < grid_m; r += 32) {
+      a1 += (double)part[((size_t)r * 2 + 0) * C + c];
+      a2 += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  sh[0][g][cl] = a1;
+  sh[1][g][cl] = a2;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < 32; ++r) {
+      t1 += sh[0][r][cl];
+      t2 += sh[1][r][cl];
+    }
+    const double m = t1 / count;
+    double var = t2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double istd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * istd);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * istd);
+    mean[c] = (float)m;
+    invstd[c] = (float)istd;
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+  }
+}
+
+__global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                     const float* rv, float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float istd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * istd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BN apply + ReLU (+ pool).  One thread = one pixel (POOL=false) or one 2x2 window (POOL=true)
+// x VEC channels; consecutive threads walk the channel chunks of one pixel/window first, so each
+// wave-instruction reads whole contiguous pixel rows.
+// ------------------------------------------------------------------------------------------
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(
+    const T* __restrict__ y, int ldy, const float* __restrict__ scale, const float* __restrict__ shift,
+    int N, int H, int W, int C, T* __restrict__ act, int lda, T* __restrict__ pooled, int ldp) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CC = C / VEC;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long long total = POOL ? (long long)N * Ho * Wo * CC : (long long)N * H * W * CC;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % CC);
+    const long long u = idx / CC;
+    const int c0 = cc * VEC;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(scale + c0 + i);
+      *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(shift + c0 + i);
+    }
+    if constexpr (!POOL) {
+      float v[VEC];
+      load_f(y + (size_t)u * ldy + c0, v);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+      store_f(act + (size_t)u * lda + c0, v);
+    } else {
+      const int wo = (int)(u % Wo);
+      const long long t = u / Wo;
+      const int ho = (int)(t % Ho);
+      const int img = (int)(t / Ho);
+      const size_t p00 = ((size_t)img * H + 2 * ho) * W + 2 * wo;
+      float m[VEC];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const size_t p = p00 + (k >> 1) * W + (k & 1);
+        float v[VEC];
+        load_f(y + p * ldy + c0, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+          m[i] = (k == 0) ? v[i] : fmaxf(m[i], v[i]);
+        }
+        store_f(act + p * lda + c0, v);
+      }
+      store_f(pooled + (size_t)u * ldp + c0, m);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of BN(train) + ReLU (+ pool): shared per-thread work.
+// For its pixel (or 2x2 window) and VEC channels the thread forms dz = g * [act > 0] and xhat.
+// PASS 1 accumulates S0 += dz, S1 += dz*xhat; PASS 2 writes dy = scale*(dz - S0/N - xhat*S1/N).
+// The pool gradient goes to the FIRST maximum of the window in (0,0),(0,1),(1,0),(1,1) order,
+// which is the element ATen's max_pool2d records (strict '>' scan).
+// ------------------------------------------------------------------------------------------
+struct BnBwdArgs {
+  const void* y;
+  const void* g0;
+  const void* g1;
+  const void* gp;
+  void* dy;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  double* sums;        // pass 1 out / pass 2 in: [2][C]
+  float* dgamma;
+  float* dbeta;
+  double inv_count;
+  int N, H, W, C, ldy, ldg0, ldg1, ldgp, lddy;
+};
+
+template <typename T, bool POOL, int PASS>
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int NPIX = POOL ? 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // PASS 1: [blockDim.y][blockDim.x][2*VEC]
+  const T* __restrict__ y = static_cast<const T*>(a.y);
+  const T* __restrict__ g0 = static_cast<const T*>(a.g0);
+  const T* __restrict__ g1 = static_cast<const T*>(a.g1);
+  const T* __restrict__ gp = static_cast<const T*>(a.gp);
+  T* __restrict__ dy = static_cast<T*>(a.dy);
+  const int CC = a.C / VEC;
+  const int cc = blockIdx.y * blockDim.x + threadIdx.x;  // channel chunk of this thread
+  const bool cok = cc < CC;
+  const int c0 = (cok ? cc : 0) * VEC;
+  const int Ho = a.H >> 1, Wo = a.W >> 1;
+  const long long units = POOL ? (long long)a.N * Ho * Wo : (long long)a.N * a.H * a.W;
+
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC], k0[VEC], k1[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = a.scale[c0 + i];
+    sh[i] = a.shift[c0 + i];
+    mu[i] = a.mean[c0 + i];
+    is[i] = a.invstd[c0 + i];
+    if (PASS == 2) {
+      k0[i] = (float)(a.sums[c0 + i] * a.inv_count);
+      k1[i] = (float)(a.sums[a.C + c0 + i] * a.inv_count);
+    }
+  }
+  float S0[VEC], S1[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) S0[i] = S1[i] = 0.f;
+
+  for (long long u = (long long)blockIdx.x * blockDim.y + threadIdx.y; u < units && cok;
+       u += (long long)gridDim.x * blockDim.y) {
+    size_t p00;
+    if constexpr (POOL) {
+      const int wo = (int)(u % Wo);
+      const long long t = u / Wo;
+      const int ho = (int)(t % Ho);
+      const int img = (int)(t / Ho);
+      p00 = ((size_t)img * a.H + 2 * ho) * a.W + 2 * wo;
+    } else {
+      p00 = (size_t)u;
+    }
+    float yv[NPIX][VEC], gv[NPIX][VEC];
+#pragma unroll
+    for (int k = 0; k < NPIX; ++k) {
+      const size_t p = POOL ? p00 + (k >> 1) * a.W + (k & 1) : p00;
+      load_f(y + p * a.ldy + c0, yv[k]);
+      if (g0 != nullptr) {
+        load_f(g0 + p * a.ldg0 + c0, gv[k]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv[k][i] = 0.f;
+      }
+      if (g1 != nullptr) {
+        float t[VEC];
+        load_f(g1 + p * a.ldg1 + c0, t);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv[k][i] += t[i];
+      }
+    }
+    if constexpr (POOL) {
+      if (gp != nullptr) {
+        float gpv[VEC];
+        load_f(gp + (size_t)u * a.ldgp + c0, gpv);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          float best = fmaxf(fmaf(yv[0][i], sc[i], sh[i]), 0.f);
+          int bk = 0;
+#pragma unroll
+          for (int k = 1; k < 4; ++k) {
+            const float v = fmaxf(fmaf(yv[k][i], sc[i], sh[i]), 0.f);
+            if (v > best) {
+              best = v;
+              bk = k;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gv[k][i] += (k == bk) ? gpv[i] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NPIX; ++k) {
+      float out[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float pre = fmaf(yv[k][i], sc[i], sh[i]);
+        const float dz = pre > 0.f ? gv[k][i] : 0.f;
+        const float xh = (yv[k][i] - mu[i]) * is[i];
+        if (PASS == 1) {
+          S0[i] += dz;
+          S1[i] += dz * xh;
+        } else {
+          out[i] = sc[i] * (dz - k0[i] - xh * k1[i]);
+        }
+      }
+      if (PASS == 2) {
+        const size_t p = POOL ? p00 + (k >> 1) * a.W + (k & 1) : p00;
+        store_f(dy + p * a.lddy + c0, out);
+      }
+    }
+  }
+
+  if (PASS == 1) {
+    // reduce over threadIdx.y through LDS, then one double atomic per channel and block
+    float* mine = red + ((size_t)threadIdx.y * blockDim.x + threadIdx.x) * (2 * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mine[i] = S0[i];
+      mine[VEC + i] = S1[i];
+    }
+    __syncthreads();
+    // thread (x, y) finalises element e = y, y + blockDim.y, ... of chunk x
+    for (int e = threadIdx.y; e < 2 * VEC; e += blockDim.y) {
+      float t = 0.f;
+      for (int r = 0; r < (int)blockDim.y; ++r) t += red[((size_t)r * blockDim.x + threadIdx.x) * (2 * VEC) + e];
+      if (cok) {
+        const int which = e / VEC, ch = c0 + (e % VEC);
+        atomicAdd(a.sums + (size_t)which * a.C + ch, (double)t);
+      }
+    }
+  } else {
+    if (blockIdx.x == 0 && threadIdx.y == 0 && cok && a.dgamma != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        a.dbeta[c0 + i] = (float)a.sums[c0 + i];
+        a.dgamma[c0 + i] = (float)a.sums[a.C + c0 + i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// OutConv: 1x1 convolution to Kout <= 8 logits, NCHW fp32 output.  LPP = C/VEC lanes cooperate
+// on one pixel (one 16-byte load each) and combine with xor-shuffles.
+// ------------------------------------------------------------------------------------------
+constexpr int OUTCONV_MAXK = 8;
+
+template <typename T, int KOUT>
+__global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ x, int ldx, int N,
+                                                          int HW, int C, const float* __restrict__ w,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ out) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int LPP = C / VEC;  // lanes per pixel: power of two, <= 64
+  const int ppb = blockDim.x / LPP;
+  const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+  const long long P = (long long)N * HW;
+  float wr[KOUT][VEC];
+#pragma unroll
+  for (int k = 0; k < KOUT; ++k)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) wr[k][i] = w[k * C + sub * VEC + i];
+  for (long long p0 = (long long)blockIdx.x * ppb; p0 < P; p0 += (long long)gridDim.x * ppb) {
+    const long long p = p0 + pl;
+    float v[VEC];
+    if (p < P) {
+      load_f(x + (size_t)p * ldx + sub * VEC, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+    }
+    const long long img = p / HW, hw = p - img * HW;
+#pragma unroll
+    for (int k = 0; k < KOUT; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s = fmaf(v[i], wr[k][i], s);
+      for (int o = LPP >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (sub == 0 && p < P) out[((size_t)img * KOUT + k) * HW + hw] = s + b[k];
+    }
+  }
+}
+
+template <typename T, int KOUT>
+__global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ x, int ldx, int N,
+                                                          int HW, int C, const float* __restrict__ w,
+                                                          const float* __restrict__ g,
+                                                          T* __restrict__ dx, int lddx,
+                                                          float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ float red[256 * 9];
+  const int LPP = C / VEC;
+  const int ppb = blockDim.x / LPP;
+  const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+  const long long P = (long long)N * HW;
+  float wr[KOUT][VEC], aw[KOUT][VEC], ab[KOUT];
+#pragma unroll
+  for (int k = 0; k < KOUT; ++k) {
+    ab[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      wr[k][i] = w[k * C + sub * VEC + i];
+      aw[k][i] = 0.f;
+    }
+  }
+  for (long long p0 = (long long)blockIdx.x * ppb; p0 < P; p0 += (long long)gridDim.x * ppb) {
+    const long long p = p0 + pl;
+    if (p >= P) continue;
+    const long long img = p / HW, hw = p - img * HW;
+    float v[VEC], d[VEC];
+    load_f(x + (size_t)p * ldx + sub * VEC, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) d[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KOUT; ++k) {
+      const float gk = g[((size_t)img * KOUT + k) * HW + hw];
+      ab[k] += gk;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        d[i] = fmaf(gk, wr[k][i], d[i]);
+        aw[k][i] = fmaf(gk, v[i], aw[k][i]);
+      }
+    }
+    if (dx != nullptr) store_f(dx + (size_t)p * lddx + sub * VEC, d);
+  }
+  // block reduction over the ppb pixel lanes that share `sub`
+#pragma unroll
+  for (int k = 0; k < KOUT; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x * 9 + i] = aw[k][i];
+    red[threadIdx.x * 9 + 8] = ab[k];
+    __syncthreads();
+    if (pl == 0) {
+      float t[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) t[i] = 0.f;
+      for (int r = 0; r < ppb; ++r)
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+          if (i < VEC || i == 8) t[i] += red[(r * LPP + sub) * 9 + i];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) atomicAdd(dw + k * C + sub * VEC + i, t[i]);
+      if (sub == 0) atomicAdd(db + k, t[8]);
+    }
+  }
+}
+
+#define UZ_KOUT_SWITCH(K, ...)                   \
+  switch (K) {                                   \
+    case 1: { constexpr int KOUT = 1; __VA_ARGS__; break; } \
+    case 2: { constexpr int KOUT = 2; __VA_ARGS__; break; } \
+    case 3: { constexpr int KOUT = 3; __VA_ARGS__; break; } \
+    case 4: { constexpr int KOUT = 4; __VA_ARGS__; break; } \
+    case 5: { constexpr int KOUT = 5; __VA_ARGS__; break; } \
+    case 6: { constexpr int KOUT = 6; __VA_ARGS__; break; } \
+    case 7: { constexpr int KOUT = 7; __VA_ARGS__; break; } \
+    default: { constexpr int KOUT = 8; __VA_ARGS__; break; } \
+  }
+
+// out[c] += sum_p x[p*ld + c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long long P, int C,
+                                                     float* __restrict__ out) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [blockDim.y][blockDim.x][VEC]
+  const int CC = C / VEC;
+  const int cc = blockIdx.y * blockDim.x + threadIdx.x;
+  const bool cok = cc < CC;
+  const int c0 = (cok ? cc : 0) * VEC;
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.y + threadIdx.y; p < P && cok;
+       p += (long long)gridDim.x * blockDim.y) {
+    float v[VEC];
+    load_f(x + (size_t)p * ld + c0, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] += v[i];
+  }
+  float* mine = red + ((size_t)threadIdx.y * blockDim.x + threadIdx.x) * VEC;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) mine[i] = s[i];
+  __syncthreads();
+  for (int e = threadIdx.y; e < VEC; e += blockDim.y) {
+    float t = 0.f;
+    for (int r = 0; r < (int)blockDim.y; ++r) t += red[((size_t)r * blockDim.x + threadIdx.x) * VEC + e];
+    if (cok) atomicAdd(out + c0 + e, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight packing and input im2col
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(int mode, const float* __restrict__ w, int Co, int Ci, int Tn,
+                                    int Kpad, T* __restrict__ dst, long long total) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    switch (mode) {
+      case UZ_PACK_CONV_FWD: {  // dst[Co][t*Ci+ci] <- w[co][ci][t]
+        const int k = (int)(idx % ((long long)Tn * Ci));
+        const int co = (int)(idx / ((long long)Tn * Ci));
+        const int t = k / Ci, ci = k - t * Ci;
+        v = w[((size_t)co * Ci + ci) * Tn + t];
+        break;
+      }
+      case UZ_PACK_CONV_DGRAD: {  // dst[Ci][(T-1-t)*Co+co] <- w[co][ci][t]
+        const int k = (int)(idx % ((long long)Tn * Co));
+        const int ci = (int)(idx / ((long long)Tn * Co));
+        const int tf = k / Co, co = k - tf * Co;
+        v = w[((size_t)co * Ci + ci) * Tn + (Tn - 1 - tf)];
+        break;
+      }
+      case UZ_PACK_CONVT_FWD: {  // dst[t*Co+co][ci] <- w[ci][co][t]
+        const int ci = (int)(idx % Ci);
+        const int r = (int)(idx / Ci);
+        const int t = r / Co, co = r - t * Co;
+        v = w[((size_t)ci * Co + co) * Tn + t];
+        break;
+      }
+      case UZ_PACK_CONVT_DGRAD: {  // dst[ci][t*Co+co] <- w[ci][co][t]
+        const int k = (int)(idx % ((long long)Tn * Co));
+        const int ci = (int)(idx / ((long long)Tn * Co));
+        const int t = k / Co, co = k - t * Co;
+        v = w[((size_t)ci * Co + co) * Tn + t];
+        break;
+      }
+      default: {  // UZ_PACK_IM2COL: dst[Co][Kpad], k = t*Ci+ci
+        const int k = (int)(idx % Kpad);
+        const int co = (int)(idx / Kpad);
+        if (k < Tn * Ci) {
+          const int t = k / Ci, ci = k - t * Ci;
+          v = w[((size_t)co * Ci + ci) * Tn + t];
+        }
+        break;
+      }
+    }
+    dst[idx] = (T)v;
+  }
+}
+
+template <typename T>
+__global__ void im2col3x3_kernel(const float* __restrict__ x, int N, int C, int H, int W, int Kpad,
+                                 T* __restrict__ dst, long long total) {
+  // one thread per destination element; consecutive threads = consecutive k of one pixel
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Kpad);
+    const long long p = idx / Kpad;
+    float v = 0.f;
+    if (k < 9 * C) {
+      const int t = k / C, c = k - t * C;
+      const int w0 = (int)(p % W);
+      const long long q = p / W;
+      const int h0 = (int)(q % H);
+      const int img = (int)(q / H);
+      const int hh = h0 + t / 3 - 1, ww = w0 + t % 3 - 1;
+      if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+        v = x[(((size_t)img * C + c) * H + hh) * W + ww];
+    }
+    dst[idx] = (T)v;
+  }
+}
+
+int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  const long long cap = (long long)UZ_NUM_CU * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// thread-block shape for the (channel-chunk x pixel) reductions
+void reduce_shape(int CC, long long units, dim3* grid, dim3* block) {
+  int bx = 1;
+  while (bx < CC && bx < 64) bx <<= 1;
+  const int by = 256 / bx;
+  const int gy = (CC + bx - 1) / bx;
+  long long gx = (units + by - 1) / by;
+  long long cap = (long long)UZ_NUM_CU * 4 / gy;
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  *grid = dim3((unsigned)gx, (unsigned)gy);
+  *block = dim3(bx, by);
+}
+
+}  // namespace
+
+extern "C" int uz_bn_finalize(const float* stats_partial, int grid_m, int C, double count,
+                              const float* gamma, const float* beta, float eps, float momentum,
+                              float* running_mean, float* running_var, float* scale, float* shift,
+                              float* mean, float* invstd, void* stream) {
+  UZ_REQUIRE(stats_partial && gamma && beta && scale && shift && mean && invstd, "uz_bn_finalize: null");
+  UZ_REQUIRE(grid_m > 0 && C > 0 && count > 0, "uz_bn_finalize: bad shape");
+  UZ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "uz_bn_finalize: running stats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(uz_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream,
+                     stats_partial, grid_m, C, count, gamma, beta, eps, momentum, running_mean,
+                     running_var, scale, shift, mean, invstd);
+  UZ_LAUNCH_CHECK("uz_bn_finalize");
+  return UZ_OK;
+}
+
+extern "C" int uz_bn_eval_scale(int C, const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, float* scale, float* shift,
+                                void* stream) {
+  UZ_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "uz_bn_eval_scale: null");
+  hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(uz_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C,
+                     gamma, beta, running_mean, running_var, eps, scale, shift);
+  UZ_LAUNCH_CHECK("uz_bn_eval_scale");
+  return UZ_OK;
+}
+
+template <typename T>
+static int bn_relu_apply_t(const void* y, int ldy, const float* scale, const float* shift, int N, int H,
+                           int W, int C, void* act, int lda, void* pooled, int ldp, hipStream_t s) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  if (pooled != nullptr) {
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / VEC);
+    hipLaunchKernelGGL((bn_relu_apply_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, s,
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)pooled, ldp);
+  } else {
+    const long long total = (long long)N * H * W * (C / VEC);
+    hipLaunchKernelGGL((bn_relu_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, s,
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0);
+  }
+  UZ_LAUNCH_CHECK("uz_bn_relu_apply");
+  return UZ_OK;
+}
+
+extern "C" int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                                int N, int H, int W, int C, void* act, int lda, void* pooled, int ldp,
+                                void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_bn_relu_apply: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(y && scale && shift && act, "uz_bn_relu_apply: null pointer");
+  UZ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "uz_bn_relu_apply: C=%d must be a multiple of %d", C, vec);
+  UZ_REQUIRE(ldy % vec == 0 && lda % vec == 0 && ldy >= C && lda >= C, "uz_bn_relu_apply: bad ld");
+  if (pooled != nullptr) {
+    UZ_REQUIRE(H % 2 == 0 && W % 2 == 0, "uz_bn_relu_apply: fused pool needs even H, W (got %dx%d)", H, W);
+    UZ_REQUIRE(ldp % vec == 0 && ldp >= C, "uz_bn_relu_apply: bad ldp");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == UZ_BF16 ? bn_relu_apply_t<bf16_t>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, s)
+                          : bn_relu_apply_t<float>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, s);
+}
+
+static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, const void* gp) {
+  UZ_REQUIRE(d != nullptr, "uz_bn_relu_bwd: null descriptor");
+  UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "uz_bn_relu_bwd: bad dtype");
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % vec == 0, "uz_bn_relu_bwd: bad shape");
+  UZ_REQUIRE(d->ldy % vec == 0 && d->ldy >= d->C, "uz_bn_relu_bwd: bad ldy");
+  if (g0) UZ_REQUIRE(d->ldg0 % vec == 0 && d->ldg0 >= d->C, "uz_bn_relu_bwd: bad ldg0");
+  if (g1) UZ_REQUIRE(d->ldg1 % vec == 0 && d->ldg1 >= d->C, "uz_bn_relu_bwd: bad ldg1");
+  if (gp) {
+    UZ_REQUIRE(d->ldgp % vec == 0 && d->ldgp >= d->C, "uz_bn_relu_bwd: bad ldgp");
+    UZ_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "uz_bn_relu_bwd: pooled gradient needs even H, W");
+  }
+  UZ_REQUIRE(g0 || g1 || gp, "uz_bn_relu_bwd: no incoming gradient");
+  return UZ_OK;
+}
+
+template <typename T, int PASS>
+static int bnbwd_launch(const uz_bnbwd_desc* d, const BnBwdArgs& a, bool pool, hipStream_t s) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  dim3 grid, block;
+  const long long units = pool ? (long long)d->N * (d->H / 2) * (d->W / 2) : (long long)d->N * d->H * d->W;
+  reduce_shape(d->C / VEC, units, &grid, &block);
+  const size_t shm = PASS == 1 ? (size_t)256 * 2 * VEC * sizeof(float) : 0;
+  if (pool) {
+    hipLaunchKernelGGL((bn_relu_bwd_kernel<T, true, PASS>), grid, block, shm, s, a);
+  } else {
+    hipLaunchKernelGGL((bn_relu_bwd_kernel<T, false, PASS>), grid, block, shm, s, a);
+  }
+  UZ_LAUNCH_CHECK("uz_bn_relu_bwd");
+  return UZ_OK;
+}
+
+static BnBwdArgs bnbwd_args(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const void* g0, const void* g1,
+                            const void* gp) {
+  BnBwdArgs a;
+  a.y = y;
+  a.g0 = g0;
+  a.g1 = g1;
+  a.gp = gp;
+  a.dy = nullptr;
+  a.scale = scale;
+  a.shift = shift;
+  a.mean = mean;
+  a.invstd = invstd;
+  a.sums = nullptr;
+  a.dgamma = nullptr;
+  a.dbeta = nullptr;
+  a.inv_count = 0.0;
+  a.N = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.C = d->C;
+  a.ldy = d->ldy;
+  a.ldg0 = d->ldg0;
+  a.ldg1 = d->ldg1;
+  a.ldgp = d->ldgp;
+  a.lddy = d->lddy;
+  return a;
+}
+
+extern "C" int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd,
+                                     const void* g0, const void* g1, const void* gpool, double* sums,
+                                     void* stream) {
+  const int rc = bnbwd_check(d, g0, g1, gpool);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(y && scale && shift && mean && invstd && sums, "uz_bn_relu_bwd_reduce: null pointer");
+  BnBwdArgs a = bnbwd_args(d, y, scale, shift, mean, invstd, g0, g1, gpool);
+  a.sums = sums;
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 1>(d, a, gpool != nullptr, s)
+                             : bnbwd_launch<float, 1>(d, a, gpool != nullptr, s);
+}
+
+extern "C" int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd,
+                                    const void* g0, const void* g1, const void* gpool, const double* sums,
+                                    double count, void* dy, float* dgamma, float* dbeta, void* stream) {
+  const int rc = bnbwd_check(d, g0, g1, gpool);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(y && scale && shift && mean && invstd && sums && dy, "uz_bn_relu_bwd_apply: null pointer");
+  UZ_REQUIRE(count > 0, "uz_bn_relu_bwd_apply: count");
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(d->lddy % vec == 0 && d->lddy >= d->C, "uz_bn_relu_bwd_apply: bad lddy");
+  UZ_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "uz_bn_relu_bwd_apply: dgamma/dbeta");
+  BnBwdArgs a = bnbwd_args(d, y, scale, shift, mean, invstd, g0, g1, gpool);
+  a.sums = const_cast<double*>(sums);
+  a.dy = dy;
+  a.dgamma = dgamma;
+  a.dbeta = dbeta;
+  a.inv_count = 1.0 / count;
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 2>(d, a, gpool != nullptr, s)
+                             : bnbwd_launch<float, 2>(d, a, gpool != nullptr, s);
+}
+
+extern "C" int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,
+                              const float* b, int Kout, float* out_nchw, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_outconv_fwd: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && w && b && out_nchw, "uz_outconv_fwd: null pointer");
+  UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_fwd: Kout=%d (max %d)", Kout, OUTCONV_MAXK);
+  UZ_REQUIRE(C % vec == 0 && is_pow2(C / vec) && C / vec <= 64, "uz_outconv_fwd: C=%d unsupported", C);
+  UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0, "uz_outconv_fwd: bad shape");
+  const int ppb = 256 / (C / vec);
+  const int grid = grid_for(((long long)N * HW + ppb - 1) / ppb, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UZ_BF16) {
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_fwd_kernel<bf16_t, KOUT>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, b, out_nchw))
+  } else {
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_fwd_kernel<float, KOUT>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, b, out_nchw))
+  }
+  UZ_LAUNCH_CHECK("uz_outconv_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,
+                              int Kout, const float* g_nchw, void* dx, int lddx, float* dw, float* db,
+                              void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_outconv_bwd: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && w && g_nchw && dw && db, "uz_outconv_bwd: null pointer");
+  UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_bwd: Kout=%d", Kout);
+  UZ_REQUIRE(C % vec == 0 && is_pow2(C / vec) && C / vec <= 64, "uz_outconv_bwd: C=%d unsupported", C);
+  UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0, "uz_outconv_bwd: bad shape");
+  if (dx) UZ_REQUIRE(lddx % vec == 0 && lddx >= C, "uz_outconv_bwd: bad lddx");
+  const int ppb = 256 / (C / vec);
+  long long g = ((long long)N * HW + ppb - 1) / ppb;
+  if (g > UZ_NUM_CU * 4) g = UZ_NUM_CU * 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UZ_BF16) {
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, dw, db))
+  } else {
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<float, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, g_nchw, (float*)dx, lddx, dw, db))
+  }
+  UZ_LAUNCH_CHECK("uz_outconv_bwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_colsum: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && out && P > 0 && C > 0 && C % vec == 0 && ld % vec == 0 && ld >= C, "uz_colsum: bad args");
+  dim3 grid, block;
+  reduce_shape(C / vec, P, &grid, &block);
+  const size_t shm = (size_t)256 * vec * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, shm, s, (const bf16_t*)x, ld, (long long)P, C, out);
+  else
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, block, shm, s, (const float*)x, ld, (long long)P, C, out);
+  UZ_LAUNCH_CHECK("uz_colsum");
+  return UZ_OK;
+}
+
+extern "C" int uz_pack_weights(int dtype, int mode, const float* w, int Co, int Ci, int T, int Kpad,
+                               void* dst, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_pack_weights: bad dtype");
+  UZ_REQUIRE(w && dst && Co > 0 && Ci > 0 && T > 0, "uz_pack_weights: bad args");
+  UZ_REQUIRE(mode >= UZ_PACK_CONV_FWD && mode <= UZ_PACK_IM2COL, "uz_pack_weights: bad mode %d", mode);
+  long long total = (long long)Co * Ci * T;
+  if (mode == UZ_PACK_IM2COL) {
+    UZ_REQUIRE(Kpad >= T * Ci, "uz_pack_weights: Kpad too small");
+    total = (long long)Co * Kpad;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for(total, 256);
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, mode, w, Co, Ci, T, Kpad, (bf16_t*)dst, total);
+  else
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, mode, w, Co, Ci, T, Kpad, (float*)dst, total);
+  UZ_LAUNCH_CHECK("uz_pack_weights");
+  return UZ_OK;
+}
+
+extern "C" int uz_im2col3x3_nchw(int dtype, const float* x_nchw, int N, int C, int H, int W, int Kpad,
+                                 void* dst, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_im2col3x3_nchw: bad dtype");
+  UZ_REQUIRE(x_nchw && dst && N > 0 && C > 0 && H > 0 && W > 0 && Kpad >= 9 * C, "uz_im2col3x3_nchw: bad args");
+  const long long total = (long long)N * H * W * Kpad;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for(total, 256);
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((im2col3x3_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, x_nchw, N, C, H, W, Kpad, (bf16_t*)dst, total);
+  else
+    hipLaunchKernelGGL((im2col3x3_kernel<float>), dim3(grid), dim3(256), 0, s, x_nchw, N, C, H, W, Kpad, (float*)dst, total);
+  UZ_LAUNCH_CHECK("uz_im2col3x3_nchw");
+  return UZ_OK;
+}
+
+// ---- error string -------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void uz_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* uz_last_error_string(void) { return g_err; }
+extern "C" int uz_abi_version(void) { return UZ_ABI_VERSION; }

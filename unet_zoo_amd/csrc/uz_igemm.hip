@@ -1,0 +1,355 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): 3x3 (any dilation) / 1x1 / ConvTranspose-k2s2
+// forward and input-gradient on the MFMA matrix cores, NHWC activations.
+//
+// Stands in for the ATen convolution the reference reaches through nn.Conv2d /
+// nn.ConvTranspose2d (reference: unet_zoo/models/common_layers.py:28,31,47,52,71,104,
+// u2net.py:10) and for its input-gradient under autograd (SURVEY.md §8a rows a1,a2,a4,a7,a10,a19).
+//
+// GEMM view:  C[M = pixels][N = out channels] = A[M][K = taps*Cin] * B[N][K]^T
+//   A row m, K-slab (tap, c0..c0+BK): 128 contiguous bytes of the tap-shifted input pixel
+//   (zero when the tap falls outside the image), B row n: packed weights, K contiguous.
+// Block tile BM x BN, 4 waves (64 lanes each), K-step = 128 bytes per row (64 bf16 / 32 fp32),
+// register-staged global->LDS double buffer, XOR-swizzled 16-byte chunks so every
+// ds_read_b128 of a 16-lane group hits 16 distinct slots of the 256-byte bank row.
+// bf16: v_mfma_f32_32x32x16_bf16;  fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+// Each block walks several M tiles (persistent over M) so the per-channel BatchNorm partial
+// sums stay in registers and leave the block once, as one deterministic partial row.
+#include "uz_common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  float* stats;
+  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, dil, store, Co, tiles_m;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const Vec16<bf16_t>& a, const Vec16<bf16_t>& b,
+                                             f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // The K order inside a 128-byte slab is permuted identically for A and B (lane half h owns
+  // elements 4h..4h+3 of each 32-byte pair of chunks), which leaves the dot product unchanged.
+  static __device__ __forceinline__ void run(const Vec16<float>& a, const Vec16<float>& b,
+                                             f32x16& c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b.v[t], c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int BK = 8 * VEC;  // elements per 128-byte row slab
+  constexpr int AR = BM / 32, BR = BN / 32;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lc = tid & 7, lr = tid >> 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  const T* __restrict__ xg = static_cast<const T*>(a.x);
+  const T* __restrict__ wg = static_cast<const T*>(a.w);
+  T* __restrict__ yg = static_cast<T*>(a.y);
+
+  const T* bptr[BR];
+  bool bval[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int n = n0 + lr + 32 * i;
+    bval[i] = n < a.Nout;
+    bptr[i] = wg + (size_t)(bval[i] ? n : 0) * a.K + lc * VEC;
+  }
+
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) s1[i] = s2[i] = 0.f;
+
+  const int nk = a.K / BK;
+  const int cpt = a.Cin / BK;  // K-steps per tap
+  const int HW = a.H * a.W;
+  const int st_sw = ((lr >> 1) & 7);       // store-side swizzle (row = lr + 32 i)
+  const int ld_sw = ((l31 >> 1) & 7);      // read-side swizzle (row = 32 j + l31)
+
+  for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+    const int m0 = tile * BM;
+    int rh[AR], rw[AR], rpix[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int m = m0 + lr + 32 * i;
+      const bool ok = m < a.M;
+      const int mm = ok ? m : 0;
+      const int img = mm / HW;
+      const int rem = mm - img * HW;
+      const int h = rem / a.W;
+      const int w = rem - h * a.W;
+      rh[i] = ok ? h : -(1 << 28);
+      rw[i] = w;
+      rpix[i] = (a.mode == UZ_TAPS_CONV) ? (img * a.Hin + h) * a.Win + w
+                                          : (img * a.Hin + 2 * h) * a.Win + 2 * w;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Vec16<T> ra[AR], rb[BR];
+    int tap = 0, cb = 0;  // position of the K-step being loaded
+
+    auto load_step = [&](int kb) {
+      int dy = 0, dx = 0;
+      if (a.mode == UZ_TAPS_CONV) {
+        if (a.ntaps == 9) {
+          const int ty = tap / 3;
+          dy = (ty - 1) * a.dil;
+          dx = (tap - 3 * ty - 1) * a.dil;
+        }
+      } else {
+        dy = tap >> 1;
+        dx = tap & 1;
+      }
+      const int coff = cb * BK + lc * VEC;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        bool ok;
+        if (a.mode == UZ_TAPS_CONV) {
+          const int hh = rh[i] + dy, ww = rw[i] + dx;
+          ok = (unsigned)hh < (unsigned)a.Hin && (unsigned)ww < (unsigned)a.Win;
+        } else {
+          ok = rh[i] >= 0;
+        }
+        const size_t off = (size_t)(rpix[i] + dy * a.Win + dx) * (size_t)a.ldx + coff;
+        ra[i] = ok ? ld16(xg + off) : zero16<T>();
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i) rb[i] = bval[i] ? ld16(bptr[i] + (size_t)kb * BK) : zero16<T>();
+      if (++cb == cpt) {
+        cb = 0;
+        ++tap;
+      }
+    };
+    auto store_step = [&](int buf) {
+      char* sA = smem + buf * STAGE;
+      char* sB = sA + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        *reinterpret_cast<Vec16<T>*>(sA + (lr + 32 * i) * 128 + ((lc ^ st_sw) << 4)) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        *reinterpret_cast<Vec16<T>*>(sB + (lr + 32 * i) * 128 + ((lc ^ st_sw) << 4)) = rb[i];
+    };
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int kb = 0; kb < nk; ++kb) {
+      const bool more = kb + 1 < nk;
+      if (more) load_step(kb + 1);
+      const char* sA = smem + (kb & 1) * STAGE;
+      const char* sB = sA + A_BYTES;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chunk = ((2 * q + lh) ^ ld_sw) << 4;
+        Vec16<T> af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const Vec16<T>*>(sA + (wm * WTM + i * 32 + l31) * 128 + chunk);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[j] = *reinterpret_cast<const Vec16<T>*>(sB + (wn * WTN + j * 32 + l31) * 128 + chunk);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+      }
+      if (more) store_step((kb + 1) & 1);
+      __syncthreads();
+    }
+
+    // Epilogue: bias, store, per-channel statistics of the stored value.
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + l31;
+      const bool nok = n < a.Nout;
+      const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+      int ab = 0, co = n;
+      if (a.store == UZ_STORE_SHUFFLE2X2) {
+        ab = n / a.Co;
+        co = n - ab * a.Co;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < a.M && nok) {
+            const T tv = (T)(acc[i][j][r] + bv);
+            size_t o;
+            if (a.store == UZ_STORE_PLAIN) {
+              o = (size_t)m * a.ldy + n;
+            } else {
+              const int img = m / HW;
+              const int rem = m - img * HW;
+              const int h = rem / a.W;
+              const int w = rem - h * a.W;
+              const size_t opix =
+                  ((size_t)img * (2 * a.H) + 2 * h + (ab >> 1)) * (size_t)(2 * a.W) + 2 * w + (ab & 1);
+              o = opix * a.ldy + co;
+            }
+            yg[o] = tv;
+            const float fv = (float)tv;
+            s1[j] += fv;
+            s2[j] += fv * fv;
+          }
+        }
+      }
+    }
+  }
+
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
+    if (lh == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + l31;
+        red[(wm * BN + col) * 2 + 0] = s1[j];
+        red[(wm * BN + col) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WM; ++k) {
+        t1 += red[(k * BN + tid) * 2 + 0];
+        t2 += red[(k * BN + tid) * 2 + 1];
+      }
+      const int n = n0 + tid;
+      if (n < a.Nout) {
+        a.stats[((size_t)blockIdx.x * 2 + 0) * a.Nout + n] = t1;
+        a.stats[((size_t)blockIdx.x * 2 + 1) * a.Nout + n] = t2;
+      }
+    }
+  }
+}
+
+struct Plan {
+  int bn;       // 64 or 128
+  int tiles_m, tiles_n, grid_m;
+};
+
+int make_plan(const uz_conv_desc* d, Plan* p) {
+  UZ_REQUIRE(d != nullptr, "uz_conv_igemm: null descriptor");
+  UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "uz_conv_igemm: bad dtype %d", d->dtype);
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  const int bk = 8 * vec;
+  UZ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Nout > 0,
+             "uz_conv_igemm: non-positive shape");
+  UZ_REQUIRE(d->Cin % bk == 0, "uz_conv_igemm: Cin=%d must be a multiple of %d", d->Cin, bk);
+  UZ_REQUIRE(d->ldx % vec == 0 && d->ldx >= d->Cin, "uz_conv_igemm: bad ldx=%d (Cin=%d)", d->ldx,
+             d->Cin);
+  if (d->taps_mode == UZ_TAPS_CONV) {
+    UZ_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "uz_conv_igemm: ntaps=%d", d->ntaps);
+    UZ_REQUIRE(d->Hin == d->H && d->Win == d->W, "uz_conv_igemm: conv taps need Hin==H, Win==W");
+    UZ_REQUIRE(d->dil >= 1, "uz_conv_igemm: dil=%d", d->dil);
+  } else {
+    UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4,
+               "uz_conv_igemm: gather2x2 needs ntaps=4");
+    UZ_REQUIRE(d->Hin == 2 * d->H && d->Win == 2 * d->W, "uz_conv_igemm: gather2x2 needs Hin=2H");
+  }
+  if (d->store_mode == UZ_STORE_SHUFFLE2X2) {
+    UZ_REQUIRE(d->Co > 0 && d->Nout == 4 * d->Co, "uz_conv_igemm: shuffle store needs Nout=4*Co");
+    UZ_REQUIRE(d->ldy >= d->Co, "uz_conv_igemm: bad ldy");
+  } else {
+    UZ_REQUIRE(d->store_mode == UZ_STORE_PLAIN, "uz_conv_igemm: bad store_mode");
+    UZ_REQUIRE(d->ldy >= d->Nout, "uz_conv_igemm: bad ldy=%d (Nout=%d)", d->ldy, d->Nout);
+  }
+  const long long M = (long long)d->N * d->H * d->W;
+  UZ_REQUIRE(M * (long long)(d->ldx > d->ldy ? d->ldx : d->ldy) < (1LL << 40) && M < (1LL << 31),
+             "uz_conv_igemm: tensor too large");
+  UZ_REQUIRE((long long)d->N * d->Hin * d->Win < (1LL << 31), "uz_conv_igemm: input too large");
+  p->bn = d->Nout <= 64 ? 64 : 128;
+  p->tiles_m = uz_cdiv(M, 128);
+  p->tiles_n = uz_cdiv(d->Nout, p->bn);
+  int cap = (2 * UZ_NUM_CU) / p->tiles_n;
+  if (cap < 1) cap = 1;
+  p->grid_m = p->tiles_m < cap ? p->tiles_m : cap;
+  return UZ_OK;
+}
+
+template <typename T>
+int launch(const uz_conv_desc* d, const Plan& p, const IgemmArgs& a, hipStream_t s) {
+  dim3 grid(p.grid_m, p.tiles_n), block(256);
+  if (p.bn == 64) {
+    hipLaunchKernelGGL((igemm_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((igemm_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, a);
+  }
+  UZ_LAUNCH_CHECK("uz_conv_igemm");
+  return UZ_OK;
+}
+
+}  // namespace
+
+extern "C" int uz_conv_igemm_grid_m(const uz_conv_desc* d) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  return p.grid_m;
+}
+
+extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed,
+                             const float* bias, void* y, float* stats_partial, void* stream) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(x && w_packed && y, "uz_conv_igemm: null pointer");
+  UZ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0,
+             "uz_conv_igemm: x / w must be 16-byte aligned");
+  IgemmArgs a;
+  a.x = x;
+  a.w = w_packed;
+  a.y = y;
+  a.bias = bias;
+  a.stats = stats_partial;
+  a.M = d->N * d->H * d->W;
+  a.H = d->H;
+  a.W = d->W;
+  a.Hin = d->Hin;
+  a.Win = d->Win;
+  a.Cin = d->Cin;
+  a.ldx = d->ldx;
+  a.Nout = d->Nout;
+  a.ldy = d->ldy;
+  a.K = d->ntaps * d->Cin;
+  a.ntaps = d->ntaps;
+  a.mode = d->taps_mode;
+  a.dil = d->dil;
+  a.store = d->store_mode;
+  a.Co = d->Co;
+  a.tiles_m = p.tiles_m;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return d->dtype == UZ_BF16 ? launch<bf16_t>(d, p, a, s) : launch<float>(d, p, a, s);
+}

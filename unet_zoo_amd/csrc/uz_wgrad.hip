@@ -1,0 +1,314 @@
+// Weight-gradient kernel for gfx950 (MI355X): out[i][j][tap] (+)= sum_p L[p][i] * R[pix(p,tap)][j]
+//
+// Stands in for the weight-gradient half of autograd for nn.Conv2d k3/k1 and
+// nn.ConvTranspose2d k2s2 (reference call sites: unet_zoo/models/common_layers.py:28,31,104,125;
+// entered from loss.backward(), unet_zoo/utils/training_loop.py:119).
+//
+// GEMM view per tap: D[BI x BJ] += L^T[BI x pixels] * R[pixels x BJ]; the reduction (pixel) index
+// is the slow index of both NHWC operands, so tiles are staged pixel-major in LDS ([k][channel])
+// and fragments are read
+//   bf16: ds_read_b64_tr_b16 (hardware transpose: each lane receives 4 consecutive pixels of its
+//         channel), rows padded by 64 B so the four pixel rows of a read land on distinct banks;
+//   fp32: ds_read_b32 (the 32x32x2 fp32 MFMA wants one element per lane; 32 lanes = 32
+//         consecutive channels = conflict-free).
+// Pixels are split over gridDim.z; partial products are combined with fp32 atomics when split>1.
+#include "uz_common.h"
+
+namespace {
+
+struct WgradArgs {
+  const void* L;
+  const void* R;
+  float* out;
+  int P, H, W, Hr, Wr, Ci, ldl, Cj, ldr, ntaps, mode, dil, split, chunk, tiles_j;
+};
+
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16_t> {
+  static constexpr int BKP = 64;  // pixels per K-step
+  static constexpr int PAD = 64;  // bytes of row padding
+};
+template <> struct WgCfg<float> {
+  static constexpr int BKP = 32;
+  static constexpr int PAD = 0;
+};
+
+template <typename T, int BI, int BJ>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int BKP = WgCfg<T>::BKP;
+  constexpr int CPR_I = BI / VEC, CPR_J = BJ / VEC;        // 16-byte chunks per pixel row
+  constexpr int RPP_I = 256 / CPR_I, RPP_J = 256 / CPR_J;  // pixel rows per pass
+  constexpr int NI = BKP / RPP_I, NJ = BKP / RPP_J;
+  static_assert(NI >= 1 && NJ >= 1, "tile too wide for BKP");
+  constexpr int RS_I = BI * (int)sizeof(T) + WgCfg<T>::PAD;
+  constexpr int RS_J = BJ * (int)sizeof(T) + WgCfg<T>::PAD;
+  constexpr int L_BYTES = BKP * RS_I, R_BYTES = BKP * RS_J, STAGE = L_BYTES + R_BYTES;
+  constexpr int WTI = BI / 2, WTJ = BJ / 2, TI = WTI / 32, TJ = WTJ / 32;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ti0 = (blockIdx.x / a.tiles_j) * BI, tj0 = (blockIdx.x % a.tiles_j) * BJ;
+  const int tap = blockIdx.y;
+  const int pbeg = blockIdx.z * a.chunk;
+  const int pend = (pbeg + a.chunk < a.P) ? pbeg + a.chunk : a.P;
+  const T* __restrict__ Lg = static_cast<const T*>(a.L);
+  const T* __restrict__ Rg = static_cast<const T*>(a.R);
+
+  int dy = 0, dx = 0;
+  if (a.mode == UZ_TAPS_CONV) {
+    if (a.ntaps == 9) {
+      const int ty = tap / 3;
+      dy = (ty - 1) * a.dil;
+      dx = (tap - 3 * ty - 1) * a.dil;
+    }
+  } else {
+    dy = tap >> 1;
+    dx = tap & 1;
+  }
+
+  // L rows handled by this thread
+  const int lcI = tid % CPR_I, lrI = tid / CPR_I;
+  const bool cokI = ti0 + lcI * VEC < a.Ci;
+  // R rows handled by this thread: keep (img, h, w) per row, advanced by BKP pixels per step
+  const int lcJ = tid % CPR_J, lrJ = tid / CPR_J;
+  const bool cokJ = tj0 + lcJ * VEC < a.Cj;
+  int rn[NJ], rh[NJ], rw[NJ];
+  const int HW = a.H * a.W;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int p = pbeg + lrJ + RPP_J * i;
+    const int img = p / HW;
+    const int rem = p - img * HW;
+    rn[i] = img;
+    rh[i] = rem / a.W;
+    rw[i] = rem - rh[i] * a.W;
+  }
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Vec16<T> rl[NI], rr[NJ];
+  int pk = pbeg;  // first pixel of the K-step being loaded
+
+  auto load_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int p = pk + lrI + RPP_I * i;
+      const bool ok = cokI && p < pend;
+      rl[i] = ok ? ld16(Lg + (size_t)p * a.ldl + ti0 + lcI * VEC) : zero16<T>();
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const int p = pk + lrJ + RPP_J * i;
+      bool ok = cokJ && p < pend;
+      size_t pix;
+      if (a.mode == UZ_TAPS_CONV) {
+        const int hh = rh[i] + dy, ww = rw[i] + dx;
+        ok = ok && (unsigned)hh < (unsigned)a.Hr && (unsigned)ww < (unsigned)a.Wr;
+        pix = ((size_t)rn[i] * a.Hr + hh) * a.Wr + ww;
+      } else {
+        pix = ((size_t)rn[i] * a.Hr + 2 * rh[i] + dy) * a.Wr + 2 * rw[i] + dx;
+      }
+      rr[i] = ok ? ld16(Rg + pix * a.ldr + tj0 + lcJ * VEC) : zero16<T>();
+      // advance this row's coordinates to the next K-step
+      rw[i] += BKP;
+      while (rw[i] >= a.W) {
+        rw[i] -= a.W;
+        if (++rh[i] == a.H) {
+          rh[i] = 0;
+          ++rn[i];
+        }
+      }
+    }
+    pk += BKP;
+  };
+  auto store_step = [&](int buf) {
+    char* sL = smem + buf * STAGE;
+    char* sR = sL + L_BYTES;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      *reinterpret_cast<Vec16<T>*>(sL + (lrI + RPP_I * i) * RS_I + lcI * 16) = rl[i];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+      *reinterpret_cast<Vec16<T>*>(sR + (lrJ + RPP_J * i) * RS_J + lcJ * 16) = rr[i];
+  };
+
+  const int nk = (pend - pbeg + BKP - 1) / BKP;
+  if (nk > 0) {
+    load_step();
+    store_step(0);
+  }
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const bool more = kb + 1 < nk;
+    if (more) load_step();
+    const char* sL = smem + (kb & 1) * STAGE;
+    const char* sR = sL + L_BYTES;
+    if constexpr (sizeof(T) == 2) {
+      // lane -> (16-lane group g, row q, column quad p4) of the transposed 4x16 block read
+      const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+      const int krow = 8 * (g >> 1) + q;
+      const int ccol = 16 * (g & 1) + 4 * p4;
+      typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+#pragma unroll
+      for (int ks = 0; ks < BKP / 16; ++ks) {
+        bf16x8 af[TI], bfr[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const char* p0 = sL + (ks * 16 + krow) * RS_I + (wi * WTI + i * 32 + ccol) * 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p0));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p0 + 4 * RS_I));
+          af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const char* p0 = sR + (ks * 16 + krow) * RS_J + (wj * WTJ + j * 32 + ccol) * 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p0));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p0 + 4 * RS_J));
+          bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int s = 0; s < BKP / 2; ++s) {
+        const int k = 2 * s + lh;
+        float af[TI], bfr[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+          af[i] = *reinterpret_cast<const float*>(sL + k * RS_I + (wi * WTI + i * 32 + l31) * 4);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+          bfr[j] = *reinterpret_cast<const float*>(sR + k * RS_J + (wj * WTJ + j * 32 + l31) * 4);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) store_step((kb + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const int cj = tj0 + wj * WTJ + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ti0 + wi * WTI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ci < a.Ci && cj < a.Cj) {
+          float* o = a.out + ((size_t)ci * a.Cj + cj) * a.ntaps + tap;
+          if (a.split > 1)
+            atomicAdd(o, acc[i][j][r]);
+          else
+            *o = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+struct Plan {
+  int b;  // tile edge: 64 or 128
+  int tiles_i, tiles_j, split, chunk;
+};
+
+int make_plan(const uz_wgrad_desc* d, Plan* p) {
+  UZ_REQUIRE(d != nullptr, "uz_wgrad: null descriptor");
+  UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "uz_wgrad: bad dtype %d", d->dtype);
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  const int bkp = d->dtype == UZ_BF16 ? 64 : 32;
+  UZ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ci > 0 && d->Cj > 0, "uz_wgrad: bad shape");
+  UZ_REQUIRE(d->Ci % vec == 0 && d->Cj % vec == 0, "uz_wgrad: channels must be multiples of %d", vec);
+  UZ_REQUIRE(d->ldl % vec == 0 && d->ldr % vec == 0 && d->ldl >= d->Ci && d->ldr >= d->Cj,
+             "uz_wgrad: bad leading dimension");
+  if (d->taps_mode == UZ_TAPS_CONV) {
+    UZ_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "uz_wgrad: ntaps=%d", d->ntaps);
+    UZ_REQUIRE(d->Hr == d->H && d->Wr == d->W && d->dil >= 1, "uz_wgrad: conv taps need Hr==H");
+  } else {
+    UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && d->Hr == 2 * d->H &&
+                   d->Wr == 2 * d->W,
+               "uz_wgrad: gather2x2 needs ntaps=4, Hr=2H, Wr=2W");
+  }
+  const long long P = (long long)d->N * d->H * d->W;
+  UZ_REQUIRE(P < (1LL << 31) && (long long)d->N * d->Hr * d->Wr < (1LL << 31), "uz_wgrad: too large");
+  p->b = (d->Ci > 64 && d->Cj > 64) ? 128 : 64;
+  p->tiles_i = uz_cdiv(d->Ci, p->b);
+  p->tiles_j = uz_cdiv(d->Cj, p->b);
+  const long long base = (long long)p->tiles_i * p->tiles_j * d->ntaps;
+  long long split = (4 * UZ_NUM_CU + base - 1) / base;
+  const long long max_split = P / (4LL * bkp) > 0 ? P / (4LL * bkp) : 1;
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  long long chunk = (P + split - 1) / split;
+  chunk = ((chunk + bkp - 1) / bkp) * bkp;
+  split = (P + chunk - 1) / chunk;
+  p->split = (int)split;
+  p->chunk = (int)chunk;
+  return UZ_OK;
+}
+
+template <typename T> int launch(const Plan& p, const WgradArgs& a, hipStream_t s) {
+  dim3 grid(p.tiles_i * p.tiles_j, a.ntaps, p.split), block(256);
+  if (p.b == 64) {
+    hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<T, 128, 128>), grid, block, 0, s, a);
+  }
+  UZ_LAUNCH_CHECK("uz_wgrad");
+  return UZ_OK;
+}
+
+}  // namespace
+
+extern "C" int uz_wgrad_split(const uz_wgrad_desc* d) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  return p.split;
+}
+
+extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out,
+                        void* stream) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(L && R && out, "uz_wgrad: null pointer");
+  UZ_REQUIRE(((uintptr_t)L & 15) == 0 && ((uintptr_t)R & 15) == 0, "uz_wgrad: L / R must be 16-byte aligned");
+  WgradArgs a;
+  a.L = L;
+  a.R = R;
+  a.out = out;
+  a.P = d->N * d->H * d->W;
+  a.H = d->H;
+  a.W = d->W;
+  a.Hr = d->Hr;
+  a.Wr = d->Wr;
+  a.Ci = d->Ci;
+  a.ldl = d->ldl;
+  a.Cj = d->Cj;
+  a.ldr = d->ldr;
+  a.ntaps = d->ntaps;
+  a.mode = d->taps_mode;
+  a.dil = d->dil;
+  a.split = p.split;
+  a.chunk = p.chunk;
+  a.tiles_j = p.tiles_j;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
+}

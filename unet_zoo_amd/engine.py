@@ -1,0 +1,230 @@
+"""Kernel-level execution engine: a model's ``emit`` method calls the block functions below, which
+launch HIP kernels immediately (forward) and record a closure per block on a tape; ``backward``
+replays the tape in reverse.  No tracing compiler, no per-op autograd graph: the whole network is
+ONE ``torch.autograd.Function`` node (see ``graph_fn.py``), PyTorch only owns parameters, the
+optimizer and the loss.
+
+Step semantics follow the reference's training loop (unet_zoo/utils/training_loop.py:108-121):
+train-mode BatchNorm uses batch statistics (biased variance) and updates running statistics with
+momentum and the unbiased variance; eval mode uses the running statistics.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .ops import Act
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Engine:
+    def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
+                 grad_sink: Optional[Callable[[nn.Parameter, torch.Tensor], None]] = None):
+        self.dtype = dtype
+        self.device = device
+        self.training = training
+        self.record = record          # build a tape for backward
+        self.tape: List[Callable[[], None]] = []
+        self.param_grads: Dict[nn.Parameter, torch.Tensor] = {}
+        self.grad_sink = grad_sink    # called as soon as a parameter gradient has been launched
+        self.bk = 64 if dtype == torch.bfloat16 else 32  # K-slab of the igemm kernel (128 bytes)
+        self._bn_channels = 0
+        self._sums: Optional[torch.Tensor] = None
+        self._sums_used = 0
+        self._packed: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._heads: List[Callable[[torch.Tensor], None]] = []
+
+    # ------------------------------------------------------------------ buffers
+    def new_act(self, N, H, W, C, needs_grad=True) -> Act:
+        return ops.new_act(N, H, W, C, self.dtype, self.device, needs_grad)
+
+    def new_cat(self, N, H, W, channels: Sequence[int]) -> Tuple[Act, List[Act]]:
+        """One buffer holding a channel-concat; producers write their part in place."""
+        full = self.new_act(N, H, W, sum(channels))
+        parts, o = [], 0
+        for c in channels:
+            parts.append(full.window(o, c))
+            o += c
+        full.parts = parts
+        return full, parts
+
+    def _give_grad(self, p: nn.Parameter, g: torch.Tensor) -> None:
+        if p in self.param_grads:
+            self.param_grads[p] = self.param_grads[p] + g
+        else:
+            self.param_grads[p] = g
+        if self.grad_sink is not None:
+            self.grad_sink(p, self.param_grads[p])
+
+    def _pack(self, p: nn.Parameter, mode: int, kpad: int = 0) -> torch.Tensor:
+        key = (id(p), mode)
+        if key not in self._packed:
+            self._packed[key] = ops.pack_weights(p.detach(), mode, self.dtype, kpad)
+        return self._packed[key]
+
+    def _bn_sums(self, C: int) -> torch.Tensor:
+        if self._sums is None:
+            self._sums = torch.zeros(2 * self._bn_channels, dtype=torch.float64, device=self.device)
+            self._sums_used = 0
+        s = self._sums[self._sums_used:self._sums_used + 2 * C].view(2, C)
+        self._sums_used += 2 * C
+        return s
+
+    @staticmethod
+    def _sum_grads(a: Act, limit: int) -> List[Act]:
+        """Return at most `limit` same-resolution gradient sources (pre-adding the rest)."""
+        gs = list(a.grads)
+        while len(gs) > limit:
+            x, y = gs.pop(), gs.pop()
+            t = (x.buf[:, x.off:x.off + x.C].float() + y.buf[:, y.off:y.off + y.C].float()).to(x.dtype)
+            gs.append(Act(t.contiguous(), 0, x.C, x.N, x.H, x.W))
+        return gs
+
+    # ------------------------------------------------------------------ blocks
+    def input_im2col(self, x: torch.Tensor) -> Act:
+        """Network input (N,C,H,W) fp32 -> 3x3 patches [P][Kpad] for the first convolution."""
+        L.require_cuda(x)
+        if x.dim() != 4:
+            raise ValueError(f"expected a (N, C, H, W) input, got shape {tuple(x.shape)}")
+        C = x.shape[1]
+        return ops.im2col3x3_nchw(x.contiguous().float(), _round_up(9 * C, self.bk), self.dtype)
+
+    def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
+                     pool: bool = False, im2col: bool = False) -> Tuple[Act, Optional[Act]]:
+        """Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
+
+        Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
+        u2net.py:10-17) and DownSample's pool (common_layers.py:90-95).  Returns (act, pooled)."""
+        N, H, W = x.N, x.H, x.W
+        Cout = conv.out_channels
+        dil = conv.dilation[0]
+        if im2col:
+            wp = self._pack(conv.weight, L.PACK_IM2COL, x.C)
+            ntaps = 1
+        else:
+            assert conv.kernel_size == (3, 3) and conv.in_channels == x.C
+            wp = self._pack(conv.weight, L.PACK_CONV_FWD)
+            ntaps = 9
+        y = self.new_act(N, H, W, Cout)
+        bias = conv.bias.detach() if conv.bias is not None else None
+        stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, want_stats=self.training)
+        if self.training:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            vec = ops.bn_finalize(stats, y.P, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                  bn.running_mean, bn.running_var)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        else:
+            vec = ops.bn_eval_scale(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                    bn.running_var, bn.eps)
+        act = out if out is not None else self.new_act(N, H, W, Cout)
+        pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
+        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled)
+
+        if self.record:
+            if not self.training:
+                raise NotImplementedError(
+                    "backward through eval-mode BatchNorm is not implemented; call model.train() "
+                    "or wrap evaluation in torch.no_grad() as the reference does "
+                    "(training_loop.py:159)")
+            self._bn_channels += Cout
+
+            def bwd():
+                gs = self._sum_grads(act, 2)
+                gp = self._sum_grads(pooled, 1)[0] if (pooled is not None and pooled.grads) else None
+                g0 = gs[0] if len(gs) > 0 else None
+                g1 = gs[1] if len(gs) > 1 else None
+                if g0 is None and gp is None:
+                    return  # nothing downstream used this activation
+                dy = self.new_act(N, H, W, Cout)
+                dgb = torch.empty((2, Cout), dtype=torch.float32, device=self.device)
+                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgb[0], dgb[1])
+                self._give_grad(bn.weight, dgb[0])
+                self._give_grad(bn.bias, dgb[1])
+                if conv.bias is not None:
+                    # d(bias) = sum_p dy == 0 analytically under train-mode BN (the batch mean
+                    # removes any per-channel constant); the reference's value is rounding noise.
+                    self._give_grad(conv.bias, torch.zeros(Cout, dtype=torch.float32, device=self.device))
+                if im2col:
+                    dwp = ops.wgrad(dy, x, (Cout, x.C), ntaps=1)
+                    cin = conv.in_channels
+                    dw = dwp[:, :9 * cin].reshape(Cout, 9, cin).permute(0, 2, 1).reshape(conv.weight.shape)
+                    self._give_grad(conv.weight, dw.contiguous())
+                else:
+                    self._give_grad(conv.weight,
+                                    ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=9, dil=dil))
+                    if x.needs_grad:
+                        dx = self.new_act(N, H, W, x.C)
+                        ops.conv_igemm(dy, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx,
+                                       ntaps=9, dil=dil)
+                        x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return act, pooled
+
+    def conv_transpose2x2(self, x: Act, m: nn.ConvTranspose2d, out: Act) -> Act:
+        """ConvTranspose2d(k=2, s=2) written straight into its slot of the concat buffer.
+        Reference: UpSample_UNet.up (common_layers.py:104,108)."""
+        assert m.kernel_size == (2, 2) and m.stride == (2, 2) and m.in_channels == x.C
+        Co = m.out_channels
+        assert out.C == Co and out.H == 2 * x.H and out.W == 2 * x.W
+        wp = self._pack(m.weight, L.PACK_CONVT_FWD)
+        bias4 = m.bias.detach().repeat(4) if m.bias is not None else None
+        ops.conv_igemm(x, wp, bias4, out, ntaps=1, store_mode=L.STORE_SHUFFLE2X2, nout=4 * Co, co=Co)
+
+        if self.record:
+            def bwd():
+                g = self._sum_grads(out, 1)[0]
+                if m.bias is not None:
+                    self._give_grad(m.bias, ops.colsum(g))
+                self._give_grad(m.weight, ops.wgrad(x, g, tuple(m.weight.shape), ntaps=4,
+                                                    taps_mode=L.TAPS_GATHER2X2))
+                if x.needs_grad:
+                    dx = self.new_act(x.N, x.H, x.W, x.C)
+                    ops.conv_igemm(g, self._pack(m.weight, L.PACK_CONVT_DGRAD), None, dx, ntaps=4,
+                                   taps_mode=L.TAPS_GATHER2X2)
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return out
+
+    def out_conv(self, x: Act, conv: nn.Conv2d) -> torch.Tensor:
+        """1x1 convolution to the logits, (N, K, H, W) fp32.  Reference: OutConv (common_layers.py:125)."""
+        assert conv.kernel_size == (1, 1) and conv.in_channels == x.C
+        K = conv.out_channels
+        w = conv.weight.detach().reshape(K, x.C)
+        b = conv.bias.detach() if conv.bias is not None else torch.zeros(K, device=self.device)
+        logits = ops.outconv_fwd(x, w, b)
+        if self.record:
+            def bwd(g_logits: torch.Tensor):
+                dx = self.new_act(x.N, x.H, x.W, x.C) if x.needs_grad else None
+                dw, db = ops.outconv_bwd(x, w, g_logits.contiguous().float(), dx)
+                self._give_grad(conv.weight, dw.reshape(conv.weight.shape))
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, db)
+                if dx is not None:
+                    x.add_grad(dx)
+
+            self._heads.append(bwd)
+        return logits
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, grad_outputs: Sequence[Optional[torch.Tensor]]) -> Dict[nn.Parameter, torch.Tensor]:
+        """Run the recorded tape in reverse.  `grad_outputs` pairs with the out_conv heads in
+        emission order."""
+        heads = self._heads
+        assert len(grad_outputs) == len(heads)
+        for fn, g in zip(reversed(heads), reversed(list(grad_outputs))):
+            if g is not None:
+                fn(g)
+        for fn in reversed(self.tape):
+            fn()
+        self.tape.clear()
+        return self.param_grads

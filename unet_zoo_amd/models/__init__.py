@@ -1,0 +1,106 @@
+"""Model registry with the reference's public surface (unet_zoo/models/__init__.py:27-238):
+``create_model(name, pretrained=False, **kwargs)``, ``list_models()``, ``get_model_config(name)``.
+
+Same 24 names, same case-insensitive lookup, same kwarg adaptation and error types
+(``ValueError`` for an unknown name or a missing ``image_size``, ``TypeError`` for stray
+kwargs, raised by the constructor).  Names whose graph is not yet on the HIP engine raise
+``NotImplementedError`` — there is deliberately no PyTorch fallback backend in the product path
+(SURVEY.md §8 scope: the hot path only).
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional
+
+import torch.nn as nn
+
+from .unet import UNet
+
+# every name the reference registers (models/__init__.py:27-52); value = constructor or None
+_model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
+    'unet': UNet,
+    'attention_unet': None,
+    'transatt_unet': None,
+    'raunet': None,
+    'da_transformer': None,
+    'unet_transformer': None,
+    'uctransnet': None,
+    'multiresunet': None,
+    'nested_unet': None,
+    'missformer': None,
+    'vnet': None,
+    'u2net': None,
+    'u2netp': None,
+    'swin_unet_v2': None,
+    'resunet': None,
+    'wranet': None,
+    'egeunet': None,
+    'unext': None,
+    'unext_s': None,
+    'mmunet': None,
+    'axialunet': None,
+    'gated': None,
+    'medt': None,
+    'logo': None,
+}
+
+_config_functions: Dict[str, Callable[..., Dict[str, Any]]] = {}
+
+
+def list_models() -> List[str]:
+    """All registered model names, sorted (reference: models/__init__.py:59-61)."""
+    return sorted(_model_entries.keys())
+
+
+def hip_models() -> List[str]:
+    """The subset of :func:`list_models` that runs on the HIP engine today."""
+    return sorted(k for k, v in _model_entries.items() if v is not None)
+
+
+def get_model_config(model_name: str, **kwargs) -> Dict[str, Any]:
+    """Default configuration of a model, ``{}`` if it has none (models/__init__.py:63-76)."""
+    if model_name in _config_functions:
+        return _config_functions[model_name](**kwargs)
+    return {}
+
+
+def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Module:
+    """Instantiate a UNet variant by name (reference: models/__init__.py:78-238)."""
+    name = model_name.lower()
+    if name not in _model_entries:
+        raise ValueError(f"Unknown model: '{model_name}'. Available models: {list_models()}")
+    factory = _model_entries[name]
+
+    in_channels = kwargs.pop('in_channels', 3)
+    num_classes = kwargs.pop('num_classes', 1)
+    image_size = kwargs.pop('image_size', None)
+    depth = kwargs.pop('depth', 5)
+
+    if name in ('swin_unet_v2', 'uctransnet') and image_size is None:
+        raise ValueError(f"Model '{model_name}' requires 'image_size' parameter in config.")
+
+    if factory is None:
+        raise NotImplementedError(
+            f"'{name}' is registered (the reference's name list is kept) but its graph is not yet "
+            f"implemented on the MI355X HIP engine; available today: {hip_models()}")
+
+    args: Dict[str, Any] = {}
+    if name == 'unet':
+        # `depth` is accepted and dropped, as in the reference (models/__init__.py:97-99)
+        args.update(in_channels=in_channels, num_classes=num_classes)
+    elif name == 'attention_unet':
+        args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
+    elif name in ('u2net', 'u2netp'):
+        args.update(in_ch=in_channels, out_ch=num_classes)
+    elif name == 'swin_unet_v2':
+        args.update(img_size=image_size, in_chans=in_channels, num_classes=num_classes)
+    else:
+        args.update(in_channels=in_channels, num_classes=num_classes)
+    args.update(kwargs)  # leftovers reach the constructor: unknown ones raise TypeError there
+
+    model = factory(**args)
+    if pretrained:
+        print(f"Warning: Pre-trained weights for {model_name} are not yet implemented.")
+    return model
+
+
+__all__ = ['UNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']

@@ -1,0 +1,234 @@
+"""Python face of the C ABI: each function launches exactly one HIP kernel of libunetzoo_hip.so on
+torch's current stream.  Activations are :class:`Act` views — NHWC, possibly a channel window of
+a wider buffer (that is how the reference's ``torch.cat`` skip-concats, common_layers.py:115,
+are never materialised).
+"""
+from __future__ import annotations
+
+from ctypes import byref
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+class Act:
+    """NHWC activation: element (pixel p, channel c) at ``buf[p, off + c]``; ``buf`` is (P, ld)."""
+
+    __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "needs_grad")
+
+    def __init__(self, buf: torch.Tensor, off: int, C: int, N: int, H: int, W: int,
+                 needs_grad: bool = True):
+        assert buf.dim() == 2 and buf.is_contiguous() and buf.shape[0] == N * H * W
+        assert 0 <= off and off + C <= buf.shape[1]
+        self.buf, self.off, self.C, self.N, self.H, self.W = buf, off, C, N, H, W
+        self.grads: List["Act"] = []        # gradient contributions (same resolution as self)
+        self.parts: Optional[Sequence["Act"]] = None  # set on the full view of a concat buffer
+        self.needs_grad = needs_grad
+
+    @property
+    def ld(self) -> int:
+        return self.buf.shape[1]
+
+    @property
+    def P(self) -> int:
+        return self.buf.shape[0]
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.buf.dtype
+
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + self.off * self.buf.element_size()
+
+    def window(self, off: int, C: int) -> "Act":
+        return Act(self.buf, self.off + off, C, self.N, self.H, self.W, self.needs_grad)
+
+    def add_grad(self, g: "Act") -> None:
+        """Register a gradient contribution; a concat view forwards channel windows to its parts."""
+        if self.parts is not None:
+            o = 0
+            for part in self.parts:
+                part.add_grad(g.window(o, part.C))
+                o += part.C
+        else:
+            self.grads.append(g)
+
+    def dense(self) -> torch.Tensor:
+        """(N, C, H, W) fp32 copy — test/debug helper, not used on the hot path."""
+        v = self.buf[:, self.off:self.off + self.C].float()
+        return v.reshape(self.N, self.H, self.W, self.C).permute(0, 3, 1, 2).contiguous()
+
+
+def new_act(N: int, H: int, W: int, C: int, dtype: torch.dtype, device, needs_grad=True) -> Act:
+    return Act(torch.empty((N * H * W, C), dtype=dtype, device=device), 0, C, N, H, W, needs_grad)
+
+
+def act_from_nchw(x: torch.Tensor, dtype: torch.dtype) -> Act:
+    """Test helper: (N,C,H,W) tensor -> NHWC Act."""
+    N, C, H, W = x.shape
+    buf = x.permute(0, 2, 3, 1).reshape(N * H * W, C).to(dtype).contiguous()
+    return Act(buf, 0, C, N, H, W)
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+def pack_weights(w: torch.Tensor, mode: int, dtype: torch.dtype, kpad: int = 0) -> torch.Tensor:
+    """fp32 master weights (reference layout) -> kernel layout in the run dtype."""
+    L.require_cuda(w)
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    d0, d1 = w.shape[0], w.shape[1]
+    T = w.numel() // (d0 * d1)
+    if mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD, L.PACK_IM2COL):
+        Co, Ci = d0, d1
+    else:  # ConvTranspose2d weight is (Cin, Cout, kh, kw)
+        Ci, Co = d0, d1
+    if mode == L.PACK_CONV_FWD:
+        shape = (Co, T * Ci)
+    elif mode == L.PACK_CONV_DGRAD:
+        shape = (Ci, T * Co)
+    elif mode == L.PACK_CONVT_FWD:
+        shape = (T * Co, Ci)
+    elif mode == L.PACK_CONVT_DGRAD:
+        shape = (Ci, T * Co)
+    else:
+        shape = (Co, kpad)
+    dst = torch.empty(shape, dtype=dtype, device=w.device)
+    L.check(L.load().uz_pack_weights(L.dtype_code(dtype), mode, w.data_ptr(), Co, Ci, T, kpad,
+                                     dst.data_ptr(), L.stream_ptr()), "uz_pack_weights")
+    return dst
+
+
+def im2col3x3_nchw(x: torch.Tensor, kpad: int, dtype: torch.dtype) -> Act:
+    L.require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, C, H, W = x.shape
+    out = new_act(N, H, W, kpad, dtype, x.device, needs_grad=False)
+    L.check(L.load().uz_im2col3x3_nchw(L.dtype_code(dtype), x.data_ptr(), N, C, H, W, kpad,
+                                       out.buf.data_ptr(), L.stream_ptr()), "uz_im2col3x3_nchw")
+    return out
+
+
+def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Act, *,
+               ntaps: int, dil: int = 1, taps_mode: int = L.TAPS_CONV,
+               store_mode: int = L.STORE_PLAIN, nout: Optional[int] = None, co: int = 0,
+               want_stats: bool = False) -> Optional[torch.Tensor]:
+    """y = conv(x, w) + bias on the matrix cores; returns the BN partial-sum rows if asked."""
+    L.require_cuda(x.buf, w_packed, y.buf)
+    lib = L.load()
+    if taps_mode == L.TAPS_CONV:
+        N, H, W = x.N, x.H, x.W
+    else:
+        N, H, W = x.N, x.H // 2, x.W // 2
+    d = L.ConvDesc(L.dtype_code(x.dtype), N, H, W, x.H, x.W, x.C, x.ld,
+                   nout if nout is not None else y.C, y.ld, ntaps, taps_mode, dil, store_mode, co)
+    assert w_packed.dtype == x.dtype and y.dtype == x.dtype
+    assert w_packed.shape == (d.Nout, ntaps * x.C), (tuple(w_packed.shape), d.Nout, ntaps, x.C)
+    stats = None
+    if want_stats:
+        gm = L.check_count(lib.uz_conv_igemm_grid_m(byref(d)), "uz_conv_igemm_grid_m")
+        stats = torch.empty((gm, 2, d.Nout), dtype=torch.float32, device=x.buf.device)
+    L.check(lib.uz_conv_igemm(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
+                              L.stream_ptr()), "uz_conv_igemm")
+    return stats
+
+
+def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
+          taps_mode: int = L.TAPS_CONV) -> torch.Tensor:
+    """out[i, j, tap] = sum_p L[p, i] * R[pix(p, tap), j]  (fp32, reference parameter layout)."""
+    L.require_cuda(Lt.buf, Rt.buf)
+    lib = L.load()
+    d = L.WgradDesc(L.dtype_code(Lt.dtype), Lt.N, Lt.H, Lt.W, Rt.H, Rt.W, Lt.C, Lt.ld, Rt.C, Rt.ld,
+                    ntaps, taps_mode, dil)
+    split = L.check_count(lib.uz_wgrad_split(byref(d)), "uz_wgrad_split")
+    alloc = torch.zeros if split > 1 else torch.empty
+    out = alloc(out_shape, dtype=torch.float32, device=Lt.buf.device)
+    assert out.numel() == Lt.C * Rt.C * ntaps
+    L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), L.stream_ptr()), "uz_wgrad")
+    return out
+
+
+def bn_finalize(stats: torch.Tensor, count: int, gamma, beta, eps: float, momentum: float,
+                running_mean, running_var):
+    lib = L.load()
+    C = stats.shape[2]
+    dev = stats.device
+    vec = torch.empty((4, C), dtype=torch.float32, device=dev)  # scale, shift, mean, invstd
+    L.check(lib.uz_bn_finalize(stats.data_ptr(), stats.shape[0], C, float(count), gamma.data_ptr(),
+                               beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
+                               vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                               vec[3].data_ptr(), L.stream_ptr()), "uz_bn_finalize")
+    return vec
+
+
+def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
+    lib = L.load()
+    C = gamma.numel()
+    vec = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    L.check(lib.uz_bn_eval_scale(C, gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
+                                 running_var.data_ptr(), eps, vec[0].data_ptr(), vec[1].data_ptr(),
+                                 L.stream_ptr()), "uz_bn_eval_scale")
+    return vec
+
+
+def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
+                  pooled: Optional[Act] = None) -> None:
+    lib = L.load()
+    L.check(lib.uz_bn_relu_apply(L.dtype_code(y.dtype), y.ptr(), y.ld, scale.data_ptr(),
+                                 shift.data_ptr(), y.N, y.H, y.W, y.C, act.ptr(), act.ld,
+                                 pooled.ptr() if pooled is not None else None,
+                                 pooled.ld if pooled is not None else 0, L.stream_ptr()),
+            "uz_bn_relu_apply")
+
+
+def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
+                gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
+                dbeta: torch.Tensor) -> None:
+    """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a zeroed float64 (2, C) scratch."""
+    lib = L.load()
+    d = L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
+                    g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
+                    gpool.ld if gpool is not None else 0, dy.ld)
+    args = (y.ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
+            g0.ptr() if g0 is not None else None, g1.ptr() if g1 is not None else None,
+            gpool.ptr() if gpool is not None else None)
+    s = L.stream_ptr()
+    L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, sums.data_ptr(), s), "uz_bn_relu_bwd_reduce")
+    L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(),
+                                     dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_apply")
+
+
+def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    lib = L.load()
+    K = w.shape[0]
+    out = torch.empty((x.N, K, x.H, x.W), dtype=torch.float32, device=x.buf.device)
+    L.check(lib.uz_outconv_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.N, x.H * x.W, x.C,
+                               w.data_ptr(), b.data_ptr(), K, out.data_ptr(), L.stream_ptr()),
+            "uz_outconv_fwd")
+    return out
+
+
+def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act]):
+    lib = L.load()
+    K = w.shape[0]
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.shape == (x.N, K, x.H, x.W)
+    dwb = torch.zeros(K * x.C + K, dtype=torch.float32, device=x.buf.device)
+    dw, db = dwb[:K * x.C], dwb[K * x.C:]
+    L.check(lib.uz_outconv_bwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.N, x.H * x.W, x.C,
+                               w.data_ptr(), K, g.data_ptr(),
+                               dx.ptr() if dx is not None else None,
+                               dx.ld if dx is not None else 0, dw.data_ptr(), db.data_ptr(),
+                               L.stream_ptr()), "uz_outconv_bwd")
+    return dw.view(K, x.C), db
+
+
+def colsum(x: Act) -> torch.Tensor:
+    lib = L.load()
+    out = torch.zeros(x.C, dtype=torch.float32, device=x.buf.device)
+    L.check(lib.uz_colsum(L.dtype_code(x.dtype), x.ptr(), x.ld, x.P, x.C, out.data_ptr(),
+                          L.stream_ptr()), "uz_colsum")
+    return out
