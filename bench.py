@@ -1,0 +1,182 @@
+"""Benchmark of the BASELINE.json metric: images/sec of the 'unet' training hot path at B=16
+3x256x256 bf16 per GPU on 1..8 MI355X (weak scaling: per-GPU batch fixed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = the reference's whole training step (unet_zoo/utils/training_loop.py:112-121):
+zero_grad -> forward -> BCEWithLogits -> backward (-> RCCL gradient all-reduce) ->
+clip_grad_norm_(1.0) -> AdamW.  Inputs are synthetic and already resident in HBM.  `value` is
+images/sec of that WHOLE step (a lower bound of the fwd+bwd rate, which is reported beside it as
+`fwd_bwd_images_per_s` from HIP events recorded inside the same timed steps).
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel (most GPU time), timed live with HIP events on the launch
+                 stream during the timed steps; flops/bytes are the algorithmic counts of
+                 SURVEY.md §8d for exactly the launches timed.
+  cpu_baseline — the CPU oracle (oracle/torch_ref.py, a port of the reference graph to
+                 torch.nn.functional, pinned to the reference by tests/golden) doing the same
+                 step on the host cores, rank 0, N=1 only, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import unet_zoo_amd  # noqa: E402
+from unet_zoo_amd import ops  # noqa: E402
+from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
+
+PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
+
+
+def cpu_baseline(batch: int, hw: int, steps: int):
+    """Reference step on the host CPU through the oracle (checker code, used here only as the
+    reported baseline)."""
+    from oracle import torch_ref
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=1)
+    sd = m.state_dict()
+    st = torch_ref.clone_state(sd, requires_grad=True)
+    params = [v for v in st.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5)
+    x, mask = torch_ref.synthetic_batch(batch, 3, hw, hw, seed=1234)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = F.binary_cross_entropy_with_logits(torch_ref.unet_forward(st, x, True), mask)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])  # drop the warm-up step
+    med = times[len(times) // 2]
+    return {"value": round(batch / med, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"unet train step on CPU fp32, B={batch} 3x{hw}x{hw}, 1 warm-up + {steps} timed steps, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    run_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=1)
+    model.run_dtype = run_dtype
+    model = model.to(dev).train()
+    net = RcclDataParallel(model) if world > 1 else model
+    params = list(model.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5)
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(dev)
+    mask = (torch.rand(args.batch, 1, args.size, args.size, generator=g) > 0.5).float().to(dev)
+
+    fb_events = []
+
+    def step(timed: bool):
+        opt.zero_grad(set_to_none=True)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = net(x)
+        loss = F.binary_cross_entropy_with_logits(out, mask)
+        loss.backward()
+        if timed:
+            e1.record()
+            fb_events.append((e0, e1))
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step(False)
+    ops.profile_begin()  # HIP events around every matrix-core launch of the timed steps
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        fb_ms = sorted(a.elapsed_time(b) for a, b in fb_events)[len(fb_events) // 2]
+        # dominant kernel = the family with the largest summed duration
+        dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
+        roofline = None
+        if dom is not None:
+            flops_per_launch = dom["flops"] / dom["launches"]
+            sec_per_launch = dom["ms"] * 1e-3 / dom["launches"]
+            ach = flops_per_launch / sec_per_launch / 1e12
+            peak = PEAK["mfma_bf16_tflops"] if run_dtype == torch.bfloat16 else PEAK["mfma_f32_tflops"]
+            roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "launches_per_step": dom["launches"] // args.steps,
+                        "avg_launch_us": round(sec_per_launch * 1e6, 2),
+                        "algorithmic_gbytes_per_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+                        "share_of_step": round(dom["ms"] / args.steps / ms, 4)}
+        line = {
+            "metric": "images/sec (fwd+bwd) at B=16 3x256x256, 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"unet train step (zero_grad+fwd+BCE+bwd+clip+AdamW), B={args.batch}/GPU "
+                                   f"3x{args.size}x{args.size}, random-init weights",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+            "fwd_bwd_ms": round(fb_ms, 3),
+            "fwd_bwd_images_per_s": round(args.batch * world / (fb_ms * 1e-3), 2),
+            "loss": round(loss.item(), 5),
+            "roofline": roofline,
+            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

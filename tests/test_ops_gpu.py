@@ -1,7 +1,7 @@
 """GPU: every C-ABI kernel against the plain-PyTorch fp32 CPU restatement of the same op
 (torch.nn.functional — what the reference itself calls), on seeded inputs, ragged sizes included.
-fp32 run dtype must agree to 1e-4 (north-star tolerance is 1e-3 relative); bf16 is checked
-against the same fp32 math fed bf16-rounded operands."""
+fp32 run dtype must agree to 2e-5 of the tensor's max (measured ~1e-6; the north-star tolerance is
+1e-3 relative); bf16 is checked against the same fp32 math fed bf16-rounded operands."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -17,7 +17,7 @@ DTYPES = [torch.float32, torch.bfloat16]
 
 
 def tol(dt):
-    return 2e-4 if dt == torch.float32 else 2e-2
+    return 2e-5 if dt == torch.float32 else 2e-2
 
 
 def rnd(dt, t):

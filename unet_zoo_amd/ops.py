@@ -77,6 +77,59 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 # ------------------------------------------------------------------------------------------------
+# Optional per-launch timing (bench.py): HIP events recorded on the launch stream around each
+# kernel, grouped by kernel family, with the algorithmic flops / bytes of exactly those launches.
+_prof_on = False
+_prof_log: list = []
+
+
+def profile_begin() -> None:
+    global _prof_on
+    _prof_log.clear()
+    _prof_on = True
+
+
+def profile_end() -> dict:
+    """Returns {family: {"ms", "launches", "flops", "bytes"}}; synchronises the device."""
+    global _prof_on
+    _prof_on = False
+    torch.cuda.synchronize()
+    out: dict = {}
+    for name, e0, e1, fl, by in _prof_log:
+        d = out.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["launches"] += 1
+        d["flops"] += fl
+        d["bytes"] += by
+    _prof_log.clear()
+    return out
+
+
+class _Timed:
+    __slots__ = ("name", "flops", "bytes", "e0")
+
+    def __init__(self, name: str, flops: float, nbytes: float):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        if _prof_on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _prof_on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _prof_log.append((self.name, self.e0, e1, self.flops, self.bytes))
+        return False
+
+
+def _tname(dt: torch.dtype) -> str:
+    return "bf16" if dt == torch.bfloat16 else "f32"
+
+
+# ------------------------------------------------------------------------------------------------
 def pack_weights(w: torch.Tensor, mode: int, dtype: torch.dtype, kpad: int = 0) -> torch.Tensor:
     """fp32 master weights (reference layout) -> kernel layout in the run dtype."""
     L.require_cuda(w)
@@ -132,8 +185,11 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     if want_stats:
         gm = L.check_count(lib.uz_conv_igemm_grid_m(byref(d)), "uz_conv_igemm_grid_m")
         stats = torch.empty((gm, 2, d.Nout), dtype=torch.float32, device=x.buf.device)
-    L.check(lib.uz_conv_igemm(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
-                              L.stream_ptr()), "uz_conv_igemm")
+    M, K, es = N * H * W, ntaps * x.C, x.buf.element_size()
+    with _Timed(f"igemm_{_tname(x.dtype)}_128x{64 if d.Nout <= 64 else 128}", 2.0 * M * d.Nout * K,
+                es * (x.P * x.C + M * d.Nout + d.Nout * K)):
+        L.check(lib.uz_conv_igemm(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
+                                  L.stream_ptr()), "uz_conv_igemm")
     return stats
 
 
@@ -148,7 +204,10 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     alloc = torch.zeros if split > 1 else torch.empty
     out = alloc(out_shape, dtype=torch.float32, device=Lt.buf.device)
     assert out.numel() == Lt.C * Rt.C * ntaps
-    L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), L.stream_ptr()), "uz_wgrad")
+    tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
+    with _Timed(f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}", 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
+                Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
+        L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), L.stream_ptr()), "uz_wgrad")
     return out
 
 
@@ -178,11 +237,13 @@ def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
 def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
                   pooled: Optional[Act] = None) -> None:
     lib = L.load()
-    L.check(lib.uz_bn_relu_apply(L.dtype_code(y.dtype), y.ptr(), y.ld, scale.data_ptr(),
-                                 shift.data_ptr(), y.N, y.H, y.W, y.C, act.ptr(), act.ld,
-                                 pooled.ptr() if pooled is not None else None,
-                                 pooled.ld if pooled is not None else 0, L.stream_ptr()),
-            "uz_bn_relu_apply")
+    es = y.buf.element_size()
+    with _Timed("bn_relu_apply", 0.0, es * y.P * y.C * (2.25 if pooled is not None else 2.0)):
+        L.check(lib.uz_bn_relu_apply(L.dtype_code(y.dtype), y.ptr(), y.ld, scale.data_ptr(),
+                                     shift.data_ptr(), y.N, y.H, y.W, y.C, act.ptr(), act.ld,
+                                     pooled.ptr() if pooled is not None else None,
+                                     pooled.ld if pooled is not None else 0, L.stream_ptr()),
+                "uz_bn_relu_apply")
 
 
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
@@ -197,9 +258,13 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
             g0.ptr() if g0 is not None else None, g1.ptr() if g1 is not None else None,
             gpool.ptr() if gpool is not None else None)
     s = L.stream_ptr()
-    L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, sums.data_ptr(), s), "uz_bn_relu_bwd_reduce")
-    L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(),
-                                     dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_apply")
+    nsrc = (g0 is not None) + (g1 is not None) + 0.25 * (gpool is not None)
+    es = y.buf.element_size()
+    with _Timed("bn_relu_bwd_reduce", 0.0, es * y.P * y.C * (1 + nsrc)):
+        L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, sums.data_ptr(), s), "uz_bn_relu_bwd_reduce")
+    with _Timed("bn_relu_bwd_apply", 0.0, es * y.P * y.C * (2 + nsrc)):
+        L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(),
+                                         dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_apply")
 
 
 def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
