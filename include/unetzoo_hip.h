@@ -83,7 +83,10 @@ int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed, co
  * conv k3/k1:  L = dy (i = c_out), R = x (j = c_in)   -> out is OIHW        (nn.Conv2d.weight)
  * convT k2s2:  L = x  (i = c_in),  R = dy (j = c_out) -> out is (Cin,Cout,2,2) (ConvTranspose2d.weight)
  * Replaces the weight-gradient half of autograd for the call sites above.
- * `out` must be zero-filled by the caller when uz_wgrad_split() > 1 (atomic accumulation).
+ * Two kernels: the pixel range is split over uz_wgrad_split() workgroup slices that each write an
+ * fp32 partial slab into `workspace` (uz_wgrad_workspace_bytes() bytes, no initialisation
+ * needed); a second kernel adds the slabs in fixed order and transposes into `out`
+ * (deterministic, no atomics).
  * ------------------------------------------------------------------------------------------- */
 typedef struct uz_wgrad_desc {
   int dtype;
@@ -95,7 +98,9 @@ typedef struct uz_wgrad_desc {
 } uz_wgrad_desc;
 
 int uz_wgrad_split(const uz_wgrad_desc* d);
-int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* stream);
+long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d); /* <0 on error */
+int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace,
+             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight re-packing: fp32 master parameters in the reference layout -> kernel layout in run dtype.
@@ -139,22 +144,25 @@ int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, cons
 /* Backward of (BN train -> ReLU [-> MaxPool2d(2,2)]) in two passes.
  * The gradient arriving at the activation is
  *     g = g0[p] + g1[p] + (p is the first max of its 2x2 window ? gpool[window] : 0)
- * (any of g0/g1/gpool may be NULL).  Pass 1 accumulates sums[0][c] = sum g*mask,
- * sums[1][c] = sum g*mask*xhat (double, caller zero-fills).  Pass 2 writes
- *     dy = scale * (g*mask - sums0/count - xhat*sums1/count)
- * and dgamma = sums1, dbeta = sums0 (fp32). */
+ * (any of g0/g1/gpool may be NULL).  Pass 1 (uz_bn_relu_bwd_reduce) writes one partial row per
+ * workgroup into `workspace` (uz_bn_relu_bwd_workspace_bytes() bytes), then a finalize kernel
+ * sums the rows in fixed order into sums[0][c] = sum g*mask, sums[1][c] = sum g*mask*xhat
+ * (double) and dbeta = sums[0], dgamma = sums[1] (fp32; may be NULL).  Pass 2 writes
+ *     dy = scale * (g*mask - sums0/count - xhat*sums1/count). */
 typedef struct uz_bnbwd_desc {
   int dtype;
   int N, H, W, C;
   int ldy, ldg0, ldg1, ldgp, lddy;
 } uz_bnbwd_desc;
+long long uz_bn_relu_bwd_workspace_bytes(const uz_bnbwd_desc* d, int has_pool_grad);
 int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, const float* scale,
                           const float* shift, const float* mean, const float* invstd, const void* g0,
-                          const void* g1, const void* gpool, double* sums, void* stream);
+                          const void* g1, const void* gpool, void* workspace, double* sums,
+                          float* dgamma, float* dbeta, void* stream);
 int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const float* scale,
                          const float* shift, const float* mean, const float* invstd, const void* g0,
                          const void* g1, const void* gpool, const double* sums, double count,
-                         void* dy, float* dgamma, float* dbeta, void* stream);
+                         void* dy, void* stream);
 
 /* 1x1 convolution with few outputs (OutConv, common_layers.py:125), NCHW fp32 logits.
  *   out[n, k, h, w] = b[k] + sum_c x[p, c] * w[k, c],  k < Kout <= 8 */

@@ -23,8 +23,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 # every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "uz_abi_version", "uz_last_error_string", "uz_conv_igemm_grid_m", "uz_conv_igemm",
-    "uz_wgrad_split", "uz_wgrad", "uz_pack_weights", "uz_im2col3x3_nchw", "uz_bn_finalize",
-    "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
+    "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_im2col3x3_nchw", "uz_bn_finalize",
+    "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd", "uz_colsum",
 )
 
@@ -69,22 +69,25 @@ def load():
     lib.uz_conv_igemm_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     lib.uz_wgrad_split.argtypes = [POINTER(WgradDesc)]
-    lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp]
+    lib.uz_wgrad_workspace_bytes.argtypes = [POINTER(WgradDesc)]
+    lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]
     lib.uz_pack_weights.argtypes = [ip, ip, vp, ip, ip, ip, ip, vp, vp]
     lib.uz_im2col3x3_nchw.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp]
     lib.uz_bn_finalize.argtypes = [vp, ip, ip, c_double, vp, vp, fp, fp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_bn_eval_scale.argtypes = [ip, vp, vp, vp, vp, fp, vp, vp, vp]
     lib.uz_bn_relu_apply.argtypes = [ip, vp, ip, vp, vp, ip, ip, ip, ip, vp, ip, vp, ip, vp]
-    lib.uz_bn_relu_bwd_reduce.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_bn_relu_bwd_workspace_bytes.argtypes = [POINTER(BnBwdDesc), ip]
+    lib.uz_bn_relu_bwd_reduce.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                          vp, vp, vp]
     lib.uz_bn_relu_bwd_apply.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                         c_double, vp, vp, vp, vp]
+                                         c_double, vp, vp]
     lib.uz_outconv_fwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
     lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp]
     lib.uz_colsum.argtypes = [ip, vp, ip, ip, ip, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("uz_last_error_string",):
-            fn.restype = c_int
+            fn.restype = ctypes.c_longlong if name.endswith("_workspace_bytes") else c_int
     if lib.uz_abi_version() != 1:
         raise HipLibraryError("libunetzoo_hip.so ABI version mismatch; rebuild it")
     _lib = lib

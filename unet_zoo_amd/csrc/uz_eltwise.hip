@@ -149,7 +149,8 @@ struct BnBwdArgs {
   const float* shift;
   const float* mean;
   const float* invstd;
-  double* sums;        // pass 1 out / pass 2 in: [2][C]
+  double* sums;        // pass 2 in: [2][C] totals
+  float* partials;     // pass 1 out: [gridDim.x][2][C]
   float* dgamma;
   float* dbeta;
   double inv_count;
@@ -277,16 +278,40 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
       for (int r = 0; r < (int)blockDim.y; ++r) t += red[((size_t)r * blockDim.x + threadIdx.x) * (2 * VEC) + e];
       if (cok) {
         const int which = e / VEC, ch = c0 + (e % VEC);
-        atomicAdd(a.sums + (size_t)which * a.C + ch, (double)t);
+        a.partials[((size_t)blockIdx.x * 2 + which) * a.C + ch] = t;  // one deterministic row per block
       }
     }
-  } else {
-    if (blockIdx.x == 0 && threadIdx.y == 0 && cok && a.dgamma != nullptr) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        a.dbeta[c0 + i] = (float)a.sums[c0 + i];
-        a.dgamma[c0 + i] = (float)a.sums[a.C + c0 + i];
-      }
+  }
+}
+
+// totals[2][C] (double) = sum over the partial rows; dbeta = totals[0], dgamma = totals[1]
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows,
+                                                               int C, double* __restrict__ sums,
+                                                               float* dgamma, float* dbeta) {
+  __shared__ double sh[2][32][33];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    for (int r = g; r < rows; r += 32) {
+      a1 += (double)part[((size_t)r * 2 + 0) * C + c];
+      a2 += (double)part[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  sh[0][g][cl] = a1;
+  sh[1][g][cl] = a2;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < 32; ++r) {
+      t1 += sh[0][r][cl];
+      t2 += sh[1][r][cl];
+    }
+    sums[c] = t1;
+    sums[C + c] = t2;
+    if (dgamma != nullptr) {
+      dbeta[c] = (float)t1;
+      dgamma[c] = (float)t2;
     }
   }
 }
@@ -618,12 +643,17 @@ static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, c
   return UZ_OK;
 }
 
+static void bnbwd_shape(const uz_bnbwd_desc* d, bool pool, dim3* grid, dim3* block) {
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  const long long units = pool ? (long long)d->N * (d->H / 2) * (d->W / 2) : (long long)d->N * d->H * d->W;
+  reduce_shape(d->C / vec, units, grid, block);
+}
+
 template <typename T, int PASS>
 static int bnbwd_launch(const uz_bnbwd_desc* d, const BnBwdArgs& a, bool pool, hipStream_t s) {
   constexpr int VEC = ElemTraits<T>::VEC;
   dim3 grid, block;
-  const long long units = pool ? (long long)d->N * (d->H / 2) * (d->W / 2) : (long long)d->N * d->H * d->W;
-  reduce_shape(d->C / VEC, units, &grid, &block);
+  bnbwd_shape(d, pool, &grid, &block);
   const size_t shm = PASS == 1 ? (size_t)256 * 2 * VEC * sizeof(float) : 0;
   if (pool) {
     hipLaunchKernelGGL((bn_relu_bwd_kernel<T, true, PASS>), grid, block, shm, s, a);
@@ -648,6 +678,7 @@ static BnBwdArgs bnbwd_args(const uz_bnbwd_desc* d, const void* y, const float* 
   a.mean = mean;
   a.invstd = invstd;
   a.sums = nullptr;
+  a.partials = nullptr;
   a.dgamma = nullptr;
   a.dbeta = nullptr;
   a.inv_count = 0.0;
@@ -663,36 +694,49 @@ static BnBwdArgs bnbwd_args(const uz_bnbwd_desc* d, const void* y, const float* 
   return a;
 }
 
+extern "C" long long uz_bn_relu_bwd_workspace_bytes(const uz_bnbwd_desc* d, int has_pool_grad) {
+  UZ_REQUIRE(d != nullptr && d->C > 0 && d->N > 0 && d->H > 0 && d->W > 0, "uz_bn_relu_bwd_workspace_bytes: bad descriptor");
+  UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "uz_bn_relu_bwd_workspace_bytes: bad dtype");
+  dim3 grid, block;
+  bnbwd_shape(d, has_pool_grad != 0, &grid, &block);
+  return (long long)grid.x * 2 * d->C * (long long)sizeof(float);
+}
+
 extern "C" int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, const float* scale,
                                      const float* shift, const float* mean, const float* invstd,
-                                     const void* g0, const void* g1, const void* gpool, double* sums,
-                                     void* stream) {
+                                     const void* g0, const void* g1, const void* gpool, void* workspace,
+                                     double* sums, float* dgamma, float* dbeta, void* stream) {
   const int rc = bnbwd_check(d, g0, g1, gpool);
   if (rc != UZ_OK) return rc;
-  UZ_REQUIRE(y && scale && shift && mean && invstd && sums, "uz_bn_relu_bwd_reduce: null pointer");
+  UZ_REQUIRE(y && scale && shift && mean && invstd && sums && workspace, "uz_bn_relu_bwd_reduce: null pointer");
+  UZ_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "uz_bn_relu_bwd_reduce: dgamma/dbeta");
   BnBwdArgs a = bnbwd_args(d, y, scale, shift, mean, invstd, g0, g1, gpool);
-  a.sums = sums;
+  a.partials = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 1>(d, a, gpool != nullptr, s)
-                             : bnbwd_launch<float, 1>(d, a, gpool != nullptr, s);
+  const int rc2 = d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 1>(d, a, gpool != nullptr, s)
+                                      : bnbwd_launch<float, 1>(d, a, gpool != nullptr, s);
+  if (rc2 != UZ_OK) return rc2;
+  dim3 grid, block;
+  bnbwd_shape(d, gpool != nullptr, &grid, &block);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(uz_cdiv(d->C, 32)), dim3(1024), 0, s,
+                     static_cast<const float*>(workspace), (int)grid.x, d->C, sums, dgamma, dbeta);
+  UZ_LAUNCH_CHECK("uz_bn_relu_bwd_reduce(finalize)");
+  return UZ_OK;
 }
 
 extern "C" int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const float* scale,
                                     const float* shift, const float* mean, const float* invstd,
                                     const void* g0, const void* g1, const void* gpool, const double* sums,
-                                    double count, void* dy, float* dgamma, float* dbeta, void* stream) {
+                                    double count, void* dy, void* stream) {
   const int rc = bnbwd_check(d, g0, g1, gpool);
   if (rc != UZ_OK) return rc;
   UZ_REQUIRE(y && scale && shift && mean && invstd && sums && dy, "uz_bn_relu_bwd_apply: null pointer");
   UZ_REQUIRE(count > 0, "uz_bn_relu_bwd_apply: count");
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(d->lddy % vec == 0 && d->lddy >= d->C, "uz_bn_relu_bwd_apply: bad lddy");
-  UZ_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "uz_bn_relu_bwd_apply: dgamma/dbeta");
   BnBwdArgs a = bnbwd_args(d, y, scale, shift, mean, invstd, g0, g1, gpool);
   a.sums = const_cast<double*>(sums);
   a.dy = dy;
-  a.dgamma = dgamma;
-  a.dbeta = dbeta;
   a.inv_count = 1.0 / count;
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 2>(d, a, gpool != nullptr, s)

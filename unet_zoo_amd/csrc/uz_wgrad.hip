@@ -11,7 +11,9 @@
 //         channel), rows padded by 64 B so the four pixel rows of a read land on distinct banks;
 //   fp32: ds_read_b32 (the 32x32x2 fp32 MFMA wants one element per lane; 32 lanes = 32
 //         consecutive channels = conflict-free).
-// Pixels are split over gridDim.z; partial products are combined with fp32 atomics when split>1.
+// Pixels are split over gridDim.z; every split writes its own fp32 slab [z][tap][Ci][Cj] with
+// coalesced plain stores and a second kernel sums the slabs in a fixed order while transposing to
+// the parameter layout (deterministic; float atomics at a 36-byte lane stride ran 17x slower).
 #include "uz_common.h"
 
 namespace {
@@ -203,6 +205,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     __syncthreads();
   }
 
+  // partial slab [split][tap][Ci][Cj]: lanes 0..31 write 32 consecutive j (128 contiguous bytes)
+  float* slab = a.out + ((size_t)blockIdx.z * a.ntaps + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -211,15 +215,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ti0 + wi * WTI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ci < a.Ci && cj < a.Cj) {
-          float* o = a.out + ((size_t)ci * a.Cj + cj) * a.ntaps + tap;
-          if (a.split > 1)
-            atomicAdd(o, acc[i][j][r]);
-          else
-            *o = acc[i][j][r];
-        }
+        if (ci < a.Ci && cj < a.Cj) slab[(size_t)ci * a.Cj + cj] = acc[i][j][r];
       }
     }
+  }
+}
+
+// out[i][j][tap] = sum_z slab[z][tap][i][j]: thread (x, zg) owns element (i,j) = blockIdx.x*64 + x
+// and the splits z = zg, zg+4, ...; reads are contiguous along j, each thread finally writes its
+// element's ntaps values (ntaps*4 contiguous bytes; a wave writes one contiguous span).
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int split,
+                                                           long long CiCj, float* __restrict__ out) {
+  __shared__ float red[4][64][NT + 1];
+  const int x = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + x;
+  float acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+  if (e < CiCj) {
+    for (int z = zg; z < split; z += 4) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] += slab[((size_t)z * NT + t) * CiCj + e];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) red[zg][x][t] = acc[t];
+  __syncthreads();
+  if (zg == 0 && e < CiCj) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      out[e * NT + t] = red[0][x][t] + red[1][x][t] + red[2][x][t] + red[3][x][t];
   }
 }
 
@@ -252,7 +278,8 @@ int make_plan(const uz_wgrad_desc* d, Plan* p) {
   p->tiles_j = uz_cdiv(d->Cj, p->b);
   const long long base = (long long)p->tiles_i * p->tiles_j * d->ntaps;
   long long split = (4 * UZ_NUM_CU + base - 1) / base;
-  const long long max_split = P / (4LL * bkp) > 0 ? P / (4LL * bkp) : 1;
+  long long max_split = P / (4LL * bkp) > 0 ? P / (4LL * bkp) : 1;
+  if (max_split > 64) max_split = 64;
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   long long chunk = (P + split - 1) / split;
@@ -283,17 +310,24 @@ extern "C" int uz_wgrad_split(const uz_wgrad_desc* d) {
   return p.split;
 }
 
-extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out,
-                        void* stream) {
+extern "C" long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
-  UZ_REQUIRE(L && R && out, "uz_wgrad: null pointer");
+  return (long long)p.split * d->ntaps * d->Ci * d->Cj * (long long)sizeof(float);
+}
+
+extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out,
+                        void* workspace, void* stream) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(L && R && out && workspace, "uz_wgrad: null pointer");
   UZ_REQUIRE(((uintptr_t)L & 15) == 0 && ((uintptr_t)R & 15) == 0, "uz_wgrad: L / R must be 16-byte aligned");
   WgradArgs a;
   a.L = L;
   a.R = R;
-  a.out = out;
+  a.out = static_cast<float*>(workspace);
   a.P = d->N * d->H * d->W;
   a.H = d->H;
   a.W = d->W;
@@ -310,5 +344,18 @@ extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, fl
   a.chunk = p.chunk;
   a.tiles_j = p.tiles_j;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
+  const int rc2 = d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
+  if (rc2 != UZ_OK) return rc2;
+  const long long cicj = (long long)d->Ci * d->Cj;
+  const dim3 grid((unsigned)((cicj + 63) / 64)), block(256);
+  const float* slab = static_cast<const float*>(workspace);
+  if (d->ntaps == 9) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, block, 0, s, slab, p.split, cicj, out);
+  } else if (d->ntaps == 4) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), grid, block, 0, s, slab, p.split, cicj, out);
+  } else {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, block, 0, s, slab, p.split, cicj, out);
+  }
+  UZ_LAUNCH_CHECK("uz_wgrad(reduce)");
+  return UZ_OK;
 }

@@ -71,7 +71,7 @@ class Engine:
 
     def _bn_sums(self, C: int) -> torch.Tensor:
         if self._sums is None:
-            self._sums = torch.zeros(2 * self._bn_channels, dtype=torch.float64, device=self.device)
+            self._sums = torch.empty(2 * self._bn_channels, dtype=torch.float64, device=self.device)
             self._sums_used = 0
         s = self._sums[self._sums_used:self._sums_used + 2 * C].view(2, C)
         self._sums_used += 2 * C

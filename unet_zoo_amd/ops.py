@@ -200,14 +200,15 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     lib = L.load()
     d = L.WgradDesc(L.dtype_code(Lt.dtype), Lt.N, Lt.H, Lt.W, Rt.H, Rt.W, Lt.C, Lt.ld, Rt.C, Rt.ld,
                     ntaps, taps_mode, dil)
-    split = L.check_count(lib.uz_wgrad_split(byref(d)), "uz_wgrad_split")
-    alloc = torch.zeros if split > 1 else torch.empty
-    out = alloc(out_shape, dtype=torch.float32, device=Lt.buf.device)
+    ws_bytes = L.check_count(lib.uz_wgrad_workspace_bytes(byref(d)), "uz_wgrad_workspace_bytes")
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=Lt.buf.device)
+    out = torch.empty(out_shape, dtype=torch.float32, device=Lt.buf.device)
     assert out.numel() == Lt.C * Rt.C * ntaps
     tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
     with _Timed(f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}", 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
-        L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), L.stream_ptr()), "uz_wgrad")
+        L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
+                             L.stream_ptr()), "uz_wgrad")
     return out
 
 
@@ -249,7 +250,7 @@ def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
                 dbeta: torch.Tensor) -> None:
-    """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a zeroed float64 (2, C) scratch."""
+    """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch."""
     lib = L.load()
     d = L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
                     g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
@@ -260,11 +261,15 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
     s = L.stream_ptr()
     nsrc = (g0 is not None) + (g1 is not None) + 0.25 * (gpool is not None)
     es = y.buf.element_size()
+    wsb = L.check_count(lib.uz_bn_relu_bwd_workspace_bytes(byref(d), int(gpool is not None)),
+                        "uz_bn_relu_bwd_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=y.buf.device)
     with _Timed("bn_relu_bwd_reduce", 0.0, es * y.P * y.C * (1 + nsrc)):
-        L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, sums.data_ptr(), s), "uz_bn_relu_bwd_reduce")
+        L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, ws.data_ptr(), sums.data_ptr(),
+                                          dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_reduce")
     with _Timed("bn_relu_bwd_apply", 0.0, es * y.P * y.C * (2 + nsrc)):
-        L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(),
-                                         dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_apply")
+        L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(), s),
+                "uz_bn_relu_bwd_apply")
 
 
 def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
