@@ -61,3 +61,11 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
 }
 
 static inline int uz_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// direct 3x3 convolution (uz_conv3x3.hip), dispatched from uz_conv_igemm()
+struct UzDirectPlan {
+  int tw, bn, bres, th_n, tw_n, ntiles, tiles_n, grid_m;
+};
+int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p);
+int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
+                     const float* bias, void* y, float* stats, hipStream_t s);

@@ -1,0 +1,429 @@
+// Direct 3x3 convolution (stride 1, dilation 1, zero padding 1) for gfx950 (MI355X), NHWC.
+//
+// Stands in for nn.Conv2d(k=3, padding=1) forward and, with flipped/transposed packed weights,
+// its input-gradient (reference: unet_zoo/models/common_layers.py:28,31,47,52,71; autograd a19).
+//
+// One 512-thread workgroup (8 waves, one per CU) owns a 2-D patch of 256 output pixels
+// (8x32 or 16x16) and BN output channels.  For each 128-byte slab of input channels the
+// (TH+2)x(TW+2) halo patch is brought into LDS ONCE by LDS-DMA (buffer_load ... lds: rows that
+// fall outside the image are made out-of-range in the buffer descriptor, so the hardware writes the
+// zero padding) and then serves all nine taps: a tap is only a different row offset in LDS.
+// Weights stream through a 3-slot LDS ring, one [BN][128 B] tile per (slab, tap) step, two steps
+// ahead of the MFMAs behind a counted `s_waitcnt vmcnt(N)`; one raw s_barrier per step.
+// When the whole [BN][9*Cin] weight matrix fits (Cin = one slab, BN = 64: the memory-bound
+// 64->64 layers) it is loaded once per workgroup and stays resident while the workgroup walks its
+// tiles, and the next tile's halo patch is prefetched during the current tile's 144 MFMAs per wave.
+// LDS rows are 128 bytes; 16-byte chunks are XOR-swizzled with ((row>>1)&7) on the DMA SOURCE
+// address and on the ds_read_b128 address (the LDS image itself stays lane-linear).
+// Epilogue: bias, BatchNorm partial sums of the stored value, then the bf16 tile is transposed
+// through LDS so that every lane stores 16 contiguous bytes of one pixel (full-line writes).
+#include "uz_common.h"
+
+namespace {
+
+struct DirectArgs {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  float* stats;
+  unsigned xbytes, wbytes;
+  int N, H, W, Cin, ldx, Nout, ldy, K;
+  int th_n, tw_n, ntiles;
+};
+
+template <typename T> struct Mma2;
+template <> struct Mma2<bf16_t> {
+  static __device__ __forceinline__ void run(const Vec16<bf16_t>& a, const Vec16<bf16_t>& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma2<float> {
+  static __device__ __forceinline__ void run(const Vec16<float>& a, const Vec16<float>& b, f32x16& c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b.v[t], c, 0, 0, 0);
+  }
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
+  // one wave-instruction: lane i writes LDS bytes [base + 16 i, +16) with the 16 bytes at voff
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor's num_records (tensors < 2 GiB)
+
+template <typename T, int TW, int BN, bool BRES>
+__global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs a) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 8 * VEC;
+  constexpr int TH = 256 / TW, PH = TH + 2, PW = TW + 2, PROWS = PH * PW;
+  constexpr int APIECES = (PROWS + 7) / 8;
+  constexpr int A_BYTES = APIECES * 1024;
+  constexpr int APW = (APIECES + 7) / 8;  // A pieces per wave
+  constexpr int NBP = BN / 64;            // B pieces per wave per step
+  constexpr int B_STAGE = BN * 128;
+  constexpr int B_SLOTS = BRES ? 9 : 3;
+  constexpr int TN = BN / 64;             // 32-wide N tiles per wave (waves: 4 (M) x 2 (N))
+  constexpr int WTN = BN / 2;
+  static_assert(APW <= 9, "A patch pieces must fit the nine tap steps");
+  __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + B_SLOTS * B_STAGE];
+  char* const sB = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
+  T* __restrict__ yg = static_cast<T*>(a.y);
+
+  // ---- DMA pieces --------------------------------------------------------------------------
+  // A piece p = wave + 8 i covers patch rows 8p .. 8p+7; this lane: row 8p + (lane>>3), physical
+  // chunk (lane&7), which must hold logical chunk (lane&7) ^ swz(row).  Everything is recomputed
+  // from i when a piece is issued (a handful of VALU ops) instead of living in registers.
+  unsigned b_row_off[NBP];
+  int b_coff[NBP];
+#pragma unroll
+  for (int i = 0; i < NBP; ++i) {
+    const int n = (wave + 8 * i) * 8 + (lane >> 3);
+    b_row_off[i] = (n0 + n < a.Nout) ? (unsigned)(n0 + n) * (unsigned)a.K * ES : OOB;
+    b_coff[i] = (((lane & 7) ^ ((n >> 1) & 7)) * VEC) * ES;
+  }
+  // ---- per-lane constants of the MFMA fragment reads ----------------------------------------
+  // M tile mt = 2 wm + i: 32 pixels = one patch row (TW 32) or two half rows (TW 16)
+  int f_pi[2], f_pj;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mt = 2 * wm + i;
+    f_pi[i] = (TW == 32) ? mt : 2 * mt + (l31 >> 4);
+  }
+  f_pj = (TW == 32) ? l31 : (l31 & 15);
+  int b_frag_off[TN];
+  int b_sw[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int brow = wn * WTN + j * 32 + l31;
+    b_frag_off[j] = brow * 128;
+    b_sw[j] = (brow >> 1) & 7;
+  }
+
+  const int ncb = a.Cin / BK;
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+
+  int img = 0, h0 = 0, w0 = 0;
+  auto decode = [&](int tile, int& im, int& hh0, int& ww0) {
+    const int per = a.th_n * a.tw_n;
+    im = tile / per;
+    const int rem = tile - im * per;
+    const int ti = rem / a.tw_n;
+    hh0 = ti * TH;
+    ww0 = (rem - ti * a.tw_n) * TW;
+  };
+  auto issue_a_piece = [&](int i, int buf, int cb, int im, int hh0, int ww0) {
+    const int piece = wave + 8 * i;
+    if (piece >= APIECES) return;  // wave-uniform
+    const int r = piece * 8 + (lane >> 3);
+    const int pi = r / PW, pj = r - pi * PW;
+    const int hh = hh0 - 1 + pi, ww = ww0 - 1 + pj;
+    const bool ok = r < PROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+    const int coff = (((lane & 7) ^ ((r >> 1) & 7)) * VEC) * ES;
+    const unsigned off = ok ? ((unsigned)((im * a.H + hh) * a.W + ww) * (unsigned)a.ldx + cb * BK) * ES + coff
+                            : OOB;
+    dma16(xr, smem + buf * A_BYTES + piece * 1024, off);
+  };
+  auto issue_b = [&](int slot, int cb, int tap) {
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+      const unsigned off = b_row_off[i] == OOB ? OOB : b_row_off[i] + (tap * a.Cin + cb * BK) * ES + b_coff[i];
+      dma16(wr, sB + slot * B_STAGE + (wave + 8 * i) * 1024, off);
+    }
+  };
+
+  f32x16 acc[2][TN];
+  auto compute = [&](int tap, int abuf, int bslot) {
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;  // tap in 0..8
+    const char* sA = smem + abuf * A_BYTES;
+    const char* sBs = sB + bslot * B_STAGE;
+    int arow[2], asw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int prow = (f_pi[i] + ty) * PW + f_pj + tx;
+      arow[i] = prow * 128;
+      asw[i] = (prow >> 1) & 7;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lc = 2 * q + lh;
+      Vec16<T> af[2], bf[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const Vec16<T>*>(sA + arow[i] + ((lc ^ asw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const Vec16<T>*>(sBs + b_frag_off[j] + ((lc ^ b_sw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma2<T>::run(af[i], bf[j], acc[i][j]);
+    }
+  };
+
+  if constexpr (BRES) {
+    // resident weights: 9 tap tiles, loaded once
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) issue_b(tap, 0, tap);
+  }
+  int first = blockIdx.x;
+  if (BRES && first < a.ntiles) {
+    decode(first, img, h0, w0);
+#pragma unroll
+    for (int i = 0; i < APW; ++i) issue_a_piece(i, 0, 0, img, h0, w0);
+  }
+
+  int it = 0;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
+    decode(tile, img, h0, w0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int cbuf;  // A buffer that holds the C staging area afterwards
+    if constexpr (BRES) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const int next = tile + gridDim.x;
+      if (next < a.ntiles) {
+        int im2, hh2, ww2;
+        decode(next, im2, hh2, ww2);
+#pragma unroll
+        for (int i = 0; i < APW; ++i) issue_a_piece(i, (it + 1) & 1, 0, im2, hh2, ww2);
+      }
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) compute(tap, it & 1, tap);
+      cbuf = it & 1;
+    } else {
+      const int nsteps = ncb * 9;
+      __builtin_amdgcn_s_barrier();  // previous tile (its C staging reads) is finished everywhere
+#pragma unroll
+      for (int i = 0; i < APW; ++i) issue_a_piece(i, 0, 0, img, h0, w0);
+      issue_b(0, 0, 0);
+      issue_b(1, 0, 1);
+      int tap = 0, cb = 0;    // (slab, tap) of step s
+      int tap2 = 2, cb2 = 0;  // ... of step s + 2
+#pragma unroll 1
+      for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) {
+          wait_vmcnt<NBP>();  // everything but the newest weight tile (step s+1) has landed
+        } else {
+          wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        // next slab's halo patch, one piece per step, issued BEFORE this step's weight tile
+        if (tap < APW && cb + 1 < ncb) issue_a_piece(tap, (cb + 1) & 1, cb + 1, img, h0, w0);
+        if (s + 2 < nsteps) issue_b(tap2 % 3, cb2, tap2);
+        compute(tap, cb & 1, tap % 3);
+        if (++tap == 9) {
+          tap = 0;
+          ++cb;
+        }
+        if (++tap2 == 9) {
+          tap2 = 0;
+          ++cb2;
+        }
+      }
+      cbuf = 0;
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------
+    // bias + statistics from registers
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + l31;
+      bv[j] = (a.bias != nullptr && n < a.Nout) ? a.bias[n] : 0.f;
+    }
+    if constexpr (sizeof(T) == 2) {
+      constexpr int RSC = BN * ES + 16;  // C staging row stride (bytes)
+      static_assert(256 * RSC <= A_BYTES * 2, "C staging must fit the A buffers");
+      __builtin_amdgcn_s_barrier();  // every wave has finished reading A/B of this tile
+      char* sC = smem + ((BRES ? cbuf : 0) * A_BYTES);
+      if (BRES) static_assert(256 * (64 * 2 + 16) <= A_BYTES, "C staging must fit one A buffer");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int mt = 2 * wm + i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * WTN + j * 32 + l31;
+          const bool nok = n0 + col < a.Nout;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside the 32-pixel M tile
+            const T tv = (T)(acc[i][j][r] + bv[j]);
+            *reinterpret_cast<T*>(sC + (mt * 32 + ml) * RSC + col * ES) = tv;
+            // statistics only over pixels inside the image
+            const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
+            const int pj = (TW == 32) ? ml : (ml & 15);
+            if (nok && h0 + pi < a.H && w0 + pj < a.W) {
+              const float fv = (float)tv;
+              s1[j] += fv;
+              s2[j] += fv * fv;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      constexpr int CPR = BN * ES / 16;  // 16-byte chunks per pixel
+      for (int id = tid; id < 256 * CPR; id += 512) {
+        const int m = id / CPR, cc = id - m * CPR;
+        const int mt = m >> 5, ml = m & 31;
+        const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
+        const int pj = (TW == 32) ? ml : (ml & 15);
+        const int hh = h0 + pi, ww = w0 + pj;
+        const int n = n0 + cc * VEC;
+        if (hh < a.H && ww < a.W && n < a.Nout) {
+          const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(sC + m * RSC + cc * 16);
+          st16(yg + ((size_t)(img * a.H + hh) * a.W + ww) * a.ldy + n, v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int mt = 2 * wm + i;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
+            const int pj = (TW == 32) ? ml : (ml & 15);
+            const int hh = h0 + pi, ww = w0 + pj;
+            if (n < a.Nout && hh < a.H && ww < a.W) {
+              const T tv = (T)(acc[i][j][r] + bv[j]);
+              yg[((size_t)(img * a.H + hh) * a.W + ww) * a.ldy + n] = tv;
+              const float fv = (float)tv;
+              s1[j] += fv;
+              s2[j] += fv * fv;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [4][BN][2]
+    if (lh == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + l31;
+        red[(wm * BN + col) * 2 + 0] = s1[j];
+        red[(wm * BN + col) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t1 += red[(k * BN + tid) * 2 + 0];
+        t2 += red[(k * BN + tid) * 2 + 1];
+      }
+      const int n = n0 + tid;
+      if (n < a.Nout) {
+        a.stats[((size_t)blockIdx.x * 2 + 0) * a.Nout + n] = t1;
+        a.stats[((size_t)blockIdx.x * 2 + 1) * a.Nout + n] = t2;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ---- host side ------------------------------------------------------------------------------
+// returns 1 and fills the plan when the direct kernel applies to this descriptor, 0 otherwise
+int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
+  if (d->taps_mode != UZ_TAPS_CONV || d->ntaps != 9 || d->dil != 1 || d->store_mode != UZ_STORE_PLAIN) return 0;
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4, bk = 8 * vec;
+  if (d->Cin % bk != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
+  const long long xbytes = ((long long)d->N * d->H * d->W - 1) * d->ldx * es + (long long)d->Cin * es;
+  const long long wbytes = (long long)d->Nout * 9 * d->Cin * es;
+  if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31)) return 0;
+  p->tw = d->W >= 32 ? 32 : 16;
+  const int th = 256 / p->tw;
+  p->th_n = (d->H + th - 1) / th;
+  p->tw_n = (d->W + p->tw - 1) / p->tw;
+  p->ntiles = d->N * p->th_n * p->tw_n;
+  p->bn = d->Nout <= 64 ? 64 : 128;
+  p->bres = (p->bn == 64 && d->Cin == bk) ? 1 : 0;
+  p->tiles_n = (d->Nout + p->bn - 1) / p->bn;
+  int cap = UZ_NUM_CU / p->tiles_n;
+  if (cap < 1) cap = 1;
+  p->grid_m = p->ntiles < cap ? p->ntiles : cap;
+  return 1;
+}
+
+template <typename T>
+static int direct_launch_t(const UzDirectPlan& p, const DirectArgs& a, hipStream_t s) {
+  dim3 grid(p.grid_m, p.tiles_n), block(512);
+  if (p.bn == 64) {
+    if (p.bres) {
+      if (p.tw == 32) hipLaunchKernelGGL((conv3x3_direct_kernel<T, 32, 64, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv3x3_direct_kernel<T, 16, 64, true>), grid, block, 0, s, a);
+    } else {
+      if (p.tw == 32) hipLaunchKernelGGL((conv3x3_direct_kernel<T, 32, 64, false>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((conv3x3_direct_kernel<T, 16, 64, false>), grid, block, 0, s, a);
+    }
+  } else {
+    if (p.tw == 32) hipLaunchKernelGGL((conv3x3_direct_kernel<T, 32, 128, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_direct_kernel<T, 16, 128, false>), grid, block, 0, s, a);
+  }
+  UZ_LAUNCH_CHECK("uz_conv_igemm(direct3x3)");
+  return UZ_OK;
+}
+
+int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
+                     const float* bias, void* y, float* stats, hipStream_t s) {
+  const int es = d->dtype == UZ_BF16 ? 2 : 4;
+  DirectArgs a;
+  a.x = x;
+  a.w = w;
+  a.y = y;
+  a.bias = bias;
+  a.stats = stats;
+  a.xbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldx * es + (long long)d->Cin * es);
+  a.wbytes = (unsigned)((long long)d->Nout * 9 * d->Cin * es);
+  a.N = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.Cin = d->Cin;
+  a.ldx = d->ldx;
+  a.Nout = d->Nout;
+  a.ldy = d->ldy;
+  a.K = 9 * d->Cin;
+  a.th_n = p.th_n;
+  a.tw_n = p.tw_n;
+  a.ntiles = p.ntiles;
+  return d->dtype == UZ_BF16 ? direct_launch_t<bf16_t>(p, a, s) : direct_launch_t<float>(p, a, s);
+}

@@ -317,6 +317,8 @@ extern "C" int uz_conv_igemm_grid_m(const uz_conv_desc* d) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
+  UzDirectPlan dp;
+  if (uz_direct_plan(d, &dp)) return dp.grid_m;
   return p.grid_m;
 }
 
@@ -326,8 +328,11 @@ extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
   UZ_REQUIRE(x && w_packed && y, "uz_conv_igemm: null pointer");
-  UZ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0,
-             "uz_conv_igemm: x / w must be 16-byte aligned");
+  UZ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 15) == 0,
+             "uz_conv_igemm: x / w / y must be 16-byte aligned");
+  UzDirectPlan dp;
+  if (uz_direct_plan(d, &dp))
+    return uz_direct_launch(d, dp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));
   IgemmArgs a;
   a.x = x;
   a.w = w_packed;
