@@ -44,6 +44,13 @@ def cpu_baseline(batch: int, hw: int, steps: int):
     """Reference step on the host CPU through the oracle (checker code, used here only as the
     reported baseline)."""
     from oracle import torch_ref
+    # the GPU box gives one GPU's job a 16-core share of the host; more threads than that
+    # oversubscribe and run slower (measured: 256 threads 0.05 img/s, 128 threads 0.69 img/s)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))
     torch.manual_seed(0)
     m = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=1)
     sd = m.state_dict()
@@ -63,6 +70,7 @@ def cpu_baseline(batch: int, hw: int, steps: int):
     times = sorted(times[1:])  # drop the warm-up step
     med = times[len(times) // 2]
     return {"value": round(batch / med, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(),
             "kind": "port",
             "sample": f"unet train step on CPU fp32, B={batch} 3x{hw}x{hw}, 1 warm-up + {steps} timed steps, median"}
 
@@ -97,7 +105,7 @@ def main():
     model = model.to(dev).train()
     net = RcclDataParallel(model) if world > 1 else model
     params = list(model.parameters())
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True)
 
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(dev)
@@ -116,7 +124,7 @@ def main():
         if timed:
             e1.record()
             fb_events.append((e0, e1))
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        torch.nn.utils.clip_grad_norm_(params, 1.0, foreach=True)
         opt.step()
         return loss
 

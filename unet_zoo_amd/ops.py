@@ -186,7 +186,14 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         gm = L.check_count(lib.uz_conv_igemm_grid_m(byref(d)), "uz_conv_igemm_grid_m")
         stats = torch.empty((gm, 2, d.Nout), dtype=torch.float32, device=x.buf.device)
     M, K, es = N * H * W, ntaps * x.C, x.buf.element_size()
-    with _Timed(f"igemm_{_tname(x.dtype)}_128x{64 if d.Nout <= 64 else 128}", 2.0 * M * d.Nout * K,
+    bn = 64 if d.Nout <= 64 else 128
+    vec = 16 // es
+    if (taps_mode == L.TAPS_CONV and ntaps == 9 and dil == 1 and store_mode == L.STORE_PLAIN
+            and d.Nout % vec == 0 and y.ld % vec == 0):   # mirrors uz_direct_plan()
+        kname = f"conv3x3_direct_{_tname(x.dtype)}_bn{bn}" + ("_resident" if (bn == 64 and x.C == 8 * vec) else "")
+    else:
+        kname = f"igemm_{_tname(x.dtype)}_128x{bn}"
+    with _Timed(kname, 2.0 * M * d.Nout * K,
                 es * (x.P * x.C + M * d.Nout + d.Nout * K)):
         L.check(lib.uz_conv_igemm(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
                                   L.stream_ptr()), "uz_conv_igemm")
