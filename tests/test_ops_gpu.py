@@ -39,6 +39,8 @@ def bk(dt):
     (1, 16, 16, 128, 192, 1),    # Nout tail inside a 128-wide tile
     (3, 9, 7, 64, 128, 2),       # odd sizes, dilation 2
     (1, 33, 5, 64, 32, 4),       # dilation larger than W
+    (2, 11, 40, 64, 64, 1),      # W >= 32: 8x32 patches, ragged in both directions
+    (1, 40, 72, 128, 256, 1),    # 8x32 patches, two channel slabs, two N tiles
 ])
 def test_conv3x3_fwd_bias_stats(dt, N, H, W, Cin, Cout, dil):
     g = torch.Generator().manual_seed(0)
@@ -75,6 +77,31 @@ def test_conv3x3_dgrad_and_wgrad(dt, N, H, W, Cin, Cout, dil):
     assert relerr(dx.dense().cpu(), x.grad) < tol(dt)
     dw = ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9, dil=dil)
     assert relerr(dw.cpu(), w.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [
+    (2, 16, 64, 64, 64),     # 64x64 channel tile, all nine taps per workgroup, one row per K-step
+    (1, 8, 16, 128, 128),    # 128x128 tile, W=16: four image rows per K-step
+    (1, 4, 32, 256, 128),    # W=32: two rows per K-step, several channel tiles
+    (2, 6, 128, 128, 64),    # W=128: two K-steps per row; Cout=64 -> 64-tiles
+    (3, 2, 64, 64, 192),     # ragged split count
+])
+def test_wgrad3x3_lds_dma_kernel_shapes(dt, N, H, W, Cin, Cout):
+    """shapes the LDS-DMA 3x3 weight-gradient kernel takes in bf16 (fp32 runs the generic one),
+    with both operands living in wider buffers (channel windows)"""
+    g = torch.Generator().manual_seed(9)
+    x = rnd(dt, torch.randn(N, Cin, H, W, generator=g))
+    dy = rnd(dt, torch.randn(N, Cout, H, W, generator=g))
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    P = N * H * W
+    xw = torch.full((P, Cin + 64), 3.0, dtype=dt, device=DEV)
+    xw[:, 64:] = act_from_nchw(x.to(DEV), dt).buf
+    dw_ = torch.full((P, 2 * Cout), -2.0, dtype=dt, device=DEV)
+    dw_[:, :Cout] = act_from_nchw(dy.to(DEV), dt).buf
+    dwg = ops.wgrad(Act(dw_, 0, Cout, N, H, W), Act(xw, 64, Cin, N, H, W), (Cout, Cin, 3, 3), ntaps=9)
+    assert relerr(dwg.cpu(), w.grad) < tol(dt)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -69,3 +69,11 @@ struct UzDirectPlan {
 int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p);
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
                      const float* bias, void* y, float* stats, hipStream_t s);
+
+// 3x3 weight gradient with LDS-DMA pipeline (uz_wgrad3x3.hip), dispatched from uz_wgrad()
+struct UzWgrad2Plan {
+  int big, kw, kr, tiles_i, tiles_j, kg, units, upb, split, nslabs;
+};
+int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
+int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
+                       float* slab, hipStream_t s);

@@ -224,17 +224,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // out[i][j][tap] = sum_z slab[z][tap][i][j]: thread (x, zg) owns element (i,j) = blockIdx.x*64 + x
 // and the splits z = zg, zg+4, ...; reads are contiguous along j, each thread finally writes its
 // element's ntaps values (ntaps*4 contiguous bytes; a wave writes one contiguous span).
-template <int NT>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int split,
-                                                           long long CiCj, float* __restrict__ out) {
-  __shared__ float red[4][64][NT + 1];
+template <int NT, int ZG>
+__global__ __launch_bounds__(64 * ZG) void wgrad_reduce_kernel(const float* __restrict__ slab, int split,
+                                                              long long CiCj, float* __restrict__ out) {
+  __shared__ float red[ZG][64][NT + 1];
   const int x = threadIdx.x & 63, zg = threadIdx.x >> 6;
   const long long e = (long long)blockIdx.x * 64 + x;
   float acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = 0.f;
   if (e < CiCj) {
-    for (int z = zg; z < split; z += 4) {
+    for (int z = zg; z < split; z += ZG) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] += slab[((size_t)z * NT + t) * CiCj + e];
     }
@@ -244,8 +244,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   __syncthreads();
   if (zg == 0 && e < CiCj) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      out[e * NT + t] = red[0][x][t] + red[1][x][t] + red[2][x][t] + red[3][x][t];
+    for (int t = 0; t < NT; ++t) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < ZG; ++k) v += red[k][x][t];
+      out[e * NT + t] = v;
+    }
   }
 }
 
@@ -307,6 +311,8 @@ extern "C" int uz_wgrad_split(const uz_wgrad_desc* d) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
+  UzWgrad2Plan p2;
+  if (uz_wgrad3x3_plan(d, &p2)) return p2.nslabs;
   return p.split;
 }
 
@@ -314,7 +320,9 @@ extern "C" long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
-  return (long long)p.split * d->ntaps * d->Ci * d->Cj * (long long)sizeof(float);
+  UzWgrad2Plan p2;
+  const long long nslabs = uz_wgrad3x3_plan(d, &p2) ? p2.nslabs : p.split;
+  return nslabs * d->ntaps * d->Ci * d->Cj * (long long)sizeof(float);
 }
 
 extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out,
@@ -344,17 +352,28 @@ extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, fl
   a.chunk = p.chunk;
   a.tiles_j = p.tiles_j;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int rc2 = d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
+  UzWgrad2Plan p2;
+  int nslabs = p.split;
+  int rc2;
+  if (uz_wgrad3x3_plan(d, &p2)) {
+    nslabs = p2.nslabs;
+    rc2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s);
+  } else {
+    rc2 = d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
+  }
   if (rc2 != UZ_OK) return rc2;
   const long long cicj = (long long)d->Ci * d->Cj;
-  const dim3 grid((unsigned)((cicj + 63) / 64)), block(256);
+  const dim3 grid((unsigned)((cicj + 63) / 64));
   const float* slab = static_cast<const float*>(workspace);
   if (d->ntaps == 9) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<9>), grid, block, 0, s, slab, p.split, cicj, out);
+    if (nslabs >= 32)
+      hipLaunchKernelGGL((wgrad_reduce_kernel<9, 16>), grid, dim3(1024), 0, s, slab, nslabs, cicj, out);
+    else
+      hipLaunchKernelGGL((wgrad_reduce_kernel<9, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out);
   } else if (d->ntaps == 4) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<4>), grid, block, 0, s, slab, p.split, cicj, out);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out);
   } else {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<1>), grid, block, 0, s, slab, p.split, cicj, out);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<1, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out);
   }
   UZ_LAUNCH_CHECK("uz_wgrad(reduce)");
   return UZ_OK;

@@ -1,0 +1,278 @@
+// Weight gradient of a 3x3 convolution (stride 1, dilation 1), bf16, for gfx950 (MI355X):
+//     dW[co][ci][ty][tx] = sum_p dy[p][co] * x[p + (ty-1, tx-1)][ci]
+// (autograd weight-gradient of nn.Conv2d k3 p1: reference unet_zoo/models/common_layers.py:28,31,
+// entered from loss.backward(), unet_zoo/utils/training_loop.py:119).
+//
+// The reduction index is the pixel.  A K-step is 64 pixels of one image (one 64-pixel row
+// segment, or 64/W whole rows when W is 16 or 32), so every 16-pixel MFMA sub-step lies inside
+// one image row and a tap is a constant row offset in the LDS image of x:
+//   L tile (dy):  64 pixels x BI channels
+//   R tile (x) :  the same pixels plus a one-pixel halo left/right (and, when the workgroup owns
+//                 all nine taps, one row above/below), out-of-image pixels zero-filled by the
+//                 buffer descriptor's range check
+// both brought in by LDS-DMA (buffer_load ... lds) through a 3-stage ring, two K-steps ahead of
+// the MFMAs behind a counted s_waitcnt vmcnt, one raw s_barrier per K-step.  One R tile serves
+// three (config A: 128x128 channel tile, one kernel row per workgroup) or nine taps (config D:
+// 64x64 channel tile) of MFMAs, so LDS-fill traffic per MFMA is 3-9x lower than one tap per load.
+// Tiles are pixel-major [pixel][channel]; fragments come through ds_read_b64_tr_b16 (hardware
+// transpose).  64-byte granules of a row are XOR-swizzled with the pixel index (on the DMA
+// source address and on the read address) so the four pixel rows of a transposed read fall into
+// distinct banks for any tap shift.
+// Each (split, k-group) writes a coalesced fp32 slab [tap][Ci][Cj]; uz_wgrad's reduce kernel sums
+// the slabs in fixed order and transposes to OIHW.
+#include "uz_common.h"
+
+namespace {
+
+struct Wg2Args {
+  const void* L;
+  const void* R;
+  float* slab;
+  unsigned lbytes, rbytes;
+  int N, H, W, Ci, ldl, Cj, ldr;
+  int KW, kw_log2, KR;  // K-step = KR rows x KW columns = 64 pixels
+  int units;            // K-steps in the whole tensor
+  int upb;              // K-steps per split
+  int tiles_j;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+constexpr unsigned OOB = 0x80000000u;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BI x BJ channel tile, NTY kernel rows per workgroup (1 -> blockIdx.y selects the row; 3 -> all),
+// 8 waves = WI x WJ x KG (KG k-groups split the four 16-pixel sub-steps of a K-step)
+template <int BI, int BJ, int NTY, int WI, int WJ, int KG>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
+  static_assert(WI * WJ * KG == 8, "8 waves");
+  constexpr int RBL = BI * 2, RBR = BJ * 2;             // bytes per pixel row
+  constexpr int CPRL = RBL / 16, CPRR = RBR / 16;       // 16-byte chunks per row
+  constexpr int RPPL = 1024 / RBL, RPPR = 1024 / RBR;   // pixel rows per 1 KiB DMA piece
+  constexpr int NLP = 64 / RPPL;                        // L pieces per stage
+  constexpr int RPX = (NTY == 1) ? 72 : 200;            // R tile capacity in pixels
+  constexpr int NRP = RPX / RPPR;
+  constexpr int PPW = 5;                                // pieces per wave per stage (40 slots)
+  static_assert(NLP + NRP <= 8 * PPW, "stage layout");
+  constexpr int STAGE = 8 * PPW * 1024;
+  constexpr int WTI = BI / WI, WTJ = BJ / WJ, TI = WTI / 32, TJ = WTJ / 32;
+  constexpr int NTAP = 3 * NTY;
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave / (WI * WJ), wij = wave % (WI * WJ);
+  const int wi = wij / WJ, wj = wij % WJ;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ti0 = (blockIdx.x / a.tiles_j) * BI, tj0 = (blockIdx.x % a.tiles_j) * BJ;
+  const int ty_blk = (NTY == 1) ? blockIdx.y : 0;
+  const int u_beg = blockIdx.z * a.upb;
+  const int u_end = (u_beg + a.upb < a.units) ? u_beg + a.upb : a.units;
+  const int nu = u_end - u_beg;
+  const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.L), 0, a.lbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.R), 0, a.rbytes, 0x00020000);
+
+  const int KW = a.KW, PWR = KW + 2;               // R tile row length in pixels
+  const int RR = a.KR + ((NTY == 3) ? 2 : 0);      // R tile rows
+  const int roff = (NTY == 3) ? -1 : ty_blk - 1;   // image row of R tile row 0, relative to h
+
+  // ---- per-lane constants of this wave's five DMA pieces ---------------------------------------
+  int p_rrel[PPW], p_crel[PPW], p_delta[PPW], p_coff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int q = wave + 8 * i;
+    if (q < NLP) {
+      const int k = q * RPPL + lane / CPRL, pc = lane % CPRL;
+      const int r = k >> a.kw_log2, c = k & (KW - 1);
+      const int sw = (CPRL == 16) ? (k & 3) : ((k >> 1) & 1);
+      p_rrel[i] = r;
+      p_crel[i] = c;
+      p_delta[i] = r * a.W + c;
+      p_coff[i] = (ti0 * 2) + ((((pc >> 2) ^ sw) << 2) + (pc & 3)) * 16;
+    } else if (q < NLP + NRP) {
+      const int t = (q - NLP) * RPPR + lane / CPRR, pc = lane % CPRR;
+      const int trow = t / PWR, tcol = t - trow * PWR;
+      const int sw = (CPRR == 16) ? (t & 3) : ((t >> 1) & 1);
+      p_rrel[i] = (trow < RR) ? trow + roff : -(1 << 20);
+      p_crel[i] = tcol - 1;
+      p_delta[i] = (trow + roff) * a.W + tcol - 1;
+      p_coff[i] = (tj0 * 2) + ((((pc >> 2) ^ sw) << 2) + (pc & 3)) * 16;
+    } else {
+      p_rrel[i] = -(1 << 20);
+      p_crel[i] = 0;
+      p_delta[i] = 0;
+      p_coff[i] = 0;
+    }
+  }
+
+  const int upi = (a.H * a.W) >> 6;  // K-steps per image
+  const int upr = a.W / KW;          // K-steps per row block (1 unless W > 64)
+  auto issue = [&](int stage, int u) {
+    const int img = u / upi;
+    const int rem = u - img * upi;
+    const int rb = rem / upr;
+    const int h = rb * a.KR, w0 = (rem - rb * upr) * KW;
+    const int base = (img * a.H + h) * a.W + w0;
+    char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int q = wave + 8 * i;
+      const bool ok = (unsigned)(h + p_rrel[i]) < (unsigned)a.H && (unsigned)(w0 + p_crel[i]) < (unsigned)a.W;
+      const unsigned pix = (unsigned)(base + p_delta[i]);
+      if (q < NLP) {
+        const unsigned off = ok ? pix * (unsigned)(a.ldl * 2) + p_coff[i] : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
+      } else {
+        const unsigned off = ok ? pix * (unsigned)(a.ldr * 2) + p_coff[i] : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ][NTAP];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][t][r] = 0.f;
+
+  // transposed-read lane roles: 16-lane group g, pixel row q4 and column quad p4 inside the 4x16 block
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int lk = 8 * (g >> 1) + q4;           // pixel row of this lane inside a 16-pixel sub-step
+  const int lcol = 16 * (g & 1) + 4 * p4;     // channel inside a 32-channel MFMA tile
+
+  auto frag = [&](const char* tile, int row, int col, int rowbytes, bool four_granules) -> bf16x8 {
+    const int sw = four_granules ? (row & 3) : ((row >> 1) & 1);
+    const char* p = tile + row * rowbytes + ((((col >> 5) ^ sw)) << 6) + (col & 31) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 4 * rowbytes));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  auto compute = [&](int stage) {
+    const char* sL = smem + stage * STAGE;
+    const char* sR = sL + NLP * 1024;
+#pragma unroll 1
+    for (int ks = kg; ks < 4; ks += KG) {
+      const int k0 = ks * 16;
+      const int r = k0 >> a.kw_log2, c0 = k0 & (KW - 1);
+      bf16x8 af[TI];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) af[i] = frag(sL, k0 + lk, wi * WTI + i * 32 + lcol, RBL, CPRL == 16);
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const int tyo = (NTY == 3) ? t / 3 : 0, tx = t % 3;
+        const int t0 = (r + tyo) * PWR + c0 + tx;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const bf16x8 bfr = frag(sR, t0 + lk, wj * WTJ + j * 32 + lcol, RBR, CPRR == 16);
+#pragma unroll
+          for (int i = 0; i < TI; ++i)
+            acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i][j][t], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  if (nu > 0) issue(0, u_beg);
+  if (nu > 1) issue(1, u_beg + 1);
+#pragma unroll 1
+  for (int s = 0; s < nu; ++s) {
+    if (s + 1 < nu) {
+      wait_vmcnt<PPW>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < nu) issue((s + 2) % 3, u_beg + s + 2);
+    compute(s % 3);
+  }
+
+  // ---- partial slab [split*KG + kg][tap][Ci][Cj] ----------------------------------------------
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const int tap = (NTY == 3) ? t : ty_blk * 3 + t;
+    float* slab = a.slab + (((size_t)blockIdx.z * KG + kg) * 9 + tap) * (size_t)a.Ci * a.Cj;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int cj = tj0 + wj * WTJ + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = ti0 + wi * WTI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[(size_t)ci * a.Cj + cj] = acc[i][j][t][r];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
+  if (d->dtype != UZ_BF16 || d->taps_mode != UZ_TAPS_CONV || d->ntaps != 9 || d->dil != 1) return 0;
+  if (d->Ci % 64 != 0 || d->Cj % 64 != 0) return 0;
+  const int W = d->W, H = d->H;
+  if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return 0;
+  p->kw = W < 64 ? W : 64;
+  p->kr = 64 / p->kw;
+  if (H % p->kr != 0) return 0;
+  const long long lbytes = ((long long)d->N * H * W - 1) * d->ldl * 2 + (long long)d->Ci * 2;
+  const long long rbytes = ((long long)d->N * H * W - 1) * d->ldr * 2 + (long long)d->Cj * 2;
+  if (lbytes >= (1LL << 31) || rbytes >= (1LL << 31)) return 0;
+  p->big = (d->Ci % 128 == 0 && d->Cj % 128 == 0) ? 1 : 0;
+  const int b = p->big ? 128 : 64;
+  p->tiles_i = d->Ci / b;
+  p->tiles_j = d->Cj / b;
+  p->kg = p->big ? 1 : 2;
+  p->units = (int)((long long)d->N * H * W / 64);
+  const long long base = (long long)p->tiles_i * p->tiles_j * (p->big ? 3 : 1);
+  long long split = (2 * UZ_NUM_CU + base - 1) / base;
+  long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
+  if (max_split > 128) max_split = 128;
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  p->upb = (int)((p->units + split - 1) / split);
+  p->split = (p->units + p->upb - 1) / p->upb;
+  p->nslabs = p->split * p->kg;
+  return 1;
+}
+
+int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
+                       float* slab, hipStream_t s) {
+  Wg2Args a;
+  a.L = L;
+  a.R = R;
+  a.slab = slab;
+  a.lbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldl * 2 + (long long)d->Ci * 2);
+  a.rbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldr * 2 + (long long)d->Cj * 2);
+  a.N = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.Ci = d->Ci;
+  a.ldl = d->ldl;
+  a.Cj = d->Cj;
+  a.ldr = d->ldr;
+  a.KW = p.kw;
+  a.kw_log2 = p.kw == 64 ? 6 : (p.kw == 32 ? 5 : 4);
+  a.KR = p.kr;
+  a.units = p.units;
+  a.upb = p.upb;
+  a.tiles_j = p.tiles_j;
+  if (p.big) {
+    dim3 grid(p.tiles_i * p.tiles_j, 3, p.split), block(512);
+    hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 2, 4, 1>), grid, block, 0, s, a);
+  } else {
+    dim3 grid(p.tiles_i * p.tiles_j, 1, p.split), block(512);
+    hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 2, 2, 2>), grid, block, 0, s, a);
+  }
+  UZ_LAUNCH_CHECK("uz_wgrad(3x3)");
+  return UZ_OK;
+}

@@ -212,7 +212,14 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     out = torch.empty(out_shape, dtype=torch.float32, device=Lt.buf.device)
     assert out.numel() == Lt.C * Rt.C * ntaps
     tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
-    with _Timed(f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}", 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
+    kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
+    W_ = Lt.W
+    if (Lt.dtype == torch.bfloat16 and taps_mode == L.TAPS_CONV and ntaps == 9 and dil == 1
+            and Lt.C % 64 == 0 and Rt.C % 64 == 0 and (W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0))
+            and Lt.H % (64 // min(W_, 64)) == 0):   # mirrors uz_wgrad3x3_plan()
+        big = Lt.C % 128 == 0 and Rt.C % 128 == 0
+        kname = "wgrad3x3_bf16_" + ("128x128_3tap" if big else "64x64_9tap")
+    with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
         L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
                              L.stream_ptr()), "uz_wgrad")
