@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole step from one hipGraph (auto: try, fall back to eager)")
+    ap.add_argument("--profile-steps", type=int, default=5,
+                    help="eager steps with per-launch HIP events, run after the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +109,8 @@ def main():
     model = model.to(dev).train()
     net = RcclDataParallel(model) if world > 1 else model
     params = list(model.parameters())
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True)
+    use_graph = args.graph != "off"
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
 
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(dev)
@@ -128,29 +133,65 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
-        step(False)
-    ops.profile_begin()  # HIP events around every matrix-core launch of the timed steps
+    # warm-up (eager, on a side stream so that a graph can be captured afterwards)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(args.warmup, 1)):
+            loss = step(False)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    graph = None
+    launch_mode = "eager"
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step(False)
+            graph.replay()            # one untimed replay
+            torch.cuda.synchronize()
+            launch_mode = "hipGraph"
+        except Exception as e:  # noqa: BLE001
+            if args.graph == "on":
+                raise
+            graph = None
+            torch.cuda.synchronize()
+            if rank == 0:
+                print(f"# hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches",
+                      file=sys.stderr, flush=True)
+
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(True)
+    if graph is not None:
+        for _ in range(args.steps):
+            graph.replay()
+        loss = static_loss
+    else:
+        for _ in range(args.steps):
+            loss = step(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = ops.profile_end()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # per-launch HIP events (same process, same shapes, eager launches right after the timed steps)
+    ops.profile_begin()
+    for _ in range(args.profile_steps):
+        step(True)
+    prof = ops.profile_end()
+    nprof = max(args.profile_steps, 1)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
-        fb_ms = sorted(a.elapsed_time(b) for a, b in fb_events)[len(fb_events) // 2]
+        fb_ms = sorted(a.elapsed_time(b) for a, b in fb_events)[len(fb_events) // 2] if fb_events else float("nan")
         # dominant kernel = the family with the largest summed duration
         dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
         roofline = None
@@ -161,10 +202,10 @@ def main():
             peak = PEAK["mfma_bf16_tflops"] if run_dtype == torch.bfloat16 else PEAK["mfma_f32_tflops"]
             roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                        "launches_per_step": dom["launches"] // args.steps,
+                        "launches_per_step": dom["launches"] // nprof,
                         "avg_launch_us": round(sec_per_launch * 1e6, 2),
                         "algorithmic_gbytes_per_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
-                        "share_of_step": round(dom["ms"] / args.steps / ms, 4)}
+                        "share_of_step": round(dom["ms"] / nprof / ms, 4)}
         line = {
             "metric": "images/sec (fwd+bwd) at B=16 3x256x256, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -177,7 +218,8 @@ def main():
             "fwd_bwd_images_per_s": round(args.batch * world / (fb_ms * 1e-3), 2),
             "loss": round(loss.item(), 5),
             "roofline": roofline,
-            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+            "launch": launch_mode,
+            "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps)
