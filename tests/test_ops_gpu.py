@@ -105,6 +105,18 @@ def test_wgrad3x3_lds_dma_kernel_shapes(dt, N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Ci,Cj", [(2, 8, 64, 64, 64), (1, 16, 16, 128, 128), (1, 6, 10, 64, 64)])
+def test_wgrad_one_tap(dt, N, H, W, Ci, Cj):
+    """ntaps = 1 (1x1 convolution / the im2col'd first layer): out[i][j] = sum_p L[p,i] R[p,j]"""
+    g = torch.Generator().manual_seed(10)
+    a = rnd(dt, torch.randn(N, Ci, H, W, generator=g))
+    b = rnd(dt, torch.randn(N, Cj, H, W, generator=g))
+    ref = torch.einsum("nihw,njhw->ij", a.double(), b.double()).float()
+    got = ops.wgrad(act_from_nchw(a.to(DEV), dt), act_from_nchw(b.to(DEV), dt), (Ci, Cj), ntaps=1)
+    assert relerr(got.cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_wgrad_split_k_large_pixel_count(dt):
     """many pixels, few channels: the split-K / atomic path"""
     g = torch.Generator().manual_seed(2)

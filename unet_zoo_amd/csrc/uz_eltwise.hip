@@ -522,23 +522,31 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, int C
 template <typename T>
 __global__ void im2col3x3_kernel(const float* __restrict__ x, int N, int C, int H, int W, int Kpad,
                                  T* __restrict__ dst, long long total) {
-  // one thread per destination element; consecutive threads = consecutive k of one pixel
+  // one thread per 16-byte destination chunk; consecutive threads = consecutive chunks of a pixel
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = Kpad / VEC;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % Kpad);
-    const long long p = idx / Kpad;
-    float v = 0.f;
-    if (k < 9 * C) {
-      const int t = k / C, c = k - t * C;
-      const int w0 = (int)(p % W);
-      const long long q = p / W;
-      const int h0 = (int)(q % H);
-      const int img = (int)(q / H);
-      const int hh = h0 + t / 3 - 1, ww = w0 + t % 3 - 1;
-      if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
-        v = x[(((size_t)img * C + c) * H + hh) * W + ww];
+    const int ch = (int)(idx % cpr);
+    const long long p = idx / cpr;
+    const int w0 = (int)(p % W);
+    const long long q = p / W;
+    const int h0 = (int)(q % H);
+    const int img = (int)(q / H);
+    Vec16<T> v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int k = ch * VEC + e;
+      float f = 0.f;
+      if (k < 9 * C) {
+        const int t = k / C, c = k - t * C;
+        const int hh = h0 + t / 3 - 1, ww = w0 + t % 3 - 1;
+        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+          f = x[(((size_t)img * C + c) * H + hh) * W + ww];
+      }
+      v.v[e] = (T)f;
     }
-    dst[idx] = (T)v;
+    st16(dst + (size_t)p * Kpad + ch * VEC, v);
   }
 }
 
@@ -826,7 +834,9 @@ extern "C" int uz_im2col3x3_nchw(int dtype, const float* x_nchw, int N, int C, i
                                  void* dst, void* stream) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_im2col3x3_nchw: bad dtype");
   UZ_REQUIRE(x_nchw && dst && N > 0 && C > 0 && H > 0 && W > 0 && Kpad >= 9 * C, "uz_im2col3x3_nchw: bad args");
-  const long long total = (long long)N * H * W * Kpad;
+  const int vec_ = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(Kpad % vec_ == 0, "uz_im2col3x3_nchw: Kpad must be a multiple of %d", vec_);
+  const long long total = (long long)N * H * W * (Kpad / vec_);
   hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for(total, 256);
   if (dtype == UZ_BF16)

@@ -46,9 +46,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // BI x BJ channel tile, NTY kernel rows per workgroup (1 -> blockIdx.y selects the row; 3 -> all),
 // 8 waves = WI x WJ x KG (KG k-groups split the four 16-pixel sub-steps of a K-step)
-template <int BI, int BJ, int NTY, int WI, int WJ, int KG>
+template <int BI, int BJ, int NTY, int NTX, int WI, int WJ, int KG>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   static_assert(WI * WJ * KG == 8, "8 waves");
+  static_assert((NTX == 3) || (NTX == 1 && NTY == 1), "1 tap or 3/9 taps");
+  constexpr int HALO = (NTX == 3) ? 1 : 0;
   constexpr int RBL = BI * 2, RBR = BJ * 2;             // bytes per pixel row
   constexpr int CPRL = RBL / 16, CPRR = RBR / 16;       // 16-byte chunks per row
   constexpr int RPPL = 1024 / RBL, RPPR = 1024 / RBR;   // pixel rows per 1 KiB DMA piece
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   static_assert(NLP + NRP <= 8 * PPW, "stage layout");
   constexpr int STAGE = 8 * PPW * 1024;
   constexpr int WTI = BI / WI, WTJ = BJ / WJ, TI = WTI / 32, TJ = WTJ / 32;
-  constexpr int NTAP = 3 * NTY;
+  constexpr int NTAP = NTX * NTY;
   __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -68,16 +70,16 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   const int wi = wij / WJ, wj = wij % WJ;
   const int l31 = lane & 31, lh = lane >> 5;
   const int ti0 = (blockIdx.x / a.tiles_j) * BI, tj0 = (blockIdx.x % a.tiles_j) * BJ;
-  const int ty_blk = (NTY == 1) ? blockIdx.y : 0;
+  const int ty_blk = (NTY == 1 && NTX == 3) ? blockIdx.y : 0;
   const int u_beg = blockIdx.z * a.upb;
   const int u_end = (u_beg + a.upb < a.units) ? u_beg + a.upb : a.units;
   const int nu = u_end - u_beg;
   const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.L), 0, a.lbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.R), 0, a.rbytes, 0x00020000);
 
-  const int KW = a.KW, PWR = KW + 2;               // R tile row length in pixels
+  const int KW = a.KW, PWR = KW + 2 * HALO;        // R tile row length in pixels
   const int RR = a.KR + ((NTY == 3) ? 2 : 0);      // R tile rows
-  const int roff = (NTY == 3) ? -1 : ty_blk - 1;   // image row of R tile row 0, relative to h
+  const int roff = (NTX == 1) ? 0 : ((NTY == 3) ? -1 : ty_blk - 1);  // image row of R tile row 0 - h
 
   // ---- per-lane constants of this wave's five DMA pieces ---------------------------------------
   int p_rrel[PPW], p_crel[PPW], p_delta[PPW], p_coff[PPW];
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
       const int trow = t / PWR, tcol = t - trow * PWR;
       const int sw = (CPRR == 16) ? (t & 3) : ((t >> 1) & 1);
       p_rrel[i] = (trow < RR) ? trow + roff : -(1 << 20);
-      p_crel[i] = tcol - 1;
-      p_delta[i] = (trow + roff) * a.W + tcol - 1;
+      p_crel[i] = tcol - HALO;
+      p_delta[i] = (trow + roff) * a.W + tcol - HALO;
       p_coff[i] = (tj0 * 2) + ((((pc >> 2) ^ sw) << 2) + (pc & 3)) * 16;
     } else {
       p_rrel[i] = -(1 << 20);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
       for (int i = 0; i < TI; ++i) af[i] = frag(sL, k0 + lk, wi * WTI + i * 32 + lcol, RBL, CPRL == 16);
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) {
-        const int tyo = (NTY == 3) ? t / 3 : 0, tx = t % 3;
+        const int tyo = (NTY == 3) ? t / 3 : 0, tx = (NTX == 3) ? t % 3 : 0;
         const int t0 = (r + tyo) * PWR + c0 + tx;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
     const int tap = (NTY == 3) ? t : ty_blk * 3 + t;
-    float* slab = a.slab + (((size_t)blockIdx.z * KG + kg) * 9 + tap) * (size_t)a.Ci * a.Cj;
+    float* slab = a.slab + (((size_t)blockIdx.z * KG + kg) * (NTX == 1 ? 1 : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -217,7 +219,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 }  // namespace
 
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
-  if (d->dtype != UZ_BF16 || d->taps_mode != UZ_TAPS_CONV || d->ntaps != 9 || d->dil != 1) return 0;
+  if (d->dtype != UZ_BF16 || d->taps_mode != UZ_TAPS_CONV) return 0;
+  if (!((d->ntaps == 9 && d->dil == 1) || d->ntaps == 1)) return 0;
+  p->one_tap = d->ntaps == 1;
   if (d->Ci % 64 != 0 || d->Cj % 64 != 0) return 0;
   const int W = d->W, H = d->H;
   if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return 0;
@@ -233,7 +237,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   p->tiles_j = d->Cj / b;
   p->kg = p->big ? 1 : 2;
   p->units = (int)((long long)d->N * H * W / 64);
-  const long long base = (long long)p->tiles_i * p->tiles_j * (p->big ? 3 : 1);
+  const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : 1);
   long long split = (2 * UZ_NUM_CU + base - 1) / base;
   long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
   if (max_split > 128) max_split = 128;
@@ -266,12 +270,17 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.units = p.units;
   a.upb = p.upb;
   a.tiles_j = p.tiles_j;
-  if (p.big) {
-    dim3 grid(p.tiles_i * p.tiles_j, 3, p.split), block(512);
-    hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 2, 4, 1>), grid, block, 0, s, a);
+  dim3 block(512);
+  if (p.one_tap) {
+    dim3 grid(p.tiles_i * p.tiles_j, 1, p.split);
+    if (p.big) hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 1, 2, 4, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 1, 1, 2, 2, 2>), grid, block, 0, s, a);
+  } else if (p.big) {
+    dim3 grid(p.tiles_i * p.tiles_j, 3, p.split);
+    hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>), grid, block, 0, s, a);
   } else {
-    dim3 grid(p.tiles_i * p.tiles_j, 1, p.split), block(512);
-    hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 2, 2, 2>), grid, block, 0, s, a);
+    dim3 grid(p.tiles_i * p.tiles_j, 1, p.split);
+    hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 3, 2, 2, 2>), grid, block, 0, s, a);
   }
   UZ_LAUNCH_CHECK("uz_wgrad(3x3)");
   return UZ_OK;

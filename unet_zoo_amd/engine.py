@@ -144,10 +144,11 @@ class Engine:
                 if g0 is None and gp is None:
                     return  # nothing downstream used this activation
                 dy = self.new_act(N, H, W, Cout)
-                dgb = torch.empty((2, Cout), dtype=torch.float32, device=self.device)
-                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgb[0], dgb[1])
-                self._give_grad(bn.weight, dgb[0])
-                self._give_grad(bn.bias, dgb[1])
+                dgamma = torch.empty(Cout, dtype=torch.float32, device=self.device)
+                dbeta = torch.empty(Cout, dtype=torch.float32, device=self.device)
+                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta)
+                self._give_grad(bn.weight, dgamma)
+                self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:
                     # d(bias) = sum_p dy == 0 analytically under train-mode BN (the batch mean
                     # removes any per-channel constant); the reference's value is rounding noise.
@@ -162,8 +163,13 @@ class Engine:
                                     ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=9, dil=dil))
                     if x.needs_grad:
                         dx = self.new_act(N, H, W, x.C)
-                        ops.conv_igemm(dy, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx,
-                                       ntaps=9, dil=dil)
+                        # per-channel sums of dx come for free from the kernel's statistics
+                        # epilogue; a ConvTranspose2d feeding x takes its bias gradient from them
+                        want = x.parts is not None
+                        part = ops.conv_igemm(dy, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx,
+                                              ntaps=9, dil=dil, want_stats=want)
+                        if want:
+                            dx.colsums = (part, 0)
                         x.add_grad(dx)
 
             self.tape.append(bwd)
@@ -183,7 +189,8 @@ class Engine:
             def bwd():
                 g = self._sum_grads(out, 1)[0]
                 if m.bias is not None:
-                    self._give_grad(m.bias, ops.colsum(g))
+                    cs = g.channel_sums()
+                    self._give_grad(m.bias, cs if cs is not None else ops.colsum(g))
                 self._give_grad(m.weight, ops.wgrad(x, g, tuple(m.weight.shape), ntaps=4,
                                                     taps_mode=L.TAPS_GATHER2X2))
                 if x.needs_grad:

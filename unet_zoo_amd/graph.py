@@ -58,6 +58,8 @@ class _GraphFn(torch.autograd.Function):
         out = []
         for i, p in enumerate(ctx.plist):
             out.append(grads.get(p) if ctx.needs_input_grad[4 + i] else None)
+        # drop every other reference so autograd can adopt the tensors as .grad without copying
+        grads.clear()
         return (None, None, None, None, *out)
 
 

@@ -16,7 +16,7 @@ from . import _lib as L
 class Act:
     """NHWC activation: element (pixel p, channel c) at ``buf[p, off + c]``; ``buf`` is (P, ld)."""
 
-    __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "needs_grad")
+    __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "needs_grad", "colsums")
 
     def __init__(self, buf: torch.Tensor, off: int, C: int, N: int, H: int, W: int,
                  needs_grad: bool = True):
@@ -26,6 +26,9 @@ class Act:
         self.grads: List["Act"] = []        # gradient contributions (same resolution as self)
         self.parts: Optional[Sequence["Act"]] = None  # set on the full view of a concat buffer
         self.needs_grad = needs_grad
+        # optional (partials [G, 2, Ctot], channel offset): per-channel sums of this tensor that its
+        # producing kernel delivered for free (used for ConvTranspose2d bias gradients)
+        self.colsums = None
 
     @property
     def ld(self) -> int:
@@ -43,7 +46,17 @@ class Act:
         return self.buf.data_ptr() + self.off * self.buf.element_size()
 
     def window(self, off: int, C: int) -> "Act":
-        return Act(self.buf, self.off + off, C, self.N, self.H, self.W, self.needs_grad)
+        w = Act(self.buf, self.off + off, C, self.N, self.H, self.W, self.needs_grad)
+        if self.colsums is not None:
+            w.colsums = (self.colsums[0], self.colsums[1] + off)
+        return w
+
+    def channel_sums(self) -> Optional[torch.Tensor]:
+        """sum over pixels per channel (fp32) if the producer recorded partial sums, else None"""
+        if self.colsums is None:
+            return None
+        part, o = self.colsums
+        return part[:, 0, o:o + self.C].sum(0)
 
     def add_grad(self, g: "Act") -> None:
         """Register a gradient contribution; a concat view forwards channel windows to its parts."""
@@ -214,11 +227,11 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
     kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
     W_ = Lt.W
-    if (Lt.dtype == torch.bfloat16 and taps_mode == L.TAPS_CONV and ntaps == 9 and dil == 1
+    if (Lt.dtype == torch.bfloat16 and taps_mode == L.TAPS_CONV and ((ntaps == 9 and dil == 1) or ntaps == 1)
             and Lt.C % 64 == 0 and Rt.C % 64 == 0 and (W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0))
             and Lt.H % (64 // min(W_, 64)) == 0):   # mirrors uz_wgrad3x3_plan()
         big = Lt.C % 128 == 0 and Rt.C % 128 == 0
-        kname = "wgrad3x3_bf16_" + ("128x128_3tap" if big else "64x64_9tap")
+        kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + ("_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
     with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
         L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
