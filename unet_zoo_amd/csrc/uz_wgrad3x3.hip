@@ -44,11 +44,25 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Transposed LDS reads are issued from inline asm: for the ds_read_tr builtin hipcc (ROCm 7.2)
+// inserts `s_waitcnt vmcnt(0)` before every read while LDS-DMA is in flight, which serialises the
+// whole pipeline; asm reads are invisible to that pass, their lgkmcnt is counted by hand below.
+template <int OFF>
+__device__ __forceinline__ void tr_pair(bf16x4& lo, bf16x4& hi, unsigned lds_addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+               : "=&v"(lo), "=&v"(hi)
+               : "v"(lds_addr), "i"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pin(bf16x4& v) { asm volatile("" : "+v"(v)); }
+
 // BI x BJ channel tile, NTY kernel rows per workgroup (1 -> blockIdx.y selects the row; 3 -> all),
-// 8 waves = WI x WJ x KG (KG k-groups split the four 16-pixel sub-steps of a K-step)
-template <int BI, int BJ, int NTY, int NTX, int WI, int WJ, int KG>
+// 8 waves = WI x WJ x TG (TG tap groups share the NTX*NTY taps of the workgroup)
+template <int BI, int BJ, int NTY, int NTX, int WI, int WJ, int TG>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
-  static_assert(WI * WJ * KG == 8, "8 waves");
+  static_assert(WI * WJ * TG == 8, "8 waves");
   static_assert((NTX == 3) || (NTX == 1 && NTY == 1), "1 tap or 3/9 taps");
   constexpr int HALO = (NTX == 3) ? 1 : 0;
   constexpr int RBL = BI * 2, RBR = BJ * 2;             // bytes per pixel row
@@ -61,12 +75,14 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   static_assert(NLP + NRP <= 8 * PPW, "stage layout");
   constexpr int STAGE = 8 * PPW * 1024;
   constexpr int WTI = BI / WI, WTJ = BJ / WJ, TI = WTI / 32, TJ = WTJ / 32;
-  constexpr int NTAP = NTX * NTY;
+  constexpr int NTAP = NTX * NTY;               // taps of the workgroup
+  constexpr int NTW = (NTAP + TG - 1) / TG;     // taps per wave
+  static_assert(TJ == 1, "one 32-channel R tile per wave");
   __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave / (WI * WJ), wij = wave % (WI * WJ);
+  const int tg = wave / (WI * WJ), wij = wave % (WI * WJ);
   const int wi = wij / WJ, wj = wij % WJ;
   const int l31 = lane & 31, lh = lane >> 5;
   const int ti0 = (blockIdx.x / a.tiles_j) * BI, tj0 = (blockIdx.x % a.tiles_j) * BJ;
@@ -134,49 +150,71 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
     }
   };
 
-  f32x16 acc[TI][TJ][NTAP];
+  f32x16 acc[TI][NTW];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-      for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
   // transposed-read lane roles: 16-lane group g, pixel row q4 and column quad p4 inside the 4x16 block
   const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
   const int lk = 8 * (g >> 1) + q4;           // pixel row of this lane inside a 16-pixel sub-step
   const int lcol = 16 * (g & 1) + 4 * p4;     // channel inside a 32-channel MFMA tile
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const unsigned smem_u = (unsigned)(size_t)(lds_char_ptr)smem;
 
-  auto frag = [&](const char* tile, int row, int col, int rowbytes, bool four_granules) -> bf16x8 {
+  // byte address of this lane's transposed-read block: pixel row `row`, channel `col`
+  auto tr_addr = [&](unsigned tile, int row, int col, int rowbytes, bool four_granules) -> unsigned {
     const int sw = four_granules ? (row & 3) : ((row >> 1) & 1);
-    const char* p = tile + row * rowbytes + ((((col >> 5) ^ sw)) << 6) + (col & 31) * 2;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 4 * rowbytes));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return tile + row * rowbytes + ((((col >> 5) ^ sw)) << 6) + (col & 31) * 2;
+  };
+  // (row offset, column shift) of the wave's tt-th tap inside the R tile
+  auto tap_shift = [&](int tt, int r, int c0) -> int {
+    const int tap = tg * NTW + tt;
+    const int tyo = (NTY == 3) ? (tap * 11) >> 5 : 0;          // tap / 3 for tap in 0..8
+    const int tx = (NTX == 3) ? tap - 3 * ((tap * 11) >> 5) : 0;
+    return (r + tyo) * PWR + c0 + tx;
   };
 
   auto compute = [&](int stage) {
-    const char* sL = smem + stage * STAGE;
-    const char* sR = sL + NLP * 1024;
+    const unsigned sL = smem_u + stage * STAGE;
+    const unsigned sR = sL + NLP * 1024;
 #pragma unroll 1
-    for (int ks = kg; ks < 4; ks += KG) {
+    for (int ks = 0; ks < 4; ++ks) {
       const int k0 = ks * 16;
       const int r = k0 >> a.kw_log2, c0 = k0 & (KW - 1);
-      bf16x8 af[TI];
+      bf16x4 alo[TI], ahi[TI], blo[2], bhi[2];
 #pragma unroll
-      for (int i = 0; i < TI; ++i) af[i] = frag(sL, k0 + lk, wi * WTI + i * 32 + lcol, RBL, CPRL == 16);
+      for (int i = 0; i < TI; ++i)
+        tr_pair<4 * RBL>(alo[i], ahi[i], tr_addr(sL, k0 + lk, wi * WTI + i * 32 + lcol, RBL, CPRL == 16));
+      tr_pair<4 * RBR>(blo[0], bhi[0], tr_addr(sR, tap_shift(0, r, c0) + lk, wj * WTJ + lcol, RBR, CPRR == 16));
 #pragma unroll
-      for (int t = 0; t < NTAP; ++t) {
-        const int tyo = (NTY == 3) ? t / 3 : 0, tx = (NTX == 3) ? t % 3 : 0;
-        const int t0 = (r + tyo) * PWR + c0 + tx;
+      for (int tt = 0; tt < NTW; ++tt) {
+        if (tt + 1 < NTW) {
+          tr_pair<4 * RBR>(blo[(tt + 1) & 1], bhi[(tt + 1) & 1],
+                           tr_addr(sR, tap_shift(tt + 1, r, c0) + lk, wj * WTJ + lcol, RBR, CPRR == 16));
+          wait_lgkm<2>();  // everything but the pair just issued has returned (LDS returns in order)
+        } else {
+          wait_lgkm<0>();
+        }
+        if (tt == 0) {
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const bf16x8 bfr = frag(sR, t0 + lk, wj * WTJ + j * 32 + lcol, RBR, CPRR == 16);
+          for (int i = 0; i < TI; ++i) {
+            pin(alo[i]);
+            pin(ahi[i]);
+          }
+        }
+        pin(blo[tt & 1]);
+        pin(bhi[tt & 1]);
+        const bf16x8 bfr = __builtin_shufflevector(blo[tt & 1], bhi[tt & 1], 0, 1, 2, 3, 4, 5, 6, 7);
+        if (NTAP % TG == 0 || tg * NTW + tt < NTAP) {  // wave-uniform
 #pragma unroll
-          for (int i = 0; i < TI; ++i)
-            acc[i][j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i][j][t], 0, 0, 0);
+          for (int i = 0; i < TI; ++i) {
+            const bf16x8 afr = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i][tt], 0, 0, 0);
+          }
         }
       }
     }
@@ -196,21 +234,20 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
     compute(s % 3);
   }
 
-  // ---- partial slab [split*KG + kg][tap][Ci][Cj] ----------------------------------------------
+  // ---- partial slab [split][tap][Ci][Cj] ----------------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < NTAP; ++t) {
-    const int tap = (NTY == 3) ? t : ty_blk * 3 + t;
-    float* slab = a.slab + (((size_t)blockIdx.z * KG + kg) * (NTX == 1 ? 1 : 9) + tap) * (size_t)a.Ci * a.Cj;
+  for (int tt = 0; tt < NTW; ++tt) {
+    const int tw = tg * NTW + tt;
+    if (tw >= NTAP) continue;  // wave-uniform
+    const int tap = (NTY == 3 || NTX == 1) ? tw : ty_blk * 3 + tw;
+    float* slab = a.slab + ((size_t)blockIdx.z * (NTX == 1 ? 1 : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
+      const int cj = tj0 + wj * WTJ + l31;
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int cj = tj0 + wj * WTJ + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ci = ti0 + wi * WTI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[(size_t)ci * a.Cj + cj] = acc[i][j][t][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ti0 + wi * WTI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slab[(size_t)ci * a.Cj + cj] = acc[i][tt][r];
       }
     }
   }
@@ -235,12 +272,12 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   const int b = p->big ? 128 : 64;
   p->tiles_i = d->Ci / b;
   p->tiles_j = d->Cj / b;
-  p->kg = p->big ? 1 : 2;
+  p->kg = 1;
   p->units = (int)((long long)d->N * H * W / 64);
   const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : 1);
   long long split = (2 * UZ_NUM_CU + base - 1) / base;
   long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
-  if (max_split > 128) max_split = 128;
+  if (max_split > 256) max_split = 256;
   if (split > max_split) split = max_split;
   if (split < 1) split = 1;
   p->upb = (int)((p->units + split - 1) / split);
@@ -274,7 +311,7 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   if (p.one_tap) {
     dim3 grid(p.tiles_i * p.tiles_j, 1, p.split);
     if (p.big) hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 1, 2, 4, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 1, 1, 2, 2, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 1, 1, 2, 2, 2>), grid, block, 0, s, a);  // 4 waves idle: memory-bound
   } else if (p.big) {
     dim3 grid(p.tiles_i * p.tiles_j, 3, p.split);
     hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>), grid, block, 0, s, a);
