@@ -114,6 +114,17 @@ enum { UZ_PACK_CONV_FWD = 0, UZ_PACK_CONV_DGRAD = 1, UZ_PACK_CONVT_FWD = 2, UZ_P
        UZ_PACK_IM2COL = 4 };
 int uz_pack_weights(int dtype, int mode, const float* w, int Co, int Ci, int T, int Kpad, void* dst,
                     void* stream);
+/* The same for a whole model in one launch: `items_device` is a device array of n_items entries
+ * sorted by `begin` = number of destination elements of all earlier entries; total_elements = sum. */
+typedef struct uz_pack_item {
+  const float* src;
+  void* dst;
+  long long begin;
+  int mode, Co, Ci, T, Kpad;
+  int pad_;
+} uz_pack_item;
+int uz_pack_weights_batched(int dtype, const uz_pack_item* items_device, int n_items,
+                            long long total_elements, void* stream);
 
 /* im2col of a small-channel NCHW fp32 input (the network input, unet.py:31 first conv):
  *   dst[p][t*C + c] = x[n, c, h+dy, w+dx] (zero padded), dst row length Kpad, k >= 9C zero. */

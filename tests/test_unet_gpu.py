@@ -172,3 +172,28 @@ def test_full_size_properties_bf16():
     with torch.no_grad():
         b = m(x)
     assert torch.equal(a.detach(), b)   # same batch statistics -> identical forward
+
+
+def test_three_training_steps_track_the_oracle():
+    """several optimizer steps (weights change between forwards): the packed kernel-layout copies
+    must follow the master weights; loss trajectory vs the CPU oracle with the same AdamW"""
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("unet")
+    m.run_dtype = torch.float32
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(2, 3, 32, 32, seed=3)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    st = torch_ref.clone_state(sd, requires_grad=True)
+    ropt = torch.optim.AdamW([v for v in st.values() if v.requires_grad], lr=1e-3, weight_decay=1e-5)
+    for step in range(3):
+        opt.zero_grad()
+        loss = F.binary_cross_entropy_with_logits(m(x.to(DEV)), mask.to(DEV))
+        loss.backward()
+        opt.step()
+        ropt.zero_grad()
+        rloss = F.binary_cross_entropy_with_logits(torch_ref.unet_forward(st, x, True), mask)
+        rloss.backward()
+        ropt.step()
+        assert abs(loss.item() - rloss.item()) < 2e-3 * (step + 1), (step, loss.item(), rloss.item())
+    assert loss.item() < 0.72   # and it actually trains

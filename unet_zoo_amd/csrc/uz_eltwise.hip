@@ -331,14 +331,14 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ 
   const int LPP = C / VEC;  // lanes per pixel: power of two, <= 64
   const int ppb = blockDim.x / LPP;
   const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
-  const long long P = (long long)N * HW;
+  const int P = N * HW;  // < 2^31 (checked on the host)
   float wr[KOUT][VEC];
 #pragma unroll
   for (int k = 0; k < KOUT; ++k)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) wr[k][i] = w[k * C + sub * VEC + i];
-  for (long long p0 = (long long)blockIdx.x * ppb; p0 < P; p0 += (long long)gridDim.x * ppb) {
-    const long long p = p0 + pl;
+  for (int p0 = blockIdx.x * ppb; p0 < P; p0 += gridDim.x * ppb) {
+    const int p = p0 + pl;
     float v[VEC];
     if (p < P) {
       load_f(x + (size_t)p * ldx + sub * VEC, v);
@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int i = 0; i < VEC; ++i) v[i] = 0.f;
     }
-    const long long img = p / HW, hw = p - img * HW;
+    const int img = (KOUT == 1) ? 0 : p / HW;
+    const int hw = p - img * HW;
 #pragma unroll
     for (int k = 0; k < KOUT; ++k) {
       float s = 0.f;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
   const int LPP = C / VEC;
   const int ppb = blockDim.x / LPP;
   const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
-  const long long P = (long long)N * HW;
+  const int P = N * HW;  // < 2^31 (checked on the host)
   float wr[KOUT][VEC], aw[KOUT][VEC], ab[KOUT];
 #pragma unroll
   for (int k = 0; k < KOUT; ++k) {
@@ -381,10 +382,11 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
       aw[k][i] = 0.f;
     }
   }
-  for (long long p0 = (long long)blockIdx.x * ppb; p0 < P; p0 += (long long)gridDim.x * ppb) {
-    const long long p = p0 + pl;
+  for (int p0 = blockIdx.x * ppb; p0 < P; p0 += gridDim.x * ppb) {
+    const int p = p0 + pl;
     if (p >= P) continue;
-    const long long img = p / HW, hw = p - img * HW;
+    const int img = (KOUT == 1) ? 0 : p / HW;  // KOUT == 1: NCHW index == pixel index
+    const int hw = p - img * HW;
     float v[VEC], d[VEC];
     load_f(x + (size_t)p * ldx + sub * VEC, v);
 #pragma unroll
@@ -470,53 +472,62 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 // ------------------------------------------------------------------------------------------
 // Weight packing and input im2col
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pack_element(int mode, const float* __restrict__ w, int Co, int Ci,
+                                              int Tn, int Kpad, long long idx) {
+  switch (mode) {
+    case UZ_PACK_CONV_FWD: {  // dst[Co][t*Ci+ci] <- w[co][ci][t]
+      const int k = (int)(idx % ((long long)Tn * Ci));
+      const int co = (int)(idx / ((long long)Tn * Ci));
+      const int t = k / Ci, ci = k - t * Ci;
+      return w[((size_t)co * Ci + ci) * Tn + t];
+    }
+    case UZ_PACK_CONV_DGRAD: {  // dst[Ci][(T-1-t)*Co+co] <- w[co][ci][t]
+      const int k = (int)(idx % ((long long)Tn * Co));
+      const int ci = (int)(idx / ((long long)Tn * Co));
+      const int tf = k / Co, co = k - tf * Co;
+      return w[((size_t)co * Ci + ci) * Tn + (Tn - 1 - tf)];
+    }
+    case UZ_PACK_CONVT_FWD: {  // dst[t*Co+co][ci] <- w[ci][co][t]
+      const int ci = (int)(idx % Ci);
+      const int r = (int)(idx / Ci);
+      const int t = r / Co, co = r - t * Co;
+      return w[((size_t)ci * Co + co) * Tn + t];
+    }
+    case UZ_PACK_CONVT_DGRAD: {  // dst[ci][t*Co+co] <- w[ci][co][t]
+      const int k = (int)(idx % ((long long)Tn * Co));
+      const int ci = (int)(idx / ((long long)Tn * Co));
+      const int t = k / Co, co = k - t * Co;
+      return w[((size_t)ci * Co + co) * Tn + t];
+    }
+    default: {  // UZ_PACK_IM2COL: dst[Co][Kpad], k = t*Ci+ci
+      const int k = (int)(idx % Kpad);
+      const int co = (int)(idx / Kpad);
+      if (k < Tn * Ci) {
+        const int t = k / Ci, ci = k - t * Ci;
+        return w[((size_t)co * Ci + ci) * Tn + t];
+      }
+      return 0.f;
+    }
+  }
+}
+
 template <typename T>
 __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, int Co, int Ci, int Tn,
                                     int Kpad, T* __restrict__ dst, long long total) {
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    switch (mode) {
-      case UZ_PACK_CONV_FWD: {  // dst[Co][t*Ci+ci] <- w[co][ci][t]
-        const int k = (int)(idx % ((long long)Tn * Ci));
-        const int co = (int)(idx / ((long long)Tn * Ci));
-        const int t = k / Ci, ci = k - t * Ci;
-        v = w[((size_t)co * Ci + ci) * Tn + t];
-        break;
-      }
-      case UZ_PACK_CONV_DGRAD: {  // dst[Ci][(T-1-t)*Co+co] <- w[co][ci][t]
-        const int k = (int)(idx % ((long long)Tn * Co));
-        const int ci = (int)(idx / ((long long)Tn * Co));
-        const int tf = k / Co, co = k - tf * Co;
-        v = w[((size_t)co * Ci + ci) * Tn + (Tn - 1 - tf)];
-        break;
-      }
-      case UZ_PACK_CONVT_FWD: {  // dst[t*Co+co][ci] <- w[ci][co][t]
-        const int ci = (int)(idx % Ci);
-        const int r = (int)(idx / Ci);
-        const int t = r / Co, co = r - t * Co;
-        v = w[((size_t)ci * Co + co) * Tn + t];
-        break;
-      }
-      case UZ_PACK_CONVT_DGRAD: {  // dst[ci][t*Co+co] <- w[ci][co][t]
-        const int k = (int)(idx % ((long long)Tn * Co));
-        const int ci = (int)(idx / ((long long)Tn * Co));
-        const int t = k / Co, co = k - t * Co;
-        v = w[((size_t)ci * Co + co) * Tn + t];
-        break;
-      }
-      default: {  // UZ_PACK_IM2COL: dst[Co][Kpad], k = t*Ci+ci
-        const int k = (int)(idx % Kpad);
-        const int co = (int)(idx / Kpad);
-        if (k < Tn * Ci) {
-          const int t = k / Ci, ci = k - t * Ci;
-          v = w[((size_t)co * Ci + ci) * Tn + t];
-        }
-        break;
-      }
-    }
-    dst[idx] = (T)v;
-  }
+       idx += (long long)gridDim.x * blockDim.x)
+    dst[idx] = (T)pack_element(mode, w, Co, Ci, Tn, Kpad, idx);
+}
+
+// every weight tensor of a model in ONE launch: blockIdx.y = item, blockIdx.x strides over its elements
+template <typename T>
+__global__ void pack_weights_batched_kernel(const uz_pack_item* __restrict__ items, int n, long long total) {
+  const uz_pack_item it = items[blockIdx.y];
+  const long long count = ((int)blockIdx.y + 1 < n ? items[blockIdx.y + 1].begin : total) - it.begin;
+  T* __restrict__ dst = static_cast<T*>(it.dst);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < count;
+       idx += (long long)gridDim.x * blockDim.x)
+    dst[idx] = (T)pack_element(it.mode, it.src, it.Co, it.Ci, it.T, it.Kpad, idx);
 }
 
 template <typename T>
@@ -567,7 +578,7 @@ void reduce_shape(int CC, long long units, dim3* grid, dim3* block) {
   const int by = 256 / bx;
   const int gy = (CC + bx - 1) / bx;
   long long gx = (units + by - 1) / by;
-  long long cap = (long long)UZ_NUM_CU * 4 / gy;
+  long long cap = (long long)UZ_NUM_CU * 2 / gy;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
@@ -758,7 +769,8 @@ extern "C" int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, 
   UZ_REQUIRE(x && w && b && out_nchw, "uz_outconv_fwd: null pointer");
   UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_fwd: Kout=%d (max %d)", Kout, OUTCONV_MAXK);
   UZ_REQUIRE(C % vec == 0 && is_pow2(C / vec) && C / vec <= 64, "uz_outconv_fwd: C=%d unsupported", C);
-  UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0, "uz_outconv_fwd: bad shape");
+  UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0 && (long long)N * HW < (1LL << 31),
+             "uz_outconv_fwd: bad shape");
   const int ppb = 256 / (C / vec);
   const int grid = grid_for(((long long)N * HW + ppb - 1) / ppb, 1);
   hipStream_t s = (hipStream_t)stream;
@@ -779,11 +791,12 @@ extern "C" int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, 
   UZ_REQUIRE(x && w && g_nchw && dw && db, "uz_outconv_bwd: null pointer");
   UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_bwd: Kout=%d", Kout);
   UZ_REQUIRE(C % vec == 0 && is_pow2(C / vec) && C / vec <= 64, "uz_outconv_bwd: C=%d unsupported", C);
-  UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0, "uz_outconv_bwd: bad shape");
+  UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0 && (long long)N * HW < (1LL << 31),
+             "uz_outconv_bwd: bad shape");
   if (dx) UZ_REQUIRE(lddx % vec == 0 && lddx >= C, "uz_outconv_bwd: bad lddx");
   const int ppb = 256 / (C / vec);
   long long g = ((long long)N * HW + ppb - 1) / ppb;
-  if (g > UZ_NUM_CU * 4) g = UZ_NUM_CU * 4;
+  if (g > UZ_NUM_CU * 8) g = UZ_NUM_CU * 8;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16) {
     UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, dw, db))
@@ -827,6 +840,21 @@ extern "C" int uz_pack_weights(int dtype, int mode, const float* w, int Co, int 
   else
     hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, mode, w, Co, Ci, T, Kpad, (float*)dst, total);
   UZ_LAUNCH_CHECK("uz_pack_weights");
+  return UZ_OK;
+}
+
+extern "C" int uz_pack_weights_batched(int dtype, const uz_pack_item* items_device, int n_items,
+                                       long long total_elements, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_pack_weights_batched: bad dtype");
+  UZ_REQUIRE(items_device && n_items > 0 && total_elements > 0, "uz_pack_weights_batched: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  UZ_REQUIRE(n_items <= 65535, "uz_pack_weights_batched: too many items");
+  const dim3 grid(128, n_items);
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((pack_weights_batched_kernel<bf16_t>), grid, dim3(256), 0, s, items_device, n_items, total_elements);
+  else
+    hipLaunchKernelGGL((pack_weights_batched_kernel<float>), grid, dim3(256), 0, s, items_device, n_items, total_elements);
+  UZ_LAUNCH_CHECK("uz_pack_weights_batched");
   return UZ_OK;
 }
 

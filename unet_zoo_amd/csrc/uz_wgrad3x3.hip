@@ -275,7 +275,8 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   p->kg = 1;
   p->units = (int)((long long)d->N * H * W / 64);
   const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : 1);
-  long long split = (2 * UZ_NUM_CU + base - 1) / base;
+  // one workgroup per CU (160 KB LDS each): aim for a single full round of <= 256 workgroups
+  long long split = base >= UZ_NUM_CU ? 1 : UZ_NUM_CU / base;
   long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
   if (max_split > 256) max_split = 256;
   if (split > max_split) split = max_split;

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import Engine
+from .engine import Engine, PackCache
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
            "float32": torch.float32}
@@ -39,7 +39,9 @@ class _GraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model: "HipModule", plist: List[nn.Parameter], record: bool, x: torch.Tensor,
                 *params: torch.Tensor):
-        eng = Engine(model.run_dtype, x.device, model.training, record, model._grad_sink)
+        model._pack_cache.refresh(model.run_dtype)
+        eng = Engine(model.run_dtype, x.device, model.training, record, model._grad_sink,
+                     model._pack_cache)
         outs = model.emit(eng, x)
         ctx.eng = eng if record else None
         ctx.plist = plist
@@ -73,6 +75,12 @@ class HipModule(nn.Module):
         # kernels are enqueued, and once with the whole dict when backward has been enqueued
         self._grad_sink: Optional[Callable] = None
         self._grad_sink_done: Optional[Callable] = None
+        self._pack_cache = PackCache()
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to()/.cuda()/.float() replace parameter storage: packed copies and their pointer table die
+        self._pack_cache.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     # -- to be provided by the model --------------------------------------------------------
     def emit(self, eng: Engine, x: torch.Tensor) -> Sequence[torch.Tensor]:
