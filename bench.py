@@ -8,7 +8,7 @@ One "step" = the reference's whole training step (unet_zoo/utils/training_loop.p
 zero_grad -> forward -> BCEWithLogits -> backward (-> RCCL gradient all-reduce) ->
 clip_grad_norm_(1.0) -> AdamW.  Inputs are synthetic and already resident in HBM.  `value` is
 images/sec of that WHOLE step (a lower bound of the fwd+bwd rate, which is reported beside it as
-`fwd_bwd_images_per_s` from HIP events recorded inside the same timed steps).
+`fwd_bwd_images_per_s`, timed on the forward+backward hipGraph alone).
 
 Extra objects on the JSON line:
   roofline     — the dominant kernel (most GPU time), timed live with HIP events on the launch
@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the whole step from one hipGraph (auto: try, fall back to eager)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and use the multi-GPU launch strategy even for 1 rank")
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="eager steps with per-launch HIP events, run after the timed region")
     args = ap.parse_args()
@@ -95,8 +97,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
@@ -107,7 +112,7 @@ def main():
     model = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=1)
     model.run_dtype = run_dtype
     model = model.to(dev).train()
-    net = RcclDataParallel(model) if world > 1 else model
+    net = RcclDataParallel(model) if (world > 1 or args.force_dist) else model
     params = list(model.parameters())
     use_graph = args.graph != "off"
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
@@ -118,8 +123,7 @@ def main():
 
     fb_events = []
 
-    def step(timed: bool):
-        opt.zero_grad(set_to_none=True)
+    def fwd_bwd(timed: bool = False):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -129,8 +133,16 @@ def main():
         if timed:
             e1.record()
             fb_events.append((e0, e1))
+        return loss
+
+    def opt_step():
         torch.nn.utils.clip_grad_norm_(params, 1.0, foreach=True)
         opt.step()
+
+    def step(timed: bool):
+        opt.zero_grad(set_to_none=True)
+        loss = fwd_bwd(timed)
+        opt_step()
         return loss
 
     # warm-up (eager, on a side stream so that a graph can be captured afterwards)
@@ -142,46 +154,93 @@ def main():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
 
-    graph = None
+    # ---- launch strategy ---------------------------------------------------------------------
+    #  The step is two hipGraphs: (zero + fwd + loss + bwd, gradients accumulated into one flat fp32
+    #  buffer) and (clip + AdamW).  With N > 1 ranks ONE eager RCCL all-reduce (AVG) of the flat
+    #  buffer runs between them: collectives stay out of graph capture.  (The bucket reducer that
+    #  overlaps all-reduce with backward, parallel.RcclDataParallel, is the eager path: --graph off.)
+    run_one = None
     launch_mode = "eager"
+    distributed = world > 1 or args.force_dist
     if use_graph:
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step(False)
-            graph.replay()            # one untimed replay
+            inner = net.module if isinstance(net, RcclDataParallel) else net
+            inner._grad_sink = None          # gradients are reduced from the flat buffer instead
+            inner._grad_sink_done = None
+            flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:                 # .grad = views of one buffer -> one collective
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb):
+                flat.zero_()
+                out = inner(x)
+                static_loss = F.binary_cross_entropy_with_logits(out, mask)
+                static_loss.backward()       # accumulates into the views of `flat`
+            with torch.cuda.graph(g_opt):
+                opt_step()
+
+            if distributed:
+                def run_one():
+                    g_fb.replay()
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                    g_opt.replay()
+                launch_mode = "hipGraph(fwd+bwd) + eager RCCL all-reduce + hipGraph(clip+AdamW)"
+            else:
+                def run_one():
+                    g_fb.replay()
+                    g_opt.replay()
+                launch_mode = "hipGraph(fwd+bwd) + hipGraph(clip+AdamW)"
+            run_one()                 # one untimed replay
             torch.cuda.synchronize()
-            launch_mode = "hipGraph"
         except Exception as e:  # noqa: BLE001
             if args.graph == "on":
                 raise
-            graph = None
+            run_one = None
+            launch_mode = "eager"
             torch.cuda.synchronize()
+            for p in params:
+                p.grad = None
+            if isinstance(net, RcclDataParallel):
+                net.module._grad_sink = net.reducer.push
+                net.module._grad_sink_done = net.reducer.finish
             if rank == 0:
                 print(f"# hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches",
                       file=sys.stderr, flush=True)
 
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if graph is not None:
+    if run_one is not None:
         for _ in range(args.steps):
-            graph.replay()
+            run_one()
         loss = static_loss
     else:
         for _ in range(args.steps):
             loss = step(False)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    final_loss = float(loss.item())
+    fb_graph_ms = None
+    if run_one is not None:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            g_fb.replay()
+        torch.cuda.synchronize()
+        fb_graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     # per-launch HIP events (same process, same shapes, eager launches right after the timed steps)
+    for p in params:          # the eager profiling steps own their gradients again
+        p.grad = None
     ops.profile_begin()
     for _ in range(args.profile_steps):
         step(True)
@@ -191,7 +250,10 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
-        fb_ms = sorted(a.elapsed_time(b) for a, b in fb_events)[len(fb_events) // 2] if fb_events else float("nan")
+        if fb_graph_ms is not None:
+            fb_ms = fb_graph_ms
+        else:
+            fb_ms = sorted(a.elapsed_time(b) for a, b in fb_events)[len(fb_events) // 2] if fb_events else None
         # dominant kernel = the family with the largest summed duration
         dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
         roofline = None
@@ -214,9 +276,9 @@ def main():
             "config": {"workload": f"unet train step (zero_grad+fwd+BCE+bwd+clip+AdamW), B={args.batch}/GPU "
                                    f"3x{args.size}x{args.size}, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-            "fwd_bwd_ms": round(fb_ms, 3),
-            "fwd_bwd_images_per_s": round(args.batch * world / (fb_ms * 1e-3), 2),
-            "loss": round(loss.item(), 5),
+            "fwd_bwd_ms": round(fb_ms, 3) if fb_ms else None,
+            "fwd_bwd_images_per_s": round(args.batch * world / (fb_ms * 1e-3), 2) if fb_ms else None,
+            "loss": round(final_loss, 5),
             "roofline": roofline,
             "launch": launch_mode,
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
@@ -224,7 +286,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

@@ -62,6 +62,13 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
 
 static inline int uz_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// tuning switches for in-process A/B measurements (tools/kbench.py): integer in env UZ_TUNE, default 0
+#include <stdlib.h>
+static inline int uz_tune_flags() {
+  const char* e = getenv("UZ_TUNE");
+  return e ? atoi(e) : 0;
+}
+
 // direct 3x3 convolution (uz_conv3x3.hip), dispatched from uz_conv_igemm()
 struct UzDirectPlan {
   int tw, bn, bres, th_n, tw_n, ntiles, tiles_n, grid_m;

@@ -30,6 +30,7 @@ struct DirectArgs {
   unsigned xbytes, wbytes;
   int N, H, W, Cin, ldx, Nout, ldy, K;
   int th_n, tw_n, ntiles;
+  int flags;  // tuning/ablation switches (env UZ_TUNE, tools/kbench.py); 0 in production
 };
 
 template <typename T> struct Mma2;
@@ -179,6 +180,42 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     }
   };
 
+  // Resident-weight tiles have only two MFMAs per fragment set (wave tile 64x32), too few to
+  // cover an LDS round trip: walk the 36 (tap, K-chunk) groups of a tile as ONE software pipeline,
+  // group g+1's three ds_read_b128 issued ahead of group g's MFMAs (two register sets; the order is
+  // pinned with sched_group_barrier because the scheduler otherwise folds the sets back into one).
+  auto compute_tile_pipelined = [&](int abuf) {
+    const char* sA = smem + abuf * A_BYTES;
+    Vec16<T> af[2][2], bf[2][TN];
+    auto load_group = [&](int gidx, int set) {
+      const int tap = gidx >> 2, q = gidx & 3;
+      const int ty = tap / 3, tx = tap - 3 * ty;
+      const int lc = 2 * q + lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int prow = (f_pi[i] + ty) * PW + f_pj + tx;
+        af[set][i] = *reinterpret_cast<const Vec16<T>*>(sA + prow * 128 + ((lc ^ ((prow >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[set][j] = *reinterpret_cast<const Vec16<T>*>(sB + tap * B_STAGE + b_frag_off[j] + ((lc ^ b_sw[j]) << 4));
+    };
+    load_group(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + TN, 0);
+#pragma unroll
+    for (int gidx = 0; gidx < 36; ++gidx) {
+      if (gidx + 1 < 36) {
+        load_group(gidx + 1, (gidx + 1) & 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + TN, 0);   // DS reads of the next group
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma2<T>::run(af[gidx & 1][i], bf[gidx & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_group_barrier(0x008, (sizeof(T) == 2 ? 2 : 8) * TN, 0);  // this group's MFMAs
+    }
+  };
+
   if constexpr (BRES) {
     // resident weights: 9 tap tiles, loaded once
 #pragma unroll 1
@@ -189,6 +226,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     decode(first, img, h0, w0);
 #pragma unroll
     for (int i = 0; i < APW; ++i) issue_a_piece(i, 0, 0, img, h0, w0);
+    wait_vmcnt<0>();  // resident weights + first patch
+  }
+
+  float bv[TN];  // bias of this lane's output channels (loaded once, not per tile)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + l31;
+    bv[j] = (a.bias != nullptr && n < a.Nout) ? a.bias[n] : 0.f;
   }
 
   int it = 0;
@@ -203,7 +248,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
 
     int cbuf;  // A buffer that holds the C staging area afterwards
     if constexpr (BRES) {
-      wait_vmcnt<0>();
+      // this tile's patch (and the weights) were waited for before the previous epilogue's stores
+      // were issued, so those stores may still be in flight here: only the barrier is needed
       __builtin_amdgcn_s_barrier();
       const int next = tile + gridDim.x;
       if (next < a.ntiles) {
@@ -212,8 +258,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
 #pragma unroll
         for (int i = 0; i < APW; ++i) issue_a_piece(i, (it + 1) & 1, 0, im2, hh2, ww2);
       }
-#pragma unroll 1
-      for (int tap = 0; tap < 9; ++tap) compute(tap, it & 1, tap);
+      compute_tile_pipelined(it & 1);
+      wait_vmcnt<0>();  // next tile's patch has landed (it had the whole tap loop to arrive)
       cbuf = it & 1;
     } else {
       const int nsteps = ncb * 9;
@@ -248,15 +294,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       cbuf = 0;
     }
 
-    // ---- epilogue --------------------------------------------------------------------------
-    // bias + statistics from registers
-    float bv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WTN + j * 32 + l31;
-      bv[j] = (a.bias != nullptr && n < a.Nout) ? a.bias[n] : 0.f;
-    }
-    if constexpr (sizeof(T) == 2) {
+    // ---- epilogue: bias + statistics from registers ------------------------------------------
+    if (a.flags & 1) {
+      asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][0][3]));
+    } else if constexpr (sizeof(T) == 2) {
       constexpr int RSC = BN * ES + 16;  // C staging row stride (bytes)
       static_assert(256 * RSC <= A_BYTES * 2, "C staging must fit the A buffers");
       __builtin_amdgcn_s_barrier();  // every wave has finished reading A/B of this tile
@@ -277,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
             // statistics only over pixels inside the image
             const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
             const int pj = (TW == 32) ? ml : (ml & 15);
-            if (nok && h0 + pi < a.H && w0 + pj < a.W) {
+            if (!(a.flags & 2) && nok && h0 + pi < a.H && w0 + pj < a.W) {
               const float fv = (float)tv;
               s1[j] += fv;
               s2[j] += fv * fv;
@@ -376,6 +417,7 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
   p->tw_n = (d->W + p->tw - 1) / p->tw;
   p->ntiles = d->N * p->th_n * p->tw_n;
   p->bn = d->Nout <= 64 ? 64 : 128;
+  if (p->bn == 128 && (long long)p->ntiles * ((d->Nout + 127) / 128) <= UZ_NUM_CU / 2) p->bn = 64;
   p->bres = (p->bn == 64 && d->Cin == bk) ? 1 : 0;
   p->tiles_n = (d->Nout + p->bn - 1) / p->bn;
   int cap = UZ_NUM_CU / p->tiles_n;
@@ -425,5 +467,6 @@ int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x
   a.th_n = p.th_n;
   a.tw_n = p.tw_n;
   a.ntiles = p.ntiles;
+  a.flags = uz_tune_flags();
   return d->dtype == UZ_BF16 ? direct_launch_t<bf16_t>(p, a, s) : direct_launch_t<float>(p, a, s);
 }

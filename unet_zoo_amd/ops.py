@@ -203,6 +203,10 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     vec = 16 // es
     if (taps_mode == L.TAPS_CONV and ntaps == 9 and dil == 1 and store_mode == L.STORE_PLAIN
             and d.Nout % vec == 0 and y.ld % vec == 0):   # mirrors uz_direct_plan()
+        tw_ = 32 if W >= 32 else 16
+        ntl = N * ((H + 256 // tw_ - 1) // (256 // tw_)) * ((W + tw_ - 1) // tw_)
+        if bn == 128 and ntl * ((d.Nout + 127) // 128) <= 128:
+            bn = 64
         kname = f"conv3x3_direct_{_tname(x.dtype)}_bn{bn}" + ("_resident" if (bn == 64 and x.C == 8 * vec) else "")
     else:
         kname = f"igemm_{_tname(x.dtype)}_128x{bn}"
