@@ -84,3 +84,11 @@ struct UzWgrad2Plan {
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
                        float* slab, hipStream_t s);
+
+// LDS-DMA pixel-major GEMM (uz_gemm_dma.hip): 1x1 / ConvTranspose fwd + dgrad, dispatched from uz_conv_igemm()
+struct UzGemmPlan {
+  int bn, tiles_m, tiles_n, grid_m;
+};
+int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p);
+int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
+                       const float* bias, void* y, float* stats, hipStream_t s);

@@ -1,0 +1,350 @@
+// Pixel-major GEMM with an LDS-DMA pipeline for gfx950 (MI355X): the shapes of the hot path that are
+// plain matrix products over the pixel index —
+//   * 1x1 convolution and the im2col'd first convolution (reference: nn.Conv2d k1,
+//     unet_zoo/models/attention_unet.py:11,18,25; first conv of unet.py:31 after uz_im2col3x3_nchw)
+//   * ConvTranspose2d k2 s2 forward  = [P_in, Cin] x [Cin, 4*Cout] with a pixel-shuffle store
+//   * ConvTranspose2d k2 s2 input-gradient = 2x2 gather of the fine grid, K = 4*Cout
+//     (reference: unet_zoo/models/common_layers.py:104, backward via autograd a19)
+// y[m][n] = bias[n] + sum_k A[m][k] * W[n][k],  A row m, K-step s = (tap, 128-byte channel slab).
+//
+// 512-thread workgroup = 256 consecutive pixels x BN output channels; every K-step brings one
+// [256][128 B] activation tile and one [BN][128 B] weight tile into a 3-stage LDS ring by LDS-DMA
+// (buffer_load ... lds, rows past the end are out of range in the descriptor -> zero fill), two
+// steps ahead of the MFMAs behind a counted s_waitcnt vmcnt; one raw s_barrier per step.
+// Same 128-byte-row / XOR-swizzled 16-byte-chunk LDS image and the same epilogue (bias, BatchNorm
+// partial sums, bf16 tile transposed through LDS to 16-byte row stores) as uz_conv3x3.hip.
+#include "uz_common.h"
+
+namespace {
+
+struct GArgs {
+  const void* x;
+  const void* w;
+  void* y;
+  const float* bias;
+  float* stats;
+  unsigned xbytes, wbytes;
+  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m;
+};
+
+template <typename T> struct Mma3;
+template <> struct Mma3<bf16_t> {
+  static __device__ __forceinline__ void run(const Vec16<bf16_t>& a, const Vec16<bf16_t>& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma3<float> {
+  static __device__ __forceinline__ void run(const Vec16<float>& a, const Vec16<float>& b, f32x16& c) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b.v[t], c, 0, 0, 0);
+  }
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB = 0x80000000u;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 8 * VEC;
+  constexpr int A_BYTES = 256 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NAP = 4;          // A pieces per wave per stage (32 pieces of 8 rows)
+  constexpr int NBP = BN / 64;    // B pieces per wave per stage
+  constexpr int TN = BN / 64, WTN = BN / 2;  // waves: 4 (M) x 2 (N), wave tile 64 x BN/2
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
+  T* __restrict__ yg = static_cast<T*>(a.y);
+  const int HW = a.H * a.W;
+  const int ncb = a.Cin / BK;
+  const int nsteps = a.ntaps * ncb;
+
+  unsigned b_row_off[NBP];
+  int b_coff[NBP];
+#pragma unroll
+  for (int i = 0; i < NBP; ++i) {
+    const int n = (wave + 8 * i) * 8 + (lane >> 3);
+    b_row_off[i] = (n0 + n < a.Nout) ? (unsigned)(n0 + n) * (unsigned)a.K * ES : OOB;
+    b_coff[i] = (((lane & 7) ^ ((n >> 1) & 7)) * VEC) * ES;
+  }
+  int b_frag_off[TN], b_sw[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int brow = wn * WTN + j * 32 + l31;
+    b_frag_off[j] = brow * 128;
+    b_sw[j] = (brow >> 1) & 7;
+  }
+  int a_frag_off[2], a_sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int arow = wm * 64 + i * 32 + l31;
+    a_frag_off[i] = arow * 128;
+    a_sw[i] = (arow >> 1) & 7;
+  }
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + l31;
+    bv[j] = (a.bias != nullptr && n < a.Nout) ? a.bias[n] : 0.f;
+  }
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+
+  for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+    const int m0 = tile * 256;
+    // this lane's four A rows: pixel offset (in pixels) of tap 0, or -1 when past the end
+    int a_pix[NAP], a_coff[NAP];
+#pragma unroll
+    for (int i = 0; i < NAP; ++i) {
+      const int row = (wave + 8 * i) * 8 + (lane >> 3);
+      const int m = m0 + row;
+      a_coff[i] = (((lane & 7) ^ ((row >> 1) & 7)) * VEC) * ES;
+      if (m >= a.M) {
+        a_pix[i] = -1;
+      } else if (a.mode == UZ_TAPS_CONV) {
+        a_pix[i] = m;
+      } else {
+        const int img = m / HW, rem = m - img * HW;
+        const int h = rem / a.W, w = rem - h * a.W;
+        a_pix[i] = (img * a.Hin + 2 * h) * a.Win + 2 * w;
+      }
+    }
+    auto issue = [&](int stage, int s) {
+      const int tap = s / ncb, cb = s - tap * ncb;
+      const int dpix = (a.mode == UZ_TAPS_CONV) ? 0 : (tap >> 1) * a.Win + (tap & 1);
+      char* sA = smem + stage * STAGE;
+      char* sBt = sA + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < NAP; ++i) {
+        const unsigned off = a_pix[i] < 0 ? OOB
+                                          : ((unsigned)(a_pix[i] + dpix) * (unsigned)a.ldx + cb * BK) * ES + a_coff[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(sA + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NBP; ++i) {
+        const unsigned off = b_row_off[i] == OOB ? OOB : b_row_off[i] + (unsigned)(s * BK) * ES + b_coff[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(sBt + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+      }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    __builtin_amdgcn_s_barrier();  // previous tile's staging reads are finished everywhere
+    issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) {
+        wait_vmcnt<NAP + NBP>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (s + 2 < nsteps) issue((s + 2) % 3, s + 2);
+      const char* sA = smem + (s % 3) * STAGE;
+      const char* sBt = sA + A_BYTES;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int lc = 2 * q + lh;
+        Vec16<T> af[2], bf[TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const Vec16<T>*>(sA + a_frag_off[i] + ((lc ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[j] = *reinterpret_cast<const Vec16<T>*>(sBt + b_frag_off[j] + ((lc ^ b_sw[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma3<T>::run(af[i], bf[j], acc[i][j]);
+      }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    // output row of local pixel ml (0..255): plain -> pixel m0+ml; shuffle -> (2h+a, 2w+b)
+    auto out_row = [&](int ml, int ab) -> long long {
+      const int m = m0 + ml;
+      if (m >= a.M) return -1;
+      if (a.store == UZ_STORE_PLAIN) return m;
+      const int img = m / HW, rem = m - img * HW;
+      const int h = rem / a.W, w = rem - h * a.W;
+      return ((long long)img * (2 * a.H) + 2 * h + (ab >> 1)) * (2 * a.W) + 2 * w + (ab & 1);
+    };
+    // a whole BN tile belongs to one sub-pixel (Co % BN == 0, checked on the host)
+    const int ab = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 / a.Co : 0;
+    const int co0 = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 - ab * a.Co : n0;
+    if constexpr (sizeof(T) == 2) {
+      constexpr int RSC = BN * ES + 16;
+      static_assert(256 * RSC <= 3 * STAGE, "C staging must fit the ring");
+      __builtin_amdgcn_s_barrier();
+      char* sC = smem;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * WTN + j * 32 + l31;
+          const bool nok = n0 + col < a.Nout;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const T tv = (T)(acc[i][j][r] + bv[j]);
+            *reinterpret_cast<T*>(sC + ml * RSC + col * ES) = tv;
+            if (nok && m0 + ml < a.M) {
+              const float fv = (float)tv;
+              s1[j] += fv;
+              s2[j] += fv * fv;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      constexpr int CPR = BN * ES / 16;
+      for (int id = tid; id < 256 * CPR; id += 512) {
+        const int ml = id / CPR, cc = id - ml * CPR;
+        const long long orow = out_row(ml, ab);
+        if (orow >= 0 && n0 + cc * VEC < a.Nout) {
+          const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(sC + ml * RSC + cc * 16);
+          st16(yg + (size_t)orow * a.ldy + co0 + cc * VEC, v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * WTN + j * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long long orow = out_row(ml, ab);
+            if (orow >= 0 && n0 + col < a.Nout) {
+              const T tv = (T)(acc[i][j][r] + bv[j]);
+              yg[(size_t)orow * a.ldy + co0 + col] = tv;
+              const float fv = (float)tv;
+              s1[j] += fv;
+              s2[j] += fv * fv;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [4][BN][2]
+    if (lh == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + l31;
+        red[(wm * BN + col) * 2 + 0] = s1[j];
+        red[(wm * BN + col) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t1 += red[(k * BN + tid) * 2 + 0];
+        t2 += red[(k * BN + tid) * 2 + 1];
+      }
+      const int n = n0 + tid;
+      if (n < a.Nout) {
+        a.stats[((size_t)blockIdx.x * 2 + 0) * a.Nout + n] = t1;
+        a.stats[((size_t)blockIdx.x * 2 + 1) * a.Nout + n] = t2;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4, bk = 8 * vec;
+  const bool conv1 = d->taps_mode == UZ_TAPS_CONV && d->ntaps == 1;
+  const bool gath = d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4;
+  if (!conv1 && !gath) return 0;
+  if (d->Cin % bk != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
+  const long long pin = (long long)d->N * d->Hin * d->Win;
+  const long long xbytes = (pin - 1) * d->ldx * es + (long long)d->Cin * es;
+  const long long wbytes = (long long)d->Nout * d->ntaps * d->Cin * es;
+  if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31)) return 0;
+  p->bn = d->Nout <= 64 ? 64 : 128;
+  if (d->store_mode == UZ_STORE_SHUFFLE2X2) {
+    if (gath) return 0;
+    if (d->Co % 128 == 0) p->bn = 128;
+    else if (d->Co % 64 == 0) p->bn = 64;
+    else return 0;
+  }
+  const long long M = (long long)d->N * d->H * d->W;
+  p->tiles_m = (int)((M + 255) / 256);
+  p->tiles_n = (d->Nout + p->bn - 1) / p->bn;
+  int cap = UZ_NUM_CU / p->tiles_n;
+  if (cap < 1) cap = 1;
+  p->grid_m = p->tiles_m < cap ? p->tiles_m : cap;
+  return 1;
+}
+
+template <typename T>
+static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
+  dim3 grid(p.grid_m, p.tiles_n), block(512);
+  if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<T, 128>), grid, block, 0, s, a);
+  UZ_LAUNCH_CHECK("uz_conv_igemm(gemm_dma)");
+  return UZ_OK;
+}
+
+int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
+                       const float* bias, void* y, float* stats, hipStream_t s) {
+  const int es = d->dtype == UZ_BF16 ? 2 : 4;
+  GArgs a;
+  a.x = x;
+  a.w = w;
+  a.y = y;
+  a.bias = bias;
+  a.stats = stats;
+  a.xbytes = (unsigned)(((long long)d->N * d->Hin * d->Win - 1) * d->ldx * es + (long long)d->Cin * es);
+  a.wbytes = (unsigned)((long long)d->Nout * d->ntaps * d->Cin * es);
+  a.M = d->N * d->H * d->W;
+  a.H = d->H;
+  a.W = d->W;
+  a.Hin = d->Hin;
+  a.Win = d->Win;
+  a.Cin = d->Cin;
+  a.ldx = d->ldx;
+  a.Nout = d->Nout;
+  a.ldy = d->ldy;
+  a.K = d->ntaps * d->Cin;
+  a.ntaps = d->ntaps;
+  a.mode = d->taps_mode;
+  a.store = d->store_mode;
+  a.Co = d->Co;
+  a.tiles_m = p.tiles_m;
+  return d->dtype == UZ_BF16 ? gemm_launch_t<bf16_t>(p, a, s) : gemm_launch_t<float>(p, a, s);
+}

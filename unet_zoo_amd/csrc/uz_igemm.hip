@@ -319,6 +319,8 @@ extern "C" int uz_conv_igemm_grid_m(const uz_conv_desc* d) {
   if (rc != UZ_OK) return rc;
   UzDirectPlan dp;
   if (uz_direct_plan(d, &dp)) return dp.grid_m;
+  UzGemmPlan gp;
+  if (uz_gemm_dma_plan(d, &gp)) return gp.grid_m;
   return p.grid_m;
 }
 
@@ -333,6 +335,9 @@ extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w
   UzDirectPlan dp;
   if (uz_direct_plan(d, &dp))
     return uz_direct_launch(d, dp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));
+  UzGemmPlan gp;
+  if (uz_gemm_dma_plan(d, &gp))
+    return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));
   IgemmArgs a;
   a.x = x;
   a.w = w_packed;

@@ -208,6 +208,9 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         if bn == 128 and ntl * ((d.Nout + 127) // 128) <= 128:
             bn = 64
         kname = f"conv3x3_direct_{_tname(x.dtype)}_bn{bn}" + ("_resident" if (bn == 64 and x.C == 8 * vec) else "")
+    elif ((ntaps == 1 and taps_mode == L.TAPS_CONV) or (ntaps == 4 and taps_mode == L.TAPS_GATHER2X2)) \
+            and d.Nout % vec == 0 and y.ld % vec == 0 and (store_mode == L.STORE_PLAIN or co % 64 == 0):
+        kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
     else:
         kname = f"igemm_{_tname(x.dtype)}_128x{bn}"
     with _Timed(kname, 2.0 * M * d.Nout * K,
