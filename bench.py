@@ -172,12 +172,12 @@ def main():
             for p in params:                 # .grad = views of one buffer -> one collective
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
+            inner.grads_in_place = True      # kernels write straight into the views of `flat`
             g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_fb):
-                flat.zero_()
                 out = inner(x)
                 static_loss = F.binary_cross_entropy_with_logits(out, mask)
-                static_loss.backward()       # accumulates into the views of `flat`
+                static_loss.backward()       # every parameter gradient overwritten in place
             with torch.cuda.graph(g_opt):
                 opt_step()
 
@@ -202,6 +202,7 @@ def main():
             torch.cuda.synchronize()
             for p in params:
                 p.grad = None
+            (net.module if isinstance(net, RcclDataParallel) else net).grads_in_place = False
             if isinstance(net, RcclDataParallel):
                 net.module._grad_sink = net.reducer.push
                 net.module._grad_sink_done = net.reducer.finish
@@ -241,6 +242,7 @@ def main():
     # per-launch HIP events (same process, same shapes, eager launches right after the timed steps)
     for p in params:          # the eager profiling steps own their gradients again
         p.grad = None
+    (net.module if isinstance(net, RcclDataParallel) else net).grads_in_place = False
     ops.profile_begin()
     for _ in range(args.profile_steps):
         step(True)

@@ -179,9 +179,12 @@ int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const float* sca
  *   out[n, k, h, w] = b[k] + sum_c x[p, c] * w[k, c],  k < Kout <= 8 */
 int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,
                    const float* b, int Kout, float* out_nchw, void* stream);
-/* dx[p,c] = sum_k g[n,k,hw] * w[k,c];  dw[k,c] += sum_p g*x;  db[k] += sum_p g (dw, db zeroed by caller) */
+/* dx[p,c] = sum_k g[n,k,hw] * w[k,c];  dw[k,c] = sum_p g*x;  db[k] = sum_p g.
+ * Two kernels (per-workgroup partial rows in `workspace`, then a fixed-order sum): deterministic. */
+long long uz_outconv_bwd_workspace_bytes(int dtype, int N, int HW, int C, int Kout);
 int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w, int Kout,
-                   const float* g_nchw, void* dx, int lddx, float* dw, float* db, void* stream);
+                   const float* g_nchw, void* dx, int lddx, float* dw, float* db, void* workspace,
+                   void* stream);
 
 /* out[c] = sum_p x[p*ld + c] (fp32; out zeroed by caller). ConvTranspose2d bias gradient. */
 int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* stream);

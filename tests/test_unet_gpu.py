@@ -197,3 +197,29 @@ def test_three_training_steps_track_the_oracle():
         ropt.step()
         assert abs(loss.item() - rloss.item()) < 2e-3 * (step + 1), (step, loss.item(), rloss.item())
     assert loss.item() < 0.72   # and it actually trains
+
+
+def test_in_place_gradient_mode_matches_autograd_mode():
+    """grads_in_place: kernels overwrite pre-allocated p.grad views of one flat buffer (what
+    bench.py's hipGraph path and a flat all-reduce use); must equal the ordinary autograd result"""
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("unet").to(DEV).train()
+    m.run_dtype = torch.float32
+    x, mask = torch_ref.synthetic_batch(2, 3, 32, 32, seed=4)
+    x, mask = x.to(DEV), mask.to(DEV)
+    F.binary_cross_entropy_with_logits(m(x), mask).backward()
+    ref = [p.grad.clone() for p in m.parameters()]
+    params = list(m.parameters())
+    flat = torch.full((sum(p.numel() for p in params),), 0.0, device=DEV)
+    off = 0
+    for p in params:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    m.grads_in_place = True
+    for _ in range(2):   # twice: overwrite semantics, not accumulation
+        F.binary_cross_entropy_with_logits(m(x), mask).backward()
+    for p, r in zip(params, ref):
+        assert p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+        scale = r.abs().max() + 1e-12
+        # running statistics moved between the passes only through BN buffers, not the math of this batch
+        assert (p.grad - r).abs().max() <= 1e-4 * scale + 1e-9

@@ -25,7 +25,7 @@ EXPORTS = (
     "uz_abi_version", "uz_last_error_string", "uz_conv_igemm_grid_m", "uz_conv_igemm",
     "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
-    "uz_outconv_fwd", "uz_outconv_bwd", "uz_colsum",
+    "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_colsum",
 )
 
 
@@ -88,7 +88,8 @@ def load():
     lib.uz_bn_relu_bwd_apply.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                          c_double, vp, vp]
     lib.uz_outconv_fwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
-    lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp]
+    lib.uz_outconv_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]
+    lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp, vp]
     lib.uz_colsum.argtypes = [ip, vp, ip, ip, ip, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

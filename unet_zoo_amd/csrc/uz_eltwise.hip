@@ -364,9 +364,11 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
                                                           int HW, int C, const float* __restrict__ w,
                                                           const float* __restrict__ g,
                                                           T* __restrict__ dx, int lddx,
-                                                          float* __restrict__ dw,
-                                                          float* __restrict__ db) {
+                                                          float* __restrict__ partial) {
+  // partial[blockIdx.x][k][C + 1]: per-workgroup sums of g*x (C values) and g (1 value); a second
+  // kernel adds the rows (float atomics onto the 65 hot addresses serialised: 425 us -> this form)
   constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int UNR = 4;
   __shared__ float red[256 * 9];
   const int LPP = C / VEC;
   const int ppb = blockDim.x / LPP;
@@ -382,26 +384,42 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
       aw[k][i] = 0.f;
     }
   }
-  for (int p0 = blockIdx.x * ppb; p0 < P; p0 += gridDim.x * ppb) {
-    const int p = p0 + pl;
-    if (p >= P) continue;
-    const int img = (KOUT == 1) ? 0 : p / HW;  // KOUT == 1: NCHW index == pixel index
-    const int hw = p - img * HW;
-    float v[VEC], d[VEC];
-    load_f(x + (size_t)p * ldx + sub * VEC, v);
+  for (int p0 = blockIdx.x * ppb * UNR; p0 < P; p0 += gridDim.x * ppb * UNR) {
+    float v[UNR][VEC], gk[UNR][KOUT];
+    int pp[UNR];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) d[i] = 0.f;
+    for (int u = 0; u < UNR; ++u) {   // all loads first: UNR pixels in flight
+      const int p = p0 + u * ppb + pl;
+      pp[u] = p < P ? p : -1;
+      if (pp[u] >= 0) {
+        load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
+        const int img = (KOUT == 1) ? 0 : p / HW;  // KOUT == 1: NCHW index == pixel index
+        const int hw = p - img * HW;
 #pragma unroll
-    for (int k = 0; k < KOUT; ++k) {
-      const float gk = g[((size_t)img * KOUT + k) * HW + hw];
-      ab[k] += gk;
+        for (int k = 0; k < KOUT; ++k) gk[u][k] = g[((size_t)img * KOUT + k) * HW + hw];
+      } else {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        d[i] = fmaf(gk, wr[k][i], d[i]);
-        aw[k][i] = fmaf(gk, v[i], aw[k][i]);
+        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KOUT; ++k) gk[u][k] = 0.f;
       }
     }
-    if (dx != nullptr) store_f(dx + (size_t)p * lddx + sub * VEC, d);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float d[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) d[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KOUT; ++k) {
+        ab[k] += gk[u][k];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          d[i] = fmaf(gk[u][k], wr[k][i], d[i]);
+          aw[k][i] = fmaf(gk[u][k], v[u][i], aw[k][i]);
+        }
+      }
+      if (dx != nullptr && pp[u] >= 0) store_f(dx + (size_t)pp[u] * lddx + sub * VEC, d);
+    }
   }
   // block reduction over the ppb pixel lanes that share `sub`
 #pragma unroll
@@ -419,10 +437,34 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 9; ++i)
           if (i < VEC || i == 8) t[i] += red[(r * LPP + sub) * 9 + i];
+      float* row = partial + ((size_t)blockIdx.x * KOUT + k) * (C + 1);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) atomicAdd(dw + k * C + sub * VEC + i, t[i]);
-      if (sub == 0) atomicAdd(db + k, t[8]);
+      for (int i = 0; i < VEC; ++i) row[sub * VEC + i] = t[i];
+      if (sub == 0) row[C] = t[8];
     }
+  }
+}
+
+// dw[k][c] = sum_rows partial[row][k][c]; db[k] = sum_rows partial[row][k][C]
+// 1024 threads per 32 elements: thread (e = t & 31, g = t >> 5) adds rows g, g+32, ...
+__global__ __launch_bounds__(1024) void outconv_bwd_finalize_kernel(const float* __restrict__ partial, int rows,
+                                                                    int Kout, int C, float* __restrict__ dw,
+                                                                    float* __restrict__ db) {
+  __shared__ double sh[32][33];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int ne = Kout * (C + 1);
+  const int e = blockIdx.x * 32 + el;
+  double s = 0.0;
+  if (e < ne)
+    for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * ne + e];
+  sh[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < ne) {
+    double t = 0.0;
+    for (int r = 0; r < 32; ++r) t += sh[r][el];
+    const int k = e / (C + 1), c = e - k * (C + 1);
+    if (c < C) dw[k * C + c] = (float)t;
+    else db[k] = (float)t;
   }
 }
 
@@ -530,10 +572,10 @@ __global__ void pack_weights_batched_kernel(const uz_pack_item* __restrict__ ite
     dst[idx] = (T)pack_element(it.mode, it.src, it.Co, it.Ci, it.T, it.Kpad, idx);
 }
 
+// generic: one thread per 16-byte destination chunk
 template <typename T>
 __global__ void im2col3x3_kernel(const float* __restrict__ x, int N, int C, int H, int W, int Kpad,
                                  T* __restrict__ dst, long long total) {
-  // one thread per 16-byte destination chunk; consecutive threads = consecutive chunks of a pixel
   constexpr int VEC = ElemTraits<T>::VEC;
   const int cpr = Kpad / VEC;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -558,6 +600,43 @@ __global__ void im2col3x3_kernel(const float* __restrict__ x, int N, int C, int 
       v.v[e] = (T)f;
     }
     st16(dst + (size_t)p * Kpad + ch * VEC, v);
+  }
+}
+
+// small compile-time C (the RGB / grey network input): one thread per pixel.  For a fixed
+// (tap, channel) consecutive lanes read consecutive w of the NCHW image (coalesced 4-byte loads);
+// each thread then writes its whole row in 16-byte pieces (a wave writes one contiguous span).
+template <typename T, int C>
+__global__ __launch_bounds__(256) void im2col3x3_smallc_kernel(const float* __restrict__ x, int N, int H,
+                                                               int W, int Kpad, T* __restrict__ dst,
+                                                               long long npix) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int K = 9 * C;
+  constexpr int MAXCH = 64 / VEC;  // Kpad <= 64
+  const int nch = Kpad / VEC;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x) {
+    const int w0 = (int)(p % W);
+    const long long q = p / W;
+    const int h0 = (int)(q % H);
+    const int img = (int)(q / H);
+    float row[K];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hh = h0 + t / 3 - 1, ww = w0 + t % 3 - 1;
+      const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < C; ++c) row[t * C + c] = ok ? x[(((size_t)img * C + c) * H + hh) * W + ww] : 0.f;
+    }
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch) {
+      if (ch < nch) {
+        Vec16<T> v;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v.v[e] = (ch * VEC + e < K) ? (T)row[(ch * VEC + e < K) ? ch * VEC + e : 0] : (T)0.f;
+        st16(dst + (size_t)p * Kpad + ch * VEC, v);
+      }
+    }
   }
 }
 
@@ -783,27 +862,46 @@ extern "C" int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, 
   return UZ_OK;
 }
 
+static int outconv_bwd_grid(int dtype, int N, int HW, int C) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  const int ppb = 256 / (C / vec);
+  long long g = ((long long)N * HW + (long long)ppb * 4 - 1) / ((long long)ppb * 4);
+  if (g > UZ_NUM_CU * 4) g = UZ_NUM_CU * 4;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" long long uz_outconv_bwd_workspace_bytes(int dtype, int N, int HW, int C, int Kout) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_outconv_bwd_workspace_bytes: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(N > 0 && HW > 0 && Kout >= 1 && Kout <= OUTCONV_MAXK && C % vec == 0 && is_pow2(C / vec) && C / vec <= 64,
+             "uz_outconv_bwd_workspace_bytes: bad shape");
+  return (long long)outconv_bwd_grid(dtype, N, HW, C) * Kout * (C + 1) * (long long)sizeof(float);
+}
+
 extern "C" int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,
                               int Kout, const float* g_nchw, void* dx, int lddx, float* dw, float* db,
-                              void* stream) {
+                              void* workspace, void* stream) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_outconv_bwd: bad dtype");
   const int vec = dtype == UZ_BF16 ? 8 : 4;
-  UZ_REQUIRE(x && w && g_nchw && dw && db, "uz_outconv_bwd: null pointer");
+  UZ_REQUIRE(x && w && g_nchw && dw && db && workspace, "uz_outconv_bwd: null pointer");
   UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_bwd: Kout=%d", Kout);
   UZ_REQUIRE(C % vec == 0 && is_pow2(C / vec) && C / vec <= 64, "uz_outconv_bwd: C=%d unsupported", C);
   UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0 && (long long)N * HW < (1LL << 31),
              "uz_outconv_bwd: bad shape");
   if (dx) UZ_REQUIRE(lddx % vec == 0 && lddx >= C, "uz_outconv_bwd: bad lddx");
-  const int ppb = 256 / (C / vec);
-  long long g = ((long long)N * HW + ppb - 1) / ppb;
-  if (g > UZ_NUM_CU * 8) g = UZ_NUM_CU * 8;
+  const int g = outconv_bwd_grid(dtype, N, HW, C);
+  float* part = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16) {
-    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, dw, db))
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, part))
   } else {
-    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<float, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, g_nchw, (float*)dx, lddx, dw, db))
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<float, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, g_nchw, (float*)dx, lddx, part))
   }
   UZ_LAUNCH_CHECK("uz_outconv_bwd");
+  const int ne = Kout * (C + 1);
+  hipLaunchKernelGGL(outconv_bwd_finalize_kernel, dim3(uz_cdiv(ne, 32)), dim3(1024), 0, s, part, g, Kout, C, dw, db);
+  UZ_LAUNCH_CHECK("uz_outconv_bwd(finalize)");
   return UZ_OK;
 }
 
@@ -864,13 +962,28 @@ extern "C" int uz_im2col3x3_nchw(int dtype, const float* x_nchw, int N, int C, i
   UZ_REQUIRE(x_nchw && dst && N > 0 && C > 0 && H > 0 && W > 0 && Kpad >= 9 * C, "uz_im2col3x3_nchw: bad args");
   const int vec_ = dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(Kpad % vec_ == 0, "uz_im2col3x3_nchw: Kpad must be a multiple of %d", vec_);
-  const long long total = (long long)N * H * W * (Kpad / vec_);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = grid_for(total, 256);
-  if (dtype == UZ_BF16)
-    hipLaunchKernelGGL((im2col3x3_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, x_nchw, N, C, H, W, Kpad, (bf16_t*)dst, total);
-  else
-    hipLaunchKernelGGL((im2col3x3_kernel<float>), dim3(grid), dim3(256), 0, s, x_nchw, N, C, H, W, Kpad, (float*)dst, total);
+  const long long npix = (long long)N * H * W;
+  if (C <= 4 && Kpad <= 64) {
+    const int grid = grid_for(npix, 256);
+#define UZ_IM2COL_C(TT, CC) \
+  hipLaunchKernelGGL((im2col3x3_smallc_kernel<TT, CC>), dim3(grid), dim3(256), 0, s, x_nchw, N, H, W, Kpad, (TT*)dst, npix)
+    if (dtype == UZ_BF16) {
+      if (C == 1) UZ_IM2COL_C(bf16_t, 1); else if (C == 2) UZ_IM2COL_C(bf16_t, 2);
+      else if (C == 3) UZ_IM2COL_C(bf16_t, 3); else UZ_IM2COL_C(bf16_t, 4);
+    } else {
+      if (C == 1) UZ_IM2COL_C(float, 1); else if (C == 2) UZ_IM2COL_C(float, 2);
+      else if (C == 3) UZ_IM2COL_C(float, 3); else UZ_IM2COL_C(float, 4);
+    }
+#undef UZ_IM2COL_C
+  } else {
+    const long long total = npix * (Kpad / vec_);
+    const int grid = grid_for(total, 256);
+    if (dtype == UZ_BF16)
+      hipLaunchKernelGGL((im2col3x3_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, x_nchw, N, C, H, W, Kpad, (bf16_t*)dst, total);
+    else
+      hipLaunchKernelGGL((im2col3x3_kernel<float>), dim3(grid), dim3(256), 0, s, x_nchw, N, C, H, W, Kpad, (float*)dst, total);
+  }
   UZ_LAUNCH_CHECK("uz_im2col3x3_nchw");
   return UZ_OK;
 }

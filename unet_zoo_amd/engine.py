@@ -78,7 +78,7 @@ class PackCache:
 class Engine:
     def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
                  grad_sink: Optional[Callable[[nn.Parameter, torch.Tensor], None]] = None,
-                 pack_cache: Optional[PackCache] = None):
+                 pack_cache: Optional[PackCache] = None, grads_in_place: bool = False):
         self.dtype = dtype
         self.device = device
         self.training = training
@@ -91,6 +91,9 @@ class Engine:
         self._sums: Optional[torch.Tensor] = None
         self._sums_used = 0
         self._cache = pack_cache if pack_cache is not None else PackCache()
+        # write every parameter gradient straight into the existing p.grad storage (overwrite, no
+        # accumulation, no temporaries): used with pre-allocated flat gradient buffers / hipGraphs
+        self.grads_in_place = grads_in_place
         self._heads: List[Callable[[torch.Tensor], None]] = []
 
     # ------------------------------------------------------------------ buffers
@@ -107,7 +110,24 @@ class Engine:
         full.parts = parts
         return full, parts
 
-    def _give_grad(self, p: nn.Parameter, g: torch.Tensor) -> None:
+    def _dst(self, p: nn.Parameter) -> Optional[torch.Tensor]:
+        """Destination tensor for p's gradient in in-place mode (None: allocate a fresh one)."""
+        if self.grads_in_place and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32:
+            return p.grad
+        return None
+
+    def _give_grad(self, p: nn.Parameter, g: Optional[torch.Tensor]) -> None:
+        if self.grads_in_place and p.grad is not None:
+            if g is None:
+                return                               # analytically zero and p.grad was never touched
+            if g.data_ptr() != p.grad.data_ptr():
+                p.grad.copy_(g.reshape(p.grad.shape))
+            self.param_grads[p] = None               # autograd must not add it a second time
+            if self.grad_sink is not None:
+                self.grad_sink(p, p.grad)
+            return
+        if g is None:
+            g = torch.zeros(p.shape, dtype=torch.float32, device=self.device)
         if p in self.param_grads:
             self.param_grads[p] = self.param_grads[p] + g
         else:
@@ -193,23 +213,26 @@ class Engine:
                 if g0 is None and gp is None:
                     return  # nothing downstream used this activation
                 dy = self.new_act(N, H, W, Cout)
-                dgamma = torch.empty(Cout, dtype=torch.float32, device=self.device)
-                dbeta = torch.empty(Cout, dtype=torch.float32, device=self.device)
+                dgamma, dbeta = self._dst(bn.weight), self._dst(bn.bias)
+                if dgamma is None:
+                    dgamma = torch.empty(Cout, dtype=torch.float32, device=self.device)
+                if dbeta is None:
+                    dbeta = torch.empty(Cout, dtype=torch.float32, device=self.device)
                 ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:
                     # d(bias) = sum_p dy == 0 analytically under train-mode BN (the batch mean
                     # removes any per-channel constant); the reference's value is rounding noise.
-                    self._give_grad(conv.bias, torch.zeros(Cout, dtype=torch.float32, device=self.device))
+                    self._give_grad(conv.bias, None)
                 if im2col:
                     dwp = ops.wgrad(dy, x, (Cout, x.C), ntaps=1)
                     cin = conv.in_channels
                     dw = dwp[:, :9 * cin].reshape(Cout, 9, cin).permute(0, 2, 1).reshape(conv.weight.shape)
                     self._give_grad(conv.weight, dw.contiguous())
                 else:
-                    self._give_grad(conv.weight,
-                                    ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=9, dil=dil))
+                    self._give_grad(conv.weight, ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=9,
+                                                           dil=dil, out=self._dst(conv.weight)))
                     if x.needs_grad:
                         dx = self.new_act(N, H, W, x.C)
                         # per-channel sums of dx come for free from the kernel's statistics
@@ -241,7 +264,7 @@ class Engine:
                     cs = g.channel_sums()
                     self._give_grad(m.bias, cs if cs is not None else ops.colsum(g))
                 self._give_grad(m.weight, ops.wgrad(x, g, tuple(m.weight.shape), ntaps=4,
-                                                    taps_mode=L.TAPS_GATHER2X2))
+                                                    taps_mode=L.TAPS_GATHER2X2, out=self._dst(m.weight)))
                 if x.needs_grad:
                     dx = self.new_act(x.N, x.H, x.W, x.C)
                     ops.conv_igemm(g, self._pack(m.weight, L.PACK_CONVT_DGRAD), None, dx, ntaps=4,
@@ -261,8 +284,11 @@ class Engine:
         if self.record:
             def bwd(g_logits: torch.Tensor):
                 dx = self.new_act(x.N, x.H, x.W, x.C) if x.needs_grad else None
-                dw, db = ops.outconv_bwd(x, w, g_logits.contiguous().float(), dx)
-                self._give_grad(conv.weight, dw.reshape(conv.weight.shape))
+                dwt = self._dst(conv.weight)
+                dbt = self._dst(conv.bias) if conv.bias is not None else None
+                dw, db = ops.outconv_bwd(x, w, g_logits.contiguous().float(), dx,
+                                         dwt.view(K, x.C) if dwt is not None else None, dbt)
+                self._give_grad(conv.weight, dwt if dwt is not None else dw.reshape(conv.weight.shape))
                 if conv.bias is not None:
                     self._give_grad(conv.bias, db)
                 if dx is not None:

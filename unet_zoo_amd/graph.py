@@ -41,7 +41,7 @@ class _GraphFn(torch.autograd.Function):
                 *params: torch.Tensor):
         model._pack_cache.refresh(model.run_dtype)
         eng = Engine(model.run_dtype, x.device, model.training, record, model._grad_sink,
-                     model._pack_cache)
+                     model._pack_cache, model.grads_in_place)
         outs = model.emit(eng, x)
         ctx.eng = eng if record else None
         ctx.plist = plist
@@ -76,6 +76,10 @@ class HipModule(nn.Module):
         self._grad_sink: Optional[Callable] = None
         self._grad_sink_done: Optional[Callable] = None
         self._pack_cache = PackCache()
+        # True: backward OVERWRITES existing p.grad tensors in place (no accumulation, no temporaries;
+        # conv biases in front of a train-mode BatchNorm are left untouched = zero).  For pre-allocated
+        # flat gradient buffers and hipGraph capture; default False = ordinary autograd semantics.
+        self.grads_in_place = False
 
     def _apply(self, fn, *args, **kwargs):
         # .to()/.cuda()/.float() replace parameter storage: packed copies and their pointer table die

@@ -221,7 +221,7 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
 
 
 def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
-          taps_mode: int = L.TAPS_CONV) -> torch.Tensor:
+          taps_mode: int = L.TAPS_CONV, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i, j, tap] = sum_p L[p, i] * R[pix(p, tap), j]  (fp32, reference parameter layout)."""
     L.require_cuda(Lt.buf, Rt.buf)
     lib = L.load()
@@ -229,8 +229,9 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
                     ntaps, taps_mode, dil)
     ws_bytes = L.check_count(lib.uz_wgrad_workspace_bytes(byref(d)), "uz_wgrad_workspace_bytes")
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=Lt.buf.device)
-    out = torch.empty(out_shape, dtype=torch.float32, device=Lt.buf.device)
-    assert out.numel() == Lt.C * Rt.C * ntaps
+    if out is None:
+        out = torch.empty(out_shape, dtype=torch.float32, device=Lt.buf.device)
+    assert out.numel() == Lt.C * Rt.C * ntaps and out.is_contiguous() and out.dtype == torch.float32
     tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
     kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
     W_ = Lt.W
@@ -316,17 +317,24 @@ def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act]):
+def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act],
+                dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None):
     lib = L.load()
     K = w.shape[0]
     assert g.dtype == torch.float32 and g.is_contiguous() and g.shape == (x.N, K, x.H, x.W)
-    dwb = torch.zeros(K * x.C + K, dtype=torch.float32, device=x.buf.device)
-    dw, db = dwb[:K * x.C], dwb[K * x.C:]
-    L.check(lib.uz_outconv_bwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.N, x.H * x.W, x.C,
-                               w.data_ptr(), K, g.data_ptr(),
+    dev = x.buf.device
+    if dw is None:
+        dw = torch.empty((K, x.C), dtype=torch.float32, device=dev)
+    if db is None:
+        db = torch.empty(K, dtype=torch.float32, device=dev)
+    code = L.dtype_code(x.dtype)
+    wsb = L.check_count(lib.uz_outconv_bwd_workspace_bytes(code, x.N, x.H * x.W, x.C, K),
+                        "uz_outconv_bwd_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    L.check(lib.uz_outconv_bwd(code, x.ptr(), x.ld, x.N, x.H * x.W, x.C, w.data_ptr(), K, g.data_ptr(),
                                dx.ptr() if dx is not None else None,
                                dx.ld if dx is not None else 0, dw.data_ptr(), db.data_ptr(),
-                               L.stream_ptr()), "uz_outconv_bwd")
+                               ws.data_ptr(), L.stream_ptr()), "uz_outconv_bwd")
     return dw.view(K, x.C), db
 
 
