@@ -125,6 +125,15 @@ typedef struct uz_pack_item {
 } uz_pack_item;
 int uz_pack_weights_batched(int dtype, const uz_pack_item* items_device, int n_items,
                             long long total_elements, void* stream);
+/* 3x3 convolution weights (Co, Ci multiples of 32): forward AND input-gradient layouts from one
+ * coalesced read of the OIHW tensor; either destination may be NULL. */
+typedef struct uz_pack3x3_item {
+  const float* src;
+  void* dst_fwd;    /* [Co][t*Ci + ci]        (UZ_PACK_CONV_FWD)   */
+  void* dst_dgrad;  /* [Ci][(8-t)*Co + co]    (UZ_PACK_CONV_DGRAD) */
+  int Co, Ci;
+} uz_pack3x3_item;
+int uz_pack_conv3x3_batched(int dtype, const uz_pack3x3_item* items_device, int n_items, void* stream);
 
 /* im2col of a small-channel NCHW fp32 input (the network input, unet.py:31 first conv):
  *   dst[p][t*C + c] = x[n, c, h+dy, w+dx] (zero padded), dst row length Kpad, k >= 9C zero. */

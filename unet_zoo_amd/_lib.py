@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 # every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "uz_abi_version", "uz_last_error_string", "uz_conv_igemm_grid_m", "uz_conv_igemm",
-    "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
+    "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_colsum",
 )
@@ -48,6 +48,10 @@ class BnBwdDesc(Structure):
 class PackItem(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("begin", ctypes.c_longlong), ("mode", c_int),
                 ("Co", c_int), ("Ci", c_int), ("T", c_int), ("Kpad", c_int), ("pad_", c_int)]
+
+
+class Pack3x3Item(Structure):
+    _fields_ = [("src", c_void_p), ("dst_fwd", c_void_p), ("dst_dgrad", c_void_p), ("Co", c_int), ("Ci", c_int)]
 
 
 class HipLibraryError(RuntimeError):
@@ -78,6 +82,7 @@ def load():
     lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]
     lib.uz_pack_weights.argtypes = [ip, ip, vp, ip, ip, ip, ip, vp, vp]
     lib.uz_pack_weights_batched.argtypes = [ip, vp, ip, ctypes.c_longlong, vp]
+    lib.uz_pack_conv3x3_batched.argtypes = [ip, vp, ip, vp]
     lib.uz_im2col3x3_nchw.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp]
     lib.uz_bn_finalize.argtypes = [vp, ip, ip, c_double, vp, vp, fp, fp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_bn_eval_scale.argtypes = [ip, vp, vp, vp, vp, fp, vp, vp, vp]

@@ -941,6 +941,49 @@ extern "C" int uz_pack_weights(int dtype, int mode, const float* w, int Co, int 
   return UZ_OK;
 }
 
+// 3x3 conv weights, both kernel layouts from ONE coalesced read: a workgroup stages a
+// [32 co][32 ci][9] block of the OIHW tensor in LDS and writes the forward layout (ci fastest) and
+// the input-gradient layout (co fastest, taps flipped) from it.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv3x3_tiled_kernel(const uz_pack3x3_item* __restrict__ items) {
+  __shared__ float tile[9][32][33];
+  const uz_pack3x3_item it = items[blockIdx.y];
+  const int tiles_ci = it.Ci / 32, ntiles = (it.Co / 32) * tiles_ci;
+  T* __restrict__ df = static_cast<T*>(it.dst_fwd);
+  T* __restrict__ dd = static_cast<T*>(it.dst_dgrad);
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int co0 = (tl / tiles_ci) * 32, ci0 = (tl % tiles_ci) * 32;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+      const int co_l = e / 288, r = e - co_l * 288;
+      const int ci_l = r / 9, tap = r - ci_l * 9;
+      tile[tap][co_l][ci_l] = it.src[((size_t)(co0 + co_l) * it.Ci + ci0) * 9 + r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * 1024; e += 256) {
+      const int x = e & 31, y = (e >> 5) & 31, tap = e >> 10;
+      if (df != nullptr)  // x = ci, y = co
+        df[(size_t)(co0 + y) * 9 * it.Ci + tap * it.Ci + ci0 + x] = (T)tile[tap][y][x];
+      if (dd != nullptr)  // x = co, y = ci
+        dd[(size_t)(ci0 + y) * 9 * it.Co + (8 - tap) * it.Co + co0 + x] = (T)tile[tap][x][y];
+    }
+  }
+}
+
+extern "C" int uz_pack_conv3x3_batched(int dtype, const uz_pack3x3_item* items_device, int n_items,
+                                       void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_pack_conv3x3_batched: bad dtype");
+  UZ_REQUIRE(items_device && n_items > 0 && n_items <= 65535, "uz_pack_conv3x3_batched: bad args");
+  const dim3 grid(64, n_items);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((pack_conv3x3_tiled_kernel<bf16_t>), grid, dim3(256), 0, s, items_device);
+  else
+    hipLaunchKernelGGL((pack_conv3x3_tiled_kernel<float>), grid, dim3(256), 0, s, items_device);
+  UZ_LAUNCH_CHECK("uz_pack_conv3x3_batched");
+  return UZ_OK;
+}
+
 extern "C" int uz_pack_weights_batched(int dtype, const uz_pack_item* items_device, int n_items,
                                        long long total_elements, void* stream) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_pack_weights_batched: bad dtype");

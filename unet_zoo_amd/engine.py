@@ -34,12 +34,12 @@ class PackCache:
         self._total = 0
         self._n = 0
         self._table_dtype = None
-        self._seen_versions = None
+        self._table3: Optional[torch.Tensor] = None
+        self._n3 = 0
 
     def invalidate(self) -> None:
         self.entries.clear()
         self._table = None
-        self._seen_versions = None
 
     def get(self, p: nn.Parameter, mode: int, kpad: int, dtype: torch.dtype) -> torch.Tensor:
         key = (id(p), mode, kpad, dtype)
@@ -59,21 +59,44 @@ class PackCache:
         if not ents:
             return
         if self._table is None or self._table_dtype != dtype:
-            import ctypes
-            arr = (L.PackItem * len(ents))()
-            begin = 0
-            for i, (p, mode, kpad, _, dst) in enumerate(ents):
-                d0, d1 = p.shape[0], p.shape[1]
-                T = p.numel() // (d0 * d1)
-                co, ci = (d0, d1) if mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD, L.PACK_IM2COL) else (d1, d0)
-                arr[i] = L.PackItem(p.data_ptr(), dst.data_ptr(), begin, mode, co, ci, T, kpad, 0)
-                begin += dst.numel()
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self._table = raw.to(ents[0][4].device)
-            self._total, self._n, self._table_dtype = begin, len(ents), dtype
-        L.check(L.load().uz_pack_weights_batched(L.dtype_code(dtype), self._table.data_ptr(), self._n,
-                                                 self._total, L.stream_ptr()), "uz_pack_weights_batched")
+            self._build_tables(ents, dtype)
+        lib = L.load()
+        if self._n3 > 0:
+            L.check(lib.uz_pack_conv3x3_batched(L.dtype_code(dtype), self._table3.data_ptr(), self._n3,
+                                                L.stream_ptr()), "uz_pack_conv3x3_batched")
+        if self._n > 0:
+            L.check(lib.uz_pack_weights_batched(L.dtype_code(dtype), self._table.data_ptr(), self._n,
+                                                self._total, L.stream_ptr()), "uz_pack_weights_batched")
 
+    def _build_tables(self, ents, dtype) -> None:
+        dev = ents[0][4].device
+        # 3x3 conv weights with 32-divisible channel counts: one tiled item per parameter
+        tiled = {}
+        generic = []
+        for (p, mode, kpad, _, dst) in ents:
+            ok = (mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD) and p.dim() == 4 and tuple(p.shape[2:]) == (3, 3)
+                  and p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0)
+            if ok:
+                it = tiled.setdefault(id(p), [p, None, None])
+                it[1 if mode == L.PACK_CONV_FWD else 2] = dst
+            else:
+                generic.append((p, mode, kpad, dst))
+        arr3 = (L.Pack3x3Item * max(len(tiled), 1))()
+        for i, (p, df, dd) in enumerate(tiled.values()):
+            arr3[i] = L.Pack3x3Item(p.data_ptr(), df.data_ptr() if df is not None else None,
+                                    dd.data_ptr() if dd is not None else None, p.shape[0], p.shape[1])
+        self._n3 = len(tiled)
+        self._table3 = torch.frombuffer(bytearray(bytes(arr3)), dtype=torch.uint8).to(dev)
+        arr = (L.PackItem * max(len(generic), 1))()
+        begin = 0
+        for i, (p, mode, kpad, dst) in enumerate(generic):
+            d0, d1 = p.shape[0], p.shape[1]
+            T = p.numel() // (d0 * d1)
+            co, ci = (d0, d1) if mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD, L.PACK_IM2COL) else (d1, d0)
+            arr[i] = L.PackItem(p.data_ptr(), dst.data_ptr(), begin, mode, co, ci, T, kpad, 0)
+            begin += dst.numel()
+        self._table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self._total, self._n, self._table_dtype = begin, len(generic), dtype
 
 class Engine:
     def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
