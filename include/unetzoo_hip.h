@@ -132,8 +132,11 @@ typedef struct uz_pack3x3_item {
   void* dst_fwd;    /* [Co][t*Ci + ci]        (UZ_PACK_CONV_FWD)   */
   void* dst_dgrad;  /* [Ci][(8-t)*Co + co]    (UZ_PACK_CONV_DGRAD) */
   int Co, Ci;
+  int tile_begin;   /* number of 32x32 (co, ci) tiles of all earlier items */
+  int pad_;
 } uz_pack3x3_item;
-int uz_pack_conv3x3_batched(int dtype, const uz_pack3x3_item* items_device, int n_items, void* stream);
+int uz_pack_conv3x3_batched(int dtype, const uz_pack3x3_item* items_device, int n_items, int total_tiles,
+                            void* stream);
 
 /* im2col of a small-channel NCHW fp32 input (the network input, unet.py:31 first conv):
  *   dst[p][t*C + c] = x[n, c, h+dy, w+dx] (zero padded), dst row length Kpad, k >= 9C zero. */

@@ -51,7 +51,8 @@ class PackItem(Structure):
 
 
 class Pack3x3Item(Structure):
-    _fields_ = [("src", c_void_p), ("dst_fwd", c_void_p), ("dst_dgrad", c_void_p), ("Co", c_int), ("Ci", c_int)]
+    _fields_ = [("src", c_void_p), ("dst_fwd", c_void_p), ("dst_dgrad", c_void_p), ("Co", c_int), ("Ci", c_int),
+                ("tile_begin", c_int), ("pad_", c_int)]
 
 
 class HipLibraryError(RuntimeError):
@@ -82,7 +83,7 @@ def load():
     lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]
     lib.uz_pack_weights.argtypes = [ip, ip, vp, ip, ip, ip, ip, vp, vp]
     lib.uz_pack_weights_batched.argtypes = [ip, vp, ip, ctypes.c_longlong, vp]
-    lib.uz_pack_conv3x3_batched.argtypes = [ip, vp, ip, vp]
+    lib.uz_pack_conv3x3_batched.argtypes = [ip, vp, ip, ip, vp]
     lib.uz_im2col3x3_nchw.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp]
     lib.uz_bn_finalize.argtypes = [vp, ip, ip, c_double, vp, vp, fp, fp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_bn_eval_scale.argtypes = [ip, vp, vp, vp, vp, fp, vp, vp, vp]

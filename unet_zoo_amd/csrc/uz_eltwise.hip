@@ -945,13 +945,20 @@ extern "C" int uz_pack_weights(int dtype, int mode, const float* w, int Co, int 
 // [32 co][32 ci][9] block of the OIHW tensor in LDS and writes the forward layout (ci fastest) and
 // the input-gradient layout (co fastest, taps flipped) from it.
 template <typename T>
-__global__ __launch_bounds__(256) void pack_conv3x3_tiled_kernel(const uz_pack3x3_item* __restrict__ items) {
+__global__ __launch_bounds__(256) void pack_conv3x3_tiled_kernel(const uz_pack3x3_item* __restrict__ items,
+                                                                 int n, int total_tiles) {
   __shared__ float tile[9][32][33];
-  const uz_pack3x3_item it = items[blockIdx.y];
-  const int tiles_ci = it.Ci / 32, ntiles = (it.Co / 32) * tiles_ci;
-  T* __restrict__ df = static_cast<T*>(it.dst_fwd);
-  T* __restrict__ dd = static_cast<T*>(it.dst_dgrad);
-  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+  for (int gt = blockIdx.x; gt < total_tiles; gt += gridDim.x) {
+    int lo = 0, hi = n - 1;  // item that owns global tile gt (tile_begin is a prefix sum)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items[mid].tile_begin <= gt) lo = mid; else hi = mid - 1;
+    }
+    const uz_pack3x3_item it = items[lo];
+    const int tl = gt - it.tile_begin;
+    const int tiles_ci = it.Ci / 32;
+    T* __restrict__ df = static_cast<T*>(it.dst_fwd);
+    T* __restrict__ dd = static_cast<T*>(it.dst_dgrad);
     const int co0 = (tl / tiles_ci) * 32, ci0 = (tl % tiles_ci) * 32;
     __syncthreads();
     for (int e = threadIdx.x; e < 32 * 288; e += 256) {
@@ -971,15 +978,15 @@ __global__ __launch_bounds__(256) void pack_conv3x3_tiled_kernel(const uz_pack3x
 }
 
 extern "C" int uz_pack_conv3x3_batched(int dtype, const uz_pack3x3_item* items_device, int n_items,
-                                       void* stream) {
+                                       int total_tiles, void* stream) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_pack_conv3x3_batched: bad dtype");
-  UZ_REQUIRE(items_device && n_items > 0 && n_items <= 65535, "uz_pack_conv3x3_batched: bad args");
-  const dim3 grid(64, n_items);
+  UZ_REQUIRE(items_device && n_items > 0 && total_tiles > 0, "uz_pack_conv3x3_batched: bad args");
+  const dim3 grid(total_tiles < 4096 ? total_tiles : 4096);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16)
-    hipLaunchKernelGGL((pack_conv3x3_tiled_kernel<bf16_t>), grid, dim3(256), 0, s, items_device);
+    hipLaunchKernelGGL((pack_conv3x3_tiled_kernel<bf16_t>), grid, dim3(256), 0, s, items_device, n_items, total_tiles);
   else
-    hipLaunchKernelGGL((pack_conv3x3_tiled_kernel<float>), grid, dim3(256), 0, s, items_device);
+    hipLaunchKernelGGL((pack_conv3x3_tiled_kernel<float>), grid, dim3(256), 0, s, items_device, n_items, total_tiles);
   UZ_LAUNCH_CHECK("uz_pack_conv3x3_batched");
   return UZ_OK;
 }

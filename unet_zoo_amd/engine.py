@@ -36,6 +36,7 @@ class PackCache:
         self._table_dtype = None
         self._table3: Optional[torch.Tensor] = None
         self._n3 = 0
+        self._tiles3 = 0
 
     def invalidate(self) -> None:
         self.entries.clear()
@@ -63,7 +64,7 @@ class PackCache:
         lib = L.load()
         if self._n3 > 0:
             L.check(lib.uz_pack_conv3x3_batched(L.dtype_code(dtype), self._table3.data_ptr(), self._n3,
-                                                L.stream_ptr()), "uz_pack_conv3x3_batched")
+                                                self._tiles3, L.stream_ptr()), "uz_pack_conv3x3_batched")
         if self._n > 0:
             L.check(lib.uz_pack_weights_batched(L.dtype_code(dtype), self._table.data_ptr(), self._n,
                                                 self._total, L.stream_ptr()), "uz_pack_weights_batched")
@@ -82,10 +83,12 @@ class PackCache:
             else:
                 generic.append((p, mode, kpad, dst))
         arr3 = (L.Pack3x3Item * max(len(tiled), 1))()
+        tb = 0
         for i, (p, df, dd) in enumerate(tiled.values()):
             arr3[i] = L.Pack3x3Item(p.data_ptr(), df.data_ptr() if df is not None else None,
-                                    dd.data_ptr() if dd is not None else None, p.shape[0], p.shape[1])
-        self._n3 = len(tiled)
+                                    dd.data_ptr() if dd is not None else None, p.shape[0], p.shape[1], tb, 0)
+            tb += (p.shape[0] // 32) * (p.shape[1] // 32)
+        self._n3, self._tiles3 = len(tiled), tb
         self._table3 = torch.frombuffer(bytearray(bytes(arr3)), dtype=torch.uint8).to(dev)
         arr = (L.PackItem * max(len(generic), 1))()
         begin = 0
