@@ -41,7 +41,10 @@ enum {
 /* tap geometry of an implicit-GEMM convolution */
 enum {
   UZ_TAPS_CONV = 0,     /* ntaps = 1 (1x1) or 9 (3x3, dilation `dil`, zero padding `dil`) */
-  UZ_TAPS_GATHER2X2 = 1 /* ntaps = 4: input pixel (2h+a, 2w+b), tap = 2a+b (ConvTranspose k2s2 dgrad) */
+  UZ_TAPS_GATHER2X2 = 1, /* ntaps = 4: input pixel (2h+a, 2w+b), tap = 2a+b (ConvTranspose k2s2 dgrad) */
+  UZ_TAPS_CONV_UP2 = 2   /* 3x3 taps on the nearest-neighbour x2 upsampling of the input: the input tensor
+                            lives at (H/2, W/2) and pixel (h, w) reads (h>>1, w>>1)
+                            (nn.Upsample(scale_factor=2) + Conv2d, common_layers.py:69-72) */
 };
 enum {
   UZ_STORE_PLAIN = 0,    /* y[p*ldy + n] */
@@ -197,6 +200,37 @@ long long uz_outconv_bwd_workspace_bytes(int dtype, int N, int HW, int C, int Ko
 int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w, int Kout,
                    const float* g_nchw, void* dx, int lddx, float* dw, float* db, void* workspace,
                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Additive attention gate (AttentionBlock.forward, attention_unet.py:34-40), everything except the
+ * two 1x1 convolutions W_g / W_x (those are uz_conv_igemm with statistics):
+ *   q[p]   = b_psi + sum_c relu(bn_g(g1raw) + bn_x(x1raw))[p,c] * w_psi[c]      uz_attn_psi_fwd
+ *   out    = x * sigmoid(bn_q(q))                                               uz_attn_gate_fwd
+ * and the backward chain (see uz_attn.hip).  vec_* are the [4][channels] (scale, shift, mean,
+ * invstd) rows produced by uz_bn_finalize; partial buffers hold uz_attn_grid() rows.
+ * ------------------------------------------------------------------------------------------- */
+int uz_attn_grid(int dtype, int P, int channels);
+int uz_attn_psi_fwd(int dtype, const void* g1raw, int ldg, const void* x1raw, int ldx, const float* vec_g,
+                    const float* vec_x, const float* wpsi, const float* bpsi /* device, may be NULL */,
+                    int P, int F, float* q, float* partial /* [grid(F)][2] */, void* stream);
+int uz_attn_gate_fwd(int dtype, const void* x, int ldx, const float* q, const float* vec_q, int P, int C,
+                     void* out, int ldo, void* stream);
+int uz_attn_bwd_psi(int dtype, const void* dout, int ldd, const void* x, int ldx, const float* q,
+                    const float* vec_q, int P, int C, void* dx_direct, int lddx, float* dz,
+                    float* partial /* [grid(C)][2] */, void* stream);
+int uz_attn_bwd_reduce(int dtype, const void* g1raw, int ldg, const void* x1raw, int ldx, const float* q,
+                       const float* dz, const float* wpsi, const float* vec_g, const float* vec_x,
+                       const float* vec_q, const double* a01, int P, int F,
+                       float* partial /* [grid(F)][4F+1] */, void* stream);
+int uz_attn_bwd_apply(int dtype, const void* g1raw, int ldg, const void* x1raw, int ldx, const float* q,
+                      const float* dz, const float* wpsi, const float* vec_g, const float* vec_x,
+                      const float* vec_q, const double* a01, const double* totals, int P, int F,
+                      void* dg1raw, int lddg, void* dx1raw, int lddx, void* stream);
+/* out[e] (double) = sum over rows of partial[row][e] */
+int uz_sum_rows(const float* partial, int rows, int n, double* out, void* stream);
+/* backward of nearest x2 upsampling: dx[coarse pixel] = sum of its 2x2 fine pixels (H, W coarse) */
+int uz_sum2x2(int dtype, const void* du, int ldu, int N, int H, int W, int C, void* dx, int lddx,
+              void* stream);
 
 /* out[c] = sum_p x[p*ld + c] (fp32; out zeroed by caller). ConvTranspose2d bias gradient. */
 int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* stream);

@@ -53,7 +53,8 @@ def sample_idx(n: int, k: int) -> np.ndarray:
     return np.sort(rng.choice(n, size=min(k, n), replace=False))
 
 
-def run_case(model, B, H, W, tag, full_logits: bool):
+def run_case(model, B, H, W, tag, full_logits: bool, name: str = "unet",
+             bn_keys=("down_convolution_1.conv.conv_op.1", "bottle_neck.conv_op.4", "up_convolution_4.conv.conv_op.4")):
     x, mask = synthetic_batch(B, 3, H, W, seed=1)
     model.train()
     logits = model(x)
@@ -64,7 +65,7 @@ def run_case(model, B, H, W, tag, full_logits: bool):
     gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)).item()
     arrays = {}
     meta = {
-        "model": "unet", "B": B, "H": H, "W": W, "input_sha256": sha(x), "mask_sha256": sha(mask),
+        "model": name, "B": B, "H": H, "W": W, "input_sha256": sha(x), "mask_sha256": sha(mask),
         "loss": loss.item(), "global_grad_norm": gnorm,
         "train_logits_mean": logits.mean().item(), "train_logits_std": logits.std().item(),
         "train_positive_pixels": int((logits > 0).sum().item()),
@@ -82,7 +83,7 @@ def run_case(model, B, H, W, tag, full_logits: bool):
             arrays["gval/" + n] = p.grad.flatten()[gi].numpy()
     # running statistics after the single train-mode forward
     sd = model.state_dict()
-    for k in ("down_convolution_1.conv.conv_op.1", "bottle_neck.conv_op.4", "up_convolution_4.conv.conv_op.4"):
+    for k in bn_keys:
         arrays["rm/" + k] = sd[k + ".running_mean"].numpy()
         arrays["rv/" + k] = sd[k + ".running_var"].numpy()
     model.eval()
@@ -97,6 +98,29 @@ def run_case(model, B, H, W, tag, full_logits: bool):
     with open(os.path.join(OUT, f"{tag}.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print(tag, "loss", meta["loss"], "gnorm", gnorm, "train mean", meta["train_logits_mean"])
+
+
+def write_manifest(model, name):
+    sd = model.state_dict()
+    manifest = {
+        "model": name, "seed": 0, "n_params": sum(p.numel() for p in model.parameters()),
+        "entries": [[k, list(v.shape), str(v.dtype).replace("torch.", ""), sha(v)] for k, v in sd.items()],
+    }
+    with open(os.path.join(OUT, f"{name}_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0)
+    print("manifest", name, manifest["n_params"], len(manifest["entries"]))
+
+
+def write_attention_unet():
+    """attention_unet: B=2 3x64x64 with every number kept (the BASELINE
+    config's 512x512 is reduced as SURVEY §8c allows)."""
+    mods = load_reference("common_layers", "attention_unet")
+    Ref = mods["attention_unet"].AttentionUNet
+    torch.manual_seed(0)
+    model = Ref(in_channels=3, num_classes=1, depth=5)
+    write_manifest(model, "attention_unet")
+    run_case(model, 2, 64, 64, "attention_unet_b2_64", full_logits=True, name="attention_unet",
+             bn_keys=("conv1.conv.1", "att5.psi.1", "att2.w_g.1", "up2.up.2", "upconv2.conv.4"))
 
 
 def main():
@@ -122,6 +146,7 @@ def main():
 
     # case A: small, every number kept
     run_case(model, 2, 64, 64, "unet_b2_64", full_logits=True)
+    write_attention_unet()
     # case B: BASELINE configs[0] (B=2, 256x256): fresh seed-0 model
     torch.manual_seed(0)
     model = RefUNet(in_channels=3, num_classes=1)

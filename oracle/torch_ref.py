@@ -74,7 +74,55 @@ def unet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Tensor:
     return F.conv2d(u4, sd["out.conv.weight"], sd["out.conv.bias"])  # OutConv, common_layers.py:125
 
 
-FORWARDS = {"unet": unet_forward}
+# ---------------------------------------------------------------------------------------------
+# Attention U-Net
+# ---------------------------------------------------------------------------------------------
+def conv_block(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """ConvBlock.forward — common_layers.py:39-61 (``prefix`` ends in .conv)."""
+    x = conv_bn_relu(x, sd, f"{prefix}.0", f"{prefix}.1", training)
+    return conv_bn_relu(x, sd, f"{prefix}.3", f"{prefix}.4", training)
+
+
+def up_conv_block(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """UpConvBlock.forward — common_layers.py:63-80: nn.Upsample(scale_factor=2) (nearest), Conv3x3, BN, ReLU."""
+    x = F.interpolate(x, scale_factor=2, mode="nearest")
+    return conv_bn_relu(x, sd, f"{prefix}.up.1", f"{prefix}.up.2", training)
+
+
+def _conv1x1_bn(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    x = F.conv2d(x, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"])
+    x = F.batch_norm(x, sd[f"{prefix}.1.running_mean"], sd[f"{prefix}.1.running_var"], sd[f"{prefix}.1.weight"],
+                     sd[f"{prefix}.1.bias"], training=training, momentum=0.1, eps=1e-5)
+    if training and f"{prefix}.1.num_batches_tracked" in sd:
+        sd[f"{prefix}.1.num_batches_tracked"] += 1
+    return x
+
+
+def attention_block(g, x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """AttentionBlock.forward — attention_unet.py:34-40."""
+    g1 = _conv1x1_bn(g, sd, f"{prefix}.w_g", training)
+    x1 = _conv1x1_bn(x, sd, f"{prefix}.w_x", training)
+    psi = torch.sigmoid(_conv1x1_bn(F.relu(g1 + x1), sd, f"{prefix}.psi", training))
+    return psi * x
+
+
+def attention_unet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """AttentionUNet.forward — attention_unet.py:73-110."""
+    pool = lambda t: F.max_pool2d(t, kernel_size=2, stride=2)  # noqa: E731  (shared self.maxpool)
+    x1 = conv_block(x, sd, "conv1.conv", training)
+    x2 = conv_block(pool(x1), sd, "conv2.conv", training)
+    x3 = conv_block(pool(x2), sd, "conv3.conv", training)
+    x4 = conv_block(pool(x3), sd, "conv4.conv", training)
+    x5 = conv_block(pool(x4), sd, "conv5.conv", training)
+    d = x5
+    for lvl, skip in ((5, x4), (4, x3), (3, x2), (2, x1)):
+        d = up_conv_block(d, sd, f"up{lvl}", training)
+        gated = attention_block(d, skip, sd, f"att{lvl}", training)
+        d = conv_block(torch.cat((gated, d), dim=1), sd, f"upconv{lvl}.conv", training)
+    return F.conv2d(d, sd["conv_1x1.weight"], sd["conv_1x1.bias"])
+
+
+FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward}
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":

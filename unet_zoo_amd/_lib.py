@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_voi
 import torch
 
 UZ_F32, UZ_BF16 = 0, 1
-TAPS_CONV, TAPS_GATHER2X2 = 0, 1
+TAPS_CONV, TAPS_GATHER2X2, TAPS_CONV_UP2 = 0, 1, 2
 STORE_PLAIN, STORE_SHUFFLE2X2 = 0, 1
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD, PACK_IM2COL = range(5)
 
@@ -26,6 +26,8 @@ EXPORTS = (
     "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_colsum",
+    "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd", "uz_attn_bwd_psi", "uz_attn_bwd_reduce",
+    "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum2x2",
 )
 
 
@@ -97,6 +99,15 @@ def load():
     lib.uz_outconv_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]
     lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp, vp]
     lib.uz_colsum.argtypes = [ip, vp, ip, ip, ip, vp, vp]
+    lib.uz_attn_grid.argtypes = [ip, ip, ip]
+    lib.uz_attn_psi_fwd.argtypes = [ip, vp, ip, vp, ip, vp, vp, vp, vp, ip, ip, vp, vp, vp]
+    lib.uz_attn_gate_fwd.argtypes = [ip, vp, ip, vp, vp, ip, ip, vp, ip, vp]
+    lib.uz_attn_bwd_psi.argtypes = [ip, vp, ip, vp, ip, vp, vp, ip, ip, vp, ip, vp, vp, vp]
+    lib.uz_attn_bwd_reduce.argtypes = [ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, vp, vp]
+    lib.uz_attn_bwd_apply.argtypes = [ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, vp, ip,
+                                      vp, ip, vp]
+    lib.uz_sum_rows.argtypes = [vp, ip, ip, vp, vp]
+    lib.uz_sum2x2.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("uz_last_error_string",):

@@ -31,6 +31,7 @@ struct DirectArgs {
   int N, H, W, Cin, ldx, Nout, ldy, K;
   int th_n, tw_n, ntiles;
   int flags;  // tuning/ablation switches (env UZ_TUNE, tools/kbench.py); 0 in production
+  int ups;    // 1: the input lives at (H/2, W/2) and is read through nearest x2 upsampling
 };
 
 template <typename T> struct Mma2;
@@ -140,8 +141,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     const int hh = hh0 - 1 + pi, ww = ww0 - 1 + pj;
     const bool ok = r < PROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
     const int coff = (((lane & 7) ^ ((r >> 1) & 7)) * VEC) * ES;
-    const unsigned off = ok ? ((unsigned)((im * a.H + hh) * a.W + ww) * (unsigned)a.ldx + cb * BK) * ES + coff
-                            : OOB;
+    const unsigned pix = a.ups ? (unsigned)((im * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1))
+                               : (unsigned)((im * a.H + hh) * a.W + ww);
+    const unsigned off = ok ? (pix * (unsigned)a.ldx + cb * BK) * ES + coff : OOB;
     dma16(xr, smem + buf * A_BYTES + piece * 1024, off);
   };
   auto issue_b = [&](int slot, int cb, int tap) {
@@ -405,10 +407,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
 // ---- host side ------------------------------------------------------------------------------
 // returns 1 and fills the plan when the direct kernel applies to this descriptor, 0 otherwise
 int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
-  if (d->taps_mode != UZ_TAPS_CONV || d->ntaps != 9 || d->dil != 1 || d->store_mode != UZ_STORE_PLAIN) return 0;
+  const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
+  if (!(d->taps_mode == UZ_TAPS_CONV || up) || d->ntaps != 9 || d->dil != 1 || d->store_mode != UZ_STORE_PLAIN) return 0;
+  if (up && ((d->H & 1) || (d->W & 1) || d->Hin * 2 != d->H || d->Win * 2 != d->W)) return 0;
   const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4, bk = 8 * vec;
   if (d->Cin % bk != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
-  const long long xbytes = ((long long)d->N * d->H * d->W - 1) * d->ldx * es + (long long)d->Cin * es;
+  const long long xbytes = ((long long)d->N * d->Hin * d->Win - 1) * d->ldx * es + (long long)d->Cin * es;
   const long long wbytes = (long long)d->Nout * 9 * d->Cin * es;
   if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31)) return 0;
   p->tw = d->W >= 32 ? 32 : 16;
@@ -454,7 +458,8 @@ int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x
   a.y = y;
   a.bias = bias;
   a.stats = stats;
-  a.xbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldx * es + (long long)d->Cin * es);
+  a.xbytes = (unsigned)(((long long)d->N * d->Hin * d->Win - 1) * d->ldx * es + (long long)d->Cin * es);
+  a.ups = d->taps_mode == UZ_TAPS_CONV_UP2 ? 1 : 0;
   a.wbytes = (unsigned)((long long)d->Nout * 9 * d->Cin * es);
   a.N = d->N;
   a.H = d->H;

@@ -68,17 +68,18 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
   T* __restrict__ yg = static_cast<T*>(a.y);
   const int HW = a.H * a.W;
-  const int ncb = a.Cin / BK;
+  const int ncb = (a.Cin + BK - 1) / BK;  // the last slab of a tap may be partial: zero-filled
   const int nsteps = a.ntaps * ncb;
 
   unsigned b_row_off[NBP];
-  int b_coff[NBP];
+  int b_coff[NBP];   // byte offset of this lane's logical chunk inside a 128-byte slab
 #pragma unroll
   for (int i = 0; i < NBP; ++i) {
     const int n = (wave + 8 * i) * 8 + (lane >> 3);
     b_row_off[i] = (n0 + n < a.Nout) ? (unsigned)(n0 + n) * (unsigned)a.K * ES : OOB;
     b_coff[i] = (((lane & 7) ^ ((n >> 1) & 7)) * VEC) * ES;
   }
+  const int cin_bytes = a.Cin * ES;
   int b_frag_off[TN], b_sw[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -125,17 +126,19 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
     auto issue = [&](int stage, int s) {
       const int tap = s / ncb, cb = s - tap * ncb;
       const int dpix = (a.mode == UZ_TAPS_CONV) ? 0 : (tap >> 1) * a.Win + (tap & 1);
+      const int slab = cb * BK * ES;            // byte offset of the slab inside the tap's channels
       char* sA = smem + stage * STAGE;
       char* sBt = sA + A_BYTES;
 #pragma unroll
       for (int i = 0; i < NAP; ++i) {
-        const unsigned off = a_pix[i] < 0 ? OOB
-                                          : ((unsigned)(a_pix[i] + dpix) * (unsigned)a.ldx + cb * BK) * ES + a_coff[i];
+        const bool ok = a_pix[i] >= 0 && slab + a_coff[i] < cin_bytes;
+        const unsigned off = ok ? (unsigned)(a_pix[i] + dpix) * (unsigned)(a.ldx * ES) + slab + a_coff[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(sA + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < NBP; ++i) {
-        const unsigned off = b_row_off[i] == OOB ? OOB : b_row_off[i] + (unsigned)(s * BK) * ES + b_coff[i];
+        const bool ok = b_row_off[i] != OOB && slab + b_coff[i] < cin_bytes;
+        const unsigned off = ok ? b_row_off[i] + (unsigned)(tap * cin_bytes) + slab + b_coff[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(sBt + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
       }
     };
@@ -290,7 +293,8 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
   const bool conv1 = d->taps_mode == UZ_TAPS_CONV && d->ntaps == 1;
   const bool gath = d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4;
   if (!conv1 && !gath) return 0;
-  if (d->Cin % bk != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
+  (void)bk;
+  if (d->Cin % vec != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
   const long long pin = (long long)d->N * d->Hin * d->Win;
   const long long xbytes = (pin - 1) * d->ldx * es + (long long)d->Cin * es;
   const long long wbytes = (long long)d->Nout * d->ntaps * d->Cin * es;

@@ -267,10 +267,18 @@ int make_plan(const uz_conv_desc* d, Plan* p) {
   const int bk = 8 * vec;
   UZ_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Nout > 0,
              "uz_conv_igemm: non-positive shape");
-  UZ_REQUIRE(d->Cin % bk == 0, "uz_conv_igemm: Cin=%d must be a multiple of %d", d->Cin, bk);
+  {
+    UzGemmPlan gp_;
+    UZ_REQUIRE(d->Cin % bk == 0 || uz_gemm_dma_plan(d, &gp_),
+               "uz_conv_igemm: Cin=%d must be a multiple of %d for this shape", d->Cin, bk);
+  }
   UZ_REQUIRE(d->ldx % vec == 0 && d->ldx >= d->Cin, "uz_conv_igemm: bad ldx=%d (Cin=%d)", d->ldx,
              d->Cin);
-  if (d->taps_mode == UZ_TAPS_CONV) {
+  if (d->taps_mode == UZ_TAPS_CONV_UP2) {
+    UzDirectPlan dp_;
+    UZ_REQUIRE(uz_direct_plan(d, &dp_), "uz_conv_igemm: upsampled input needs the direct 3x3 kernel "
+               "(ntaps=9, dil=1, even H/W, Hin=H/2, channel multiples, tensor < 2 GiB)");
+  } else if (d->taps_mode == UZ_TAPS_CONV) {
     UZ_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "uz_conv_igemm: ntaps=%d", d->ntaps);
     UZ_REQUIRE(d->Hin == d->H && d->Win == d->W, "uz_conv_igemm: conv taps need Hin==H, Win==W");
     UZ_REQUIRE(d->dil >= 1, "uz_conv_igemm: dil=%d", d->dil);

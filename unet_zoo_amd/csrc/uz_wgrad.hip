@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const T* __restrict__ Rg = static_cast<const T*>(a.R);
 
   int dy = 0, dx = 0;
-  if (a.mode == UZ_TAPS_CONV) {
+  if (a.mode == UZ_TAPS_CONV || a.mode == UZ_TAPS_CONV_UP2) {
     if (a.ntaps == 9) {
       const int ty = tap / 3;
       dy = (ty - 1) * a.dil;
@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         const int hh = rh[i] + dy, ww = rw[i] + dx;
         ok = ok && (unsigned)hh < (unsigned)a.Hr && (unsigned)ww < (unsigned)a.Wr;
         pix = ((size_t)rn[i] * a.Hr + hh) * a.Wr + ww;
+      } else if (a.mode == UZ_TAPS_CONV_UP2) {  // R lives at (H/2, W/2), read through nearest x2
+        const int hh = rh[i] + dy, ww = rw[i] + dx;
+        ok = ok && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        pix = ((size_t)rn[i] * a.Hr + (hh >> 1)) * a.Wr + (ww >> 1);
       } else {
         pix = ((size_t)rn[i] * a.Hr + 2 * rh[i] + dy) * a.Wr + 2 * rw[i] + dx;
       }
@@ -270,6 +274,9 @@ int make_plan(const uz_wgrad_desc* d, Plan* p) {
   if (d->taps_mode == UZ_TAPS_CONV) {
     UZ_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "uz_wgrad: ntaps=%d", d->ntaps);
     UZ_REQUIRE(d->Hr == d->H && d->Wr == d->W && d->dil >= 1, "uz_wgrad: conv taps need Hr==H");
+  } else if (d->taps_mode == UZ_TAPS_CONV_UP2) {
+    UZ_REQUIRE(d->ntaps == 9 && d->dil == 1 && d->Hr * 2 == d->H && d->Wr * 2 == d->W,
+               "uz_wgrad: upsampled R needs ntaps=9, dil=1, Hr=H/2, Wr=W/2");
   } else {
     UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && d->Hr == 2 * d->H &&
                    d->Wr == 2 * d->W,

@@ -34,6 +34,7 @@ struct Wg2Args {
   int units;            // K-steps in the whole tensor
   int upb;              // K-steps per split
   int tiles_j;
+  int r_up;  // 1: R lives at (H/2, W/2) and is read through nearest x2 upsampling
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -144,7 +145,12 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
         const unsigned off = ok ? pix * (unsigned)(a.ldl * 2) + p_coff[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
       } else {
-        const unsigned off = ok ? pix * (unsigned)(a.ldr * 2) + p_coff[i] : OOB;
+        unsigned rp = pix;
+        if (a.r_up) {
+          const int hh = h + p_rrel[i], ww = w0 + p_crel[i];
+          rp = (unsigned)((img * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1));
+        }
+        const unsigned off = ok ? rp * (unsigned)(a.ldr * 2) + p_coff[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
       }
     }
@@ -256,8 +262,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 }  // namespace
 
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
-  if (d->dtype != UZ_BF16 || d->taps_mode != UZ_TAPS_CONV) return 0;
-  if (!((d->ntaps == 9 && d->dil == 1) || d->ntaps == 1)) return 0;
+  const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
+  if (d->dtype != UZ_BF16 || !(d->taps_mode == UZ_TAPS_CONV || up)) return 0;
+  if (!((d->ntaps == 9 && d->dil == 1) || (d->ntaps == 1 && !up))) return 0;
   p->one_tap = d->ntaps == 1;
   if (d->Ci % 64 != 0 || d->Cj % 64 != 0) return 0;
   const int W = d->W, H = d->H;
@@ -266,7 +273,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   p->kr = 64 / p->kw;
   if (H % p->kr != 0) return 0;
   const long long lbytes = ((long long)d->N * H * W - 1) * d->ldl * 2 + (long long)d->Ci * 2;
-  const long long rbytes = ((long long)d->N * H * W - 1) * d->ldr * 2 + (long long)d->Cj * 2;
+  const long long rbytes = ((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2;
   if (lbytes >= (1LL << 31) || rbytes >= (1LL << 31)) return 0;
   p->big = (d->Ci % 128 == 0 && d->Cj % 128 == 0) ? 1 : 0;
   const int b = p->big ? 128 : 64;
@@ -294,7 +301,8 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.R = R;
   a.slab = slab;
   a.lbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldl * 2 + (long long)d->Ci * 2);
-  a.rbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldr * 2 + (long long)d->Cj * 2);
+  a.rbytes = (unsigned)(((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2);
+  a.r_up = d->taps_mode == UZ_TAPS_CONV_UP2 ? 1 : 0;
   a.N = d->N;
   a.H = d->H;
   a.W = d->W;

@@ -192,12 +192,18 @@ class Engine:
         return ops.im2col3x3_nchw(x.contiguous().float(), _round_up(9 * C, self.bk), self.dtype)
 
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
-                     pool: bool = False, im2col: bool = False) -> Tuple[Act, Optional[Act]]:
-        """Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
+                     pool: bool = False, im2col: bool = False, upsample: bool = False
+                     ) -> Tuple[Act, Optional[Act]]:
+        """[nearest x2 upsample ->] Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
 
         Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
-        u2net.py:10-17) and DownSample's pool (common_layers.py:90-95).  Returns (act, pooled)."""
+        u2net.py:10-17), DownSample's pool (common_layers.py:90-95) and UpConvBlock
+        (common_layers.py:69-76: the upsampled tensor is never materialised, the convolution reads
+        the half-resolution input at (h>>1, w>>1)).  Returns (act, pooled)."""
         N, H, W = x.N, x.H, x.W
+        if upsample:
+            H, W = 2 * H, 2 * W
+        tmode = L.TAPS_CONV_UP2 if upsample else L.TAPS_CONV
         Cout = conv.out_channels
         dil = conv.dilation[0]
         if im2col:
@@ -209,7 +215,8 @@ class Engine:
             ntaps = 9
         y = self.new_act(N, H, W, Cout)
         bias = conv.bias.detach() if conv.bias is not None else None
-        stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, want_stats=self.training)
+        stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, taps_mode=tmode,
+                               want_stats=self.training)
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
             vec = ops.bn_finalize(stats, y.P, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
@@ -258,8 +265,17 @@ class Engine:
                     self._give_grad(conv.weight, dw.contiguous())
                 else:
                     self._give_grad(conv.weight, ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=9,
-                                                           dil=dil, out=self._dst(conv.weight)))
-                    if x.needs_grad:
+                                                           dil=dil, taps_mode=tmode,
+                                                           out=self._dst(conv.weight)))
+                    if x.needs_grad and upsample:
+                        # gradient of the (virtual) upsampled tensor, then 2x2 sums
+                        du = self.new_act(N, H, W, x.C)
+                        ops.conv_igemm(dy, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, du,
+                                       ntaps=9, dil=dil)
+                        dx = self.new_act(x.N, x.H, x.W, x.C)
+                        ops.sum2x2(du, dx)
+                        x.add_grad(dx)
+                    elif x.needs_grad:
                         dx = self.new_act(N, H, W, x.C)
                         # per-channel sums of dx come for free from the kernel's statistics
                         # epilogue; a ConvTranspose2d feeding x takes its bias gradient from them
@@ -272,6 +288,85 @@ class Engine:
 
             self.tape.append(bwd)
         return act, pooled
+
+    def attention_gate(self, g: Act, x: Act, blk: nn.Module, out: Act) -> Act:
+        """out = x * sigmoid(BN(W_psi relu(BN(W_g g) + BN(W_x x)))), written into its concat slot.
+        Reference: AttentionBlock.forward (attention_unet.py:34-40); `blk` owns w_g, w_x, psi."""
+        conv_g, bn_g = blk.w_g[0], blk.w_g[1]
+        conv_x, bn_x = blk.w_x[0], blk.w_x[1]
+        conv_q, bn_q = blk.psi[0], blk.psi[1]
+        N, H, W, P = x.N, x.H, x.W, x.P
+        Fi = conv_g.out_channels
+        assert (g.N, g.H, g.W) == (N, H, W) and conv_q.out_channels == 1
+
+        def conv1x1_bn(src: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+            raw = self.new_act(N, H, W, conv.out_channels)
+            st = ops.conv_igemm(src, self._pack(conv.weight, L.PACK_CONV_FWD),
+                                conv.bias.detach() if conv.bias is not None else None, raw, ntaps=1,
+                                want_stats=self.training)
+            return raw, self._bn_vectors(bn, st, P)
+
+        g1, vec_g = conv1x1_bn(g, conv_g, bn_g)
+        x1, vec_x = conv1x1_bn(x, conv_x, bn_x)
+        wpsi = conv_q.weight.detach().reshape(Fi)
+        q, part = ops.attn_psi_fwd(g1, x1, vec_g, vec_x, wpsi,
+                                   conv_q.bias.detach() if conv_q.bias is not None else None)
+        vec_q = self._bn_vectors(bn_q, part, P)
+        ops.attn_gate_fwd(x, q, vec_q, out)
+
+        if self.record:
+            if not self.training:
+                raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+
+            def bwd():
+                dout = self._sum_grads(out, 1)
+                if not dout:
+                    return
+                dxd = self.new_act(N, H, W, x.C)
+                dz, a01 = ops.attn_bwd_psi(dout[0], x, q, vec_q, dxd)
+                dg1 = self.new_act(N, H, W, Fi)
+                dx1 = self.new_act(N, H, W, Fi)
+                tot = ops.attn_bwd_branches(g1, x1, q, dz, wpsi, vec_g, vec_x, vec_q, a01, dg1, dx1)
+                totf, a01f = tot.float(), a01.float()
+                self._give_grad(bn_q.weight, a01f[1:2])
+                self._give_grad(bn_q.bias, a01f[0:1])
+                self._give_grad(bn_g.weight, totf[Fi:2 * Fi])
+                self._give_grad(bn_g.bias, totf[0:Fi])
+                self._give_grad(bn_x.weight, totf[2 * Fi:3 * Fi])
+                self._give_grad(bn_x.bias, totf[0:Fi].clone())
+                self._give_grad(conv_q.weight, totf[3 * Fi:4 * Fi].reshape(conv_q.weight.shape))
+                for c in (conv_q, conv_g, conv_x):
+                    if c.bias is not None:
+                        self._give_grad(c.bias, None)   # a train-mode BatchNorm follows: analytically zero
+                self._give_grad(conv_g.weight, ops.wgrad(dg1, g, tuple(conv_g.weight.shape), ntaps=1,
+                                                         out=self._dst(conv_g.weight)))
+                self._give_grad(conv_x.weight, ops.wgrad(dx1, x, tuple(conv_x.weight.shape), ntaps=1,
+                                                         out=self._dst(conv_x.weight)))
+                if g.needs_grad:
+                    dg = self.new_act(N, H, W, g.C)
+                    ops.conv_igemm(dg1, self._pack(conv_g.weight, L.PACK_CONV_DGRAD), None, dg, ntaps=1)
+                    g.add_grad(dg)
+                if x.needs_grad:
+                    dxx = self.new_act(N, H, W, x.C)
+                    ops.conv_igemm(dx1, self._pack(conv_x.weight, L.PACK_CONV_DGRAD), None, dxx, ntaps=1)
+                    x.add_grad(dxx)
+                    x.add_grad(dxd)
+
+            self.tape.append(bwd)
+        return out
+
+    def _bn_vectors(self, bn: nn.BatchNorm2d, stats: Optional[torch.Tensor], count: int) -> torch.Tensor:
+        """(scale, shift, mean, invstd) rows for a BatchNorm: batch statistics + running-stat update
+        in training, running statistics in eval."""
+        if self.training:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            vec = ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
+                                  bn.running_mean, bn.running_var)
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            return vec
+        v2 = ops.bn_eval_scale(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        return torch.cat([v2, bn.running_mean.reshape(1, -1), torch.rsqrt(bn.running_var + bn.eps).reshape(1, -1)])
 
     def conv_transpose2x2(self, x: Act, m: nn.ConvTranspose2d, out: Act) -> Act:
         """ConvTranspose2d(k=2, s=2) written straight into its slot of the concat buffer.

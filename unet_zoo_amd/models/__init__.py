@@ -14,11 +14,12 @@ from typing import Any, Callable, Dict, List, Optional
 import torch.nn as nn
 
 from .unet import UNet
+from .attention_unet import AttentionUNet
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'unet': UNet,
-    'attention_unet': None,
+    'attention_unet': AttentionUNet,
     'transatt_unet': None,
     'raunet': None,
     'da_transformer': None,
@@ -103,4 +104,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']

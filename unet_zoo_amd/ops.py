@@ -188,6 +188,8 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     lib = L.load()
     if taps_mode == L.TAPS_CONV:
         N, H, W = x.N, x.H, x.W
+    elif taps_mode == L.TAPS_CONV_UP2:       # x is the half-resolution tensor
+        N, H, W = x.N, 2 * x.H, 2 * x.W
     else:
         N, H, W = x.N, x.H // 2, x.W // 2
     d = L.ConvDesc(L.dtype_code(x.dtype), N, H, W, x.H, x.W, x.C, x.ld,
@@ -201,20 +203,22 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     M, K, es = N * H * W, ntaps * x.C, x.buf.element_size()
     bn = 64 if d.Nout <= 64 else 128
     vec = 16 // es
-    if (taps_mode == L.TAPS_CONV and ntaps == 9 and dil == 1 and store_mode == L.STORE_PLAIN
+    if (taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) and ntaps == 9 and dil == 1 and store_mode == L.STORE_PLAIN
             and d.Nout % vec == 0 and y.ld % vec == 0):   # mirrors uz_direct_plan()
         tw_ = 32 if W >= 32 else 16
         ntl = N * ((H + 256 // tw_ - 1) // (256 // tw_)) * ((W + tw_ - 1) // tw_)
         if bn == 128 and ntl * ((d.Nout + 127) // 128) <= 128:
             bn = 64
         kname = f"conv3x3_direct_{_tname(x.dtype)}_bn{bn}" + ("_resident" if (bn == 64 and x.C == 8 * vec) else "")
+        if taps_mode == L.TAPS_CONV_UP2:
+            kname += "_up2"
     elif ((ntaps == 1 and taps_mode == L.TAPS_CONV) or (ntaps == 4 and taps_mode == L.TAPS_GATHER2X2)) \
             and d.Nout % vec == 0 and y.ld % vec == 0 and (store_mode == L.STORE_PLAIN or co % 64 == 0):
         kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
     else:
         kname = f"igemm_{_tname(x.dtype)}_128x{bn}"
     with _Timed(kname, 2.0 * M * d.Nout * K,
-                es * (x.P * x.C + M * d.Nout + d.Nout * K)):
+                        es * (x.P * x.C + M * d.Nout + d.Nout * K)):
         L.check(lib.uz_conv_igemm(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
                                   L.stream_ptr()), "uz_conv_igemm")
     return stats
@@ -235,7 +239,7 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
     kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
     W_ = Lt.W
-    if (Lt.dtype == torch.bfloat16 and taps_mode == L.TAPS_CONV and ((ntaps == 9 and dil == 1) or ntaps == 1)
+    if (Lt.dtype == torch.bfloat16 and taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) and ((ntaps == 9 and dil == 1) or ntaps == 1)
             and Lt.C % 64 == 0 and Rt.C % 64 == 0 and (W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0))
             and Lt.H % (64 // min(W_, 64)) == 0):   # mirrors uz_wgrad3x3_plan()
         big = Lt.C % 128 == 0 and Rt.C % 128 == 0
@@ -344,3 +348,73 @@ def colsum(x: Act) -> torch.Tensor:
     L.check(lib.uz_colsum(L.dtype_code(x.dtype), x.ptr(), x.ld, x.P, x.C, out.data_ptr(),
                           L.stream_ptr()), "uz_colsum")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# attention gate (AttentionBlock, attention_unet.py:34-40) and nearest-upsample backward
+def sum_rows(partial: torch.Tensor, rows: int, n: int) -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float64, device=partial.device)
+    L.check(L.load().uz_sum_rows(partial.data_ptr(), rows, n, out.data_ptr(), L.stream_ptr()), "uz_sum_rows")
+    return out
+
+
+def attn_grid(dtype: torch.dtype, P: int, channels: int) -> int:
+    return L.check_count(L.load().uz_attn_grid(L.dtype_code(dtype), P, channels), "uz_attn_grid")
+
+
+def attn_psi_fwd(g1: Act, x1: Act, vec_g, vec_x, wpsi: torch.Tensor, bpsi: Optional[torch.Tensor]):
+    """q[p] = b + sum_c relu(bn(g1)+bn(x1))*w ; returns (q fp32 [P], partial [G,2,1])"""
+    dev = g1.buf.device
+    G = attn_grid(g1.dtype, g1.P, g1.C)
+    q = torch.empty(g1.P, dtype=torch.float32, device=dev)
+    part = torch.empty((G, 2, 1), dtype=torch.float32, device=dev)
+    with _Timed("attn_psi_fwd", 0.0, g1.buf.element_size() * 2.0 * g1.P * g1.C):
+        L.check(L.load().uz_attn_psi_fwd(L.dtype_code(g1.dtype), g1.ptr(), g1.ld, x1.ptr(), x1.ld,
+                                         vec_g.data_ptr(), vec_x.data_ptr(), wpsi.data_ptr(), _p(bpsi),
+                                         g1.P, g1.C, q.data_ptr(), part.data_ptr(), L.stream_ptr()),
+                "uz_attn_psi_fwd")
+    return q, part
+
+
+def attn_gate_fwd(x: Act, q: torch.Tensor, vec_q: torch.Tensor, out: Act) -> None:
+    with _Timed("attn_gate_fwd", 0.0, x.buf.element_size() * 2.0 * x.P * x.C):
+        L.check(L.load().uz_attn_gate_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, q.data_ptr(), vec_q.data_ptr(),
+                                          x.P, x.C, out.ptr(), out.ld, L.stream_ptr()), "uz_attn_gate_fwd")
+
+
+def attn_bwd_psi(dout: Act, x: Act, q: torch.Tensor, vec_q: torch.Tensor, dxd: Act):
+    dev = x.buf.device
+    G = attn_grid(x.dtype, x.P, x.C)
+    dz = torch.empty(x.P, dtype=torch.float32, device=dev)
+    part = torch.empty((G, 2), dtype=torch.float32, device=dev)
+    with _Timed("attn_bwd_psi", 0.0, x.buf.element_size() * 3.0 * x.P * x.C):
+        L.check(L.load().uz_attn_bwd_psi(L.dtype_code(x.dtype), dout.ptr(), dout.ld, x.ptr(), x.ld, q.data_ptr(),
+                                         vec_q.data_ptr(), x.P, x.C, dxd.ptr(), dxd.ld, dz.data_ptr(),
+                                         part.data_ptr(), L.stream_ptr()), "uz_attn_bwd_psi")
+    return dz, sum_rows(part, G, 2)
+
+
+def attn_bwd_branches(g1: Act, x1: Act, q, dz, wpsi, vec_g, vec_x, vec_q, a01, dg1: Act, dx1: Act) -> torch.Tensor:
+    """reduce + apply passes; returns the float64 totals [4F+1] = (B0, B1, D1, dw_psi, sum dq)"""
+    lib = L.load()
+    F_, P = g1.C, g1.P
+    G = attn_grid(g1.dtype, P, F_)
+    part = torch.empty((G, 4 * F_ + 1), dtype=torch.float32, device=g1.buf.device)
+    code = L.dtype_code(g1.dtype)
+    common = (code, g1.ptr(), g1.ld, x1.ptr(), x1.ld, q.data_ptr(), dz.data_ptr(), wpsi.data_ptr(),
+              vec_g.data_ptr(), vec_x.data_ptr(), vec_q.data_ptr(), a01.data_ptr())
+    es = g1.buf.element_size()
+    with _Timed("attn_bwd_reduce", 0.0, es * 2.0 * P * F_):
+        L.check(lib.uz_attn_bwd_reduce(*common, P, F_, part.data_ptr(), L.stream_ptr()), "uz_attn_bwd_reduce")
+    tot = sum_rows(part, G, 4 * F_ + 1)
+    with _Timed("attn_bwd_apply", 0.0, es * 4.0 * P * F_):
+        L.check(lib.uz_attn_bwd_apply(*common, tot.data_ptr(), P, F_, dg1.ptr(), dg1.ld, dx1.ptr(), dx1.ld,
+                                      L.stream_ptr()), "uz_attn_bwd_apply")
+    return tot
+
+
+def sum2x2(du: Act, dx: Act) -> None:
+    """backward of nearest x2 upsampling: dx (coarse) = sum of the 2x2 fine pixels of du"""
+    with _Timed("sum2x2", 0.0, du.buf.element_size() * 1.25 * du.P * du.C):
+        L.check(L.load().uz_sum2x2(L.dtype_code(du.dtype), du.ptr(), du.ld, dx.N, dx.H, dx.W, dx.C, dx.ptr(),
+                                   dx.ld, L.stream_ptr()), "uz_sum2x2")
