@@ -40,7 +40,7 @@ from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
 
 
-def cpu_baseline(batch: int, hw: int, steps: int):
+def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
     """Reference step on the host CPU through the oracle (checker code, used here only as the
     reported baseline)."""
     from oracle import torch_ref
@@ -52,7 +52,7 @@ def cpu_baseline(batch: int, hw: int, steps: int):
         ncpu = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(16, ncpu)))
     torch.manual_seed(0)
-    m = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=1)
+    m = unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1)
     sd = m.state_dict()
     st = torch_ref.clone_state(sd, requires_grad=True)
     params = [v for v in st.values() if v.requires_grad]
@@ -62,7 +62,7 @@ def cpu_baseline(batch: int, hw: int, steps: int):
     for i in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss = F.binary_cross_entropy_with_logits(torch_ref.unet_forward(st, x, True), mask)
+        loss = F.binary_cross_entropy_with_logits(torch_ref.FORWARDS[model_name](st, x, True), mask)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
@@ -72,7 +72,7 @@ def cpu_baseline(batch: int, hw: int, steps: int):
     return {"value": round(batch / med, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
             "host_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": f"unet train step on CPU fp32, B={batch} 3x{hw}x{hw}, 1 warm-up + {steps} timed steps, median"}
+            "sample": f"{model_name} train step on CPU fp32, B={batch} 3x{hw}x{hw}, 1 warm-up + {steps} timed steps, median"}
 
 
 def main():
@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet"],
+                    help="unet = BASELINE configs[1] (the headline metric); attention_unet = configs[2] with --size 512")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -109,7 +111,7 @@ def main():
 
     run_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=1)
+    model = unet_zoo_amd.create_model(args.model, in_channels=3, num_classes=1)
     model.run_dtype = run_dtype
     model = model.to(dev).train()
     net = RcclDataParallel(model) if (world > 1 or args.force_dist) else model
@@ -271,11 +273,12 @@ def main():
                         "algorithmic_gbytes_per_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
                         "share_of_step": round(dom["ms"] / nprof / ms, 4)}
         line = {
-            "metric": "images/sec (fwd+bwd) at B=16 3x256x256, 1/2/4/8 MI355X",
+            "metric": "images/sec (fwd+bwd) at B=16 3x256x256, 1/2/4/8 MI355X" if (args.model, args.size, args.batch) == ("unet", 256, 16)
+                      else f"images/sec (fwd+bwd) {args.model} B={args.batch} 3x{args.size}x{args.size}",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"unet train step (zero_grad+fwd+BCE+bwd+clip+AdamW), B={args.batch}/GPU "
+            "config": {"workload": f"{args.model} train step (zero_grad+fwd+BCE+bwd+clip+AdamW), B={args.batch}/GPU "
                                    f"3x{args.size}x{args.size}, random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "fwd_bwd_ms": round(fb_ms, 3) if fb_ms else None,
@@ -286,7 +289,7 @@ def main():
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps, args.model)
         print(json.dumps(line), flush=True)
     if world > 1 or args.force_dist:
         dist.destroy_process_group()

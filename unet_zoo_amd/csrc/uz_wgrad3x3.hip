@@ -107,18 +107,20 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
       const int k = q * RPPL + lane / CPRL, pc = lane % CPRL;
       const int r = k >> a.kw_log2, c = k & (KW - 1);
       const int sw = (CPRL == 16) ? (k & 3) : ((k >> 1) & 1);
-      p_rrel[i] = r;
+      const int lchunk = (((pc >> 2) ^ sw) << 2) + (pc & 3);   // logical 16-byte chunk = 8 channels
+      p_rrel[i] = (ti0 + lchunk * 8 < a.Ci) ? r : -(1 << 20);  // channel tail -> zero fill
       p_crel[i] = c;
       p_delta[i] = r * a.W + c;
-      p_coff[i] = (ti0 * 2) + ((((pc >> 2) ^ sw) << 2) + (pc & 3)) * 16;
+      p_coff[i] = (ti0 * 2) + lchunk * 16;
     } else if (q < NLP + NRP) {
       const int t = (q - NLP) * RPPR + lane / CPRR, pc = lane % CPRR;
       const int trow = t / PWR, tcol = t - trow * PWR;
       const int sw = (CPRR == 16) ? (t & 3) : ((t >> 1) & 1);
-      p_rrel[i] = (trow < RR) ? trow + roff : -(1 << 20);
+      const int lchunk = (((pc >> 2) ^ sw) << 2) + (pc & 3);
+      p_rrel[i] = (trow < RR && tj0 + lchunk * 8 < a.Cj) ? trow + roff : -(1 << 20);
       p_crel[i] = tcol - HALO;
       p_delta[i] = (trow + roff) * a.W + tcol - HALO;
-      p_coff[i] = (tj0 * 2) + ((((pc >> 2) ^ sw) << 2) + (pc & 3)) * 16;
+      p_coff[i] = (tj0 * 2) + lchunk * 16;
     } else {
       p_rrel[i] = -(1 << 20);
       p_crel[i] = 0;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ti0 + wi * WTI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        slab[(size_t)ci * a.Cj + cj] = acc[i][tt][r];
+        if (ci < a.Ci && cj < a.Cj) slab[(size_t)ci * a.Cj + cj] = acc[i][tt][r];
       }
     }
   }
@@ -266,7 +268,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   if (d->dtype != UZ_BF16 || !(d->taps_mode == UZ_TAPS_CONV || up)) return 0;
   if (!((d->ntaps == 9 && d->dil == 1) || (d->ntaps == 1 && !up))) return 0;
   p->one_tap = d->ntaps == 1;
-  if (d->Ci % 64 != 0 || d->Cj % 64 != 0) return 0;
+  if (d->Ci % 8 != 0 || d->Cj % 8 != 0) return 0;
   const int W = d->W, H = d->H;
   if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return 0;
   p->kw = W < 64 ? W : 64;
@@ -277,8 +279,8 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   if (lbytes >= (1LL << 31) || rbytes >= (1LL << 31)) return 0;
   p->big = (d->Ci % 128 == 0 && d->Cj % 128 == 0) ? 1 : 0;
   const int b = p->big ? 128 : 64;
-  p->tiles_i = d->Ci / b;
-  p->tiles_j = d->Cj / b;
+  p->tiles_i = (d->Ci + b - 1) / b;
+  p->tiles_j = (d->Cj + b - 1) / b;
   p->kg = 1;
   p->units = (int)((long long)d->N * H * W / 64);
   const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : 1);

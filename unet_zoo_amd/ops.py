@@ -240,7 +240,7 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
     W_ = Lt.W
     if (Lt.dtype == torch.bfloat16 and taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) and ((ntaps == 9 and dil == 1) or ntaps == 1)
-            and Lt.C % 64 == 0 and Rt.C % 64 == 0 and (W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0))
+            and Lt.C % 8 == 0 and Rt.C % 8 == 0 and (W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0))
             and Lt.H % (64 // min(W_, 64)) == 0):   # mirrors uz_wgrad3x3_plan()
         big = Lt.C % 128 == 0 and Rt.C % 128 == 0
         kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + ("_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
