@@ -261,13 +261,29 @@ def main():
         # dominant kernel = the family with the largest summed duration
         dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
         roofline = None
+        # HBM traffic of the dominant kernel: from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md
+        # prescribes for gfx950) -- counters cannot be read from inside this process
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+            key = {"conv3x3_direct_bf16_bn128": "21conv3x3_direct_kernelIDF16bLi32ELi128ELb0EEEvNS_10DirectArgsE",
+                   "wgrad3x3_bf16_128x128_3tap": "wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>"}.get(dom_name)
+            if key in pmc and args.model == "unet" and args.size == 256 and args.batch == 16:
+                traffic = {"hbm_read_mb_per_launch": pmc[key]["hbm_read_mb_per_launch_corrected"],
+                           "hbm_write_mb_per_launch": pmc[key]["hbm_write_mb_per_launch"],
+                           "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 2 ** 20, 2),
+                           "source": "profiles/r01_pmc_traffic.json"}
+        except (OSError, KeyError, ValueError):
+            pass
         if dom is not None:
             flops_per_launch = dom["flops"] / dom["launches"]
             sec_per_launch = dom["ms"] * 1e-3 / dom["launches"]
             ach = flops_per_launch / sec_per_launch / 1e12
             peak = PEAK["mfma_bf16_tflops"] if run_dtype == torch.bfloat16 else PEAK["mfma_f32_tflops"]
             roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                         "launches_per_step": dom["launches"] // nprof,
                         "avg_launch_us": round(sec_per_launch * 1e6, 2),
                         "algorithmic_gbytes_per_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),

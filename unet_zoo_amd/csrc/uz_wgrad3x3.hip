@@ -35,6 +35,7 @@ struct Wg2Args {
   int upb;              // K-steps per split
   int tiles_j;
   int r_up;  // 1: R lives at (H/2, W/2) and is read through nearest x2 upsampling
+  int flags; // tuning switches (env UZ_TUNE): bit 2 = plain workgroup order
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -86,9 +87,24 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   const int tg = wave / (WI * WJ), wij = wave % (WI * WJ);
   const int wi = wij / WJ, wj = wij % WJ;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int ti0 = (blockIdx.x / a.tiles_j) * BI, tj0 = (blockIdx.x % a.tiles_j) * BJ;
-  const int ty_blk = (NTY == 1 && NTX == 3) ? blockIdx.y : 0;
-  const int u_beg = blockIdx.z * a.upb;
+  // work item = (channel tile, kernel row ty, pixel split z).  The three kernel rows of one
+  // (tile, z) read the same dy tile and overlapping x rows: give them workgroup ids that differ by
+  // multiples of 8 so that they share an XCD (one L2) and run at about the same time (speed only).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (NTY == 1 && NTX == 3) {
+    const int U = gridDim.x * gridDim.z;           // (tile, z) pairs
+    if ((U & 7) == 0 && !(a.flags & 4)) {
+      const int id = blockIdx.x + gridDim.x * (blockIdx.y + 3 * blockIdx.z);
+      const int xcd = id & 7, j = id >> 3;
+      by = j % 3;
+      const int u = (j / 3) * 8 + xcd;
+      bx = u % (int)gridDim.x;
+      bz = u / (int)gridDim.x;
+    }
+  }
+  const int ti0 = (bx / a.tiles_j) * BI, tj0 = (bx % a.tiles_j) * BJ;
+  const int ty_blk = (NTY == 1 && NTX == 3) ? by : 0;
+  const int u_beg = bz * a.upb;
   const int u_end = (u_beg + a.upb < a.units) ? u_beg + a.upb : a.units;
   const int nu = u_end - u_beg;
   const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.L), 0, a.lbytes, 0x00020000);
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
     const int tw = tg * NTW + tt;
     if (tw >= NTAP) continue;  // wave-uniform
     const int tap = (NTY == 3 || NTX == 1) ? tw : ty_blk * 3 + tw;
-    float* slab = a.slab + ((size_t)blockIdx.z * (NTX == 1 ? 1 : 9) + tap) * (size_t)a.Ci * a.Cj;
+    float* slab = a.slab + ((size_t)bz * (NTX == 1 ? 1 : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int cj = tj0 + wj * WTJ + l31;
@@ -292,6 +308,21 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   if (split < 1) split = 1;
   p->upb = (int)((p->units + split - 1) / split);
   p->split = (p->units + p->upb - 1) / p->upb;
+  if (p->big && !p->one_tap) {
+    // make (tiles * split) a multiple of 8 when a nearby split allows it (XCD-aware id remap)
+    const long long tiles = (long long)p->tiles_i * p->tiles_j;
+    for (int ds = 0; ds < 8; ++ds) {
+      const long long s2 = split - ds;
+      if (s2 < 1) break;
+      const int upb2 = (int)((p->units + s2 - 1) / s2);
+      const int sp2 = (p->units + upb2 - 1) / upb2;
+      if ((tiles * sp2) % 8 == 0) {
+        p->upb = upb2;
+        p->split = sp2;
+        break;
+      }
+    }
+  }
   p->nslabs = p->split * p->kg;
   return 1;
 }
@@ -305,6 +336,7 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.lbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldl * 2 + (long long)d->Ci * 2);
   a.rbytes = (unsigned)(((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2);
   a.r_up = d->taps_mode == UZ_TAPS_CONV_UP2 ? 1 : 0;
+  a.flags = uz_tune_flags();
   a.N = d->N;
   a.H = d->H;
   a.W = d->W;
