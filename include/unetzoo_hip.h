@@ -166,6 +166,12 @@ int uz_bn_eval_scale(int C, const float* gamma, const float* beta, const float* 
 int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
                      int N, int H, int W, int C, void* act, int lda, void* pooled, int ldp,
                      void* stream);
+/* Same with a residual: act = relu(scale*y + shift) + res, pooled = MaxPool2d(2,2)(act).
+ * Replaces the RSU block tail `hx1d + hxin` (u2net.py:74,119,157,188,213) and the stage pools
+ * (u2net.py:221-229).  res == NULL is uz_bn_relu_apply. */
+int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                         int N, int H, int W, int C, const void* res, int ldr, void* act, int lda,
+                         void* pooled, int ldp, void* stream);
 
 /* Backward of (BN train -> ReLU [-> MaxPool2d(2,2)]) in two passes.
  * The gradient arriving at the activation is
@@ -231,6 +237,44 @@ int uz_sum_rows(const float* partial, int rows, int n, double* out, void* stream
 /* backward of nearest x2 upsampling: dx[coarse pixel] = sum of its 2x2 fine pixels (H, W coarse) */
 int uz_sum2x2(int dtype, const void* du, int ldu, int N, int H, int W, int C, void* dx, int lddx,
               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * U^2-Net pieces (reference: unet_zoo/models/u2net.py).
+ * ------------------------------------------------------------------------------------------- */
+/* F.interpolate(mode='bilinear', align_corners=False, size=(Ho, Wo)) (u2net.py:19-22).
+ * Element (n, h, w, c) of x lives at x[n*x_img_stride + (h*Wi + w)*ldx + c] (strides in elements),
+ * likewise y: NHWC activations (ld = channel count of the holding buffer) and NCHW 1-channel logit
+ * planes (ld = 1, C = 1) go through the same entry point. */
+int uz_bilinear_fwd(int dtype, const void* x, int ldx, long long x_img_stride, int N, int Hi, int Wi,
+                    int C, void* y, int ldy, long long y_img_stride, int Ho, int Wo, void* stream);
+/* its backward: g at (Ho, Wo) -> dx at (Hi, Wi), overwritten (gather form, deterministic) */
+int uz_bilinear_bwd(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi,
+                    int C, void* dx, int lddx, long long dx_img_stride, int Ho, int Wo, void* stream);
+/* out = g0 + g1 + unpool(gp): total gradient of `act` consumed directly (g0, g1 may be NULL) and through
+ * MaxPool2d(2,2) (gp at (H/2, W/2), routed to the first maximum of each window as ATen does). */
+int uz_pool_grad_combine(int dtype, int N, int H, int W, int C, const void* act, int lda, const void* g0,
+                         int ldg0, const void* g1, int ldg1, const void* gp, int ldgp, void* out, int ldo,
+                         void* stream);
+/* Side head Conv2d(C, 1, 3, padding=1) (u2net.py:238-243): x NHWC, w = the (1, C, 3, 3) fp32 parameter,
+ * bias 1 value or NULL, out[n*out_img_stride + h*W + w] fp32; taps_ws: N*9*H*W floats of scratch. */
+int uz_sideconv3x3_fwd(int dtype, const void* x, int ldx, int N, int H, int W, int C, const float* w,
+                       const float* bias, float* taps_ws, float* out, long long out_img_stride,
+                       void* stream);
+long long uz_sideconv3x3_bwd_workspace_bytes(int dtype, int N, int H, int W, int C);
+/* g[n*g_img_stride + hw] = d(loss)/d(out); dx (NHWC, may be NULL), dw (1, C, 3, 3), db (1 value or NULL) */
+int uz_sideconv3x3_bwd(int dtype, const void* x, int ldx, int N, int H, int W, int C, const float* w,
+                       const float* g, long long g_img_stride, void* dx, int lddx, float* dw, float* db,
+                       void* workspace, void* stream);
+/* Fuse conv Conv2d(Cc, K, 1) on the NCHW fp32 concat d (N, Cc, HW) of the side maps (u2net.py:244,288) */
+int uz_fuse1x1_fwd(const float* d, int N, int HW, int Cc, int K, const float* w, const float* b,
+                   float* out, void* stream);
+long long uz_fuse1x1_bwd_workspace_bytes(int N, int HW, int Cc, int K);
+/* dcat = W^T g (+ g_extra[s] added onto channels [s*K, (s+1)*K): the gradients that arrive at the
+ * side outputs themselves; host array of n_extra = Cc/K device pointers, entries may be NULL; n_extra
+ * may be 0), dw (K, Cc), db (K).  g == NULL: only the extras flow, dw = db = 0. */
+int uz_fuse1x1_bwd(const float* d, int N, int HW, int Cc, int K, const float* w, const float* g,
+                   const float* const* g_extra, int n_extra, float* dcat, float* dw, float* db,
+                   void* workspace, void* stream);
 
 /* out[c] = sum_p x[p*ld + c] (fp32; out zeroed by caller). ConvTranspose2d bias gradient. */
 int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* stream);

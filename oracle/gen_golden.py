@@ -123,8 +123,59 @@ def write_attention_unet():
              bn_keys=("conv1.conv.1", "att5.psi.1", "att2.w_g.1", "up2.up.2", "upconv2.conv.4"))
 
 
+def write_u2net():
+    """u2net: seed-0 U2NET(3, 1), B=2 3x64x64 train step with the summed
+    seven-head BCE loss of the reference's training loop (training_loop.py:24-32, 60-64), all seven
+    maps kept; reduced from the BASELINE config's 512x512 as SURVEY §8c allows."""
+    mods = load_reference("u2net")
+    torch.manual_seed(0)
+    model = mods["u2net"].U2NET(in_ch=3, out_ch=1)
+    write_manifest(model, "u2net")
+    B, H, W, tag = 2, 64, 64, "u2net_b2_64"
+    x, mask = synthetic_batch(B, 3, H, W, seed=1)
+    model.train()
+    outs = model(x)
+    loss = sum(F.binary_cross_entropy_with_logits(v, mask) for v in outs.values())
+    model.zero_grad()
+    loss.backward()
+    named = list(model.named_parameters())
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)).item()
+    arrays = {}
+    meta = {"model": "u2net", "B": B, "H": H, "W": W, "input_sha256": sha(x), "mask_sha256": sha(mask),
+            "loss": loss.item(), "global_grad_norm": gnorm, "keys": list(outs.keys()),
+            "grad_l2": {n: p.grad.double().norm().item() for n, p in named},
+            "train_positive_pixels": {k: int((v > 0).sum().item()) for k, v in outs.items()}}
+    for k, v in outs.items():
+        arrays["train/" + k] = v.detach().numpy()
+    for n, p in named:
+        gi = sample_idx(p.numel(), 64)
+        arrays["gidx/" + n] = gi
+        arrays["gval/" + n] = p.grad.flatten()[gi].numpy()
+    sd = model.state_dict()
+    bn_keys = ("stage1.rebnconvin.bn_s1", "stage1.rebnconv7.bn_s1", "stage5.rebnconv4.bn_s1", "stage6.rebnconv1d.bn_s1",
+               "stage3d.rebnconv2d.bn_s1", "stage1d.rebnconv1d.bn_s1")
+    meta["bn_keys"] = list(bn_keys)
+    for k in bn_keys:
+        arrays["rm/" + k] = sd[k + ".running_mean"].numpy()
+        arrays["rv/" + k] = sd[k + ".running_var"].numpy()
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)
+    for k, v in ev.items():
+        arrays["eval/" + k] = v.numpy()
+    meta["eval_positive_pixels"] = {k: int((v > 0).sum().item()) for k, v in ev.items()}
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **arrays)
+    with open(os.path.join(OUT, f"{tag}.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(tag, "loss", meta["loss"], "gnorm", gnorm)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["u2net"]:
+        torch.set_num_threads(8)
+        write_u2net()
+        return
     torch.set_num_threads(8)
     mods = load_reference("common_layers", "unet")
     RefUNet = mods["unet"].UNet
@@ -151,6 +202,7 @@ def main():
     torch.manual_seed(0)
     model = RefUNet(in_channels=3, num_classes=1)
     run_case(model, 2, 256, 256, "unet_b2_256", full_logits=False)
+    write_u2net()
 
 
 if __name__ == "__main__":

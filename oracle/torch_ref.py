@@ -18,22 +18,42 @@ import torch.nn.functional as F
 
 State = Dict[str, torch.Tensor]
 
+# Optional storage-rounding model.  None (default): the reference's fp32 arithmetic.  torch.bfloat16:
+# every tensor the HIP engine STORES in bf16 (image, conv weights, conv outputs, activations, resized
+# maps) is rounded to bf16 at the same point, arithmetic in between stays fp32 — this separates "the
+# product rounds to bf16 here" from "a kernel computes the wrong thing" on networks whose low-sample
+# BatchNorms amplify rounding (u2net: see DESIGN.md).  Only conv_bn_relu/upsample_like honour it.
+_STORE_DTYPE = None
+
+
+def set_storage_rounding(dtype) -> None:
+    global _STORE_DTYPE
+    _STORE_DTYPE = dtype
+
+
+def _q(t: torch.Tensor) -> torch.Tensor:
+    return t if _STORE_DTYPE is None else t.to(_STORE_DTYPE).float()
+
+
 
 # ---------------------------------------------------------------------------------------------
 # primitives
 # ---------------------------------------------------------------------------------------------
 def conv_bn_relu(x: torch.Tensor, sd: State, conv: str, bn: str, training: bool,
-                 dilation: int = 1) -> torch.Tensor:
+                 dilation: int = 1, residual: torch.Tensor = None) -> torch.Tensor:
     """Conv2d(k3, padding=dilation) -> BatchNorm2d -> ReLU.
     unet_zoo/models/common_layers.py:28-30 (and :31-33, :47-56; u2net.py:10-17 with dilation).
     Train mode: batch mean / biased variance, running stats updated with momentum 0.1 and the
     unbiased variance (torch.nn.BatchNorm2d defaults, eps 1e-5)."""
-    x = F.conv2d(x, sd[conv + ".weight"], sd.get(conv + ".bias"), padding=dilation, dilation=dilation)
+    x = _q(F.conv2d(_q(x), _q(sd[conv + ".weight"]), sd.get(conv + ".bias"), padding=dilation, dilation=dilation))
     x = F.batch_norm(x, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"],
                      sd[bn + ".bias"], training=training, momentum=0.1, eps=1e-5)
     if training and (bn + ".num_batches_tracked") in sd:
         sd[bn + ".num_batches_tracked"] += 1
-    return F.relu(x)
+    x = F.relu(x)
+    if residual is not None:  # RSU tail `hx1d + hxin` (u2net.py:74)
+        x = x + residual
+    return _q(x)
 
 
 def double_conv(x: torch.Tensor, sd: State, prefix: str, training: bool) -> torch.Tensor:
@@ -122,7 +142,102 @@ def attention_unet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.
     return F.conv2d(d, sd["conv_1x1.weight"], sd["conv_1x1.bias"])
 
 
-FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward}
+# ---------------------------------------------------------------------------------------------
+# U^2-Net (unet_zoo/models/u2net.py)
+# ---------------------------------------------------------------------------------------------
+def rebnconv(x, sd: State, prefix: str, training: bool, dirate: int = 1, residual=None) -> torch.Tensor:
+    """REBNCONV.forward — u2net.py:6-17: Conv3x3(dilation=d, padding=d) -> BN -> ReLU."""
+    return conv_bn_relu(x, sd, f"{prefix}.conv_s1", f"{prefix}.bn_s1", training, dilation=dirate,
+                        residual=residual)
+
+
+def upsample_like(src: torch.Tensor, tar: torch.Tensor) -> torch.Tensor:
+    """_upsample_like — u2net.py:19-22."""
+    return _q(F.interpolate(src, size=tar.shape[2:], mode="bilinear", align_corners=False))
+
+
+def rsu(x, sd: State, prefix: str, training: bool, depth: int) -> torch.Tensor:
+    """RSU7/6/5/4.forward — u2net.py:48-74, 97-119, 139-157, 174-188 (depth = 7, 6, 5, 4):
+    in-conv, `depth-1` encoder convs with ceil-mode 2x2 pools between them, one dilation-2 conv at the
+    bottom, decoder convs on cat((upsampled, skip), 1), residual with the in-conv output."""
+    hxin = rebnconv(x, sd, f"{prefix}.rebnconvin", training)
+    skips = []
+    hx = hxin
+    for i in range(1, depth):
+        hx = rebnconv(hx, sd, f"{prefix}.rebnconv{i}", training)
+        skips.append(hx)
+        if i < depth - 1:
+            hx = F.max_pool2d(hx, 2, stride=2, ceil_mode=True)
+    hx = rebnconv(skips[-1], sd, f"{prefix}.rebnconv{depth}", training, dirate=2)
+    for i in range(depth - 1, 0, -1):
+        skip = skips[i - 1]
+        if hx.shape[2:] != skip.shape[2:]:
+            hx = upsample_like(hx, skip)
+        hx = rebnconv(torch.cat((hx, skip), 1), sd, f"{prefix}.rebnconv{i}d", training,
+                      residual=hxin if i == 1 else None)   # `hx1d + hxin`
+    return hx
+
+
+def rsu4f(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """RSU4F.forward — u2net.py:203-213: dilations 1,2,4,8 down, 4,2,1 up, no resampling."""
+    hxin = rebnconv(x, sd, f"{prefix}.rebnconvin", training)
+    hx1 = rebnconv(hxin, sd, f"{prefix}.rebnconv1", training, 1)
+    hx2 = rebnconv(hx1, sd, f"{prefix}.rebnconv2", training, 2)
+    hx3 = rebnconv(hx2, sd, f"{prefix}.rebnconv3", training, 4)
+    hx4 = rebnconv(hx3, sd, f"{prefix}.rebnconv4", training, 8)
+    hx3d = rebnconv(torch.cat((hx4, hx3), 1), sd, f"{prefix}.rebnconv3d", training, 4)
+    hx2d = rebnconv(torch.cat((hx3d, hx2), 1), sd, f"{prefix}.rebnconv2d", training, 2)
+    return rebnconv(torch.cat((hx2d, hx1), 1), sd, f"{prefix}.rebnconv1d", training, 1, residual=hxin)  # hx1d + hxin
+
+
+_U2NET_STAGES = (("stage1", 7), ("stage2", 6), ("stage3", 5), ("stage4", 4), ("stage5", 0), ("stage6", 0))
+
+
+def _u2_stage(x, sd, name, depth, training):
+    return rsu4f(x, sd, name, training) if depth == 0 else rsu(x, sd, name, training, depth)
+
+
+def u2net_forward(sd: State, x: torch.Tensor, training: bool) -> Dict[str, torch.Tensor]:
+    """U2NET.forward — u2net.py:246-298.  Returns the reference's dict of seven logit maps."""
+    enc = []
+    hx = x
+    for i, (name, depth) in enumerate(_U2NET_STAGES):
+        h = _u2_stage(hx, sd, name, depth, training)
+        enc.append(h)
+        if i < 5:
+            hx = F.max_pool2d(h, 2, stride=2, ceil_mode=True)
+    dec = {6: enc[5]}
+    cur = enc[5]
+    for lvl, depth in ((5, 0), (4, 4), (3, 5), (2, 6), (1, 7)):
+        up = upsample_like(cur, enc[lvl - 1])
+        cur = _u2_stage(torch.cat((up, enc[lvl - 1]), 1), sd, f"stage{lvl}d", depth, training)
+        dec[lvl] = cur
+    sides = []
+    for k in range(1, 7):
+        d = F.conv2d(dec[k], sd[f"side{k}.weight"], sd[f"side{k}.bias"], padding=1)
+        if k > 1:  # fp32 logit planes: never rounded
+            d = F.interpolate(d, size=sides[0].shape[2:], mode="bilinear", align_corners=False)
+        sides.append(d)
+    d0 = F.conv2d(torch.cat(sides, 1), sd["outconv.weight"], sd["outconv.bias"])
+    out = {"main": d0}
+    for k in range(6):
+        out[f"side{k + 1}"] = sides[k]
+    return out
+
+
+def model_loss(outputs, mask: torch.Tensor) -> torch.Tensor:
+    """BCEWithLogits on a tensor output; on U2Net's dict the unit-weighted sum over the seven heads
+    (unet_zoo/utils/training_loop.py:24-32, 60-64; every head is at the mask's resolution)."""
+    if isinstance(outputs, dict):
+        total = None
+        for v in outputs.values():
+            l = F.binary_cross_entropy_with_logits(v, mask)
+            total = l if total is None else total + l
+        return total
+    return F.binary_cross_entropy_with_logits(outputs, mask)
+
+
+FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward}
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":
@@ -145,10 +260,14 @@ def train_step_reference(model_name: str, sd: State, x: torch.Tensor, mask: torc
     Returns (logits, loss, {param name: grad}, updated state with new running stats)."""
     st = clone_state(sd, requires_grad=True)
     logits = FORWARDS[model_name](st, x.float().cpu(), True)
-    loss = F.binary_cross_entropy_with_logits(logits, mask.float().cpu())
+    loss = model_loss(logits, mask.float().cpu())
     names = [k for k, v in st.items() if v.requires_grad]
     grads = torch.autograd.grad(loss, [st[k] for k in names])
-    return logits.detach(), loss.detach(), dict(zip(names, grads)), st
+    if isinstance(logits, dict):
+        logits = {k: v.detach() for k, v in logits.items()}
+    else:
+        logits = logits.detach()
+    return logits, loss.detach(), dict(zip(names, grads)), st
 
 
 def synthetic_batch(B: int, C: int, H: int, W: int, seed: int = 1):

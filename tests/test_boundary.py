@@ -84,6 +84,6 @@ def test_library_loads_and_exports_header_symbols():
 
 def test_bad_descriptor_is_rejected_without_a_gpu():
     lib = _lib.load()
-    d = _lib.ConvDesc(_lib.UZ_BF16, 1, 8, 8, 8, 8, 24, 24, 64, 64, 9, 0, 1, 0, 0)  # Cin % 64 != 0
+    d = _lib.ConvDesc(_lib.UZ_BF16, 1, 8, 8, 8, 8, 20, 24, 64, 64, 9, 0, 1, 0, 0)  # Cin % 8 != 0
     assert lib.uz_conv_igemm_grid_m(ctypes.byref(d)) == -1
     assert b"Cin" in lib.uz_last_error_string()

@@ -28,6 +28,9 @@ EXPORTS = (
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_colsum",
     "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd", "uz_attn_bwd_psi", "uz_attn_bwd_reduce",
     "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum2x2",
+    "uz_bn_relu_add_apply", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_pool_grad_combine",
+    "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
+    "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
 )
 
 
@@ -108,6 +111,17 @@ def load():
                                       vp, ip, vp]
     lib.uz_sum_rows.argtypes = [vp, ip, ip, vp, vp]
     lib.uz_sum2x2.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, vp]
+    ll = ctypes.c_longlong
+    lib.uz_bn_relu_add_apply.argtypes = [ip, vp, ip, vp, vp, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, vp]
+    lib.uz_bilinear_fwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, vp]
+    lib.uz_bilinear_bwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, vp]
+    lib.uz_pool_grad_combine.argtypes = [ip, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, vp, ip, vp, ip, vp]
+    lib.uz_sideconv3x3_fwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp, vp, vp, ll, vp]
+    lib.uz_sideconv3x3_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]
+    lib.uz_sideconv3x3_bwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp, ll, vp, ip, vp, vp, vp, vp]
+    lib.uz_fuse1x1_fwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, vp, vp]
+    lib.uz_fuse1x1_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip]
+    lib.uz_fuse1x1_bwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, POINTER(c_void_p), ip, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("uz_last_error_string",):

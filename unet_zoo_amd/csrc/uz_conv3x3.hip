@@ -94,12 +94,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
   // chunk (lane&7), which must hold logical chunk (lane&7) ^ swz(row).  Everything is recomputed
   // from i when a piece is issued (a handful of VALU ops) instead of living in registers.
   unsigned b_row_off[NBP];
-  int b_coff[NBP];
+  int b_ch[NBP];  // first channel (inside a slab) of the logical chunk this lane fetches
 #pragma unroll
   for (int i = 0; i < NBP; ++i) {
     const int n = (wave + 8 * i) * 8 + (lane >> 3);
     b_row_off[i] = (n0 + n < a.Nout) ? (unsigned)(n0 + n) * (unsigned)a.K * ES : OOB;
-    b_coff[i] = (((lane & 7) ^ ((n >> 1) & 7)) * VEC) * ES;
+    b_ch[i] = ((lane & 7) ^ ((n >> 1) & 7)) * VEC;
   }
   // ---- per-lane constants of the MFMA fragment reads ----------------------------------------
   // M tile mt = 2 wm + i: 32 pixels = one patch row (TW 32) or two half rows (TW 16)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     b_sw[j] = (brow >> 1) & 7;
   }
 
-  const int ncb = a.Cin / BK;
+  const int ncb = (a.Cin + BK - 1) / BK;  // the last slab may be partial: channels >= Cin read as zero
   float s1[TN], s2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
@@ -139,17 +139,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     const int r = piece * 8 + (lane >> 3);
     const int pi = r / PW, pj = r - pi * PW;
     const int hh = hh0 - 1 + pi, ww = ww0 - 1 + pj;
-    const bool ok = r < PROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
-    const int coff = (((lane & 7) ^ ((r >> 1) & 7)) * VEC) * ES;
+    const int ch = cb * BK + ((lane & 7) ^ ((r >> 1) & 7)) * VEC;
+    const bool ok = r < PROWS && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && ch < a.Cin;
     const unsigned pix = a.ups ? (unsigned)((im * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1))
                                : (unsigned)((im * a.H + hh) * a.W + ww);
-    const unsigned off = ok ? (pix * (unsigned)a.ldx + cb * BK) * ES + coff : OOB;
+    const unsigned off = ok ? (pix * (unsigned)a.ldx + ch) * ES : OOB;
     dma16(xr, smem + buf * A_BYTES + piece * 1024, off);
   };
   auto issue_b = [&](int slot, int cb, int tap) {
 #pragma unroll
     for (int i = 0; i < NBP; ++i) {
-      const unsigned off = b_row_off[i] == OOB ? OOB : b_row_off[i] + (tap * a.Cin + cb * BK) * ES + b_coff[i];
+      const int ch = cb * BK + b_ch[i];
+      const unsigned off = (b_row_off[i] == OOB || ch >= a.Cin) ? OOB : b_row_off[i] + (tap * a.Cin + ch) * ES;
       dma16(wr, sB + slot * B_STAGE + (wave + 8 * i) * 1024, off);
     }
   };
@@ -411,7 +412,7 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
   if (!(d->taps_mode == UZ_TAPS_CONV || up) || d->ntaps != 9 || d->dil != 1 || d->store_mode != UZ_STORE_PLAIN) return 0;
   if (up && ((d->H & 1) || (d->W & 1) || d->Hin * 2 != d->H || d->Win * 2 != d->W)) return 0;
   const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4, bk = 8 * vec;
-  if (d->Cin % bk != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
+  if (d->Cin % vec != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
   const long long xbytes = ((long long)d->N * d->Hin * d->Win - 1) * d->ldx * es + (long long)d->Cin * es;
   const long long wbytes = (long long)d->Nout * 9 * d->Cin * es;
   if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31)) return 0;

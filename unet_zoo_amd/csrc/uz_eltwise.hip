@@ -86,7 +86,9 @@ __global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* bet
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
     const T* __restrict__ y, int ldy, const float* __restrict__ scale, const float* __restrict__ shift,
-    int N, int H, int W, int C, T* __restrict__ act, int lda, T* __restrict__ pooled, int ldp) {
+    int N, int H, int W, int C, T* __restrict__ act, int lda, T* __restrict__ pooled, int ldp,
+    const T* __restrict__ res, int ldr) {
+  // res != nullptr: act = relu(bn(y)) + res (the RSU residual, u2net.py:74), pooled = maxpool(act)
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CC = C / VEC;
   const int Ho = H >> 1, Wo = W >> 1;
@@ -107,6 +109,12 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
       load_f(y + (size_t)u * ldy + c0, v);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+      if (res != nullptr) {
+        float r[VEC];
+        load_f(res + (size_t)u * ldr + c0, r);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] += r[i];
+      }
       store_f(act + (size_t)u * lda + c0, v);
     } else {
       const int wo = (int)(u % Wo);
@@ -118,11 +126,13 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const size_t p = p00 + (k >> 1) * W + (k & 1);
-        float v[VEC];
+        float v[VEC], r[VEC];
         load_f(y + p * ldy + c0, v);
+        if (res != nullptr) load_f(res + p * ldr + c0, r);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+          if (res != nullptr) v[i] = (float)(T)(v[i] + r[i]);  // the pool sees the stored value
           m[i] = (k == 0) ? v[i] : fmaxf(m[i], v[i]);
         }
         store_f(act + p * lda + c0, v);
@@ -693,36 +703,48 @@ extern "C" int uz_bn_eval_scale(int C, const float* gamma, const float* beta, co
 
 template <typename T>
 static int bn_relu_apply_t(const void* y, int ldy, const float* scale, const float* shift, int N, int H,
-                           int W, int C, void* act, int lda, void* pooled, int ldp, hipStream_t s) {
+                           int W, int C, void* act, int lda, void* pooled, int ldp, const void* res, int ldr,
+                           hipStream_t s) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (pooled != nullptr) {
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)pooled, ldp);
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)pooled, ldp, (const T*)res, ldr);
   } else {
     const long long total = (long long)N * H * W * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0);
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr);
   }
   UZ_LAUNCH_CHECK("uz_bn_relu_apply");
   return UZ_OK;
 }
 
+extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                                    int N, int H, int W, int C, const void* res, int ldr, void* act, int lda,
+                                    void* pooled, int ldp, void* stream);
+
 extern "C" int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
                                 int N, int H, int W, int C, void* act, int lda, void* pooled, int ldp,
                                 void* stream) {
+  return uz_bn_relu_add_apply(dtype, y, ldy, scale, shift, N, H, W, C, nullptr, 0, act, lda, pooled, ldp, stream);
+}
+
+extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
+                                    int N, int H, int W, int C, const void* res, int ldr, void* act, int lda,
+                                    void* pooled, int ldp, void* stream) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_bn_relu_apply: bad dtype");
   const int vec = dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(y && scale && shift && act, "uz_bn_relu_apply: null pointer");
   UZ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "uz_bn_relu_apply: C=%d must be a multiple of %d", C, vec);
   UZ_REQUIRE(ldy % vec == 0 && lda % vec == 0 && ldy >= C && lda >= C, "uz_bn_relu_apply: bad ld");
+  if (res != nullptr) UZ_REQUIRE(ldr % vec == 0 && ldr >= C, "uz_bn_relu_apply: bad ldr");
   if (pooled != nullptr) {
     UZ_REQUIRE(H % 2 == 0 && W % 2 == 0, "uz_bn_relu_apply: fused pool needs even H, W (got %dx%d)", H, W);
     UZ_REQUIRE(ldp % vec == 0 && ldp >= C, "uz_bn_relu_apply: bad ldp");
   }
   hipStream_t s = (hipStream_t)stream;
-  return dtype == UZ_BF16 ? bn_relu_apply_t<bf16_t>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, s)
-                          : bn_relu_apply_t<float>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, s);
+  return dtype == UZ_BF16 ? bn_relu_apply_t<bf16_t>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, res, ldr, s)
+                          : bn_relu_apply_t<float>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, res, ldr, s);
 }
 
 static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, const void* gp) {

@@ -70,15 +70,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   for (int i = 0; i < BR; ++i) {
     const int n = n0 + lr + 32 * i;
     bval[i] = n < a.Nout;
-    bptr[i] = wg + (size_t)(bval[i] ? n : 0) * a.K + lc * VEC;
+    bptr[i] = wg + (size_t)(bval[i] ? n : 0) * a.K;
   }
 
   float s1[TN], s2[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) s1[i] = s2[i] = 0.f;
 
-  const int nk = a.K / BK;
-  const int cpt = a.Cin / BK;  // K-steps per tap
+  const int cpt = (a.Cin + BK - 1) / BK;  // K-steps per tap; the last slab may be partial (zeros)
+  const int nk = a.ntaps * cpt;
   const int HW = a.H * a.W;
   const int st_sw = ((lr >> 1) & 7);       // store-side swizzle (row = lr + 32 i)
   const int ld_sw = ((l31 >> 1) & 7);      // read-side swizzle (row = 32 j + l31)
@@ -125,20 +125,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         dx = tap & 1;
       }
       const int coff = cb * BK + lc * VEC;
+      const bool cok = coff < a.Cin;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         bool ok;
         if (a.mode == UZ_TAPS_CONV) {
           const int hh = rh[i] + dy, ww = rw[i] + dx;
-          ok = (unsigned)hh < (unsigned)a.Hin && (unsigned)ww < (unsigned)a.Win;
+          ok = cok && (unsigned)hh < (unsigned)a.Hin && (unsigned)ww < (unsigned)a.Win;
         } else {
-          ok = rh[i] >= 0;
+          ok = cok && rh[i] >= 0;
         }
         const size_t off = (size_t)(rpix[i] + dy * a.Win + dx) * (size_t)a.ldx + coff;
         ra[i] = ok ? ld16(xg + off) : zero16<T>();
       }
 #pragma unroll
-      for (int i = 0; i < BR; ++i) rb[i] = bval[i] ? ld16(bptr[i] + (size_t)kb * BK) : zero16<T>();
+      for (int i = 0; i < BR; ++i)
+        rb[i] = (bval[i] && cok) ? ld16(bptr[i] + (size_t)tap * a.Cin + coff) : zero16<T>();
       if (++cb == cpt) {
         cb = 0;
         ++tap;
@@ -269,8 +271,9 @@ int make_plan(const uz_conv_desc* d, Plan* p) {
              "uz_conv_igemm: non-positive shape");
   {
     UzGemmPlan gp_;
-    UZ_REQUIRE(d->Cin % bk == 0 || uz_gemm_dma_plan(d, &gp_),
-               "uz_conv_igemm: Cin=%d must be a multiple of %d for this shape", d->Cin, bk);
+    (void)gp_;
+    (void)bk;
+    UZ_REQUIRE(d->Cin % vec == 0, "uz_conv_igemm: Cin=%d must be a multiple of %d", d->Cin, vec);
   }
   UZ_REQUIRE(d->ldx % vec == 0 && d->ldx >= d->Cin, "uz_conv_igemm: bad ldx=%d (Cin=%d)", d->ldx,
              d->Cin);

@@ -120,7 +120,7 @@ class Engine:
         # write every parameter gradient straight into the existing p.grad storage (overwrite, no
         # accumulation, no temporaries): used with pre-allocated flat gradient buffers / hipGraphs
         self.grads_in_place = grads_in_place
-        self._heads: List[Callable[[torch.Tensor], None]] = []
+        self._heads: List[Tuple[Callable[..., None], int]] = []   # (backward fn, number of outputs)
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, N, H, W, C, needs_grad=True) -> Act:
@@ -192,14 +192,15 @@ class Engine:
         return ops.im2col3x3_nchw(x.contiguous().float(), _round_up(9 * C, self.bk), self.dtype)
 
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
-                     pool: bool = False, im2col: bool = False, upsample: bool = False
-                     ) -> Tuple[Act, Optional[Act]]:
+                     pool: bool = False, im2col: bool = False, upsample: bool = False,
+                     residual: Optional[Act] = None) -> Tuple[Act, Optional[Act]]:
         """[nearest x2 upsample ->] Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
 
         Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
         u2net.py:10-17), DownSample's pool (common_layers.py:90-95) and UpConvBlock
         (common_layers.py:69-76: the upsampled tensor is never materialised, the convolution reads
-        the half-resolution input at (h>>1, w>>1)).  Returns (act, pooled)."""
+        the half-resolution input at (h>>1, w>>1)).  `residual` is added AFTER the ReLU and before
+        the pool (the RSU tail `hx1d + hxin`, u2net.py:74).  Returns (act, pooled)."""
         N, H, W = x.N, x.H, x.W
         if upsample:
             H, W = 2 * H, 2 * W
@@ -228,7 +229,7 @@ class Engine:
                                     bn.running_var, bn.eps)
         act = out if out is not None else self.new_act(N, H, W, Cout)
         pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
-        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled)
+        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual)
 
         if self.record:
             if not self.training:
@@ -245,6 +246,15 @@ class Engine:
                 g1 = gs[1] if len(gs) > 1 else None
                 if g0 is None and gp is None:
                     return  # nothing downstream used this activation
+                if residual is not None:
+                    # the residual branch needs the TOTAL gradient of act as one tensor; the pool's
+                    # argmax is over act (= relu + residual), not over relu(bn(y))
+                    if gp is not None or g1 is not None:
+                        tot = self.new_act(N, H, W, Cout)
+                        ops.pool_grad_combine(act, g0, g1, gp, tot)
+                        g0, g1, gp = tot, None, None
+                    if residual.needs_grad:
+                        residual.add_grad(g0)
                 dy = self.new_act(N, H, W, Cout)
                 dgamma, dbeta = self._dst(bn.weight), self._dst(bn.bias)
                 if dgamma is None:
@@ -395,6 +405,96 @@ class Engine:
             self.tape.append(bwd)
         return out
 
+    def resize_bilinear(self, x: Act, out: Act) -> Act:
+        """out = F.interpolate(x, size=out's, mode='bilinear', align_corners=False), written into its
+        concat slot.  Reference: _upsample_like (u2net.py:19-22)."""
+        assert x.N == out.N and x.C == out.C
+        ops.bilinear_fwd(x, out)
+        if self.record and x.needs_grad:
+            def bwd():
+                gs = self._sum_grads(out, 1)
+                if not gs:
+                    return
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                ops.bilinear_bwd(gs[0], dx)
+                x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return out
+
+    def u2net_heads(self, feats: Sequence[Act], sides: Sequence[nn.Conv2d], fuse: nn.Conv2d) -> List[torch.Tensor]:
+        """The six 3x3 side heads, their bilinear resize to the first head's resolution, and the 1x1
+        fuse convolution over their concat.  Returns [d0, d1, ..., d6] as (N, K, H, W) fp32 (d1..d6
+        are channel slices of one concat buffer).  Reference: U2NET.forward, u2net.py:277-298."""
+        N, H, W = feats[0].N, feats[0].H, feats[0].W
+        S, K, HW = len(feats), sides[0].out_channels, H * W
+        assert fuse.kernel_size == (1, 1) and fuse.in_channels == S * K and fuse.out_channels == K
+        dev = self.device
+        dcat = torch.empty((N, S * K, H, W), dtype=torch.float32, device=dev)
+        taps = torch.empty(N * 9 * HW, dtype=torch.float32, device=dev)
+        for s_, (f, conv) in enumerate(zip(feats, sides)):
+            assert conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.in_channels == f.C
+            wt = conv.weight.detach()
+            hw = f.H * f.W
+            low = None if (f.H, f.W) == (H, W) else torch.empty((N, K, f.H, f.W), dtype=torch.float32, device=dev)
+            for o in range(K):
+                wp = wt.data_ptr() + o * f.C * 9 * 4
+                bp = conv.bias.detach().data_ptr() + 4 * o if conv.bias is not None else None
+                plane = dcat.data_ptr() + (s_ * K + o) * HW * 4
+                if low is None:
+                    ops.sideconv_fwd(f, wp, bp, taps, plane, S * K * HW)
+                else:
+                    lp = low.data_ptr() + o * hw * 4
+                    ops.sideconv_fwd(f, wp, bp, taps, lp, K * hw)
+                    ops.bilinear_planes(lp, K * hw, f.H, f.W, plane, S * K * HW, H, W, N)
+        wf = fuse.weight.detach().reshape(K, S * K)
+        d0 = ops.fuse1x1_fwd(dcat, wf, fuse.bias.detach() if fuse.bias is not None else None)
+        outs = [d0] + [dcat[:, s_ * K:(s_ + 1) * K] for s_ in range(S)]
+
+        if self.record:
+            def bwd(*gs: Optional[torch.Tensor]):
+                if all(g is None for g in gs):
+                    return
+                g0 = gs[0].contiguous().float() if gs[0] is not None else None
+                extras = [g.contiguous().float() if g is not None else None for g in gs[1:]]
+                dwf, dbf = self._dst(fuse.weight), (self._dst(fuse.bias) if fuse.bias is not None else None)
+                if dwf is None:
+                    dwf = torch.empty(fuse.weight.shape, dtype=torch.float32, device=dev)
+                if dbf is None and fuse.bias is not None:
+                    dbf = torch.empty(K, dtype=torch.float32, device=dev)
+                dcat_g = ops.fuse1x1_bwd(dcat, wf, g0, extras, dwf, dbf)
+                self._give_grad(fuse.weight, dwf)
+                if fuse.bias is not None:
+                    self._give_grad(fuse.bias, dbf)
+                for s_, (f, conv) in enumerate(zip(feats, sides)):
+                    hw = f.H * f.W
+                    dw, db = self._dst(conv.weight), (self._dst(conv.bias) if conv.bias is not None else None)
+                    if dw is None:
+                        dw = torch.empty(conv.weight.shape, dtype=torch.float32, device=dev)
+                    if db is None and conv.bias is not None:
+                        db = torch.empty(K, dtype=torch.float32, device=dev)
+                    low = None if (f.H, f.W) == (H, W) else torch.empty((N, K, f.H, f.W), dtype=torch.float32, device=dev)
+                    wt = conv.weight.detach()
+                    for o in range(K):
+                        plane = dcat_g.data_ptr() + (s_ * K + o) * HW * 4
+                        if low is None:
+                            gp_, gi = plane, S * K * HW
+                        else:
+                            gp_, gi = low.data_ptr() + o * hw * 4, K * hw
+                            ops.bilinear_planes(plane, S * K * HW, f.H, f.W, gp_, gi, H, W, N, backward=True)
+                        dx = self.new_act(f.N, f.H, f.W, f.C) if f.needs_grad else None
+                        ops.sideconv_bwd(f, wt.data_ptr() + o * f.C * 9 * 4, gp_, gi, dx,
+                                         dw.data_ptr() + o * f.C * 9 * 4,
+                                         db.data_ptr() + 4 * o if db is not None else None)
+                        if dx is not None:
+                            f.add_grad(dx)
+                    self._give_grad(conv.weight, dw)
+                    if conv.bias is not None:
+                        self._give_grad(conv.bias, db)
+
+            self._heads.append((bwd, len(outs)))
+        return outs
+
     def out_conv(self, x: Act, conv: nn.Conv2d) -> torch.Tensor:
         """1x1 convolution to the logits, (N, K, H, W) fp32.  Reference: OutConv (common_layers.py:125)."""
         assert conv.kernel_size == (1, 1) and conv.in_channels == x.C
@@ -415,18 +515,21 @@ class Engine:
                 if dx is not None:
                     x.add_grad(dx)
 
-            self._heads.append(bwd)
+            self._heads.append((bwd, 1))
         return logits
 
     # ------------------------------------------------------------------ backward
     def backward(self, grad_outputs: Sequence[Optional[torch.Tensor]]) -> Dict[nn.Parameter, torch.Tensor]:
         """Run the recorded tape in reverse.  `grad_outputs` pairs with the out_conv heads in
         emission order."""
-        heads = self._heads
-        assert len(grad_outputs) == len(heads)
-        for fn, g in zip(reversed(heads), reversed(list(grad_outputs))):
-            if g is not None:
-                fn(g)
+        gl, pos, calls = list(grad_outputs), 0, []
+        for fn, n in self._heads:
+            calls.append((fn, gl[pos:pos + n]))
+            pos += n
+        assert pos == len(gl)
+        for fn, gs in reversed(calls):
+            if any(g is not None for g in gs):
+                fn(*gs)
         for fn in reversed(self.tape):
             fn()
         self.tape.clear()

@@ -275,15 +275,18 @@ def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
 
 
 def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
-                  pooled: Optional[Act] = None) -> None:
+                  pooled: Optional[Act] = None, res: Optional[Act] = None) -> None:
+    """act = relu(scale*y + shift) [+ res]; pooled = maxpool2x2(act)"""
     lib = L.load()
     es = y.buf.element_size()
-    with _Timed("bn_relu_apply", 0.0, es * y.P * y.C * (2.25 if pooled is not None else 2.0)):
-        L.check(lib.uz_bn_relu_apply(L.dtype_code(y.dtype), y.ptr(), y.ld, scale.data_ptr(),
-                                     shift.data_ptr(), y.N, y.H, y.W, y.C, act.ptr(), act.ld,
-                                     pooled.ptr() if pooled is not None else None,
-                                     pooled.ld if pooled is not None else 0, L.stream_ptr()),
-                "uz_bn_relu_apply")
+    with _Timed("bn_relu_apply", 0.0, es * y.P * y.C * ((2.25 if pooled is not None else 2.0) + (res is not None))):
+        L.check(lib.uz_bn_relu_add_apply(L.dtype_code(y.dtype), y.ptr(), y.ld, scale.data_ptr(),
+                                         shift.data_ptr(), y.N, y.H, y.W, y.C,
+                                         res.ptr() if res is not None else None,
+                                         res.ld if res is not None else 0, act.ptr(), act.ld,
+                                         pooled.ptr() if pooled is not None else None,
+                                         pooled.ld if pooled is not None else 0, L.stream_ptr()),
+                "uz_bn_relu_add_apply")
 
 
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
@@ -418,3 +421,97 @@ def sum2x2(du: Act, dx: Act) -> None:
     with _Timed("sum2x2", 0.0, du.buf.element_size() * 1.25 * du.P * du.C):
         L.check(L.load().uz_sum2x2(L.dtype_code(du.dtype), du.ptr(), du.ld, dx.N, dx.H, dx.W, dx.C, dx.ptr(),
                                    dx.ld, L.stream_ptr()), "uz_sum2x2")
+
+
+# ------------------------------------------------------------------------------------------------
+# U^2-Net pieces (u2net.py): bilinear resize, residual/pool gradient merge, side heads, fuse conv
+def bilinear_fwd(x: Act, out: Act) -> None:
+    """out = F.interpolate(x, size=(out.H, out.W), mode='bilinear', align_corners=False)"""
+    assert x.N == out.N and x.C == out.C and x.dtype == out.dtype
+    es = x.buf.element_size()
+    with _Timed("bilinear_fwd", 0.0, es * (x.P + out.P) * x.C):
+        L.check(L.load().uz_bilinear_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.H * x.W * x.ld, x.N, x.H, x.W,
+                                         x.C, out.ptr(), out.ld, out.H * out.W * out.ld, out.H, out.W,
+                                         L.stream_ptr()), "uz_bilinear_fwd")
+
+
+def bilinear_bwd(g: Act, dx: Act) -> None:
+    """dx (at the resize's input resolution) from g (at its output resolution)"""
+    assert g.N == dx.N and g.C == dx.C and g.dtype == dx.dtype
+    es = g.buf.element_size()
+    with _Timed("bilinear_bwd", 0.0, es * (g.P + dx.P) * g.C):
+        L.check(L.load().uz_bilinear_bwd(L.dtype_code(g.dtype), g.ptr(), g.ld, g.H * g.W * g.ld, g.N, dx.H, dx.W,
+                                         g.C, dx.ptr(), dx.ld, dx.H * dx.W * dx.ld, g.H, g.W, L.stream_ptr()),
+                "uz_bilinear_bwd")
+
+
+def bilinear_planes(src_ptr: int, src_img: int, hi: int, wi: int, dst_ptr: int, dst_img: int, ho: int, wo: int,
+                    n: int, backward: bool = False) -> None:
+    """fp32 single-channel planes (the logit maps); strides in elements.  backward: src is the
+    gradient at (ho, wo), dst the gradient at (hi, wi)."""
+    lib = L.load()
+    fn = lib.uz_bilinear_bwd if backward else lib.uz_bilinear_fwd
+    with _Timed("bilinear_planes_bwd" if backward else "bilinear_planes_fwd", 0.0, 4.0 * n * (hi * wi + ho * wo)):
+        L.check(fn(L.UZ_F32, src_ptr, 1, src_img, n, hi, wi, 1, dst_ptr, 1, dst_img, ho, wo, L.stream_ptr()),
+                "uz_bilinear(planes)")
+
+
+def pool_grad_combine(act: Act, g0: Optional[Act], g1: Optional[Act], gp: Optional[Act], out: Act) -> None:
+    if g0 is None:
+        g0, g1 = g1, None
+    es = act.buf.element_size()
+    n = 1 + (g0 is not None) + (g1 is not None) + (1.25 if gp is not None else 0)
+    with _Timed("pool_grad_combine", 0.0, es * act.P * act.C * n):
+        L.check(L.load().uz_pool_grad_combine(
+            L.dtype_code(act.dtype), act.N, act.H, act.W, act.C, act.ptr(), act.ld,
+            g0.ptr() if g0 is not None else None, g0.ld if g0 is not None else 0,
+            g1.ptr() if g1 is not None else None, g1.ld if g1 is not None else 0,
+            gp.ptr() if gp is not None else None, gp.ld if gp is not None else 0,
+            out.ptr(), out.ld, L.stream_ptr()), "uz_pool_grad_combine")
+
+
+def sideconv_fwd(x: Act, w_ptr: int, b_ptr: Optional[int], taps_ws: torch.Tensor, out_ptr: int, out_img: int) -> None:
+    assert taps_ws.numel() >= x.N * 9 * x.H * x.W and taps_ws.dtype == torch.float32
+    with _Timed("sideconv3x3_fwd", 18.0 * x.P * x.C, x.buf.element_size() * x.P * x.C + 4.0 * 19 * x.P):
+        L.check(L.load().uz_sideconv3x3_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.N, x.H, x.W, x.C, w_ptr, b_ptr,
+                                            taps_ws.data_ptr(), out_ptr, out_img, L.stream_ptr()),
+                "uz_sideconv3x3_fwd")
+
+
+def sideconv_bwd(x: Act, w_ptr: int, g_ptr: int, g_img: int, dx: Optional[Act], dw_ptr: int,
+                 db_ptr: Optional[int]) -> None:
+    lib = L.load()
+    code = L.dtype_code(x.dtype)
+    wsb = L.check_count(lib.uz_sideconv3x3_bwd_workspace_bytes(code, x.N, x.H, x.W, x.C),
+                        "uz_sideconv3x3_bwd_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.buf.device)
+    with _Timed("sideconv3x3_bwd", 36.0 * x.P * x.C, x.buf.element_size() * 2.0 * x.P * x.C):
+        L.check(lib.uz_sideconv3x3_bwd(code, x.ptr(), x.ld, x.N, x.H, x.W, x.C, w_ptr, g_ptr, g_img,
+                                       dx.ptr() if dx is not None else None, dx.ld if dx is not None else 0,
+                                       dw_ptr, db_ptr, ws.data_ptr(), L.stream_ptr()), "uz_sideconv3x3_bwd")
+
+
+def fuse1x1_fwd(d: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    N, Cc, H, W = d.shape
+    K = w.shape[0]
+    out = torch.empty((N, K, H, W), dtype=torch.float32, device=d.device)
+    L.check(L.load().uz_fuse1x1_fwd(d.data_ptr(), N, H * W, Cc, K, w.data_ptr(), _p(b), out.data_ptr(),
+                                    L.stream_ptr()), "uz_fuse1x1_fwd")
+    return out
+
+
+def fuse1x1_bwd(d: torch.Tensor, w: torch.Tensor, g: Optional[torch.Tensor], extras: Sequence[Optional[torch.Tensor]],
+                dw: torch.Tensor, db: Optional[torch.Tensor]) -> torch.Tensor:
+    import ctypes
+    lib = L.load()
+    N, Cc, H, W = d.shape
+    K = w.shape[0]
+    assert len(extras) == Cc // K
+    dcat = torch.empty_like(d)
+    wsb = L.check_count(lib.uz_fuse1x1_bwd_workspace_bytes(N, H * W, Cc, K), "uz_fuse1x1_bwd_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=d.device)
+    arr = (ctypes.c_void_p * len(extras))(*[(e.data_ptr() if e is not None else None) for e in extras])
+    L.check(lib.uz_fuse1x1_bwd(d.data_ptr(), N, H * W, Cc, K, w.data_ptr(), _p(g), arr, len(extras),
+                               dcat.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), L.stream_ptr()),
+            "uz_fuse1x1_bwd")
+    return dcat
