@@ -40,6 +40,18 @@ from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
 
 
+def model_loss(out, mask):
+    """BCEWithLogits (scripts/train.py:135); u2net's dict of seven heads: their unit-weighted sum
+    (unet_zoo/utils/training_loop.py:24-32, 60-64)."""
+    if isinstance(out, dict):
+        total = None
+        for v in out.values():
+            l = F.binary_cross_entropy_with_logits(v, mask)
+            total = l if total is None else total + l
+        return total
+    return F.binary_cross_entropy_with_logits(out, mask)
+
+
 def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
     """Reference step on the host CPU through the oracle (checker code, used here only as the
     reported baseline)."""
@@ -62,7 +74,7 @@ def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
     for i in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss = F.binary_cross_entropy_with_logits(torch_ref.FORWARDS[model_name](st, x, True), mask)
+        loss = torch_ref.model_loss(torch_ref.FORWARDS[model_name](st, x, True), mask)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
@@ -82,8 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet"],
-                    help="unet = BASELINE configs[1] (the headline metric); attention_unet = configs[2] with --size 512")
+    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet", "u2net"],
+                    help="unet = BASELINE configs[1] (the headline metric); attention_unet = configs[2] with --size 512; "
+                         "u2net = configs[4] with --size 512 --batch 8")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -130,7 +143,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         out = net(x)
-        loss = F.binary_cross_entropy_with_logits(out, mask)
+        loss = model_loss(out, mask)
         loss.backward()
         if timed:
             e1.record()
@@ -178,7 +191,7 @@ def main():
             g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_fb):
                 out = inner(x)
-                static_loss = F.binary_cross_entropy_with_logits(out, mask)
+                static_loss = model_loss(out, mask)
                 static_loss.backward()       # every parameter gradient overwritten in place
             with torch.cuda.graph(g_opt):
                 opt_step()
