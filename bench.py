@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 import unet_zoo_amd  # noqa: E402
 from unet_zoo_amd import ops  # noqa: E402
+from unet_zoo_amd.graph import PhasedStep
 from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
 
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
@@ -105,6 +106,9 @@ def main():
                     help="replay the whole step from one hipGraph (auto: try, fall back to eager)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and use the multi-GPU launch strategy even for 1 rank")
+    ap.add_argument("--phases", type=int, default=5,
+                    help="N>1 ranks, graph mode: number of backward phases (hipGraphs) whose gradient "
+                         "all-reduce overlaps the next phase; 1 = one all-reduce after the whole backward")
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="eager steps with per-launch HIP events, run after the timed region")
     args = ap.parse_args()
@@ -183,30 +187,81 @@ def main():
             inner._grad_sink = None          # gradients are reduced from the flat buffer instead
             inner._grad_sink_done = None
             flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
-            off = 0
-            for p in params:                 # .grad = views of one buffer -> one collective
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
             inner.grads_in_place = True      # kernels write straight into the views of `flat`
-            g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fb):
-                out = inner(x)
-                static_loss = model_loss(out, mask)
-                static_loss.backward()       # every parameter gradient overwritten in place
-            with torch.cuda.graph(g_opt):
-                opt_step()
+            g_opt = torch.cuda.CUDAGraph()
+            if distributed and args.phases > 1:
+                # backward cut into phases, one hipGraph each; the gradients a phase completed are
+                # all-reduced (async RCCL) while the next phase's graph runs
+                ps = PhasedStep(inner, model_loss)
+                for p in params:
+                    p.grad = torch.zeros_like(p)
+                ps.forward(x, mask)          # eager dry run: which tape entry completes which parameter
+                ps.backward(ps.n_entries, 0, True)
+                # cut where the cumulative gradient bytes cross k/(K-1) * 85 %: the last phase (the
+                # high-resolution encoder layers: few parameters, long compute) hides the exchange
+                # of everything before it and leaves ~15 % of the bytes exposed
+                cuts, groups = ps.plan([0.85 * (i + 1) / (args.phases - 1) for i in range(args.phases - 1)])
+                ps.finish()
+                off, spans = 0, []
+                for grp in groups:           # flat buffer ordered by phase: one collective per phase
+                    a0 = off
+                    for p in grp:
+                        p.grad = flat[off:off + p.numel()].view_as(p)
+                        off += p.numel()
+                    spans.append((a0, off))
+                assert off == flat.numel()
+                graphs, pool = [], None
+                for k in range(len(groups)):
+                    gk = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gk, pool=pool):
+                        if k == 0:
+                            static_loss = ps.forward(x, mask)
+                        ps.backward(cuts[k], cuts[k + 1], k == 0)
+                    pool = gk.pool()
+                    graphs.append(gk)
+                ps.finish()
 
-            if distributed:
+                def fb_replay():
+                    for gk in graphs:
+                        gk.replay()
+                with torch.cuda.graph(g_opt):
+                    opt_step()
+
                 def run_one():
-                    g_fb.replay()
-                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                    works = []
+                    for gk, (a0, a1) in zip(graphs, spans):
+                        gk.replay()
+                        works.append(dist.all_reduce(flat[a0:a1], op=dist.ReduceOp.AVG, async_op=True))
+                    for w in works:
+                        w.wait()
                     g_opt.replay()
-                launch_mode = "hipGraph(fwd+bwd) + eager RCCL all-reduce + hipGraph(clip+AdamW)"
+                mb = [round((a1 - a0) * 4 / 2 ** 20, 1) for a0, a1 in spans]
+                launch_mode = (f"{len(graphs)} hipGraphs (fwd + backward phases) with async RCCL all-reduce of "
+                               f"{mb} MB overlapped with the next phase + hipGraph(clip+AdamW)")
             else:
-                def run_one():
-                    g_fb.replay()
-                    g_opt.replay()
-                launch_mode = "hipGraph(fwd+bwd) + hipGraph(clip+AdamW)"
+                off = 0
+                for p in params:             # .grad = views of one buffer -> one collective
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+                g_fb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb):
+                    out = inner(x)
+                    static_loss = model_loss(out, mask)
+                    static_loss.backward()   # every parameter gradient overwritten in place
+                fb_replay = g_fb.replay
+                with torch.cuda.graph(g_opt):
+                    opt_step()
+                if distributed:
+                    def run_one():
+                        g_fb.replay()
+                        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                        g_opt.replay()
+                    launch_mode = "hipGraph(fwd+bwd) + eager RCCL all-reduce + hipGraph(clip+AdamW)"
+                else:
+                    def run_one():
+                        g_fb.replay()
+                        g_opt.replay()
+                    launch_mode = "hipGraph(fwd+bwd) + hipGraph(clip+AdamW)"
             run_one()                 # one untimed replay
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
@@ -250,7 +305,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            g_fb.replay()
+            fb_replay()
         torch.cuda.synchronize()
         fb_graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
 

@@ -223,3 +223,57 @@ def test_in_place_gradient_mode_matches_autograd_mode():
         scale = r.abs().max() + 1e-12
         # running statistics moved between the passes only through BN buffers, not the math of this batch
         assert (p.grad - r).abs().max() <= 1e-4 * scale + 1e-9
+
+
+@pytest.mark.parametrize("name", ["unet", "attention_unet", "u2netp"])
+def test_phased_backward_equals_one_shot_backward(name):
+    """graph.PhasedStep (bench.py's multi-GPU graph mode): the backward cut into phases, each
+    phase's parameters laid out contiguously in one flat buffer, gives bit-identical gradients to the
+    autograd path; the plan covers every parameter exactly once and its cuts descend to 0."""
+    from unet_zoo_amd.graph import PhasedStep
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model(name).to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=4)
+    x, mask = x.to(DEV), mask.to(DEV)
+
+    def loss_fn(out, t):
+        if isinstance(out, dict):
+            return sum(F.binary_cross_entropy_with_logits(v, t) for v in out.values())
+        return F.binary_cross_entropy_with_logits(out, t)
+
+    loss_ref = loss_fn(m(x), mask)
+    loss_ref.backward()
+    ref = {p: p.grad.clone() for p in m.parameters()}
+    params = list(m.parameters())
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    ps = PhasedStep(m, loss_fn)
+    ps.forward(x, mask)
+    ps.backward(ps.n_entries, 0, True)
+    cuts, groups = ps.plan((0.4, 0.8))
+    ps.finish()
+    assert cuts[0] > cuts[-1] == 0 and all(a >= b for a, b in zip(cuts, cuts[1:])) and len(groups) == len(cuts) - 1
+    flat_ids = [id(p) for g in groups for p in g]
+    assert sorted(flat_ids) == sorted(id(p) for p in params)          # every parameter exactly once
+    assert len(groups) == 3 and all(len(g) > 0 for g in groups)
+    flat = torch.zeros(sum(p.numel() for p in params), device=DEV)
+    off, spans = 0, []
+    for g in groups:
+        a0 = off
+        for p in g:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        spans.append((a0, off))
+    loss = ps.forward(x, mask)
+    for k in range(len(groups)):
+        ps.backward(cuts[k], cuts[k + 1], k == 0)
+        # after phase k its span must already hold the final values (that is what gets all-reduced)
+        a0, a1 = spans[k]
+        snap = flat[a0:a1].clone()
+        spans[k] = (a0, a1, snap)
+    ps.finish()
+    assert abs(loss.item() - loss_ref.item()) < 1e-6
+    for (a0, a1, snap) in spans:
+        assert torch.equal(flat[a0:a1], snap)                        # later phases did not touch it
+    for p in params:
+        assert torch.equal(p.grad, ref[p])

@@ -121,6 +121,9 @@ class Engine:
         # accumulation, no temporaries): used with pre-allocated flat gradient buffers / hipGraphs
         self.grads_in_place = grads_in_place
         self._heads: List[Tuple[Callable[..., None], int]] = []   # (backward fn, number of outputs)
+        # (tape position, parameter) in the order gradients are produced; position len(tape) = heads
+        self.grad_log: List[Tuple[int, nn.Parameter]] = []
+        self._cur_entry = -1
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, N, H, W, C, needs_grad=True) -> Act:
@@ -143,6 +146,7 @@ class Engine:
         return None
 
     def _give_grad(self, p: nn.Parameter, g: Optional[torch.Tensor]) -> None:
+        self.grad_log.append((self._cur_entry, p))
         if self.grads_in_place and p.grad is not None:
             if g is None:
                 return                               # analytically zero and p.grad was never touched
@@ -522,15 +526,25 @@ class Engine:
     def backward(self, grad_outputs: Sequence[Optional[torch.Tensor]]) -> Dict[nn.Parameter, torch.Tensor]:
         """Run the recorded tape in reverse.  `grad_outputs` pairs with the out_conv heads in
         emission order."""
-        gl, pos, calls = list(grad_outputs), 0, []
-        for fn, n in self._heads:
-            calls.append((fn, gl[pos:pos + n]))
-            pos += n
-        assert pos == len(gl)
-        for fn, gs in reversed(calls):
-            if any(g is not None for g in gs):
-                fn(*gs)
-        for fn in reversed(self.tape):
-            fn()
+        self.backward_range(grad_outputs, len(self.tape), 0)
         self.tape.clear()
         return self.param_grads
+
+    def backward_range(self, grad_outputs: Optional[Sequence[Optional[torch.Tensor]]], hi: int, lo: int) -> None:
+        """Part of the backward: the heads (when `grad_outputs` is given), then tape entries
+        hi-1, hi-2, ..., lo.  Lets a caller run the backward in phases (graph.PhasedStep) so that the
+        gradients of a finished phase can be all-reduced while the next phase computes."""
+        if grad_outputs is not None:
+            self._cur_entry = len(self.tape)
+            gl, pos, calls = list(grad_outputs), 0, []
+            for fn, n in self._heads:
+                calls.append((fn, gl[pos:pos + n]))
+                pos += n
+            assert pos == len(gl)
+            for fn, gs in reversed(calls):
+                if any(g is not None for g in gs):
+                    fn(*gs)
+        for i in range(hi - 1, lo - 1, -1):
+            self._cur_entry = i
+            self.tape[i]()
+        self._cur_entry = -1
