@@ -79,6 +79,15 @@ typedef struct uz_conv_desc {
 int uz_conv_igemm_grid_m(const uz_conv_desc* d); /* number of stats partial rows; <0 on error */
 int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                   void* y, float* stats_partial, void* stream);
+/* Same with a scratch buffer: small-M 3x3 problems on the generic kernel (u2net's dilated layers at
+ * <= 32x32 maps, u2net.py:196-201) split their nine taps across workgroups into fp32 partial tiles in
+ * `workspace` and finish with a fixed-order reduce + bias + statistics pass.  workspace_bytes() == 0:
+ * identical to uz_conv_igemm (workspace may be NULL).  The statistics rows of THIS entry point are
+ * counted by uz_conv_igemm_ws_grid_m(). */
+long long uz_conv_igemm_workspace_bytes(const uz_conv_desc* d);
+int uz_conv_igemm_ws_grid_m(const uz_conv_desc* d);
+int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                     void* y, float* stats_partial, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient (reduction over pixels), fp32 output in the reference's parameter layout.

@@ -31,6 +31,7 @@ EXPORTS = (
     "uz_bn_relu_add_apply", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_pool_grad_combine",
     "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
+    "uz_conv_igemm_workspace_bytes", "uz_conv_igemm_ws_grid_m", "uz_conv_igemm_ws",
 )
 
 
@@ -83,6 +84,9 @@ def load():
     vp, ip, fp = c_void_p, c_int, c_float
     lib.uz_conv_igemm_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    lib.uz_conv_igemm_workspace_bytes.argtypes = [POINTER(ConvDesc)]
+    lib.uz_conv_igemm_ws_grid_m.argtypes = [POINTER(ConvDesc)]
+    lib.uz_conv_igemm_ws.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     lib.uz_wgrad_split.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad_workspace_bytes.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]

@@ -25,6 +25,11 @@ struct IgemmArgs {
   const float* bias;
   float* stats;
   int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, dil, store, Co, tiles_m;
+  // tap split (small-M problems: 16-128 output tiles cannot fill 256 CUs and each walks a long,
+  // latency-bound K loop): blockIdx.z owns taps [z*tpg, (z+1)*tpg) and writes its fp32 partial tile to
+  // part[z][M][Nout]; igemm_split_reduce_kernel sums them in fixed order (deterministic)
+  float* part;
+  int tpg;
 };
 
 template <typename T> struct Mma;
@@ -78,7 +83,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   for (int i = 0; i < TN; ++i) s1[i] = s2[i] = 0.f;
 
   const int cpt = (a.Cin + BK - 1) / BK;  // K-steps per tap; the last slab may be partial (zeros)
-  const int nk = a.ntaps * cpt;
+  const int tap_lo = a.part != nullptr ? (int)blockIdx.z * a.tpg : 0;
+  const int tap_hi = a.part != nullptr ? min(a.ntaps, tap_lo + a.tpg) : a.ntaps;
+  const int nk = (tap_hi - tap_lo) * cpt;
   const int HW = a.H * a.W;
   const int st_sw = ((lr >> 1) & 7);       // store-side swizzle (row = lr + 32 i)
   const int ld_sw = ((l31 >> 1) & 7);      // read-side swizzle (row = 32 j + l31)
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     Vec16<T> ra[AR], rb[BR];
-    int tap = 0, cb = 0;  // position of the K-step being loaded
+    int tap = tap_lo, cb = 0;  // position of the K-step being loaded
 
     auto load_step = [&](int kb) {
       int dy = 0, dx = 0;
@@ -184,6 +191,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
       __syncthreads();
     }
 
+    if (a.part != nullptr) {  // split: raw fp32 partial tile, finished by the reduce kernel
+      float* __restrict__ pz = a.part + (size_t)blockIdx.z * a.M * a.Nout;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < a.M && n < a.Nout) pz[(size_t)m * a.Nout + n] = acc[i][j][r];
+          }
+      }
+      continue;
+    }
     // Epilogue: bias, store, per-channel statistics of the stored value.
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -224,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     }
   }
 
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr && a.part == nullptr) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       s1[j] += __shfl_xor(s1[j], 32);
@@ -257,9 +279,81 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
   }
 }
 
+// y[m][n] = T(sum_z part[z][m][n] + bias[n]); statistics of the stored value as per-workgroup rows.
+// block (bx chunk lanes, by pixel lanes); grid (gx pixel groups, gy chunk groups)
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_split_reduce_kernel(const float* __restrict__ part, int split, int M,
+                                                                 int Nout, const float* __restrict__ bias,
+                                                                 T* __restrict__ y, int ldy,
+                                                                 float* __restrict__ stats) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [by][bx][2*VEC]
+  const int CC = Nout / VEC;
+  const int cc = blockIdx.y * blockDim.x + threadIdx.x;
+  const bool cok = cc < CC;
+  const int c0 = (cok ? cc : 0) * VEC;
+  float bv[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    bv[i] = (bias != nullptr && cok) ? bias[c0 + i] : 0.f;
+    s1[i] = s2[i] = 0.f;
+  }
+  const size_t slab = (size_t)M * Nout;
+  for (int m = blockIdx.x * blockDim.y + threadIdx.y; m < M && cok; m += gridDim.x * blockDim.y) {
+    float v[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = bv[i];
+    const float* src = part + (size_t)m * Nout + c0;
+    for (int z = 0; z < split; ++z) {
+#pragma unroll
+      for (int i = 0; i < VEC; i += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (size_t)z * slab + i);
+        v[i] += t.x;
+        v[i + 1] += t.y;
+        v[i + 2] += t.z;
+        v[i + 3] += t.w;
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      o.v[i] = (T)v[i];
+      const float f = (float)o.v[i];
+      s1[i] += f;
+      s2[i] += f * f;
+    }
+    st16(y + (size_t)m * ldy + c0, o);
+  }
+  if (stats == nullptr) return;
+  float* mine = red + ((size_t)threadIdx.y * blockDim.x + threadIdx.x) * 2 * VEC;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    mine[i] = s1[i];
+    mine[VEC + i] = s2[i];
+  }
+  __syncthreads();
+  if (threadIdx.y == 0 && cok) {
+    for (int r = 1; r < (int)blockDim.y; ++r) {
+      const float* o = red + ((size_t)r * blockDim.x + threadIdx.x) * 2 * VEC;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        s1[i] += o[i];
+        s2[i] += o[VEC + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      stats[((size_t)blockIdx.x * 2 + 0) * Nout + c0 + i] = s1[i];
+      stats[((size_t)blockIdx.x * 2 + 1) * Nout + c0 + i] = s2[i];
+    }
+  }
+}
+
 struct Plan {
   int bn;       // 64 or 128
   int tiles_m, tiles_n, grid_m;
+  int split;    // tap groups (1 = none); > 1 needs a workspace
+  int rbx, rby, rgx, rgy;  // reduce kernel launch shape
 };
 
 int make_plan(const uz_conv_desc* d, Plan* p) {
@@ -307,19 +401,53 @@ int make_plan(const uz_conv_desc* d, Plan* p) {
   int cap = (2 * UZ_NUM_CU) / p->tiles_n;
   if (cap < 1) cap = 1;
   p->grid_m = p->tiles_m < cap ? p->tiles_m : cap;
+  // tap split for the small-M generic-kernel problems (u2net's dilated layers at <= 32x32 maps)
+  p->split = 1;
+  const int vec_ = d->dtype == UZ_BF16 ? 8 : 4;
+  if (d->taps_mode == UZ_TAPS_CONV && d->ntaps == 9 && d->store_mode == UZ_STORE_PLAIN &&
+      p->tiles_m * p->tiles_n <= UZ_NUM_CU / 2 && d->Nout % vec_ == 0 && d->ldy % vec_ == 0 &&
+      !(uz_tune_flags() & 8)) {
+    p->split = 9;
+    const int CC = d->Nout / vec_;
+    int bx = 1;
+    while (bx < CC && bx < 64) bx <<= 1;
+    p->rbx = bx;
+    p->rby = 256 / bx;
+    p->rgy = (CC + bx - 1) / bx;
+    long long gx = (M + p->rby * 4 - 1) / (p->rby * 4);
+    long long capx = (long long)UZ_NUM_CU * 2 / p->rgy;
+    if (capx < 1) capx = 1;
+    if (gx > capx) gx = capx;
+    if (gx < 1) gx = 1;
+    p->rgx = (int)gx;
+  }
   return UZ_OK;
 }
 
 template <typename T>
 int launch(const uz_conv_desc* d, const Plan& p, const IgemmArgs& a, hipStream_t s) {
-  dim3 grid(p.grid_m, p.tiles_n), block(256);
+  dim3 grid(p.grid_m, p.tiles_n, a.part != nullptr ? p.split : 1), block(256);
   if (p.bn == 64) {
     hipLaunchKernelGGL((igemm_kernel<T, 128, 64, 2, 2>), grid, block, 0, s, a);
   } else {
     hipLaunchKernelGGL((igemm_kernel<T, 128, 128, 2, 2>), grid, block, 0, s, a);
   }
   UZ_LAUNCH_CHECK("uz_conv_igemm");
+  if (a.part != nullptr) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const size_t shm = (size_t)256 * 2 * VEC * sizeof(float);
+    hipLaunchKernelGGL((igemm_split_reduce_kernel<T>), dim3(p.rgx, p.rgy), dim3(p.rbx, p.rby), shm, s, a.part,
+                       p.split, a.M, a.Nout, a.bias, static_cast<T*>(a.y), a.ldy, a.stats);
+    UZ_LAUNCH_CHECK("uz_conv_igemm(split reduce)");
+  }
   return UZ_OK;
+}
+
+// 1 when the descriptor takes the generic kernel (no direct / LDS-DMA GEMM plan)
+bool generic_path(const uz_conv_desc* d) {
+  UzDirectPlan dp;
+  UzGemmPlan gp;
+  return !uz_direct_plan(d, &dp) && !uz_gemm_dma_plan(d, &gp);
 }
 
 }  // namespace
@@ -335,8 +463,30 @@ extern "C" int uz_conv_igemm_grid_m(const uz_conv_desc* d) {
   return p.grid_m;
 }
 
+extern "C" long long uz_conv_igemm_workspace_bytes(const uz_conv_desc* d) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  if (p.split <= 1 || !generic_path(d)) return 0;
+  return (long long)p.split * d->N * d->H * d->W * d->Nout * (long long)sizeof(float);
+}
+
+extern "C" int uz_conv_igemm_ws_grid_m(const uz_conv_desc* d) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  if (p.split > 1 && generic_path(d)) return p.rgx;
+  return uz_conv_igemm_grid_m(d);
+}
+
 extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed,
                              const float* bias, void* y, float* stats_partial, void* stream) {
+  return uz_conv_igemm_ws(d, x, w_packed, bias, y, stats_partial, nullptr, stream);
+}
+
+extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed,
+                                const float* bias, void* y, float* stats_partial, void* workspace,
+                                void* stream) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
@@ -371,6 +521,8 @@ extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w
   a.store = d->store_mode;
   a.Co = d->Co;
   a.tiles_m = p.tiles_m;
+  a.part = (p.split > 1 && workspace != nullptr) ? static_cast<float*>(workspace) : nullptr;
+  a.tpg = (d->ntaps + p.split - 1) / p.split;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return d->dtype == UZ_BF16 ? launch<bf16_t>(d, p, a, s) : launch<float>(d, p, a, s);
 }

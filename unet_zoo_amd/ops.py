@@ -198,8 +198,10 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     assert w_packed.shape == (d.Nout, ntaps * x.C), (tuple(w_packed.shape), d.Nout, ntaps, x.C)
     stats = None
     if want_stats:
-        gm = L.check_count(lib.uz_conv_igemm_grid_m(byref(d)), "uz_conv_igemm_grid_m")
+        gm = L.check_count(lib.uz_conv_igemm_ws_grid_m(byref(d)), "uz_conv_igemm_ws_grid_m")
         stats = torch.empty((gm, 2, d.Nout), dtype=torch.float32, device=x.buf.device)
+    wsb = L.check_count(lib.uz_conv_igemm_workspace_bytes(byref(d)), "uz_conv_igemm_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.buf.device) if wsb > 0 else None
     M, K, es = N * H * W, ntaps * x.C, x.buf.element_size()
     bn = 64 if d.Nout <= 64 else 128
     vec = 16 // es
@@ -216,11 +218,11 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
             and d.Nout % vec == 0 and y.ld % vec == 0 and (store_mode == L.STORE_PLAIN or co % 64 == 0):
         kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
     else:
-        kname = f"igemm_{_tname(x.dtype)}_128x{bn}"
+        kname = f"igemm_{_tname(x.dtype)}_128x{bn}" + ("_tapsplit" if ws is not None else "")
     with _Timed(kname, 2.0 * M * d.Nout * K,
                         es * (x.P * x.C + M * d.Nout + d.Nout * K)):
-        L.check(lib.uz_conv_igemm(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
-                                  L.stream_ptr()), "uz_conv_igemm")
+        L.check(lib.uz_conv_igemm_ws(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
+                                     _p(ws), L.stream_ptr()), "uz_conv_igemm_ws")
     return stats
 
 
