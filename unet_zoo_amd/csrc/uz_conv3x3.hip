@@ -36,9 +36,12 @@ struct DirectArgs {
 
 template <typename T> struct Mma2;
 template <> struct Mma2<bf16_t> {
+  // bf16 tiles are accumulated TRANSPOSED (weights as the row operand): accumulator column = pixel
+  // (lane & 31), rows = output channels, so that a lane owns 4 CONSECUTIVE channels of one pixel per
+  // register quad and the epilogue stages them with 8-byte LDS writes (see the epilogue)
   static __device__ __forceinline__ void run(const Vec16<bf16_t>& a, const Vec16<bf16_t>& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
-                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&b),
+                                                *reinterpret_cast<const bf16x8*>(&a), c, 0, 0, 0);
   }
 };
 template <> struct Mma2<float> {
@@ -146,16 +149,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     const unsigned off = ok ? (pix * (unsigned)a.ldx + ch) * ES : OOB;
     dma16(xr, smem + buf * A_BYTES + piece * 1024, off);
   };
+  auto issue_b_piece = [&](int i, int slot, int cb, int tap) {
+    const int ch = cb * BK + b_ch[i];
+    const unsigned off = (b_row_off[i] == OOB || ch >= a.Cin) ? OOB : b_row_off[i] + (tap * a.Cin + ch) * ES;
+    dma16(wr, sB + slot * B_STAGE + (wave + 8 * i) * 1024, off);
+  };
   auto issue_b = [&](int slot, int cb, int tap) {
 #pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-      const int ch = cb * BK + b_ch[i];
-      const unsigned off = (b_row_off[i] == OOB || ch >= a.Cin) ? OOB : b_row_off[i] + (tap * a.Cin + ch) * ES;
-      dma16(wr, sB + slot * B_STAGE + (wave + 8 * i) * 1024, off);
-    }
+    for (int i = 0; i < NBP; ++i) issue_b_piece(i, slot, cb, tap);
   };
 
   f32x16 acc[2][TN];
+  // One (tap, slab) step.  (Measured and rejected: placing the step's LDS-DMA pieces between the
+  // K-chunks, staggered between the two waves of a SIMD, instead of at the head of the step: 13-15 %
+  // slower on every non-resident layer.)
   auto compute = [&](int tap, int abuf, int bslot) {
     const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;  // tap in 0..8
     const char* sA = smem + abuf * A_BYTES;
@@ -166,6 +173,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       const int prow = (f_pi[i] + ty) * PW + f_pj + tx;
       arow[i] = prow * 128;
       asw[i] = (prow >> 1) & 7;
+    }
+    if (a.flags & 0x300) {  // ablations (tools/kbench.py): 0x100 LDS reads without MFMAs, 0x200 MFMAs without LDS reads
+      if (a.flags & 0x100) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int lc = 2 * q + lh;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(sA + arow[i] + ((lc ^ asw[i]) << 4));
+            asm volatile("" ::"v"(*reinterpret_cast<f32x4*>(&t)));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(sBs + b_frag_off[j] + ((lc ^ b_sw[j]) << 4));
+            asm volatile("" ::"v"(*reinterpret_cast<f32x4*>(&t)));
+          }
+        }
+      } else {
+        Vec16<T> z = zero16<T>();
+        asm volatile("" : "+v"(*reinterpret_cast<f32x4*>(&z)));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) Mma2<T>::run(z, z, acc[i][j]);
+      }
+      return;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -232,12 +267,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     wait_vmcnt<0>();  // resident weights + first patch
   }
 
-  float bv[TN];  // bias of this lane's output channels (loaded once, not per tile)
+  float bv[TN];  // fp32 path: bias of this lane's output channel (loaded once, not per tile)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + l31;
     bv[j] = (a.bias != nullptr && n < a.Nout) ? a.bias[n] : 0.f;
   }
+  // bf16 path (transposed accumulators): accumulator register r of N tile j is channel
+  // wn*WTN + 32 j + (r & 3) + 8 (r >> 2) + 4 lh
+  float bq[TN][16];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bq[j][r] = (a.bias != nullptr && n < a.Nout) ? a.bias[n] : 0.f;
+      }
+  }
+  // read-back phase of the bf16 epilogue: thread `tid` always handles the 16-byte channel chunk
+  // tid % CPR of 256*CPR/512 pixels, so its statistics accumulate in registers across tiles
+  float sq1[VEC], sq2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sq1[e] = sq2[e] = 0.f;
 
   int it = 0;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
@@ -280,10 +332,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
         } else {
           wait_vmcnt<0>();
         }
-        __builtin_amdgcn_s_barrier();
-        // next slab's halo patch, one piece per step, issued BEFORE this step's weight tile
-        if (tap < APW && cb + 1 < ncb) issue_a_piece(tap, (cb + 1) & 1, cb + 1, img, h0, w0);
-        if (s + 2 < nsteps) issue_b(tap2 % 3, cb2, tap2);
+        if (!(a.flags & 0x400)) __builtin_amdgcn_s_barrier();
+        // next slab's halo patch (one piece per step) BEFORE the weight tile of step s + 2: the
+        // counted wait above relies on the weight pieces being the youngest operations
+        // ablation bits: 0x40 no weight DMA, 0x80 no halo DMA after the first slab, 0x400 no barrier
+        if (tap < APW && cb + 1 < ncb && !(a.flags & 0x80)) issue_a_piece(tap, (cb + 1) & 1, cb + 1, img, h0, w0);
+        if (s + 2 < nsteps && !(a.flags & 0x40)) issue_b(tap2 % 3, cb2, tap2);
         compute(tap, cb & 1, tap % 3);
         if (++tap == 9) {
           tap = 0;
@@ -306,41 +360,45 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       __builtin_amdgcn_s_barrier();  // every wave has finished reading A/B of this tile
       char* sC = smem + ((BRES ? cbuf : 0) * A_BYTES);
       if (BRES) static_assert(256 * (64 * 2 + 16) <= A_BYTES, "C staging must fit one A buffer");
+      // stage: lane = pixel (l31) of M tile mt, register quad q = 4 consecutive channels -> one
+      // 8-byte LDS write (was: 64 two-byte writes per lane with sub-dword bank conflicts)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int mt = 2 * wm + i;
+        char* rowp = sC + (mt * 32 + l31) * RSC;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int col = wn * WTN + j * 32 + l31;
-          const bool nok = n0 + col < a.Nout;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ml = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside the 32-pixel M tile
-            const T tv = (T)(acc[i][j][r] + bv[j]);
-            *reinterpret_cast<T*>(sC + (mt * 32 + ml) * RSC + col * ES) = tv;
-            // statistics only over pixels inside the image
-            const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
-            const int pj = (TW == 32) ? ml : (ml & 15);
-            if (!(a.flags & 2) && nok && h0 + pi < a.H && w0 + pj < a.W) {
-              const float fv = (float)tv;
-              s1[j] += fv;
-              s2[j] += fv * fv;
-            }
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[i][j][4 * q + e] + bq[j][4 * q + e]);
+            *reinterpret_cast<bf16x4*>(rowp + (wn * WTN + j * 32 + 8 * q + 4 * lh) * ES) = pk;
           }
         }
       }
       __builtin_amdgcn_s_barrier();
       constexpr int CPR = BN * ES / 16;  // 16-byte chunks per pixel
-      for (int id = tid; id < 256 * CPR; id += 512) {
-        const int m = id / CPR, cc = id - m * CPR;
+      static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
+      const int cc = tid % CPR;
+      const int n = n0 + cc * VEC;
+      const bool dostats = !(a.flags & 2);
+      for (int m = tid / CPR; m < 256; m += 512 / CPR) {
         const int mt = m >> 5, ml = m & 31;
         const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
         const int pj = (TW == 32) ? ml : (ml & 15);
         const int hh = h0 + pi, ww = w0 + pj;
-        const int n = n0 + cc * VEC;
         if (hh < a.H && ww < a.W && n < a.Nout) {
           const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(sC + m * RSC + cc * 16);
           st16(yg + ((size_t)(img * a.H + hh) * a.W + ww) * a.ldy + n, v);
+          if (dostats) {  // statistics of the stored values, pixels inside the image only
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float fv = (float)v.v[e];
+              sq1[e] += fv;
+              sq2[e] += fv * fv;
+            }
+          }
         }
       }
     } else {
@@ -369,6 +427,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     }
   }
 
+  if constexpr (sizeof(T) == 2) {
+    if (a.stats != nullptr) {
+      constexpr int CPR = BN * ES / 16;
+      wait_vmcnt<0>();
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);  // [512][2 * VEC]
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        red[tid * 2 * VEC + e] = sq1[e];
+        red[tid * 2 * VEC + VEC + e] = sq2[e];
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {  // (which, channel): sum the 512 / CPR threads that own this channel's chunk
+        const int which = tid / BN, ch = tid - which * BN;
+        const int cc = ch / VEC, e = ch - cc * VEC;
+        float t = 0.f;
+        for (int k = cc; k < 512; k += CPR) t += red[k * 2 * VEC + which * VEC + e];
+        if (n0 + ch < a.Nout) a.stats[((size_t)blockIdx.x * 2 + which) * a.Nout + n0 + ch] = t;
+      }
+    }
+    return;
+  }
   if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

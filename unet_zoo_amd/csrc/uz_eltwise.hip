@@ -661,13 +661,15 @@ int grid_for(long long total, int block) {
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // thread-block shape for the (channel-chunk x pixel) reductions
-void reduce_shape(int CC, long long units, dim3* grid, dim3* block) {
+void reduce_shape(int CC, long long units, dim3* grid, dim3* block, int wg_per_cu = 2) {
   int bx = 1;
   while (bx < CC && bx < 64) bx <<= 1;
   const int by = 256 / bx;
   const int gy = (CC + bx - 1) / bx;
   long long gx = (units + by - 1) / by;
-  long long cap = (long long)UZ_NUM_CU * 2 / gy;
+  // reductions: 2 workgroups per CU (every workgroup leaves one partial row for the finalize kernel);
+  // the write-back pass of the BN backward has no rows to keep few and runs 8 per CU
+  long long cap = (long long)UZ_NUM_CU * wg_per_cu / gy;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
@@ -763,17 +765,17 @@ static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, c
   return UZ_OK;
 }
 
-static void bnbwd_shape(const uz_bnbwd_desc* d, bool pool, dim3* grid, dim3* block) {
+static void bnbwd_shape(const uz_bnbwd_desc* d, bool pool, dim3* grid, dim3* block, int pass = 1) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   const long long units = pool ? (long long)d->N * (d->H / 2) * (d->W / 2) : (long long)d->N * d->H * d->W;
-  reduce_shape(d->C / vec, units, grid, block);
+  reduce_shape(d->C / vec, units, grid, block, pass == 2 ? 8 : 2);
 }
 
 template <typename T, int PASS>
 static int bnbwd_launch(const uz_bnbwd_desc* d, const BnBwdArgs& a, bool pool, hipStream_t s) {
   constexpr int VEC = ElemTraits<T>::VEC;
   dim3 grid, block;
-  bnbwd_shape(d, pool, &grid, &block);
+  bnbwd_shape(d, pool, &grid, &block, PASS);
   const size_t shm = PASS == 1 ? (size_t)256 * 2 * VEC * sizeof(float) : 0;
   if (pool) {
     hipLaunchKernelGGL((bn_relu_bwd_kernel<T, true, PASS>), grid, block, shm, s, a);
