@@ -285,6 +285,60 @@ int uz_fuse1x1_bwd(const float* d, int N, int HW, int Cc, int K, const float* w,
                    const float* const* g_extra, int n_extra, float* dcat, float* dw, float* db,
                    void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Swin-UNet V2 pieces (reference: unet_zoo/models/swin_unet_v2.py).  Tokens are NHWC activations:
+ * row = (image, h, w) on the token grid, C channels.  nn.Linear runs on uz_conv_igemm (ntaps = 1).
+ * ------------------------------------------------------------------------------------------- */
+/* PatchEmbed's Conv2d(kernel = stride = patch) input (swin_unet_v2.py:548-556):
+ * out[(b,i,j)][(kh*patch + kw)*C + c] = x[b][c][i*patch+kh][j*patch+kw], zero up to Kpad. */
+int uz_patchify(int dtype, const float* x_nchw, int N, int C, int H, int W, int patch, int Kpad,
+                void* out, void* stream);
+
+/* nn.LayerNorm over C of an (N, Ho, Wo, C) token tensor.  mode selects how an output token's input
+ * row is addressed (the reference's permutations, never materialised):
+ *   UZ_LN_PLAIN   x[token][c]
+ *   UZ_LN_MERGE   PatchMerging (:315-332): input grid (2Ho, 2Wo) with C/4 channels; channel segment
+ *                 s = c/(C/4) of output token (i, j) is input token (2i + (s&1), 2j + (s>>1))
+ *   UZ_LN_EXPAND  PatchExpand / FinalPatchExpand_X4 (:352-362, :375-387): input grid (Ho/r, Wo/r) with
+ *                 r*r*C channels; output token (h*r+p1, w*r+p2) reads channels (p1*r+p2)*C + c
+ * y = [res +] [image_scale[image] *] LN(x): the block tail shortcut + drop_path(norm1(.)) (:264-267).
+ * stats: (P_out, 2) fp32 mean / rstd, kept for the backward. */
+enum { UZ_LN_PLAIN = 0, UZ_LN_MERGE = 1, UZ_LN_EXPAND = 2 };
+typedef struct uz_ln_desc {
+  int dtype, N, Ho, Wo, C;
+  int ldx, ldy, ldr, ldg, lddx; /* row strides (elements) of x, y, res, g (grad of y), dx */
+  int mode, r;
+  float eps;
+} uz_ln_desc;
+int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
+                     const void* res, const float* image_scale, void* y, float* stats, void* stream);
+int uz_layernorm_bwd_rows(const uz_ln_desc* d); /* rows of `partial`; <0 on error */
+/* dx (addressed like x; every input element is written exactly once) and per-workgroup partial rows
+ * partial[row][2][C] = sums of g*xhat (-> dgamma) and g (-> dbeta), g already scaled by image_scale;
+ * add the rows with uz_sum_rows().  The residual branch's gradient is g itself. */
+int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* stats,
+                     const void* g, const float* image_scale, void* dx, float* partial, void* stream);
+
+/* WindowAttention core (:127-159) with window_partition / roll / window_reverse (:30-56, :246-262)
+ * as index arithmetic: qkv (P, 3C) = [3][heads][32] per token, out (P, C).  For window tokens i, j
+ *   S_ij = (scale q_i . k_j) / max(|scale q_i| |k_j|, 1e-6) / max(tau[h][i][j], 0.01) + bias[h][i][j]
+ *          (- 100 when the shifted-window region ids differ, :214-236);  out_i = softmax_j(S) v
+ * tau: (heads, Nt, Nt) parameter (Nt >= ws*ws), bias: (heads, ws*ws, ws*ws) fp32 = cpb MLP output.
+ * lse: (B*nW, heads, ws*ws) row log-sum-exp kept for the backward.  head_dim must be 32, ws <= 8. */
+typedef struct uz_winattn_desc {
+  int dtype, B, H, W, C, heads, ws, shift, Nt;
+  int ldq, ldo;
+  float scale;
+} uz_winattn_desc;
+int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
+                   void* out, float* lse, void* stream);
+int uz_winattn_bwd_rows(const uz_winattn_desc* d); /* rows of `partial`; <0 on error */
+/* dqkv (P, 3C) fully written; partial[row][heads][2][N][N]: sums over the row's windows of dS (-> d bias)
+ * and of d tau (zero where tau < 0.01); add the rows with uz_sum_rows(). */
+int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
+                   const void* out, const float* lse, const void* dout, int lddo, void* dqkv, int lddq,
+                   float* partial, void* stream);
+
 /* out[c] = sum_p x[p*ld + c] (fp32; out zeroed by caller). ConvTranspose2d bias gradient. */
 int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* stream);
 

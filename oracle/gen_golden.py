@@ -170,8 +170,109 @@ def write_u2net():
     print(tag, "loss", meta["loss"], "gnorm", gnorm)
 
 
+def _timm_stand_in():
+    """`swin_unet_v2.py:9` imports three helpers from timm, which this image lacks:
+    to_2tuple, trunc_normal_ (= torch.nn.init.trunc_normal_) and DropPath (stochastic depth: per-sample
+    Bernoulli(keep) / keep in training, identity otherwise).  Supplied in-process; the goldens below
+    use drop_path_rate=0 (train) or eval mode, where DropPath is the identity either way."""
+    import torch.nn as nn
+    layers = types.ModuleType("timm.models.layers")
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob=0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1.0 - self.drop_prob
+            m = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+            return x * m / keep
+
+    layers.DropPath = DropPath
+    layers.to_2tuple = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    timm, models = types.ModuleType("timm"), types.ModuleType("timm.models")
+    timm.models, models.layers = models, layers
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+
+
+def write_swin():
+    """swin_unet_v2.  (A) img 64 / window 4, B=2: full train step (drop_path_rate 0)
+    with every gradient norm + sampled values, eval logits; (B) img 256 / window 8 (the north-star shape)
+    and (C) img 224 / window 7 (BASELINE configs[3] shape), B=1: sampled train/eval logits."""
+    import contextlib
+    import io
+    _timm_stand_in()
+    Ref = load_reference("swin_unet_v2")["swin_unet_v2"].SwinTransformerSys
+
+    def build(img, ws):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            return Ref(img_size=img, in_chans=3, num_classes=1, window_size=ws, drop_path_rate=0.0)
+
+    model = build(64, 4)
+    write_manifest(model, "swin_unet_v2_64_ws4")
+    B, H, tag = 2, 64, "swin_unet_v2_b2_64_ws4"
+    x, mask = synthetic_batch(B, 3, H, H, seed=1)
+    model.train()
+    logits = model(x)
+    loss = F.binary_cross_entropy_with_logits(logits, mask)
+    model.zero_grad()
+    loss.backward()
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+    unused = [n for n, p in model.named_parameters() if p.grad is None]
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)).item()
+    arrays = {"train_logits": logits.detach().numpy()}
+    meta = {"model": "swin_unet_v2", "B": B, "H": H, "W": H, "window_size": 4, "input_sha256": sha(x),
+            "mask_sha256": sha(mask), "loss": loss.item(), "global_grad_norm": gnorm,
+            "grad_l2": {n: p.grad.double().norm().item() for n, p in named}, "unused_parameters": unused,
+            "train_positive_pixels": int((logits > 0).sum().item())}
+    for n, p in named:
+        gi = sample_idx(p.numel(), 64)
+        arrays["gidx/" + n] = gi
+        arrays["gval/" + n] = p.grad.flatten()[gi].numpy()
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)
+    arrays["eval_logits"] = ev.numpy()
+    meta["eval_positive_pixels"] = int((ev > 0).sum().item())
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **arrays)
+    with open(os.path.join(OUT, f"{tag}.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(tag, "loss", meta["loss"], "gnorm", gnorm, "unused", len(unused))
+
+    for img, ws in ((256, 8), (224, 7)):
+        model = build(img, ws)
+        if img == 256:
+            write_manifest(model, "swin_unet_v2_256_ws8")
+        tag = f"swin_unet_v2_b1_{img}_ws{ws}"
+        x, mask = synthetic_batch(1, 3, img, img, seed=1)
+        model.train()
+        with torch.no_grad():
+            tr = model(x)
+        model.eval()
+        with torch.no_grad():
+            ev = model(x)
+        idx = sample_idx(tr.numel(), 8192)
+        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), logit_idx=idx,
+                            train_logits_sampled=tr.flatten()[idx].numpy(), eval_logits_sampled=ev.flatten()[idx].numpy())
+        meta = {"model": "swin_unet_v2", "B": 1, "H": img, "W": img, "window_size": ws, "input_sha256": sha(x),
+                "train_logits_mean": tr.mean().item(), "train_logits_std": tr.std().item(),
+                "train_positive_pixels": int((tr > 0).sum().item()),
+                "loss": F.binary_cross_entropy_with_logits(tr, mask).item()}
+        with open(os.path.join(OUT, f"{tag}.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(tag, meta["train_logits_mean"], meta["train_positive_pixels"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["swin"]:
+        torch.set_num_threads(8)
+        write_swin()
+        return
     if sys.argv[1:] == ["u2net"]:
         torch.set_num_threads(8)
         write_u2net()
@@ -203,6 +304,7 @@ def main():
     model = RefUNet(in_channels=3, num_classes=1)
     run_case(model, 2, 256, 256, "unet_b2_256", full_logits=False)
     write_u2net()
+    write_swin()
 
 
 if __name__ == "__main__":

@@ -237,7 +237,145 @@ def model_loss(outputs, mask: torch.Tensor) -> torch.Tensor:
     return F.binary_cross_entropy_with_logits(outputs, mask)
 
 
-FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward}
+# ---------------------------------------------------------------------------------------------
+# Swin-UNet V2 (unet_zoo/models/swin_unet_v2.py)
+# ---------------------------------------------------------------------------------------------
+def swin_config(sd: State, img_size: int, window_size: int = 7, drop_path_rate: float = 0.1,
+                depths=(2, 2, 2, 2), num_heads=(3, 6, 12, 24), patch_size: int = 4) -> dict:
+    """Static configuration of SwinTransformerSys (swin_unet_v2.py:590-667); embed_dim from the weights."""
+    return {"img": img_size, "ws": window_size, "dpr": drop_path_rate, "depths": tuple(depths),
+            "heads": tuple(num_heads), "patch": patch_size, "embed": sd["patch_embed.proj.weight"].shape[0]}
+
+
+def _layer_norm(x, sd: State, prefix: str):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
+
+
+def swin_attention_mask(H: int, W: int, ws: int, shift: int) -> torch.Tensor:
+    """SwinTransformerBlock.__init__ — swin_unet_v2.py:214-236: (nW, N, N) of 0 / -100."""
+    img = torch.zeros(1, H, W, 1)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, hs, wsl, :] = cnt
+            cnt += 1
+    mw = img.view(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+
+
+def swin_window_attention(xw, sd: State, prefix: str, heads: int, mask):
+    """WindowAttention.forward — swin_unet_v2.py:127-159: cosine attention with a learned per-entry
+    temperature tau (clipped at 0.01), continuous position bias from the log-spaced offsets through
+    cpb = Linear(2,256)-ReLU-Linear(256,heads), optional shift mask, softmax, @v, proj."""
+    B_, N, C = xw.shape
+    d = C // heads
+    qkv = F.linear(xw, sd[prefix + ".qkv.weight"], sd.get(prefix + ".qkv.bias"))
+    qkv = qkv.reshape(B_, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * d ** -0.5, qkv[1], qkv[2]
+    attn = torch.einsum("bhqd,bhkd->bhqk", q, k) / torch.maximum(
+        q.norm(dim=-1, keepdim=True) * k.norm(dim=-1, keepdim=True).transpose(-2, -1),
+        torch.tensor(1e-6, dtype=q.dtype))
+    attn = attn / torch.clip(sd[prefix + ".tau"].unsqueeze(0)[:, :, :N, :N], min=0.01)
+    idx = sd[prefix + ".log_relative_position_index"][:N, :N]
+    bias = F.linear(F.relu(F.linear(idx, sd[prefix + ".cpb.fc1.weight"], sd[prefix + ".cpb.fc1.bias"])),
+                    sd[prefix + ".cpb.fc2.weight"], sd[prefix + ".cpb.fc2.bias"])
+    attn = attn + bias.permute(2, 0, 1).unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    return F.linear(x, sd[prefix + ".proj.weight"], sd[prefix + ".proj.bias"])
+
+
+def swin_block(x, sd: State, prefix: str, H: int, W: int, heads: int, ws: int, shift: int,
+               drop_scale=None):
+    """SwinTransformerBlock.forward — swin_unet_v2.py:240-269.  NOTE: the reference returns after
+    `shortcut + drop_path(norm1(attention))`; its mlp / norm2 members are never called.
+    drop_scale: per-sample (B,) factor of the stochastic-depth branch (None = identity)."""
+    if min(H, W) <= ws:                       # :199-202
+        shift, ws = 0, min(H, W)
+    B, L, C = x.shape
+    xs = x.view(B, H, W, C)
+    if shift > 0:
+        xs = torch.roll(xs, shifts=(-shift, -shift), dims=(1, 2))
+    xw = xs.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    mask = swin_attention_mask(H, W, ws, shift) if shift > 0 else None
+    aw = swin_window_attention(xw, sd, prefix + ".attn", heads, mask)
+    xs = aw.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    if shift > 0:
+        xs = torch.roll(xs, shifts=(shift, shift), dims=(1, 2))
+    y = _layer_norm(xs.reshape(B, L, C), sd, prefix + ".norm1")
+    if drop_scale is not None:
+        y = y * drop_scale.view(B, 1, 1)
+    return x + y
+
+
+def swin_patch_merging(x, sd: State, prefix: str, H: int, W: int):
+    """PatchMerging.forward — swin_unet_v2.py:315-332."""
+    B, L, C = x.shape
+    x = x.view(B, H, W, C)
+    x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).view(B, -1, 4 * C)
+    return F.linear(_layer_norm(x, sd, prefix + ".norm"), sd[prefix + ".reduction.weight"])
+
+
+def swin_patch_expand(x, sd: State, prefix: str, H: int, W: int, r: int):
+    """PatchExpand.forward (r=2, :352-362) / FinalPatchExpand_X4.forward (r=4, :375-387):
+    Linear, 'b h w (p1 p2 c) -> b (h p1) (w p2) c', LayerNorm."""
+    x = F.linear(x, sd[prefix + ".expand.weight"])
+    B, L, C = x.shape
+    c = C // (r * r)
+    x = x.view(B, H, W, r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(B, H * r * W * r, c)
+    return _layer_norm(x, sd, prefix + ".norm")
+
+
+def swin_unet_v2_forward(sd: State, x: torch.Tensor, training: bool, cfg: dict = None,
+                         drop_scales: Dict[str, torch.Tensor] = None) -> torch.Tensor:
+    """SwinTransformerSys.forward — swin_unet_v2.py:711-758.  Stochastic depth (train mode,
+    drop_path_rate > 0) is driven by `drop_scales[block prefix]` = Bernoulli(keep)/keep per sample; with
+    drop_scales None it is the identity (eval mode, or drop_path_rate 0)."""
+    if cfg is None:
+        cfg = swin_config(sd, x.shape[-1])
+    E, ws, depths, heads, ps = cfg["embed"], cfg["ws"], cfg["depths"], cfg["heads"], cfg["patch"]
+    nl = len(depths)
+    B = x.shape[0]
+    R = cfg["img"] // ps
+    ds = drop_scales or {}
+    # PatchEmbed (:548-556): Conv2d(k=s=patch) -> tokens -> LayerNorm
+    t = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
+    t = _layer_norm(t, sd, "patch_embed.norm")
+    skips = []
+    for i in range(nl):                                       # forward_features (:711-723)
+        skips.append(t)
+        r = R >> i
+        for b in range(depths[i]):
+            pre = f"layers.{i}.blocks.{b}"
+            t = swin_block(t, sd, pre, r, r, heads[i], ws, 0 if b % 2 == 0 else ws // 2, ds.get(pre))
+        if i < nl - 1:
+            t = swin_patch_merging(t, sd, f"layers.{i}.downsample", r, r)
+    t = _layer_norm(t, sd, "norm")
+    for inx in range(nl):                                     # forward_up_features (:725-741)
+        lvl = nl - 1 - inx
+        r = R >> lvl
+        if inx == 0:
+            t = swin_patch_expand(t, sd, "layers_up.0", r, r, 2)
+            continue
+        t = torch.cat([t, skips[lvl]], -1)
+        t = F.linear(t, sd[f"concat_back_dim.{inx}.weight"], sd[f"concat_back_dim.{inx}.bias"])
+        for b in range(depths[lvl]):
+            pre = f"layers_up.{inx}.blocks.{b}"
+            t = swin_block(t, sd, pre, r, r, heads[lvl], ws, 0 if b % 2 == 0 else ws // 2, ds.get(pre))
+        if inx < nl - 1:
+            t = swin_patch_expand(t, sd, f"layers_up.{inx}.upsample", r, r, 2)
+    t = _layer_norm(t, sd, "norm_up")
+    t = swin_patch_expand(t, sd, "up", R, R, 4)               # up_x4 (:743-754)
+    t = t.view(B, 4 * R, 4 * R, E).permute(0, 3, 1, 2)
+    return F.conv2d(t, sd["output.weight"])
+
+
+FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward,
+            "swin_unet_v2": swin_unet_v2_forward}
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":
@@ -251,18 +389,20 @@ def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, tor
 
 
 def _is_buffer(key: str) -> bool:
-    return key.endswith(("running_mean", "running_var", "num_batches_tracked"))
+    return key.endswith(("running_mean", "running_var", "num_batches_tracked", "attn_mask",
+                         "log_relative_position_index"))
 
 
-def train_step_reference(model_name: str, sd: State, x: torch.Tensor, mask: torch.Tensor):
+def train_step_reference(model_name: str, sd: State, x: torch.Tensor, mask: torch.Tensor, **fw_kwargs):
     """One forward + BCEWithLogits + backward of the reference step
     (unet_zoo/utils/training_loop.py:112-119, criterion from scripts/train.py:135).
     Returns (logits, loss, {param name: grad}, updated state with new running stats)."""
     st = clone_state(sd, requires_grad=True)
-    logits = FORWARDS[model_name](st, x.float().cpu(), True)
+    logits = FORWARDS[model_name](st, x.float().cpu(), True, **fw_kwargs)
     loss = model_loss(logits, mask.float().cpu())
     names = [k for k, v in st.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [st[k] for k in names])
+    grads = torch.autograd.grad(loss, [st[k] for k in names], allow_unused=True)
+    names, grads = zip(*[(n, g) for n, g in zip(names, grads) if g is not None])  # swin: mlp / norm2 are unused
     if isinstance(logits, dict):
         logits = {k: v.detach() for k, v in logits.items()}
     else:

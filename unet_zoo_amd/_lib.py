@@ -32,6 +32,8 @@ EXPORTS = (
     "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
     "uz_conv_igemm_workspace_bytes", "uz_conv_igemm_ws_grid_m", "uz_conv_igemm_ws",
+    "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd",
+    "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
 )
 
 
@@ -49,6 +51,19 @@ class WgradDesc(Structure):
 class BnBwdDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         "dtype", "N", "H", "W", "C", "ldy", "ldg0", "ldg1", "ldgp", "lddy")]
+
+
+class LnDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("dtype", "N", "Ho", "Wo", "C", "ldx", "ldy", "ldr", "ldg", "lddx", "mode", "r")] \
+        + [("eps", c_float)]
+
+
+class WinAttnDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("dtype", "B", "H", "W", "C", "heads", "ws", "shift", "Nt", "ldq", "ldo")] \
+        + [("scale", c_float)]
+
+
+LN_PLAIN, LN_MERGE, LN_EXPAND = 0, 1, 2
 
 
 class PackItem(Structure):
@@ -87,6 +102,13 @@ def load():
     lib.uz_conv_igemm_workspace_bytes.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm_ws_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm_ws.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_patchify.argtypes = [ip, vp, ip, ip, ip, ip, ip, ip, vp, vp]
+    lib.uz_layernorm_fwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_layernorm_bwd_rows.argtypes = [POINTER(LnDesc)]
+    lib.uz_layernorm_bwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_winattn_fwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp]
+    lib.uz_winattn_bwd_rows.argtypes = [POINTER(WinAttnDesc)]
+    lib.uz_winattn_bwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp]
     lib.uz_wgrad_split.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad_workspace_bytes.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]

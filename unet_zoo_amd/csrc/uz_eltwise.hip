@@ -331,6 +331,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 // on one pixel (one 16-byte load each) and combine with xor-shuffles.
 // ------------------------------------------------------------------------------------------
 constexpr int OUTCONV_MAXK = 8;
+__host__ __device__ inline int lanes_per_pixel(int chunks) {  // power of two >= chunks
+  int l = 1;
+  while (l < chunks) l <<= 1;
+  return l;
+}
 
 template <typename T, int KOUT>
 __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ x, int ldx, int N,
@@ -338,19 +343,20 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ b,
                                                           float* __restrict__ out) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  const int LPP = C / VEC;  // lanes per pixel: power of two, <= 64
+  const int LPP = lanes_per_pixel(C / VEC);  // power of two >= C/VEC, <= 64; lanes >= C/VEC carry zeros
   const int ppb = blockDim.x / LPP;
   const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+  const bool live = sub < C / VEC;
   const int P = N * HW;  // < 2^31 (checked on the host)
   float wr[KOUT][VEC];
 #pragma unroll
   for (int k = 0; k < KOUT; ++k)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) wr[k][i] = w[k * C + sub * VEC + i];
+    for (int i = 0; i < VEC; ++i) wr[k][i] = live ? w[k * C + sub * VEC + i] : 0.f;
   for (int p0 = blockIdx.x * ppb; p0 < P; p0 += gridDim.x * ppb) {
     const int p = p0 + pl;
     float v[VEC];
-    if (p < P) {
+    if (p < P && live) {
       load_f(x + (size_t)p * ldx + sub * VEC, v);
     } else {
 #pragma unroll
@@ -380,9 +386,10 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int UNR = 4;
   __shared__ float red[256 * 9];
-  const int LPP = C / VEC;
+  const int LPP = lanes_per_pixel(C / VEC);
   const int ppb = blockDim.x / LPP;
   const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+  const bool live = sub < C / VEC;
   const int P = N * HW;  // < 2^31 (checked on the host)
   float wr[KOUT][VEC], aw[KOUT][VEC], ab[KOUT];
 #pragma unroll
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
     ab[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      wr[k][i] = w[k * C + sub * VEC + i];
+      wr[k][i] = live ? w[k * C + sub * VEC + i] : 0.f;
       aw[k][i] = 0.f;
     }
   }
@@ -402,7 +409,12 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
       const int p = p0 + u * ppb + pl;
       pp[u] = p < P ? p : -1;
       if (pp[u] >= 0) {
-        load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
+        if (live) {
+          load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+        }
         const int img = (KOUT == 1) ? 0 : p / HW;  // KOUT == 1: NCHW index == pixel index
         const int hw = p - img * HW;
 #pragma unroll
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
           aw[k][i] = fmaf(gk[u][k], v[u][i], aw[k][i]);
         }
       }
-      if (dx != nullptr && pp[u] >= 0) store_f(dx + (size_t)pp[u] * lddx + sub * VEC, d);
+      if (dx != nullptr && pp[u] >= 0 && live) store_f(dx + (size_t)pp[u] * lddx + sub * VEC, d);
     }
   }
   // block reduction over the ppb pixel lanes that share `sub`
@@ -448,8 +460,10 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
         for (int i = 0; i < 9; ++i)
           if (i < VEC || i == 8) t[i] += red[(r * LPP + sub) * 9 + i];
       float* row = partial + ((size_t)blockIdx.x * KOUT + k) * (C + 1);
+      if (live) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) row[sub * VEC + i] = t[i];
+        for (int i = 0; i < VEC; ++i) row[sub * VEC + i] = t[i];
+      }
       if (sub == 0) row[C] = t[8];
     }
   }
@@ -658,7 +672,6 @@ int grid_for(long long total, int block) {
   return (int)g;
 }
 
-bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // thread-block shape for the (channel-chunk x pixel) reductions
 void reduce_shape(int CC, long long units, dim3* grid, dim3* block, int wg_per_cu = 2) {
@@ -871,10 +884,10 @@ extern "C" int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, 
   const int vec = dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(x && w && b && out_nchw, "uz_outconv_fwd: null pointer");
   UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_fwd: Kout=%d (max %d)", Kout, OUTCONV_MAXK);
-  UZ_REQUIRE(C % vec == 0 && is_pow2(C / vec) && C / vec <= 64, "uz_outconv_fwd: C=%d unsupported", C);
+  UZ_REQUIRE(C % vec == 0 && C / vec <= 64, "uz_outconv_fwd: C=%d unsupported", C);
   UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0 && (long long)N * HW < (1LL << 31),
              "uz_outconv_fwd: bad shape");
-  const int ppb = 256 / (C / vec);
+  const int ppb = 256 / lanes_per_pixel(C / vec);
   const int grid = grid_for(((long long)N * HW + ppb - 1) / ppb, 1);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16) {
@@ -888,7 +901,7 @@ extern "C" int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, 
 
 static int outconv_bwd_grid(int dtype, int N, int HW, int C) {
   const int vec = dtype == UZ_BF16 ? 8 : 4;
-  const int ppb = 256 / (C / vec);
+  const int ppb = 256 / lanes_per_pixel(C / vec);
   long long g = ((long long)N * HW + (long long)ppb * 4 - 1) / ((long long)ppb * 4);
   if (g > UZ_NUM_CU * 4) g = UZ_NUM_CU * 4;
   if (g < 1) g = 1;
@@ -898,7 +911,7 @@ static int outconv_bwd_grid(int dtype, int N, int HW, int C) {
 extern "C" long long uz_outconv_bwd_workspace_bytes(int dtype, int N, int HW, int C, int Kout) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_outconv_bwd_workspace_bytes: bad dtype");
   const int vec = dtype == UZ_BF16 ? 8 : 4;
-  UZ_REQUIRE(N > 0 && HW > 0 && Kout >= 1 && Kout <= OUTCONV_MAXK && C % vec == 0 && is_pow2(C / vec) && C / vec <= 64,
+  UZ_REQUIRE(N > 0 && HW > 0 && Kout >= 1 && Kout <= OUTCONV_MAXK && C % vec == 0 && C / vec <= 64,
              "uz_outconv_bwd_workspace_bytes: bad shape");
   return (long long)outconv_bwd_grid(dtype, N, HW, C) * Kout * (C + 1) * (long long)sizeof(float);
 }
@@ -910,7 +923,7 @@ extern "C" int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, 
   const int vec = dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(x && w && g_nchw && dw && db && workspace, "uz_outconv_bwd: null pointer");
   UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_bwd: Kout=%d", Kout);
-  UZ_REQUIRE(C % vec == 0 && is_pow2(C / vec) && C / vec <= 64, "uz_outconv_bwd: C=%d unsupported", C);
+  UZ_REQUIRE(C % vec == 0 && C / vec <= 64, "uz_outconv_bwd: C=%d unsupported", C);
   UZ_REQUIRE(ldx % vec == 0 && ldx >= C && N > 0 && HW > 0 && (long long)N * HW < (1LL << 31),
              "uz_outconv_bwd: bad shape");
   if (dx) UZ_REQUIRE(lddx % vec == 0 && lddx >= C, "uz_outconv_bwd: bad lddx");

@@ -1,0 +1,630 @@
+// Swin-UNet V2 specific kernels for gfx950 (MI355X)  (reference: unet_zoo/models/swin_unet_v2.py):
+//   * patch extraction for PatchEmbed's Conv2d(k = s = patch)                           (:548-556)
+//   * LayerNorm forward / backward over the channel dimension of a token tensor [P][C], with the
+//     reference's token permutations folded into the addressing — PatchMerging's 2x2 gather+concat
+//     (:315-332), PatchExpand / FinalPatchExpand_X4's 'b h w (p1 p2 c) -> b (h p1) (w p2) c'
+//     (:352-362, :375-387) — and the block tail `shortcut + drop_path(norm1(.))` (:264-267) fused in
+//   * window attention core, forward / backward                                          (:127-159):
+//     cosine attention with learned per-entry temperature tau (clipped at 0.01), additive continuous
+//     position bias, shifted-window mask computed from the region ids (:214-236), softmax, @v.
+//     window_partition / torch.roll / window_reverse (:30-56, :246-262) are index arithmetic here:
+//     a (window, head) workgroup reads q, k, v of its tokens from the [P][3C] qkv tensor and writes
+//     the head's output back to the SAME token rows.
+// The Linear layers around these run on the LDS-DMA GEMM (uz_gemm_dma.hip) and the weight-gradient
+// kernels.  Everything here is bandwidth / latency bound: the attention core is 0.5 MFLOP per
+// (window, head) and 3 % of the model's flops, so it is plain fp32 VALU code, one thread per query
+// (forward, first backward phase) or per key (second backward phase), flash-style: the forward keeps
+// only the row log-sum-exp, the backward recomputes P.
+#include "uz_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void load_f(const T* p, float* f) {
+  const Vec16<T> v = ld16(p);
+#pragma unroll
+  for (int i = 0; i < ElemTraits<T>::VEC; ++i) f[i] = (float)v.v[i];
+}
+template <typename T> __device__ __forceinline__ void store_f(T* p, const float* f) {
+  Vec16<T> v;
+#pragma unroll
+  for (int i = 0; i < ElemTraits<T>::VEC; ++i) v.v[i] = (T)f[i];
+  st16(p, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// patches: out[p = (b, i, j)][k = (kh*ps + kw)*C + c] = x[b][c][i*ps + kh][j*ps + kw], zero for k >= ps*ps*C
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, int N, int C, int H, int W, int ps,
+                                                       int Kpad, T* __restrict__ out) {
+  const int Ho = H / ps, Wo = W / ps, K = ps * ps * C;
+  const long long total = (long long)N * Ho * Wo * Kpad;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Kpad);
+    const long long p = idx / Kpad;
+    float v = 0.f;
+    if (k < K) {
+      const int c = k % C, tap = k / C, kh = tap / ps, kw = tap - kh * ps;
+      const int j = (int)(p % Wo);
+      const long long t = p / Wo;
+      const int i = (int)(t % Ho), b = (int)(t / Ho);
+      v = x[(((size_t)b * C + c) * H + i * ps + kh) * W + j * ps + kw];
+    }
+    out[idx] = (T)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm.  Output token t (grid Ho x Wo, C channels); its input row is assembled by `mode`:
+//   0 plain     : x[t][c]
+//   1 merge 2x2 : Ho = H/2; channel segment s = c / (C/4) comes from input token (2i + (s&1), 2j + (s>>1)),
+//                 channels c - s*C/4 (torch.cat([x0, x1, x2, x3], -1) of PatchMerging)
+//   2 expand r  : Ho = H*r; output token (h*r + p1, w*r + p2) reads input token (h, w), channels
+//                 (p1*r + p2)*C + c
+// y = [res +] [sb[image] *] (xhat * gamma + beta); mean and rstd per token are kept for the backward.
+// One wave per token, lanes stride over the 16-byte channel chunks (at most MAXIT per lane).
+// ---------------------------------------------------------------------------------------------
+struct LnArgs {
+  const void* x;
+  void* y;            // fwd: output; bwd: unused
+  const void* res;    // fwd: optional residual (same layout as y)
+  const void* g;      // bwd: gradient of y
+  void* dx;           // bwd: gradient of x (mapped like x)
+  const float* gamma;
+  const float* beta;
+  const float* sb;    // optional per-image factor of the normalised branch (stochastic depth)
+  float* stats;       // [P_out][2] mean, rstd
+  float* partial;     // bwd: [gridDim.x][2][C] sums of g*xhat (dgamma) and g (dbeta)
+  int N, Ho, Wo, C, ldx, ldy, ldr, ldg, lddx, mode, r;
+  float eps;
+};
+
+constexpr int LN_MAXIT = 6;     // 16-byte chunks per lane: C <= 64 * 6 * 4 = 1536 in fp32
+constexpr int LN_MAXC = 1536;   // PatchMerging of the 384-channel stage: LayerNorm(4 * 384)
+
+template <typename T> __device__ __forceinline__ size_t ln_src(const LnArgs& a, int img, int oh, int ow, int c0, int ld) {
+  if (a.mode == 0) return ((size_t)(img * a.Ho + oh) * a.Wo + ow) * ld + c0;
+  if (a.mode == 1) {
+    const int Cq = a.C >> 2, s = c0 / Cq;
+    const int H = a.Ho * 2, W = a.Wo * 2;
+    return ((size_t)(img * H + 2 * oh + (s & 1)) * W + 2 * ow + (s >> 1)) * ld + (c0 - s * Cq);
+  }
+  const int r = a.r, H = a.Ho / r, W = a.Wo / r;
+  const int h = oh / r, p1 = oh - h * r, w = ow / r, p2 = ow - w * r;
+  return ((size_t)(img * H + h) * W + w) * ld + (p1 * r + p2) * a.C + c0;
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int CC = a.C / VEC;
+  const int P = a.N * a.Ho * a.Wo;
+  const T* __restrict__ x = static_cast<const T*>(a.x);
+  float gam[LN_MAXIT][VEC], bet[LN_MAXIT][VEC], ag[LN_MAXIT][VEC], ab[LN_MAXIT][VEC];
+#pragma unroll
+  for (int it = 0; it < LN_MAXIT; ++it) {
+    const int cc = lane + 64 * it;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      gam[it][e] = cc < CC ? a.gamma[cc * VEC + e] : 0.f;
+      bet[it][e] = (!BWD && cc < CC) ? a.beta[cc * VEC + e] : 0.f;
+      ag[it][e] = ab[it][e] = 0.f;
+    }
+  }
+  const float invC = 1.f / (float)a.C;
+  for (int t = blockIdx.x * 4 + wave; t < P; t += gridDim.x * 4) {
+    const int ow = t % a.Wo, tt = t / a.Wo, oh = tt % a.Ho, img = tt / a.Ho;
+    float v[LN_MAXIT][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+      const int cc = lane + 64 * it;
+      if (cc < CC) {
+        load_f(x + ln_src<T>(a, img, oh, ow, cc * VEC, a.ldx), v[it]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[it][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[it][e] = 0.f;
+      }
+    }
+    float mean, rstd;
+    if constexpr (!BWD) {
+      mean = wave_sum(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int it = 0; it < LN_MAXIT; ++it)
+        if (lane + 64 * it < CC) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float d = v[it][e] - mean;
+            q += d * d;
+          }
+        }
+      rstd = rsqrtf(wave_sum(q) * invC + a.eps);
+      if (lane == 0) {
+        a.stats[(size_t)t * 2] = mean;
+        a.stats[(size_t)t * 2 + 1] = rstd;
+      }
+      const float f = a.sb != nullptr ? a.sb[img] : 1.f;
+      T* __restrict__ y = static_cast<T*>(a.y);
+      const T* __restrict__ res = static_cast<const T*>(a.res);
+#pragma unroll
+      for (int it = 0; it < LN_MAXIT; ++it) {
+        const int cc = lane + 64 * it;
+        if (cc < CC) {
+          float o[VEC], rv[VEC];
+          if (res != nullptr) load_f(res + (size_t)t * a.ldr + cc * VEC, rv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            o[e] = f * ((v[it][e] - mean) * rstd * gam[it][e] + bet[it][e]);
+            if (res != nullptr) o[e] += rv[e];
+          }
+          store_f(y + (size_t)t * a.ldy + cc * VEC, o);
+        }
+      }
+    } else {
+      mean = a.stats[(size_t)t * 2];
+      rstd = a.stats[(size_t)t * 2 + 1];
+      const float f = a.sb != nullptr ? a.sb[img] : 1.f;
+      const T* __restrict__ g = static_cast<const T*>(a.g);
+      T* __restrict__ dx = static_cast<T*>(a.dx);
+      float gv[LN_MAXIT][VEC];
+      float s1 = 0.f, s2 = 0.f;  // sum of g*gamma, sum of g*gamma*xhat
+#pragma unroll
+      for (int it = 0; it < LN_MAXIT; ++it) {
+        const int cc = lane + 64 * it;
+        if (cc < CC) {
+          load_f(g + (size_t)t * a.ldg + cc * VEC, gv[it]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            gv[it][e] *= f;
+            const float xh = (v[it][e] - mean) * rstd;
+            ag[it][e] += gv[it][e] * xh;
+            ab[it][e] += gv[it][e];
+            const float gg = gv[it][e] * gam[it][e];
+            s1 += gg;
+            s2 += gg * xh;
+          }
+        }
+      }
+      s1 = wave_sum(s1) * invC;
+      s2 = wave_sum(s2) * invC;
+#pragma unroll
+      for (int it = 0; it < LN_MAXIT; ++it) {
+        const int cc = lane + 64 * it;
+        if (cc < CC) {
+          float o[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float xh = (v[it][e] - mean) * rstd;
+            o[e] = rstd * (gv[it][e] * gam[it][e] - s1 - xh * s2);
+          }
+          store_f(dx + ln_src<T>(a, img, oh, ow, cc * VEC, a.lddx), o);
+        }
+      }
+    }
+  }
+  if constexpr (BWD) {
+    // one partial row per workgroup: sum the four waves through LDS
+    __shared__ float red[4][2][LN_MAXC];
+    float* mine0 = &red[wave][0][0];
+    float* mine1 = &red[wave][1][0];
+#pragma unroll
+    for (int it = 0; it < LN_MAXIT; ++it) {
+      const int cc = lane + 64 * it;
+      if (cc < CC) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          mine0[cc * VEC + e] = ag[it][e];
+          mine1[cc * VEC + e] = ab[it][e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) {
+      const int which = c / a.C, ch = c - which * a.C;
+      a.partial[((size_t)blockIdx.x * 2 + which) * a.C + ch] =
+          red[0][which][ch] + red[1][which][ch] + red[2][which][ch] + red[3][which][ch];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window attention.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const void* qkv;    // [P][3C]: per token [3][heads][32]
+  void* out;          // [P][C]   (bwd: the forward output, read)
+  float* lse;         // [B*nW][heads][N] row log-sum-exp
+  const float* tau;   // [heads][Nt][Nt] (Nt = window_size^2 of the parameter, N <= Nt used)
+  const float* bias;  // [heads][N][N]
+  const void* dout;   // bwd: gradient of out [P][C]
+  void* dqkv;         // bwd: gradient of qkv [P][3C]
+  float* partial;     // bwd: [gridDim.x][heads][2][N][N] sums of dS (dbias) and d(tau)
+  int B, H, W, C, heads, ws, shift, Nt;
+  int ldq, ldo, lddo, lddq;
+  float scale;
+};
+
+constexpr int AD = 32;       // head dimension (embed_dim 96 / 3 heads, doubled together: always 32)
+constexpr int AN = 64;       // max tokens per window (window_size <= 8)
+constexpr int ARS = AD + 1;  // LDS row stride of the [token][32] tiles (conflict-free row writes)
+constexpr int ANS = AN + 1;  // LDS row stride of the [N][N] matrices
+
+struct WinTok {
+  int tok;   // row of the token tensor
+  int cnt;   // region id of the shifted-window mask
+};
+__device__ __forceinline__ WinTok win_token(const AttnArgs& a, int win, int i) {
+  const int nwx = a.W / a.ws, nwy = a.H / a.ws, nW = nwx * nwy;
+  const int b = win / nW, wi = win - b * nW, wy = wi / nwx, wx = wi - wy * nwx;
+  const int iy = i / a.ws, ix = i - iy * a.ws;
+  const int hs = wy * a.ws + iy, wsx = wx * a.ws + ix;  // coordinates in the rolled image
+  int h = hs + a.shift, w = wsx + a.shift;
+  if (h >= a.H) h -= a.H;
+  if (w >= a.W) w -= a.W;
+  WinTok t;
+  t.tok = (b * a.H + h) * a.W + w;
+  const int hid = hs < a.H - a.ws ? 0 : (hs < a.H - a.shift ? 1 : 2);
+  const int wid = wsx < a.W - a.ws ? 0 : (wsx < a.W - a.shift ? 1 : 2);
+  t.cnt = a.shift > 0 ? hid * 3 + wid : 0;
+  return t;
+}
+
+template <typename T> __device__ __forceinline__ void load_head(const T* p, float* f) {  // 32 values
+  constexpr int VEC = ElemTraits<T>::VEC;
+#pragma unroll
+  for (int c = 0; c < AD / VEC; ++c) load_f(p + c * VEC, f + c * VEC);
+}
+template <typename T> __device__ __forceinline__ void store_head(T* p, const float* f) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+#pragma unroll
+  for (int c = 0; c < AD / VEC; ++c) store_f(p + c * VEC, f + c * VEC);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnArgs a) {
+  __shared__ float sK[AN * ARS], sV[AN * ARS], sKn[AN], sTi[AN * ANS], sBi[AN * ANS];
+  __shared__ int sCnt[AN];
+  const int i = threadIdx.x, h = blockIdx.y;
+  const int N = a.ws * a.ws;
+  const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
+  const T* __restrict__ qkv = static_cast<const T*>(a.qkv);
+  T* __restrict__ out = static_cast<T*>(a.out);
+  // this head's 1/clip(tau) and bias, staged once (coalesced) for all windows of the workgroup
+  for (int e = i; e < N * N; e += 64) {
+    const int r = e / N, c = e - r * N;
+    sTi[r * ANS + c] = 1.f / fmaxf(a.tau[((size_t)h * a.Nt + r) * a.Nt + c], 0.01f);
+    sBi[r * ANS + c] = a.bias[((size_t)h * N + r) * N + c];
+  }
+  for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
+    __syncthreads();  // previous window's readers are done (and the staging above has landed)
+    float q[AD];
+    float qn = 0.f;
+    WinTok me = {0, 0};
+    if (i < N) {
+      me = win_token(a, win, i);
+      const T* row = qkv + (size_t)me.tok * a.ldq + h * AD;
+      float kv[AD];
+      load_head(row, q);
+      load_head(row + a.C, kv);
+      float kn = 0.f;
+#pragma unroll
+      for (int e = 0; e < AD; ++e) {
+        q[e] *= a.scale;
+        qn += q[e] * q[e];
+        kn += kv[e] * kv[e];
+        sK[i * ARS + e] = kv[e];
+      }
+      sKn[i] = sqrtf(kn);
+      load_head(row + 2 * a.C, kv);
+#pragma unroll
+      for (int e = 0; e < AD; ++e) sV[i * ARS + e] = kv[e];
+      sCnt[i] = me.cnt;
+      qn = sqrtf(qn);
+    }
+    __syncthreads();
+    if (i < N) {
+      float m = -INFINITY, l = 0.f, o[AD];
+#pragma unroll
+      for (int e = 0; e < AD; ++e) o[e] = 0.f;
+      for (int j = 0; j < N; ++j) {
+        float u = 0.f;
+#pragma unroll
+        for (int e = 0; e < AD; ++e) u = fmaf(q[e], sK[j * ARS + e], u);
+        float s = u / fmaxf(qn * sKn[j], 1e-6f) * sTi[i * ANS + j] + sBi[i * ANS + j];
+        if (sCnt[j] != me.cnt) s -= 100.f;
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn), p = __expf(s - mn);
+        l = l * corr + p;
+#pragma unroll
+        for (int e = 0; e < AD; ++e) o[e] = fmaf(p, sV[j * ARS + e], o[e] * corr);
+        m = mn;
+      }
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int e = 0; e < AD; ++e) o[e] *= inv;
+      store_head(out + (size_t)me.tok * a.ldo + h * AD, o);
+      a.lse[((size_t)win * a.heads + h) * N + i] = m + __logf(l);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnArgs a) {
+  // per window: phase A, thread = query i (row of dS, dq); phase B, thread = key j (dk, dv)
+  __shared__ float sK[AN * ARS], sV[AN * ARS], sQ[AN * ARS], sG[AN * ARS], sKn[AN], sQn[AN];
+  __shared__ float sP[AN * ANS], sDC[AN * ANS], sDB[AN * ANS], sDT[AN * ANS];
+  __shared__ int sCnt[AN];
+  const int i = threadIdx.x, h = blockIdx.y;
+  const int N = a.ws * a.ws;
+  const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
+  const T* __restrict__ qkv = static_cast<const T*>(a.qkv);
+  const T* __restrict__ out = static_cast<const T*>(a.out);
+  const T* __restrict__ dout = static_cast<const T*>(a.dout);
+  T* __restrict__ dqkv = static_cast<T*>(a.dqkv);
+  for (int e = i; e < AN * ANS; e += 64) sDB[e] = sDT[e] = 0.f;
+  for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
+    __syncthreads();
+    float q[AD], kk[AD], go[AD];
+    float qn = 0.f, kn = 0.f, Di = 0.f;
+    WinTok me = {0, 0};
+    if (i < N) {
+      me = win_token(a, win, i);
+      const T* row = qkv + (size_t)me.tok * a.ldq + h * AD;
+      float t[AD];
+      load_head(row, q);
+      load_head(row + a.C, kk);
+      load_head(row + 2 * a.C, t);
+      load_head(dout + (size_t)me.tok * a.lddo + h * AD, go);
+#pragma unroll
+      for (int e = 0; e < AD; ++e) {
+        q[e] *= a.scale;
+        qn += q[e] * q[e];
+        kn += kk[e] * kk[e];
+        sK[i * ARS + e] = kk[e];
+        sV[i * ARS + e] = t[e];
+        sQ[i * ARS + e] = q[e];
+        sG[i * ARS + e] = go[e];
+      }
+      load_head(out + (size_t)me.tok * a.ldo + h * AD, t);
+#pragma unroll
+      for (int e = 0; e < AD; ++e) Di = fmaf(go[e], t[e], Di);
+      qn = sqrtf(qn);
+      kn = sqrtf(kn);
+      sQn[i] = qn;
+      sKn[i] = kn;
+      sCnt[i] = me.cnt;
+    }
+    __syncthreads();
+    if (i < N) {  // ---- phase A: query row i
+      const float lse = a.lse[((size_t)win * a.heads + h) * N + i];
+      float av[AD], bs = 0.f;
+#pragma unroll
+      for (int e = 0; e < AD; ++e) av[e] = 0.f;
+      for (int j = 0; j < N; ++j) {
+        float u = 0.f, dp = 0.f;
+#pragma unroll
+        for (int e = 0; e < AD; ++e) {
+          u = fmaf(q[e], sK[j * ARS + e], u);
+          dp = fmaf(go[e], sV[j * ARS + e], dp);
+        }
+        const float nn = qn * sKn[j];
+        const bool clamped = nn <= 1e-6f;
+        const float den = clamped ? 1e-6f : nn;
+        const float tv = a.tau[((size_t)h * a.Nt + i) * a.Nt + j];
+        const float ti = 1.f / fmaxf(tv, 0.01f);
+        const float c = u / den;
+        float s = c * ti + a.bias[((size_t)h * N + i) * N + j];
+        if (sCnt[j] != me.cnt) s -= 100.f;
+        const float p = __expf(s - lse);
+        const float ds = p * (dp - Di);
+        sP[i * ANS + j] = p;
+        sDB[i * ANS + j] += ds;
+        if (tv >= 0.01f) sDT[i * ANS + j] -= ds * c * ti * ti;
+        const float dc = ds * ti;
+        sDC[i * ANS + j] = dc;
+        const float w1 = dc / den;
+#pragma unroll
+        for (int e = 0; e < AD; ++e) av[e] = fmaf(w1, sK[j * ARS + e], av[e]);
+        if (!clamped) bs += dc * u * sKn[j] / (den * den * qn);   // d(den)/d(qs_i) = kn_j * qs_i / n_i
+      }
+      float dq[AD];
+#pragma unroll
+      for (int e = 0; e < AD; ++e) dq[e] = a.scale * (av[e] - bs * q[e]);
+      store_head(dqkv + (size_t)me.tok * a.lddq + h * AD, dq);
+    }
+    __syncthreads();
+    if (i < N) {  // ---- phase B: key column j = i
+      const int j = i;
+      float dk[AD], dv[AD], bs = 0.f;
+#pragma unroll
+      for (int e = 0; e < AD; ++e) dk[e] = dv[e] = 0.f;
+      for (int r = 0; r < N; ++r) {
+        const float p = sP[r * ANS + j], dc = sDC[r * ANS + j];
+        float u = 0.f;
+#pragma unroll
+        for (int e = 0; e < AD; ++e) {
+          u = fmaf(sQ[r * ARS + e], kk[e], u);
+          dv[e] = fmaf(p, sG[r * ARS + e], dv[e]);
+        }
+        const float nn = sQn[r] * kn;
+        const bool clamped = nn <= 1e-6f;
+        const float den = clamped ? 1e-6f : nn;
+        const float w1 = dc / den;
+#pragma unroll
+        for (int e = 0; e < AD; ++e) dk[e] = fmaf(w1, sQ[r * ARS + e], dk[e]);
+        if (!clamped) bs += dc * u * sQn[r] / (den * den * kn);
+      }
+#pragma unroll
+      for (int e = 0; e < AD; ++e) dk[e] -= bs * kk[e];
+      T* row = dqkv + (size_t)me.tok * a.lddq + h * AD;
+      store_head(row + a.C, dk);
+      store_head(row + 2 * a.C, dv);
+    }
+  }
+  __syncthreads();
+  float* part = a.partial + ((size_t)blockIdx.x * a.heads + h) * 2 * N * N;
+  for (int e = i; e < N * N; e += 64) {
+    const int r = e / N, c = e - r * N;
+    part[e] = sDB[r * ANS + c];
+    part[N * N + e] = sDT[r * ANS + c];
+  }
+}
+
+inline int grid_cap(long long units, int per_block, int per_cu) {
+  long long g = (units + per_block - 1) / per_block;
+  const long long cap = (long long)UZ_NUM_CU * per_cu;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int ln_check(const char* fn, const uz_ln_desc* d) {
+  UZ_REQUIRE(d != nullptr, "%s: null descriptor", fn);
+  UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "%s: bad dtype", fn);
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->C > 0 && d->C % vec == 0, "%s: bad shape", fn);
+  UZ_REQUIRE(d->C / vec <= 64 * LN_MAXIT && d->C <= LN_MAXC, "%s: C=%d too large (max %d)", fn, d->C, LN_MAXC);
+  UZ_REQUIRE(d->mode >= 0 && d->mode <= 2, "%s: bad mode %d", fn, d->mode);
+  if (d->mode == 1) UZ_REQUIRE(d->C % (4 * vec) == 0 && d->ldx % vec == 0 && d->ldx >= d->C / 4, "%s: merge needs C %% %d == 0", fn, 4 * vec);
+  if (d->mode == 2) UZ_REQUIRE(d->r >= 1 && d->Ho % d->r == 0 && d->Wo % d->r == 0 && d->ldx >= d->r * d->r * d->C, "%s: bad expand factor", fn);
+  if (d->mode == 0) UZ_REQUIRE(d->ldx >= d->C, "%s: bad ldx", fn);
+  UZ_REQUIRE(d->ldx % vec == 0, "%s: ldx must be a multiple of %d", fn, vec);
+  UZ_REQUIRE((long long)d->N * d->Ho * d->Wo < (1LL << 31), "%s: too many tokens", fn);
+  return UZ_OK;
+}
+
+int ln_grid(const uz_ln_desc* d) { return grid_cap((long long)d->N * d->Ho * d->Wo, 4 * 4, 4); }
+
+}  // namespace
+
+extern "C" int uz_patchify(int dtype, const float* x_nchw, int N, int C, int H, int W, int patch, int Kpad,
+                           void* out, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_patchify: bad dtype");
+  UZ_REQUIRE(x_nchw && out && N > 0 && C > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "uz_patchify: bad shape");
+  UZ_REQUIRE(Kpad >= patch * patch * C, "uz_patchify: Kpad too small");
+  const long long total = (long long)N * (H / patch) * (W / patch) * Kpad;
+  const dim3 grid(grid_cap(total, 256, 16)), block(256);
+  if (dtype == UZ_BF16) hipLaunchKernelGGL((patchify_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, x_nchw, N, C, H, W, patch, Kpad, (bf16_t*)out);
+  else hipLaunchKernelGGL((patchify_kernel<float>), grid, block, 0, (hipStream_t)stream, x_nchw, N, C, H, W, patch, Kpad, (float*)out);
+  UZ_LAUNCH_CHECK("uz_patchify");
+  return UZ_OK;
+}
+
+extern "C" int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
+                                const void* res, const float* image_scale, void* y, float* stats, void* stream) {
+  const int rc = ln_check("uz_layernorm_fwd", d);
+  if (rc != UZ_OK) return rc;
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && gamma && beta && y && stats, "uz_layernorm_fwd: null pointer");
+  UZ_REQUIRE(d->ldy % vec == 0 && d->ldy >= d->C, "uz_layernorm_fwd: bad ldy");
+  if (res) UZ_REQUIRE(d->ldr % vec == 0 && d->ldr >= d->C, "uz_layernorm_fwd: bad ldr");
+  LnArgs a{};
+  a.x = x; a.y = y; a.res = res; a.gamma = gamma; a.beta = beta; a.sb = image_scale; a.stats = stats;
+  a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
+  a.mode = d->mode; a.r = d->r; a.eps = d->eps;
+  const dim3 grid(ln_grid(d)), block(256);
+  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, (hipStream_t)stream, a);
+  UZ_LAUNCH_CHECK("uz_layernorm_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_layernorm_bwd_rows(const uz_ln_desc* d) {
+  const int rc = ln_check("uz_layernorm_bwd_rows", d);
+  if (rc != UZ_OK) return rc;
+  return ln_grid(d);
+}
+
+extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* stats,
+                                const void* g, const float* image_scale, void* dx, float* partial, void* stream) {
+  const int rc = ln_check("uz_layernorm_bwd", d);
+  if (rc != UZ_OK) return rc;
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && gamma && stats && g && dx && partial, "uz_layernorm_bwd: null pointer");
+  UZ_REQUIRE(d->ldg % vec == 0 && d->ldg >= d->C && d->lddx % vec == 0, "uz_layernorm_bwd: bad ldg / lddx");
+  LnArgs a{};
+  a.x = x; a.g = g; a.dx = dx; a.gamma = gamma; a.sb = image_scale; a.stats = const_cast<float*>(stats);
+  a.partial = partial;
+  a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldg = d->ldg; a.lddx = d->lddx;
+  a.mode = d->mode; a.r = d->r; a.eps = d->eps;
+  const dim3 grid(ln_grid(d)), block(256);
+  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, (hipStream_t)stream, a);
+  UZ_LAUNCH_CHECK("uz_layernorm_bwd");
+  return UZ_OK;
+}
+
+static int attn_check(const char* fn, const uz_winattn_desc* d) {
+  UZ_REQUIRE(d != nullptr, "%s: null descriptor", fn);
+  UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "%s: bad dtype", fn);
+  UZ_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->heads > 0 && d->C == d->heads * AD,
+             "%s: needs head_dim 32 (C=%d, heads=%d)", fn, d->C, d->heads);
+  UZ_REQUIRE(d->ws >= 1 && d->ws * d->ws <= AN && d->H % d->ws == 0 && d->W % d->ws == 0,
+             "%s: window %d does not tile %dx%d (or exceeds 8x8)", fn, d->ws, d->H, d->W);
+  UZ_REQUIRE(d->shift >= 0 && d->shift < d->ws && d->Nt >= d->ws * d->ws, "%s: bad shift / tau size", fn);
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(d->ldq % vec == 0 && d->ldq >= 3 * d->C && d->ldo % vec == 0 && d->ldo >= d->C, "%s: bad strides", fn);
+  UZ_REQUIRE((long long)d->B * d->H * d->W < (1LL << 31), "%s: too many tokens", fn);
+  return UZ_OK;
+}
+
+static int attn_grid_x(const uz_winattn_desc* d) {
+  const long long nwin = (long long)d->B * (d->H / d->ws) * (d->W / d->ws);
+  long long g = (UZ_NUM_CU * 2 + d->heads - 1) / d->heads;
+  if (g > nwin) g = nwin;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
+                              void* out, float* lse, void* stream) {
+  const int rc = attn_check("uz_winattn_fwd", d);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(qkv && tau && bias && out && lse, "uz_winattn_fwd: null pointer");
+  AttnArgs a{};
+  a.qkv = qkv; a.out = out; a.lse = lse; a.tau = tau; a.bias = bias;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
+  a.ldq = d->ldq; a.ldo = d->ldo; a.scale = d->scale;
+  const dim3 grid(attn_grid_x(d), d->heads), block(64);
+  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((winattn_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((winattn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
+  UZ_LAUNCH_CHECK("uz_winattn_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_winattn_bwd_rows(const uz_winattn_desc* d) {
+  const int rc = attn_check("uz_winattn_bwd_rows", d);
+  if (rc != UZ_OK) return rc;
+  return attn_grid_x(d);
+}
+
+extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
+                              const void* out, const float* lse, const void* dout, int lddo, void* dqkv, int lddq,
+                              float* partial, void* stream) {
+  const int rc = attn_check("uz_winattn_bwd", d);
+  if (rc != UZ_OK) return rc;
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(qkv && tau && bias && out && lse && dout && dqkv && partial, "uz_winattn_bwd: null pointer");
+  UZ_REQUIRE(lddo % vec == 0 && lddo >= d->C && lddq % vec == 0 && lddq >= 3 * d->C, "uz_winattn_bwd: bad strides");
+  AttnArgs a{};
+  a.qkv = qkv; a.out = const_cast<void*>(out); a.lse = const_cast<float*>(lse); a.tau = tau; a.bias = bias;
+  a.dout = dout; a.dqkv = dqkv; a.partial = partial;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
+  a.ldq = d->ldq; a.ldo = d->ldo; a.lddo = lddo; a.lddq = lddq; a.scale = d->scale;
+  const dim3 grid(attn_grid_x(d), d->heads), block(64);
+  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((winattn_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((winattn_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
+  UZ_LAUNCH_CHECK("uz_winattn_bwd");
+  return UZ_OK;
+}

@@ -409,6 +409,167 @@ class Engine:
             self.tape.append(bwd)
         return out
 
+    # ------------------------------------------------------------------ Swin-UNet V2 blocks
+    def _total_grad(self, a: Act) -> Optional[Act]:
+        """All gradient contributions of `a` as ONE tensor (uz_pool_grad_combine sums pairs)."""
+        gs = list(a.grads)
+        if not gs:
+            return None
+        while len(gs) > 1:
+            g1, g0 = gs.pop(), gs.pop()
+            tot = self.new_act(a.N, a.H, a.W, a.C)
+            ops.pool_grad_combine(a, g0, g1, None, tot)
+            gs.append(tot)
+        return gs[0]
+
+    def linear(self, x: Act, lin: nn.Linear, out: Optional[Act] = None) -> Act:
+        """nn.Linear on a token tensor: y[p] = W x[p] + b, on the LDS-DMA GEMM (ntaps = 1)."""
+        assert lin.in_features == x.C
+        y = out if out is not None else self.new_act(x.N, x.H, x.W, lin.out_features)
+        ops.conv_igemm(x, self._pack(lin.weight, L.PACK_CONV_FWD), lin.bias.detach() if lin.bias is not None else None,
+                       y, ntaps=1)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                if lin.bias is not None:
+                    self._give_grad(lin.bias, ops.colsum(g))
+                self._give_grad(lin.weight, ops.wgrad(g, x, tuple(lin.weight.shape), ntaps=1,
+                                                      out=self._dst(lin.weight)))
+                if x.needs_grad:
+                    dx = self.new_act(x.N, x.H, x.W, x.C)
+                    ops.conv_igemm(g, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=1)
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def linear_expand2(self, x: Act, lin: nn.Linear) -> Act:
+        """PatchExpand's Linear(C, 2C, bias=False) + 'b h w (p1 p2 c) -> b (h p1) (w p2) c' (p = 2):
+        the GEMM's pixel-shuffle store writes the rearranged tensor directly (swin_unet_v2.py:352-360)."""
+        assert lin.bias is None and lin.in_features == x.C and lin.out_features % 4 == 0
+        Co = lin.out_features // 4
+        y = self.new_act(x.N, 2 * x.H, 2 * x.W, Co)
+        ops.conv_igemm(x, self._pack(lin.weight, L.PACK_CONV_FWD), None, y, ntaps=1,
+                       store_mode=L.STORE_SHUFFLE2X2, nout=4 * Co, co=Co)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                dwt = ops.wgrad(x, g, (x.C, Co, 2, 2), ntaps=4, taps_mode=L.TAPS_GATHER2X2)   # [cin][co][tap]
+                self._give_grad(lin.weight, dwt.view(x.C, Co, 4).permute(2, 1, 0).reshape(4 * Co, x.C).contiguous())
+                if x.needs_grad:
+                    dx = self.new_act(x.N, x.H, x.W, x.C)
+                    ops.conv_igemm(g, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=4,
+                                   taps_mode=L.TAPS_GATHER2X2)
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def layer_norm(self, x: Act, ln: nn.LayerNorm, *, out: Optional[Act] = None, mode: int = L.LN_PLAIN, r: int = 1,
+                   residual: Optional[Act] = None, image_scale: Optional[torch.Tensor] = None) -> Act:
+        """out = [residual +] [image_scale[b] *] LayerNorm(x); mode folds PatchMerging's gather+concat
+        (LN_MERGE) or PatchExpand's rearrange (LN_EXPAND, factor r) into the addressing."""
+        C = ln.normalized_shape[0]
+        if mode == L.LN_PLAIN:
+            shape = (x.N, x.H, x.W)
+            assert C == x.C
+        elif mode == L.LN_MERGE:
+            shape = (x.N, x.H // 2, x.W // 2)
+            assert C == 4 * x.C and x.H % 2 == 0 and x.W % 2 == 0
+        else:
+            shape = (x.N, x.H * r, x.W * r)
+            assert C * r * r == x.C
+        y = out if out is not None else self.new_act(*shape, C)
+        assert (y.N, y.H, y.W, y.C) == (*shape, C)
+        gamma, beta = ln.weight.detach(), ln.bias.detach()
+        stats = ops.layernorm_fwd(x, gamma, beta, y, mode=mode, r=r, eps=ln.eps, res=residual, image_scale=image_scale)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                if residual is not None and residual.needs_grad:
+                    residual.add_grad(g)
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                dgam, dbet = ops.layernorm_bwd(x, gamma, stats, g, dx, mode=mode, r=r, eps=ln.eps,
+                                               image_scale=image_scale)
+                self._give_grad(ln.weight, dgam)
+                self._give_grad(ln.bias, dbet)
+                if x.needs_grad:
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def patch_embed(self, x: torch.Tensor, conv: nn.Conv2d) -> Act:
+        """PatchEmbed.proj: Conv2d(kernel = stride = patch) as patch extraction + GEMM
+        (swin_unet_v2.py:548-553); returns the (N, H/p, W/p, embed_dim) token tensor."""
+        L.require_cuda(x)
+        ps = conv.kernel_size[0]
+        assert conv.kernel_size == conv.stride == (ps, ps) and x.dim() == 4 and x.shape[1] == conv.in_channels
+        K = ps * ps * conv.in_channels
+        kpad = _round_up(K, self.bk)
+        p = ops.patchify(x.contiguous().float(), ps, kpad, self.dtype)
+        y = self.new_act(p.N, p.H, p.W, conv.out_channels)
+        ops.conv_igemm(p, self._pack(conv.weight, L.PACK_IM2COL, kpad), conv.bias.detach() if conv.bias is not None else None,
+                       y, ntaps=1)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, ops.colsum(g))
+                dwp = ops.wgrad(g, p, (conv.out_channels, kpad), ntaps=1)
+                dw = dwp[:, :K].reshape(conv.out_channels, ps * ps, conv.in_channels).permute(0, 2, 1)
+                self._give_grad(conv.weight, dw.reshape(conv.weight.shape).contiguous())
+
+            self.tape.append(bwd)
+        return y
+
+    def window_attention(self, x: Act, attn: nn.Module, heads: int, ws: int, shift: int) -> Act:
+        """WindowAttention on the un-partitioned token tensor (swin_unet_v2.py:127-159 with the roll /
+        window_partition / window_reverse of :246-262 folded into the core kernel's addressing):
+        qkv Linear -> cosine-attention core -> proj Linear.  The continuous position bias
+        cpb(log_relative_position_index) is a function of parameters only ((ws^2)^2 x 2 inputs): it is
+        evaluated with torch ops like the weight re-packing, its parameter gradients by autograd from
+        the kernel's d(bias)."""
+        import torch.nn.functional as F
+        N = ws * ws
+        qkv = self.linear(x, attn.qkv)
+        cpb = attn.cpb
+        with torch.set_grad_enabled(self.record):
+            idx = attn.log_relative_position_index[:N, :N]
+            bias_g = F.linear(F.relu(F.linear(idx, cpb.fc1.weight, cpb.fc1.bias)), cpb.fc2.weight, cpb.fc2.bias)
+            bias_g = bias_g.permute(2, 0, 1).contiguous()                     # (heads, N, N)
+        bias = bias_g.detach().float()
+        tau = attn.tau.detach()
+        o = self.new_act(x.N, x.H, x.W, x.C)
+        lse = ops.winattn_fwd(qkv, tau, bias, o, heads, ws, shift)
+        if self.record:
+            def bwd():
+                g = self._total_grad(o)
+                if g is None:
+                    return
+                dqkv = self.new_act(qkv.N, qkv.H, qkv.W, qkv.C)
+                dbias, dtau = ops.winattn_bwd(qkv, tau, bias, o, lse, g, dqkv, heads, ws, shift)
+                qkv.add_grad(dqkv)
+                if dtau.shape != attn.tau.shape:                               # window clipped to the map size
+                    full = torch.zeros_like(attn.tau)
+                    full[:, :N, :N] = dtau
+                    dtau = full
+                self._give_grad(attn.tau, dtau.contiguous())
+                ps = [cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias]
+                for p_, g_ in zip(ps, torch.autograd.grad(bias_g, ps, dbias.to(bias_g.dtype))):
+                    self._give_grad(p_, g_)
+
+            self.tape.append(bwd)
+        return self.linear(o, attn.proj)
+
     def resize_bilinear(self, x: Act, out: Act) -> Act:
         """out = F.interpolate(x, size=out's, mode='bilinear', align_corners=False), written into its
         concat slot.  Reference: _upsample_like (u2net.py:19-22)."""

@@ -16,6 +16,7 @@ import torch.nn as nn
 from .unet import UNet
 from .attention_unet import AttentionUNet
 from .u2net import U2NET, U2NETP
+from .swin_unet_v2 import SwinTransformerSys
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
@@ -32,7 +33,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'vnet': None,
     'u2net': U2NET,
     'u2netp': U2NETP,
-    'swin_unet_v2': None,
+    'swin_unet_v2': SwinTransformerSys,
     'resunet': None,
     'wranet': None,
     'egeunet': None,
@@ -105,4 +106,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'list_models', 'hip_models', 'get_model_config', 'create_model']

@@ -517,3 +517,80 @@ def fuse1x1_bwd(d: torch.Tensor, w: torch.Tensor, g: Optional[torch.Tensor], ext
                                dcat.data_ptr(), dw.data_ptr(), _p(db), ws.data_ptr(), L.stream_ptr()),
             "uz_fuse1x1_bwd")
     return dcat
+
+
+# ------------------------------------------------------------------------------------------------
+# Swin-UNet V2 pieces (swin_unet_v2.py): patch extraction, LayerNorm with folded permutations, window attention
+def patchify(x: torch.Tensor, patch: int, kpad: int, dtype: torch.dtype) -> Act:
+    L.require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, C, H, W = x.shape
+    out = new_act(N, H // patch, W // patch, kpad, dtype, x.device, needs_grad=False)
+    L.check(L.load().uz_patchify(L.dtype_code(dtype), x.data_ptr(), N, C, H, W, patch, kpad, out.buf.data_ptr(),
+                                 L.stream_ptr()), "uz_patchify")
+    return out
+
+
+def _ln_desc(x: Act, N: int, Ho: int, Wo: int, C: int, mode: int, r: int, eps: float, ldy=0, ldr=0, ldg=0, lddx=0):
+    return L.LnDesc(L.dtype_code(x.dtype), N, Ho, Wo, C, x.ld, ldy, ldr, ldg, lddx, mode, r, eps)
+
+
+def layernorm_fwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, out: Act, *, mode: int = L.LN_PLAIN, r: int = 1,
+                  eps: float = 1e-5, res: Optional[Act] = None, image_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = [res +] [image_scale[b] *] LayerNorm(x rows addressed by `mode`); returns the (P, 2) mean/rstd"""
+    d = _ln_desc(x, out.N, out.H, out.W, out.C, mode, r, eps, ldy=out.ld, ldr=res.ld if res is not None else 0)
+    stats = torch.empty((out.P, 2), dtype=torch.float32, device=x.buf.device)
+    es = x.buf.element_size()
+    with _Timed("layernorm_fwd", 0.0, es * out.P * out.C * (2 + (res is not None))):
+        L.check(L.load().uz_layernorm_fwd(byref(d), x.ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          res.ptr() if res is not None else None, _p(image_scale), out.ptr(),
+                                          stats.data_ptr(), L.stream_ptr()), "uz_layernorm_fwd")
+    return stats
+
+
+def layernorm_bwd(x: Act, gamma: torch.Tensor, stats: torch.Tensor, g: Act, dx: Act, *, mode: int = L.LN_PLAIN,
+                  r: int = 1, eps: float = 1e-5, image_scale: Optional[torch.Tensor] = None):
+    """returns (dgamma, dbeta) fp32; dx is written with x's addressing"""
+    lib = L.load()
+    d = _ln_desc(x, g.N, g.H, g.W, g.C, mode, r, eps, ldg=g.ld, lddx=dx.ld)
+    rows = L.check_count(lib.uz_layernorm_bwd_rows(byref(d)), "uz_layernorm_bwd_rows")
+    part = torch.empty((rows, 2, g.C), dtype=torch.float32, device=x.buf.device)
+    es = x.buf.element_size()
+    with _Timed("layernorm_bwd", 0.0, es * g.P * g.C * 3):
+        L.check(lib.uz_layernorm_bwd(byref(d), x.ptr(), gamma.data_ptr(), stats.data_ptr(), g.ptr(), _p(image_scale),
+                                     dx.ptr(), part.data_ptr(), L.stream_ptr()), "uz_layernorm_bwd")
+    tot = sum_rows(part, rows, 2 * g.C).float()
+    return tot[:g.C], tot[g.C:]
+
+
+def _attn_desc(qkv: Act, heads: int, ws: int, shift: int, Nt: int, ldo: int):
+    C = qkv.C // 3
+    return L.WinAttnDesc(L.dtype_code(qkv.dtype), qkv.N, qkv.H, qkv.W, C, heads, ws, shift, Nt, qkv.ld, ldo,
+                         float((C // heads) ** -0.5))
+
+
+def winattn_fwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, heads: int, ws: int, shift: int) -> torch.Tensor:
+    d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld)
+    nwin = qkv.N * (qkv.H // ws) * (qkv.W // ws)
+    lse = torch.empty((nwin, heads, ws * ws), dtype=torch.float32, device=qkv.buf.device)
+    assert tau.dtype == torch.float32 and tau.is_contiguous() and bias.shape == (heads, ws * ws, ws * ws)
+    with _Timed("winattn_fwd", 4.0 * qkv.P * ws * ws * out.C, qkv.buf.element_size() * qkv.P * out.C * 4):
+        L.check(L.load().uz_winattn_fwd(byref(d), qkv.ptr(), tau.data_ptr(), bias.data_ptr(), out.ptr(), lse.data_ptr(),
+                                        L.stream_ptr()), "uz_winattn_fwd")
+    return lse
+
+
+def winattn_bwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, lse: torch.Tensor, dout: Act, dqkv: Act,
+                heads: int, ws: int, shift: int):
+    """returns (dbias, dtau) as (heads, N, N) fp32"""
+    lib = L.load()
+    d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld)
+    rows = L.check_count(lib.uz_winattn_bwd_rows(byref(d)), "uz_winattn_bwd_rows")
+    N = ws * ws
+    part = torch.empty((rows, heads, 2, N, N), dtype=torch.float32, device=qkv.buf.device)
+    with _Timed("winattn_bwd", 10.0 * qkv.P * N * out.C, qkv.buf.element_size() * qkv.P * out.C * 8):
+        L.check(lib.uz_winattn_bwd(byref(d), qkv.ptr(), tau.data_ptr(), bias.data_ptr(), out.ptr(), lse.data_ptr(),
+                                   dout.ptr(), dout.ld, dqkv.ptr(), dqkv.ld, part.data_ptr(), L.stream_ptr()),
+                "uz_winattn_bwd")
+    tot = sum_rows(part, rows, heads * 2 * N * N).float().view(heads, 2, N, N)
+    return tot[:, 0], tot[:, 1]
