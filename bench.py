@@ -53,6 +53,15 @@ def model_loss(out, mask):
     return F.binary_cross_entropy_with_logits(out, mask)
 
 
+def make_model(model_name: str, hw: int):
+    """the reference's create_model call for this workload; swin needs image_size and a window that
+    tiles the 4x4-patch token grid (8 for 256, the reference's default 7 for 224)"""
+    kw = {}
+    if model_name == "swin_unet_v2":
+        kw = {"image_size": hw, "window_size": 7 if (hw // 4) % 7 == 0 else 8}
+    return unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1, **kw), kw
+
+
 def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
     """Reference step on the host CPU through the oracle (checker code, used here only as the
     reported baseline)."""
@@ -65,19 +74,34 @@ def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
         ncpu = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(16, ncpu)))
     torch.manual_seed(0)
-    m = unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1)
+    m, kw = make_model(model_name, hw)
     sd = m.state_dict()
+    fkw = {"cfg": torch_ref.swin_config(sd, hw, window_size=kw["window_size"])} if model_name == "swin_unet_v2" else {}
     st = torch_ref.clone_state(sd, requires_grad=True)
     params = [v for v in st.values() if v.requires_grad]
+    drops = None
+    if model_name == "swin_unet_v2":
+        # stochastic depth as in the reference's training mode (default rate 0.1, linspace over the blocks)
+        pres = [k[:-len(".norm1.weight")] for k in sd if k.endswith(".norm1.weight") and k.startswith("layers.")]
+        rates = torch.linspace(0, 0.1, len(pres)).tolist()
+        pres_up = [k[:-len(".norm1.weight")] for k in sd if k.endswith(".norm1.weight") and k.startswith("layers_up.")]
+        # decoder level lvl reuses the encoder rates of the same level (swin_unet_v2.py:647-649)
+        rate_of = dict(zip(pres, rates))
+        for pu in pres_up:
+            inx, b = int(pu.split(".")[1]), int(pu.split(".")[3])
+            rate_of[pu] = rate_of[f"layers.{3 - inx}.blocks.{b}"]
+        drops = rate_of
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5)
     x, mask = torch_ref.synthetic_batch(batch, 3, hw, hw, seed=1234)
     times = []
     for i in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss = torch_ref.model_loss(torch_ref.FORWARDS[model_name](st, x, True), mask)
+        if drops is not None:
+            fkw["drop_scales"] = {k: torch.empty(batch).bernoulli_(1 - r) / (1 - r) for k, r in drops.items() if r > 0}
+        loss = torch_ref.model_loss(torch_ref.FORWARDS[model_name](st, x, True, **fkw), mask)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
         opt.step()
         times.append(time.perf_counter() - t0)
     times = sorted(times[1:])  # drop the warm-up step
@@ -95,9 +119,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet", "u2net"],
+    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet", "u2net", "swin_unet_v2"],
                     help="unet = BASELINE configs[1] (the headline metric); attention_unet = configs[2] with --size 512; "
-                         "u2net = configs[4] with --size 512 --batch 8")
+                         "u2net = configs[4] with --size 512 --batch 8; swin_unet_v2 = the second north-star model at "
+                         "--size 256 (window 8) or configs[3] with --size 224 --batch 32 (window 7)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -128,7 +153,7 @@ def main():
 
     run_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = unet_zoo_amd.create_model(args.model, in_channels=3, num_classes=1)
+    model, _ = make_model(args.model, args.size)
     model.run_dtype = run_dtype
     model = model.to(dev).train()
     net = RcclDataParallel(model) if (world > 1 or args.force_dist) else model
@@ -186,14 +211,19 @@ def main():
             inner = net.module if isinstance(net, RcclDataParallel) else net
             inner._grad_sink = None          # gradients are reduced from the flat buffer instead
             inner._grad_sink_done = None
-            flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+            # parameters the graph never reaches (swin's mlp / norm2, swin_unet_v2.py:264-267) keep
+            # .grad = None exactly as in the reference, so clip and AdamW (incl. weight decay) skip them
+            used = [p for p in params if p.grad is not None]
+            for p in params:
+                p.grad = None
+            flat = torch.zeros(sum(p.numel() for p in used), dtype=torch.float32, device=dev)
             inner.grads_in_place = True      # kernels write straight into the views of `flat`
             g_opt = torch.cuda.CUDAGraph()
             if distributed and args.phases > 1:
                 # backward cut into phases, one hipGraph each; the gradients a phase completed are
                 # all-reduced (async RCCL) while the next phase's graph runs
                 ps = PhasedStep(inner, model_loss)
-                for p in params:
+                for p in used:
                     p.grad = torch.zeros_like(p)
                 ps.forward(x, mask)          # eager dry run: which tape entry completes which parameter
                 ps.backward(ps.n_entries, 0, True)
@@ -240,7 +270,7 @@ def main():
                                f"{mb} MB overlapped with the next phase + hipGraph(clip+AdamW)")
             else:
                 off = 0
-                for p in params:             # .grad = views of one buffer -> one collective
+                for p in used:               # .grad = views of one buffer -> one collective
                     p.grad = flat[off:off + p.numel()].view_as(p)
                     off += p.numel()
                 g_fb = torch.cuda.CUDAGraph()

@@ -538,15 +538,13 @@ class Engine:
         cpb(log_relative_position_index) is a function of parameters only ((ws^2)^2 x 2 inputs): it is
         evaluated with torch ops like the weight re-packing, its parameter gradients by autograd from
         the kernel's d(bias)."""
-        import torch.nn.functional as F
         N = ws * ws
         qkv = self.linear(x, attn.qkv)
         cpb = attn.cpb
-        with torch.set_grad_enabled(self.record):
-            idx = attn.log_relative_position_index[:N, :N]
-            bias_g = F.linear(F.relu(F.linear(idx, cpb.fc1.weight, cpb.fc1.bias)), cpb.fc2.weight, cpb.fc2.bias)
-            bias_g = bias_g.permute(2, 0, 1).contiguous()                     # (heads, N, N)
-        bias = bias_g.detach().float()
+        w1, b1, w2, b2 = (t.detach() for t in (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias))
+        idx = attn.log_relative_position_index[:N, :N].reshape(N * N, 2)
+        hid = torch.relu(torch.addmm(b1, idx, w1.t()))                        # (N^2, 256)
+        bias = torch.addmm(b2, hid, w2.t()).t().contiguous().view(heads, N, N).float()
         tau = attn.tau.detach()
         o = self.new_act(x.N, x.H, x.W, x.C)
         lse = ops.winattn_fwd(qkv, tau, bias, o, heads, ws, shift)
@@ -563,9 +561,15 @@ class Engine:
                     full[:, :N, :N] = dtau
                     dtau = full
                 self._give_grad(attn.tau, dtau.contiguous())
-                ps = [cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias]
-                for p_, g_ in zip(ps, torch.autograd.grad(bias_g, ps, dbias.to(bias_g.dtype))):
-                    self._give_grad(p_, g_)
+                # cpb backward as plain matrix products (row sums as products with a ones vector: the
+                # library reduction kernel behind .sum(0) returned garbage under hipGraph replay)
+                G = dbias.reshape(heads, N * N)                                # d bias^T: (heads, N^2)
+                ones = torch.ones(N * N, 1, dtype=G.dtype, device=G.device)
+                dl = (G.t() @ w2) * (hid > 0)                                  # (N^2, 256)
+                self._give_grad(cpb.fc2.weight, G @ hid)
+                self._give_grad(cpb.fc2.bias, (G @ ones).view(-1))
+                self._give_grad(cpb.fc1.weight, dl.t() @ idx)
+                self._give_grad(cpb.fc1.bias, (dl.t() @ ones).view(-1))
 
             self.tape.append(bwd)
         return self.linear(o, attn.proj)

@@ -178,6 +178,8 @@ class PhasedStep:
                 while fi < len(fr) and acc >= fr[fi] * total:
                     fi += 1
         cuts.append(0)
-        cur += [p for p in self.model.parameters() if p not in last]   # never produced: ride with the last phase
+        # allocated but not produced in this pass (e.g. analytically-zero conv biases): ride with the last
+        # phase; parameters without a .grad tensor (never reached by the graph) stay out
+        cur += [p for p in self.model.parameters() if p not in last and p.grad is not None]
         groups.append(cur)
         return cuts, groups
