@@ -246,6 +246,7 @@ def main():
                     with torch.cuda.graph(gk, pool=pool):
                         if k == 0:
                             static_loss = ps.forward(x, mask)
+                            out = ps.outputs
                         ps.backward(cuts[k], cuts[k + 1], k == 0)
                     pool = gk.pool()
                     graphs.append(gk)
@@ -294,6 +295,13 @@ def main():
                     launch_mode = "hipGraph(fwd+bwd) + hipGraph(clip+AdamW)"
             run_one()                 # one untimed replay
             torch.cuda.synchronize()
+            if os.environ.get("UZ_BENCH_DEBUG"):
+                for _ in range(4):
+                    run_one()
+                    torch.cuda.synchronize()
+                    print("# debug loss", float(static_loss.item()), float(model_loss(out, mask).item()),
+                          "grad norm", float(flat.norm().item()),
+                          file=sys.stderr, flush=True)
         except Exception as e:  # noqa: BLE001
             if args.graph == "on":
                 raise
@@ -317,7 +325,11 @@ def main():
     if run_one is not None:
         for _ in range(args.steps):
             run_one()
-        loss = static_loss
+        # the loss is re-evaluated eagerly from the last replay's logits: the library's multi-block mean
+        # reduction inside a replayed hipGraph intermittently returned 0 on this stack (gradients are
+        # unaffected: they do not depend on the reduced value)
+        with torch.no_grad():
+            loss = model_loss(out, mask)
     else:
         for _ in range(args.steps):
             loss = step(False)

@@ -31,12 +31,6 @@ template <typename T> __device__ __forceinline__ void store_f(T* p, const float*
   st16(p, v);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------
 // patches: out[p = (b, i, j)][k = (kh*ps + kw)*C + c] = x[b][c][i*ps + kh][j*ps + kw], zero for k >= ps*ps*C
 // ---------------------------------------------------------------------------------------------
@@ -101,17 +95,26 @@ template <typename T> __device__ __forceinline__ size_t ln_src(const LnArgs& a, 
   return ((size_t)(img * H + h) * W + w) * ld + (p1 * r + p2) * a.C + c0;
 }
 
+// sum over the LPT consecutive lanes that share a token (LPT a power of two <= 64)
+__device__ __forceinline__ float group_sum(float v, int lpt) {
+  for (int o = lpt >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// LPT = min(64, pow2 >= C/VEC) lanes per token, 64/LPT tokens per wave, 4 waves per workgroup: a
+// 96-channel bf16 token (12 chunks) occupies 16 lanes, not a whole wave.
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (lpt - 1), grp = lane / lpt, tpw = 64 / lpt;
   const int CC = a.C / VEC;
   const int P = a.N * a.Ho * a.Wo;
   const T* __restrict__ x = static_cast<const T*>(a.x);
   float gam[LN_MAXIT][VEC], bet[LN_MAXIT][VEC], ag[LN_MAXIT][VEC], ab[LN_MAXIT][VEC];
 #pragma unroll
   for (int it = 0; it < LN_MAXIT; ++it) {
-    const int cc = lane + 64 * it;
+    const int cc = sub + lpt * it;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       gam[it][e] = cc < CC ? a.gamma[cc * VEC + e] : 0.f;
@@ -120,14 +123,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     }
   }
   const float invC = 1.f / (float)a.C;
-  for (int t = blockIdx.x * 4 + wave; t < P; t += gridDim.x * 4) {
-    const int ow = t % a.Wo, tt = t / a.Wo, oh = tt % a.Ho, img = tt / a.Ho;
+  const int tpb = 4 * tpw;  // tokens per workgroup pass
+  for (int t0 = blockIdx.x * tpb; t0 < P; t0 += gridDim.x * tpb) {
+    const int t = t0 + wave * tpw + grp;
+    const bool tok = t < P;   // whole lane groups go idle together; shuffles below stay inside a group
+    const int tc = tok ? t : 0;
+    const int ow = tc % a.Wo, tt = tc / a.Wo, oh = tt % a.Ho, img = tt / a.Ho;
     float v[LN_MAXIT][VEC];
     float s = 0.f;
 #pragma unroll
     for (int it = 0; it < LN_MAXIT; ++it) {
-      const int cc = lane + 64 * it;
-      if (cc < CC) {
+      const int cc = sub + lpt * it;
+      if (cc < CC && tok) {
         load_f(x + ln_src<T>(a, img, oh, ow, cc * VEC, a.ldx), v[it]);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s += v[it][e];
@@ -138,19 +145,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     }
     float mean, rstd;
     if constexpr (!BWD) {
-      mean = wave_sum(s) * invC;
+      mean = group_sum(s, lpt) * invC;
       float q = 0.f;
 #pragma unroll
       for (int it = 0; it < LN_MAXIT; ++it)
-        if (lane + 64 * it < CC) {
+        if (sub + lpt * it < CC) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const float d = v[it][e] - mean;
             q += d * d;
           }
         }
-      rstd = rsqrtf(wave_sum(q) * invC + a.eps);
-      if (lane == 0) {
+      rstd = rsqrtf(group_sum(q, lpt) * invC + a.eps);
+      if (sub == 0 && tok) {
         a.stats[(size_t)t * 2] = mean;
         a.stats[(size_t)t * 2 + 1] = rstd;
       }
@@ -159,8 +166,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
       const T* __restrict__ res = static_cast<const T*>(a.res);
 #pragma unroll
       for (int it = 0; it < LN_MAXIT; ++it) {
-        const int cc = lane + 64 * it;
-        if (cc < CC) {
+        const int cc = sub + lpt * it;
+        if (cc < CC && tok) {
           float o[VEC], rv[VEC];
           if (res != nullptr) load_f(res + (size_t)t * a.ldr + cc * VEC, rv);
 #pragma unroll
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
         }
       }
     } else {
-      mean = a.stats[(size_t)t * 2];
-      rstd = a.stats[(size_t)t * 2 + 1];
+      mean = tok ? a.stats[(size_t)t * 2] : 0.f;
+      rstd = tok ? a.stats[(size_t)t * 2 + 1] : 0.f;
       const float f = a.sb != nullptr ? a.sb[img] : 1.f;
       const T* __restrict__ g = static_cast<const T*>(a.g);
       T* __restrict__ dx = static_cast<T*>(a.dx);
@@ -181,8 +188,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
       float s1 = 0.f, s2 = 0.f;  // sum of g*gamma, sum of g*gamma*xhat
 #pragma unroll
       for (int it = 0; it < LN_MAXIT; ++it) {
-        const int cc = lane + 64 * it;
-        if (cc < CC) {
+        const int cc = sub + lpt * it;
+        if (cc < CC && tok) {
           load_f(g + (size_t)t * a.ldg + cc * VEC, gv[it]);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
@@ -196,12 +203,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
           }
         }
       }
-      s1 = wave_sum(s1) * invC;
-      s2 = wave_sum(s2) * invC;
+      s1 = group_sum(s1, lpt) * invC;
+      s2 = group_sum(s2, lpt) * invC;
 #pragma unroll
       for (int it = 0; it < LN_MAXIT; ++it) {
-        const int cc = lane + 64 * it;
-        if (cc < CC) {
+        const int cc = sub + lpt * it;
+        if (cc < CC && tok) {
           float o[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
@@ -214,26 +221,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     }
   }
   if constexpr (BWD) {
-    // one partial row per workgroup: sum the four waves through LDS
-    __shared__ float red[4][2][LN_MAXC];
-    float* mine0 = &red[wave][0][0];
-    float* mine1 = &red[wave][1][0];
+    // one partial row per workgroup: the 4 * tpw lane groups are summed through LDS in a fixed order
+    extern __shared__ float red[];  // [4 * tpw][2][C]
+    const int gidx = wave * tpw + grp, ngrp = 4 * tpw;
+    float* mine = red + (size_t)gidx * 2 * a.C;
 #pragma unroll
     for (int it = 0; it < LN_MAXIT; ++it) {
-      const int cc = lane + 64 * it;
+      const int cc = sub + lpt * it;
       if (cc < CC) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          mine0[cc * VEC + e] = ag[it][e];
-          mine1[cc * VEC + e] = ab[it][e];
+          mine[cc * VEC + e] = ag[it][e];
+          mine[a.C + cc * VEC + e] = ab[it][e];
         }
       }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < 2 * a.C; c += 256) {
-      const int which = c / a.C, ch = c - which * a.C;
-      a.partial[((size_t)blockIdx.x * 2 + which) * a.C + ch] =
-          red[0][which][ch] + red[1][which][ch] + red[2][which][ch] + red[3][which][ch];
+      float t = 0.f;
+      for (int k = 0; k < ngrp; ++k) t += red[(size_t)k * 2 * a.C + c];
+      a.partial[(size_t)blockIdx.x * 2 * a.C + c] = t;
     }
   }
 }
@@ -359,20 +366,41 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// Backward: one 256-thread workgroup (one wave per SIMD) per (window, head).  Phase A: lane = query i, the
+// four waves split the key range; phase B: lane = key j, the waves split the query range; per-wave
+// partial sums of dq / dk / dv meet in LDS and are added in a fixed order.  dS-derived sums for d(bias)
+// and d(tau) accumulate over the workgroup's windows in LDS (wave w owns its key columns).
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) {  // 8 consecutive values
+  constexpr int VEC = ElemTraits<T>::VEC;
+#pragma unroll
+  for (int c = 0; c < 8 / VEC; ++c) store_f(p + c * VEC, f + c * VEC);
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnArgs a) {
-  // per window: phase A, thread = query i (row of dS, dq); phase B, thread = key j (dk, dv)
-  __shared__ float sK[AN * ARS], sV[AN * ARS], sQ[AN * ARS], sG[AN * ARS], sKn[AN], sQn[AN];
-  __shared__ float sP[AN * ANS], sDC[AN * ANS], sDB[AN * ANS], sDT[AN * ANS];
+__global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
+  constexpr int TILE = AN * ARS, MAT = AN * ANS;
+  __shared__ float smem[2 * TILE + 2 * MAT + 4 * TILE + 2 * MAT + 3 * AN];
   __shared__ int sCnt[AN];
-  const int i = threadIdx.x, h = blockIdx.y;
+  float* const sK = smem;                 // phase A: K rows; phase B: Q rows
+  float* const sV = smem + TILE;          // phase A: V rows; phase B: dO rows
+  float* const sP = smem + 2 * TILE;
+  float* const sDC = sP + MAT;
+  float* const sRA = sDC + MAT;           // [4][AN][ARS]: per-wave partial (dq vector part, scalar part)
+  float* const sDB = sRA + 4 * TILE;
+  float* const sDT = sDB + MAT;
+  float* const sKn = sDT + MAT;
+  float* const sQn = sKn + AN;
+  float* const sPB = smem;                // [4][AN][ANS] partial (dk, dv, scalar), aliases sK .. sRA after phase B
+  static_assert(4 * MAT <= 2 * TILE + 2 * MAT + 4 * TILE, "phase B partials must fit the aliased region");
+  const int tid = threadIdx.x, w = tid >> 6, i = tid & 63, h = blockIdx.y;
   const int N = a.ws * a.ws;
+  const int jc = (N + 3) >> 2, lo = w * jc, hi = min(N, lo + jc);
   const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
   const T* __restrict__ qkv = static_cast<const T*>(a.qkv);
   const T* __restrict__ out = static_cast<const T*>(a.out);
   const T* __restrict__ dout = static_cast<const T*>(a.dout);
   T* __restrict__ dqkv = static_cast<T*>(a.dqkv);
-  for (int e = i; e < AN * ANS; e += 64) sDB[e] = sDT[e] = 0.f;
+  for (int e = tid; e < MAT; e += 256) sDB[e] = sDT[e] = 0.f;
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
     __syncthreads();
     float q[AD], kk[AD], go[AD];
@@ -384,97 +412,158 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnArgs a) {
       float t[AD];
       load_head(row, q);
       load_head(row + a.C, kk);
-      load_head(row + 2 * a.C, t);
       load_head(dout + (size_t)me.tok * a.lddo + h * AD, go);
+      load_head(out + (size_t)me.tok * a.ldo + h * AD, t);
 #pragma unroll
       for (int e = 0; e < AD; ++e) {
         q[e] *= a.scale;
         qn += q[e] * q[e];
         kn += kk[e] * kk[e];
-        sK[i * ARS + e] = kk[e];
-        sV[i * ARS + e] = t[e];
-        sQ[i * ARS + e] = q[e];
-        sG[i * ARS + e] = go[e];
+        Di = fmaf(go[e], t[e], Di);
       }
-      load_head(out + (size_t)me.tok * a.ldo + h * AD, t);
-#pragma unroll
-      for (int e = 0; e < AD; ++e) Di = fmaf(go[e], t[e], Di);
       qn = sqrtf(qn);
       kn = sqrtf(kn);
-      sQn[i] = qn;
-      sKn[i] = kn;
-      sCnt[i] = me.cnt;
+      if (w == 0) {
+        load_head(row + 2 * a.C, t);
+#pragma unroll
+        for (int e = 0; e < AD; ++e) {
+          sK[i * ARS + e] = kk[e];
+          sV[i * ARS + e] = t[e];
+        }
+        sKn[i] = kn;
+        sQn[i] = qn;
+        sCnt[i] = me.cnt;
+      }
     }
     __syncthreads();
-    if (i < N) {  // ---- phase A: query row i
-      const float lse = a.lse[((size_t)win * a.heads + h) * N + i];
+    {  // ---- phase A: query i, keys [lo, hi)
       float av[AD], bs = 0.f;
 #pragma unroll
       for (int e = 0; e < AD; ++e) av[e] = 0.f;
-      for (int j = 0; j < N; ++j) {
-        float u = 0.f, dp = 0.f;
+      if (i < N) {
+        const float lse = a.lse[((size_t)win * a.heads + h) * N + i];
+        for (int j = lo; j < hi; ++j) {
+          float u = 0.f, dp = 0.f;
 #pragma unroll
-        for (int e = 0; e < AD; ++e) {
-          u = fmaf(q[e], sK[j * ARS + e], u);
-          dp = fmaf(go[e], sV[j * ARS + e], dp);
+          for (int e = 0; e < AD; ++e) {
+            u = fmaf(q[e], sK[j * ARS + e], u);
+            dp = fmaf(go[e], sV[j * ARS + e], dp);
+          }
+          const float nn = qn * sKn[j];
+          const bool clamped = nn <= 1e-6f;
+          const float den = clamped ? 1e-6f : nn;
+          const float tv = a.tau[((size_t)h * a.Nt + i) * a.Nt + j];
+          const float ti = 1.f / fmaxf(tv, 0.01f);
+          const float c = u / den;
+          float s = c * ti + a.bias[((size_t)h * N + i) * N + j];
+          if (sCnt[j] != me.cnt) s -= 100.f;
+          const float p = __expf(s - lse);
+          const float ds = p * (dp - Di);
+          sP[i * ANS + j] = p;
+          sDB[i * ANS + j] += ds;
+          if (tv >= 0.01f) sDT[i * ANS + j] -= ds * c * ti * ti;
+          const float dc = ds * ti;
+          sDC[i * ANS + j] = dc;
+          const float w1 = dc / den;
+#pragma unroll
+          for (int e = 0; e < AD; ++e) av[e] = fmaf(w1, sK[j * ARS + e], av[e]);
+          if (!clamped) bs += dc * u * sKn[j] / (den * den * qn);  // d(den)/d(qs_i) = kn_j * qs_i / n_i
         }
-        const float nn = qn * sKn[j];
-        const bool clamped = nn <= 1e-6f;
-        const float den = clamped ? 1e-6f : nn;
-        const float tv = a.tau[((size_t)h * a.Nt + i) * a.Nt + j];
-        const float ti = 1.f / fmaxf(tv, 0.01f);
-        const float c = u / den;
-        float s = c * ti + a.bias[((size_t)h * N + i) * N + j];
-        if (sCnt[j] != me.cnt) s -= 100.f;
-        const float p = __expf(s - lse);
-        const float ds = p * (dp - Di);
-        sP[i * ANS + j] = p;
-        sDB[i * ANS + j] += ds;
-        if (tv >= 0.01f) sDT[i * ANS + j] -= ds * c * ti * ti;
-        const float dc = ds * ti;
-        sDC[i * ANS + j] = dc;
-        const float w1 = dc / den;
-#pragma unroll
-        for (int e = 0; e < AD; ++e) av[e] = fmaf(w1, sK[j * ARS + e], av[e]);
-        if (!clamped) bs += dc * u * sKn[j] / (den * den * qn);   // d(den)/d(qs_i) = kn_j * qs_i / n_i
       }
-      float dq[AD];
+      float* ra = sRA + (w * AN + i) * ARS;
 #pragma unroll
-      for (int e = 0; e < AD; ++e) dq[e] = a.scale * (av[e] - bs * q[e]);
-      store_head(dqkv + (size_t)me.tok * a.lddq + h * AD, dq);
+      for (int e = 0; e < AD; ++e) ra[e] = av[e];
+      ra[AD] = bs;
     }
     __syncthreads();
-    if (i < N) {  // ---- phase B: key column j = i
-      const int j = i;
-      float dk[AD], dv[AD], bs = 0.f;
+    if (i < N) {  // dq: wave w finishes components [8w, 8w + 8) of query i; wave 0 re-stages Q and dO
+      float tot[8], bt = 0.f;
 #pragma unroll
-      for (int e = 0; e < AD; ++e) dk[e] = dv[e] = 0.f;
-      for (int r = 0; r < N; ++r) {
+      for (int e = 0; e < 8; ++e) tot[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* ra = sRA + (k * AN + i) * ARS;
+        bt += ra[AD];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tot[e] += ra[8 * w + e];
+      }
+      float dq[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float qe = 0.f;  // q[8 w + e] without dynamic register indexing
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qe = (w == k) ? q[8 * k + e] : qe;
+        dq[e] = a.scale * (tot[e] - bt * qe);
+      }
+      store8(dqkv + (size_t)me.tok * a.lddq + h * AD + 8 * w, dq);
+      if (w == 0) {
+#pragma unroll
+        for (int e = 0; e < AD; ++e) {
+          sK[i * ARS + e] = q[e];
+          sV[i * ARS + e] = go[e];
+        }
+      }
+    }
+    __syncthreads();
+    float dk[AD], dv[AD], bsk = 0.f;
+#pragma unroll
+    for (int e = 0; e < AD; ++e) dk[e] = dv[e] = 0.f;
+    if (i < N) {  // ---- phase B: key j = i, queries [lo, hi)
+      const int j = i;
+      for (int r = lo; r < hi; ++r) {
         const float p = sP[r * ANS + j], dc = sDC[r * ANS + j];
         float u = 0.f;
 #pragma unroll
         for (int e = 0; e < AD; ++e) {
-          u = fmaf(sQ[r * ARS + e], kk[e], u);
-          dv[e] = fmaf(p, sG[r * ARS + e], dv[e]);
+          u = fmaf(sK[r * ARS + e], kk[e], u);
+          dv[e] = fmaf(p, sV[r * ARS + e], dv[e]);
         }
         const float nn = sQn[r] * kn;
         const bool clamped = nn <= 1e-6f;
         const float den = clamped ? 1e-6f : nn;
         const float w1 = dc / den;
 #pragma unroll
-        for (int e = 0; e < AD; ++e) dk[e] = fmaf(w1, sQ[r * ARS + e], dk[e]);
-        if (!clamped) bs += dc * u * sQn[r] / (den * den * kn);
+        for (int e = 0; e < AD; ++e) dk[e] = fmaf(w1, sK[r * ARS + e], dk[e]);
+        if (!clamped) bsk += dc * u * sQn[r] / (den * den * kn);
       }
+    }
+    __syncthreads();  // everyone is done with sP / sDC / the Q, dO tiles: the partials may overwrite them
+    {
+      float* pb = sPB + (w * AN + i) * ANS;
 #pragma unroll
-      for (int e = 0; e < AD; ++e) dk[e] -= bs * kk[e];
-      T* row = dqkv + (size_t)me.tok * a.lddq + h * AD;
-      store_head(row + a.C, dk);
-      store_head(row + 2 * a.C, dv);
+      for (int e = 0; e < AD; ++e) {
+        pb[e] = dk[e];
+        pb[AD + e] = dv[e];
+      }
+      pb[2 * AD] = bsk;
+    }
+    __syncthreads();
+    if (i < N) {  // waves 0, 1: halves of dk; waves 2, 3: halves of dv
+      float tot[16], bt = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tot[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* pb = sPB + (k * AN + i) * ANS;
+        bt += pb[2 * AD];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[e] += pb[16 * w + e];
+      }
+      if (w < 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float ke = (w == 0) ? kk[e] : kk[16 + e];
+          tot[e] -= bt * ke;
+        }
+      }
+      T* row = dqkv + (size_t)me.tok * a.lddq + h * AD + (w < 2 ? a.C + 16 * w : 2 * a.C + 16 * (w - 2));
+      store8(row, tot);
+      store8(row + 8, tot + 8);
     }
   }
   __syncthreads();
   float* part = a.partial + ((size_t)blockIdx.x * a.heads + h) * 2 * N * N;
-  for (int e = i; e < N * N; e += 64) {
+  for (int e = tid; e < N * N; e += 256) {
     const int r = e / N, c = e - r * N;
     part[e] = sDB[r * ANS + c];
     part[N * N + e] = sDT[r * ANS + c];
@@ -489,12 +578,21 @@ inline int grid_cap(long long units, int per_block, int per_cu) {
   return (int)g;
 }
 
+int ln_lpt(const uz_ln_desc* d) {
+  const int cc = d->C / (d->dtype == UZ_BF16 ? 8 : 4);
+  int l = 1;
+  while (l < cc && l < 64) l <<= 1;
+  return l;
+}
+
 int ln_check(const char* fn, const uz_ln_desc* d) {
   UZ_REQUIRE(d != nullptr, "%s: null descriptor", fn);
   UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "%s: bad dtype", fn);
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(d->N > 0 && d->Ho > 0 && d->Wo > 0 && d->C > 0 && d->C % vec == 0, "%s: bad shape", fn);
   UZ_REQUIRE(d->C / vec <= 64 * LN_MAXIT && d->C <= LN_MAXC, "%s: C=%d too large (max %d)", fn, d->C, LN_MAXC);
+  // dynamic LDS of the backward: 4 * (64 / lanes-per-token) groups x 2 x C floats
+  UZ_REQUIRE((long long)4 * (64 / ln_lpt(d)) * 2 * d->C * 4 <= 64 * 1024, "%s: C=%d: partial-row staging exceeds 64 KiB", fn, d->C);
   UZ_REQUIRE(d->mode >= 0 && d->mode <= 2, "%s: bad mode %d", fn, d->mode);
   if (d->mode == 1) UZ_REQUIRE(d->C % (4 * vec) == 0 && d->ldx % vec == 0 && d->ldx >= d->C / 4, "%s: merge needs C %% %d == 0", fn, 4 * vec);
   if (d->mode == 2) UZ_REQUIRE(d->r >= 1 && d->Ho % d->r == 0 && d->Wo % d->r == 0 && d->ldx >= d->r * d->r * d->C, "%s: bad expand factor", fn);
@@ -504,7 +602,10 @@ int ln_check(const char* fn, const uz_ln_desc* d) {
   return UZ_OK;
 }
 
-int ln_grid(const uz_ln_desc* d) { return grid_cap((long long)d->N * d->Ho * d->Wo, 4 * 4, 4); }
+int ln_grid(const uz_ln_desc* d) {
+  const int tpb = 4 * (64 / ln_lpt(d));
+  return grid_cap((long long)d->N * d->Ho * d->Wo, tpb * 4, 4);
+}
 
 }  // namespace
 
@@ -534,8 +635,9 @@ extern "C" int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float*
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
   a.mode = d->mode; a.r = d->r; a.eps = d->eps;
   const dim3 grid(ln_grid(d)), block(256);
-  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, (hipStream_t)stream, a);
+  const int lpt = ln_lpt(d);
+  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, (hipStream_t)stream, a, lpt);
+  else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, (hipStream_t)stream, a, lpt);
   UZ_LAUNCH_CHECK("uz_layernorm_fwd");
   return UZ_OK;
 }
@@ -559,8 +661,10 @@ extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float*
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldg = d->ldg; a.lddx = d->lddx;
   a.mode = d->mode; a.r = d->r; a.eps = d->eps;
   const dim3 grid(ln_grid(d)), block(256);
-  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, (hipStream_t)stream, a);
+  const int lpt = ln_lpt(d);
+  const size_t shm = (size_t)4 * (64 / lpt) * 2 * d->C * sizeof(float);
+  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, shm, (hipStream_t)stream, a, lpt);
+  else hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, shm, (hipStream_t)stream, a, lpt);
   UZ_LAUNCH_CHECK("uz_layernorm_bwd");
   return UZ_OK;
 }
@@ -622,7 +726,7 @@ extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const f
   a.dout = dout; a.dqkv = dqkv; a.partial = partial;
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
   a.ldq = d->ldq; a.ldo = d->ldo; a.lddo = lddo; a.lddq = lddq; a.scale = d->scale;
-  const dim3 grid(attn_grid_x(d), d->heads), block(64);
+  const dim3 grid(attn_grid_x(d), d->heads), block(256);
   if (d->dtype == UZ_BF16) hipLaunchKernelGGL((winattn_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((winattn_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
   UZ_LAUNCH_CHECK("uz_winattn_bwd");

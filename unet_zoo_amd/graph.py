@@ -135,6 +135,7 @@ class PhasedStep:
         with torch.no_grad():
             outs = tuple(m.emit(self.eng, x))
         leaves = tuple(o.detach().requires_grad_(True) for o in outs)
+        self.outputs = m.wrap_outputs(tuple(o.detach() for o in outs))
         with torch.enable_grad():
             loss = self.loss_fn(m.wrap_outputs(leaves), target)
             self._gouts = torch.autograd.grad(loss, leaves, allow_unused=True)
