@@ -332,6 +332,13 @@ typedef struct uz_winattn_desc {
 } uz_winattn_desc;
 int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
                    void* out, float* lse, void* stream);
+/* Continuous position bias (:121-125, Mlp_Relu :58-72): bias[h][r] = fc2(relu(fc1(idx[r]))) over the
+ * R = N*N log-spaced offsets idx (R, 2); w1 (hidden, 2), b1 (hidden), w2 (heads, hidden), b2 (heads), fp32.
+ * Backward from G = d bias (heads, R): gradients of the four parameter tensors, overwritten. */
+int uz_cpb_fwd(const float* idx, const float* w1, const float* b1, const float* w2, const float* b2, int R,
+               int hidden, int heads, float* bias, void* stream);
+int uz_cpb_bwd(const float* idx, const float* w1, const float* b1, const float* w2, const float* G, int R,
+               int hidden, int heads, float* dw1, float* db1, float* dw2, float* db2, void* stream);
 int uz_winattn_bwd_rows(const uz_winattn_desc* d); /* rows of `partial`; <0 on error */
 /* dqkv (P, 3C) fully written; partial[row][heads][2][N][N]: sums over the row's windows of dS (-> d bias)
  * and of d tau (zero where tau < 0.01); add the rows with uz_sum_rows(). */
@@ -341,6 +348,10 @@ int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const float* tau, 
 
 /* out[c] = sum_p x[p*ld + c] (fp32; out zeroed by caller). ConvTranspose2d bias gradient. */
 int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* stream);
+/* Deterministic form (per-workgroup partial rows in `workspace`, fixed-order finalize; `out` is
+ * overwritten, no zeroing needed): nn.Linear / PatchEmbed bias gradients (swin_unet_v2.py:120,123,546). */
+long long uz_colsum_workspace_bytes(int dtype, int P, int C);
+int uz_colsum_ws(int dtype, const void* x, int ld, int P, int C, float* out, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -315,3 +315,25 @@ def test_swin_registry_errors_match_the_reference():
     m = _swin(64, 4).to(DEV)
     with pytest.raises(AssertionError):
         m(torch.zeros(1, 3, 32, 32, device=DEV))                    # size check of PatchEmbed.forward (:550-552)
+
+
+@pytest.mark.parametrize("heads,N", [(3, 64), (24, 4), (6, 49)])
+def test_continuous_position_bias_mlp(heads, N):
+    """cpb = Linear(2,256)-ReLU-Linear(256,heads) on the log-spaced offsets (swin_unet_v2.py:58-72, 121-125)"""
+    g = torch.Generator().manual_seed(47)
+    R = N * N
+    idx = torch.randn(R, 2, generator=g)
+    w1 = (torch.randn(256, 2, generator=g)).requires_grad_(True)
+    b1 = (torch.randn(256, generator=g) * 0.5).requires_grad_(True)
+    w2 = (torch.randn(heads, 256, generator=g) * 0.1).requires_grad_(True)
+    b2 = torch.randn(heads, generator=g).requires_grad_(True)
+    G = torch.randn(heads, R, generator=g)
+    ref = F.linear(F.relu(F.linear(idx, w1, b1)), w2, b2).t()
+    ref.backward(G)
+    d = [t.detach().to(DEV) for t in (idx, w1, b1, w2, b2)]
+    bias = ops.cpb_fwd(*d)
+    assert relerr(bias.cpu(), ref.detach()) < 2e-6
+    outs = [torch.empty_like(t) for t in d[1:]]
+    ops.cpb_bwd(d[0], d[1], d[2], d[3], G.to(DEV).contiguous(), *outs)
+    for got, want in zip(outs, (w1.grad, b1.grad, w2.grad, b2.grad)):
+        assert relerr(got.cpu(), want) < 1e-5

@@ -34,6 +34,7 @@ EXPORTS = (
     "uz_conv_igemm_workspace_bytes", "uz_conv_igemm_ws_grid_m", "uz_conv_igemm_ws",
     "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd",
     "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
+    "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_cpb_fwd", "uz_cpb_bwd",
 )
 
 
@@ -109,6 +110,8 @@ def load():
     lib.uz_winattn_fwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp]
     lib.uz_winattn_bwd_rows.argtypes = [POINTER(WinAttnDesc)]
     lib.uz_winattn_bwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp]
+    lib.uz_cpb_fwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp]
+    lib.uz_cpb_bwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp]
     lib.uz_wgrad_split.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad_workspace_bytes.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]
@@ -128,6 +131,8 @@ def load():
     lib.uz_outconv_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]
     lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp, vp]
     lib.uz_colsum.argtypes = [ip, vp, ip, ip, ip, vp, vp]
+    lib.uz_colsum_workspace_bytes.argtypes = [ip, ip, ip]
+    lib.uz_colsum_ws.argtypes = [ip, vp, ip, ip, ip, vp, vp, vp]
     lib.uz_attn_grid.argtypes = [ip, ip, ip]
     lib.uz_attn_psi_fwd.argtypes = [ip, vp, ip, vp, ip, vp, vp, vp, vp, ip, ip, vp, vp, vp]
     lib.uz_attn_gate_fwd.argtypes = [ip, vp, ip, vp, vp, ip, ip, vp, ip, vp]

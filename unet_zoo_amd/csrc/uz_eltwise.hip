@@ -505,7 +505,9 @@ __global__ __launch_bounds__(1024) void outconv_bwd_finalize_kernel(const float*
   }
 
 // out[c] += sum_p x[p*ld + c]
-template <typename T>
+// PARTIAL: one row of per-workgroup sums (out[blockIdx.x][C], finished by colsum_finalize_kernel:
+// deterministic, no contended atomics); otherwise atomicAdd onto out[C] (legacy uz_colsum).
+template <typename T, bool PARTIAL>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long long P, int C,
                                                      float* __restrict__ out) {
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -531,7 +533,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   for (int e = threadIdx.y; e < VEC; e += blockDim.y) {
     float t = 0.f;
     for (int r = 0; r < (int)blockDim.y; ++r) t += red[((size_t)r * blockDim.x + threadIdx.x) * VEC + e];
-    if (cok) atomicAdd(out + c0 + e, t);
+    if (cok) {
+      if (PARTIAL) out[(size_t)blockIdx.x * C + c0 + e] = t;
+      else atomicAdd(out + c0 + e, t);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+                                                               float* __restrict__ out) {
+  __shared__ double sh[32][33];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + el;
+  double s = 0.0;
+  if (c < C)
+    for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * C + c];
+  sh[g][el] = s;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double t = 0.0;
+    for (int r = 0; r < 32; ++r) t += sh[r][el];
+    out[c] = (float)t;
   }
 }
 
@@ -951,10 +973,39 @@ extern "C" int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* 
   const size_t shm = (size_t)256 * vec * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16)
-    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, shm, s, (const bf16_t*)x, ld, (long long)P, C, out);
+    hipLaunchKernelGGL((colsum_kernel<bf16_t, false>), grid, block, shm, s, (const bf16_t*)x, ld, (long long)P, C, out);
   else
-    hipLaunchKernelGGL((colsum_kernel<float>), grid, block, shm, s, (const float*)x, ld, (long long)P, C, out);
+    hipLaunchKernelGGL((colsum_kernel<float, false>), grid, block, shm, s, (const float*)x, ld, (long long)P, C, out);
   UZ_LAUNCH_CHECK("uz_colsum");
+  return UZ_OK;
+}
+
+extern "C" long long uz_colsum_workspace_bytes(int dtype, int P, int C) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_colsum_workspace_bytes: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(P > 0 && C > 0 && C % vec == 0, "uz_colsum_workspace_bytes: bad shape");
+  dim3 grid, block;
+  reduce_shape(C / vec, P, &grid, &block);
+  return (long long)grid.x * C * (long long)sizeof(float);
+}
+
+extern "C" int uz_colsum_ws(int dtype, const void* x, int ld, int P, int C, float* out, void* workspace,
+                            void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_colsum_ws: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && out && workspace && P > 0 && C > 0 && C % vec == 0 && ld % vec == 0 && ld >= C, "uz_colsum_ws: bad args");
+  dim3 grid, block;
+  reduce_shape(C / vec, P, &grid, &block);
+  const size_t shm = (size_t)256 * vec * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = static_cast<float*>(workspace);
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, block, shm, s, (const bf16_t*)x, ld, (long long)P, C, part);
+  else
+    hipLaunchKernelGGL((colsum_kernel<float, true>), grid, block, shm, s, (const float*)x, ld, (long long)P, C, part);
+  UZ_LAUNCH_CHECK("uz_colsum_ws");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(uz_cdiv(C, 32)), dim3(1024), 0, s, part, (int)grid.x, C, out);
+  UZ_LAUNCH_CHECK("uz_colsum_ws(finalize)");
   return UZ_OK;
 }
 

@@ -298,17 +298,28 @@ template <typename T> __device__ __forceinline__ void store_head(T* p, const flo
   for (int c = 0; c < AD / VEC; ++c) store_f(p + c * VEC, f + c * VEC);
 }
 
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) {  // 8 consecutive values
+  constexpr int VEC = ElemTraits<T>::VEC;
+#pragma unroll
+  for (int c = 0; c < 8 / VEC; ++c) store_f(p + c * VEC, f + c * VEC);
+}
+
+// Forward: one 256-thread workgroup (one wave per SIMD) per (window, head); lane = query i, the four
+// waves split the key range, each with its own running (max, sum, output); the partial states are
+// merged through LDS in a fixed order.
 template <typename T>
-__global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnArgs a) {
-  __shared__ float sK[AN * ARS], sV[AN * ARS], sKn[AN], sTi[AN * ANS], sBi[AN * ANS];
+__global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
+  constexpr int PS = AD + 3;  // partial row: 32 outputs, max, sum (+1 pad)
+  __shared__ float sK[AN * ARS], sV[AN * ARS], sKn[AN], sTi[AN * ANS], sBi[AN * ANS], sPart[4 * AN * PS];
   __shared__ int sCnt[AN];
-  const int i = threadIdx.x, h = blockIdx.y;
+  const int tid = threadIdx.x, w = tid >> 6, i = tid & 63, h = blockIdx.y;
   const int N = a.ws * a.ws;
+  const int jc = (N + 3) >> 2, lo = w * jc, hi = min(N, lo + jc);
   const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
   const T* __restrict__ qkv = static_cast<const T*>(a.qkv);
   T* __restrict__ out = static_cast<T*>(a.out);
   // this head's 1/clip(tau) and bias, staged once (coalesced) for all windows of the workgroup
-  for (int e = i; e < N * N; e += 64) {
+  for (int e = tid; e < N * N; e += 256) {
     const int r = e / N, c = e - r * N;
     sTi[r * ANS + c] = 1.f / fmaxf(a.tau[((size_t)h * a.Nt + r) * a.Nt + c], 0.01f);
     sBi[r * ANS + c] = a.bias[((size_t)h * N + r) * N + c];
@@ -321,47 +332,78 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnArgs a) {
     if (i < N) {
       me = win_token(a, win, i);
       const T* row = qkv + (size_t)me.tok * a.ldq + h * AD;
-      float kv[AD];
       load_head(row, q);
-      load_head(row + a.C, kv);
-      float kn = 0.f;
 #pragma unroll
       for (int e = 0; e < AD; ++e) {
         q[e] *= a.scale;
         qn += q[e] * q[e];
-        kn += kv[e] * kv[e];
-        sK[i * ARS + e] = kv[e];
       }
-      sKn[i] = sqrtf(kn);
-      load_head(row + 2 * a.C, kv);
-#pragma unroll
-      for (int e = 0; e < AD; ++e) sV[i * ARS + e] = kv[e];
-      sCnt[i] = me.cnt;
       qn = sqrtf(qn);
+      if (w == 0) {
+        float kv[AD];
+        load_head(row + a.C, kv);
+        float kn = 0.f;
+#pragma unroll
+        for (int e = 0; e < AD; ++e) {
+          kn += kv[e] * kv[e];
+          sK[i * ARS + e] = kv[e];
+        }
+        sKn[i] = sqrtf(kn);
+        sCnt[i] = me.cnt;
+      } else if (w == 1) {
+        float kv[AD];
+        load_head(row + 2 * a.C, kv);
+#pragma unroll
+        for (int e = 0; e < AD; ++e) sV[i * ARS + e] = kv[e];
+      }
     }
     __syncthreads();
-    if (i < N) {
+    {
       float m = -INFINITY, l = 0.f, o[AD];
 #pragma unroll
       for (int e = 0; e < AD; ++e) o[e] = 0.f;
-      for (int j = 0; j < N; ++j) {
-        float u = 0.f;
+      if (i < N) {
+        for (int j = lo; j < hi; ++j) {
+          float u = 0.f;
 #pragma unroll
-        for (int e = 0; e < AD; ++e) u = fmaf(q[e], sK[j * ARS + e], u);
-        float s = u / fmaxf(qn * sKn[j], 1e-6f) * sTi[i * ANS + j] + sBi[i * ANS + j];
-        if (sCnt[j] != me.cnt) s -= 100.f;
-        const float mn = fmaxf(m, s);
-        const float corr = __expf(m - mn), p = __expf(s - mn);
-        l = l * corr + p;
+          for (int e = 0; e < AD; ++e) u = fmaf(q[e], sK[j * ARS + e], u);
+          float s = u / fmaxf(qn * sKn[j], 1e-6f) * sTi[i * ANS + j] + sBi[i * ANS + j];
+          if (sCnt[j] != me.cnt) s -= 100.f;
+          const float mn = fmaxf(m, s);
+          const float corr = __expf(m - mn), p = __expf(s - mn);
+          l = l * corr + p;
 #pragma unroll
-        for (int e = 0; e < AD; ++e) o[e] = fmaf(p, sV[j * ARS + e], o[e] * corr);
-        m = mn;
+          for (int e = 0; e < AD; ++e) o[e] = fmaf(p, sV[j * ARS + e], o[e] * corr);
+          m = mn;
+        }
+      }
+      float* pr = sPart + (w * AN + i) * PS;
+#pragma unroll
+      for (int e = 0; e < AD; ++e) pr[e] = o[e];
+      pr[AD] = m;
+      pr[AD + 1] = l;
+    }
+    __syncthreads();
+    if (i < N) {  // merge the four partial states; wave w writes output components [8w, 8w + 8)
+      float m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m = fmaxf(m, sPart[(k * AN + i) * PS + AD]);
+      float l = 0.f, o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* pr = sPart + (k * AN + i) * PS;
+        const float f = pr[AD + 1] > 0.f ? __expf(pr[AD] - m) : 0.f;  // a wave with an empty key range has l = 0
+        l = fmaf(pr[AD + 1], f, l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(pr[8 * w + e], f, o[e]);
       }
       const float inv = 1.f / l;
 #pragma unroll
-      for (int e = 0; e < AD; ++e) o[e] *= inv;
-      store_head(out + (size_t)me.tok * a.ldo + h * AD, o);
-      a.lse[((size_t)win * a.heads + h) * N + i] = m + __logf(l);
+      for (int e = 0; e < 8; ++e) o[e] *= inv;
+      store8(out + (size_t)me.tok * a.ldo + h * AD + 8 * w, o);
+      if (w == 0) a.lse[((size_t)win * a.heads + h) * N + i] = m + __logf(l);
     }
   }
 }
@@ -370,12 +412,6 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnArgs a) {
 // four waves split the key range; phase B: lane = key j, the waves split the query range; per-wave
 // partial sums of dq / dk / dv meet in LDS and are added in a fixed order.  dS-derived sums for d(bias)
 // and d(tau) accumulate over the workgroup's windows in LDS (wave w owns its key columns).
-template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) {  // 8 consecutive values
-  constexpr int VEC = ElemTraits<T>::VEC;
-#pragma unroll
-  for (int c = 0; c < 8 / VEC; ++c) store_f(p + c * VEC, f + c * VEC);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
   constexpr int TILE = AN * ARS, MAT = AN * ANS;
@@ -570,6 +606,94 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Continuous position bias: bias[h][r] = b2[h] + sum_k w2[h][k] relu(w1[k][0] x0(r) + w1[k][1] x1(r) + b1[k])
+// over the R = N*N log-spaced offsets (get_continuous_relative_position_bias, swin_unet_v2.py:121-125 with
+// Mlp_Relu :58-72).  A function of parameters only; R <= 4096, hidden = 256, heads <= 32.
+// ---------------------------------------------------------------------------------------------
+constexpr int CPB_MAXH = 32;
+
+__global__ __launch_bounds__(256) void cpb_fwd_kernel(const float* __restrict__ idx, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, int R, int hidden, int heads,
+                                                      float* __restrict__ bias) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float x0 = idx[2 * r], x1 = idx[2 * r + 1];
+  float acc[CPB_MAXH];
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h) acc[h] = h < heads ? b2[h] : 0.f;
+  for (int k = 0; k < hidden; ++k) {
+    const float hv = fmaxf(fmaf(w1[2 * k], x0, fmaf(w1[2 * k + 1], x1, b1[k])), 0.f);
+#pragma unroll
+    for (int h = 0; h < CPB_MAXH; ++h)
+      if (h < heads) acc[h] = fmaf(w2[h * hidden + k], hv, acc[h]);
+  }
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h)
+    if (h < heads) bias[(size_t)h * R + r] = acc[h];
+}
+
+// one workgroup per hidden unit k: sums over the R rows of everything that involves k (fixed order)
+__global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* __restrict__ idx, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ G, int R, int hidden, int heads,
+                                                      float* __restrict__ dw1, float* __restrict__ db1,
+                                                      float* __restrict__ dw2, float* __restrict__ db2) {
+  __shared__ float red[256];
+  const int k = blockIdx.x, t = threadIdx.x;
+  const float wa = w1[2 * k], wb = w1[2 * k + 1], bk = b1[k];
+  float a2[CPB_MAXH], g2[CPB_MAXH], a10 = 0.f, a11 = 0.f, ab = 0.f;
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h) a2[h] = g2[h] = 0.f;
+  for (int r = t; r < R; r += 256) {
+    const float x0 = idx[2 * r], x1 = idx[2 * r + 1];
+    const float pre = fmaf(wa, x0, fmaf(wb, x1, bk));
+    const float hv = fmaxf(pre, 0.f);
+    float gs = 0.f;
+#pragma unroll
+    for (int h = 0; h < CPB_MAXH; ++h)
+      if (h < heads) {
+        const float g = G[(size_t)h * R + r];
+        gs = fmaf(g, w2[h * hidden + k], gs);
+        a2[h] = fmaf(g, hv, a2[h]);
+        g2[h] += g;
+      }
+    const float dl = pre > 0.f ? gs : 0.f;
+    a10 = fmaf(dl, x0, a10);
+    a11 = fmaf(dl, x1, a11);
+    ab += dl;
+  }
+  auto block_sum = [&](float v) {
+    __syncthreads();
+    red[t] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (t < st) red[t] += red[t + st];
+      __syncthreads();
+    }
+    return red[0];
+  };
+  float v;
+  v = block_sum(a10);
+  if (t == 0) dw1[2 * k] = v;
+  v = block_sum(a11);
+  if (t == 0) dw1[2 * k + 1] = v;
+  v = block_sum(ab);
+  if (t == 0) db1[k] = v;
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h) {
+    if (h < heads) {
+      v = block_sum(a2[h]);
+      if (t == 0) dw2[h * hidden + k] = v;
+      if (k == 0) {
+        v = block_sum(g2[h]);
+        if (t == 0) db2[h] = v;
+      }
+    }
+  }
+}
+
 inline int grid_cap(long long units, int per_block, int per_cu) {
   long long g = (units + per_block - 1) / per_block;
   const long long cap = (long long)UZ_NUM_CU * per_cu;
@@ -700,7 +824,7 @@ extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const f
   a.qkv = qkv; a.out = out; a.lse = lse; a.tau = tau; a.bias = bias;
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
   a.ldq = d->ldq; a.ldo = d->ldo; a.scale = d->scale;
-  const dim3 grid(attn_grid_x(d), d->heads), block(64);
+  const dim3 grid(attn_grid_x(d), d->heads), block(256);
   if (d->dtype == UZ_BF16) hipLaunchKernelGGL((winattn_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((winattn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
   UZ_LAUNCH_CHECK("uz_winattn_fwd");
@@ -730,5 +854,32 @@ extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const f
   if (d->dtype == UZ_BF16) hipLaunchKernelGGL((winattn_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((winattn_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
   UZ_LAUNCH_CHECK("uz_winattn_bwd");
+  return UZ_OK;
+}
+
+static int cpb_check(const char* fn, int R, int hidden, int heads) {
+  UZ_REQUIRE(R > 0 && hidden > 0 && heads > 0 && heads <= CPB_MAXH, "%s: bad shape (heads <= %d)", fn, CPB_MAXH);
+  return UZ_OK;
+}
+
+extern "C" int uz_cpb_fwd(const float* idx, const float* w1, const float* b1, const float* w2, const float* b2, int R,
+                          int hidden, int heads, float* bias, void* stream) {
+  const int rc = cpb_check("uz_cpb_fwd", R, hidden, heads);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(idx && w1 && b1 && w2 && b2 && bias, "uz_cpb_fwd: null pointer");
+  hipLaunchKernelGGL(cpb_fwd_kernel, dim3(uz_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, idx, w1, b1, w2, b2, R,
+                     hidden, heads, bias);
+  UZ_LAUNCH_CHECK("uz_cpb_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_cpb_bwd(const float* idx, const float* w1, const float* b1, const float* w2, const float* G, int R,
+                          int hidden, int heads, float* dw1, float* db1, float* dw2, float* db2, void* stream) {
+  const int rc = cpb_check("uz_cpb_bwd", R, hidden, heads);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(idx && w1 && b1 && w2 && G && dw1 && db1 && dw2 && db2, "uz_cpb_bwd: null pointer");
+  hipLaunchKernelGGL(cpb_bwd_kernel, dim3(hidden), dim3(256), 0, (hipStream_t)stream, idx, w1, b1, w2, G, R, hidden,
+                     heads, dw1, db1, dw2, db2);
+  UZ_LAUNCH_CHECK("uz_cpb_bwd");
   return UZ_OK;
 }

@@ -542,9 +542,8 @@ class Engine:
         qkv = self.linear(x, attn.qkv)
         cpb = attn.cpb
         w1, b1, w2, b2 = (t.detach() for t in (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias))
-        idx = attn.log_relative_position_index[:N, :N].reshape(N * N, 2)
-        hid = torch.relu(torch.addmm(b1, idx, w1.t()))                        # (N^2, 256)
-        bias = torch.addmm(b2, hid, w2.t()).t().contiguous().view(heads, N, N).float()
+        idx = attn.log_relative_position_index[:N, :N].reshape(N * N, 2).contiguous()
+        bias = ops.cpb_fwd(idx, w1, b1, w2, b2).view(heads, N, N)
         tau = attn.tau.detach()
         o = self.new_act(x.N, x.H, x.W, x.C)
         lse = ops.winattn_fwd(qkv, tau, bias, o, heads, ws, shift)
@@ -561,15 +560,13 @@ class Engine:
                     full[:, :N, :N] = dtau
                     dtau = full
                 self._give_grad(attn.tau, dtau.contiguous())
-                # cpb backward as plain matrix products (row sums as products with a ones vector: the
-                # library reduction kernel behind .sum(0) returned garbage under hipGraph replay)
-                G = dbias.reshape(heads, N * N)                                # d bias^T: (heads, N^2)
-                ones = torch.ones(N * N, 1, dtype=G.dtype, device=G.device)
-                dl = (G.t() @ w2) * (hid > 0)                                  # (N^2, 256)
-                self._give_grad(cpb.fc2.weight, G @ hid)
-                self._give_grad(cpb.fc2.bias, (G @ ones).view(-1))
-                self._give_grad(cpb.fc1.weight, dl.t() @ idx)
-                self._give_grad(cpb.fc1.bias, (dl.t() @ ones).view(-1))
+                gs = []
+                for p_ in (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias):
+                    d_ = self._dst(p_)
+                    gs.append(d_ if d_ is not None else torch.empty(p_.shape, dtype=torch.float32, device=self.device))
+                ops.cpb_bwd(idx, w1, b1, w2, dbias.reshape(heads, N * N).contiguous(), *gs)
+                for p_, g_ in zip((cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias), gs):
+                    self._give_grad(p_, g_)
 
             self.tape.append(bwd)
         return self.linear(o, attn.proj)

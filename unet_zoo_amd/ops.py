@@ -348,10 +348,15 @@ def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act],
 
 
 def colsum(x: Act) -> torch.Tensor:
+    """per-channel sums over the pixels / tokens (fp32), deterministic two-stage reduction"""
     lib = L.load()
-    out = torch.zeros(x.C, dtype=torch.float32, device=x.buf.device)
-    L.check(lib.uz_colsum(L.dtype_code(x.dtype), x.ptr(), x.ld, x.P, x.C, out.data_ptr(),
-                          L.stream_ptr()), "uz_colsum")
+    code = L.dtype_code(x.dtype)
+    out = torch.empty(x.C, dtype=torch.float32, device=x.buf.device)
+    wsb = L.check_count(lib.uz_colsum_workspace_bytes(code, x.P, x.C), "uz_colsum_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.buf.device)
+    with _Timed("colsum", 0.0, x.buf.element_size() * x.P * x.C):
+        L.check(lib.uz_colsum_ws(code, x.ptr(), x.ld, x.P, x.C, out.data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                "uz_colsum_ws")
     return out
 
 
@@ -594,3 +599,21 @@ def winattn_bwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, lse: 
                 "uz_winattn_bwd")
     tot = sum_rows(part, rows, heads * 2 * N * N).float().view(heads, 2, N, N)
     return tot[:, 0], tot[:, 1]
+
+
+def cpb_fwd(idx: torch.Tensor, w1, b1, w2, b2) -> torch.Tensor:
+    """continuous position bias (heads, R) from the (R, 2) log-spaced offsets"""
+    R, heads, hidden = idx.shape[0], w2.shape[0], w1.shape[0]
+    assert idx.is_contiguous() and idx.dtype == torch.float32
+    bias = torch.empty((heads, R), dtype=torch.float32, device=idx.device)
+    L.check(L.load().uz_cpb_fwd(idx.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), R, hidden,
+                                heads, bias.data_ptr(), L.stream_ptr()), "uz_cpb_fwd")
+    return bias
+
+
+def cpb_bwd(idx: torch.Tensor, w1, b1, w2, G: torch.Tensor, dw1, db1, dw2, db2) -> None:
+    R, heads, hidden = idx.shape[0], w2.shape[0], w1.shape[0]
+    assert G.is_contiguous() and G.shape == (heads, R) and G.dtype == torch.float32
+    L.check(L.load().uz_cpb_bwd(idx.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), G.data_ptr(), R, hidden,
+                                heads, dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), L.stream_ptr()),
+            "uz_cpb_bwd")
