@@ -266,6 +266,7 @@ constexpr int AD = 32;       // head dimension (embed_dim 96 / 3 heads, doubled 
 constexpr int AN = 64;       // max tokens per window (window_size <= 8)
 constexpr int ARS = AD + 1;  // LDS row stride of the [token][32] tiles (conflict-free row writes)
 constexpr int ANS = AN + 1;  // LDS row stride of the [N][N] matrices
+constexpr int AJ = AN / 4;   // keys (forward, backward phase A) per wave: the four waves split the other index
 
 struct WinTok {
   int tok;   // row of the token tensor
@@ -310,7 +311,7 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float* 
 template <typename T>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
   constexpr int PS = AD + 3;  // partial row: 32 outputs, max, sum (+1 pad)
-  __shared__ float sK[AN * ARS], sV[AN * ARS], sKn[AN], sTi[AN * ANS], sBi[AN * ANS], sPart[4 * AN * PS];
+  __shared__ float sK[AN * ARS], sV[AN * ARS], sKn[AN], sPart[4 * AN * PS];
   __shared__ int sCnt[AN];
   const int tid = threadIdx.x, w = tid >> 6, i = tid & 63, h = blockIdx.y;
   const int N = a.ws * a.ws;
@@ -318,14 +319,17 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
   const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
   const T* __restrict__ qkv = static_cast<const T*>(a.qkv);
   T* __restrict__ out = static_cast<T*>(a.out);
-  // this head's 1/clip(tau) and bias, staged once (coalesced) for all windows of the workgroup
-  for (int e = tid; e < N * N; e += 256) {
-    const int r = e / N, c = e - r * N;
-    sTi[r * ANS + c] = 1.f / fmaxf(a.tau[((size_t)h * a.Nt + r) * a.Nt + c], 0.01f);
-    sBi[r * ANS + c] = a.bias[((size_t)h * N + r) * N + c];
+  // 1/clip(tau) and bias of this thread's (query, key range): fixed for the head, kept in registers
+  float ti[AJ], bi[AJ];
+#pragma unroll
+  for (int jj = 0; jj < AJ; ++jj) {
+    const int j = lo + jj;
+    const bool ok = i < N && j < hi;
+    ti[jj] = ok ? 1.f / fmaxf(a.tau[((size_t)h * a.Nt + i) * a.Nt + j], 0.01f) : 0.f;
+    bi[jj] = ok ? a.bias[((size_t)h * N + i) * N + j] : 0.f;
   }
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
-    __syncthreads();  // previous window's readers are done (and the staging above has landed)
+    __syncthreads();  // previous window's readers are done
     float q[AD];
     float qn = 0.f;
     WinTok me = {0, 0};
@@ -363,18 +367,22 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < AD; ++e) o[e] = 0.f;
       if (i < N) {
-        for (int j = lo; j < hi; ++j) {
-          float u = 0.f;
 #pragma unroll
-          for (int e = 0; e < AD; ++e) u = fmaf(q[e], sK[j * ARS + e], u);
-          float s = u / fmaxf(qn * sKn[j], 1e-6f) * sTi[i * ANS + j] + sBi[i * ANS + j];
-          if (sCnt[j] != me.cnt) s -= 100.f;
-          const float mn = fmaxf(m, s);
-          const float corr = __expf(m - mn), p = __expf(s - mn);
-          l = l * corr + p;
+        for (int jj = 0; jj < AJ; ++jj) {
+          const int j = lo + jj;
+          if (j < hi) {
+            float u = 0.f;
 #pragma unroll
-          for (int e = 0; e < AD; ++e) o[e] = fmaf(p, sV[j * ARS + e], o[e] * corr);
-          m = mn;
+            for (int e = 0; e < AD; ++e) u = fmaf(q[e], sK[j * ARS + e], u);
+            float s = u / fmaxf(qn * sKn[j], 1e-6f) * ti[jj] + bi[jj];
+            if (sCnt[j] != me.cnt) s -= 100.f;
+            const float mn = fmaxf(m, s);
+            const float corr = __expf(m - mn), p = __expf(s - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int e = 0; e < AD; ++e) o[e] = fmaf(p, sV[j * ARS + e], o[e] * corr);
+            m = mn;
+          }
         }
       }
       float* pr = sPart + (w * AN + i) * PS;
@@ -605,6 +613,9 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
     part[N * N + e] = sDT[r * ANS + c];
   }
 }
+// (Measured and rejected: keeping the tau / bias values and the d(bias) / d(tau) sums of a lane's 16 keys in
+// registers with the key loop fully unrolled — 15 % slower, the unrolled body no longer fits the
+// instruction cache; recomputing P in phase B to halve LDS and double the occupancy — 26 % slower.)
 
 // ---------------------------------------------------------------------------------------------
 // Continuous position bias: bias[h][r] = b2[h] + sum_k w2[h][k] relu(w1[k][0] x0(r) + w1[k][1] x1(r) + b1[k])
@@ -612,40 +623,46 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
 // Mlp_Relu :58-72).  A function of parameters only; R <= 4096, hidden = 256, heads <= 32.
 // ---------------------------------------------------------------------------------------------
 constexpr int CPB_MAXH = 32;
+constexpr int CPB_MAXHID = 512;
 
+// grid (R / 256, heads): one thread per (offset r, head h); fc1 and this head's fc2 row sit in LDS
 __global__ __launch_bounds__(256) void cpb_fwd_kernel(const float* __restrict__ idx, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, int R, int hidden, int heads,
                                                       float* __restrict__ bias) {
+  __shared__ float4 sW[CPB_MAXHID];  // (w1[k][0], w1[k][1], b1[k], w2[h][k])
+  const int h = blockIdx.y;
+  for (int k = threadIdx.x; k < hidden; k += 256)
+    sW[k] = make_float4(w1[2 * k], w1[2 * k + 1], b1[k], w2[h * hidden + k]);
+  __syncthreads();
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const float x0 = idx[2 * r], x1 = idx[2 * r + 1];
-  float acc[CPB_MAXH];
-#pragma unroll
-  for (int h = 0; h < CPB_MAXH; ++h) acc[h] = h < heads ? b2[h] : 0.f;
+  float acc = b2[h];
+#pragma unroll 8
   for (int k = 0; k < hidden; ++k) {
-    const float hv = fmaxf(fmaf(w1[2 * k], x0, fmaf(w1[2 * k + 1], x1, b1[k])), 0.f);
-#pragma unroll
-    for (int h = 0; h < CPB_MAXH; ++h)
-      if (h < heads) acc[h] = fmaf(w2[h * hidden + k], hv, acc[h]);
+    const float4 wv = sW[k];
+    acc = fmaf(wv.w, fmaxf(fmaf(wv.x, x0, fmaf(wv.y, x1, wv.z)), 0.f), acc);
   }
-#pragma unroll
-  for (int h = 0; h < CPB_MAXH; ++h)
-    if (h < heads) bias[(size_t)h * R + r] = acc[h];
+  bias[(size_t)h * R + r] = acc;
 }
 
-// one workgroup per hidden unit k: sums over the R rows of everything that involves k (fixed order)
+// one workgroup per hidden unit k: sums over the R rows of everything that involves k (fixed order:
+// per-thread strided sums, xor-shuffle within a wave, then the four waves in order)
 __global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* __restrict__ idx, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ G, int R, int hidden, int heads,
                                                       float* __restrict__ dw1, float* __restrict__ db1,
                                                       float* __restrict__ dw2, float* __restrict__ db2) {
-  __shared__ float red[256];
-  const int k = blockIdx.x, t = threadIdx.x;
+  __shared__ float red[4][2 * CPB_MAXH + 3];
+  const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const float wa = w1[2 * k], wb = w1[2 * k + 1], bk = b1[k];
-  float a2[CPB_MAXH], g2[CPB_MAXH], a10 = 0.f, a11 = 0.f, ab = 0.f;
+  float a2[CPB_MAXH], g2[CPB_MAXH], a10 = 0.f, a11 = 0.f, ab = 0.f, w2k[CPB_MAXH];
 #pragma unroll
-  for (int h = 0; h < CPB_MAXH; ++h) a2[h] = g2[h] = 0.f;
+  for (int h = 0; h < CPB_MAXH; ++h) {
+    a2[h] = g2[h] = 0.f;
+    w2k[h] = h < heads ? w2[h * hidden + k] : 0.f;
+  }
   for (int r = t; r < R; r += 256) {
     const float x0 = idx[2 * r], x1 = idx[2 * r + 1];
     const float pre = fmaf(wa, x0, fmaf(wb, x1, bk));
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* __restrict__ 
     for (int h = 0; h < CPB_MAXH; ++h)
       if (h < heads) {
         const float g = G[(size_t)h * R + r];
-        gs = fmaf(g, w2[h * hidden + k], gs);
+        gs = fmaf(g, w2k[h], gs);
         a2[h] = fmaf(g, hv, a2[h]);
         g2[h] += g;
       }
@@ -664,32 +681,41 @@ __global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* __restrict__ 
     a11 = fmaf(dl, x1, a11);
     ab += dl;
   }
-  auto block_sum = [&](float v) {
-    __syncthreads();
-    red[t] = v;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-      if (t < st) red[t] += red[t + st];
-      __syncthreads();
-    }
-    return red[0];
-  };
-  float v;
-  v = block_sum(a10);
-  if (t == 0) dw1[2 * k] = v;
-  v = block_sum(a11);
-  if (t == 0) dw1[2 * k + 1] = v;
-  v = block_sum(ab);
-  if (t == 0) db1[k] = v;
+  auto wsum = [](float v) {
 #pragma unroll
-  for (int h = 0; h < CPB_MAXH; ++h) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  a10 = wsum(a10);
+  a11 = wsum(a11);
+  ab = wsum(ab);
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h)
     if (h < heads) {
-      v = block_sum(a2[h]);
-      if (t == 0) dw2[h * hidden + k] = v;
-      if (k == 0) {
-        v = block_sum(g2[h]);
-        if (t == 0) db2[h] = v;
+      a2[h] = wsum(a2[h]);
+      if (k == 0) g2[h] = wsum(g2[h]);
+    }
+  if (lane == 0) {
+    red[wv][0] = a10;
+    red[wv][1] = a11;
+    red[wv][2] = ab;
+#pragma unroll
+    for (int h = 0; h < CPB_MAXH; ++h)
+      if (h < heads) {
+        red[wv][3 + h] = a2[h];
+        red[wv][3 + CPB_MAXH + h] = g2[h];
       }
+  }
+  __syncthreads();
+  if (t < 3 + 2 * CPB_MAXH) {
+    const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (t == 0) dw1[2 * k] = v;
+    else if (t == 1) dw1[2 * k + 1] = v;
+    else if (t == 2) db1[k] = v;
+    else if (t < 3 + CPB_MAXH) {
+      if (t - 3 < heads) dw2[(t - 3) * hidden + k] = v;
+    } else if (k == 0 && t - 3 - CPB_MAXH < heads) {
+      db2[t - 3 - CPB_MAXH] = v;
     }
   }
 }
@@ -858,7 +884,8 @@ extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const f
 }
 
 static int cpb_check(const char* fn, int R, int hidden, int heads) {
-  UZ_REQUIRE(R > 0 && hidden > 0 && heads > 0 && heads <= CPB_MAXH, "%s: bad shape (heads <= %d)", fn, CPB_MAXH);
+  UZ_REQUIRE(R > 0 && hidden > 0 && hidden <= CPB_MAXHID && heads > 0 && heads <= CPB_MAXH,
+             "%s: bad shape (heads <= %d, hidden <= %d)", fn, CPB_MAXH, CPB_MAXHID);
   return UZ_OK;
 }
 
@@ -867,8 +894,8 @@ extern "C" int uz_cpb_fwd(const float* idx, const float* w1, const float* b1, co
   const int rc = cpb_check("uz_cpb_fwd", R, hidden, heads);
   if (rc != UZ_OK) return rc;
   UZ_REQUIRE(idx && w1 && b1 && w2 && b2 && bias, "uz_cpb_fwd: null pointer");
-  hipLaunchKernelGGL(cpb_fwd_kernel, dim3(uz_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, idx, w1, b1, w2, b2, R,
-                     hidden, heads, bias);
+  hipLaunchKernelGGL(cpb_fwd_kernel, dim3(uz_cdiv(R, 256), heads), dim3(256), 0, (hipStream_t)stream, idx, w1, b1, w2,
+                     b2, R, hidden, heads, bias);
   UZ_LAUNCH_CHECK("uz_cpb_fwd");
   return UZ_OK;
 }
