@@ -264,9 +264,30 @@ struct AttnArgs {
 
 constexpr int AD = 32;       // head dimension (embed_dim 96 / 3 heads, doubled together: always 32)
 constexpr int AN = 64;       // max tokens per window (window_size <= 8)
-constexpr int ARS = AD + 1;  // LDS row stride of the [token][32] tiles (conflict-free row writes)
+constexpr int ARS = AD + 4;  // LDS row stride of the [token][32] tiles: rows stay 16-byte aligned, so a row
+                             // (read by all lanes at once = broadcast) costs 8 ds_read_b128, not 32 ds_read_b32
 constexpr int ANS = AN + 1;  // LDS row stride of the [N][N] matrices
 constexpr int AJ = AN / 4;   // keys (forward, backward phase A) per wave: the four waves split the other index
+
+__device__ __forceinline__ void lds_row(const float* row, float* f) {  // 32 floats, 16-byte aligned
+#pragma unroll
+  for (int c = 0; c < AD / 4; ++c) {
+    const float4 v = reinterpret_cast<const float4*>(row)[c];
+    f[4 * c] = v.x;
+    f[4 * c + 1] = v.y;
+    f[4 * c + 2] = v.z;
+    f[4 * c + 3] = v.w;
+  }
+}
+__device__ __forceinline__ float dot32(const float* a, const float* b) {
+  float u0 = 0.f, u1 = 0.f;  // two chains: pairs map onto v_pk_fma_f32
+#pragma unroll
+  for (int e = 0; e < AD; e += 2) {
+    u0 = fmaf(a[e], b[e], u0);
+    u1 = fmaf(a[e + 1], b[e + 1], u1);
+  }
+  return u0 + u1;
+}
 
 struct WinTok {
   int tok;   // row of the token tensor
@@ -371,16 +392,17 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
         for (int jj = 0; jj < AJ; ++jj) {
           const int j = lo + jj;
           if (j < hi) {
-            float u = 0.f;
-#pragma unroll
-            for (int e = 0; e < AD; ++e) u = fmaf(q[e], sK[j * ARS + e], u);
+            float row[AD];
+            lds_row(sK + j * ARS, row);
+            const float u = dot32(q, row);
             float s = u / fmaxf(qn * sKn[j], 1e-6f) * ti[jj] + bi[jj];
             if (sCnt[j] != me.cnt) s -= 100.f;
             const float mn = fmaxf(m, s);
             const float corr = __expf(m - mn), p = __expf(s - mn);
             l = l * corr + p;
+            lds_row(sV + j * ARS, row);
 #pragma unroll
-            for (int e = 0; e < AD; ++e) o[e] = fmaf(p, sV[j * ARS + e], o[e] * corr);
+            for (int e = 0; e < AD; ++e) o[e] = fmaf(p, row[e], o[e] * corr);
             m = mn;
           }
         }
@@ -487,12 +509,10 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
       if (i < N) {
         const float lse = a.lse[((size_t)win * a.heads + h) * N + i];
         for (int j = lo; j < hi; ++j) {
-          float u = 0.f, dp = 0.f;
-#pragma unroll
-          for (int e = 0; e < AD; ++e) {
-            u = fmaf(q[e], sK[j * ARS + e], u);
-            dp = fmaf(go[e], sV[j * ARS + e], dp);
-          }
+          float krow[AD], vrow[AD];
+          lds_row(sK + j * ARS, krow);
+          lds_row(sV + j * ARS, vrow);
+          const float u = dot32(q, krow), dp = dot32(go, vrow);
           const float nn = qn * sKn[j];
           const bool clamped = nn <= 1e-6f;
           const float den = clamped ? 1e-6f : nn;
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
           sDC[i * ANS + j] = dc;
           const float w1 = dc / den;
 #pragma unroll
-          for (int e = 0; e < AD; ++e) av[e] = fmaf(w1, sK[j * ARS + e], av[e]);
+          for (int e = 0; e < AD; ++e) av[e] = fmaf(w1, krow[e], av[e]);
           if (!clamped) bs += dc * u * sKn[j] / (den * den * qn);  // d(den)/d(qs_i) = kn_j * qs_i / n_i
         }
       }
@@ -556,18 +576,18 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
       const int j = i;
       for (int r = lo; r < hi; ++r) {
         const float p = sP[r * ANS + j], dc = sDC[r * ANS + j];
-        float u = 0.f;
+        float qrow[AD], grow[AD];
+        lds_row(sK + r * ARS, qrow);
+        lds_row(sV + r * ARS, grow);
+        const float u = dot32(qrow, kk);
 #pragma unroll
-        for (int e = 0; e < AD; ++e) {
-          u = fmaf(sK[r * ARS + e], kk[e], u);
-          dv[e] = fmaf(p, sV[r * ARS + e], dv[e]);
-        }
+        for (int e = 0; e < AD; ++e) dv[e] = fmaf(p, grow[e], dv[e]);
         const float nn = sQn[r] * kn;
         const bool clamped = nn <= 1e-6f;
         const float den = clamped ? 1e-6f : nn;
         const float w1 = dc / den;
 #pragma unroll
-        for (int e = 0; e < AD; ++e) dk[e] = fmaf(w1, sK[r * ARS + e], dk[e]);
+        for (int e = 0; e < AD; ++e) dk[e] = fmaf(w1, qrow[e], dk[e]);
         if (!clamped) bsk += dc * u * sQn[r] / (den * den * kn);
       }
     }
