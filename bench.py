@@ -38,6 +38,9 @@ from unet_zoo_amd import ops  # noqa: E402
 from unet_zoo_amd.graph import PhasedStep
 from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
 
+# hipGraph capture checks only THIS thread's calls: the process-group watchdog thread polls its events
+# concurrently (legal for it, but fatal to a capture in the default "global" mode)
+CAPTURE_MODE = "thread_local"
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
 
 
@@ -243,7 +246,7 @@ def main():
                 graphs, pool = [], None
                 for k in range(len(groups)):
                     gk = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gk, pool=pool):
+                    with torch.cuda.graph(gk, pool=pool, capture_error_mode=CAPTURE_MODE):
                         if k == 0:
                             static_loss = ps.forward(x, mask)
                             out = ps.outputs
@@ -255,7 +258,7 @@ def main():
                 def fb_replay():
                     for gk in graphs:
                         gk.replay()
-                with torch.cuda.graph(g_opt):
+                with torch.cuda.graph(g_opt, capture_error_mode=CAPTURE_MODE):
                     opt_step()
 
                 def run_one():
@@ -275,12 +278,12 @@ def main():
                     p.grad = flat[off:off + p.numel()].view_as(p)
                     off += p.numel()
                 g_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb):
+                with torch.cuda.graph(g_fb, capture_error_mode=CAPTURE_MODE):
                     out = inner(x)
                     static_loss = model_loss(out, mask)
                     static_loss.backward()   # every parameter gradient overwritten in place
                 fb_replay = g_fb.replay
-                with torch.cuda.graph(g_opt):
+                with torch.cuda.graph(g_opt, capture_error_mode=CAPTURE_MODE):
                     opt_step()
                 if distributed:
                     def run_one():
