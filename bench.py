@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 import unet_zoo_amd  # noqa: E402
 from unet_zoo_amd import ops  # noqa: E402
 from unet_zoo_amd.graph import PhasedStep
+from unet_zoo_amd.optim import FlatClipAdamW
 from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
 
 # hipGraph capture checks only THIS thread's calls: the process-group watchdog thread polls its events
@@ -134,6 +135,9 @@ def main():
                     help="replay the whole step from one hipGraph (auto: try, fall back to eager)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and use the multi-GPU launch strategy even for 1 rank")
+    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"],
+                    help="graph mode: flat = clip + AdamW as three launches on flat buffers (unet_zoo_amd.optim), "
+                         "torch = torch.nn.utils.clip_grad_norm_ + fused torch.optim.AdamW")
     ap.add_argument("--phases", type=int, default=5,
                     help="N>1 ranks, graph mode: number of backward phases (hipGraphs) whose gradient "
                          "all-reduce overlaps the next phase; 1 = one all-reduce after the whole backward")
@@ -219,9 +223,24 @@ def main():
             used = [p for p in params if p.grad is not None]
             for p in params:
                 p.grad = None
-            flat = torch.zeros(sum(p.numel() for p in used), dtype=torch.float32, device=dev)
             inner.grads_in_place = True      # kernels write straight into the views of `flat`
             g_opt = torch.cuda.CUDAGraph()
+            optname = "clip+AdamW on flat buffers, 3 launches" if args.optimizer == "flat" else "torch clip_grad_norm_ + fused AdamW"
+
+            def lay_out(ordered):
+                """one flat gradient buffer in the given parameter order (+ the flat optimizer on it)"""
+                if args.optimizer == "flat":
+                    fo = FlatClipAdamW(ordered, lr=1e-4, weight_decay=1e-5, max_norm=1.0)
+                    inner._pack_cache.repoint()      # parameters moved into the flat buffer:
+                    inner._pack_cache.refresh(inner.run_dtype)   # new pointer tables, built outside any capture
+                    return fo.flat_g[:fo.n], fo.step
+                A = FlatClipAdamW.ALIGN
+                fl = torch.zeros(sum((p.numel() + A - 1) // A * A for p in ordered), dtype=torch.float32, device=dev)
+                o = 0
+                for p in ordered:
+                    p.grad = fl[o:o + p.numel()].view_as(p)
+                    o += (p.numel() + A - 1) // A * A
+                return fl, opt_step
             if distributed and args.phases > 1:
                 # backward cut into phases, one hipGraph each; the gradients a phase completed are
                 # all-reduced (async RCCL) while the next phase's graph runs
@@ -235,13 +254,12 @@ def main():
                 # of everything before it and leaves ~15 % of the bytes exposed
                 cuts, groups = ps.plan([0.85 * (i + 1) / (args.phases - 1) for i in range(args.phases - 1)])
                 ps.finish()
-                off, spans = 0, []
-                for grp in groups:           # flat buffer ordered by phase: one collective per phase
-                    a0 = off
-                    for p in grp:
-                        p.grad = flat[off:off + p.numel()].view_as(p)
-                        off += p.numel()
-                    spans.append((a0, off))
+                flat, do_opt = lay_out([p for grp in groups for p in grp])   # ordered by phase: one collective each
+                off, spans, A = 0, [], FlatClipAdamW.ALIGN
+                for grp in groups:
+                    k = sum((p.numel() + A - 1) // A * A for p in grp)
+                    spans.append((off, off + k))
+                    off += k
                 assert off == flat.numel()
                 graphs, pool = [], None
                 for k in range(len(groups)):
@@ -259,7 +277,7 @@ def main():
                     for gk in graphs:
                         gk.replay()
                 with torch.cuda.graph(g_opt, capture_error_mode=CAPTURE_MODE):
-                    opt_step()
+                    do_opt()
 
                 def run_one():
                     works = []
@@ -271,12 +289,9 @@ def main():
                     g_opt.replay()
                 mb = [round((a1 - a0) * 4 / 2 ** 20, 1) for a0, a1 in spans]
                 launch_mode = (f"{len(graphs)} hipGraphs (fwd + backward phases) with async RCCL all-reduce of "
-                               f"{mb} MB overlapped with the next phase + hipGraph(clip+AdamW)")
+                               f"{mb} MB overlapped with the next phase + hipGraph({optname})")
             else:
-                off = 0
-                for p in used:               # .grad = views of one buffer -> one collective
-                    p.grad = flat[off:off + p.numel()].view_as(p)
-                    off += p.numel()
+                flat, do_opt = lay_out(used)  # .grad = views of one buffer -> one collective
                 g_fb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_fb, capture_error_mode=CAPTURE_MODE):
                     out = inner(x)
@@ -284,18 +299,18 @@ def main():
                     static_loss.backward()   # every parameter gradient overwritten in place
                 fb_replay = g_fb.replay
                 with torch.cuda.graph(g_opt, capture_error_mode=CAPTURE_MODE):
-                    opt_step()
+                    do_opt()
                 if distributed:
                     def run_one():
                         g_fb.replay()
                         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
                         g_opt.replay()
-                    launch_mode = "hipGraph(fwd+bwd) + eager RCCL all-reduce + hipGraph(clip+AdamW)"
+                    launch_mode = f"hipGraph(fwd+bwd) + eager RCCL all-reduce + hipGraph({optname})"
                 else:
                     def run_one():
                         g_fb.replay()
                         g_opt.replay()
-                    launch_mode = "hipGraph(fwd+bwd) + hipGraph(clip+AdamW)"
+                    launch_mode = f"hipGraph(fwd+bwd) + hipGraph({optname})"
             run_one()                 # one untimed replay
             torch.cuda.synchronize()
             if os.environ.get("UZ_BENCH_DEBUG"):

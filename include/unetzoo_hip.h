@@ -353,6 +353,18 @@ int uz_colsum(int dtype, const void* x, int ld, int P, int C, float* out, void* 
 long long uz_colsum_workspace_bytes(int dtype, int P, int C);
 int uz_colsum_ws(int dtype, const void* x, int ld, int P, int C, float* out, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Step tail: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.AdamW.step()
+ * (unet_zoo/utils/training_loop.py:119-121) over FLAT fp32 buffers p, g, m (exp_avg), v (exp_avg_sq) of n
+ * elements.  The clipped gradient is consumed, not written back.  `step` is a device scalar (float),
+ * incremented by this call; max_norm <= 0 disables clipping.  After the call workspace holds, at byte
+ * offset 8192, four floats: clip coefficient, 1-beta1^t, 1-beta2^t, total gradient norm.
+ * ------------------------------------------------------------------------------------------- */
+long long uz_clip_adamw_workspace_bytes(void);
+int uz_clip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float max_norm, float* step, void* workspace,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

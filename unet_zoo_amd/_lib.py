@@ -35,6 +35,7 @@ EXPORTS = (
     "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd",
     "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
     "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_cpb_fwd", "uz_cpb_bwd",
+    "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
 )
 
 
@@ -112,6 +113,8 @@ def load():
     lib.uz_winattn_bwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp]
     lib.uz_cpb_fwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp]
     lib.uz_cpb_bwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp]
+    lib.uz_clip_adamw_workspace_bytes.argtypes = []
+    lib.uz_clip_adamw.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, fp, fp, fp, fp, fp, fp, vp, vp, vp]
     lib.uz_wgrad_split.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad_workspace_bytes.argtypes = [POINTER(WgradDesc)]
     lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]

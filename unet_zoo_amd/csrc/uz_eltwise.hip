@@ -1136,3 +1136,122 @@ void uz_set_error(const char* fmt, ...) {
 }
 extern "C" const char* uz_last_error_string(void) { return g_err; }
 extern "C" int uz_abi_version(void) { return UZ_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------
+// clip_grad_norm_ + AdamW over flat fp32 buffers (reference step tail, training_loop.py:119-121:
+// torch.nn.utils.clip_grad_norm_(max_norm=1.0); optimizer.step() with torch.optim.AdamW).
+// Three launches: per-workgroup sums of squares -> one workgroup derives the clip coefficient,
+// advances the step counter and the bias corrections -> one streaming pass over p, g, m, v
+// (28 bytes per parameter; the separate torch calls move 48).
+// ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int ADAMW_ROWS = 1024;
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long long n,
+                                                             double* __restrict__ partial) {
+  __shared__ double red[256];
+  double s = 0.0;
+  const long long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = g4[i];
+    s += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(n4 << 2) + threadIdx.x];
+    s += (double)v * v;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// scal[0] = clip coefficient, scal[1] = 1 - beta1^t, scal[2] = 1 - beta2^t, scal[3] = total gradient norm
+__global__ __launch_bounds__(256) void adamw_prepare_kernel(const double* __restrict__ partial, int rows, float max_norm,
+                                                            float beta1, float beta2, float* __restrict__ step,
+                                                            float* __restrict__ scal) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < rows; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]);
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+      coef = max_norm / (norm + 1e-6f);   // torch: clamp(max_norm / (total_norm + 1e-6), max=1)
+      if (coef > 1.f) coef = 1.f;
+    }
+    const float t = step[0] + 1.f;
+    step[0] = t;
+    scal[0] = coef;
+    scal[1] = 1.f - powf(beta1, t);
+    scal[2] = 1.f - powf(beta2, t);
+    scal[3] = norm;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, long long n,
+                                                          float lr, float beta1, float beta2, float eps, float wd,
+                                                          const float* __restrict__ scal) {
+  const float coef = scal[0], bc1 = scal[1], bc2 = scal[2];
+  const float step_size = lr / bc1, rs2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  auto upd = [&](float& pv, float gv, float& mv, float& vv) {
+    gv *= coef;
+    pv *= decay;                                   // decoupled weight decay
+    mv = beta1 * mv + (1.f - beta1) * gv;          // torch: exp_avg.lerp_(grad, 1 - beta1)
+    vv = beta2 * vv + (1.f - beta2) * gv * gv;
+    pv -= step_size * mv / (sqrtf(vv) * rs2 + eps);
+  };
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    upd(pv.x, gv.x, mv.x, vv.x);
+    upd(pv.y, gv.y, mv.y, vv.y);
+    upd(pv.z, gv.z, mv.z, vv.z);
+    upd(pv.w, gv.w, mv.w, vv.w);
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    upd(p[i], g[i], m[i], v[i]);
+  }
+}
+
+}  // namespace
+
+extern "C" long long uz_clip_adamw_workspace_bytes(void) { return (long long)ADAMW_ROWS * 8 + 64; }
+
+extern "C" int uz_clip_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float max_norm, float* step,
+                             void* workspace, void* stream) {
+  UZ_REQUIRE(p && g && m && v && step && workspace && n > 0, "uz_clip_adamw: bad args");
+  UZ_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)workspace) & 15) == 0,
+             "uz_clip_adamw: buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = static_cast<double*>(workspace);
+  float* scal = reinterpret_cast<float*>(partial + ADAMW_ROWS);
+  long long blocks = (n / 4 + 255) / 256;
+  int rows = (int)(blocks < ADAMW_ROWS ? (blocks < 1 ? 1 : blocks) : ADAMW_ROWS);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(rows), dim3(256), 0, s, g, n, partial);
+  UZ_LAUNCH_CHECK("uz_clip_adamw(norm)");
+  hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(256), 0, s, partial, rows, max_norm, beta1, beta2, step, scal);
+  UZ_LAUNCH_CHECK("uz_clip_adamw(prepare)");
+  const int grid = (int)(blocks < UZ_NUM_CU * 8 ? (blocks < 1 ? 1 : blocks) : UZ_NUM_CU * 8);
+  hipLaunchKernelGGL(adamw_apply_kernel, dim3(grid), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, scal);
+  UZ_LAUNCH_CHECK("uz_clip_adamw(apply)");
+  return UZ_OK;
+}

@@ -42,6 +42,11 @@ class PackCache:
         self.entries.clear()
         self._table = None
 
+    def repoint(self) -> None:
+        """The parameters kept their identity but their storage moved (e.g. into a flat optimizer
+        buffer): keep the packed destinations, rebuild only the pointer tables at the next refresh."""
+        self._table = None
+
     def get(self, p: nn.Parameter, mode: int, kpad: int, dtype: torch.dtype) -> torch.Tensor:
         key = (id(p), mode, kpad, dtype)
         e = self.entries.get(key)
