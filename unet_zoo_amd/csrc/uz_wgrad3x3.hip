@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   constexpr int NTAP = NTX * NTY;               // taps of the workgroup
   constexpr int NTW = (NTAP + TG - 1) / TG;     // taps per wave
   static_assert(TJ == 1, "one 32-channel R tile per wave");
-  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE];  // all 160 KiB: two slots of two K-steps
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -246,6 +246,20 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 
   if (nu > 0) issue(0, u_beg);
   if (nu > 1) issue(1, u_beg + 1);
+  if (!(a.flags & 8)) {
+    // two K-steps (2 x 64 pixels) per barrier: the pair for double-step d + 1 streams in while d computes
+    const int nd = (nu + 1) >> 1;
+#pragma unroll 1
+    for (int d = 0; d < nd; ++d) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const int nxt = ((d + 1) & 1) * 2;
+      if (2 * d + 2 < nu) issue(nxt, u_beg + 2 * d + 2);
+      if (2 * d + 3 < nu) issue(nxt + 1, u_beg + 2 * d + 3);
+      compute((d & 1) * 2);
+      if (2 * d + 1 < nu) compute((d & 1) * 2 + 1);
+    }
+  } else
 #pragma unroll 1
   for (int s = 0; s < nu; ++s) {
     if (s + 1 < nu) {
