@@ -667,75 +667,108 @@ __global__ __launch_bounds__(256) void cpb_fwd_kernel(const float* __restrict__ 
   bias[(size_t)h * R + r] = acc;
 }
 
-// one workgroup per hidden unit k: sums over the R rows of everything that involves k (fixed order:
-// per-thread strided sums, xor-shuffle within a wave, then the four waves in order)
-__global__ __launch_bounds__(256) void cpb_bwd_kernel(const float* __restrict__ idx, const float* __restrict__ w1,
+// one 1024-thread workgroup per hidden unit (the kernel is bound by the latency of the few G / idx loads each
+// thread issues, so the rows are spread over 16 waves).  Sums over the R rows in a fixed order: per-thread
+// strided sums, xor-shuffle within a wave, then the sixteen waves in order.
+constexpr int CPB_KB = 1;
+constexpr int CPB_NW = 16;
+
+__global__ __launch_bounds__(1024) void cpb_bwd_kernel(const float* __restrict__ idx, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ G, int R, int hidden, int heads,
                                                       float* __restrict__ dw1, float* __restrict__ db1,
                                                       float* __restrict__ dw2, float* __restrict__ db2) {
-  __shared__ float red[4][2 * CPB_MAXH + 3];
-  const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const float wa = w1[2 * k], wb = w1[2 * k + 1], bk = b1[k];
-  float a2[CPB_MAXH], g2[CPB_MAXH], a10 = 0.f, a11 = 0.f, ab = 0.f, w2k[CPB_MAXH];
+  __shared__ float red[CPB_NW][CPB_KB * (CPB_MAXH + 3) + CPB_MAXH];
+  const int k0 = blockIdx.x * CPB_KB, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  float wa[CPB_KB], wb[CPB_KB], bk[CPB_KB];
 #pragma unroll
-  for (int h = 0; h < CPB_MAXH; ++h) {
-    a2[h] = g2[h] = 0.f;
-    w2k[h] = h < heads ? w2[h * hidden + k] : 0.f;
+  for (int q = 0; q < CPB_KB; ++q) {
+    const int k = min(k0 + q, hidden - 1);
+    wa[q] = w1[2 * k];
+    wb[q] = w1[2 * k + 1];
+    bk[q] = b1[k];
   }
-  for (int r = t; r < R; r += 256) {
+  float a2[CPB_KB][CPB_MAXH], g2[CPB_MAXH], a10[CPB_KB], a11[CPB_KB], ab[CPB_KB];
+#pragma unroll
+  for (int q = 0; q < CPB_KB; ++q) {
+    a10[q] = a11[q] = ab[q] = 0.f;
+#pragma unroll
+    for (int h = 0; h < CPB_MAXH; ++h) a2[q][h] = 0.f;
+  }
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h) g2[h] = 0.f;
+  for (int r = t; r < R; r += 64 * CPB_NW) {
     const float x0 = idx[2 * r], x1 = idx[2 * r + 1];
-    const float pre = fmaf(wa, x0, fmaf(wb, x1, bk));
-    const float hv = fmaxf(pre, 0.f);
-    float gs = 0.f;
+    float pre[CPB_KB], hv[CPB_KB], gs[CPB_KB];
+#pragma unroll
+    for (int q = 0; q < CPB_KB; ++q) {
+      pre[q] = fmaf(wa[q], x0, fmaf(wb[q], x1, bk[q]));
+      hv[q] = fmaxf(pre[q], 0.f);
+      gs[q] = 0.f;
+    }
 #pragma unroll
     for (int h = 0; h < CPB_MAXH; ++h)
       if (h < heads) {
         const float g = G[(size_t)h * R + r];
-        gs = fmaf(g, w2k[h], gs);
-        a2[h] = fmaf(g, hv, a2[h]);
         g2[h] += g;
+#pragma unroll
+        for (int q = 0; q < CPB_KB; ++q) {
+          gs[q] = fmaf(g, w2[h * hidden + min(k0 + q, hidden - 1)], gs[q]);
+          a2[q][h] = fmaf(g, hv[q], a2[q][h]);
+        }
       }
-    const float dl = pre > 0.f ? gs : 0.f;
-    a10 = fmaf(dl, x0, a10);
-    a11 = fmaf(dl, x1, a11);
-    ab += dl;
+#pragma unroll
+    for (int q = 0; q < CPB_KB; ++q) {
+      const float dl = pre[q] > 0.f ? gs[q] : 0.f;
+      a10[q] = fmaf(dl, x0, a10[q]);
+      a11[q] = fmaf(dl, x1, a11[q]);
+      ab[q] += dl;
+    }
   }
   auto wsum = [](float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
   };
-  a10 = wsum(a10);
-  a11 = wsum(a11);
-  ab = wsum(ab);
+  constexpr int PERK = CPB_MAXH + 3;
 #pragma unroll
-  for (int h = 0; h < CPB_MAXH; ++h)
-    if (h < heads) {
-      a2[h] = wsum(a2[h]);
-      if (k == 0) g2[h] = wsum(g2[h]);
+  for (int q = 0; q < CPB_KB; ++q) {
+    const float s0 = wsum(a10[q]), s1 = wsum(a11[q]), s2 = wsum(ab[q]);
+    if (lane == 0) {
+      red[wv][q * PERK] = s0;
+      red[wv][q * PERK + 1] = s1;
+      red[wv][q * PERK + 2] = s2;
     }
-  if (lane == 0) {
-    red[wv][0] = a10;
-    red[wv][1] = a11;
-    red[wv][2] = ab;
 #pragma unroll
     for (int h = 0; h < CPB_MAXH; ++h)
       if (h < heads) {
-        red[wv][3 + h] = a2[h];
-        red[wv][3 + CPB_MAXH + h] = g2[h];
+        const float v = wsum(a2[q][h]);
+        if (lane == 0) red[wv][q * PERK + 3 + h] = v;
+      }
+  }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int h = 0; h < CPB_MAXH; ++h)
+      if (h < heads) {
+        const float v = wsum(g2[h]);
+        if (lane == 0) red[wv][CPB_KB * PERK + h] = v;
       }
   }
   __syncthreads();
-  if (t < 3 + 2 * CPB_MAXH) {
-    const float v = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-    if (t == 0) dw1[2 * k] = v;
-    else if (t == 1) dw1[2 * k + 1] = v;
-    else if (t == 2) db1[k] = v;
-    else if (t < 3 + CPB_MAXH) {
-      if (t - 3 < heads) dw2[(t - 3) * hidden + k] = v;
-    } else if (k == 0 && t - 3 - CPB_MAXH < heads) {
-      db2[t - 3 - CPB_MAXH] = v;
+  if (t < CPB_KB * PERK + CPB_MAXH) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPB_NW; ++k) v += red[k][t];
+    if (t < CPB_KB * PERK) {
+      const int q = t / PERK, e = t - q * PERK, k = k0 + q;
+      if (k < hidden) {
+        if (e == 0) dw1[2 * k] = v;
+        else if (e == 1) dw1[2 * k + 1] = v;
+        else if (e == 2) db1[k] = v;
+        else if (e - 3 < heads) dw2[(e - 3) * hidden + k] = v;
+      }
+    } else if (blockIdx.x == 0 && t - CPB_KB * PERK < heads) {
+      db2[t - CPB_KB * PERK] = v;
     }
   }
 }
@@ -925,8 +958,8 @@ extern "C" int uz_cpb_bwd(const float* idx, const float* w1, const float* b1, co
   const int rc = cpb_check("uz_cpb_bwd", R, hidden, heads);
   if (rc != UZ_OK) return rc;
   UZ_REQUIRE(idx && w1 && b1 && w2 && G && dw1 && db1 && dw2 && db2, "uz_cpb_bwd: null pointer");
-  hipLaunchKernelGGL(cpb_bwd_kernel, dim3(hidden), dim3(256), 0, (hipStream_t)stream, idx, w1, b1, w2, G, R, hidden,
-                     heads, dw1, db1, dw2, db2);
+  hipLaunchKernelGGL(cpb_bwd_kernel, dim3(uz_cdiv(hidden, CPB_KB)), dim3(64 * CPB_NW), 0, (hipStream_t)stream, idx, w1, b1, w2, G,
+                     R, hidden, heads, dw1, db1, dw2, db2);
   UZ_LAUNCH_CHECK("uz_cpb_bwd");
   return UZ_OK;
 }
