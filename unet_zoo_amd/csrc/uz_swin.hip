@@ -438,6 +438,180 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 forward on the matrix cores.  One WAVE per (window, head) (four independent waves per workgroup):
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16, K rows / Q rows straight from global memory as the A / B
+//                 fragments (16 bytes of one token's head slice per lane) -> accumulator column = query
+//                 (lane & 31), rows = keys: a lane owns, for ITS query, 16 keys per 32-key tile, so the
+//                 softmax runs over registers (+ one xor-32 shuffle), no LDS round trip;
+//   O^T = V^T P^T the exponentials are packed to bf16 in registers and are directly the B fragment (the
+//                 accumulator's key order 32kt + 16s + 8(e>>2) + 4(lane>>5) + (e&3) is used as the K order
+//                 of both operands); V^T comes from a per-wave LDS tile [32 d][64 keys].
+// tau / bias of the lane's (query, key) pairs are fixed for the head and live in registers.
+// ---------------------------------------------------------------------------------------------
+constexpr int VTS = 72;  // V^T row stride in bf16 elements (144 B: 8-byte aligned rows, spreads banks)
+
+__global__ __launch_bounds__(256) void winattn_fwd_mfma_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t sVT[4][AD * VTS];
+  __shared__ float sKn[4][AN];
+  __shared__ int sCnt[4][AN];
+  __shared__ float sTab[2][AN * ANS];   // this head's 1/clip(tau) and bias, staged once per workgroup (coalesced)
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, h = blockIdx.y;
+  const int N = a.ws * a.ws;
+  const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
+  const bf16_t* __restrict__ qkv = static_cast<const bf16_t*>(a.qkv);
+  bf16_t* __restrict__ out = static_cast<bf16_t*>(a.out);
+  bf16_t* vt = sVT[w];
+  for (int e = tid; e < N * N; e += 256) {
+    const int r = e / N, c = e - r * N;
+    sTab[0][r * ANS + c] = 1.f / fmaxf(a.tau[((size_t)h * a.Nt + r) * a.Nt + c], 0.01f);
+    sTab[1][r * ANS + c] = a.bias[((size_t)h * N + r) * N + c];
+  }
+  __syncthreads();
+  // tables of this lane's (query 32 qt + l31, key 32 kt + row(r)) pairs, in registers
+  float ti[2][2][16], bi[2][2][16];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * qt + l31, j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = i < N && j < N;
+        ti[qt][kt][r] = ok ? sTab[0][i * ANS + j] : 0.f;
+        bi[qt][kt][r] = ok ? sTab[1][i * ANS + j] : 0.f;
+      }
+  for (int win = blockIdx.x * 4 + w; win < nWin; win += gridDim.x * 4) {
+    // token t = 32 x + l31 (x = 0, 1) in its query role (B fragment column) and key role (A fragment row)
+    WinTok tk[2];
+    bf16x8 qf[2][2], kf[2][2];
+    float qn[2], kn[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int t = 32 * x + l31;
+      float q2 = 0.f, k2 = 0.f;
+      if (t < N) {
+        tk[x] = win_token(a, win, t);
+        const bf16_t* row = qkv + (size_t)tk[x].tok * a.ldq + h * AD + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[x][ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+          kf[x][ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float qv = (float)qf[x][ks][e], kv = (float)kf[x][ks][e];
+            q2 = fmaf(qv, qv, q2);
+            k2 = fmaf(kv, kv, k2);
+          }
+        }
+      } else {
+        tk[x].tok = 0;
+        tk[x].cnt = -1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qf[x][ks][e] = kf[x][ks][e] = (bf16_t)0.f;
+      }
+      q2 += __shfl_xor(q2, 32);
+      k2 += __shfl_xor(k2, 32);
+      qn[x] = a.scale * sqrtf(q2);
+      kn[x] = sqrtf(k2);
+      if (lh == 0) {
+        sKn[w][t] = kn[x];
+        sCnt[w][t] = tk[x].cnt;
+      }
+    }
+    {  // V^T tile: lane = token (32 lh + l31 == lane), its 32 values scattered down the column
+      const int t = lane;
+      const WinTok me = tk[lh];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x8 v;
+        if (t < N) v = *reinterpret_cast<const bf16x8*>(qkv + (size_t)me.tok * a.ldq + 2 * a.C + h * AD + 8 * c);
+        else
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vt[(8 * c + e) * VTS + t] = v[e];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS writes are visible to its reads
+    // S^T tiles
+    f32x16 st[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kt][qt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
+      }
+    f32x16 ot[2];
+    float lsum[2], mrow[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      // scores of this lane's query against its 32 keys, then the row maximum
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float sv = st[kt][qt][r] * a.scale / fmaxf(qn[qt] * sKn[w][j], 1e-6f) * ti[qt][kt][r] + bi[qt][kt][r];
+          if (sCnt[w][j] != tk[qt].cnt) sv -= 100.f;
+          if (j >= N) sv = -INFINITY;
+          st[kt][qt][r] = sv;
+          m = fmaxf(m, sv);
+        }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (m == -INFINITY) m = 0.f;  // padded query column
+      float l = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[qt][r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 pf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float p = __expf(st[kt][qt][8 * s2 + e] - m);
+            const bf16_t pb = (bf16_t)p;
+            l += (float)pb;   // normalise by what is actually multiplied
+            pf[e] = pb;
+          }
+          // A fragment = V^T rows (d = l31), keys 32 kt + 16 s2 + 4 lh + {0..3} and + 8
+          const bf16_t* vr = vt + l31 * VTS + 32 * kt + 16 * s2 + 4 * lh;
+          const bf16x4 lo4 = *reinterpret_cast<const bf16x4*>(vr), hi4 = *reinterpret_cast<const bf16x4*>(vr + 8);
+          const bf16x8 vf = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+          ot[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[qt], 0, 0, 0);
+        }
+      l += __shfl_xor(l, 32);
+      lsum[qt] = l;
+      mrow[qt] = m;
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int i = 32 * qt + l31;
+      if (i < N) {
+        const float inv = 1.f / lsum[qt];
+        bf16_t* orow = out + (size_t)tk[qt].tok * a.ldo + h * AD + 4 * lh;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)(ot[qt][4 * q4 + e] * inv);
+          *reinterpret_cast<bf16x4*>(orow + 8 * q4) = o4;
+        }
+        if (lh == 0) a.lse[((size_t)win * a.heads + h) * N + i] = mrow[qt] + __logf(lsum[qt]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS reads done before the next window overwrites the tiles
+  }
+}
+
 // Backward: one 256-thread workgroup (one wave per SIMD) per (window, head).  Phase A: lane = query i, the
 // four waves split the key range; phase B: lane = key j, the waves split the query range; per-wave
 // partial sums of dq / dk / dv meet in LDS and are added in a fixed order.  dS-derived sums for d(bias)
@@ -904,8 +1078,17 @@ extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const f
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
   a.ldq = d->ldq; a.ldo = d->ldo; a.scale = d->scale;
   const dim3 grid(attn_grid_x(d), d->heads), block(256);
-  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((winattn_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((winattn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
+  if (d->dtype == UZ_BF16 && !(uz_tune_flags() & 0x1000)) {
+    // matrix-core path: one wave per (window, head), four per workgroup
+    const long long nwin = (long long)d->B * (d->H / d->ws) * (d->W / d->ws);
+    long long gx = (nwin + 3) / 4, cap = (UZ_NUM_CU * 2 + d->heads - 1) / d->heads;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(winattn_fwd_mfma_kernel, dim3((unsigned)gx, d->heads), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (d->dtype == UZ_BF16) {
+    hipLaunchKernelGGL((winattn_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL((winattn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
+  }
   UZ_LAUNCH_CHECK("uz_winattn_fwd");
   return UZ_OK;
 }
