@@ -279,6 +279,8 @@ __device__ __forceinline__ void lds_row(const float* row, float* f) {  // 32 flo
     f[4 * c + 3] = v.w;
   }
 }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
+
 __device__ __forceinline__ float dot32(const float* a, const float* b) {
   float u0 = 0.f, u1 = 0.f;  // two chains: pairs map onto v_pk_fma_f32
 #pragma unroll
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
             float row[AD];
             lds_row(sK + j * ARS, row);
             const float u = dot32(q, row);
-            float s = u / fmaxf(qn * sKn[j], 1e-6f) * ti[jj] + bi[jj];
+            float s = u * rcp(fmaxf(qn * sKn[j], 1e-6f)) * ti[jj] + bi[jj];
             if (sCnt[j] != me.cnt) s -= 100.f;
             const float mn = fmaxf(m, s);
             const float corr = __expf(m - mn), p = __expf(s - mn);
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma_kernel(const AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float sv = st[kt][qt][r] * a.scale / fmaxf(qn[qt] * sKn[w][j], 1e-6f) * ti[qt][kt][r] + bi[qt][kt][r];
+          float sv = st[kt][qt][r] * a.scale * rcp(fmaxf(qn[qt] * sKn[w][j], 1e-6f)) * ti[qt][kt][r] + bi[qt][kt][r];
           if (sCnt[w][j] != tk[qt].cnt) sv -= 100.f;
           if (j >= N) sv = -INFINITY;
           st[kt][qt][r] = sv;
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
     __syncthreads();
     float q[AD], kk[AD], go[AD];
-    float qn = 0.f, kn = 0.f, Di = 0.f;
+    float qn = 0.f, kn = 0.f, Di = 0.f, rqn = 0.f, rkn = 0.f;
     WinTok me = {0, 0};
     if (i < N) {
       me = win_token(a, win, i);
@@ -663,6 +665,8 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
       }
       qn = sqrtf(qn);
       kn = sqrtf(kn);
+      rqn = rcp(qn);
+      rkn = rcp(kn);
       if (w == 0) {
         load_head(row + 2 * a.C, t);
 #pragma unroll
@@ -691,8 +695,9 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
           const bool clamped = nn <= 1e-6f;
           const float den = clamped ? 1e-6f : nn;
           const float tv = a.tau[((size_t)h * a.Nt + i) * a.Nt + j];
-          const float ti = 1.f / fmaxf(tv, 0.01f);
-          const float c = u / den;
+          const float ti = rcp(fmaxf(tv, 0.01f));
+          const float rden = rcp(den);
+          const float c = u * rden;
           float s = c * ti + a.bias[((size_t)h * N + i) * N + j];
           if (sCnt[j] != me.cnt) s -= 100.f;
           const float p = __expf(s - lse);
@@ -702,10 +707,10 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
           if (tv >= 0.01f) sDT[i * ANS + j] -= ds * c * ti * ti;
           const float dc = ds * ti;
           sDC[i * ANS + j] = dc;
-          const float w1 = dc / den;
+          const float w1 = dc * rden;
 #pragma unroll
           for (int e = 0; e < AD; ++e) av[e] = fmaf(w1, krow[e], av[e]);
-          if (!clamped) bs += dc * u * sKn[j] / (den * den * qn);  // d(den)/d(qs_i) = kn_j * qs_i / n_i
+          if (!clamped) bs += dc * u * sKn[j] * rden * rden * rqn;  // d(den)/d(qs_i) = kn_j * qs_i / n_i
         }
       }
       float* ra = sRA + (w * AN + i) * ARS;
@@ -759,10 +764,11 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
         const float nn = sQn[r] * kn;
         const bool clamped = nn <= 1e-6f;
         const float den = clamped ? 1e-6f : nn;
-        const float w1 = dc / den;
+        const float rden = rcp(den);
+        const float w1 = dc * rden;
 #pragma unroll
         for (int e = 0; e < AD; ++e) dk[e] = fmaf(w1, qrow[e], dk[e]);
-        if (!clamped) bsk += dc * u * sQn[r] / (den * den * kn);
+        if (!clamped) bsk += dc * u * sQn[r] * rden * rden * rkn;
       }
     }
     __syncthreads();  // everyone is done with sP / sDC / the Q, dO tiles: the partials may overwrite them
