@@ -69,11 +69,14 @@ const char* uz_last_error_string(void);
 typedef struct uz_conv_desc {
   int dtype;
   int N, H, W;     /* output pixel grid */
-  int Hin, Win;    /* input pixel grid (== H, W for UZ_TAPS_CONV; 2H, 2W for GATHER2X2) */
+  int Hin, Win;    /* input pixel grid (== H, W for UZ_TAPS_CONV; 2H..2H+1, 2W..2W+1 for GATHER2X2) */
   int Cin, ldx;    /* channels per tap, input pixel stride */
   int Nout, ldy;   /* GEMM N (rows of w), output pixel stride */
   int ntaps, taps_mode, dil;
   int store_mode, Co; /* Co: channels per sub-pixel for UZ_STORE_SHUFFLE2X2 (Nout = 4*Co) */
+  int Hout, Wout;     /* UZ_STORE_SHUFFLE2X2: pixel grid of the destination, 2H..2H+1 x 2W..2W+1 (0 = 2H, 2W).
+                       * The 2H x 2W result lands at its top-left; UpSample_UNet's F.pad of an odd skip size
+                       * (common_layers.py:110-113) leaves the last row / column to the caller (zeros). */
 } uz_conv_desc;
 
 int uz_conv_igemm_grid_m(const uz_conv_desc* d); /* number of stats partial rows; <0 on error */
@@ -180,7 +183,9 @@ int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, cons
  * (u2net.py:221-229).  res == NULL is uz_bn_relu_apply. */
 int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
                          int N, int H, int W, int C, const void* res, int ldr, void* act, int lda,
-                         void* pooled, int ldp, void* stream);
+                         void* pooled, int ldp, int pool_ceil, void* stream);
+/* pool_ceil = 1: pooled is (N, ceil(H/2), ceil(W/2), C), border windows clipped (ceil_mode=True, u2net.py:30);
+ * pool_ceil = 0: pooled is (N, H/2, W/2, C), an odd last row / column is not pooled (MaxPool2d default). */
 
 /* Backward of (BN train -> ReLU [-> MaxPool2d(2,2)]) in two passes.
  * The gradient arriving at the activation is
@@ -194,6 +199,7 @@ typedef struct uz_bnbwd_desc {
   int dtype;
   int N, H, W, C;
   int ldy, ldg0, ldg1, ldgp, lddy;
+  int pool_ceil; /* geometry of gpool: 1 = (ceil(H/2), ceil(W/2)) with clipped border windows, 0 = (H/2, W/2) */
 } uz_bnbwd_desc;
 long long uz_bn_relu_bwd_workspace_bytes(const uz_bnbwd_desc* d, int has_pool_grad);
 int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, const float* scale,
@@ -263,7 +269,7 @@ int uz_bilinear_bwd(int dtype, const void* g, int ldg, long long g_img_stride, i
  * MaxPool2d(2,2) (gp at (H/2, W/2), routed to the first maximum of each window as ATen does). */
 int uz_pool_grad_combine(int dtype, int N, int H, int W, int C, const void* act, int lda, const void* g0,
                          int ldg0, const void* g1, int ldg1, const void* gp, int ldgp, void* out, int ldo,
-                         void* stream);
+                         int pool_ceil, void* stream);
 /* Side head Conv2d(C, 1, 3, padding=1) (u2net.py:238-243): x NHWC, w = the (1, C, 3, 3) fp32 parameter,
  * bias 1 value or NULL, out[n*out_img_stride + h*W + w] fp32; taps_ws: N*9*H*W floats of scratch. */
 int uz_sideconv3x3_fwd(int dtype, const void* x, int ldx, int N, int H, int W, int C, const float* w,

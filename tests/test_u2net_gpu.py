@@ -395,7 +395,59 @@ def test_u2net_bf16_trains_and_in_place_gradients_match():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-def test_u2net_rejects_sizes_the_pyramid_cannot_halve():
-    m = unet_zoo_amd.create_model("u2netp").to(DEV)
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 3, 48, 64, device=DEV))
+@pytest.mark.parametrize("name,H,W", [("u2netp", 72, 56), ("u2netp", 50, 83), ("u2net", 37, 64)])
+def test_u2net_odd_sizes_ceil_mode_pooling(name, H, W):
+    """MaxPool2d(2, 2, ceil_mode=True) with odd maps (clipped border windows, u2net.py:30, 221-229) and
+    _upsample_like between unequal sizes: forward + backward against the oracle, fp32"""
+    torch.manual_seed(4)
+    m = unet_zoo_amd.create_model(name)
+    m.run_dtype = torch.float32
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(2, 3, H, W, seed=6)
+    outs = m(x.to(DEV))
+    loss = _loss(outs, mask.to(DEV))
+    loss.backward()
+    st = torch_ref.clone_state(sd0, requires_grad=True)
+    ref = torch_ref.u2net_forward(st, x, True)
+    rloss = torch_ref.model_loss(ref, mask)
+    names = [k for k, v in st.items() if v.requires_grad]
+    rg = dict(zip(names, torch.autograd.grad(rloss, [st[k] for k in names])))
+    for k in ref:
+        got, want = outs[k].detach().cpu(), ref[k].detach()
+        assert got.shape == want.shape
+        assert (got - want).abs().max() <= 2e-3 * want.abs().max(), k
+    assert abs(loss.item() - rloss.item()) < 5e-5
+    keep = [n for n, _ in m.named_parameters() if not n.endswith("conv_s1.bias")]
+    named = dict(m.named_parameters())
+    gflat = torch.cat([named[n].grad.flatten().cpu() for n in keep])
+    rflat = torch.cat([rg[n].flatten() for n in keep])
+    cos = F.cosine_similarity(gflat.double(), rflat.double(), dim=0).item()
+    assert cos > 0.99, cos
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H,W,ceil", [(7, 9, True), (7, 9, False), (1, 5, True), (6, 3, False)])
+def test_fused_pool_odd_sizes(dt, H, W, ceil):
+    """BN-apply + ReLU + MaxPool2d(2, 2, ceil_mode=ceil) and its backward on odd maps"""
+    g = torch.Generator().manual_seed(38)
+    N, C = 2, 16
+    y = rnd(dt, torch.randn(N, C, H, W, generator=g))
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    a = F.relu(y * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1))
+    a_r = rnd(dt, a).requires_grad_(True)
+    pooled_ref = F.max_pool2d(a_r, 2, stride=2, ceil_mode=ceil)
+    ya = act_from_nchw(y.to(DEV), dt)
+    act = ops.new_act(N, H, W, C, dt, DEV)
+    pooled = ops.new_act(N, pooled_ref.shape[2], pooled_ref.shape[3], C, dt, DEV)
+    ops.bn_relu_apply(ya, sc.to(DEV), sh.to(DEV), act, pooled, None, ceil)
+    assert relerr(act.dense().cpu(), a_r.detach()) < (1e-6 if dt == torch.float32 else 8e-3)
+    assert torch.equal(pooled.dense().cpu(), F.max_pool2d(act.dense().cpu(), 2, stride=2, ceil_mode=ceil))
+    # gradient merge: direct + pooled gradients, routed to the first maximum of each (clipped) window
+    g0 = rnd(dt, torch.randn(N, C, H, W, generator=g))
+    gp = rnd(dt, torch.randn(pooled_ref.shape, generator=g))
+    stored = act.dense().cpu().requires_grad_(True)
+    (F.max_pool2d(stored, 2, stride=2, ceil_mode=ceil) * gp).sum().backward()
+    tot = ops.new_act(N, H, W, C, dt, DEV)
+    ops.pool_grad_combine(act, act_from_nchw(g0.to(DEV), dt), None, act_from_nchw(gp.to(DEV), dt), tot, ceil)
+    assert relerr(tot.dense().cpu(), g0 + stored.grad) < (1e-6 if dt == torch.float32 else 8e-3)

@@ -277,3 +277,34 @@ def test_phased_backward_equals_one_shot_backward(name):
         assert torch.equal(flat[a0:a1], snap)                        # later phases did not touch it
     for p in params:
         assert torch.equal(p.grad, ref[p])
+
+
+@pytest.mark.parametrize("H,W", [(50, 70), (37, 44), (65, 31)])
+def test_unet_sizes_not_divisible_by_16(H, W):
+    """floor-mode pooling of odd maps and UpSample_UNet's zero padding of the transposed-conv output to the
+    skip's size (common_layers.py:90, 110-113): forward + backward against the oracle, fp32"""
+    torch.manual_seed(5)
+    m = unet_zoo_amd.create_model("unet", in_channels=3, num_classes=2)
+    m.run_dtype = torch.float32
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(2, 3, H, W, seed=8)
+    mask = mask.expand(-1, 2, -1, -1).contiguous()
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, mask.to(DEV))
+    loss.backward()
+    ref_logits, ref_loss, ref_grads, st = torch_ref.train_step_reference("unet", sd0, x, mask)
+    got = logits.detach().cpu()
+    assert got.shape == ref_logits.shape == (2, 2, H, W)
+    assert (got - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    named = dict(m.named_parameters())
+    keep = [n for n in ref_grads if not (n.endswith(".0.bias") or n.endswith(".3.bias"))]   # conv biases before a BatchNorm
+    gflat = torch.cat([named[n].grad.flatten().cpu() for n in keep])
+    rflat = torch.cat([ref_grads[n].flatten() for n in keep])
+    cos = F.cosine_similarity(gflat.double(), rflat.double(), dim=0).item()
+    assert cos > 0.999, cos
+    assert abs(gflat.double().norm().item() / rflat.double().norm().item() - 1) < 1e-2
+    sd = m.state_dict()
+    for k in ("down_convolution_1.conv.conv_op.1", "bottle_neck.conv_op.4", "up_convolution_4.conv.conv_op.4"):
+        np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), st[k + ".running_var"].numpy(), rtol=2e-3, atol=1e-5)

@@ -42,7 +42,7 @@ EXPORTS = (
 class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in (
         "dtype", "N", "H", "W", "Hin", "Win", "Cin", "ldx", "Nout", "ldy", "ntaps", "taps_mode",
-        "dil", "store_mode", "Co")]
+        "dil", "store_mode", "Co", "Hout", "Wout")]
 
 
 class WgradDesc(Structure):
@@ -52,7 +52,7 @@ class WgradDesc(Structure):
 
 class BnBwdDesc(Structure):
     _fields_ = [(n, c_int) for n in (
-        "dtype", "N", "H", "W", "C", "ldy", "ldg0", "ldg1", "ldgp", "lddy")]
+        "dtype", "N", "H", "W", "C", "ldy", "ldg0", "ldg1", "ldgp", "lddy", "pool_ceil")]
 
 
 class LnDesc(Structure):
@@ -146,10 +146,10 @@ def load():
     lib.uz_sum_rows.argtypes = [vp, ip, ip, vp, vp]
     lib.uz_sum2x2.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, vp]
     ll = ctypes.c_longlong
-    lib.uz_bn_relu_add_apply.argtypes = [ip, vp, ip, vp, vp, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, vp]
+    lib.uz_bn_relu_add_apply.argtypes = [ip, vp, ip, vp, vp, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, ip, vp]
     lib.uz_bilinear_fwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, vp]
     lib.uz_bilinear_bwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, vp]
-    lib.uz_pool_grad_combine.argtypes = [ip, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, vp, ip, vp, ip, vp]
+    lib.uz_pool_grad_combine.argtypes = [ip, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, vp, ip, vp, ip, ip, vp]
     lib.uz_sideconv3x3_fwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp, vp, vp, ll, vp]
     lib.uz_sideconv3x3_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]
     lib.uz_sideconv3x3_bwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp, ll, vp, ip, vp, vp, vp, vp]

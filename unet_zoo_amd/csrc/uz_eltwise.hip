@@ -87,11 +87,14 @@ template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
     const T* __restrict__ y, int ldy, const float* __restrict__ scale, const float* __restrict__ shift,
     int N, int H, int W, int C, T* __restrict__ act, int lda, T* __restrict__ pooled, int ldp,
-    const T* __restrict__ res, int ldr) {
-  // res != nullptr: act = relu(bn(y)) + res (the RSU residual, u2net.py:74), pooled = maxpool(act)
+    const T* __restrict__ res, int ldr, int pool_ceil) {
+  // res != nullptr: act = relu(bn(y)) + res (the RSU residual, u2net.py:74), pooled = maxpool(act).
+  // Windows are enumerated on the ceil grid so that every pixel is visited once; a window clipped by an odd
+  // border is pooled only in ceil mode (MaxPool2d(2, 2, ceil_mode=True), u2net.py:30) and dropped in floor mode.
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CC = C / VEC;
-  const int Ho = H >> 1, Wo = W >> 1;
+  const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+  const int Hp = pool_ceil ? Ho : H >> 1, Wp = pool_ceil ? Wo : W >> 1;
   const long long total = POOL ? (long long)N * Ho * Wo * CC : (long long)N * H * W * CC;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
       float m[VEC];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        if (2 * ho + (k >> 1) >= H || 2 * wo + (k & 1) >= W) continue;  // clipped window (tap 0 is always inside)
         const size_t p = p00 + (k >> 1) * W + (k & 1);
         float v[VEC], r[VEC];
         load_f(y + p * ldy + c0, v);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
         }
         store_f(act + p * lda + c0, v);
       }
-      store_f(pooled + (size_t)u * ldp + c0, m);
+      if (ho < Hp && wo < Wp) store_f(pooled + (((size_t)img * Hp + ho) * Wp + wo) * ldp + c0, m);
     }
   }
 }
@@ -164,7 +168,7 @@ struct BnBwdArgs {
   float* dgamma;
   float* dbeta;
   double inv_count;
-  int N, H, W, C, ldy, ldg0, ldg1, ldgp, lddy;
+  int N, H, W, C, ldy, ldg0, ldg1, ldgp, lddy, pool_ceil;
 };
 
 template <typename T, bool POOL, int PASS>
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
   const int cc = blockIdx.y * blockDim.x + threadIdx.x;  // channel chunk of this thread
   const bool cok = cc < CC;
   const int c0 = (cok ? cc : 0) * VEC;
-  const int Ho = a.H >> 1, Wo = a.W >> 1;
+  const int Ho = (a.H + 1) >> 1, Wo = (a.W + 1) >> 1;   // window grid (ceil): every pixel in exactly one window
+  const int Hp = a.pool_ceil ? Ho : a.H >> 1, Wp = a.pool_ceil ? Wo : a.W >> 1;
   const long long units = POOL ? (long long)a.N * Ho * Wo : (long long)a.N * a.H * a.W;
 
   float sc[VEC], sh[VEC], mu[VEC], is[VEC], k0[VEC], k1[VEC];
@@ -203,19 +208,32 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
   for (long long u = (long long)blockIdx.x * blockDim.y + threadIdx.y; u < units && cok;
        u += (long long)gridDim.x * blockDim.y) {
     size_t p00;
+    bool in[NPIX];
+    size_t gpoff = 0;
+    bool has_pool = false;
     if constexpr (POOL) {
       const int wo = (int)(u % Wo);
       const long long t = u / Wo;
       const int ho = (int)(t % Ho);
       const int img = (int)(t / Ho);
       p00 = ((size_t)img * a.H + 2 * ho) * a.W + 2 * wo;
+#pragma unroll
+      for (int k = 0; k < NPIX; ++k) in[k] = 2 * ho + (k >> 1) < a.H && 2 * wo + (k & 1) < a.W;
+      has_pool = ho < Hp && wo < Wp;
+      gpoff = (((size_t)img * Hp + ho) * Wp + wo) * a.ldgp;
     } else {
       p00 = (size_t)u;
+      in[0] = true;
     }
     float yv[NPIX][VEC], gv[NPIX][VEC];
 #pragma unroll
     for (int k = 0; k < NPIX; ++k) {
       const size_t p = POOL ? p00 + (k >> 1) * a.W + (k & 1) : p00;
+      if (!in[k]) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) yv[k][i] = gv[k][i] = 0.f;
+        continue;
+      }
       load_f(y + p * a.ldy + c0, yv[k]);
       if (g0 != nullptr) {
         load_f(g0 + p * a.ldg0 + c0, gv[k]);
@@ -231,9 +249,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
       }
     }
     if constexpr (POOL) {
-      if (gp != nullptr) {
+      if (gp != nullptr && has_pool) {
         float gpv[VEC];
-        load_f(gp + (size_t)u * a.ldgp + c0, gpv);
+        load_f(gp + gpoff + c0, gpv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           float best = fmaxf(fmaf(yv[0][i], sc[i], sh[i]), 0.f);
@@ -241,7 +259,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
 #pragma unroll
           for (int k = 1; k < 4; ++k) {
             const float v = fmaxf(fmaf(yv[k][i], sc[i], sh[i]), 0.f);
-            if (v > best) {
+            if (in[k] && v > best) {
               best = v;
               bk = k;
             }
@@ -253,6 +271,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < NPIX; ++k) {
+      if (!in[k]) continue;
       float out[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -741,16 +760,16 @@ extern "C" int uz_bn_eval_scale(int C, const float* gamma, const float* beta, co
 template <typename T>
 static int bn_relu_apply_t(const void* y, int ldy, const float* scale, const float* shift, int N, int H,
                            int W, int C, void* act, int lda, void* pooled, int ldp, const void* res, int ldr,
-                           hipStream_t s) {
+                           int pool_ceil, hipStream_t s) {
   constexpr int VEC = ElemTraits<T>::VEC;
   if (pooled != nullptr) {
-    const long long total = (long long)N * (H / 2) * (W / 2) * (C / VEC);
+    const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)pooled, ldp, (const T*)res, ldr);
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)pooled, ldp, (const T*)res, ldr, pool_ceil);
   } else {
     const long long total = (long long)N * H * W * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr);
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, 0);
   }
   UZ_LAUNCH_CHECK("uz_bn_relu_apply");
   return UZ_OK;
@@ -758,17 +777,17 @@ static int bn_relu_apply_t(const void* y, int ldy, const float* scale, const flo
 
 extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
                                     int N, int H, int W, int C, const void* res, int ldr, void* act, int lda,
-                                    void* pooled, int ldp, void* stream);
+                                    void* pooled, int ldp, int pool_ceil, void* stream);
 
 extern "C" int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
                                 int N, int H, int W, int C, void* act, int lda, void* pooled, int ldp,
                                 void* stream) {
-  return uz_bn_relu_add_apply(dtype, y, ldy, scale, shift, N, H, W, C, nullptr, 0, act, lda, pooled, ldp, stream);
+  return uz_bn_relu_add_apply(dtype, y, ldy, scale, shift, N, H, W, C, nullptr, 0, act, lda, pooled, ldp, 0, stream);
 }
 
 extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
                                     int N, int H, int W, int C, const void* res, int ldr, void* act, int lda,
-                                    void* pooled, int ldp, void* stream) {
+                                    void* pooled, int ldp, int pool_ceil, void* stream) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_bn_relu_apply: bad dtype");
   const int vec = dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(y && scale && shift && act, "uz_bn_relu_apply: null pointer");
@@ -776,12 +795,12 @@ extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const flo
   UZ_REQUIRE(ldy % vec == 0 && lda % vec == 0 && ldy >= C && lda >= C, "uz_bn_relu_apply: bad ld");
   if (res != nullptr) UZ_REQUIRE(ldr % vec == 0 && ldr >= C, "uz_bn_relu_apply: bad ldr");
   if (pooled != nullptr) {
-    UZ_REQUIRE(H % 2 == 0 && W % 2 == 0, "uz_bn_relu_apply: fused pool needs even H, W (got %dx%d)", H, W);
+    UZ_REQUIRE(pool_ceil || (H >= 2 && W >= 2), "uz_bn_relu_apply: floor-mode pool of a %dx%d map is empty", H, W);
     UZ_REQUIRE(ldp % vec == 0 && ldp >= C, "uz_bn_relu_apply: bad ldp");
   }
   hipStream_t s = (hipStream_t)stream;
-  return dtype == UZ_BF16 ? bn_relu_apply_t<bf16_t>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, res, ldr, s)
-                          : bn_relu_apply_t<float>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, res, ldr, s);
+  return dtype == UZ_BF16 ? bn_relu_apply_t<bf16_t>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, res, ldr, pool_ceil, s)
+                          : bn_relu_apply_t<float>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, res, ldr, pool_ceil, s);
 }
 
 static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, const void* gp) {
@@ -794,7 +813,6 @@ static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, c
   if (g1) UZ_REQUIRE(d->ldg1 % vec == 0 && d->ldg1 >= d->C, "uz_bn_relu_bwd: bad ldg1");
   if (gp) {
     UZ_REQUIRE(d->ldgp % vec == 0 && d->ldgp >= d->C, "uz_bn_relu_bwd: bad ldgp");
-    UZ_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "uz_bn_relu_bwd: pooled gradient needs even H, W");
   }
   UZ_REQUIRE(g0 || g1 || gp, "uz_bn_relu_bwd: no incoming gradient");
   return UZ_OK;
@@ -802,7 +820,7 @@ static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, c
 
 static void bnbwd_shape(const uz_bnbwd_desc* d, bool pool, dim3* grid, dim3* block, int pass = 1) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
-  const long long units = pool ? (long long)d->N * (d->H / 2) * (d->W / 2) : (long long)d->N * d->H * d->W;
+  const long long units = pool ? (long long)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (long long)d->N * d->H * d->W;
   reduce_shape(d->C / vec, units, grid, block, pass == 2 ? 8 : 2);
 }
 
@@ -847,6 +865,7 @@ static BnBwdArgs bnbwd_args(const uz_bnbwd_desc* d, const void* y, const float* 
   a.ldg0 = d->ldg0;
   a.ldg1 = d->ldg1;
   a.ldgp = d->ldgp;
+  a.pool_ceil = d->pool_ceil;
   a.lddy = d->lddy;
   return a;
 }

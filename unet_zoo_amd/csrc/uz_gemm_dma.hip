@@ -24,7 +24,7 @@ struct GArgs {
   const float* bias;
   float* stats;
   unsigned xbytes, wbytes;
-  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m;
+  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m, Hout, Wout;
 };
 
 template <typename T> struct Mma3;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
       if (a.store == UZ_STORE_PLAIN) return m;
       const int img = m / HW, rem = m - img * HW;
       const int h = rem / a.W, w = rem - h * a.W;
-      return ((long long)img * (2 * a.H) + 2 * h + (ab >> 1)) * (2 * a.W) + 2 * w + (ab & 1);
+      return ((long long)img * a.Hout + 2 * h + (ab >> 1)) * a.Wout + 2 * w + (ab & 1);
     };
     // a whole BN tile belongs to one sub-pixel (Co % BN == 0, checked on the host)
     const int ab = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 / a.Co : 0;
@@ -340,6 +340,8 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x
   a.W = d->W;
   a.Hin = d->Hin;
   a.Win = d->Win;
+  a.Hout = d->Hout ? d->Hout : 2 * d->H;
+  a.Wout = d->Wout ? d->Wout : 2 * d->W;
   a.Cin = d->Cin;
   a.ldx = d->ldx;
   a.Nout = d->Nout;

@@ -24,7 +24,7 @@ struct IgemmArgs {
   void* y;
   const float* bias;
   float* stats;
-  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, dil, store, Co, tiles_m;
+  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, dil, store, Co, tiles_m, Hout, Wout;
   // tap split (small-M problems: 16-128 output tiles cannot fill 256 CUs and each walks a long,
   // latency-bound K loop): blockIdx.z owns taps [z*tpg, (z+1)*tpg) and writes its fp32 partial tile to
   // part[z][M][Nout]; igemm_split_reduce_kernel sums them in fixed order (deterministic)
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
               const int h = rem / a.W;
               const int w = rem - h * a.W;
               const size_t opix =
-                  ((size_t)img * (2 * a.H) + 2 * h + (ab >> 1)) * (size_t)(2 * a.W) + 2 * w + (ab & 1);
+                  ((size_t)img * a.Hout + 2 * h + (ab >> 1)) * (size_t)a.Wout + 2 * w + (ab & 1);
               o = opix * a.ldy + co;
             }
             yg[o] = tv;
@@ -382,10 +382,14 @@ int make_plan(const uz_conv_desc* d, Plan* p) {
   } else {
     UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4,
                "uz_conv_igemm: gather2x2 needs ntaps=4");
-    UZ_REQUIRE(d->Hin == 2 * d->H && d->Win == 2 * d->W, "uz_conv_igemm: gather2x2 needs Hin=2H");
+    UZ_REQUIRE((d->Hin == 2 * d->H || d->Hin == 2 * d->H + 1) && (d->Win == 2 * d->W || d->Win == 2 * d->W + 1),
+               "uz_conv_igemm: gather2x2 needs Hin in {2H, 2H+1}, Win in {2W, 2W+1}");
   }
   if (d->store_mode == UZ_STORE_SHUFFLE2X2) {
     UZ_REQUIRE(d->Co > 0 && d->Nout == 4 * d->Co, "uz_conv_igemm: shuffle store needs Nout=4*Co");
+    UZ_REQUIRE((d->Hout == 0 || d->Hout == 2 * d->H || d->Hout == 2 * d->H + 1) &&
+                   (d->Wout == 0 || d->Wout == 2 * d->W || d->Wout == 2 * d->W + 1),
+               "uz_conv_igemm: shuffle store destination must be 2H..2H+1 x 2W..2W+1");
     UZ_REQUIRE(d->ldy >= d->Co, "uz_conv_igemm: bad ldy");
   } else {
     UZ_REQUIRE(d->store_mode == UZ_STORE_PLAIN, "uz_conv_igemm: bad store_mode");
@@ -520,6 +524,8 @@ extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void
   a.dil = d->dil;
   a.store = d->store_mode;
   a.Co = d->Co;
+  a.Hout = d->Hout ? d->Hout : 2 * d->H;
+  a.Wout = d->Wout ? d->Wout : 2 * d->W;
   a.tiles_m = p.tiles_m;
   a.part = (p.split > 1 && workspace != nullptr) ? static_cast<float*>(workspace) : nullptr;
   a.tpg = (d->ntaps + p.split - 1) / p.split;

@@ -192,10 +192,11 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(int N, int H, int W, 
                                                            int lda, const T* __restrict__ g0, int ld0,
                                                            const T* __restrict__ g1, int ld1,
                                                            const T* __restrict__ gp, int ldp,
-                                                           T* __restrict__ out, int ldo) {
+                                                           T* __restrict__ out, int ldo, int pool_ceil) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CC = C / VEC;
-  const int Ho = H >> 1, Wo = W >> 1;
+  const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;   // window grid (ceil): every pixel in exactly one window
+  const int Hp = pool_ceil ? Ho : H >> 1, Wp = pool_ceil ? Wo : W >> 1;
   const long long total = POOL ? (long long)N * Ho * Wo * CC : (long long)N * H * W * CC;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -218,22 +219,33 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(int N, int H, int W, 
       const size_t p00 = ((size_t)img * H + 2 * ho) * W + 2 * wo;
       float av[4][VEC], gv[VEC];
       int best[VEC];
-      load_f(gp + (size_t)u * ldp + c0, gv);
+      bool in[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) load_f(act + (p00 + (k >> 1) * W + (k & 1)) * lda + c0, av[k]);
+      for (int k = 0; k < 4; ++k) in[k] = 2 * ho + (k >> 1) < H && 2 * wo + (k & 1) < W;
+      const bool has_pool = ho < Hp && wo < Wp;
+      if (has_pool) {
+        load_f(gp + (((size_t)img * Hp + ho) * Wp + wo) * ldp + c0, gv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gv[i] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (in[k]) load_f(act + (p00 + (k >> 1) * W + (k & 1)) * lda + c0, av[k]);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         best[i] = 0;
         float m = av[0][i];
 #pragma unroll
         for (int k = 1; k < 4; ++k)
-          if (av[k][i] > m) {
+          if (in[k] && av[k][i] > m) {
             m = av[k][i];
             best[i] = k;
           }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        if (!in[k]) continue;
         const size_t p = p00 + (k >> 1) * W + (k & 1);
         float s[VEC], v[VEC];
 #pragma unroll
@@ -591,7 +603,7 @@ extern "C" int uz_bilinear_bwd(int dtype, const void* g, int ldg, long long g_im
 
 extern "C" int uz_pool_grad_combine(int dtype, int N, int H, int W, int C, const void* act, int lda, const void* g0,
                                     int ldg0, const void* g1, int ldg1, const void* gp, int ldgp, void* out,
-                                    int ldo, void* stream) {
+                                    int ldo, int pool_ceil, void* stream) {
   UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_pool_grad_combine: bad dtype");
   const int vec = dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "uz_pool_grad_combine: bad shape");
@@ -601,17 +613,16 @@ extern "C" int uz_pool_grad_combine(int dtype, int N, int H, int W, int C, const
   if (g1) UZ_REQUIRE(ldg1 % vec == 0 && ldg1 >= C, "uz_pool_grad_combine: bad ldg1");
   if (gp) {
     UZ_REQUIRE(act && lda % vec == 0 && lda >= C && ldgp % vec == 0 && ldgp >= C, "uz_pool_grad_combine: bad act/gp");
-    UZ_REQUIRE(H % 2 == 0 && W % 2 == 0, "uz_pool_grad_combine: pooled gradient needs even H, W");
   }
   hipStream_t s = (hipStream_t)stream;
-  const long long total = gp ? (long long)N * (H / 2) * (W / 2) * (C / vec) : (long long)N * H * W * (C / vec);
+  const long long total = gp ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / vec) : (long long)N * H * W * (C / vec);
   const dim3 grid(grid_cap(total, 256)), block(256);
   if (dtype == UZ_BF16) {
-    if (gp) hipLaunchKernelGGL((grad_combine_kernel<bf16_t, true>), grid, block, 0, s, N, H, W, C, (const bf16_t*)act, lda, (const bf16_t*)g0, ldg0, (const bf16_t*)g1, ldg1, (const bf16_t*)gp, ldgp, (bf16_t*)out, ldo);
-    else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, false>), grid, block, 0, s, N, H, W, C, (const bf16_t*)act, lda, (const bf16_t*)g0, ldg0, (const bf16_t*)g1, ldg1, (const bf16_t*)gp, ldgp, (bf16_t*)out, ldo);
+    if (gp) hipLaunchKernelGGL((grad_combine_kernel<bf16_t, true>), grid, block, 0, s, N, H, W, C, (const bf16_t*)act, lda, (const bf16_t*)g0, ldg0, (const bf16_t*)g1, ldg1, (const bf16_t*)gp, ldgp, (bf16_t*)out, ldo, pool_ceil);
+    else hipLaunchKernelGGL((grad_combine_kernel<bf16_t, false>), grid, block, 0, s, N, H, W, C, (const bf16_t*)act, lda, (const bf16_t*)g0, ldg0, (const bf16_t*)g1, ldg1, (const bf16_t*)gp, ldgp, (bf16_t*)out, ldo, pool_ceil);
   } else {
-    if (gp) hipLaunchKernelGGL((grad_combine_kernel<float, true>), grid, block, 0, s, N, H, W, C, (const float*)act, lda, (const float*)g0, ldg0, (const float*)g1, ldg1, (const float*)gp, ldgp, (float*)out, ldo);
-    else hipLaunchKernelGGL((grad_combine_kernel<float, false>), grid, block, 0, s, N, H, W, C, (const float*)act, lda, (const float*)g0, ldg0, (const float*)g1, ldg1, (const float*)gp, ldgp, (float*)out, ldo);
+    if (gp) hipLaunchKernelGGL((grad_combine_kernel<float, true>), grid, block, 0, s, N, H, W, C, (const float*)act, lda, (const float*)g0, ldg0, (const float*)g1, ldg1, (const float*)gp, ldgp, (float*)out, ldo, pool_ceil);
+    else hipLaunchKernelGGL((grad_combine_kernel<float, false>), grid, block, 0, s, N, H, W, C, (const float*)act, lda, (const float*)g0, ldg0, (const float*)g1, ldg1, (const float*)gp, ldgp, (float*)out, ldo, pool_ceil);
   }
   UZ_LAUNCH_CHECK("uz_pool_grad_combine");
   return UZ_OK;

@@ -278,9 +278,9 @@ int make_plan(const uz_wgrad_desc* d, Plan* p) {
     UZ_REQUIRE(d->ntaps == 9 && d->dil == 1 && d->Hr * 2 == d->H && d->Wr * 2 == d->W,
                "uz_wgrad: upsampled R needs ntaps=9, dil=1, Hr=H/2, Wr=W/2");
   } else {
-    UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && d->Hr == 2 * d->H &&
-                   d->Wr == 2 * d->W,
-               "uz_wgrad: gather2x2 needs ntaps=4, Hr=2H, Wr=2W");
+    UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && (d->Hr == 2 * d->H || d->Hr == 2 * d->H + 1) &&
+                   (d->Wr == 2 * d->W || d->Wr == 2 * d->W + 1),
+               "uz_wgrad: gather2x2 needs ntaps=4, Hr in {2H, 2H+1}, Wr in {2W, 2W+1}");
   }
   const long long P = (long long)d->N * d->H * d->W;
   UZ_REQUIRE(P < (1LL << 31) && (long long)d->N * d->Hr * d->Wr < (1LL << 31), "uz_wgrad: too large");

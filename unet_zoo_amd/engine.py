@@ -202,7 +202,7 @@ class Engine:
 
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
                      pool: bool = False, im2col: bool = False, upsample: bool = False,
-                     residual: Optional[Act] = None) -> Tuple[Act, Optional[Act]]:
+                     residual: Optional[Act] = None, pool_ceil: bool = False) -> Tuple[Act, Optional[Act]]:
         """[nearest x2 upsample ->] Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
 
         Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
@@ -237,8 +237,11 @@ class Engine:
             vec = ops.bn_eval_scale(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                     bn.running_var, bn.eps)
         act = out if out is not None else self.new_act(N, H, W, Cout)
-        pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
-        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual)
+        if pool and pool_ceil:
+            pooled = self.new_act(N, (H + 1) // 2, (W + 1) // 2, Cout)
+        else:
+            pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
+        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil)
 
         if self.record:
             if not self.training:
@@ -260,7 +263,7 @@ class Engine:
                     # argmax is over act (= relu + residual), not over relu(bn(y))
                     if gp is not None or g1 is not None:
                         tot = self.new_act(N, H, W, Cout)
-                        ops.pool_grad_combine(act, g0, g1, gp, tot)
+                        ops.pool_grad_combine(act, g0, g1, gp, tot, pool_ceil)
                         g0, g1, gp = tot, None, None
                     if residual.needs_grad:
                         residual.add_grad(g0)
@@ -270,7 +273,7 @@ class Engine:
                     dgamma = torch.empty(Cout, dtype=torch.float32, device=self.device)
                 if dbeta is None:
                     dbeta = torch.empty(Cout, dtype=torch.float32, device=self.device)
-                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta)
+                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:
@@ -392,7 +395,13 @@ class Engine:
         Reference: UpSample_UNet.up (common_layers.py:104,108)."""
         assert m.kernel_size == (2, 2) and m.stride == (2, 2) and m.in_channels == x.C
         Co = m.out_channels
-        assert out.C == Co and out.H == 2 * x.H and out.W == 2 * x.W
+        # an odd skip size leaves one row / column that the reference fills with F.pad zeros
+        # (common_layers.py:110-113: pad = [0, dx, 0, dy] for dx, dy in {0, 1}); the result sits top-left
+        assert out.C == Co and out.H - 2 * x.H in (0, 1) and out.W - 2 * x.W in (0, 1)
+        if (out.H, out.W) != (2 * x.H, 2 * x.W):
+            v = out.buf.view(out.N, out.H, out.W, out.ld)[..., out.off:out.off + Co]
+            v[:, 2 * x.H:, :, :] = 0
+            v[:, :, 2 * x.W:, :] = 0
         wp = self._pack(m.weight, L.PACK_CONVT_FWD)
         bias4 = m.bias.detach().repeat(4) if m.bias is not None else None
         ops.conv_igemm(x, wp, bias4, out, ntaps=1, store_mode=L.STORE_SHUFFLE2X2, nout=4 * Co, co=Co)

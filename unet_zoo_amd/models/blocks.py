@@ -59,10 +59,8 @@ class UpSample_UNet(nn.Module):
         self.conv = DoubleConv(in_channels, out_channels)
 
     def emit(self, eng: Engine, x: Act, cat_full: Act, up_slot: Act) -> Act:
-        if (up_slot.H, up_slot.W) != (2 * x.H, 2 * x.W):
-            # the reference zero-pads odd sizes (common_layers.py:110-113); every H, W that is a
-            # multiple of 16 (the UNet contract) never takes that branch
-            raise NotImplementedError("skip/up size mismatch: H and W must be divisible by 16")
+        # odd skip sizes: the transposed convolution lands top-left, the remaining row / column is the
+        # reference's F.pad zeros (common_layers.py:110-113); handled inside conv_transpose2x2
         eng.conv_transpose2x2(x, self.up, up_slot)
         act, _ = self.conv.emit(eng, cat_full)
         return act

@@ -12,8 +12,8 @@ initialisation interchange.  The modules only own parameters; ``emit`` lowers th
 * the six side heads, their resize to full resolution and the 1x1 fuse conv run on NCHW fp32 logit
   planes (``Engine.u2net_heads``).
 
-``MaxPool2d(2, 2, ceil_mode=True)`` equals floor mode on even sizes; an odd size anywhere in the
-pyramid (H or W not divisible by 32) raises instead of silently changing the arithmetic.
+``MaxPool2d(2, 2, ceil_mode=True)`` (u2net.py:30, 221-229): the fused pool writes ceil(H/2) x ceil(W/2)
+with border windows clipped, so any input size works as in the reference.
 """
 from __future__ import annotations
 
@@ -44,11 +44,8 @@ def _pool() -> nn.MaxPool2d:
     return nn.MaxPool2d(2, stride=2, ceil_mode=True)
 
 
-def _even(a: Act, what: str) -> None:
-    if a.H % 2 or a.W % 2:
-        raise NotImplementedError(
-            f"U2Net {what}: {a.H}x{a.W} is odd; ceil-mode pooling of odd sizes is not implemented "
-            "(use H and W divisible by 32)")
+def _half(n: int) -> int:
+    return (n + 1) // 2   # output size of MaxPool2d(2, stride=2, ceil_mode=True)
 
 
 class _RSU(nn.Module):
@@ -81,15 +78,15 @@ class _RSU(nn.Module):
         # concat buffer the decoder convolution `rebnconv{i}d` reads
         cats: List[Tuple[Act, Act]] = []
         cur = hxin
+        h, w = hxin.H, hxin.W
         for i in range(1, L):
-            h, w = hxin.H >> (i - 1), hxin.W >> (i - 1)
             full, (up_slot, skip_slot) = eng.new_cat(N, h, w, (mid, mid))
             cats.append((full, up_slot))
             last = i == L - 1
-            if not last:
-                _even(cur, "RSU pool")
-            skip, pooled = getattr(self, f"rebnconv{i}").emit(eng, cur, out=skip_slot, pool=not last)
+            skip, pooled = getattr(self, f"rebnconv{i}").emit(eng, cur, out=skip_slot, pool=not last, pool_ceil=True)
             cur = skip if last else pooled
+            if not last:
+                h, w = _half(h), _half(w)
         # bottom: dilation 2 at the coarsest resolution, straight into the left half
         full, up_slot = cats[L - 2]
         getattr(self, f"rebnconv{L}").emit(eng, cur, out=up_slot)
@@ -100,7 +97,7 @@ class _RSU(nn.Module):
                 tmp, _ = getattr(self, f"rebnconv{i}d").emit(eng, full)
                 eng.resize_bilinear(tmp, cats[i - 2][1])
             else:
-                return self.rebnconv1d.emit(eng, full, out=out, pool=pool, residual=hxin)
+                return self.rebnconv1d.emit(eng, full, out=out, pool=pool, residual=hxin, pool_ceil=True)
         raise AssertionError("unreachable")
 
 
@@ -149,7 +146,7 @@ class RSU4F(nn.Module):
         self.rebnconv4.emit(eng, hx3, out=h4_slot)
         self.rebnconv3d.emit(eng, c3, out=d3_slot)
         self.rebnconv2d.emit(eng, c2, out=d2_slot)
-        return self.rebnconv1d.emit(eng, c1, out=out, pool=pool, residual=hxin)
+        return self.rebnconv1d.emit(eng, c1, out=out, pool=pool, residual=hxin, pool_ceil=True)
 
 
 class _U2NetBase(HipModule):
@@ -177,21 +174,20 @@ class _U2NetBase(HipModule):
 
     def emit(self, eng: Engine, x: torch.Tensor):
         N, _, H, W = x.shape
-        if H % 32 or W % 32:
-            raise NotImplementedError(f"U2Net on the HIP engine needs H and W divisible by 32, got {H}x{W}")
         enc_out = [c[2] for c in self.enc_cfg]
         # decoder stage `lvl`d reads cat((upsampled deeper map, encoder map lvl), 1)
         cats: Dict[int, Tuple[Act, Act]] = {}
         cur = eng.input_im2col(x)
         deepest: Optional[Act] = None
+        h, w = H, W
         for i in range(1, 7):
-            h, w = H >> (i - 1), W >> (i - 1)
             stage = getattr(self, f"stage{i}")
             if i < 6:
                 up_c = enc_out[5] if i == 5 else self.dec_cfg[4 - i][3]   # channels of the map resized into this level
                 full, (up_slot, skip_slot) = eng.new_cat(N, h, w, (up_c, enc_out[i - 1]))
                 cats[i] = (full, up_slot)
                 _, cur = stage.emit(eng, cur, out=skip_slot, pool=True, im2col=(i == 1))
+                h, w = _half(h), _half(w)
             else:
                 deepest, _ = stage.emit(eng, cur)
         dec: Dict[int, Act] = {6: deepest}

@@ -34,8 +34,8 @@ class UNet(HipModule):
 
     def emit(self, eng: Engine, x: torch.Tensor):
         N, _, H, W = x.shape
-        if H % 16 or W % 16:
-            raise ValueError(f"UNet needs H and W divisible by 16, got {H}x{W}")
+        if H < 16 or W < 16:
+            raise ValueError(f"UNet needs H, W >= 16 (four 2x2 poolings), got {H}x{W}")
         downs = (self.down_convolution_1, self.down_convolution_2, self.down_convolution_3,
                  self.down_convolution_4)
         ups = (self.up_convolution_4, self.up_convolution_3, self.up_convolution_2,

@@ -192,8 +192,10 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         N, H, W = x.N, 2 * x.H, 2 * x.W
     else:
         N, H, W = x.N, x.H // 2, x.W // 2
+    shuffle = store_mode == L.STORE_SHUFFLE2X2   # destination grid may be one row / column larger (zero pad)
     d = L.ConvDesc(L.dtype_code(x.dtype), N, H, W, x.H, x.W, x.C, x.ld,
-                   nout if nout is not None else y.C, y.ld, ntaps, taps_mode, dil, store_mode, co)
+                   nout if nout is not None else y.C, y.ld, ntaps, taps_mode, dil, store_mode, co,
+                   y.H if shuffle else 0, y.W if shuffle else 0)
     assert w_packed.dtype == x.dtype and y.dtype == x.dtype
     assert w_packed.shape == (d.Nout, ntaps * x.C), (tuple(w_packed.shape), d.Nout, ntaps, x.C)
     stats = None
@@ -277,8 +279,11 @@ def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
 
 
 def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
-                  pooled: Optional[Act] = None, res: Optional[Act] = None) -> None:
-    """act = relu(scale*y + shift) [+ res]; pooled = maxpool2x2(act)"""
+                  pooled: Optional[Act] = None, res: Optional[Act] = None, pool_ceil: bool = False) -> None:
+    """act = relu(scale*y + shift) [+ res]; pooled = maxpool2x2(act) (floor or ceil output size)"""
+    if pooled is not None:
+        want = ((y.H + 1) // 2, (y.W + 1) // 2) if pool_ceil else (y.H // 2, y.W // 2)
+        assert (pooled.H, pooled.W) == want, (pooled.H, pooled.W, want)
     lib = L.load()
     es = y.buf.element_size()
     with _Timed("bn_relu_apply", 0.0, es * y.P * y.C * ((2.25 if pooled is not None else 2.0) + (res is not None))):
@@ -287,18 +292,18 @@ def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
                                          res.ptr() if res is not None else None,
                                          res.ld if res is not None else 0, act.ptr(), act.ld,
                                          pooled.ptr() if pooled is not None else None,
-                                         pooled.ld if pooled is not None else 0, L.stream_ptr()),
+                                         pooled.ld if pooled is not None else 0, int(pool_ceil), L.stream_ptr()),
                 "uz_bn_relu_add_apply")
 
 
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
-                dbeta: torch.Tensor) -> None:
+                dbeta: torch.Tensor, pool_ceil: bool = False) -> None:
     """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch."""
     lib = L.load()
     d = L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
                     g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
-                    gpool.ld if gpool is not None else 0, dy.ld)
+                    gpool.ld if gpool is not None else 0, dy.ld, int(pool_ceil))
     args = (y.ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
             g0.ptr() if g0 is not None else None, g1.ptr() if g1 is not None else None,
             gpool.ptr() if gpool is not None else None)
@@ -463,7 +468,8 @@ def bilinear_planes(src_ptr: int, src_img: int, hi: int, wi: int, dst_ptr: int, 
                 "uz_bilinear(planes)")
 
 
-def pool_grad_combine(act: Act, g0: Optional[Act], g1: Optional[Act], gp: Optional[Act], out: Act) -> None:
+def pool_grad_combine(act: Act, g0: Optional[Act], g1: Optional[Act], gp: Optional[Act], out: Act,
+                      pool_ceil: bool = False) -> None:
     if g0 is None:
         g0, g1 = g1, None
     es = act.buf.element_size()
@@ -474,7 +480,7 @@ def pool_grad_combine(act: Act, g0: Optional[Act], g1: Optional[Act], gp: Option
             g0.ptr() if g0 is not None else None, g0.ld if g0 is not None else 0,
             g1.ptr() if g1 is not None else None, g1.ld if g1 is not None else 0,
             gp.ptr() if gp is not None else None, gp.ld if gp is not None else 0,
-            out.ptr(), out.ld, L.stream_ptr()), "uz_pool_grad_combine")
+            out.ptr(), out.ld, int(pool_ceil), L.stream_ptr()), "uz_pool_grad_combine")
 
 
 def sideconv_fwd(x: Act, w_ptr: int, b_ptr: Optional[int], taps_ws: torch.Tensor, out_ptr: int, out_img: int) -> None:
