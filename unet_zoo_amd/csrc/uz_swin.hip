@@ -281,14 +281,37 @@ __device__ __forceinline__ void lds_row(const float* row, float* f) {  // 32 flo
 }
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32, 1 ulp
 
+// 32-wide fp32 vector helpers written on float pairs so that they compile to v_pk_fma_f32 / v_pk_mul_f32
+// (two fp32 operations per lane and instruction): the attention kernels are VALU-bound
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot32(const float* a, const float* b) {
-  float u0 = 0.f, u1 = 0.f;  // two chains: pairs map onto v_pk_fma_f32
+  f32x2 acc = {0.f, 0.f};
 #pragma unroll
   for (int e = 0; e < AD; e += 2) {
-    u0 = fmaf(a[e], b[e], u0);
-    u1 = fmaf(a[e + 1], b[e + 1], u1);
+    const f32x2 x = {a[e], a[e + 1]}, y = {b[e], b[e + 1]};
+    acc = __builtin_elementwise_fma(x, y, acc);
   }
-  return u0 + u1;
+  return acc.x + acc.y;
+}
+__device__ __forceinline__ void axpy32(float w, const float* x, float* y) {  // y += w * x
+  const f32x2 ws = {w, w};
+#pragma unroll
+  for (int e = 0; e < AD; e += 2) {
+    const f32x2 xv = {x[e], x[e + 1]}, yv = {y[e], y[e + 1]};
+    const f32x2 r = __builtin_elementwise_fma(ws, xv, yv);
+    y[e] = r.x;
+    y[e + 1] = r.y;
+  }
+}
+__device__ __forceinline__ void scale_axpy32(float c, float w, const float* x, float* y) {  // y = c * y + w * x
+  const f32x2 cs = {c, c}, ws = {w, w};
+#pragma unroll
+  for (int e = 0; e < AD; e += 2) {
+    const f32x2 xv = {x[e], x[e + 1]}, yv = {y[e], y[e + 1]};
+    const f32x2 r = __builtin_elementwise_fma(ws, xv, cs * yv);
+    y[e] = r.x;
+    y[e + 1] = r.y;
+  }
 }
 
 struct WinTok {
@@ -403,8 +426,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const AttnArgs a) {
             const float corr = __expf(m - mn), p = __expf(s - mn);
             l = l * corr + p;
             lds_row(sV + j * ARS, row);
-#pragma unroll
-            for (int e = 0; e < AD; ++e) o[e] = fmaf(p, row[e], o[e] * corr);
+            scale_axpy32(corr, p, row, o);
             m = mn;
           }
         }
@@ -708,8 +730,7 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
           const float dc = ds * ti;
           sDC[i * ANS + j] = dc;
           const float w1 = dc * rden;
-#pragma unroll
-          for (int e = 0; e < AD; ++e) av[e] = fmaf(w1, krow[e], av[e]);
+          axpy32(w1, krow, av);
           if (!clamped) bs += dc * u * sKn[j] * rden * rden * rqn;  // d(den)/d(qs_i) = kn_j * qs_i / n_i
         }
       }
@@ -759,15 +780,13 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
         lds_row(sK + r * ARS, qrow);
         lds_row(sV + r * ARS, grow);
         const float u = dot32(qrow, kk);
-#pragma unroll
-        for (int e = 0; e < AD; ++e) dv[e] = fmaf(p, grow[e], dv[e]);
+        axpy32(p, grow, dv);
         const float nn = sQn[r] * kn;
         const bool clamped = nn <= 1e-6f;
         const float den = clamped ? 1e-6f : nn;
         const float rden = rcp(den);
         const float w1 = dc * rden;
-#pragma unroll
-        for (int e = 0; e < AD; ++e) dk[e] = fmaf(w1, qrow[e], dk[e]);
+        axpy32(w1, qrow, dk);
         if (!clamped) bsk += dc * u * sQn[r] * rden * rden * rkn;
       }
     }
