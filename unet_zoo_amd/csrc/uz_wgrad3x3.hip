@@ -308,6 +308,14 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   const long long rbytes = ((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2;
   if (lbytes >= (1LL << 31) || rbytes >= (1LL << 31)) return 0;
   p->big = (d->Ci % 128 == 0 && d->Cj % 128 == 0) ? 1 : 0;
+  if (p->one_tap && !p->big) {
+    // one-tap problems (nn.Linear weight gradients: 288 x 96, 96 x 96 ...) are bound by re-reading the
+    // operands, once per tile of the OTHER operand: take the 128 x 128 tile (channel tails are zero-filled)
+    // whenever that lowers Ci * tiles_j + Cj * tiles_i
+    const long long t64 = (long long)d->Ci * ((d->Cj + 63) / 64) + (long long)d->Cj * ((d->Ci + 63) / 64);
+    const long long t128 = (long long)d->Ci * ((d->Cj + 127) / 128) + (long long)d->Cj * ((d->Ci + 127) / 128);
+    if (t128 < t64) p->big = 1;
+  }
   const int b = p->big ? 128 : 64;
   p->tiles_i = (d->Ci + b - 1) / b;
   p->tiles_j = (d->Cj + b - 1) / b;

@@ -247,6 +247,10 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
             and Lt.C % 8 == 0 and Rt.C % 8 == 0 and (W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0))
             and Lt.H % (64 // min(W_, 64)) == 0):   # mirrors uz_wgrad3x3_plan()
         big = Lt.C % 128 == 0 and Rt.C % 128 == 0
+        if ntaps == 1 and not big:   # mirrors uz_wgrad3x3_plan(): fewer operand re-reads with the larger tile
+            t64 = Lt.C * ((Rt.C + 63) // 64) + Rt.C * ((Lt.C + 63) // 64)
+            t128 = Lt.C * ((Rt.C + 127) // 128) + Rt.C * ((Lt.C + 127) // 128)
+            big = t128 < t64
         kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + ("_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
     with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
