@@ -29,9 +29,11 @@ struct GArgs {
 
 template <typename T> struct Mma3;
 template <> struct Mma3<bf16_t> {
+  // bf16 tiles are accumulated transposed (weights as the row operand, as in uz_conv3x3.hip): a lane owns 4
+  // consecutive output channels of one pixel per register quad -> 8-byte LDS staging writes
   static __device__ __forceinline__ void run(const Vec16<bf16_t>& a, const Vec16<bf16_t>& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
-                                                *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&b),
+                                                *reinterpret_cast<const bf16x8*>(&a), c, 0, 0, 0);
   }
 };
 template <> struct Mma3<float> {
@@ -103,27 +105,24 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
   float s1[TN], s2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
-
-  for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
-    const int m0 = tile * 256;
-    // this lane's four A rows: pixel offset (in pixels) of tap 0, or -1 when past the end
-    int a_pix[NAP], a_coff[NAP];
+  // bf16 path: bias of accumulator register r of N tile j (channel wn*WTN + 32 j + (r&3) + 8(r>>2) + 4 lh) and
+  // the statistics of this thread's fixed 16-byte channel chunk in the coalesced read-back
+  float bq[TN][16], sq1[VEC], sq2[VEC];
+  if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int i = 0; i < NAP; ++i) {
-      const int row = (wave + 8 * i) * 8 + (lane >> 3);
-      const int m = m0 + row;
-      a_coff[i] = (((lane & 7) ^ ((row >> 1) & 7)) * VEC) * ES;
-      if (m >= a.M) {
-        a_pix[i] = -1;
-      } else if (a.mode == UZ_TAPS_CONV) {
-        a_pix[i] = m;
-      } else {
-        const int img = m / HW, rem = m - img * HW;
-        const int h = rem / a.W, w = rem - h * a.W;
-        a_pix[i] = (img * a.Hin + 2 * h) * a.Win + 2 * w;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * WTN + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bq[j][r] = (a.bias != nullptr && n < a.Nout) ? a.bias[n] : 0.f;
       }
-    }
-    auto issue = [&](int stage, int s) {
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sq1[e] = sq2[e] = 0.f;
+
+  // stage loads of tile `m0t` (pixel offsets recomputed per call: a few VALU ops, no per-tile register arrays,
+  // so the NEXT tile's first stages can be issued from the current tile's epilogue)
+  auto issue = [&](int m0t, int stage, int s) {
       const int tap = s / ncb, cb = s - tap * ncb;
       const int dpix = (a.mode == UZ_TAPS_CONV) ? 0 : (tap >> 1) * a.Win + (tap & 1);
       const int slab = cb * BK * ES;            // byte offset of the slab inside the tap's channels
@@ -131,8 +130,21 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
       char* sBt = sA + A_BYTES;
 #pragma unroll
       for (int i = 0; i < NAP; ++i) {
-        const bool ok = a_pix[i] >= 0 && slab + a_coff[i] < cin_bytes;
-        const unsigned off = ok ? (unsigned)(a_pix[i] + dpix) * (unsigned)(a.ldx * ES) + slab + a_coff[i] : OOB;
+        const int row = (wave + 8 * i) * 8 + (lane >> 3);
+        const int m = m0t + row;
+        const int a_coff = (((lane & 7) ^ ((row >> 1) & 7)) * VEC) * ES;
+        int a_pix = -1;
+        if (m < a.M) {
+          if (a.mode == UZ_TAPS_CONV) {
+            a_pix = m;
+          } else {
+            const int img = m / HW, rem = m - img * HW;
+            const int h = rem / a.W, w = rem - h * a.W;
+            a_pix = (img * a.Hin + 2 * h) * a.Win + 2 * w;
+          }
+        }
+        const bool ok = a_pix >= 0 && slab + a_coff < cin_bytes;
+        const unsigned off = ok ? (unsigned)(a_pix + dpix) * (unsigned)(a.ldx * ES) + slab + a_coff : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr_t)(sA + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
       }
 #pragma unroll
@@ -141,7 +153,15 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
         const unsigned off = ok ? b_row_off[i] + (unsigned)(tap * cin_bytes) + slab + b_coff[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr_t)(sBt + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
       }
-    };
+  };
+
+  // C staging sits at the END of the ring, so stage 0 (BN = 64: stages 0 and 1) stays free during an epilogue
+  constexpr int RSCB = BN * 2 + 16;                      // bf16 staging row stride
+  constexpr int SC_OFF = 3 * STAGE - 256 * RSCB;
+  constexpr int PRE = (SC_OFF >= 2 * STAGE) ? 2 : ((SC_OFF >= STAGE) ? 1 : 0);   // stages that may be prefetched
+  int pre = 0;   // stages of the current tile already issued by the previous tile's epilogue
+  for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+    const int m0 = tile * 256;
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -152,8 +172,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     __builtin_amdgcn_s_barrier();  // previous tile's staging reads are finished everywhere
-    issue(0, 0);
-    if (nsteps > 1) issue(1, 1);
+    if (pre < 1) issue(m0, 0, 0);
+    if (nsteps > 1 && pre < 2) issue(m0, 1, 1);
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
       if (s + 1 < nsteps) {
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
         wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
-      if (s + 2 < nsteps) issue((s + 2) % 3, s + 2);
+      if (s + 2 < nsteps) issue(m0, (s + 2) % 3, s + 2);
       const char* sA = smem + (s % 3) * STAGE;
       const char* sBt = sA + A_BYTES;
 #pragma unroll
@@ -195,38 +215,53 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
     // a whole BN tile belongs to one sub-pixel (Co % BN == 0, checked on the host)
     const int ab = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 / a.Co : 0;
     const int co0 = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 - ab * a.Co : n0;
+    pre = 0;
     if constexpr (sizeof(T) == 2) {
-      constexpr int RSC = BN * ES + 16;
+      constexpr int RSC = RSCB;
       static_assert(256 * RSC <= 3 * STAGE, "C staging must fit the ring");
-      __builtin_amdgcn_s_barrier();
-      char* sC = smem;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = wn * WTN + j * 32 + l31;
-          const bool nok = n0 + col < a.Nout;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const T tv = (T)(acc[i][j][r] + bv[j]);
-            *reinterpret_cast<T*>(sC + ml * RSC + col * ES) = tv;
-            if (nok && m0 + ml < a.M) {
-              const float fv = (float)tv;
-              s1[j] += fv;
-              s2[j] += fv * fv;
-            }
+      __builtin_amdgcn_s_barrier();   // every wave has finished reading this tile's A / B stages
+      {   // the next tile's first stage(s) stream in while this tile is staged and stored
+        const int next = tile + gridDim.x;
+        if (next < a.tiles_m && PRE > 0) {
+          issue(next * 256, 0, 0);
+          pre = 1;
+          if (PRE > 1 && nsteps > 1) {
+            issue(next * 256, 1, 1);
+            pre = 2;
           }
         }
       }
+      char* sC = smem + SC_OFF;
+      // accumulator column = pixel (l31) of M tile (wm, i); register quad q = 4 consecutive channels
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        char* rowp = sC + (wm * 64 + i * 32 + l31) * RSC;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[i][j][4 * q + e] + bq[j][4 * q + e]);
+            *reinterpret_cast<bf16x4*>(rowp + (wn * WTN + j * 32 + 8 * q + 4 * lh) * ES) = pk;
+          }
+      }
       __builtin_amdgcn_s_barrier();
       constexpr int CPR = BN * ES / 16;
-      for (int id = tid; id < 256 * CPR; id += 512) {
-        const int ml = id / CPR, cc = id - ml * CPR;
+      static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
+      const int cc = tid % CPR;
+      const bool cok = n0 + cc * VEC < a.Nout;
+      for (int ml = tid / CPR; ml < 256; ml += 512 / CPR) {
         const long long orow = out_row(ml, ab);
-        if (orow >= 0 && n0 + cc * VEC < a.Nout) {
+        if (orow >= 0 && cok) {
           const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(sC + ml * RSC + cc * 16);
           st16(yg + (size_t)orow * a.ldy + co0 + cc * VEC, v);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float fv = (float)v.v[e];
+            sq1[e] += fv;
+            sq2[e] += fv * fv;
+          }
         }
       }
     } else {
@@ -252,6 +287,28 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
     }
   }
 
+  if constexpr (sizeof(T) == 2) {
+    if (a.stats != nullptr) {
+      constexpr int CPR = BN * ES / 16;
+      wait_vmcnt<0>();
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);  // [512][2 * VEC]
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        red[tid * 2 * VEC + e] = sq1[e];
+        red[tid * 2 * VEC + VEC + e] = sq2[e];
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {  // (which, channel): sum the 512 / CPR threads that own this channel's chunk
+        const int which = tid / BN, ch = tid - which * BN;
+        const int cc = ch / VEC, e = ch - cc * VEC;
+        float t = 0.f;
+        for (int k = cc; k < 512; k += CPR) t += red[k * 2 * VEC + which * VEC + e];
+        if (n0 + ch < a.Nout) a.stats[((size_t)blockIdx.x * 2 + which) * a.Nout + n0 + ch] = t;
+      }
+    }
+    return;
+  }
   if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
