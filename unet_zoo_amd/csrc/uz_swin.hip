@@ -636,6 +636,283 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma_kernel(const AttnArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 backward on the matrix cores.
+// Pass 1 (accumulator column = query i, rows = keys): U^T = K Q^T and dP^T = V dO^T by MFMA, then per
+// element P, dS, d(bias) / d(tau) sums (registers, kept over the wave's windows) and W1 = dS/(tau den);
+// dQ^T = K^T W1^T with the bf16-packed W1 registers as the B fragment.  Pass 2 (column = key j, rows =
+// queries): U = Q K^T, dP = dO V^T, the same element math, dV^T = dO^T P and dK^T = Q^T W1.  The
+// transposed operands (K^T, dO^T, Q^T: [32 d][64 tokens]) are per-wave LDS tiles.
+// (A first version with one wave per (window, head) needed 128 running-sum registers per lane, spilled and
+// was slower than the VALU kernel; see the block decomposition inside the kernel.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 pack8(const float* f) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)f[e];
+  return v;
+}
+// A fragment of a transposed tile XT[d][token]: row d = l31, the 8 K-slots = tokens 32 t + 16 s + 4 lh + {0..3}, + 8
+__device__ __forceinline__ bf16x8 tfrag(const bf16_t* xt, int l31, int lh, int t, int s2) {
+  const bf16_t* p = xt + l31 * VTS + 32 * t + 16 * s2 + 4 * lh;
+  const bf16x4 lo4 = *reinterpret_cast<const bf16x4*>(p), hi4 = *reinterpret_cast<const bf16x4*>(p + 8);
+  return __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs a) {
+  // One workgroup per (window, head); wave w owns the 32 x 32 block (query tile qt = w >> 1, key tile kt = w & 1)
+  // of the score matrix in both passes, so a lane carries 16 + 16 running sums instead of 128 and the element
+  // code exists once.  Partial dq (over kt) and dk / dv (over qt) of the two waves that share a tile meet in LDS.
+  __shared__ __attribute__((aligned(16))) bf16_t sKT[AD * VTS], sGT[AD * VTS], sQT[AD * VTS];
+  __shared__ float sKn[AN], sQn[AN], sLse[AN], sDi[AN], sBs[2][32];
+  __shared__ int sCnt[AN];
+  __shared__ float sTab[2][AN * ANS];   // 1/clip(tau) (negated where the clip is active) and bias of this head
+  __shared__ float sRed[2][2][64 * 17]; // partial 32 x 32 fp32 tiles handed to the wave sharing the tile, [lane][16] (+1 pad)
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, h = blockIdx.y;
+  const int qt = w >> 1, kt = w & 1;
+  const int N = a.ws * a.ws;
+  const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
+  const bf16_t* __restrict__ qkv = static_cast<const bf16_t*>(a.qkv);
+  const bf16_t* __restrict__ out = static_cast<const bf16_t*>(a.out);
+  const bf16_t* __restrict__ dout = static_cast<const bf16_t*>(a.dout);
+  bf16_t* __restrict__ dqkv = static_cast<bf16_t*>(a.dqkv);
+  for (int e = tid; e < AN * AN; e += 256) {   // entries of padding tokens are read too: keep them finite
+    const int r = e >> 6, c = e & 63;
+    const bool in = r < N && c < N;
+    const float tv = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
+    const float inv = 1.f / fmaxf(tv, 0.01f);
+    sTab[0][r * ANS + c] = tv >= 0.01f ? inv : -inv;
+    sTab[1][r * ANS + c] = in ? a.bias[((size_t)h * N + r) * N + c] : 0.f;
+  }
+  // running d(bias) / d(tau) sums of (query 32 qt + l31, key 32 kt + row(r)) over this workgroup's windows
+  float accb[16], acct[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = acct[r] = 0.f;
+  const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
+
+  for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
+    __syncthreads();   // previous window: every reader of the tiles / partials is done (and sTab has landed)
+    // fragments: q, dO of query tile qt and k, v of key tile kt (16 bytes of the token's head slice per lane)
+    WinTok tq = {0, -1}, tkk = {0, -1};
+    bf16x8 qf[2], gf[2], kf[2], vf[2];
+    {
+      float q2 = 0.f, dd = 0.f, k2 = 0.f;
+      if (iq < N) {
+        tq = win_token(a, win, iq);
+        const bf16_t* row = qkv + (size_t)tq.tok * a.ldq + h * AD + 8 * lh;
+        const bf16_t* grow = dout + (size_t)tq.tok * a.lddo + h * AD + 8 * lh;
+        const bf16_t* orow = out + (size_t)tq.tok * a.ldo + h * AD + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+          gf[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks);
+          const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float qv = (float)qf[ks][e];
+            q2 = fmaf(qv, qv, q2);
+            dd = fmaf((float)gf[ks][e], (float)of[e], dd);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qf[ks][e] = gf[ks][e] = (bf16_t)0.f;
+      }
+      if (jk < N) {
+        tkk = win_token(a, win, jk);
+        const bf16_t* row = qkv + (size_t)tkk.tok * a.ldq + a.C + h * AD + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          kf[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+          vf[ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float kv = (float)kf[ks][e];
+            k2 = fmaf(kv, kv, k2);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) kf[ks][e] = vf[ks][e] = (bf16_t)0.f;
+      }
+      q2 += __shfl_xor(q2, 32);
+      dd += __shfl_xor(dd, 32);
+      k2 += __shfl_xor(k2, 32);
+      if (kt == 0) {   // the two waves of a query tile hold the same q / dO: one of them publishes
+        if (lh == 0) {
+          sQn[iq] = a.scale * sqrtf(q2);
+          sDi[iq] = dd;
+          sLse[iq] = iq < N ? a.lse[((size_t)win * a.heads + h) * N + iq] : 0.f;
+          sCnt[iq] = tq.cnt;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int d = 16 * ks + 8 * lh + e;
+            sGT[d * VTS + iq] = gf[ks][e];
+            sQT[d * VTS + iq] = qf[ks][e];
+          }
+      }
+      if (qt == 0) {
+        if (lh == 0) sKn[jk] = sqrtf(k2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sKT[(16 * ks + 8 * lh + e) * VTS + jk] = kf[ks][e];
+      }
+    }
+    __syncthreads();
+
+    // ---------------- pass 1: column = query iq, rows = keys of tile kt -> dq partial, d(bias), d(tau)
+    {
+      const float qn = sQn[iq], lse = sLse[iq], Di = sDi[iq];
+      const int cq = sCnt[iq];
+      f32x16 ut, dt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ut[r] = dt[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ut, 0, 0, 0);
+        dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], gf[ks], dt, 0, 0, 0);
+      }
+      float bs = 0.f, w1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float u = ut[r] * a.scale, kn = sKn[j];
+        const float nn = qn * kn;
+        const bool clamped = nn <= 1e-6f;
+        const float rden = rcp(clamped ? 1e-6f : nn);
+        const float tis = sTab[0][iq * ANS + j], ti = fabsf(tis);
+        const float c = u * rden;
+        float sv = c * ti + sTab[1][iq * ANS + j];
+        if (sCnt[j] != cq) sv -= 100.f;
+        const float p = (iq < N && j < N) ? __expf(sv - lse) : 0.f;
+        const float ds = p * (dt[r] - Di);
+        accb[r] += ds;
+        if (tis > 0.f) acct[r] -= ds * c * ti * ti;
+        const float dc = ds * ti;
+        w1[r] = dc * rden;
+        if (!clamped) bs += dc * u * kn * rden * rden;
+      }
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sKT, l31, lh, kt, s2), pack8(w1 + 8 * s2), dq, 0, 0, 0);
+      bs += __shfl_xor(bs, 32);
+      if (kt == 1) {   // hand the partial to the kt = 0 wave of this query tile
+        float* red = &sRed[qt][0][lane * 17];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[r] = dq[r];
+        if (lh == 0) sBs[qt][l31] = bs;
+      }
+      __syncthreads();
+      if (kt == 0 && iq < N) {
+        const float* r1 = &sRed[qt][0][lane * 17];
+        bs = (bs + sBs[qt][l31]) * rcp(fmaxf(qn, 1e-30f));
+        const bf16_t* qrow = qkv + (size_t)tq.tok * a.ldq + h * AD + 4 * lh;
+        bf16_t* drow = dqkv + (size_t)tq.tok * a.lddq + h * AD + 4 * lh;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const bf16x4 qv = *reinterpret_cast<const bf16x4*>(qrow + 8 * q4);
+          bf16x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o4[e] = (bf16_t)(a.scale * (dq[4 * q4 + e] + r1[4 * q4 + e] - bs * a.scale * (float)qv[e]));
+          *reinterpret_cast<bf16x4*>(drow + 8 * q4) = o4;
+        }
+      }
+    }
+
+    // ---------------- pass 2: column = key jk, rows = queries of tile qt -> dk, dv partials
+    {
+      const float kn = sKn[jk];
+      const int ck = sCnt[jk];
+      f32x16 uu, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) uu[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], uu, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[ks], vf[ks], dp, 0, 0, 0);
+      }
+      float bs = 0.f, pp[16], w1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float u = uu[r] * a.scale, qn = sQn[i];
+        const float nn = qn * kn;
+        const bool clamped = nn <= 1e-6f;
+        const float rden = rcp(clamped ? 1e-6f : nn);
+        const float ti = fabsf(sTab[0][i * ANS + jk]);
+        float sv = u * rden * ti + sTab[1][i * ANS + jk];
+        if (sCnt[i] != ck) sv -= 100.f;
+        const float p = (i < N && jk < N) ? __expf(sv - sLse[i]) : 0.f;
+        const float dc = p * (dp[r] - sDi[i]) * ti;
+        pp[r] = p;
+        w1[r] = dc * rden;
+        if (!clamped) bs += dc * u * qn * rden * rden;
+      }
+      f32x16 dk, dv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sGT, l31, lh, qt, s2), pack8(pp + 8 * s2), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sQT, l31, lh, qt, s2), pack8(w1 + 8 * s2), dk, 0, 0, 0);
+      }
+      bs += __shfl_xor(bs, 32);
+      __syncthreads();   // the dq partials in sRed / sBs have been consumed
+      if (qt == 1) {     // hand the partials to the qt = 0 wave of this key tile
+        float* red = &sRed[kt][0][lane * 17];
+        float* red2 = &sRed[kt][1][lane * 17];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          red[r] = dk[r];
+          red2[r] = dv[r];
+        }
+        if (lh == 0) sBs[kt][l31] = bs;
+      }
+      __syncthreads();
+      if (qt == 0 && jk < N) {
+        const float* k1 = &sRed[kt][0][lane * 17];
+        const float* v1 = &sRed[kt][1][lane * 17];
+        bs = (bs + sBs[kt][l31]) * rcp(fmaxf(kn, 1e-30f));
+        const bf16_t* krow = qkv + (size_t)tkk.tok * a.ldq + a.C + h * AD + 4 * lh;
+        bf16_t* drow = dqkv + (size_t)tkk.tok * a.lddq + a.C + h * AD + 4 * lh;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const bf16x4 kv = *reinterpret_cast<const bf16x4*>(krow + 8 * q4);
+          bf16x4 o4, o5;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o4[e] = (bf16_t)(a.scale * (dk[4 * q4 + e] + k1[4 * q4 + e]) - bs * (float)kv[e]);
+            o5[e] = (bf16_t)(dv[4 * q4 + e] + v1[4 * q4 + e]);
+          }
+          *reinterpret_cast<bf16x4*>(drow + 8 * q4) = o4;
+          *reinterpret_cast<bf16x4*>(drow + a.C + 8 * q4) = o5;
+        }
+      }
+    }
+  }
+  float* part = a.partial + ((size_t)blockIdx.x * a.heads + h) * 2 * N * N;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (iq < N && j < N) {
+      part[iq * N + j] = accb[r];
+      part[N * N + iq * N + j] = acct[r];
+    }
+  }
+}
+
 // Backward: one 256-thread workgroup (one wave per SIMD) per (window, head).  Phase A: lane = query i, the
 // four waves split the key range; phase B: lane = key j, the waves split the query range; per-wave
 // partial sums of dq / dk / dv meet in LDS and are added in a fixed order.  dS-derived sums for d(bias)
@@ -1093,6 +1370,15 @@ static int attn_grid_x(const uz_winattn_desc* d) {
   return (int)g;
 }
 
+// matrix-core kernels (bf16): one wave per (window, head), four per workgroup
+static int attn_mfma_grid_x(const uz_winattn_desc* d) {
+  const long long nwin = (long long)d->B * (d->H / d->ws) * (d->W / d->ws);
+  long long gx = (nwin + 3) / 4, cap = (UZ_NUM_CU * 2 + d->heads - 1) / d->heads;
+  if (gx > cap) gx = cap;
+  return (int)(gx < 1 ? 1 : gx);
+}
+static bool attn_bwd_mfma(const uz_winattn_desc* d) { return d->dtype == UZ_BF16 && !(uz_tune_flags() & 0x2000); }
+
 extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
                               void* out, float* lse, void* stream) {
   const int rc = attn_check("uz_winattn_fwd", d);
@@ -1105,10 +1391,7 @@ extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const f
   const dim3 grid(attn_grid_x(d), d->heads), block(256);
   if (d->dtype == UZ_BF16 && !(uz_tune_flags() & 0x1000)) {
     // matrix-core path: one wave per (window, head), four per workgroup
-    const long long nwin = (long long)d->B * (d->H / d->ws) * (d->W / d->ws);
-    long long gx = (nwin + 3) / 4, cap = (UZ_NUM_CU * 2 + d->heads - 1) / d->heads;
-    if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(winattn_fwd_mfma_kernel, dim3((unsigned)gx, d->heads), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(winattn_fwd_mfma_kernel, dim3(attn_mfma_grid_x(d), d->heads), dim3(256), 0, (hipStream_t)stream, a);
   } else if (d->dtype == UZ_BF16) {
     hipLaunchKernelGGL((winattn_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
   } else {
@@ -1138,8 +1421,13 @@ extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const f
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
   a.ldq = d->ldq; a.ldo = d->ldo; a.lddo = lddo; a.lddq = lddq; a.scale = d->scale;
   const dim3 grid(attn_grid_x(d), d->heads), block(256);
-  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((winattn_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((winattn_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
+  if (attn_bwd_mfma(d)) {
+    hipLaunchKernelGGL(winattn_bwd_mfma_kernel, grid, block, 0, (hipStream_t)stream, a);
+  } else if (d->dtype == UZ_BF16) {
+    hipLaunchKernelGGL((winattn_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL((winattn_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
+  }
   UZ_LAUNCH_CHECK("uz_winattn_bwd");
   return UZ_OK;
 }
