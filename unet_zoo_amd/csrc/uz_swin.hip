@@ -102,8 +102,11 @@ __device__ __forceinline__ float group_sum(float v, int lpt) {
 }
 
 // LPT = min(64, pow2 >= C/VEC) lanes per token, 64/LPT tokens per wave, 4 waves per workgroup: a
-// 96-channel bf16 token (12 chunks) occupies 16 lanes, not a whole wave.
-template <typename T, bool BWD>
+// 96-channel bf16 token (12 chunks) occupies 16 lanes, not a whole wave.  A lane carries MAXIT chunks of
+// each of U tokens; all their loads are issued before the first reduction, so that a wave keeps
+// U * MAXIT * 16 (x2 in the backward) bytes per lane in flight: with one token per pass and the register
+// budget of MAXIT = 6 the kernel ran at 1 - 1.5 TB/s, bound by latency.
+template <typename T, bool BWD, int MAXIT, int U>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,9 +114,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
   const int CC = a.C / VEC;
   const int P = a.N * a.Ho * a.Wo;
   const T* __restrict__ x = static_cast<const T*>(a.x);
-  float gam[LN_MAXIT][VEC], bet[LN_MAXIT][VEC], ag[LN_MAXIT][VEC], ab[LN_MAXIT][VEC];
+  float gam[MAXIT][VEC], bet[MAXIT][VEC], ag[MAXIT][VEC], ab[MAXIT][VEC];
 #pragma unroll
-  for (int it = 0; it < LN_MAXIT; ++it) {
+  for (int it = 0; it < MAXIT; ++it) {
     const int cc = sub + lpt * it;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -123,99 +126,133 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
     }
   }
   const float invC = 1.f / (float)a.C;
-  const int tpb = 4 * tpw;  // tokens per workgroup pass
+  const int tpb = 4 * tpw * U;  // tokens per workgroup pass
   for (int t0 = blockIdx.x * tpb; t0 < P; t0 += gridDim.x * tpb) {
-    const int t = t0 + wave * tpw + grp;
-    const bool tok = t < P;   // whole lane groups go idle together; shuffles below stay inside a group
-    const int tc = tok ? t : 0;
-    const int ow = tc % a.Wo, tt = tc / a.Wo, oh = tt % a.Ho, img = tt / a.Ho;
-    float v[LN_MAXIT][VEC];
-    float s = 0.f;
+    int t[U], img[U], oh[U], ow[U];
+    bool tok[U];   // whole lane groups go idle together; shuffles below stay inside a group
+    float v[U][MAXIT][VEC];
 #pragma unroll
-    for (int it = 0; it < LN_MAXIT; ++it) {
-      const int cc = sub + lpt * it;
-      if (cc < CC && tok) {
-        load_f(x + ln_src<T>(a, img, oh, ow, cc * VEC, a.ldx), v[it]);
+    for (int u = 0; u < U; ++u) {
+      t[u] = t0 + (u * 4 + wave) * tpw + grp;
+      tok[u] = t[u] < P;
+      const int tc = tok[u] ? t[u] : 0;
+      const int tt = tc / a.Wo;
+      ow[u] = tc - tt * a.Wo;
+      img[u] = tt / a.Ho;
+      oh[u] = tt - img[u] * a.Ho;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s += v[it][e];
-      } else {
+      for (int it = 0; it < MAXIT; ++it) {
+        const int cc = sub + lpt * it;
+        if (cc < CC && tok[u]) {
+          load_f(x + ln_src<T>(a, img[u], oh[u], ow[u], cc * VEC, a.ldx), v[u][it]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[it][e] = 0.f;
+          for (int e = 0; e < VEC; ++e) v[u][it][e] = 0.f;
+        }
       }
     }
-    float mean, rstd;
     if constexpr (!BWD) {
-      mean = group_sum(s, lpt) * invC;
-      float q = 0.f;
-#pragma unroll
-      for (int it = 0; it < LN_MAXIT; ++it)
-        if (sub + lpt * it < CC) {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const float d = v[it][e] - mean;
-            q += d * d;
-          }
-        }
-      rstd = rsqrtf(group_sum(q, lpt) * invC + a.eps);
-      if (sub == 0 && tok) {
-        a.stats[(size_t)t * 2] = mean;
-        a.stats[(size_t)t * 2 + 1] = rstd;
-      }
-      const float f = a.sb != nullptr ? a.sb[img] : 1.f;
       T* __restrict__ y = static_cast<T*>(a.y);
       const T* __restrict__ res = static_cast<const T*>(a.res);
+      float rv[U][MAXIT][VEC];
+      if (res != nullptr) {
 #pragma unroll
-      for (int it = 0; it < LN_MAXIT; ++it) {
-        const int cc = sub + lpt * it;
-        if (cc < CC && tok) {
-          float o[VEC], rv[VEC];
-          if (res != nullptr) load_f(res + (size_t)t * a.ldr + cc * VEC, rv);
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            o[e] = f * ((v[it][e] - mean) * rstd * gam[it][e] + bet[it][e]);
-            if (res != nullptr) o[e] += rv[e];
+          for (int it = 0; it < MAXIT; ++it) {
+            const int cc = sub + lpt * it;
+            if (cc < CC && tok[u]) load_f(res + (size_t)t[u] * a.ldr + cc * VEC, rv[u][it]);
           }
-          store_f(y + (size_t)t * a.ldy + cc * VEC, o);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s += v[u][it][e];
+        const float mean = group_sum(s, lpt) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+          if (sub + lpt * it < CC) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float d = v[u][it][e] - mean;
+              q += d * d;
+            }
+          }
+        const float rstd = rsqrtf(group_sum(q, lpt) * invC + a.eps);
+        if (sub == 0 && tok[u]) {
+          a.stats[(size_t)t[u] * 2] = mean;
+          a.stats[(size_t)t[u] * 2 + 1] = rstd;
+        }
+        const float f = a.sb != nullptr ? a.sb[img[u]] : 1.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+          const int cc = sub + lpt * it;
+          if (cc < CC && tok[u]) {
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              o[e] = f * ((v[u][it][e] - mean) * rstd * gam[it][e] + bet[it][e]);
+              if (res != nullptr) o[e] += rv[u][it][e];
+            }
+            store_f(y + (size_t)t[u] * a.ldy + cc * VEC, o);
+          }
         }
       }
     } else {
-      mean = tok ? a.stats[(size_t)t * 2] : 0.f;
-      rstd = tok ? a.stats[(size_t)t * 2 + 1] : 0.f;
-      const float f = a.sb != nullptr ? a.sb[img] : 1.f;
       const T* __restrict__ g = static_cast<const T*>(a.g);
       T* __restrict__ dx = static_cast<T*>(a.dx);
-      float gv[LN_MAXIT][VEC];
-      float s1 = 0.f, s2 = 0.f;  // sum of g*gamma, sum of g*gamma*xhat
+      float gv[U][MAXIT][VEC], mean[U], rstd[U];
 #pragma unroll
-      for (int it = 0; it < LN_MAXIT; ++it) {
-        const int cc = sub + lpt * it;
-        if (cc < CC && tok) {
-          load_f(g + (size_t)t * a.ldg + cc * VEC, gv[it]);
+      for (int u = 0; u < U; ++u) {
+        mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
+        rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            gv[it][e] *= f;
-            const float xh = (v[it][e] - mean) * rstd;
-            ag[it][e] += gv[it][e] * xh;
-            ab[it][e] += gv[it][e];
-            const float gg = gv[it][e] * gam[it][e];
-            s1 += gg;
-            s2 += gg * xh;
+        for (int it = 0; it < MAXIT; ++it) {
+          const int cc = sub + lpt * it;
+          if (cc < CC && tok[u]) {
+            load_f(g + (size_t)t[u] * a.ldg + cc * VEC, gv[u][it]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) gv[u][it][e] = 0.f;
           }
         }
       }
-      s1 = group_sum(s1, lpt) * invC;
-      s2 = group_sum(s2, lpt) * invC;
 #pragma unroll
-      for (int it = 0; it < LN_MAXIT; ++it) {
-        const int cc = sub + lpt * it;
-        if (cc < CC && tok) {
-          float o[VEC];
+      for (int u = 0; u < U; ++u) {
+        const float f = a.sb != nullptr ? a.sb[img[u]] : 1.f;
+        float s1 = 0.f, s2 = 0.f;  // sum of g*gamma, sum of g*gamma*xhat
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const float xh = (v[it][e] - mean) * rstd;
-            o[e] = rstd * (gv[it][e] * gam[it][e] - s1 - xh * s2);
+        for (int it = 0; it < MAXIT; ++it) {
+          const int cc = sub + lpt * it;
+          if (cc < CC && tok[u]) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              gv[u][it][e] *= f;
+              const float xh = (v[u][it][e] - mean[u]) * rstd[u];
+              v[u][it][e] = xh;
+              ag[it][e] += gv[u][it][e] * xh;
+              ab[it][e] += gv[u][it][e];
+              const float gg = gv[u][it][e] * gam[it][e];
+              s1 += gg;
+              s2 += gg * xh;
+            }
           }
-          store_f(dx + ln_src<T>(a, img, oh, ow, cc * VEC, a.lddx), o);
+        }
+        s1 = group_sum(s1, lpt) * invC;
+        s2 = group_sum(s2, lpt) * invC;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+          const int cc = sub + lpt * it;
+          if (cc < CC && tok[u]) {
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = rstd[u] * (gv[u][it][e] * gam[it][e] - s1 - v[u][it][e] * s2);
+            store_f(dx + ln_src<T>(a, img[u], oh[u], ow[u], cc * VEC, a.lddx), o);
+          }
         }
       }
     }
@@ -226,7 +263,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
     const int gidx = wave * tpw + grp, ngrp = 4 * tpw;
     float* mine = red + (size_t)gidx * 2 * a.C;
 #pragma unroll
-    for (int it = 0; it < LN_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
       const int cc = sub + lpt * it;
       if (cc < CC) {
 #pragma unroll
@@ -1281,9 +1318,34 @@ int ln_check(const char* fn, const uz_ln_desc* d) {
   return UZ_OK;
 }
 
+// chunks per lane and tokens per lane group and pass of the instantiation that serves d
+int ln_its(const uz_ln_desc* d) {
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4, lpt = ln_lpt(d);
+  return (d->C / vec + lpt - 1) / lpt;
+}
+int ln_unroll(const uz_ln_desc* d) { const int its = ln_its(d); return its == 1 ? 4 : its <= 3 ? 2 : 1; }
+
 int ln_grid(const uz_ln_desc* d) {
-  const int tpb = 4 * (64 / ln_lpt(d));
-  return grid_cap((long long)d->N * d->Ho * d->Wo, tpb * 4, 4);
+  const int tpb = 4 * (64 / ln_lpt(d)) * ln_unroll(d);
+  return grid_cap((long long)d->N * d->Ho * d->Wo, tpb * 2, 8);
+}
+
+template <bool BWD>
+void ln_launch(const uz_ln_desc* d, dim3 grid, dim3 block, size_t shm, hipStream_t st, const LnArgs& a, int lpt) {
+  const int its = ln_its(d);
+#define UZ_LN(T, I, U) hipLaunchKernelGGL((layernorm_kernel<T, BWD, I, U>), grid, block, shm, st, a, lpt)
+  if (d->dtype == UZ_BF16) {
+    if (its == 1) UZ_LN(bf16_t, 1, 4);
+    else if (its == 2) UZ_LN(bf16_t, 2, 2);
+    else if (its == 3) UZ_LN(bf16_t, 3, 2);
+    else UZ_LN(bf16_t, 6, 1);
+  } else {
+    if (its == 1) UZ_LN(float, 1, 4);
+    else if (its == 2) UZ_LN(float, 2, 2);
+    else if (its == 3) UZ_LN(float, 3, 2);
+    else UZ_LN(float, 6, 1);
+  }
+#undef UZ_LN
 }
 
 }  // namespace
@@ -1315,8 +1377,7 @@ extern "C" int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float*
   a.mode = d->mode; a.r = d->r; a.eps = d->eps;
   const dim3 grid(ln_grid(d)), block(256);
   const int lpt = ln_lpt(d);
-  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, (hipStream_t)stream, a, lpt);
-  else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, (hipStream_t)stream, a, lpt);
+  ln_launch<false>(d, grid, block, 0, (hipStream_t)stream, a, lpt);
   UZ_LAUNCH_CHECK("uz_layernorm_fwd");
   return UZ_OK;
 }
@@ -1342,8 +1403,7 @@ extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float*
   const dim3 grid(ln_grid(d)), block(256);
   const int lpt = ln_lpt(d);
   const size_t shm = (size_t)4 * (64 / lpt) * 2 * d->C * sizeof(float);
-  if (d->dtype == UZ_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, shm, (hipStream_t)stream, a, lpt);
-  else hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, shm, (hipStream_t)stream, a, lpt);
+  ln_launch<true>(d, grid, block, shm, (hipStream_t)stream, a, lpt);
   UZ_LAUNCH_CHECK("uz_layernorm_bwd");
   return UZ_OK;
 }
