@@ -103,9 +103,26 @@ __device__ __forceinline__ float group_sum(float v, int lpt) {
 
 // LPT = min(64, pow2 >= C/VEC) lanes per token, 64/LPT tokens per wave, 4 waves per workgroup: a
 // 96-channel bf16 token (12 chunks) occupies 16 lanes, not a whole wave.  A lane carries MAXIT chunks of
-// each of U tokens; all their loads are issued before the first reduction, so that a wave keeps
-// U * MAXIT * 16 (x2 in the backward) bytes per lane in flight: with one token per pass and the register
-// budget of MAXIT = 6 the kernel ran at 1 - 1.5 TB/s, bound by latency.
+// each of U tokens; all their loads are issued before the first reduction and stay packed (16 bytes = 4
+// registers) until they are used, so that a wave keeps U * MAXIT * 16 (x2 with a residual / in the
+// backward) bytes per lane in flight at a register count that still admits 4+ waves per SIMD: with one
+// token per pass and the register budget of MAXIT = 6 the kernel ran at 1 - 1.5 TB/s, bound by latency.
+template <typename T> __device__ __forceinline__ void unpack_f(const uint4& r, float* f);
+template <> __device__ __forceinline__ void unpack_f<float>(const uint4& r, float* f) {
+  f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack_f<bf16_t>(const uint4& r, float* f) {
+  const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(w[k] << 16);
+    f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+  }
+}
+// keeps a packed load packed: the optimiser otherwise converts every loaded chunk to fp32 as soon as it lands
+// (twice the registers), which costs the occupancy that the loads in flight were meant to buy
+__device__ __forceinline__ void pin(uint4& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
+
 template <typename T, bool BWD, int MAXIT, int U>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt) {
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -114,6 +131,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
   const int CC = a.C / VEC;
   const int P = a.N * a.Ho * a.Wo;
   const T* __restrict__ x = static_cast<const T*>(a.x);
+  const T* __restrict__ second = static_cast<const T*>(BWD ? a.g : a.res);   // g, or the optional residual
+  const int ld2 = BWD ? a.ldg : a.ldr;
   float gam[MAXIT][VEC], bet[MAXIT][VEC], ag[MAXIT][VEC], ab[MAXIT][VEC];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
@@ -128,130 +147,124 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
   const float invC = 1.f / (float)a.C;
   const int tpb = 4 * tpw * U;  // tokens per workgroup pass
   for (int t0 = blockIdx.x * tpb; t0 < P; t0 += gridDim.x * tpb) {
-    int t[U], img[U], oh[U], ow[U];
-    bool tok[U];   // whole lane groups go idle together; shuffles below stay inside a group
-    float v[U][MAXIT][VEC];
+    int t[U], img[U];
+    size_t xo[U];   // element offset of the token's first channel in x (ld = 1 units resolved below)
+    bool tok[U];    // whole lane groups go idle together; shuffles below stay inside a group
+    uint4 xr[U][MAXIT], sr[U][MAXIT];
+    float mean[U], rstd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       t[u] = t0 + (u * 4 + wave) * tpw + grp;
       tok[u] = t[u] < P;
       const int tc = tok[u] ? t[u] : 0;
-      const int tt = tc / a.Wo;
-      ow[u] = tc - tt * a.Wo;
+      const int tt = tc / a.Wo, ow = tc - tt * a.Wo;
       img[u] = tt / a.Ho;
-      oh[u] = tt - img[u] * a.Ho;
+      const int oh = tt - img[u] * a.Ho;
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int cc = sub + lpt * it;
         if (cc < CC && tok[u]) {
-          load_f(x + ln_src<T>(a, img[u], oh[u], ow[u], cc * VEC, a.ldx), v[u][it]);
+          xr[u][it] = *reinterpret_cast<const uint4*>(x + ln_src<T>(a, img[u], oh, ow, cc * VEC, a.ldx));
+          if (BWD || second != nullptr) sr[u][it] = *reinterpret_cast<const uint4*>(second + (size_t)t[u] * ld2 + cc * VEC);
+          else sr[u][it] = make_uint4(0, 0, 0, 0);
         } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) v[u][it][e] = 0.f;
+          xr[u][it] = sr[u][it] = make_uint4(0, 0, 0, 0);
         }
       }
+      xo[u] = ((size_t)oh << 32) | (unsigned)ow;
+      if constexpr (BWD) {
+        mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
+        rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        pin(xr[u][it]);
+        pin(sr[u][it]);
+      }
     if constexpr (!BWD) {
       T* __restrict__ y = static_cast<T*>(a.y);
-      const T* __restrict__ res = static_cast<const T*>(a.res);
-      float rv[U][MAXIT][VEC];
-      if (res != nullptr) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int it = 0; it < MAXIT; ++it) {
-            const int cc = sub + lpt * it;
-            if (cc < CC && tok[u]) load_f(res + (size_t)t[u] * a.ldr + cc * VEC, rv[u][it]);
-          }
-      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        __builtin_amdgcn_sched_barrier(0);   // one token at a time: the packed loads stay packed until here
+        float v[MAXIT][VEC];
         float s = 0.f;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it)
+        for (int it = 0; it < MAXIT; ++it) {
+          unpack_f<T>(xr[u][it], v[it]);
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) s += v[u][it][e];
-        const float mean = group_sum(s, lpt) * invC;
+          for (int e = 0; e < VEC; ++e) s += v[it][e];
+        }
+        const float mu = group_sum(s, lpt) * invC;
         float q = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)
           if (sub + lpt * it < CC) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              const float d = v[u][it][e] - mean;
+              const float d = v[it][e] - mu;
               q += d * d;
             }
           }
-        const float rstd = rsqrtf(group_sum(q, lpt) * invC + a.eps);
+        const float rs = rsqrtf(group_sum(q, lpt) * invC + a.eps);
         if (sub == 0 && tok[u]) {
-          a.stats[(size_t)t[u] * 2] = mean;
-          a.stats[(size_t)t[u] * 2 + 1] = rstd;
+          a.stats[(size_t)t[u] * 2] = mu;
+          a.stats[(size_t)t[u] * 2 + 1] = rs;
         }
         const float f = a.sb != nullptr ? a.sb[img[u]] : 1.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
           const int cc = sub + lpt * it;
           if (cc < CC && tok[u]) {
-            float o[VEC];
+            float o[VEC], rv[VEC];
+            unpack_f<T>(sr[u][it], rv);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              o[e] = f * ((v[u][it][e] - mean) * rstd * gam[it][e] + bet[it][e]);
-              if (res != nullptr) o[e] += rv[u][it][e];
+              o[e] = f * ((v[it][e] - mu) * rs * gam[it][e] + bet[it][e]);
+              if (second != nullptr) o[e] += rv[e];
             }
             store_f(y + (size_t)t[u] * a.ldy + cc * VEC, o);
           }
         }
       }
     } else {
-      const T* __restrict__ g = static_cast<const T*>(a.g);
       T* __restrict__ dx = static_cast<T*>(a.dx);
-      float gv[U][MAXIT][VEC], mean[U], rstd[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
-        rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-          const int cc = sub + lpt * it;
-          if (cc < CC && tok[u]) {
-            load_f(g + (size_t)t[u] * a.ldg + cc * VEC, gv[u][it]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) gv[u][it][e] = 0.f;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
+        __builtin_amdgcn_sched_barrier(0);   // one token at a time: the packed loads stay packed until here
         const float f = a.sb != nullptr ? a.sb[img[u]] : 1.f;
+        float xh[MAXIT][VEC], gv[MAXIT][VEC];
         float s1 = 0.f, s2 = 0.f;  // sum of g*gamma, sum of g*gamma*xhat
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-          const int cc = sub + lpt * it;
-          if (cc < CC && tok[u]) {
+          unpack_f<T>(xr[u][it], xh[it]);
+          unpack_f<T>(sr[u][it], gv[it]);
+          if (sub + lpt * it < CC && tok[u]) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              gv[u][it][e] *= f;
-              const float xh = (v[u][it][e] - mean[u]) * rstd[u];
-              v[u][it][e] = xh;
-              ag[it][e] += gv[u][it][e] * xh;
-              ab[it][e] += gv[u][it][e];
-              const float gg = gv[u][it][e] * gam[it][e];
+              gv[it][e] *= f;
+              xh[it][e] = (xh[it][e] - mean[u]) * rstd[u];
+              ag[it][e] += gv[it][e] * xh[it][e];
+              ab[it][e] += gv[it][e];
+              const float gg = gv[it][e] * gam[it][e];
               s1 += gg;
-              s2 += gg * xh;
+              s2 += gg * xh[it][e];
             }
           }
         }
         s1 = group_sum(s1, lpt) * invC;
         s2 = group_sum(s2, lpt) * invC;
+        const int oh = (int)(xo[u] >> 32), ow = (int)(xo[u] & 0xffffffffu);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
           const int cc = sub + lpt * it;
           if (cc < CC && tok[u]) {
             float o[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = rstd[u] * (gv[u][it][e] * gam[it][e] - s1 - v[u][it][e] * s2);
-            store_f(dx + ln_src<T>(a, img[u], oh[u], ow[u], cc * VEC, a.lddx), o);
+            for (int e = 0; e < VEC; ++e) o[e] = rstd[u] * (gv[it][e] * gam[it][e] - s1 - xh[it][e] * s2);
+            store_f(dx + ln_src<T>(a, img[u], oh, ow, cc * VEC, a.lddx), o);
           }
         }
       }
@@ -698,47 +711,62 @@ __device__ __forceinline__ bf16x8 tfrag(const bf16_t* xt, int l31, int lh, int t
 
 __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs a) {
   // One workgroup per (window, head); wave w owns the 32 x 32 block (query tile qt = w >> 1, key tile kt = w & 1)
-  // of the score matrix in both passes, so a lane carries 16 + 16 running sums instead of 128 and the element
-  // code exists once.  Partial dq (over kt) and dk / dv (over qt) of the two waves that share a tile meet in LDS.
+  // of the score matrix, so a lane carries 16 + 16 running sums instead of 128 and the element code exists once.
+  // The element pass runs with column = query (everything per query is the lane's own); it leaves P and
+  // W = dC / (|q||k|) of its block in LDS as bf16 [key][query], which is the B operand of the dk / dv products,
+  // so there is no second element pass.  The projection terms of the two normalisations come from the products
+  // themselves: with A_i = sum_j W_ij k_j, sum_j dC_ij c_ij = q_i . A_i (likewise for k), a 32-term dot in
+  // the epilogue instead of six operations per score element.  (A row whose norm product falls under the
+  // reference's 1e-6 clamp keeps the clamped quotient but not its projection-free gradient; exact zero rows
+  // are exact.  The fp32 kernel below follows the clamp to the letter.)
+  // Partial dq (over kt) and dk / dv (over qt) of the two waves that share a tile meet in LDS.
   __shared__ __attribute__((aligned(16))) bf16_t sKT[AD * VTS], sGT[AD * VTS], sQT[AD * VTS];
-  __shared__ float sKn[AN], sQn[AN], sLse[AN], sDi[AN], sBs[2][32];
+  __shared__ __attribute__((aligned(16))) bf16_t sPW[2 * AN * VTS];   // P, W [key][query]; later the dk / dv hand-over
+  __shared__ float sRedQ[2][64 * 17];   // dq hand-over of the kt = 1 waves, [lane][16] (+1 pad)
+  __shared__ float sRk[AN];             // 1 / |k_j|
   __shared__ int sCnt[AN];
   __shared__ float sTab[2][AN * ANS];   // 1/clip(tau) (negated where the clip is active) and bias of this head
-  __shared__ float sRed[2][2][64 * 17]; // partial 32 x 32 fp32 tiles handed to the wave sharing the tile, [lane][16] (+1 pad)
+  static_assert(2 * 2 * 64 * 17 * sizeof(float) <= sizeof(bf16_t) * 2 * AN * VTS, "dk / dv hand-over must fit in sPW");
+  bf16_t* sP = sPW;
+  bf16_t* sW = sPW + AN * VTS;
+  float* sRedK = reinterpret_cast<float*>(sPW);   // [2 key tiles][2 (dk, dv)][64 * 17]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, h = blockIdx.y;
   const int qt = w >> 1, kt = w & 1;
   const int N = a.ws * a.ws;
   const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
+  const bool masked = a.shift > 0;
   const bf16_t* __restrict__ qkv = static_cast<const bf16_t*>(a.qkv);
   const bf16_t* __restrict__ out = static_cast<const bf16_t*>(a.out);
   const bf16_t* __restrict__ dout = static_cast<const bf16_t*>(a.dout);
   bf16_t* __restrict__ dqkv = static_cast<bf16_t*>(a.dqkv);
-  for (int e = tid; e < AN * AN; e += 256) {   // entries of padding tokens are read too: keep them finite
+  for (int e = tid; e < AN * AN; e += 256) {
     const int r = e >> 6, c = e & 63;
     const bool in = r < N && c < N;
     const float tv = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
     const float inv = 1.f / fmaxf(tv, 0.01f);
     sTab[0][r * ANS + c] = tv >= 0.01f ? inv : -inv;
-    sTab[1][r * ANS + c] = in ? a.bias[((size_t)h * N + r) * N + c] : 0.f;
+    sTab[1][r * ANS + c] = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;   // padding: exp() = 0, no test
   }
-  // running d(bias) / d(tau) sums of (query 32 qt + l31, key 32 kt + row(r)) over this workgroup's windows
+  // running sums over this workgroup's windows of dS (-> d bias) and dS * c (-> d tau) for
+  // (query 32 qt + l31, key 32 kt + row(r))
   float accb[16], acct[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) accb[r] = acct[r] = 0.f;
   const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
 
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
-    __syncthreads();   // previous window: every reader of the tiles / partials is done (and sTab has landed)
-    // fragments: q, dO of query tile qt and k, v of key tile kt (16 bytes of the token's head slice per lane)
+    __syncthreads();   // previous window: every reader of the tiles / hand-over areas is done (and sTab has landed)
     WinTok tq = {0, -1}, tkk = {0, -1};
     bf16x8 qf[2], gf[2], kf[2], vf[2];
+    float rq = 0.f, Di = 0.f, lse = 0.f;
     {
-      float q2 = 0.f, dd = 0.f, k2 = 0.f;
+      float q2 = 0.f, k2 = 0.f;
       if (iq < N) {
         tq = win_token(a, win, iq);
         const bf16_t* row = qkv + (size_t)tq.tok * a.ldq + h * AD + 8 * lh;
         const bf16_t* grow = dout + (size_t)tq.tok * a.lddo + h * AD + 8 * lh;
         const bf16_t* orow = out + (size_t)tq.tok * a.ldo + h * AD + 8 * lh;
+        lse = a.lse[((size_t)win * a.heads + h) * N + iq];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           qf[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
@@ -748,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
           for (int e = 0; e < 8; ++e) {
             const float qv = (float)qf[ks][e];
             q2 = fmaf(qv, qv, q2);
-            dd = fmaf((float)gf[ks][e], (float)of[e], dd);
+            Di = fmaf((float)gf[ks][e], (float)of[e], Di);
           }
         }
       } else {
@@ -777,15 +805,10 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
           for (int e = 0; e < 8; ++e) kf[ks][e] = vf[ks][e] = (bf16_t)0.f;
       }
       q2 += __shfl_xor(q2, 32);
-      dd += __shfl_xor(dd, 32);
+      Di += __shfl_xor(Di, 32);
       k2 += __shfl_xor(k2, 32);
+      rq = rcp(a.scale * sqrtf(q2));   // inf for a zero row: the product below is clamped
       if (kt == 0) {   // the two waves of a query tile hold the same q / dO: one of them publishes
-        if (lh == 0) {
-          sQn[iq] = a.scale * sqrtf(q2);
-          sDi[iq] = dd;
-          sLse[iq] = iq < N ? a.lse[((size_t)win * a.heads + h) * N + iq] : 0.f;
-          sCnt[iq] = tq.cnt;
-        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -796,7 +819,10 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
           }
       }
       if (qt == 0) {
-        if (lh == 0) sKn[jk] = sqrtf(k2);
+        if (lh == 0) {
+          sRk[jk] = rcp(sqrtf(k2));
+          sCnt[jk] = tkk.cnt;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -805,10 +831,9 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
     }
     __syncthreads();
 
-    // ---------------- pass 1: column = query iq, rows = keys of tile kt -> dq partial, d(bias), d(tau)
+    // ---------------- element pass: column = query iq, rows = keys of tile kt
+    f32x16 dq, dk, dv;
     {
-      const float qn = sQn[iq], lse = sLse[iq], Di = sDi[iq];
-      const int cq = sCnt[iq];
       f32x16 ut, dt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ut[r] = dt[r] = 0.f;
@@ -817,125 +842,116 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ut, 0, 0, 0);
         dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], gf[ks], dt, 0, 0, 0);
       }
-      float bs = 0.f, w1[16];
+      float w1[16];
+      bf16_t* pcol = sP + (32 * kt + 4 * lh) * VTS + iq;
+      bf16_t* wcol = sW + (32 * kt + 4 * lh) * VTS + iq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float u = ut[r] * a.scale, kn = sKn[j];
-        const float nn = qn * kn;
-        const bool clamped = nn <= 1e-6f;
-        const float rden = rcp(clamped ? 1e-6f : nn);
+        const int jr = (r & 3) + 8 * (r >> 2);            // key row inside the tile, less 4 * lh
+        const int j = 32 * kt + jr + 4 * lh;
+        const float u = ut[r] * a.scale;
+        const float rden = fminf(rq * sRk[j], 1e6f);      // 1 / max(|scale q||k|, 1e-6)
         const float tis = sTab[0][iq * ANS + j], ti = fabsf(tis);
         const float c = u * rden;
-        float sv = c * ti + sTab[1][iq * ANS + j];
-        if (sCnt[j] != cq) sv -= 100.f;
-        const float p = (iq < N && j < N) ? __expf(sv - lse) : 0.f;
+        float sv = fmaf(c, ti, sTab[1][iq * ANS + j]);
+        if (masked && sCnt[j] != tq.cnt) sv -= 100.f;
+        const float p = __expf(sv - lse);
         const float ds = p * (dt[r] - Di);
         accb[r] += ds;
-        if (tis > 0.f) acct[r] -= ds * c * ti * ti;
-        const float dc = ds * ti;
-        w1[r] = dc * rden;
-        if (!clamped) bs += dc * u * kn * rden * rden;
+        acct[r] = fmaf(ds, c, acct[r]);
+        w1[r] = ds * ti * rden;
+        pcol[jr * VTS] = (bf16_t)p;
+        wcol[jr * VTS] = (bf16_t)w1[r];
       }
-      f32x16 dq;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      for (int r = 0; r < 16; ++r) dq[r] = dk[r] = dv[r] = 0.f;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
         dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sKT, l31, lh, kt, s2), pack8(w1 + 8 * s2), dq, 0, 0, 0);
-      bs += __shfl_xor(bs, 32);
-      if (kt == 1) {   // hand the partial to the kt = 0 wave of this query tile
-        float* red = &sRed[qt][0][lane * 17];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[r] = dq[r];
-        if (lh == 0) sBs[qt][l31] = bs;
-      }
-      __syncthreads();
-      if (kt == 0 && iq < N) {
-        const float* r1 = &sRed[qt][0][lane * 17];
-        bs = (bs + sBs[qt][l31]) * rcp(fmaxf(qn, 1e-30f));
-        const bf16_t* qrow = qkv + (size_t)tq.tok * a.ldq + h * AD + 4 * lh;
-        bf16_t* drow = dqkv + (size_t)tq.tok * a.lddq + h * AD + 4 * lh;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const bf16x4 qv = *reinterpret_cast<const bf16x4*>(qrow + 8 * q4);
-          bf16x4 o4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o4[e] = (bf16_t)(a.scale * (dq[4 * q4 + e] + r1[4 * q4 + e] - bs * a.scale * (float)qv[e]));
-          *reinterpret_cast<bf16x4*>(drow + 8 * q4) = o4;
-        }
-      }
-    }
-
-    // ---------------- pass 2: column = key jk, rows = queries of tile qt -> dk, dv partials
-    {
-      const float kn = sKn[jk];
-      const int ck = sCnt[jk];
-      f32x16 uu, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) uu[r] = dp[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        uu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], uu, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[ks], vf[ks], dp, 0, 0, 0);
-      }
-      float bs = 0.f, pp[16], w1[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float u = uu[r] * a.scale, qn = sQn[i];
-        const float nn = qn * kn;
-        const bool clamped = nn <= 1e-6f;
-        const float rden = rcp(clamped ? 1e-6f : nn);
-        const float ti = fabsf(sTab[0][i * ANS + jk]);
-        float sv = u * rden * ti + sTab[1][i * ANS + jk];
-        if (sCnt[i] != ck) sv -= 100.f;
-        const float p = (i < N && jk < N) ? __expf(sv - sLse[i]) : 0.f;
-        const float dc = p * (dp[r] - sDi[i]) * ti;
-        pp[r] = p;
-        w1[r] = dc * rden;
-        if (!clamped) bs += dc * u * qn * rden * rden;
-      }
-      f32x16 dk, dv;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+      // dv, dk partials of (key tile kt) over (query tile qt): the B operand is this wave's own P / W block
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sGT, l31, lh, qt, s2), pack8(pp + 8 * s2), dv, 0, 0, 0);
-        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sQT, l31, lh, qt, s2), pack8(w1 + 8 * s2), dk, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sGT, l31, lh, qt, s2), tfrag(sP + 32 * kt * VTS, l31, lh, qt, s2), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sQT, l31, lh, qt, s2), tfrag(sW + 32 * kt * VTS, l31, lh, qt, s2), dk, 0, 0, 0);
       }
-      bs += __shfl_xor(bs, 32);
-      __syncthreads();   // the dq partials in sRed / sBs have been consumed
-      if (qt == 1) {     // hand the partials to the qt = 0 wave of this key tile
-        float* red = &sRed[kt][0][lane * 17];
-        float* red2 = &sRed[kt][1][lane * 17];
+      if (kt == 1) {   // hand the dq partial to the kt = 0 wave of this query tile
+        float* red = &sRedQ[qt][lane * 17];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          red[r] = dk[r];
-          red2[r] = dv[r];
-        }
-        if (lh == 0) sBs[kt][l31] = bs;
+        for (int r = 0; r < 16; ++r) red[r] = dq[r];
       }
-      __syncthreads();
-      if (qt == 0 && jk < N) {
-        const float* k1 = &sRed[kt][0][lane * 17];
-        const float* v1 = &sRed[kt][1][lane * 17];
-        bs = (bs + sBs[kt][l31]) * rcp(fmaxf(kn, 1e-30f));
-        const bf16_t* krow = qkv + (size_t)tkk.tok * a.ldq + a.C + h * AD + 4 * lh;
-        bf16_t* drow = dqkv + (size_t)tkk.tok * a.lddq + a.C + h * AD + 4 * lh;
+    }
+    __syncthreads();   // dq partials visible; every wave is done with P / W
+    if (kt == 0 && iq < N) {
+      // dq_i = scale * (A_i - (q_i . A_i) / |q_i|^2 q_i), A_i = sum_j W_ij k_j
+      const float* r1 = &sRedQ[qt][lane * 17];
+      const bf16_t* qrow = qkv + (size_t)tq.tok * a.ldq + h * AD + 4 * lh;
+      bf16_t* drow = dqkv + (size_t)tq.tok * a.lddq + h * AD + 4 * lh;
+      float qv[16], dot = 0.f, q2 = 0.f;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const bf16x4 kv = *reinterpret_cast<const bf16x4*>(krow + 8 * q4);
-          bf16x4 o4, o5;
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(qrow + 8 * q4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o4[e] = (bf16_t)(a.scale * (dk[4 * q4 + e] + k1[4 * q4 + e]) - bs * (float)kv[e]);
-            o5[e] = (bf16_t)(dv[4 * q4 + e] + v1[4 * q4 + e]);
-          }
-          *reinterpret_cast<bf16x4*>(drow + 8 * q4) = o4;
-          *reinterpret_cast<bf16x4*>(drow + a.C + 8 * q4) = o5;
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q4 + e;
+          qv[r] = (float)t4[e];
+          dq[r] += r1[r];
+          dot = fmaf(qv[r], dq[r], dot);
+          q2 = fmaf(qv[r], qv[r], q2);
         }
+      }
+      dot += __shfl_xor(dot, 32);
+      q2 += __shfl_xor(q2, 32);
+      const float pr = dot * rcp(fmaxf(q2, 1e-30f));
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)(a.scale * (dq[4 * q4 + e] - pr * qv[4 * q4 + e]));
+        *reinterpret_cast<bf16x4*>(drow + 8 * q4) = o4;
+      }
+    }
+    if (qt == 1) {     // hand the dk / dv partials to the qt = 0 wave of this key tile
+      float* red = sRedK + (kt * 2 + 0) * 64 * 17 + lane * 17;
+      float* red2 = sRedK + (kt * 2 + 1) * 64 * 17 + lane * 17;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red[r] = dk[r];
+        red2[r] = dv[r];
+      }
+    }
+    __syncthreads();
+    if (qt == 0 && jk < N) {
+      // dk_j = B_j - (k_j . B_j) / |k_j|^2 k_j, B_j = scale * sum_i W_ij q_i
+      const float* k1 = sRedK + (kt * 2 + 0) * 64 * 17 + lane * 17;
+      const float* v1 = sRedK + (kt * 2 + 1) * 64 * 17 + lane * 17;
+      const bf16_t* krow = qkv + (size_t)tkk.tok * a.ldq + a.C + h * AD + 4 * lh;
+      bf16_t* drow = dqkv + (size_t)tkk.tok * a.lddq + a.C + h * AD + 4 * lh;
+      float kv[16], dot = 0.f, k2 = 0.f;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(krow + 8 * q4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q4 + e;
+          kv[r] = (float)t4[e];
+          dk[r] = a.scale * (dk[r] + k1[r]);
+          dot = fmaf(kv[r], dk[r], dot);
+          k2 = fmaf(kv[r], kv[r], k2);
+        }
+      }
+      dot += __shfl_xor(dot, 32);
+      k2 += __shfl_xor(k2, 32);
+      const float pr = dot * rcp(fmaxf(k2, 1e-30f));
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        bf16x4 o4, o5;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o4[e] = (bf16_t)(dk[4 * q4 + e] - pr * kv[4 * q4 + e]);
+          o5[e] = (bf16_t)(dv[4 * q4 + e] + v1[4 * q4 + e]);
+        }
+        *reinterpret_cast<bf16x4*>(drow + 8 * q4) = o4;
+        *reinterpret_cast<bf16x4*>(drow + a.C + 8 * q4) = o5;
       }
     }
   }
@@ -944,8 +960,9 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   for (int r = 0; r < 16; ++r) {
     const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
     if (iq < N && j < N) {
+      const float tis = sTab[0][iq * ANS + j];
       part[iq * N + j] = accb[r];
-      part[N * N + iq * N + j] = acct[r];
+      part[N * N + iq * N + j] = tis > 0.f ? -acct[r] * tis * tis : 0.f;   // d/dtau of c / clip(tau, 0.01)
     }
   }
 }
@@ -1323,24 +1340,33 @@ int ln_its(const uz_ln_desc* d) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4, lpt = ln_lpt(d);
   return (d->C / vec + lpt - 1) / lpt;
 }
-int ln_unroll(const uz_ln_desc* d) { const int its = ln_its(d); return its == 1 ? 4 : its <= 3 ? 2 : 1; }
+int ln_unroll(const uz_ln_desc* d) {
+  const int its = ln_its(d);
+  if (its > 3) return 1;
+  if (its > 1) return 2;
+  // one chunk per lane: 8 tokens per lane group when that still leaves 4+ workgroups per CU
+  const long long P = (long long)d->N * d->Ho * d->Wo;
+  const int u = (int)((uz_tune_flags() >> 16) & 15);
+  if (u == 2 || u == 4 || u == 8) return u;
+  return P >= (long long)4 * (64 / ln_lpt(d)) * 8 * UZ_NUM_CU * 4 ? 8 : 4;
+}
 
 int ln_grid(const uz_ln_desc* d) {
   const int tpb = 4 * (64 / ln_lpt(d)) * ln_unroll(d);
-  return grid_cap((long long)d->N * d->Ho * d->Wo, tpb * 2, 8);
+  return grid_cap((long long)d->N * d->Ho * d->Wo, tpb, 8);
 }
 
 template <bool BWD>
 void ln_launch(const uz_ln_desc* d, dim3 grid, dim3 block, size_t shm, hipStream_t st, const LnArgs& a, int lpt) {
-  const int its = ln_its(d);
+  const int its = ln_its(d), u = ln_unroll(d);
 #define UZ_LN(T, I, U) hipLaunchKernelGGL((layernorm_kernel<T, BWD, I, U>), grid, block, shm, st, a, lpt)
   if (d->dtype == UZ_BF16) {
-    if (its == 1) UZ_LN(bf16_t, 1, 4);
+    if (its == 1) { if (u == 8) UZ_LN(bf16_t, 1, 8); else if (u == 4) UZ_LN(bf16_t, 1, 4); else UZ_LN(bf16_t, 1, 2); }
     else if (its == 2) UZ_LN(bf16_t, 2, 2);
     else if (its == 3) UZ_LN(bf16_t, 3, 2);
     else UZ_LN(bf16_t, 6, 1);
   } else {
-    if (its == 1) UZ_LN(float, 1, 4);
+    if (its == 1) { if (u == 8) UZ_LN(float, 1, 8); else if (u == 4) UZ_LN(float, 1, 4); else UZ_LN(float, 1, 2); }
     else if (its == 2) UZ_LN(float, 2, 2);
     else if (its == 3) UZ_LN(float, 3, 2);
     else UZ_LN(float, 6, 1);
@@ -1422,20 +1448,31 @@ static int attn_check(const char* fn, const uz_winattn_desc* d) {
   return UZ_OK;
 }
 
-static int attn_grid_x(const uz_winattn_desc* d) {
-  const long long nwin = (long long)d->B * (d->H / d->ws) * (d->W / d->ws);
-  long long g = (UZ_NUM_CU * 2 + d->heads - 1) / d->heads;
-  if (g > nwin) g = nwin;
-  if (g < 1) g = 1;
-  return (int)g;
+// Workgroups of the window-attention kernels stay resident for the whole launch (each walks its share of the
+// windows of one head), so the grid must FIT: one workgroup more than the chip holds doubles the run time.
+// slots = resident workgroups per CU of the kernel; windows are dealt evenly (per-workgroup count first).
+static int attn_grid_fit(const uz_winattn_desc* d, long long units_x, int slots_per_cu) {
+  const char* e = getenv("UZ_ATTN_GX");   // measurement hook (tools/attn_bench.py)
+  if (e && atoi(e) > 0) return (int)(atoi(e) < units_x ? atoi(e) : units_x);
+  long long cap = (long long)UZ_NUM_CU * slots_per_cu / d->heads;
+  if (cap < 1) cap = 1;
+  const long long per = (units_x + cap - 1) / cap;
+  const long long g = (units_x + per - 1) / per;
+  return (int)(g < 1 ? 1 : g);
 }
+static int attn_grid_x(const uz_winattn_desc* d, int slots_per_cu) {
+  return attn_grid_fit(d, (long long)d->B * (d->H / d->ws) * (d->W / d->ws), slots_per_cu);
+}
+// resident workgroups per CU (registers / LDS of the kernels below; check with the ISA when they change)
+constexpr int ATTN_SLOTS_FWD = 2;        // winattn_fwd_kernel: 186 VGPRs, 54 KB LDS
+constexpr int ATTN_SLOTS_FWD_MFMA = 1;   // winattn_fwd_mfma_kernel: 325 VGPRs
+constexpr int ATTN_SLOTS_BWD = 1;        // winattn_bwd_kernel: 152 KB LDS
+constexpr int ATTN_SLOTS_BWD_MFMA = 2;   // winattn_bwd_mfma_kernel: 256 VGPRs, 65 KB LDS
 
-// matrix-core kernels (bf16): one wave per (window, head), four per workgroup
+// forward matrix-core kernel (bf16): one wave per (window, head), four per workgroup
 static int attn_mfma_grid_x(const uz_winattn_desc* d) {
   const long long nwin = (long long)d->B * (d->H / d->ws) * (d->W / d->ws);
-  long long gx = (nwin + 3) / 4, cap = (UZ_NUM_CU * 2 + d->heads - 1) / d->heads;
-  if (gx > cap) gx = cap;
-  return (int)(gx < 1 ? 1 : gx);
+  return attn_grid_fit(d, (nwin + 3) / 4, ATTN_SLOTS_FWD_MFMA);
 }
 static bool attn_bwd_mfma(const uz_winattn_desc* d) { return d->dtype == UZ_BF16 && !(uz_tune_flags() & 0x2000); }
 
@@ -1448,7 +1485,7 @@ extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const f
   a.qkv = qkv; a.out = out; a.lse = lse; a.tau = tau; a.bias = bias;
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
   a.ldq = d->ldq; a.ldo = d->ldo; a.scale = d->scale;
-  const dim3 grid(attn_grid_x(d), d->heads), block(256);
+  const dim3 grid(attn_grid_x(d, ATTN_SLOTS_FWD), d->heads), block(256);
   if (d->dtype == UZ_BF16 && !(uz_tune_flags() & 0x1000)) {
     // matrix-core path: one wave per (window, head), four per workgroup
     hipLaunchKernelGGL(winattn_fwd_mfma_kernel, dim3(attn_mfma_grid_x(d), d->heads), dim3(256), 0, (hipStream_t)stream, a);
@@ -1464,7 +1501,7 @@ extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const f
 extern "C" int uz_winattn_bwd_rows(const uz_winattn_desc* d) {
   const int rc = attn_check("uz_winattn_bwd_rows", d);
   if (rc != UZ_OK) return rc;
-  return attn_grid_x(d);
+  return attn_grid_x(d, attn_bwd_mfma(d) ? ATTN_SLOTS_BWD_MFMA : ATTN_SLOTS_BWD);
 }
 
 extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
@@ -1480,7 +1517,7 @@ extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const f
   a.dout = dout; a.dqkv = dqkv; a.partial = partial;
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
   a.ldq = d->ldq; a.ldo = d->ldo; a.lddo = lddo; a.lddq = lddq; a.scale = d->scale;
-  const dim3 grid(attn_grid_x(d), d->heads), block(256);
+  const dim3 grid(attn_grid_x(d, attn_bwd_mfma(d) ? ATTN_SLOTS_BWD_MFMA : ATTN_SLOTS_BWD), d->heads), block(256);
   if (attn_bwd_mfma(d)) {
     hipLaunchKernelGGL(winattn_bwd_mfma_kernel, grid, block, 0, (hipStream_t)stream, a);
   } else if (d->dtype == UZ_BF16) {
