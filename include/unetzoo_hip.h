@@ -249,6 +249,10 @@ int uz_attn_bwd_apply(int dtype, const void* g1raw, int ldg, const void* x1raw, 
                       void* dg1raw, int lddg, void* dx1raw, int lddx, void* stream);
 /* out[e] (double) = sum over rows of partial[row][e] */
 int uz_sum_rows(const float* partial, int rows, int n, double* out, void* stream);
+/* the same sums (accumulated in double) rounded to fp32 and written where they are wanted: elements
+ * [0, n0) to out0, [n0, n) to out1 (NULL when n0 == n) -- e.g. the two halves of uz_layernorm_bwd()'s
+ * rows straight into the gradient tensors of weight and bias */
+int uz_sum_rows_f32(const float* partial, int rows, int n, float* out0, int n0, float* out1, void* stream);
 /* backward of nearest x2 upsampling: dx[coarse pixel] = sum of its 2x2 fine pixels (H, W coarse) */
 int uz_sum2x2(int dtype, const void* du, int ldu, int N, int H, int W, int C, void* dx, int lddx,
               void* stream);
@@ -346,8 +350,8 @@ int uz_cpb_fwd(const float* idx, const float* w1, const float* b1, const float* 
 int uz_cpb_bwd(const float* idx, const float* w1, const float* b1, const float* w2, const float* G, int R,
                int hidden, int heads, float* dw1, float* db1, float* dw2, float* db2, void* stream);
 int uz_winattn_bwd_rows(const uz_winattn_desc* d); /* rows of `partial`; <0 on error */
-/* dqkv (P, 3C) fully written; partial[row][heads][2][N][N]: sums over the row's windows of dS (-> d bias)
- * and of d tau (zero where tau < 0.01); add the rows with uz_sum_rows(). */
+/* dqkv (P, 3C) fully written; partial[row][2][heads][N][N]: sums over the row's windows of dS (-> d bias)
+ * and of d tau (zero where tau < 0.01); add the rows with uz_sum_rows() / uz_sum_rows_f32(). */
 int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias,
                    const void* out, const float* lse, const void* dout, int lddo, void* dqkv, int lddq,
                    float* partial, void* stream);

@@ -27,7 +27,7 @@ EXPORTS = (
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_colsum",
     "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd", "uz_attn_bwd_psi", "uz_attn_bwd_reduce",
-    "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum2x2",
+    "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum_rows_f32", "uz_sum2x2",
     "uz_bn_relu_add_apply", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_pool_grad_combine",
     "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
@@ -144,6 +144,7 @@ def load():
     lib.uz_attn_bwd_apply.argtypes = [ip, vp, ip, vp, ip, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, vp, ip,
                                       vp, ip, vp]
     lib.uz_sum_rows.argtypes = [vp, ip, ip, vp, vp]
+    lib.uz_sum_rows_f32.argtypes = [vp, ip, ip, vp, ip, vp, vp]
     lib.uz_sum2x2.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, vp]
     ll = ctypes.c_longlong
     lib.uz_bn_relu_add_apply.argtypes = [ip, vp, ip, vp, vp, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, ip, vp]

@@ -306,7 +306,7 @@ struct AttnArgs {
   const float* bias;  // [heads][N][N]
   const void* dout;   // bwd: gradient of out [P][C]
   void* dqkv;         // bwd: gradient of qkv [P][3C]
-  float* partial;     // bwd: [gridDim.x][heads][2][N][N] sums of dS (dbias) and d(tau)
+  float* partial;     // bwd: [gridDim.x][2][heads][N][N] sums of dS (dbias) and d(tau)
   int B, H, W, C, heads, ws, shift, Nt;
   int ldq, ldo, lddo, lddq;
   float scale;
@@ -955,14 +955,15 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       }
     }
   }
-  float* part = a.partial + ((size_t)blockIdx.x * a.heads + h) * 2 * N * N;
+  float* part = a.partial + ((size_t)blockIdx.x * 2 * a.heads + h) * N * N;   // [row][2][heads][N][N]
+  const size_t tau_off = (size_t)a.heads * N * N;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
     if (iq < N && j < N) {
       const float tis = sTab[0][iq * ANS + j];
       part[iq * N + j] = accb[r];
-      part[N * N + iq * N + j] = tis > 0.f ? -acct[r] * tis * tis : 0.f;   // d/dtau of c / clip(tau, 0.01)
+      part[tau_off + iq * N + j] = tis > 0.f ? -acct[r] * tis * tis : 0.f;   // d/dtau of c / clip(tau, 0.01)
     }
   }
 }
@@ -1156,11 +1157,12 @@ __global__ __launch_bounds__(256) void winattn_bwd_kernel(const AttnArgs a) {
     }
   }
   __syncthreads();
-  float* part = a.partial + ((size_t)blockIdx.x * a.heads + h) * 2 * N * N;
+  float* part = a.partial + ((size_t)blockIdx.x * 2 * a.heads + h) * N * N;   // [row][2][heads][N][N]
+  const size_t tau_off = (size_t)a.heads * N * N;
   for (int e = tid; e < N * N; e += 256) {
     const int r = e / N, c = e - r * N;
     part[e] = sDB[r * ANS + c];
-    part[N * N + e] = sDT[r * ANS + c];
+    part[tau_off + e] = sDT[r * ANS + c];
   }
 }
 // (Measured and rejected: keeping the tau / bias values and the d(bias) / d(tau) sums of a lane's 16 keys in
@@ -1344,11 +1346,12 @@ int ln_unroll(const uz_ln_desc* d) {
   const int its = ln_its(d);
   if (its > 3) return 1;
   if (its > 1) return 2;
-  // one chunk per lane: 8 tokens per lane group when that still leaves 4+ workgroups per CU
+  // one chunk per lane.  Measured on the 1M-token expand LayerNorm of swin_unet_v2 (201 MB in, 201 MB out):
+  // U = 2 / 4 / 8 -> 156 / 168 / 207 us forward (occupancy beats bytes per wave); at 65k tokens U = 4 wins.
   const long long P = (long long)d->N * d->Ho * d->Wo;
   const int u = (int)((uz_tune_flags() >> 16) & 15);
   if (u == 2 || u == 4 || u == 8) return u;
-  return P >= (long long)4 * (64 / ln_lpt(d)) * 8 * UZ_NUM_CU * 4 ? 8 : 4;
+  return P >= (long long)4 * (64 / ln_lpt(d)) * 4 * UZ_NUM_CU * 8 ? 2 : 4;
 }
 
 int ln_grid(const uz_ln_desc* d) {

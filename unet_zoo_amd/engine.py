@@ -448,7 +448,7 @@ class Engine:
                 if g is None:
                     return
                 if lin.bias is not None:
-                    self._give_grad(lin.bias, ops.colsum(g))
+                    self._give_grad(lin.bias, ops.colsum(g, self._dst(lin.bias)))
                 self._give_grad(lin.weight, ops.wgrad(g, x, tuple(lin.weight.shape), ntaps=1,
                                                       out=self._dst(lin.weight)))
                 if x.needs_grad:
@@ -510,7 +510,8 @@ class Engine:
                     residual.add_grad(g)
                 dx = self.new_act(x.N, x.H, x.W, x.C)
                 dgam, dbet = ops.layernorm_bwd(x, gamma, stats, g, dx, mode=mode, r=r, eps=ln.eps,
-                                               image_scale=image_scale)
+                                               image_scale=image_scale, dgamma=self._dst(ln.weight),
+                                               dbeta=self._dst(ln.bias))
                 self._give_grad(ln.weight, dgam)
                 self._give_grad(ln.bias, dbet)
                 if x.needs_grad:
@@ -537,7 +538,7 @@ class Engine:
                 if g is None:
                     return
                 if conv.bias is not None:
-                    self._give_grad(conv.bias, ops.colsum(g))
+                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
                 dwp = ops.wgrad(g, p, (conv.out_channels, kpad), ntaps=1)
                 dw = dwp[:, :K].reshape(conv.out_channels, ps * ps, conv.in_channels).permute(0, 2, 1)
                 self._give_grad(conv.weight, dw.reshape(conv.weight.shape).contiguous())
@@ -567,18 +568,20 @@ class Engine:
                 if g is None:
                     return
                 dqkv = self.new_act(qkv.N, qkv.H, qkv.W, qkv.C)
-                dbias, dtau = ops.winattn_bwd(qkv, tau, bias, o, lse, g, dqkv, heads, ws, shift)
+                whole = tuple(attn.tau.shape) == (heads, N, N)
+                dbias, dtau = ops.winattn_bwd(qkv, tau, bias, o, lse, g, dqkv, heads, ws, shift,
+                                              dtau=self._dst(attn.tau) if whole else None)
                 qkv.add_grad(dqkv)
-                if dtau.shape != attn.tau.shape:                               # window clipped to the map size
+                if not whole:                                                   # window clipped to the map size
                     full = torch.zeros_like(attn.tau)
                     full[:, :N, :N] = dtau
                     dtau = full
-                self._give_grad(attn.tau, dtau.contiguous())
+                self._give_grad(attn.tau, dtau)
                 gs = []
                 for p_ in (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias):
                     d_ = self._dst(p_)
                     gs.append(d_ if d_ is not None else torch.empty(p_.shape, dtype=torch.float32, device=self.device))
-                ops.cpb_bwd(idx, w1, b1, w2, dbias.reshape(heads, N * N).contiguous(), *gs)
+                ops.cpb_bwd(idx, w1, b1, w2, dbias.view(heads, N * N), *gs)
                 for p_, g_ in zip((cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias), gs):
                     self._give_grad(p_, g_)
 

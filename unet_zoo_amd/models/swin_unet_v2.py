@@ -52,8 +52,26 @@ class DropPath(nn.Module):
     def factor(self, batch: int, device, training: bool) -> Optional[torch.Tensor]:
         if self.drop_prob == 0.0 or not training:
             return None
+        drawn, self._drawn = getattr(self, "_drawn", None), None
+        if drawn is not None and drawn.shape[0] == batch:
+            return drawn                                     # this forward's row of draw_all()
         keep = 1.0 - self.drop_prob
         return torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep) / keep
+
+    @staticmethod
+    def draw_all(root: nn.Module, batch: int, device, training: bool) -> None:
+        """One Bernoulli draw for every DropPath under `root` (independent per layer and sample, as in the
+        reference) instead of two tiny kernels per block: each module picks its row up in factor()."""
+        mods = [m for m in root.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0]
+        if not mods or not training:
+            return
+        cache = getattr(root, "_drop_path_keep", None)
+        if cache is None or cache.device != torch.device(device) or cache.shape[0] != len(mods):
+            cache = torch.tensor([1.0 - m.drop_prob for m in mods], dtype=torch.float32, device=device).view(-1, 1)
+            root._drop_path_keep = cache
+        f = torch.bernoulli(cache.expand(len(mods), batch)) / cache
+        for i, m in enumerate(mods):
+            m._drawn = f[i]
 
 
 class Mlp(nn.Module):
@@ -336,6 +354,7 @@ class SwinTransformerSys(HipModule):
         cats: List = []
         for lvl in range(nl - 1):
             cats.append(eng.new_cat(N, R[0] >> lvl, R[1] >> lvl, (E << lvl, E << lvl)))
+        DropPath.draw_all(self, N, eng.device, eng.training)
         t = self.patch_embed.emit(eng, x, out=cats[0][1][1])
         for i, layer in enumerate(self.layers):                 # forward_features (:711-723)
             nxt = cats[i + 1][1][1] if i + 1 < nl - 1 else None  # stage i's output is stage i+1's skip

@@ -356,11 +356,13 @@ def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act],
     return dw.view(K, x.C), db
 
 
-def colsum(x: Act) -> torch.Tensor:
+def colsum(x: Act, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """per-channel sums over the pixels / tokens (fp32), deterministic two-stage reduction"""
     lib = L.load()
     code = L.dtype_code(x.dtype)
-    out = torch.empty(x.C, dtype=torch.float32, device=x.buf.device)
+    if out is None:
+        out = torch.empty(x.C, dtype=torch.float32, device=x.buf.device)
+    assert out.numel() == x.C and out.dtype == torch.float32 and out.is_contiguous()
     wsb = L.check_count(lib.uz_colsum_workspace_bytes(code, x.P, x.C), "uz_colsum_workspace_bytes")
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.buf.device)
     with _Timed("colsum", 0.0, x.buf.element_size() * x.P * x.C):
@@ -375,6 +377,17 @@ def sum_rows(partial: torch.Tensor, rows: int, n: int) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.float64, device=partial.device)
     L.check(L.load().uz_sum_rows(partial.data_ptr(), rows, n, out.data_ptr(), L.stream_ptr()), "uz_sum_rows")
     return out
+
+
+def sum_rows_f32(partial: torch.Tensor, rows: int, out0: torch.Tensor, out1: Optional[torch.Tensor] = None) -> None:
+    """fp32 row sums written in place: the first out0.numel() elements to out0, the rest to out1"""
+    n0 = out0.numel()
+    n = n0 + (out1.numel() if out1 is not None else 0)
+    assert partial.numel() == rows * n and partial.dtype == torch.float32
+    for o in (out0, out1):
+        assert o is None or (o.dtype == torch.float32 and o.is_contiguous())
+    L.check(L.load().uz_sum_rows_f32(partial.data_ptr(), rows, n, out0.data_ptr(), n0,
+                                     out1.data_ptr() if out1 is not None else None, L.stream_ptr()), "uz_sum_rows_f32")
 
 
 def attn_grid(dtype: torch.dtype, P: int, channels: int) -> int:
@@ -564,8 +577,9 @@ def layernorm_fwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, out: Act, *, 
 
 
 def layernorm_bwd(x: Act, gamma: torch.Tensor, stats: torch.Tensor, g: Act, dx: Act, *, mode: int = L.LN_PLAIN,
-                  r: int = 1, eps: float = 1e-5, image_scale: Optional[torch.Tensor] = None):
-    """returns (dgamma, dbeta) fp32; dx is written with x's addressing"""
+                  r: int = 1, eps: float = 1e-5, image_scale: Optional[torch.Tensor] = None,
+                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None):
+    """returns (dgamma, dbeta) fp32 (written into the given tensors when passed); dx is written with x's addressing"""
     lib = L.load()
     d = _ln_desc(x, g.N, g.H, g.W, g.C, mode, r, eps, ldg=g.ld, lddx=dx.ld)
     rows = L.check_count(lib.uz_layernorm_bwd_rows(byref(d)), "uz_layernorm_bwd_rows")
@@ -574,8 +588,12 @@ def layernorm_bwd(x: Act, gamma: torch.Tensor, stats: torch.Tensor, g: Act, dx: 
     with _Timed("layernorm_bwd", 0.0, es * g.P * g.C * 3):
         L.check(lib.uz_layernorm_bwd(byref(d), x.ptr(), gamma.data_ptr(), stats.data_ptr(), g.ptr(), _p(image_scale),
                                      dx.ptr(), part.data_ptr(), L.stream_ptr()), "uz_layernorm_bwd")
-    tot = sum_rows(part, rows, 2 * g.C).float()
-    return tot[:g.C], tot[g.C:]
+    if dgamma is None:
+        dgamma = torch.empty(g.C, dtype=torch.float32, device=x.buf.device)
+    if dbeta is None:
+        dbeta = torch.empty(g.C, dtype=torch.float32, device=x.buf.device)
+    sum_rows_f32(part, rows, dgamma, dbeta)
+    return dgamma, dbeta
 
 
 def _attn_desc(qkv: Act, heads: int, ws: int, shift: int, Nt: int, ldo: int):
@@ -596,19 +614,23 @@ def winattn_fwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, heads
 
 
 def winattn_bwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, lse: torch.Tensor, dout: Act, dqkv: Act,
-                heads: int, ws: int, shift: int):
-    """returns (dbias, dtau) as (heads, N, N) fp32"""
+                heads: int, ws: int, shift: int, dtau: Optional[torch.Tensor] = None):
+    """returns (dbias, dtau) as (heads, N, N) fp32; dtau is written into the given tensor when passed"""
     lib = L.load()
     d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld)
     rows = L.check_count(lib.uz_winattn_bwd_rows(byref(d)), "uz_winattn_bwd_rows")
     N = ws * ws
-    part = torch.empty((rows, heads, 2, N, N), dtype=torch.float32, device=qkv.buf.device)
+    part = torch.empty((rows, 2, heads, N, N), dtype=torch.float32, device=qkv.buf.device)
     with _Timed("winattn_bwd", 10.0 * qkv.P * N * out.C, qkv.buf.element_size() * qkv.P * out.C * 8):
         L.check(lib.uz_winattn_bwd(byref(d), qkv.ptr(), tau.data_ptr(), bias.data_ptr(), out.ptr(), lse.data_ptr(),
                                    dout.ptr(), dout.ld, dqkv.ptr(), dqkv.ld, part.data_ptr(), L.stream_ptr()),
                 "uz_winattn_bwd")
-    tot = sum_rows(part, rows, heads * 2 * N * N).float().view(heads, 2, N, N)
-    return tot[:, 0], tot[:, 1]
+    dbias = torch.empty((heads, N, N), dtype=torch.float32, device=qkv.buf.device)
+    if dtau is None:
+        dtau = torch.empty((heads, N, N), dtype=torch.float32, device=qkv.buf.device)
+    assert dtau.shape == (heads, N, N)
+    sum_rows_f32(part, rows, dbias, dtau)
+    return dbias, dtau
 
 
 def cpb_fwd(idx: torch.Tensor, w1, b1, w2, b2) -> torch.Tensor:
