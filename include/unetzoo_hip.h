@@ -349,6 +349,26 @@ int uz_cpb_fwd(const float* idx, const float* w1, const float* b1, const float* 
                int hidden, int heads, float* bias, void* stream);
 int uz_cpb_bwd(const float* idx, const float* w1, const float* b1, const float* w2, const float* G, int R,
                int hidden, int heads, float* dw1, float* db1, float* dw2, float* db2, void* stream);
+/* All position-bias MLPs of a model in one launch each way (they depend on parameters only: forward at the
+ * start of the step, backward once every d bias is known).  Forward reads idx, w1, b1, w2, b2 and writes
+ * bias; backward reads idx, w1, b1, w2, G and overwrites dw1, db1, dw2, db2 (unused pointers may be NULL). */
+typedef struct {
+  const float* idx;      /* (R, 2) */
+  const float* w1;       /* (hidden, 2) */
+  const float* b1;       /* (hidden) */
+  const float* w2;       /* (heads, hidden) */
+  const float* b2;       /* (heads) */
+  int R, hidden, heads, reserved;
+  float* bias;           /* forward out (heads, R) */
+  const float* G;        /* backward in (heads, R) */
+  float* dw1;
+  float* db1;
+  float* dw2;
+  float* db2;
+} uz_cpb_item;
+int uz_cpb_fwd_batched(const uz_cpb_item* items, int n, void* stream);
+long long uz_cpb_bwd_batched_workspace_bytes(const uz_cpb_item* items, int n);
+int uz_cpb_bwd_batched(const uz_cpb_item* items, int n, float* workspace, void* stream);
 int uz_winattn_bwd_rows(const uz_winattn_desc* d); /* rows of `partial`; <0 on error */
 /* dqkv (P, 3C) fully written; partial[row][2][heads][N][N]: sums over the row's windows of dS (-> d bias)
  * and of d tau (zero where tau < 0.01); add the rows with uz_sum_rows() / uz_sum_rows_f32(). */

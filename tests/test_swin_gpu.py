@@ -337,3 +337,38 @@ def test_continuous_position_bias_mlp(heads, N):
     ops.cpb_bwd(d[0], d[1], d[2], d[3], G.to(DEV).contiguous(), *outs)
     for got, want in zip(outs, (w1.grad, b1.grad, w2.grad, b2.grad)):
         assert relerr(got.cpu(), want) < 1e-5
+
+
+def test_continuous_position_bias_batched_launch():
+    """uz_cpb_fwd_batched / uz_cpb_bwd_batched: every module of a model in one launch each way; mixed head
+    counts, table sizes (ragged last row block) and hidden widths against autograd"""
+    g = torch.Generator().manual_seed(53)
+    mods, refs = [], []
+    for heads, N, hidden in [(3, 64, 256), (24, 4, 256), (6, 49, 256), (12, 64, 256), (5, 20, 96), (32, 9, 512)]:
+        R = N * N
+        idx = torch.randn(R, 2, generator=g)
+        w1 = torch.randn(hidden, 2, generator=g).requires_grad_(True)
+        b1 = (torch.randn(hidden, generator=g) * 0.5).requires_grad_(True)
+        w2 = (torch.randn(heads, hidden, generator=g) * 0.1).requires_grad_(True)
+        b2 = torch.randn(heads, generator=g).requires_grad_(True)
+        G = torch.randn(heads, R, generator=g)
+        ref = F.linear(F.relu(F.linear(idx, w1, b1)), w2, b2).t()
+        ref.backward(G)
+        refs.append((ref.detach(), w1.grad, b1.grad, w2.grad, b2.grad))
+        m = {k: t.detach().to(DEV).contiguous() for k, t in (("idx", idx), ("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("G", G))}
+        m["bias"] = torch.full((heads, R), float("nan"), device=DEV)
+        for k, t in (("dw1", w1), ("db1", b1), ("dw2", w2), ("db2", b2)):
+            m[k] = torch.full(t.shape, float("nan"), device=DEV)
+        mods.append(m)
+    ops.cpb_fwd_batched(mods)
+    ops.cpb_bwd_batched(mods)
+    for m, (bias, dw1, db1, dw2, db2) in zip(mods, refs):
+        assert relerr(m["bias"].cpu(), bias) < 2e-6
+        for k, want in (("dw1", dw1), ("db1", db1), ("dw2", dw2), ("db2", db2)):
+            assert relerr(m[k].cpu(), want) < 1e-5, k
+    # the same numbers as the per-module entry points (different summation order only)
+    one = mods[0]
+    single = [torch.empty_like(one[k]) for k in ("dw1", "db1", "dw2", "db2")]
+    ops.cpb_bwd(one["idx"], one["w1"], one["b1"], one["w2"], one["G"], *single)
+    for k, t in zip(("dw1", "db1", "dw2", "db2"), single):
+        assert relerr(one[k], t) < 1e-5

@@ -35,6 +35,7 @@ EXPORTS = (
     "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd",
     "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
     "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_cpb_fwd", "uz_cpb_bwd",
+    "uz_cpb_fwd_batched", "uz_cpb_bwd_batched_workspace_bytes", "uz_cpb_bwd_batched",
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
 )
 
@@ -66,6 +67,13 @@ class WinAttnDesc(Structure):
 
 
 LN_PLAIN, LN_MERGE, LN_EXPAND = 0, 1, 2
+
+
+class CpbItem(Structure):
+    """uz_cpb_item: one continuous-position-bias MLP of a batched launch"""
+    _fields_ = [(n, c_void_p) for n in ("idx", "w1", "b1", "w2", "b2")] \
+        + [(n, c_int) for n in ("R", "hidden", "heads", "reserved")] \
+        + [(n, c_void_p) for n in ("bias", "G", "dw1", "db1", "dw2", "db2")]
 
 
 class PackItem(Structure):
@@ -113,6 +121,9 @@ def load():
     lib.uz_winattn_bwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp]
     lib.uz_cpb_fwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp]
     lib.uz_cpb_bwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp]
+    lib.uz_cpb_fwd_batched.argtypes = [vp, ip, vp]
+    lib.uz_cpb_bwd_batched_workspace_bytes.argtypes = [vp, ip]
+    lib.uz_cpb_bwd_batched.argtypes = [vp, ip, vp, vp]
     lib.uz_clip_adamw_workspace_bytes.argtypes = []
     lib.uz_clip_adamw.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, fp, fp, fp, fp, fp, fp, vp, vp, vp]
     lib.uz_wgrad_split.argtypes = [POINTER(WgradDesc)]

@@ -1305,6 +1305,134 @@ __global__ __launch_bounds__(1024) void cpb_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- all position-bias MLPs of a model in one launch ------------------------------------------------
+// The MLPs are tiny (R <= 4096 offsets, 256 hidden units, <= 32 heads) and a function of parameters only, so
+// a model's 14 of them are evaluated together at the start of the forward and differentiated together at the
+// end of the backward: 2 + 1 launches instead of 28, and the backward reads each G once (cpb_bwd_kernel above
+// re-reads it per hidden unit: 22 us per module, bound by L2).
+constexpr int CPB_MAXB = 24;     // modules per launch (the descriptor array travels in the kernel arguments)
+constexpr int CPB_ROWS = 128;    // offsets per workgroup of the batched backward
+struct CpbBatch {
+  uz_cpb_item it[CPB_MAXB];
+  long long off[CPB_MAXB];       // float offset of the module's partial sums in the workspace
+};
+
+__global__ __launch_bounds__(256) void cpb_fwd_batched_kernel(const CpbBatch b) {
+  __shared__ float4 sW[CPB_MAXHID];  // (w1[k][0], w1[k][1], b1[k], w2[h][k])
+  const uz_cpb_item& m = b.it[blockIdx.z];
+  const int h = blockIdx.y, R = m.R, hidden = m.hidden;
+  if (h >= m.heads || (int)(blockIdx.x * 256) >= R) return;   // whole workgroups
+  for (int k = threadIdx.x; k < hidden; k += 256)
+    sW[k] = make_float4(m.w1[2 * k], m.w1[2 * k + 1], m.b1[k], m.w2[h * hidden + k]);
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float x0 = m.idx[2 * r], x1 = m.idx[2 * r + 1];
+  float acc = m.b2[h];
+#pragma unroll 8
+  for (int k = 0; k < hidden; ++k) {
+    const float4 wv = sW[k];
+    acc = fmaf(wv.w, fmaxf(fmaf(wv.x, x0, fmaf(wv.y, x1, wv.z)), 0.f), acc);
+  }
+  m.bias[(size_t)h * R + r] = acc;
+}
+
+// grid (row blocks, modules), 512 threads: thread = hidden unit k (512 / hidden groups split the block's rows).
+// Partial sums per (row block, group): [(heads + 3)][hidden] = d w2[h][k] (heads), d w1[k][0], d w1[k][1], d b1[k];
+// per row block: [heads] sums of G (d b2).  cpb_bwd_finalize_kernel adds them in a fixed order.
+__global__ __launch_bounds__(512) void cpb_bwd_batched_kernel(const CpbBatch b, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float sG[CPB_ROWS][CPB_MAXH];
+  __shared__ float sX[CPB_ROWS][2];
+  const uz_cpb_item& m = b.it[blockIdx.y];
+  const int R = m.R, hidden = m.hidden, heads = m.heads, tid = threadIdx.x;
+  const int r0 = blockIdx.x * CPB_ROWS;
+  if (r0 >= R) return;
+  const int hp = (heads + 3) & ~3;
+  for (int e = tid; e < CPB_ROWS * hp; e += 512) {
+    const int h = e / CPB_ROWS, r = e - h * CPB_ROWS;
+    sG[r][h] = (h < heads && r0 + r < R) ? m.G[(size_t)h * R + r0 + r] : 0.f;
+  }
+  for (int e = tid; e < CPB_ROWS; e += 512) {
+    const bool in = r0 + e < R;
+    sX[e][0] = in ? m.idx[2 * (r0 + e)] : 0.f;
+    sX[e][1] = in ? m.idx[2 * (r0 + e) + 1] : 0.f;
+  }
+  __syncthreads();
+  const int nsub = 512 / hidden, RB = (R + CPB_ROWS - 1) / CPB_ROWS;
+  const int nmain = (heads + 3) * hidden;
+  float* main_ws = ws + b.off[blockIdx.y];
+  if (tid < heads) {   // d b2 partial of this row block
+    float t = 0.f;
+    for (int r = 0; r < CPB_ROWS; ++r) t += sG[r][tid];
+    main_ws[(size_t)RB * nsub * nmain + (size_t)blockIdx.x * heads + tid] = t;
+  }
+  const int sub = tid / hidden, k = tid - sub * hidden;
+  if (sub >= nsub) return;
+  const int rows_per = CPB_ROWS / nsub + (CPB_ROWS % nsub != 0);
+  const int rb = sub * rows_per, re = min(rb + rows_per, CPB_ROWS);
+  const float wa = m.w1[2 * k], wb = m.w1[2 * k + 1], bk = m.b1[k];
+  float w2c[CPB_MAXH], a2[CPB_MAXH];
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h) {
+    w2c[h] = h < heads ? m.w2[h * hidden + k] : 0.f;
+    a2[h] = 0.f;
+  }
+  float a10 = 0.f, a11 = 0.f, ab = 0.f;
+  for (int r = rb; r < re; ++r) {
+    const float x0 = sX[r][0], x1 = sX[r][1];
+    const float pre = fmaf(wa, x0, fmaf(wb, x1, bk));
+    const float hv = fmaxf(pre, 0.f);
+    float gs = 0.f;
+#pragma unroll
+    for (int h4 = 0; h4 < CPB_MAXH / 4; ++h4)
+      if (4 * h4 < hp) {
+        const float4 g = *reinterpret_cast<const float4*>(&sG[r][4 * h4]);
+        gs = fmaf(g.x, w2c[4 * h4], gs);
+        gs = fmaf(g.y, w2c[4 * h4 + 1], gs);
+        gs = fmaf(g.z, w2c[4 * h4 + 2], gs);
+        gs = fmaf(g.w, w2c[4 * h4 + 3], gs);
+        a2[4 * h4] = fmaf(g.x, hv, a2[4 * h4]);
+        a2[4 * h4 + 1] = fmaf(g.y, hv, a2[4 * h4 + 1]);
+        a2[4 * h4 + 2] = fmaf(g.z, hv, a2[4 * h4 + 2]);
+        a2[4 * h4 + 3] = fmaf(g.w, hv, a2[4 * h4 + 3]);
+      }
+    const float dl = pre > 0.f ? gs : 0.f;
+    a10 = fmaf(dl, x0, a10);
+    a11 = fmaf(dl, x1, a11);
+    ab += dl;
+  }
+  float* row = main_ws + ((size_t)blockIdx.x * nsub + sub) * nmain;
+#pragma unroll
+  for (int h = 0; h < CPB_MAXH; ++h)
+    if (h < heads) row[h * hidden + k] = a2[h];
+  row[heads * hidden + k] = a10;
+  row[(heads + 1) * hidden + k] = a11;
+  row[(heads + 2) * hidden + k] = ab;
+}
+
+__global__ __launch_bounds__(256) void cpb_bwd_finalize_kernel(const CpbBatch b, const float* __restrict__ ws) {
+  const uz_cpb_item& m = b.it[blockIdx.y];
+  const int hidden = m.hidden, heads = m.heads;
+  const int nsub = 512 / hidden, RB = (m.R + CPB_ROWS - 1) / CPB_ROWS, rows = RB * nsub;
+  const int nmain = (heads + 3) * hidden;
+  const float* main_ws = ws + b.off[blockIdx.y];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < nmain) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += main_ws[(size_t)r * nmain + e];
+    const int j = e / hidden, k = e - j * hidden;
+    if (j < heads) m.dw2[j * hidden + k] = t;
+    else if (j == heads) m.dw1[2 * k] = t;
+    else if (j == heads + 1) m.dw1[2 * k + 1] = t;
+    else m.db1[k] = t;
+  } else if (e - nmain < heads) {
+    const float* tail = main_ws + (size_t)rows * nmain;
+    float t = 0.f;
+    for (int r = 0; r < RB; ++r) t += tail[(size_t)r * heads + (e - nmain)];
+    m.db2[e - nmain] = t;
+  }
+}
+
 inline int grid_cap(long long units, int per_block, int per_cu) {
   long long g = (units + per_block - 1) / per_block;
   const long long cap = (long long)UZ_NUM_CU * per_cu;
@@ -1557,5 +1685,79 @@ extern "C" int uz_cpb_bwd(const float* idx, const float* w1, const float* b1, co
   hipLaunchKernelGGL(cpb_bwd_kernel, dim3(uz_cdiv(hidden, CPB_KB)), dim3(64 * CPB_NW), 0, (hipStream_t)stream, idx, w1, b1, w2, G,
                      R, hidden, heads, dw1, db1, dw2, db2);
   UZ_LAUNCH_CHECK("uz_cpb_bwd");
+  return UZ_OK;
+}
+
+static long long cpb_item_ws_floats(const uz_cpb_item* m) {
+  const long long nsub = 512 / m->hidden, RB = (m->R + CPB_ROWS - 1) / CPB_ROWS;
+  return RB * nsub * (long long)(m->heads + 3) * m->hidden + RB * m->heads;
+}
+
+static int cpb_batch_check(const char* fn, const uz_cpb_item* items, int n, bool bwd) {
+  UZ_REQUIRE(items != nullptr && n > 0, "%s: empty batch", fn);
+  for (int i = 0; i < n; ++i) {
+    const uz_cpb_item* m = items + i;
+    const int rc = cpb_check(fn, m->R, m->hidden, m->heads);
+    if (rc != UZ_OK) return rc;
+    UZ_REQUIRE(m->idx && m->w1 && m->b1 && m->w2, "%s: item %d: null pointer", fn, i);
+    if (bwd) UZ_REQUIRE(m->G && m->dw1 && m->db1 && m->dw2 && m->db2, "%s: item %d: null gradient pointer", fn, i);
+    else UZ_REQUIRE(m->b2 && m->bias, "%s: item %d: null pointer", fn, i);
+  }
+  return UZ_OK;
+}
+
+extern "C" int uz_cpb_fwd_batched(const uz_cpb_item* items, int n, void* stream) {
+  const int rc = cpb_batch_check("uz_cpb_fwd_batched", items, n, false);
+  if (rc != UZ_OK) return rc;
+  for (int i0 = 0; i0 < n; i0 += CPB_MAXB) {
+    const int nb = n - i0 < CPB_MAXB ? n - i0 : CPB_MAXB;
+    CpbBatch b{};
+    int rmax = 0, hmax = 0;
+    for (int i = 0; i < nb; ++i) {
+      b.it[i] = items[i0 + i];
+      rmax = items[i0 + i].R > rmax ? items[i0 + i].R : rmax;
+      hmax = items[i0 + i].heads > hmax ? items[i0 + i].heads : hmax;
+    }
+    hipLaunchKernelGGL(cpb_fwd_batched_kernel, dim3(uz_cdiv(rmax, 256), hmax, nb), dim3(256), 0, (hipStream_t)stream, b);
+    UZ_LAUNCH_CHECK("uz_cpb_fwd_batched");
+  }
+  return UZ_OK;
+}
+
+extern "C" long long uz_cpb_bwd_batched_workspace_bytes(const uz_cpb_item* items, int n) {
+  UZ_REQUIRE(items != nullptr && n > 0, "uz_cpb_bwd_batched_workspace_bytes: empty batch");
+  long long tot = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = cpb_check("uz_cpb_bwd_batched_workspace_bytes", items[i].R, items[i].hidden, items[i].heads);
+    if (rc != UZ_OK) return rc;
+    tot += cpb_item_ws_floats(items + i);
+  }
+  return tot * (long long)sizeof(float);
+}
+
+extern "C" int uz_cpb_bwd_batched(const uz_cpb_item* items, int n, float* workspace, void* stream) {
+  const int rc = cpb_batch_check("uz_cpb_bwd_batched", items, n, true);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(workspace != nullptr, "uz_cpb_bwd_batched: null workspace");
+  long long off = 0;
+  for (int i0 = 0; i0 < n; i0 += CPB_MAXB) {
+    const int nb = n - i0 < CPB_MAXB ? n - i0 : CPB_MAXB;
+    CpbBatch b{};
+    int rmax = 0, omax = 0;
+    for (int i = 0; i < nb; ++i) {
+      const uz_cpb_item& m = items[i0 + i];
+      b.it[i] = m;
+      b.off[i] = off;
+      off += cpb_item_ws_floats(&m);
+      rmax = m.R > rmax ? m.R : rmax;
+      const int outs = (m.heads + 3) * m.hidden + m.heads;
+      omax = outs > omax ? outs : omax;
+    }
+    hipLaunchKernelGGL(cpb_bwd_batched_kernel, dim3(uz_cdiv(rmax, CPB_ROWS), nb), dim3(512), 0, (hipStream_t)stream, b, workspace);
+    UZ_LAUNCH_CHECK("uz_cpb_bwd_batched");
+    hipLaunchKernelGGL(cpb_bwd_finalize_kernel, dim3(uz_cdiv(omax, 256), nb), dim3(256), 0, (hipStream_t)stream, b,
+                       (const float*)workspace);
+    UZ_LAUNCH_CHECK("uz_cpb_bwd_batched (finalize)");
+  }
   return UZ_OK;
 }

@@ -128,6 +128,7 @@ class Engine:
         self._heads: List[Tuple[Callable[..., None], int]] = []   # (backward fn, number of outputs)
         # (tape position, parameter) in the order gradients are produced; position len(tape) = heads
         self.grad_log: List[Tuple[int, nn.Parameter]] = []
+        self._cpb: Dict[nn.Module, dict] = {}     # position_biases(): WindowAttention module -> batched entry
         self._cur_entry = -1
 
     # ------------------------------------------------------------------ buffers
@@ -546,6 +547,43 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    def position_biases(self, attns: Sequence[Tuple[nn.Module, int]]) -> None:
+        """Evaluate the continuous position bias of every (WindowAttention module, window_size) pair in one
+        launch (they depend on parameters only) and, through the tape entry appended here -- the last one the
+        backward reaches --, differentiate them in one launch once every attention has left its d(bias).
+        window_attention() picks the results up; modules not announced here keep their own launches."""
+        mods = []
+        for attn, ws in attns:
+            N = ws * ws
+            cpb = attn.cpb
+            heads = cpb.fc2.out_features
+            idx = attn.log_relative_position_index[:N, :N].reshape(N * N, 2).contiguous()
+            m = {"N": N, "attn": attn, "idx": idx, "w1": cpb.fc1.weight.detach(), "b1": cpb.fc1.bias.detach(),
+                 "w2": cpb.fc2.weight.detach(), "b2": cpb.fc2.bias.detach(),
+                 "bias": torch.empty((heads, N * N), dtype=torch.float32, device=self.device)}
+            mods.append(m)
+            self._cpb[attn] = m
+        if not mods:
+            return
+        ops.cpb_fwd_batched(mods)
+        if self.record:
+            def bwd():
+                live = [m for m in mods if m.get("G") is not None]
+                for m in live:
+                    cpb = m["attn"].cpb
+                    m["params"] = (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias)
+                    for name, p_ in zip(("dw1", "db1", "dw2", "db2"), m["params"]):
+                        d_ = self._dst(p_)
+                        m[name] = d_ if d_ is not None else torch.empty(p_.shape, dtype=torch.float32, device=self.device)
+                if live:
+                    ops.cpb_bwd_batched(live)
+                for m in live:
+                    for name, p_ in zip(("dw1", "db1", "dw2", "db2"), m["params"]):
+                        self._give_grad(p_, m[name])
+                    m["G"] = None
+
+            self.tape.append(bwd)
+
     def window_attention(self, x: Act, attn: nn.Module, heads: int, ws: int, shift: int) -> Act:
         """WindowAttention on the un-partitioned token tensor (swin_unet_v2.py:127-159 with the roll /
         window_partition / window_reverse of :246-262 folded into the core kernel's addressing):
@@ -556,9 +594,14 @@ class Engine:
         N = ws * ws
         qkv = self.linear(x, attn.qkv)
         cpb = attn.cpb
-        w1, b1, w2, b2 = (t.detach() for t in (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias))
-        idx = attn.log_relative_position_index[:N, :N].reshape(N * N, 2).contiguous()
-        bias = ops.cpb_fwd(idx, w1, b1, w2, b2).view(heads, N, N)
+        pre = self._cpb.get(attn)                      # evaluated by position_biases() at the start of the forward
+        if pre is not None and pre["N"] == N:
+            idx, bias = pre["idx"], pre["bias"].view(heads, N, N)
+        else:
+            pre = None
+            w1, b1, w2, b2 = (t.detach() for t in (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias))
+            idx = attn.log_relative_position_index[:N, :N].reshape(N * N, 2).contiguous()
+            bias = ops.cpb_fwd(idx, w1, b1, w2, b2).view(heads, N, N)
         tau = attn.tau.detach()
         o = self.new_act(x.N, x.H, x.W, x.C)
         lse = ops.winattn_fwd(qkv, tau, bias, o, heads, ws, shift)
@@ -577,6 +620,9 @@ class Engine:
                     full[:, :N, :N] = dtau
                     dtau = full
                 self._give_grad(attn.tau, dtau)
+                if pre is not None:
+                    pre["G"] = dbias.view(heads, N * N)  # differentiated with all the others (position_biases)
+                    return
                 gs = []
                 for p_ in (cpb.fc1.weight, cpb.fc1.bias, cpb.fc2.weight, cpb.fc2.bias):
                     d_ = self._dst(p_)

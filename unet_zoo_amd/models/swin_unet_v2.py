@@ -355,6 +355,7 @@ class SwinTransformerSys(HipModule):
         for lvl in range(nl - 1):
             cats.append(eng.new_cat(N, R[0] >> lvl, R[1] >> lvl, (E << lvl, E << lvl)))
         DropPath.draw_all(self, N, eng.device, eng.training)
+        eng.position_biases([(m.attn, m.window_size) for m in self.modules() if isinstance(m, SwinTransformerBlock)])
         t = self.patch_embed.emit(eng, x, out=cats[0][1][1])
         for i, layer in enumerate(self.layers):                 # forward_features (:711-723)
             nxt = cats[i + 1][1][1] if i + 1 < nl - 1 else None  # stage i's output is stage i+1's skip

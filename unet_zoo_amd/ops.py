@@ -649,3 +649,32 @@ def cpb_bwd(idx: torch.Tensor, w1, b1, w2, G: torch.Tensor, dw1, db1, dw2, db2) 
     L.check(L.load().uz_cpb_bwd(idx.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), G.data_ptr(), R, hidden,
                                 heads, dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), L.stream_ptr()),
             "uz_cpb_bwd")
+
+def _cpb_items(mods):
+    """mods: dicts with idx, w1, b1, w2 and (forward) b2, bias or (backward) G, dw1, db1, dw2, db2 tensors"""
+    arr = (L.CpbItem * len(mods))()
+    for it, m in zip(arr, mods):
+        idx, w1, w2 = m["idx"], m["w1"], m["w2"]
+        assert idx.is_contiguous() and idx.dtype == torch.float32 and idx.shape[1] == 2
+        it.R, it.hidden, it.heads = idx.shape[0], w1.shape[0], w2.shape[0]
+        for name in ("idx", "w1", "b1", "w2", "b2", "bias", "G", "dw1", "db1", "dw2", "db2"):
+            t = m.get(name)
+            if t is not None:
+                assert t.dtype == torch.float32 and t.is_contiguous(), name
+                setattr(it, name, t.data_ptr())
+    return arr
+
+
+def cpb_fwd_batched(mods) -> None:
+    """every module's bias (heads, R) in one launch; see _cpb_items for the fields"""
+    arr = _cpb_items(mods)
+    L.check(L.load().uz_cpb_fwd_batched(arr, len(mods), L.stream_ptr()), "uz_cpb_fwd_batched")
+
+
+def cpb_bwd_batched(mods) -> None:
+    lib = L.load()
+    arr = _cpb_items(mods)
+    wsb = L.check_count(lib.uz_cpb_bwd_batched_workspace_bytes(arr, len(mods)), "uz_cpb_bwd_batched_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=mods[0]["idx"].device)
+    L.check(lib.uz_cpb_bwd_batched(arr, len(mods), ws.data_ptr(), L.stream_ptr()), "uz_cpb_bwd_batched")
+
