@@ -253,6 +253,9 @@ int uz_sum_rows(const float* partial, int rows, int n, double* out, void* stream
  * [0, n0) to out0, [n0, n) to out1 (NULL when n0 == n) -- e.g. the two halves of uz_layernorm_bwd()'s
  * rows straight into the gradient tensors of weight and bias */
 int uz_sum_rows_f32(const float* partial, int rows, int n, float* out0, int n0, float* out1, void* stream);
+/* ... of the first n columns of rows that are ld >= n floats apart (a column window of wider partial rows) */
+int uz_sum_rows_f32_ld(const float* partial, int ld, int rows, int n, float* out0, int n0, float* out1,
+                       void* stream);
 /* backward of nearest x2 upsampling: dx[coarse pixel] = sum of its 2x2 fine pixels (H, W coarse) */
 int uz_sum2x2(int dtype, const void* du, int ldu, int N, int H, int W, int C, void* dx, int lddx,
               void* stream);
@@ -328,6 +331,16 @@ int uz_layernorm_bwd_rows(const uz_ln_desc* d); /* rows of `partial`; <0 on erro
  * add the rows with uz_sum_rows().  The residual branch's gradient is g itself. */
 int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* stats,
                      const void* g, const float* image_scale, void* dx, float* partial, void* stream);
+/* LayerNorm followed by a 1x1 head (FinalPatchExpand_X4's norm + the `output` convolution of swin_unet_v2,
+ * swin_unet_v2.py:385, :690, :753) without materialising the normalised tensor: logits (N, K, Ho, Wo) fp32 =
+ * b[k] + sum_c w[k][c] LN(x)[token][c] with x addressed as in uz_layernorm_fwd (d->ldy / ldr / ldg unused),
+ * K <= 4, C <= 64 sixteen-byte chunks.  Backward from dlogits: dx with x's addressing (lddx) and partial rows
+ * [row][2C + K*C + K] = d gamma | d beta | d w | d b; add them with uz_sum_rows_f32_ld(). */
+int uz_ln_head_fwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta, const float* w,
+                   const float* b /* or NULL */, int K, float* logits, float* stats, void* stream);
+int uz_ln_head_bwd_rows(const uz_ln_desc* d, int K); /* rows of `partial`; <0 on error */
+int uz_ln_head_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta, const float* w,
+                   int K, const float* stats, const float* dlogits, void* dx, float* partial, void* stream);
 
 /* WindowAttention core (:127-159) with window_partition / roll / window_reverse (:30-56, :246-262)
  * as index arithmetic: qkv (P, 3C) = [3][heads][32] per token, out (P, C).  For window tokens i, j

@@ -84,6 +84,43 @@ def test_layernorm_plain_with_residual_and_drop_scale(dt, C):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("K,bias,expand", [(1, False, True), (3, True, True), (4, True, False), (2, False, False)])
+def test_layernorm_with_1x1_head_fused(dt, K, bias, expand):
+    """uz_ln_head_fwd / bwd: conv1x1(LayerNorm(x)) to NCHW logits without the normalised tensor, with the 4x4
+    expand addressing of FinalPatchExpand_X4 (swin_unet_v2.py:381-386) and plain tokens"""
+    g = torch.Generator().manual_seed(61)
+    B, H, W, C, r = 2, 3, 5, 96, 4
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    w = (torch.randn(K, C, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(K, generator=g).requires_grad_(True) if bias else None
+    if expand:
+        x = rnd(dt, torch.randn(B, H, W, r * r * C, generator=g) * 2 + 0.5).requires_grad_(True)
+        tok = x.view(B, H, W, r, r, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H * r, W * r, C)   # 'b h w (p1 p2 c) -> b (h p1) (w p2) c'
+        mode, Ho, Wo = L.LN_EXPAND, H * r, W * r
+    else:
+        x = rnd(dt, torch.randn(B, H, W, C, generator=g) * 2 + 0.5).requires_grad_(True)
+        tok, mode, Ho, Wo, r = x, L.LN_PLAIN, H, W, 1
+    ref = F.conv2d(_ln_ref(tok, gamma, beta).permute(0, 3, 1, 2), w.view(K, C, 1, 1), b)
+    dlog = torch.randn(ref.shape, generator=g)
+    ref.backward(dlog)
+    xa = tokens_to_act(x.detach(), dt)
+    gd, bd, wd = gamma.detach().to(DEV), beta.detach().to(DEV), w.detach().to(DEV)
+    bb = b.detach().to(DEV) if bias else None
+    assert ops.ln_head_supported(C, K, dt)
+    logits, stats = ops.ln_head_fwd(xa, gd, bd, wd, bb, B, Ho, Wo, C, mode=mode, r=r)
+    assert relerr(logits.cpu(), ref.detach()) < (2e-6 if dt == torch.float32 else 1e-5)  # x is exact in both
+    dx = ops.new_act(xa.N, xa.H, xa.W, xa.C, dt, DEV)
+    dgam, dbet, dw, db = ops.ln_head_bwd(xa, gd, bd, wd, stats, dlog.to(DEV), dx, mode=mode, r=r)
+    assert relerr(act_to_tokens(dx), x.grad) < (1e-5 if dt == torch.float32 else 1e-2)
+    assert relerr(dgam.cpu(), gamma.grad) < 1e-4 and relerr(dbet.cpu(), beta.grad) < 1e-4
+    assert relerr(dw.cpu(), w.grad) < 1e-4
+    if bias:
+        assert relerr(db.cpu(), b.grad) < 1e-5
+    assert not ops.ln_head_supported(C, 5, dt) and not ops.ln_head_supported(1536, 1, dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_layernorm_patch_merging_addressing(dt):
     """LayerNorm(4C) over cat([x0, x1, x2, x3], -1) of PatchMerging without materialising the concat"""
     g = torch.Generator().manual_seed(43)

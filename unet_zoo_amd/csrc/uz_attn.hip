@@ -280,14 +280,14 @@ __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict_
 
 // fp32 results straight into (up to) two destinations: elements [0, n0) -> out0, [n0, n) -> out1
 // (e.g. d gamma | d beta into the two parameters' gradient tensors); accumulation in double as above
-__global__ __launch_bounds__(1024) void sum_rows_f32_kernel(const float* __restrict__ partial, int rows, int n,
+__global__ __launch_bounds__(1024) void sum_rows_f32_kernel(const float* __restrict__ partial, int ld, int rows, int n,
                                                             float* __restrict__ out0, int n0, float* __restrict__ out1) {
   __shared__ double sh[32][33];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;
   double s = 0.0;
   if (e < n)
-    for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * n + e];
+    for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * ld + e];
   sh[g][el] = s;
   __syncthreads();
   if (g == 0 && e < n) {
@@ -467,12 +467,18 @@ extern "C" int uz_sum_rows(const float* partial, int rows, int n, double* out, v
   return UZ_OK;
 }
 
-extern "C" int uz_sum_rows_f32(const float* partial, int rows, int n, float* out0, int n0, float* out1, void* stream) {
-  UZ_REQUIRE(partial && out0 && rows > 0 && n > 0 && n0 >= 0 && n0 <= n && (out1 || n0 == n), "uz_sum_rows_f32: bad args");
-  hipLaunchKernelGGL(sum_rows_f32_kernel, dim3(uz_cdiv(n, 32)), dim3(1024), 0, (hipStream_t)stream, partial, rows, n,
+extern "C" int uz_sum_rows_f32_ld(const float* partial, int ld, int rows, int n, float* out0, int n0, float* out1,
+                                  void* stream) {
+  UZ_REQUIRE(partial && out0 && rows > 0 && n > 0 && ld >= n && n0 >= 0 && n0 <= n && (out1 || n0 == n),
+             "uz_sum_rows_f32: bad args");
+  hipLaunchKernelGGL(sum_rows_f32_kernel, dim3(uz_cdiv(n, 32)), dim3(1024), 0, (hipStream_t)stream, partial, ld, rows, n,
                      out0, n0, out1);
   UZ_LAUNCH_CHECK("uz_sum_rows_f32");
   return UZ_OK;
+}
+
+extern "C" int uz_sum_rows_f32(const float* partial, int rows, int n, float* out0, int n0, float* out1, void* stream) {
+  return uz_sum_rows_f32_ld(partial, n, rows, n, out0, n0, out1, stream);
 }
 
 extern "C" int uz_sum2x2(int dtype, const void* du, int ldu, int N, int H, int W, int C, void* dx, int lddx,

@@ -296,6 +296,182 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
 }
 
 // ---------------------------------------------------------------------------------------------
+// LayerNorm + 1x1 head: logits[img][k][oh][ow] = b[k] + sum_c w[k][c] LN(x)[token][c], the tail of
+// swin_unet_v2 (FinalPatchExpand_X4's norm, :385, followed by the 1x1 `output` convolution, :690 / :753).
+// At B=16 256x256 the normalised tensor is 201 MB: written by the LayerNorm, read by the head, written
+// again as its gradient and read back by the LayerNorm backward.  Fused, the forward reads x once and the
+// backward reads x and writes dx; d gamma, d beta, d w, d b leave as partial rows [2C + K*C + K] per
+// workgroup.  One chunk per lane (C <= 64 * VEC), KT = 1 or 4 classes unrolled.
+// ---------------------------------------------------------------------------------------------
+struct LnHeadArgs {
+  LnArgs ln;            // x, dx, gamma, beta, stats, partial, N, Ho, Wo, C, ldx, lddx, mode, r, eps
+  const float* w;       // [K][C]
+  const float* b;       // [K] or null
+  float* logits;        // fwd out  (N, K, Ho, Wo)
+  const float* dlogits; // bwd in   (N, K, Ho, Wo)
+  int K;
+};
+
+template <typename T, bool BWD, int KT, int U>
+__global__ __launch_bounds__(256) void ln_head_kernel(const LnHeadArgs h, int lpt) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const LnArgs& a = h.ln;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (lpt - 1), grp = lane / lpt, tpw = 64 / lpt;
+  const int CC = a.C / VEC, K = h.K;
+  const int P = a.N * a.Ho * a.Wo, HW = a.Ho * a.Wo;
+  const bool act = sub < CC;
+  const T* __restrict__ x = static_cast<const T*>(a.x);
+  float gam[VEC], bet[VEC], wk[KT][VEC], ag[VEC], ab[VEC], aw[KT][VEC], adb[KT];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    gam[e] = act ? a.gamma[sub * VEC + e] : 0.f;
+    bet[e] = act ? a.beta[sub * VEC + e] : 0.f;
+    ag[e] = ab[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      wk[k][e] = (act && k < K) ? h.w[(size_t)k * a.C + sub * VEC + e] : 0.f;
+      aw[k][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KT; ++k) adb[k] = 0.f;
+  const float invC = 1.f / (float)a.C;
+  const int tpb = 4 * tpw * U;
+  for (int t0 = blockIdx.x * tpb; t0 < P; t0 += gridDim.x * tpb) {
+    int t[U], img[U], oh[U], ow[U];
+    bool tok[U];
+    uint4 xr[U];
+    float dl[U][KT], mean[U], rstd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      t[u] = t0 + (u * 4 + wave) * tpw + grp;
+      tok[u] = t[u] < P;
+      const int tc = tok[u] ? t[u] : 0;
+      const int tt = tc / a.Wo;
+      ow[u] = tc - tt * a.Wo;
+      img[u] = tt / a.Ho;
+      oh[u] = tt - img[u] * a.Ho;
+      xr[u] = (act && tok[u]) ? *reinterpret_cast<const uint4*>(x + ln_src<T>(a, img[u], oh[u], ow[u], sub * VEC, a.ldx))
+                              : make_uint4(0, 0, 0, 0);
+      if constexpr (BWD) {
+        mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
+        rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          dl[u][k] = (tok[u] && k < K) ? h.dlogits[((size_t)img[u] * K + k) * HW + oh[u] * a.Wo + ow[u]] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) pin(xr[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+      float v[VEC];
+      unpack_f<T>(xr[u], v);
+      if constexpr (!BWD) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[e];
+        const float mu = group_sum(s, lpt) * invC;
+        float q = 0.f;
+        if (act) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float d = v[e] - mu;
+            q += d * d;
+          }
+        }
+        const float rs = rsqrtf(group_sum(q, lpt) * invC + a.eps);
+        if (sub == 0 && tok[u]) {
+          a.stats[(size_t)t[u] * 2] = mu;
+          a.stats[(size_t)t[u] * 2 + 1] = rs;
+        }
+        float lk[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) lk[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float y = (v[e] - mu) * rs * gam[e] + bet[e];   // gamma = beta = 0 on idle lanes
+#pragma unroll
+          for (int k = 0; k < KT; ++k) lk[k] = fmaf(y, wk[k][e], lk[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const float tot = group_sum(lk[k], lpt);
+          if (sub == 0 && tok[u] && k < K)
+            h.logits[((size_t)img[u] * K + k) * HW + oh[u] * a.Wo + ow[u]] = tot + (h.b != nullptr ? h.b[k] : 0.f);
+        }
+      } else {
+        T* __restrict__ dx = static_cast<T*>(a.dx);
+        float gv[VEC], xh[VEC];
+        float s1 = 0.f, s2 = 0.f;
+        if (act && tok[u]) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            xh[e] = (v[e] - mean[u]) * rstd[u];
+            const float y = xh[e] * gam[e] + bet[e];
+            float g = 0.f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+              g = fmaf(dl[u][k], wk[k][e], g);
+              aw[k][e] = fmaf(dl[u][k], y, aw[k][e]);
+            }
+            gv[e] = g;
+            ag[e] = fmaf(g, xh[e], ag[e]);
+            ab[e] += g;
+            const float gg = g * gam[e];
+            s1 += gg;
+            s2 = fmaf(gg, xh[e], s2);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) gv[e] = xh[e] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) adb[k] += dl[u][k];
+        s1 = group_sum(s1, lpt) * invC;
+        s2 = group_sum(s2, lpt) * invC;
+        if (act && tok[u]) {
+          float o[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = rstd[u] * (gv[e] * gam[e] - s1 - xh[e] * s2);
+          store_f(dx + ln_src<T>(a, img[u], oh[u], ow[u], sub * VEC, a.lddx), o);
+        }
+      }
+    }
+  }
+  if constexpr (BWD) {
+    // one partial row per workgroup: [d gamma (C) | d beta (C) | d w (K*C) | d b (K)]
+    extern __shared__ float red[];  // [4 * tpw][(2 + K) * C + K]
+    const int gidx = wave * tpw + grp, ngrp = 4 * tpw;
+    const int n = (2 + K) * a.C + K;
+    float* mine = red + (size_t)gidx * n;
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        mine[sub * VEC + e] = ag[e];
+        mine[a.C + sub * VEC + e] = ab[e];
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (k < K) mine[(2 + k) * a.C + sub * VEC + e] = aw[k][e];
+      }
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+        if (k < K) mine[(2 + K) * a.C + k] = adb[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += 256) {
+      float t = 0.f;
+      for (int k = 0; k < ngrp; ++k) t += red[(size_t)k * n + c];
+      a.partial[(size_t)blockIdx.x * n + c] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Window attention.
 // ---------------------------------------------------------------------------------------------
 struct AttnArgs {
@@ -754,55 +930,65 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   for (int r = 0; r < 16; ++r) accb[r] = acct[r] = 0.f;
   const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
 
+  // A window's q, dO, O, k, v fragments are fetched one window ahead: the loads are issued right after the
+  // score products have consumed the current ones and land during the element pass.
+  WinTok ntq = {0, -1}, ntk = {0, -1};
+  bf16x8 nq[2], ng[2], no[2], nk[2], nv[2];
+  float nlse = 0.f;
+  auto fetch = [&](int win) {
+    ntq = {0, -1};
+    ntk = {0, -1};
+    nlse = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) nq[ks][e] = ng[ks][e] = no[ks][e] = nk[ks][e] = nv[ks][e] = (bf16_t)0.f;
+    if (iq < N) {
+      ntq = win_token(a, win, iq);
+      const bf16_t* row = qkv + (size_t)ntq.tok * a.ldq + h * AD + 8 * lh;
+      const bf16_t* grow = dout + (size_t)ntq.tok * a.lddo + h * AD + 8 * lh;
+      const bf16_t* orow = out + (size_t)ntq.tok * a.ldo + h * AD + 8 * lh;
+      nlse = a.lse[((size_t)win * a.heads + h) * N + iq];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        nq[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+        ng[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks);
+        no[ks] = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
+      }
+    }
+    if (jk < N) {
+      ntk = win_token(a, win, jk);
+      const bf16_t* row = qkv + (size_t)ntk.tok * a.ldq + a.C + h * AD + 8 * lh;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        nk[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+        nv[ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
+      }
+    }
+  };
+  if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
+
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
     __syncthreads();   // previous window: every reader of the tiles / hand-over areas is done (and sTab has landed)
-    WinTok tq = {0, -1}, tkk = {0, -1};
+    const WinTok tq = ntq, tkk = ntk;
     bf16x8 qf[2], gf[2], kf[2], vf[2];
-    float rq = 0.f, Di = 0.f, lse = 0.f;
+    float rq = 0.f, Di = 0.f;
+    const float lse = nlse;
     {
       float q2 = 0.f, k2 = 0.f;
-      if (iq < N) {
-        tq = win_token(a, win, iq);
-        const bf16_t* row = qkv + (size_t)tq.tok * a.ldq + h * AD + 8 * lh;
-        const bf16_t* grow = dout + (size_t)tq.tok * a.lddo + h * AD + 8 * lh;
-        const bf16_t* orow = out + (size_t)tq.tok * a.ldo + h * AD + 8 * lh;
-        lse = a.lse[((size_t)win * a.heads + h) * N + iq];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          qf[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
-          gf[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks);
-          const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = nq[ks];
+        gf[ks] = ng[ks];
+        kf[ks] = nk[ks];
+        vf[ks] = nv[ks];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float qv = (float)qf[ks][e];
-            q2 = fmaf(qv, qv, q2);
-            Di = fmaf((float)gf[ks][e], (float)of[e], Di);
-          }
+        for (int e = 0; e < 8; ++e) {
+          const float qv = (float)qf[ks][e], kv = (float)kf[ks][e];
+          q2 = fmaf(qv, qv, q2);
+          k2 = fmaf(kv, kv, k2);
+          Di = fmaf((float)gf[ks][e], (float)no[ks][e], Di);
         }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) qf[ks][e] = gf[ks][e] = (bf16_t)0.f;
-      }
-      if (jk < N) {
-        tkk = win_token(a, win, jk);
-        const bf16_t* row = qkv + (size_t)tkk.tok * a.ldq + a.C + h * AD + 8 * lh;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          kf[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
-          vf[ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float kv = (float)kf[ks][e];
-            k2 = fmaf(kv, kv, k2);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) kf[ks][e] = vf[ks][e] = (bf16_t)0.f;
       }
       q2 += __shfl_xor(q2, 32);
       Di += __shfl_xor(Di, 32);
@@ -842,6 +1028,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ut, 0, 0, 0);
         dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], gf[ks], dt, 0, 0, 0);
       }
+      if (win + (int)gridDim.x < nWin) fetch(win + gridDim.x);
       float w1[16];
       bf16_t* pcol = sP + (32 * kt + 4 * lh) * VTS + iq;
       bf16_t* wcol = sW + (32 * kt + 4 * lh) * VTS + iq;
@@ -1562,6 +1749,76 @@ extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float*
   const size_t shm = (size_t)4 * (64 / lpt) * 2 * d->C * sizeof(float);
   ln_launch<true>(d, grid, block, shm, (hipStream_t)stream, a, lpt);
   UZ_LAUNCH_CHECK("uz_layernorm_bwd");
+  return UZ_OK;
+}
+
+// ---- LayerNorm + 1x1 head --------------------------------------------------------------------------
+constexpr int LNH_U = 2, LNH_MAXK = 4;
+
+static int ln_head_check(const char* fn, const uz_ln_desc* d, int K) {
+  const int rc = ln_check(fn, d);
+  if (rc != UZ_OK) return rc;
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(d->C / vec <= 64, "%s: C=%d needs more than one chunk per lane", fn, d->C);
+  UZ_REQUIRE(K >= 1 && K <= LNH_MAXK, "%s: K=%d classes (max %d)", fn, K, LNH_MAXK);
+  const long long shm = (long long)4 * (64 / ln_lpt(d)) * ((2 + K) * d->C + K) * 4;
+  UZ_REQUIRE(shm <= 64 * 1024, "%s: partial-row staging exceeds 64 KiB", fn);
+  return UZ_OK;
+}
+static int ln_head_grid(const uz_ln_desc* d) {
+  return grid_cap((long long)d->N * d->Ho * d->Wo, 4 * (64 / ln_lpt(d)) * LNH_U, 8);
+}
+static void ln_head_args(const uz_ln_desc* d, LnHeadArgs* h) {
+  LnArgs& a = h->ln;
+  a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.lddx = d->lddx;
+  a.mode = d->mode; a.r = d->r; a.eps = d->eps;
+}
+template <bool BWD>
+static void ln_head_launch(const uz_ln_desc* d, const LnHeadArgs& h, size_t shm, hipStream_t st) {
+  const dim3 grid(ln_head_grid(d)), block(256);
+  const int lpt = ln_lpt(d);
+#define UZ_LNH(T, KT) hipLaunchKernelGGL((ln_head_kernel<T, BWD, KT, LNH_U>), grid, block, shm, st, h, lpt)
+  if (d->dtype == UZ_BF16) { if (h.K == 1) UZ_LNH(bf16_t, 1); else UZ_LNH(bf16_t, 4); }
+  else { if (h.K == 1) UZ_LNH(float, 1); else UZ_LNH(float, 4); }
+#undef UZ_LNH
+}
+
+extern "C" int uz_ln_head_fwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
+                              const float* w, const float* b, int K, float* logits, float* stats, void* stream) {
+  const int rc = ln_head_check("uz_ln_head_fwd", d, K);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(x && gamma && beta && w && logits && stats, "uz_ln_head_fwd: null pointer");
+  LnHeadArgs h{};
+  ln_head_args(d, &h);
+  h.ln.x = x; h.ln.gamma = gamma; h.ln.beta = beta; h.ln.stats = stats;
+  h.w = w; h.b = b; h.logits = logits; h.K = K;
+  ln_head_launch<false>(d, h, 0, (hipStream_t)stream);
+  UZ_LAUNCH_CHECK("uz_ln_head_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_ln_head_bwd_rows(const uz_ln_desc* d, int K) {
+  const int rc = ln_head_check("uz_ln_head_bwd_rows", d, K);
+  if (rc != UZ_OK) return rc;
+  return ln_head_grid(d);
+}
+
+extern "C" int uz_ln_head_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
+                              const float* w, int K, const float* stats, const float* dlogits, void* dx,
+                              float* partial, void* stream) {
+  const int rc = ln_head_check("uz_ln_head_bwd", d, K);
+  if (rc != UZ_OK) return rc;
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && gamma && beta && w && stats && dlogits && dx && partial, "uz_ln_head_bwd: null pointer");
+  UZ_REQUIRE(d->lddx % vec == 0, "uz_ln_head_bwd: bad lddx");
+  LnHeadArgs h{};
+  ln_head_args(d, &h);
+  h.ln.x = x; h.ln.gamma = gamma; h.ln.beta = beta; h.ln.stats = const_cast<float*>(stats);
+  h.ln.dx = dx; h.ln.partial = partial;
+  h.w = w; h.dlogits = dlogits; h.K = K;
+  const size_t shm = (size_t)4 * (64 / ln_lpt(d)) * ((2 + K) * d->C + K) * sizeof(float);
+  ln_head_launch<true>(d, h, shm, (hipStream_t)stream);
+  UZ_LAUNCH_CHECK("uz_ln_head_bwd");
   return UZ_OK;
 }
 

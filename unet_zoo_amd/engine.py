@@ -747,6 +747,44 @@ class Engine:
             self._heads.append((bwd, 1))
         return logits
 
+    def layer_norm_head(self, x: Act, ln: nn.LayerNorm, conv: nn.Conv2d, *, mode: int = L.LN_PLAIN, r: int = 1) -> torch.Tensor:
+        """conv(LayerNorm(x)) for a 1x1 `conv` to the logits, (N, K, H, W) fp32, without materialising the
+        normalised tensor (FinalPatchExpand_X4's norm + `output`, swin_unet_v2.py:385 / :753): at B=16
+        256x256 that tensor is 201 MB each way.  Falls back to layer_norm + out_conv for shapes the fused
+        kernels do not take."""
+        C, K = ln.normalized_shape[0], conv.out_channels
+        assert conv.kernel_size == (1, 1) and conv.in_channels == C
+        if not ops.ln_head_supported(C, K, self.dtype):
+            return self.out_conv(self.layer_norm(x, ln, mode=mode, r=r), conv)
+        if mode == L.LN_EXPAND:
+            assert x.C == r * r * C
+            N, Ho, Wo = x.N, x.H * r, x.W * r
+        else:
+            assert mode == L.LN_PLAIN and x.C == C
+            N, Ho, Wo = x.N, x.H, x.W
+        gamma, beta = ln.weight.detach(), ln.bias.detach()
+        w = conv.weight.detach().reshape(K, C)
+        b = conv.bias.detach() if conv.bias is not None else None
+        logits, stats = ops.ln_head_fwd(x, gamma, beta, w, b, N, Ho, Wo, C, mode=mode, r=r, eps=ln.eps)
+        if self.record:
+            def bwd(g_logits: torch.Tensor):
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                dwt = self._dst(conv.weight)
+                outs = ops.ln_head_bwd(x, gamma, beta, w, stats, g_logits.contiguous().float(), dx, mode=mode, r=r,
+                                       eps=ln.eps, dgamma=self._dst(ln.weight), dbeta=self._dst(ln.bias),
+                                       dw=dwt.view(K, C) if dwt is not None else None,
+                                       db=self._dst(conv.bias) if conv.bias is not None else None)
+                self._give_grad(conv.weight, dwt if dwt is not None else outs[2].reshape(conv.weight.shape))
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, outs[3])
+                self._give_grad(ln.weight, outs[0])
+                self._give_grad(ln.bias, outs[1])
+                if x.needs_grad:
+                    x.add_grad(dx)
+
+            self._heads.append((bwd, 1))
+        return logits
+
     # ------------------------------------------------------------------ backward
     def backward(self, grad_outputs: Sequence[Optional[torch.Tensor]]) -> Dict[nn.Parameter, torch.Tensor]:
         """Run the recorded tape in reverse.  `grad_outputs` pairs with the out_conv heads in

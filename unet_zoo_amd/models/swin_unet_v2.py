@@ -210,6 +210,10 @@ class FinalPatchExpand_X4(nn.Module):
     def emit(self, eng: Engine, x: Act) -> Act:
         return eng.layer_norm(eng.linear(x, self.expand), self.norm, mode=L.LN_EXPAND, r=self.dim_scale)
 
+    def emit_head(self, eng: Engine, x: Act, conv: nn.Conv2d) -> torch.Tensor:
+        """this module followed by the 1x1 `conv` to the logits, the normalised map kept in registers"""
+        return eng.layer_norm_head(eng.linear(x, self.expand), self.norm, conv, mode=L.LN_EXPAND, r=self.dim_scale)
+
 
 def _blocks(dim, input_resolution, depth, num_heads, window_size, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop,
             drop_path, norm_layer) -> nn.ModuleList:
@@ -370,5 +374,4 @@ class SwinTransformerSys(HipModule):
             t = eng.linear(cats[lvl][0], self.concat_back_dim[inx])
             t = layer_up.emit(eng, t, out=dst)
         t = eng.layer_norm(t, self.norm_up)
-        t = self.up.emit(eng, t)                                 # up_x4 (:743-754)
-        return (eng.out_conv(t, self.output),)
+        return (self.up.emit_head(eng, t, self.output),)         # up_x4 + output (:743-754)

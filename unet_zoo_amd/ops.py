@@ -8,6 +8,8 @@ from __future__ import annotations
 from ctypes import byref
 from typing import List, Optional, Sequence
 
+import math
+
 import torch
 
 from . import _lib as L
@@ -594,6 +596,61 @@ def layernorm_bwd(x: Act, gamma: torch.Tensor, stats: torch.Tensor, g: Act, dx: 
         dbeta = torch.empty(g.C, dtype=torch.float32, device=x.buf.device)
     sum_rows_f32(part, rows, dgamma, dbeta)
     return dgamma, dbeta
+
+
+LN_HEAD_MAX_CLASSES = 4
+
+
+def ln_head_supported(C: int, K: int, dtype: torch.dtype) -> bool:
+    """shapes the fused LayerNorm + 1x1 head kernels take (one 16-byte chunk per lane, <= 4 classes)"""
+    vec = 8 if dtype == torch.bfloat16 else 4
+    return C % vec == 0 and C // vec <= 64 and 1 <= K <= LN_HEAD_MAX_CLASSES
+
+
+def ln_head_fwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor],
+                N: int, Ho: int, Wo: int, C: int, *, mode: int = L.LN_PLAIN, r: int = 1, eps: float = 1e-5):
+    """logits (N, K, Ho, Wo) fp32 = b + w . LayerNorm(x rows addressed by `mode`), and the (P, 2) mean/rstd"""
+    K = w.shape[0]
+    assert w.shape == (K, C) and w.is_contiguous() and w.dtype == torch.float32
+    d = _ln_desc(x, N, Ho, Wo, C, mode, r, eps)
+    dev = x.buf.device
+    logits = torch.empty((N, K, Ho, Wo), dtype=torch.float32, device=dev)
+    stats = torch.empty((N * Ho * Wo, 2), dtype=torch.float32, device=dev)
+    with _Timed("ln_head_fwd", 2.0 * N * Ho * Wo * C * K, x.buf.element_size() * N * Ho * Wo * C):
+        L.check(L.load().uz_ln_head_fwd(byref(d), x.ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), _p(b), K,
+                                        logits.data_ptr(), stats.data_ptr(), L.stream_ptr()), "uz_ln_head_fwd")
+    return logits, stats
+
+
+def ln_head_bwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, stats: torch.Tensor,
+                dlogits: torch.Tensor, dx: Act, *, mode: int = L.LN_PLAIN, r: int = 1, eps: float = 1e-5,
+                dgamma=None, dbeta=None, dw=None, db=None):
+    """dx (x's addressing) and (dgamma, dbeta, dw (K, C), db (K)) fp32, written into the given tensors when passed"""
+    lib = L.load()
+    N, K, Ho, Wo = dlogits.shape
+    C = w.shape[1]
+    assert dlogits.dtype == torch.float32 and dlogits.is_contiguous() and w.shape[0] == K
+    d = _ln_desc(x, N, Ho, Wo, C, mode, r, eps, lddx=dx.ld)
+    rows = L.check_count(lib.uz_ln_head_bwd_rows(byref(d), K), "uz_ln_head_bwd_rows")
+    n = (2 + K) * C + K
+    dev = x.buf.device
+    part = torch.empty((rows, n), dtype=torch.float32, device=dev)
+    with _Timed("ln_head_bwd", 4.0 * N * Ho * Wo * C * K, x.buf.element_size() * N * Ho * Wo * C * 2):
+        L.check(lib.uz_ln_head_bwd(byref(d), x.ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), K,
+                                   stats.data_ptr(), dlogits.data_ptr(), dx.ptr(), part.data_ptr(), L.stream_ptr()),
+                "uz_ln_head_bwd")
+    outs = []
+    for t, shape in ((dgamma, (C,)), (dbeta, (C,)), (dw, (K, C)), (db, (K,))):
+        if t is None:
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+        assert t.numel() == math.prod(shape) and t.dtype == torch.float32 and t.is_contiguous()
+        outs.append(t)
+    st = L.stream_ptr()
+    L.check(lib.uz_sum_rows_f32_ld(part.data_ptr(), n, rows, 2 * C, outs[0].data_ptr(), C, outs[1].data_ptr(), st),
+            "uz_sum_rows_f32_ld")
+    L.check(lib.uz_sum_rows_f32_ld(part.data_ptr() + 8 * C, n, rows, K * C + K, outs[2].data_ptr(), K * C,
+                                   outs[3].data_ptr(), st), "uz_sum_rows_f32_ld")
+    return tuple(outs)
 
 
 def _attn_desc(qkv: Act, heads: int, ws: int, shift: int, Nt: int, ldo: int):
