@@ -334,13 +334,14 @@ int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, con
 /* LayerNorm followed by a 1x1 head (FinalPatchExpand_X4's norm + the `output` convolution of swin_unet_v2,
  * swin_unet_v2.py:385, :690, :753) without materialising the normalised tensor: logits (N, K, Ho, Wo) fp32 =
  * b[k] + sum_c w[k][c] LN(x)[token][c] with x addressed as in uz_layernorm_fwd (d->ldy / ldr / ldg unused),
- * K <= 4, C <= 64 sixteen-byte chunks.  Backward from dlogits: dx with x's addressing (lddx) and partial rows
- * [row][2C + K*C + K] = d gamma | d beta | d w | d b; add them with uz_sum_rows_f32_ld(). */
+ * K <= 4 (K = 1: C <= 192 sixteen-byte chunks, else 64).  Backward from dlogits: dx with x's addressing (lddx)
+ * and the gradients of gamma, beta (C), w (K, C), b (K; may be NULL), overwritten. */
 int uz_ln_head_fwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta, const float* w,
                    const float* b /* or NULL */, int K, float* logits, float* stats, void* stream);
-int uz_ln_head_bwd_rows(const uz_ln_desc* d, int K); /* rows of `partial`; <0 on error */
+long long uz_ln_head_bwd_workspace_bytes(const uz_ln_desc* d, int K);
 int uz_ln_head_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta, const float* w,
-                   int K, const float* stats, const float* dlogits, void* dx, float* partial, void* stream);
+                   int K, const float* stats, const float* dlogits, void* dx, float* dgamma, float* dbeta,
+                   float* dw, float* db /* or NULL */, float* workspace, void* stream);
 
 /* WindowAttention core (:127-159) with window_partition / roll / window_reverse (:30-56, :246-262)
  * as index arithmetic: qkv (P, 3C) = [3][heads][32] per token, out (P, C).  For window tokens i, j

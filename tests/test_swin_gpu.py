@@ -117,7 +117,7 @@ def test_layernorm_with_1x1_head_fused(dt, K, bias, expand):
     assert relerr(dw.cpu(), w.grad) < 1e-4
     if bias:
         assert relerr(db.cpu(), b.grad) < 1e-5
-    assert not ops.ln_head_supported(C, 5, dt) and not ops.ln_head_supported(1536, 1, dt)
+    assert not ops.ln_head_supported(C, 5, dt) and not ops.ln_head_supported(3072, 1, dt)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -33,7 +33,7 @@ EXPORTS = (
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
     "uz_conv_igemm_workspace_bytes", "uz_conv_igemm_ws_grid_m", "uz_conv_igemm_ws",
     "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd",
-    "uz_ln_head_fwd", "uz_ln_head_bwd_rows", "uz_ln_head_bwd", "uz_sum_rows_f32_ld",
+    "uz_ln_head_fwd", "uz_ln_head_bwd_workspace_bytes", "uz_ln_head_bwd", "uz_sum_rows_f32_ld",
     "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
     "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_cpb_fwd", "uz_cpb_bwd",
     "uz_cpb_fwd_batched", "uz_cpb_bwd_batched_workspace_bytes", "uz_cpb_bwd_batched",
@@ -118,8 +118,8 @@ def load():
     lib.uz_layernorm_bwd_rows.argtypes = [POINTER(LnDesc)]
     lib.uz_layernorm_bwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_ln_head_fwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, ip, vp, vp, vp]
-    lib.uz_ln_head_bwd_rows.argtypes = [POINTER(LnDesc), ip]
-    lib.uz_ln_head_bwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, ip, vp, vp, vp, vp, vp]
+    lib.uz_ln_head_bwd_workspace_bytes.argtypes = [POINTER(LnDesc), ip]
+    lib.uz_ln_head_bwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, ip, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_sum_rows_f32_ld.argtypes = [vp, ip, ip, ip, vp, ip, vp, vp]
     lib.uz_winattn_fwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp]
     lib.uz_winattn_bwd_rows.argtypes = [POINTER(WinAttnDesc)]

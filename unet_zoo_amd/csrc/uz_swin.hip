@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 // y = [res +] [sb[image] *] (xhat * gamma + beta); mean and rstd per token are kept for the backward.
 // One wave per token, lanes stride over the 16-byte channel chunks (at most MAXIT per lane).
 // ---------------------------------------------------------------------------------------------
+struct FastDiv {
+  unsigned m;
+  int s;
+};
+
 struct LnArgs {
   const void* x;
   void* y;            // fwd: output; bwd: unused
@@ -78,21 +83,55 @@ struct LnArgs {
   float* partial;     // bwd: [gridDim.x][2][C] sums of g*xhat (dgamma) and g (dbeta)
   int N, Ho, Wo, C, ldx, ldy, ldr, ldg, lddx, mode, r;
   float eps;
+  FastDiv fWo, fHo, fr;   // token index -> (image, row, column) and the expand sub-position without v_rcp sequences
+  int Hin, Win;           // grid of x: (Ho, Wo) plain, (2 Ho, 2 Wo) merge, (Ho / r, Wo / r) expand
 };
 
 constexpr int LN_MAXIT = 6;     // 16-byte chunks per lane: C <= 64 * 6 * 4 = 1536 in fp32
 constexpr int LN_MAXC = 1536;   // PatchMerging of the 384-channel stage: LayerNorm(4 * 384)
 
-template <typename T> __device__ __forceinline__ size_t ln_src(const LnArgs& a, int img, int oh, int ow, int c0, int ld) {
-  if (a.mode == 0) return ((size_t)(img * a.Ho + oh) * a.Wo + ow) * ld + c0;
-  if (a.mode == 1) {
-    const int Cq = a.C >> 2, s = c0 / Cq;
-    const int H = a.Ho * 2, W = a.Wo * 2;
-    return ((size_t)(img * H + 2 * oh + (s & 1)) * W + 2 * ow + (s >> 1)) * ld + (c0 - s * Cq);
+// Unsigned division by a launch constant (n < 2^31): q = umulhi(n, m) >> s with m = ceil(2^(32+s) / d),
+// exact for every 31-bit n (Granlund & Montgomery); d = 1 is m = 0.  A runtime integer division costs ~25
+// VALU instructions; the token -> (image, row, column[, sub-position]) decomposition needs four of them per
+// token and lane and dominated the instruction count of these bandwidth kernels.
+__device__ __forceinline__ int fdiv(int n, const FastDiv f) {
+  return f.m == 0 ? n : (int)(__umulhi((unsigned)n, f.m) >> f.s);
+}
+
+// where token t of the normalised map reads x: pixel `pix` of x's grid, first channel `coff`
+struct TokPos {
+  int img, pix, coff;
+};
+__device__ __forceinline__ TokPos ln_tok(const LnArgs& a, int t) {
+  TokPos p;
+  const int tt = fdiv(t, a.fWo), ow = t - tt * a.Wo;
+  p.img = fdiv(tt, a.fHo);
+  const int oh = tt - p.img * a.Ho;
+  p.coff = 0;
+  if (a.mode == 0) {
+    p.pix = t;
+  } else if (a.mode == 1) {
+    p.pix = (p.img * a.Hin + 2 * oh) * a.Win + 2 * ow;
+  } else {
+    const int h = fdiv(oh, a.fr), p1 = oh - h * a.r, w = fdiv(ow, a.fr), p2 = ow - w * a.r;
+    p.pix = (p.img * a.Hin + h) * a.Win + w;
+    p.coff = (p1 * a.r + p2) * a.C;
   }
-  const int r = a.r, H = a.Ho / r, W = a.Wo / r;
-  const int h = oh / r, p1 = oh - h * r, w = ow / r, p2 = ow - w * r;
-  return ((size_t)(img * H + h) * W + w) * ld + (p1 * r + p2) * a.C + c0;
+  return p;
+}
+// per-lane constants of channel chunk c0: merge mode takes segment s = c0 / (C/4) from the pixel at
+// (+ (s & 1) rows, + (s >> 1) columns), channels c0 - s C/4
+__device__ __forceinline__ void ln_chunk(const LnArgs& a, int c0, int* dpix, int* cch) {
+  *dpix = 0;
+  *cch = c0;
+  if (a.mode == 1) {
+    const int Cq = a.C >> 2, sg = c0 / Cq;
+    *dpix = (sg & 1) * a.Win + (sg >> 1);
+    *cch = c0 - sg * Cq;
+  }
+}
+__device__ __forceinline__ size_t ln_off(const TokPos& p, int dpix, int cch, int ld) {
+  return (size_t)(p.pix + dpix) * ld + p.coff + cch;
 }
 
 // sum over the LPT consecutive lanes that share a token (LPT a power of two <= 64)
@@ -134,9 +173,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
   const T* __restrict__ second = static_cast<const T*>(BWD ? a.g : a.res);   // g, or the optional residual
   const int ld2 = BWD ? a.ldg : a.ldr;
   float gam[MAXIT][VEC], bet[MAXIT][VEC], ag[MAXIT][VEC], ab[MAXIT][VEC];
+  int dpix[MAXIT], cch[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int cc = sub + lpt * it;
+    ln_chunk(a, cc * VEC, &dpix[it], &cch[it]);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       gam[it][e] = cc < CC ? a.gamma[cc * VEC + e] : 0.f;
@@ -147,8 +188,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
   const float invC = 1.f / (float)a.C;
   const int tpb = 4 * tpw * U;  // tokens per workgroup pass
   for (int t0 = blockIdx.x * tpb; t0 < P; t0 += gridDim.x * tpb) {
-    int t[U], img[U];
-    size_t xo[U];   // element offset of the token's first channel in x (ld = 1 units resolved below)
+    int t[U];
+    TokPos pos[U];
     bool tok[U];    // whole lane groups go idle together; shuffles below stay inside a group
     uint4 xr[U][MAXIT], sr[U][MAXIT];
     float mean[U], rstd[U];
@@ -156,22 +197,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
     for (int u = 0; u < U; ++u) {
       t[u] = t0 + (u * 4 + wave) * tpw + grp;
       tok[u] = t[u] < P;
-      const int tc = tok[u] ? t[u] : 0;
-      const int tt = tc / a.Wo, ow = tc - tt * a.Wo;
-      img[u] = tt / a.Ho;
-      const int oh = tt - img[u] * a.Ho;
+      pos[u] = ln_tok(a, tok[u] ? t[u] : 0);
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int cc = sub + lpt * it;
         if (cc < CC && tok[u]) {
-          xr[u][it] = *reinterpret_cast<const uint4*>(x + ln_src<T>(a, img[u], oh, ow, cc * VEC, a.ldx));
+          xr[u][it] = *reinterpret_cast<const uint4*>(x + ln_off(pos[u], dpix[it], cch[it], a.ldx));
           if (BWD || second != nullptr) sr[u][it] = *reinterpret_cast<const uint4*>(second + (size_t)t[u] * ld2 + cc * VEC);
           else sr[u][it] = make_uint4(0, 0, 0, 0);
         } else {
           xr[u][it] = sr[u][it] = make_uint4(0, 0, 0, 0);
         }
       }
-      xo[u] = ((size_t)oh << 32) | (unsigned)ow;
       if constexpr (BWD) {
         mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
         rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
@@ -213,7 +250,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
           a.stats[(size_t)t[u] * 2] = mu;
           a.stats[(size_t)t[u] * 2 + 1] = rs;
         }
-        const float f = a.sb != nullptr ? a.sb[img[u]] : 1.f;
+        const float f = a.sb != nullptr ? a.sb[pos[u].img] : 1.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
           const int cc = sub + lpt * it;
@@ -234,7 +271,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         __builtin_amdgcn_sched_barrier(0);   // one token at a time: the packed loads stay packed until here
-        const float f = a.sb != nullptr ? a.sb[img[u]] : 1.f;
+        const float f = a.sb != nullptr ? a.sb[pos[u].img] : 1.f;
         float xh[MAXIT][VEC], gv[MAXIT][VEC];
         float s1 = 0.f, s2 = 0.f;  // sum of g*gamma, sum of g*gamma*xhat
 #pragma unroll
@@ -256,7 +293,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
         }
         s1 = group_sum(s1, lpt) * invC;
         s2 = group_sum(s2, lpt) * invC;
-        const int oh = (int)(xo[u] >> 32), ow = (int)(xo[u] & 0xffffffffu);
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
           const int cc = sub + lpt * it;
@@ -264,7 +300,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
             float o[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = rstd[u] * (gv[it][e] * gam[it][e] - s1 - xh[it][e] * s2);
-            store_f(dx + ln_src<T>(a, img[u], oh, ow, cc * VEC, a.lddx), o);
+            store_f(dx + ln_off(pos[u], dpix[it], cch[it], a.lddx), o);
           }
         }
       }
@@ -300,8 +336,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
 // swin_unet_v2 (FinalPatchExpand_X4's norm, :385, followed by the 1x1 `output` convolution, :690 / :753).
 // At B=16 256x256 the normalised tensor is 201 MB: written by the LayerNorm, read by the head, written
 // again as its gradient and read back by the LayerNorm backward.  Fused, the forward reads x once and the
-// backward reads x and writes dx; d gamma, d beta, d w, d b leave as partial rows [2C + K*C + K] per
-// workgroup.  One chunk per lane (C <= 64 * VEC), KT = 1 or 4 classes unrolled.
+// backward reads x and writes dx.  With wg[k][c] = w[k][c] gamma[c]:
+//   logit_k = rstd * sum_c wg_kc (x_c - mean) + (sum_c w_kc beta_c + b_k)
+//   d x     = rstd * (gg - mean_c(gg) - xhat mean_c(gg xhat)),   gg_c = sum_k dlogit_k wg_kc
+// and all four parameter gradients follow from S_kc = sum_t dlogit_tk xhat_tc and D_k = sum_t dlogit_tk:
+//   d gamma_c = sum_k w_kc S_kc   d beta_c = sum_k w_kc D_k   d w_kc = gamma_c S_kc + beta_c D_k   d b_k = D_k
+// so a lane carries wg and S only (not gamma, beta, w and four accumulators).  Partial rows [K*C + K] per
+// workgroup, finished by ln_head_finalize_kernel.  KT = 1 with three chunks per lane, or up to 4 classes with one.
 // ---------------------------------------------------------------------------------------------
 struct LnHeadArgs {
   LnArgs ln;            // x, dx, gamma, beta, stats, partial, N, Ho, Wo, C, ldx, lddx, mode, r, eps
@@ -312,7 +353,7 @@ struct LnHeadArgs {
   int K;
 };
 
-template <typename T, bool BWD, int KT, int U>
+template <typename T, bool BWD, int KT, int MAXIT, int U>
 __global__ __launch_bounds__(256) void ln_head_kernel(const LnHeadArgs h, int lpt) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const LnArgs& a = h.ln;
@@ -320,147 +361,159 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const LnHeadArgs h, int lp
   const int sub = lane & (lpt - 1), grp = lane / lpt, tpw = 64 / lpt;
   const int CC = a.C / VEC, K = h.K;
   const int P = a.N * a.Ho * a.Wo, HW = a.Ho * a.Wo;
-  const bool act = sub < CC;
   const T* __restrict__ x = static_cast<const T*>(a.x);
-  float gam[VEC], bet[VEC], wk[KT][VEC], ag[VEC], ab[VEC], aw[KT][VEC], adb[KT];
+  float wg[KT][MAXIT][VEC], S[KT][MAXIT][VEC], D[KT], cst[KT], swg[KT];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    gam[e] = act ? a.gamma[sub * VEC + e] : 0.f;
-    bet[e] = act ? a.beta[sub * VEC + e] : 0.f;
-    ag[e] = ab[e] = 0.f;
+  for (int k = 0; k < KT; ++k) {
+    float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      wk[k][e] = (act && k < K) ? h.w[(size_t)k * a.C + sub * VEC + e] : 0.f;
-      aw[k][e] = 0.f;
+    for (int it = 0; it < MAXIT; ++it) {
+      const int cc = sub + lpt * it;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const bool in = cc < CC && k < K;
+        const float wv = in ? h.w[(size_t)k * a.C + cc * VEC + e] : 0.f;
+        wg[k][it][e] = in ? wv * a.gamma[cc * VEC + e] : 0.f;
+        S[k][it][e] = 0.f;
+        c0 += in ? wv * a.beta[cc * VEC + e] : 0.f;
+        c1 += wg[k][it][e];
+      }
     }
+    cst[k] = group_sum(c0, lpt) + ((h.b != nullptr && k < K) ? h.b[k] : 0.f);
+    swg[k] = group_sum(c1, lpt);
+    D[k] = 0.f;
   }
-#pragma unroll
-  for (int k = 0; k < KT; ++k) adb[k] = 0.f;
+  (void)swg;
   const float invC = 1.f / (float)a.C;
   const int tpb = 4 * tpw * U;
   for (int t0 = blockIdx.x * tpb; t0 < P; t0 += gridDim.x * tpb) {
-    int t[U], img[U], oh[U], ow[U];
+    int t[U], rem[U];   // rem: the token's pixel inside its image (logits are NCHW planes)
+    TokPos pos[U];
     bool tok[U];
-    uint4 xr[U];
+    uint4 xr[U][MAXIT];
     float dl[U][KT], mean[U], rstd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       t[u] = t0 + (u * 4 + wave) * tpw + grp;
       tok[u] = t[u] < P;
       const int tc = tok[u] ? t[u] : 0;
-      const int tt = tc / a.Wo;
-      ow[u] = tc - tt * a.Wo;
-      img[u] = tt / a.Ho;
-      oh[u] = tt - img[u] * a.Ho;
-      xr[u] = (act && tok[u]) ? *reinterpret_cast<const uint4*>(x + ln_src<T>(a, img[u], oh[u], ow[u], sub * VEC, a.ldx))
-                              : make_uint4(0, 0, 0, 0);
+      pos[u] = ln_tok(a, tc);
+      rem[u] = tc - pos[u].img * HW;
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int cc = sub + lpt * it;
+        xr[u][it] = (cc < CC && tok[u]) ? *reinterpret_cast<const uint4*>(x + ln_off(pos[u], 0, cc * VEC, a.ldx))
+                                        : make_uint4(0, 0, 0, 0);
+      }
       if constexpr (BWD) {
         mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
         rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
 #pragma unroll
         for (int k = 0; k < KT; ++k)
-          dl[u][k] = (tok[u] && k < K) ? h.dlogits[((size_t)img[u] * K + k) * HW + oh[u] * a.Wo + ow[u]] : 0.f;
+          dl[u][k] = (tok[u] && k < K) ? h.dlogits[((size_t)pos[u].img * K + k) * HW + rem[u]] : 0.f;
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) pin(xr[u]);
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) pin(xr[u][it]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       __builtin_amdgcn_sched_barrier(0);
-      float v[VEC];
-      unpack_f<T>(xr[u], v);
+      float v[MAXIT][VEC];
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) unpack_f<T>(xr[u][it], v[it]);
       if constexpr (!BWD) {
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s += v[e];
-        const float mu = group_sum(s, lpt) * invC;
-        float q = 0.f;
-        if (act) {
+        for (int it = 0; it < MAXIT; ++it)
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const float d = v[e] - mu;
-            q += d * d;
+          for (int e = 0; e < VEC; ++e) s += v[it][e];
+        const float mu = group_sum(s, lpt) * invC;
+        float q = 0.f, lk[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) lk[k] = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+          if (sub + lpt * it < CC) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float d = v[it][e] - mu;
+              q = fmaf(d, d, q);
+#pragma unroll
+              for (int k = 0; k < KT; ++k) lk[k] = fmaf(d, wg[k][it][e], lk[k]);
+            }
           }
-        }
         const float rs = rsqrtf(group_sum(q, lpt) * invC + a.eps);
         if (sub == 0 && tok[u]) {
           a.stats[(size_t)t[u] * 2] = mu;
           a.stats[(size_t)t[u] * 2 + 1] = rs;
         }
-        float lk[KT];
-#pragma unroll
-        for (int k = 0; k < KT; ++k) lk[k] = 0.f;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const float y = (v[e] - mu) * rs * gam[e] + bet[e];   // gamma = beta = 0 on idle lanes
-#pragma unroll
-          for (int k = 0; k < KT; ++k) lk[k] = fmaf(y, wk[k][e], lk[k]);
-        }
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           const float tot = group_sum(lk[k], lpt);
-          if (sub == 0 && tok[u] && k < K)
-            h.logits[((size_t)img[u] * K + k) * HW + oh[u] * a.Wo + ow[u]] = tot + (h.b != nullptr ? h.b[k] : 0.f);
+          if (sub == 0 && tok[u] && k < K) h.logits[((size_t)pos[u].img * K + k) * HW + rem[u]] = fmaf(rs, tot, cst[k]);
         }
       } else {
         T* __restrict__ dx = static_cast<T*>(a.dx);
-        float gv[VEC], xh[VEC];
+        float gg[MAXIT][VEC];
         float s1 = 0.f, s2 = 0.f;
-        if (act && tok[u]) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+          const bool in = sub + lpt * it < CC && tok[u];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            xh[e] = (v[e] - mean[u]) * rstd[u];
-            const float y = xh[e] * gam[e] + bet[e];
+            const float xh = in ? (v[it][e] - mean[u]) * rstd[u] : 0.f;
+            v[it][e] = xh;
             float g = 0.f;
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-              g = fmaf(dl[u][k], wk[k][e], g);
-              aw[k][e] = fmaf(dl[u][k], y, aw[k][e]);
+              g = fmaf(dl[u][k], wg[k][it][e], g);
+              S[k][it][e] = fmaf(dl[u][k], xh, S[k][it][e]);
             }
-            gv[e] = g;
-            ag[e] = fmaf(g, xh[e], ag[e]);
-            ab[e] += g;
-            const float gg = g * gam[e];
-            s1 += gg;
-            s2 = fmaf(gg, xh[e], s2);
+            gg[it][e] = g;
+            s1 += g;
+            s2 = fmaf(g, xh, s2);
           }
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) gv[e] = xh[e] = 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < KT; ++k) adb[k] += dl[u][k];
+        for (int k = 0; k < KT; ++k) D[k] += dl[u][k];
         s1 = group_sum(s1, lpt) * invC;
         s2 = group_sum(s2, lpt) * invC;
-        if (act && tok[u]) {
-          float o[VEC];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) o[e] = rstd[u] * (gv[e] * gam[e] - s1 - xh[e] * s2);
-          store_f(dx + ln_src<T>(a, img[u], oh[u], ow[u], sub * VEC, a.lddx), o);
+        for (int it = 0; it < MAXIT; ++it) {
+          const int cc = sub + lpt * it;
+          if (cc < CC && tok[u]) {
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = rstd[u] * (gg[it][e] - s1 - v[it][e] * s2);
+            store_f(dx + ln_off(pos[u], 0, cc * VEC, a.lddx), o);
+          }
         }
       }
     }
   }
   if constexpr (BWD) {
-    // one partial row per workgroup: [d gamma (C) | d beta (C) | d w (K*C) | d b (K)]
-    extern __shared__ float red[];  // [4 * tpw][(2 + K) * C + K]
+    // one partial row per workgroup: [S (K*C) | D (K)]
+    extern __shared__ float red[];  // [4 * tpw][K * C + K]
     const int gidx = wave * tpw + grp, ngrp = 4 * tpw;
-    const int n = (2 + K) * a.C + K;
+    const int n = K * a.C + K;
     float* mine = red + (size_t)gidx * n;
-    if (act) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        mine[sub * VEC + e] = ag[e];
-        mine[a.C + sub * VEC + e] = ab[e];
+    for (int it = 0; it < MAXIT; ++it) {
+      const int cc = sub + lpt * it;
+      if (cc < CC) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k)
-          if (k < K) mine[(2 + k) * a.C + sub * VEC + e] = aw[k][e];
+        for (int e = 0; e < VEC; ++e)
+#pragma unroll
+          for (int k = 0; k < KT; ++k)
+            if (k < K) mine[k * a.C + cc * VEC + e] = S[k][it][e];
       }
     }
     if (sub == 0) {
 #pragma unroll
       for (int k = 0; k < KT; ++k)
-        if (k < K) mine[(2 + K) * a.C + k] = adb[k];
+        if (k < K) mine[K * a.C + k] = D[k];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < n; c += 256) {
@@ -469,6 +522,49 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const LnHeadArgs h, int lp
       a.partial[(size_t)blockIdx.x * n + c] = t;
     }
   }
+}
+
+// grid (C / 32), 1024 threads = 32 channels x 32 row groups; sums the rows (in double, fixed order) and forms
+// the four gradients from S and D (see the head comment)
+__global__ __launch_bounds__(1024) void ln_head_finalize_kernel(const float* __restrict__ partial, int rows, int C, int K,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ w, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+  __shared__ double sh[32][33];
+  __shared__ double sD[4];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + el, n = K * C + K;
+  double Skc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k <= K; ++k) {   // k == K: the D columns (el < K)
+    const int col = k < K ? k * C + c : K * C + el;
+    const bool in = k < K ? c < C : el < K;
+    double s = 0.0;
+    if (in)
+      for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * n + col];
+    __syncthreads();
+    sh[g][el] = s;
+    __syncthreads();
+    if (g == 0) {
+      double t = 0.0;
+      for (int r = 0; r < 32; ++r) t += sh[r][el];
+      if (k < K) Skc[k] = t;
+      else if (el < K) sD[el] = t;
+    }
+  }
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double dg = 0.0, dbt = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double wv = (double)w[(size_t)k * C + c];
+      dg += wv * Skc[k];
+      dbt += wv * sD[k];
+      dw[(size_t)k * C + c] = (float)((double)gamma[c] * Skc[k] + (double)beta[c] * sD[k]);
+    }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)dbt;
+  }
+  if (blockIdx.x == 0 && g == 0 && el < K && db != nullptr) db[el] = (float)sD[el];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1628,8 +1724,27 @@ inline int grid_cap(long long units, int per_block, int per_cu) {
   return (int)g;
 }
 
+// see fdiv(): m = ceil(2^(32+s) / d), d = 1 -> m = 0
+static FastDiv make_fastdiv(int d) {
+  FastDiv f{0u, 0};
+  if (d <= 1) return f;
+  int S = 0;
+  while ((1LL << S) < d) ++S;   // ceil(log2 d) >= 1
+  f.s = S - 1;
+  f.m = (unsigned)(((1ULL << (31 + S)) + (unsigned long long)d - 1) / (unsigned long long)d);
+  return f;
+}
+static void ln_geometry(const uz_ln_desc* d, LnArgs* a) {
+  a->fWo = make_fastdiv(d->Wo);
+  a->fHo = make_fastdiv(d->Ho);
+  a->fr = make_fastdiv(d->mode == 2 ? d->r : 1);
+  a->Hin = d->mode == 1 ? 2 * d->Ho : d->mode == 2 ? d->Ho / d->r : d->Ho;
+  a->Win = d->mode == 1 ? 2 * d->Wo : d->mode == 2 ? d->Wo / d->r : d->Wo;
+}
+
 int ln_lpt(const uz_ln_desc* d) {
-  const int cc = d->C / (d->dtype == UZ_BF16 ? 8 : 4);
+  int cc = d->C / (d->dtype == UZ_BF16 ? 8 : 4);
+  if (!(uz_tune_flags() & 0x100000)) cc = (cc + 2) / 3;   // three chunks per lane (see ln_unroll)
   int l = 1;
   while (l < cc && l < 64) l <<= 1;
   return l;
@@ -1657,38 +1772,40 @@ int ln_its(const uz_ln_desc* d) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4, lpt = ln_lpt(d);
   return (d->C / vec + lpt - 1) / lpt;
 }
-int ln_unroll(const uz_ln_desc* d) {
+// tokens per lane group and pass.  Measured on the 1M-token expand LayerNorm of swin_unet_v2 (201 MB in, 201 MB
+// out, three chunks per lane): forward U = 1 / 2 -> 101 / 119 us, backward 200 / 185 us; U = 4 spills.
+int ln_unroll(const uz_ln_desc* d, bool bwd) {
   const int its = ln_its(d);
-  if (its > 3) return 1;
-  if (its > 1) return 2;
-  // one chunk per lane.  Measured on the 1M-token expand LayerNorm of swin_unet_v2 (201 MB in, 201 MB out):
-  // U = 2 / 4 / 8 -> 156 / 168 / 207 us forward (occupancy beats bytes per wave); at 65k tokens U = 4 wins.
-  const long long P = (long long)d->N * d->Ho * d->Wo;
   const int u = (int)((uz_tune_flags() >> 16) & 15);
-  if (u == 2 || u == 4 || u == 8) return u;
-  return P >= (long long)4 * (64 / ln_lpt(d)) * 4 * UZ_NUM_CU * 8 ? 2 : 4;
+  if (u == 1 || u == 2 || u == 4 || (u == 8 && its == 1)) return its > 3 ? 1 : u;
+  if (its > 3) return 1;
+  if (its > 1) return bwd ? 2 : 1;
+  return 4;
 }
 
-int ln_grid(const uz_ln_desc* d) {
-  const int tpb = 4 * (64 / ln_lpt(d)) * ln_unroll(d);
+int ln_grid(const uz_ln_desc* d, bool bwd) {
+  const int tpb = 4 * (64 / ln_lpt(d)) * ln_unroll(d, bwd);
   return grid_cap((long long)d->N * d->Ho * d->Wo, tpb, 8);
 }
 
 template <bool BWD>
 void ln_launch(const uz_ln_desc* d, dim3 grid, dim3 block, size_t shm, hipStream_t st, const LnArgs& a, int lpt) {
-  const int its = ln_its(d), u = ln_unroll(d);
+  const int its = ln_its(d), u = ln_unroll(d, BWD);
 #define UZ_LN(T, I, U) hipLaunchKernelGGL((layernorm_kernel<T, BWD, I, U>), grid, block, shm, st, a, lpt)
+#define UZ_LN_U(T, I) \
+  do { if (u == 1) UZ_LN(T, I, 1); else if (u == 4) UZ_LN(T, I, 4); else UZ_LN(T, I, 2); } while (0)
   if (d->dtype == UZ_BF16) {
-    if (its == 1) { if (u == 8) UZ_LN(bf16_t, 1, 8); else if (u == 4) UZ_LN(bf16_t, 1, 4); else UZ_LN(bf16_t, 1, 2); }
-    else if (its == 2) UZ_LN(bf16_t, 2, 2);
-    else if (its == 3) UZ_LN(bf16_t, 3, 2);
+    if (its == 1) { if (u == 8) UZ_LN(bf16_t, 1, 8); else UZ_LN_U(bf16_t, 1); }
+    else if (its == 2) UZ_LN_U(bf16_t, 2);
+    else if (its == 3) UZ_LN_U(bf16_t, 3);
     else UZ_LN(bf16_t, 6, 1);
   } else {
-    if (its == 1) { if (u == 8) UZ_LN(float, 1, 8); else if (u == 4) UZ_LN(float, 1, 4); else UZ_LN(float, 1, 2); }
-    else if (its == 2) UZ_LN(float, 2, 2);
-    else if (its == 3) UZ_LN(float, 3, 2);
+    if (its == 1) { if (u == 8) UZ_LN(float, 1, 8); else UZ_LN_U(float, 1); }
+    else if (its == 2) UZ_LN_U(float, 2);
+    else if (its == 3) UZ_LN_U(float, 3);
     else UZ_LN(float, 6, 1);
   }
+#undef UZ_LN_U
 #undef UZ_LN
 }
 
@@ -1719,7 +1836,8 @@ extern "C" int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float*
   a.x = x; a.y = y; a.res = res; a.gamma = gamma; a.beta = beta; a.sb = image_scale; a.stats = stats;
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
   a.mode = d->mode; a.r = d->r; a.eps = d->eps;
-  const dim3 grid(ln_grid(d)), block(256);
+  ln_geometry(d, &a);
+  const dim3 grid(ln_grid(d, false)), block(256);
   const int lpt = ln_lpt(d);
   ln_launch<false>(d, grid, block, 0, (hipStream_t)stream, a, lpt);
   UZ_LAUNCH_CHECK("uz_layernorm_fwd");
@@ -1729,7 +1847,7 @@ extern "C" int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float*
 extern "C" int uz_layernorm_bwd_rows(const uz_ln_desc* d) {
   const int rc = ln_check("uz_layernorm_bwd_rows", d);
   if (rc != UZ_OK) return rc;
-  return ln_grid(d);
+  return ln_grid(d, true);
 }
 
 extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* stats,
@@ -1744,7 +1862,8 @@ extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float*
   a.partial = partial;
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldg = d->ldg; a.lddx = d->lddx;
   a.mode = d->mode; a.r = d->r; a.eps = d->eps;
-  const dim3 grid(ln_grid(d)), block(256);
+  ln_geometry(d, &a);
+  const dim3 grid(ln_grid(d, true)), block(256);
   const int lpt = ln_lpt(d);
   const size_t shm = (size_t)4 * (64 / lpt) * 2 * d->C * sizeof(float);
   ln_launch<true>(d, grid, block, shm, (hipStream_t)stream, a, lpt);
@@ -1753,33 +1872,49 @@ extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float*
 }
 
 // ---- LayerNorm + 1x1 head --------------------------------------------------------------------------
-constexpr int LNH_U = 2, LNH_MAXK = 4;
+constexpr int LNH_MAXK = 4;
 
+// lanes per token: one class -> three chunks per lane (the layout the plain kernel measures fastest with);
+// more classes -> one chunk per lane, so that wg and S of all classes stay in registers
+static int ln_head_its(int K) { return K == 1 ? 3 : 1; }
+static int ln_head_lpt(const uz_ln_desc* d, int K) {
+  const int its = ln_head_its(K);
+  const int cc = (d->C / (d->dtype == UZ_BF16 ? 8 : 4) + its - 1) / its;
+  int l = 1;
+  while (l < cc && l < 64) l <<= 1;
+  return l;
+}
 static int ln_head_check(const char* fn, const uz_ln_desc* d, int K) {
   const int rc = ln_check(fn, d);
   if (rc != UZ_OK) return rc;
-  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
-  UZ_REQUIRE(d->C / vec <= 64, "%s: C=%d needs more than one chunk per lane", fn, d->C);
   UZ_REQUIRE(K >= 1 && K <= LNH_MAXK, "%s: K=%d classes (max %d)", fn, K, LNH_MAXK);
-  const long long shm = (long long)4 * (64 / ln_lpt(d)) * ((2 + K) * d->C + K) * 4;
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(d->C / vec <= 64 * ln_head_its(K), "%s: C=%d too wide for %d classes", fn, d->C, K);
+  const long long shm = (long long)4 * (64 / ln_head_lpt(d, K)) * (K * d->C + K) * 4;
   UZ_REQUIRE(shm <= 64 * 1024, "%s: partial-row staging exceeds 64 KiB", fn);
   return UZ_OK;
 }
-static int ln_head_grid(const uz_ln_desc* d) {
-  return grid_cap((long long)d->N * d->Ho * d->Wo, 4 * (64 / ln_lpt(d)) * LNH_U, 8);
+static int ln_head_unroll(bool bwd, int K) { return (K == 1 && !bwd) ? 1 : 2; }
+static int ln_head_grid(const uz_ln_desc* d, int K, bool bwd) {
+  return grid_cap((long long)d->N * d->Ho * d->Wo, 4 * (64 / ln_head_lpt(d, K)) * ln_head_unroll(bwd, K), 8);
 }
 static void ln_head_args(const uz_ln_desc* d, LnHeadArgs* h) {
   LnArgs& a = h->ln;
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.lddx = d->lddx;
   a.mode = d->mode; a.r = d->r; a.eps = d->eps;
+  ln_geometry(d, &a);
 }
 template <bool BWD>
 static void ln_head_launch(const uz_ln_desc* d, const LnHeadArgs& h, size_t shm, hipStream_t st) {
-  const dim3 grid(ln_head_grid(d)), block(256);
-  const int lpt = ln_lpt(d);
-#define UZ_LNH(T, KT) hipLaunchKernelGGL((ln_head_kernel<T, BWD, KT, LNH_U>), grid, block, shm, st, h, lpt)
-  if (d->dtype == UZ_BF16) { if (h.K == 1) UZ_LNH(bf16_t, 1); else UZ_LNH(bf16_t, 4); }
-  else { if (h.K == 1) UZ_LNH(float, 1); else UZ_LNH(float, 4); }
+  const dim3 grid(ln_head_grid(d, h.K, BWD)), block(256);
+  const int lpt = ln_head_lpt(d, h.K);
+#define UZ_LNH(T) \
+  do { \
+    if (h.K == 1) hipLaunchKernelGGL((ln_head_kernel<T, BWD, 1, 3, (BWD ? 2 : 1)>), grid, block, shm, st, h, lpt); \
+    else hipLaunchKernelGGL((ln_head_kernel<T, BWD, 4, 1, 2>), grid, block, shm, st, h, lpt); \
+  } while (0)
+  if (d->dtype == UZ_BF16) UZ_LNH(bf16_t);
+  else UZ_LNH(float);
 #undef UZ_LNH
 }
 
@@ -1797,28 +1932,32 @@ extern "C" int uz_ln_head_fwd(const uz_ln_desc* d, const void* x, const float* g
   return UZ_OK;
 }
 
-extern "C" int uz_ln_head_bwd_rows(const uz_ln_desc* d, int K) {
-  const int rc = ln_head_check("uz_ln_head_bwd_rows", d, K);
+extern "C" long long uz_ln_head_bwd_workspace_bytes(const uz_ln_desc* d, int K) {
+  const int rc = ln_head_check("uz_ln_head_bwd_workspace_bytes", d, K);
   if (rc != UZ_OK) return rc;
-  return ln_head_grid(d);
+  return (long long)ln_head_grid(d, K, true) * (K * d->C + K) * (long long)sizeof(float);
 }
 
 extern "C" int uz_ln_head_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
                               const float* w, int K, const float* stats, const float* dlogits, void* dx,
-                              float* partial, void* stream) {
+                              float* dgamma, float* dbeta, float* dw, float* db, float* workspace, void* stream) {
   const int rc = ln_head_check("uz_ln_head_bwd", d, K);
   if (rc != UZ_OK) return rc;
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
-  UZ_REQUIRE(x && gamma && beta && w && stats && dlogits && dx && partial, "uz_ln_head_bwd: null pointer");
+  UZ_REQUIRE(x && gamma && beta && w && stats && dlogits && dx && dgamma && dbeta && dw && workspace,
+             "uz_ln_head_bwd: null pointer");
   UZ_REQUIRE(d->lddx % vec == 0, "uz_ln_head_bwd: bad lddx");
   LnHeadArgs h{};
   ln_head_args(d, &h);
   h.ln.x = x; h.ln.gamma = gamma; h.ln.beta = beta; h.ln.stats = const_cast<float*>(stats);
-  h.ln.dx = dx; h.ln.partial = partial;
+  h.ln.dx = dx; h.ln.partial = workspace;
   h.w = w; h.dlogits = dlogits; h.K = K;
-  const size_t shm = (size_t)4 * (64 / ln_lpt(d)) * ((2 + K) * d->C + K) * sizeof(float);
+  const size_t shm = (size_t)4 * (64 / ln_head_lpt(d, K)) * (K * d->C + K) * sizeof(float);
   ln_head_launch<true>(d, h, shm, (hipStream_t)stream);
   UZ_LAUNCH_CHECK("uz_ln_head_bwd");
+  hipLaunchKernelGGL(ln_head_finalize_kernel, dim3(uz_cdiv(d->C, 32)), dim3(1024), 0, (hipStream_t)stream,
+                     (const float*)workspace, ln_head_grid(d, K, true), d->C, K, gamma, beta, w, dgamma, dbeta, dw, db);
+  UZ_LAUNCH_CHECK("uz_ln_head_bwd (finalize)");
   return UZ_OK;
 }
 

@@ -602,9 +602,9 @@ LN_HEAD_MAX_CLASSES = 4
 
 
 def ln_head_supported(C: int, K: int, dtype: torch.dtype) -> bool:
-    """shapes the fused LayerNorm + 1x1 head kernels take (one 16-byte chunk per lane, <= 4 classes)"""
+    """shapes the fused LayerNorm + 1x1 head kernels take (<= 4 classes; one class: three 16-byte chunks per lane)"""
     vec = 8 if dtype == torch.bfloat16 else 4
-    return C % vec == 0 and C // vec <= 64 and 1 <= K <= LN_HEAD_MAX_CLASSES
+    return C % vec == 0 and 1 <= K <= LN_HEAD_MAX_CLASSES and C // vec <= (192 if K == 1 else 64)
 
 
 def ln_head_fwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor],
@@ -631,25 +631,20 @@ def ln_head_bwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor
     C = w.shape[1]
     assert dlogits.dtype == torch.float32 and dlogits.is_contiguous() and w.shape[0] == K
     d = _ln_desc(x, N, Ho, Wo, C, mode, r, eps, lddx=dx.ld)
-    rows = L.check_count(lib.uz_ln_head_bwd_rows(byref(d), K), "uz_ln_head_bwd_rows")
-    n = (2 + K) * C + K
+    wsb = L.check_count(lib.uz_ln_head_bwd_workspace_bytes(byref(d), K), "uz_ln_head_bwd_workspace_bytes")
     dev = x.buf.device
-    part = torch.empty((rows, n), dtype=torch.float32, device=dev)
-    with _Timed("ln_head_bwd", 4.0 * N * Ho * Wo * C * K, x.buf.element_size() * N * Ho * Wo * C * 2):
-        L.check(lib.uz_ln_head_bwd(byref(d), x.ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), K,
-                                   stats.data_ptr(), dlogits.data_ptr(), dx.ptr(), part.data_ptr(), L.stream_ptr()),
-                "uz_ln_head_bwd")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
     outs = []
     for t, shape in ((dgamma, (C,)), (dbeta, (C,)), (dw, (K, C)), (db, (K,))):
         if t is None:
             t = torch.empty(shape, dtype=torch.float32, device=dev)
         assert t.numel() == math.prod(shape) and t.dtype == torch.float32 and t.is_contiguous()
         outs.append(t)
-    st = L.stream_ptr()
-    L.check(lib.uz_sum_rows_f32_ld(part.data_ptr(), n, rows, 2 * C, outs[0].data_ptr(), C, outs[1].data_ptr(), st),
-            "uz_sum_rows_f32_ld")
-    L.check(lib.uz_sum_rows_f32_ld(part.data_ptr() + 8 * C, n, rows, K * C + K, outs[2].data_ptr(), K * C,
-                                   outs[3].data_ptr(), st), "uz_sum_rows_f32_ld")
+    with _Timed("ln_head_bwd", 4.0 * N * Ho * Wo * C * K, x.buf.element_size() * N * Ho * Wo * C * 2):
+        L.check(lib.uz_ln_head_bwd(byref(d), x.ptr(), gamma.data_ptr(), beta.data_ptr(), w.data_ptr(), K,
+                                   stats.data_ptr(), dlogits.data_ptr(), dx.ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
+                                   outs[2].data_ptr(), outs[3].data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                "uz_ln_head_bwd")
     return tuple(outs)
 
 
