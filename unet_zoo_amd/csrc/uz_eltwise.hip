@@ -626,12 +626,49 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, int C
     dst[idx] = (T)pack_element(mode, w, Co, Ci, Tn, Kpad, idx);
 }
 
-// every weight tensor of a model in ONE launch: blockIdx.y = item, blockIdx.x strides over its elements
+// every weight tensor of a model in ONE launch: blockIdx.y = item, blockIdx.x strides over its elements.
+// One-tap items (Linear layers, 1x1 convolutions: all of swin_unet_v2's 27 M parameters, twice per step) are
+// plain 2-D matrices and take two fast paths instead of the element-wise gather with its 64-bit divisions:
+// a vectorised convert-copy when source and destination have the same orientation, and a 64 x 64 transpose
+// through LDS (coalesced both ways) when they do not.
 template <typename T>
-__global__ void pack_weights_batched_kernel(const uz_pack_item* __restrict__ items, int n, long long total) {
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const uz_pack_item* __restrict__ items, int n, long long total) {
   const uz_pack_item it = items[blockIdx.y];
   const long long count = ((int)blockIdx.y + 1 < n ? items[blockIdx.y + 1].begin : total) - it.begin;
   T* __restrict__ dst = static_cast<T*>(it.dst);
+  const float* __restrict__ src = it.src;
+  const bool same = it.mode == UZ_PACK_CONV_FWD || it.mode == UZ_PACK_CONVT_DGRAD;
+  const bool transposed = it.mode == UZ_PACK_CONV_DGRAD || it.mode == UZ_PACK_CONVT_FWD;
+  if (it.T == 1 && same && count == (long long)it.Co * it.Ci && (count & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < count / 4;
+         q += (long long)gridDim.x * blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(src)[q];
+      dst[4 * q] = (T)v.x;
+      dst[4 * q + 1] = (T)v.y;
+      dst[4 * q + 2] = (T)v.z;
+      dst[4 * q + 3] = (T)v.w;
+    }
+    return;
+  }
+  if (it.T == 1 && transposed && count == (long long)it.Co * it.Ci) {
+    // source rows R x columns Cc -> destination [Cc][R]
+    const int R = it.mode == UZ_PACK_CONV_DGRAD ? it.Co : it.Ci;
+    const int Cc = it.mode == UZ_PACK_CONV_DGRAD ? it.Ci : it.Co;
+    __shared__ float tile[64][65];
+    const int tr = (R + 63) / 64, tc = (Cc + 63) / 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+      const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+      __syncthreads();
+      for (int r = ty; r < 64; r += 4)
+        tile[r][tx] = (r0 + r < R && c0 + tx < Cc) ? src[(size_t)(r0 + r) * Cc + c0 + tx] : 0.f;
+      __syncthreads();
+      for (int c = ty; c < 64; c += 4)
+        if (c0 + c < Cc && r0 + tx < R) dst[(size_t)(c0 + c) * R + r0 + tx] = (T)tile[tx][c];
+    }
+    return;
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < count;
        idx += (long long)gridDim.x * blockDim.x)
     dst[idx] = (T)pack_element(it.mode, it.src, it.Co, it.Ci, it.T, it.Kpad, idx);
