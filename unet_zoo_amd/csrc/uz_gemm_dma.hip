@@ -50,20 +50,27 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BN>
+// BM x BN tile per workgroup, NST stages of one 128-byte K slab each in the LDS ring (NST - 1 in flight).
+// (256, 3) is the throughput shape.  A GEMM whose 256-row tiling leaves most CUs idle (the 16x16 and 8x8
+// token maps of swin_unet_v2) is bound by the latency of its K loop -- slab s + 2 is requested when slab s is
+// consumed, so a step costs half a memory round trip whatever the tile -- and takes (128, 4): twice the
+// workgroups, and a third of a round trip per step.
+template <typename T, int BN, int BM, int NST>
 __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = 8 * VEC;
-  constexpr int A_BYTES = 256 * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int NAP = 4;          // A pieces per wave per stage (32 pieces of 8 rows)
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NAP = BM / 64;    // A pieces per wave per stage (BM / 8 pieces of 8 rows)
   constexpr int NBP = BN / 64;    // B pieces per wave per stage
-  constexpr int TN = BN / 64, WTN = BN / 2;  // waves: 4 (M) x 2 (N), wave tile 64 x BN/2
-  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+  constexpr int WM = BM / 64, WN = 8 / WM;        // waves: WM (M) x WN (N), wave tile 64 x BN / WN
+  constexpr int WTN = BN / WN, TN = WTN / 32;
+  static_assert(TN >= 1 && (BM == 256 || BM == 128) && (NST == 3 || NST == 4), "unsupported tile");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * BN;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
@@ -157,11 +164,11 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
 
   // C staging sits at the END of the ring, so stage 0 (BN = 64: stages 0 and 1) stays free during an epilogue
   constexpr int RSCB = BN * 2 + 16;                      // bf16 staging row stride
-  constexpr int SC_OFF = 3 * STAGE - 256 * RSCB;
+  constexpr int SC_OFF = NST * STAGE - BM * RSCB;
   constexpr int PRE = (SC_OFF >= 2 * STAGE) ? 2 : ((SC_OFF >= STAGE) ? 1 : 0);   // stages that may be prefetched
   int pre = 0;   // stages of the current tile already issued by the previous tile's epilogue
   for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
-    const int m0 = tile * 256;
+    const int m0 = tile * BM;
 
     f32x16 acc[2][TN];
 #pragma unroll
@@ -174,16 +181,20 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
     __builtin_amdgcn_s_barrier();  // previous tile's staging reads are finished everywhere
     if (pre < 1) issue(m0, 0, 0);
     if (nsteps > 1 && pre < 2) issue(m0, 1, 1);
+    if (NST == 4 && nsteps > 2) issue(m0, 2, 2);
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) {
+      // stage s must have landed; up to NST - 2 younger stages stay in flight
+      if (NST == 4 && s + 2 < nsteps) {
+        wait_vmcnt<2 * (NAP + NBP)>();
+      } else if (s + 1 < nsteps) {
         wait_vmcnt<NAP + NBP>();
       } else {
         wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
-      if (s + 2 < nsteps) issue(m0, (s + 2) % 3, s + 2);
-      const char* sA = smem + (s % 3) * STAGE;
+      if (s + NST - 1 < nsteps) issue(m0, (s + NST - 1) % NST, s + NST - 1);
+      const char* sA = smem + (s % NST) * STAGE;
       const char* sBt = sA + A_BYTES;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -218,15 +229,15 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
     pre = 0;
     if constexpr (sizeof(T) == 2) {
       constexpr int RSC = RSCB;
-      static_assert(256 * RSC <= 3 * STAGE, "C staging must fit the ring");
+      static_assert(BM * RSC <= NST * STAGE, "C staging must fit the ring");
       __builtin_amdgcn_s_barrier();   // every wave has finished reading this tile's A / B stages
       {   // the next tile's first stage(s) stream in while this tile is staged and stored
         const int next = tile + gridDim.x;
         if (next < a.tiles_m && PRE > 0) {
-          issue(next * 256, 0, 0);
+          issue(next * BM, 0, 0);
           pre = 1;
           if (PRE > 1 && nsteps > 1) {
-            issue(next * 256, 1, 1);
+            issue(next * BM, 1, 1);
             pre = 2;
           }
         }
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
       static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
       const int cc = tid % CPR;
       const bool cok = n0 + cc * VEC < a.Nout;
-      for (int ml = tid / CPR; ml < 256; ml += 512 / CPR) {
+      for (int ml = tid / CPR; ml < BM; ml += 512 / CPR) {
         const long long orow = out_row(ml, ab);
         if (orow >= 0 && cok) {
           const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(sC + ml * RSC + cc * 16);
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
     }
     wait_vmcnt<0>();
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [4][BN][2]
+    float* red = reinterpret_cast<float*>(smem);  // [WM][BN][2]
     if (lh == 0) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
     if (tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < WM; ++k) {
         t1 += red[(k * BN + tid) * 2 + 0];
         t2 += red[(k * BN + tid) * 2 + 1];
       }
@@ -364,8 +375,10 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
     else return 0;
   }
   const long long M = (long long)d->N * d->H * d->W;
-  p->tiles_m = (int)((M + 255) / 256);
   p->tiles_n = (d->Nout + p->bn - 1) / p->bn;
+  // latency shape (see the kernel): when 256-row tiles would occupy at most half of the CUs
+  p->bm = (p->bn == 128 && ((M + 255) / 256) * p->tiles_n * 2 <= UZ_NUM_CU && !(uz_tune_flags() & 0x200000)) ? 128 : 256;
+  p->tiles_m = (int)((M + p->bm - 1) / p->bm);
   int cap = UZ_NUM_CU / p->tiles_n;
   if (cap < 1) cap = 1;
   p->grid_m = p->tiles_m < cap ? p->tiles_m : cap;
@@ -375,8 +388,9 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
 template <typename T>
 static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
   dim3 grid(p.grid_m, p.tiles_n), block(512);
-  if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gemm_dma_kernel<T, 128>), grid, block, 0, s, a);
+  if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3>), grid, block, 0, s, a);
+  else if (p.bm == 128) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 4>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 256, 3>), grid, block, 0, s, a);
   UZ_LAUNCH_CHECK("uz_conv_igemm(gemm_dma)");
   return UZ_OK;
 }
