@@ -279,20 +279,23 @@ __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict_
 }
 
 // fp32 results straight into (up to) two destinations: elements [0, n0) -> out0, [n0, n) -> out1
-// (e.g. d gamma | d beta into the two parameters' gradient tensors); accumulation in double as above
+// (e.g. d gamma | d beta into the two parameters' gradient tensors); accumulation in double as above.
+// EW elements x 1024 / EW row groups per workgroup: many rows of few columns take EW = 8.
+template <int EW>
 __global__ __launch_bounds__(1024) void sum_rows_f32_kernel(const float* __restrict__ partial, int ld, int rows, int n,
                                                             float* __restrict__ out0, int n0, float* __restrict__ out1) {
-  __shared__ double sh[32][33];
-  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;
+  constexpr int NG = 1024 / EW;
+  __shared__ double sh[NG][EW + 1];
+  const int el = threadIdx.x % EW, g = threadIdx.x / EW;
+  const int e = blockIdx.x * EW + el;
   double s = 0.0;
   if (e < n)
-    for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * ld + e];
+    for (int r = g; r < rows; r += NG) s += (double)partial[(size_t)r * ld + e];
   sh[g][el] = s;
   __syncthreads();
   if (g == 0 && e < n) {
     double t = 0.0;
-    for (int r = 0; r < 32; ++r) t += sh[r][el];
+    for (int r = 0; r < NG; ++r) t += sh[r][el];
     if (e < n0) out0[e] = (float)t;
     else out1[e - n0] = (float)t;
   }
@@ -471,8 +474,12 @@ extern "C" int uz_sum_rows_f32_ld(const float* partial, int ld, int rows, int n,
                                   void* stream) {
   UZ_REQUIRE(partial && out0 && rows > 0 && n > 0 && ld >= n && n0 >= 0 && n0 <= n && (out1 || n0 == n),
              "uz_sum_rows_f32: bad args");
-  hipLaunchKernelGGL(sum_rows_f32_kernel, dim3(uz_cdiv(n, 32)), dim3(1024), 0, (hipStream_t)stream, partial, ld, rows, n,
-                     out0, n0, out1);
+  if (rows >= 256 && n <= 2048)
+    hipLaunchKernelGGL(sum_rows_f32_kernel<8>, dim3(uz_cdiv(n, 8)), dim3(1024), 0, (hipStream_t)stream, partial, ld, rows, n,
+                       out0, n0, out1);
+  else
+    hipLaunchKernelGGL(sum_rows_f32_kernel<32>, dim3(uz_cdiv(n, 32)), dim3(1024), 0, (hipStream_t)stream, partial, ld, rows, n,
+                       out0, n0, out1);
   UZ_LAUNCH_CHECK("uz_sum_rows_f32");
   return UZ_OK;
 }

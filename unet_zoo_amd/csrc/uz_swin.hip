@@ -524,30 +524,31 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const LnHeadArgs h, int lp
   }
 }
 
-// grid (C / 32), 1024 threads = 32 channels x 32 row groups; sums the rows (in double, fixed order) and forms
-// the four gradients from S and D (see the head comment)
+// grid (C / 8), 1024 threads = 8 channels x 128 row groups (the rows are many -- one per workgroup of the main
+// kernel -- and the columns few); sums the rows (in double, fixed order) and forms the four gradients from S
+// and D (see the head comment)
 __global__ __launch_bounds__(1024) void ln_head_finalize_kernel(const float* __restrict__ partial, int rows, int C, int K,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ w, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ dw,
                                                                 float* __restrict__ db) {
-  __shared__ double sh[32][33];
+  __shared__ double sh[128][9];
   __shared__ double sD[4];
-  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + el, n = K * C + K;
+  const int el = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + el, n = K * C + K;
   double Skc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int k = 0; k <= K; ++k) {   // k == K: the D columns (el < K)
     const int col = k < K ? k * C + c : K * C + el;
     const bool in = k < K ? c < C : el < K;
     double s = 0.0;
     if (in)
-      for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * n + col];
+      for (int r = g; r < rows; r += 128) s += (double)partial[(size_t)r * n + col];
     __syncthreads();
     sh[g][el] = s;
     __syncthreads();
     if (g == 0) {
       double t = 0.0;
-      for (int r = 0; r < 32; ++r) t += sh[r][el];
+      for (int r = 0; r < 128; ++r) t += sh[r][el];
       if (k < K) Skc[k] = t;
       else if (el < K) sD[el] = t;
     }
@@ -1955,7 +1956,7 @@ extern "C" int uz_ln_head_bwd(const uz_ln_desc* d, const void* x, const float* g
   const size_t shm = (size_t)4 * (64 / ln_head_lpt(d, K)) * (K * d->C + K) * sizeof(float);
   ln_head_launch<true>(d, h, shm, (hipStream_t)stream);
   UZ_LAUNCH_CHECK("uz_ln_head_bwd");
-  hipLaunchKernelGGL(ln_head_finalize_kernel, dim3(uz_cdiv(d->C, 32)), dim3(1024), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ln_head_finalize_kernel, dim3(uz_cdiv(d->C, 8)), dim3(1024), 0, (hipStream_t)stream,
                      (const float*)workspace, ln_head_grid(d, K, true), d->C, K, gamma, beta, w, dgamma, dbeta, dw, db);
   UZ_LAUNCH_CHECK("uz_ln_head_bwd (finalize)");
   return UZ_OK;
