@@ -1252,6 +1252,150 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   }
 }
 
+// bf16 forward, block-per-wave form (the decomposition of winattn_bwd_mfma_kernel): one workgroup per
+// (window, head), wave w owns the 32 x 32 score block (query tile qt = w >> 1, key tile kt = w & 1) with
+// column = query.  The two waves of a query tile exchange their row maxima, then their row sums and partial
+// P V products, through LDS.  ~100 VGPRs and 48 KB of LDS: three workgroups per CU where the one-wave-per-unit
+// kernel above (325 VGPRs) fits one.
+__global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t sVT[AD * VTS];
+  __shared__ float sRedO[2][64 * 17];   // P V hand-over of the kt = 1 waves, [lane][16] (+1 pad)
+  __shared__ float sM[2][AN], sL[2][AN];
+  __shared__ float sRk[AN];
+  __shared__ int sCnt[AN];
+  __shared__ float sTab[2][AN * ANS];   // 1 / clip(tau) and bias of this head (padding: bias = -1e30)
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, h = blockIdx.y;
+  const int qt = w >> 1, kt = w & 1;
+  const int N = a.ws * a.ws;
+  const int nWin = a.B * (a.H / a.ws) * (a.W / a.ws);
+  const bool masked = a.shift > 0;
+  const bf16_t* __restrict__ qkv = static_cast<const bf16_t*>(a.qkv);
+  bf16_t* __restrict__ out = static_cast<bf16_t*>(a.out);
+  for (int e = tid; e < AN * AN; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const bool in = r < N && c < N;
+    sTab[0][r * ANS + c] = in ? 1.f / fmaxf(a.tau[((size_t)h * a.Nt + r) * a.Nt + c], 0.01f) : 1.f;
+    sTab[1][r * ANS + c] = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;
+  }
+  const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
+
+  WinTok ntq = {0, -1}, ntk = {0, -1};
+  bf16x8 nq[2], nk[2], nv[2];
+  auto fetch = [&](int win) {
+    ntq = {0, -1};
+    ntk = {0, -1};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) nq[ks][e] = nk[ks][e] = nv[ks][e] = (bf16_t)0.f;
+    if (iq < N) {
+      ntq = win_token(a, win, iq);
+      const bf16_t* row = qkv + (size_t)ntq.tok * a.ldq + h * AD + 8 * lh;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) nq[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+    }
+    if (jk < N) {
+      ntk = win_token(a, win, jk);
+      const bf16_t* row = qkv + (size_t)ntk.tok * a.ldq + a.C + h * AD + 8 * lh;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        nk[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+        nv[ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
+      }
+    }
+  };
+  if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
+
+  for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
+    __syncthreads();   // previous window's readers are done (and sTab has landed)
+    const WinTok tq = ntq, tkk = ntk;
+    bf16x8 qf[2], kf[2];
+    float rq;
+    {
+      float q2 = 0.f, k2 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = nq[ks];
+        kf[ks] = nk[ks];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float qv = (float)qf[ks][e], kv = (float)kf[ks][e];
+          q2 = fmaf(qv, qv, q2);
+          k2 = fmaf(kv, kv, k2);
+        }
+      }
+      q2 += __shfl_xor(q2, 32);
+      k2 += __shfl_xor(k2, 32);
+      rq = rcp(a.scale * sqrtf(q2));   // inf for a zero row: the product below is clamped
+      if (qt == 0) {
+        if (lh == 0) {
+          sRk[jk] = rcp(sqrtf(k2));
+          sCnt[jk] = tkk.cnt;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sVT[(16 * ks + 8 * lh + e) * VTS + jk] = nv[ks][e];
+      }
+    }
+    __syncthreads();
+    f32x16 ut;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ut[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ut, 0, 0, 0);
+    if (win + (int)gridDim.x < nWin) fetch(win + gridDim.x);
+    float sv[16], mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float rden = fminf(rq * sRk[j], 1e6f);      // 1 / max(|scale q||k|, 1e-6)
+      float v = fmaf(ut[r] * a.scale * rden, sTab[0][iq * ANS + j], sTab[1][iq * ANS + j]);
+      if (masked && sCnt[j] != tq.cnt) v -= 100.f;
+      sv[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (lh == 0) sM[kt][iq] = mx;
+    __syncthreads();
+    const float m = fmaxf(sM[0][iq], sM[1][iq]);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = __expf(sv[r] - m);
+      ls += sv[r];
+    }
+    ls += __shfl_xor(ls, 32);
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(sVT, l31, lh, kt, s2), pack8(sv + 8 * s2), o, 0, 0, 0);
+    if (kt == 1) {
+      float* red = &sRedO[qt][lane * 17];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[r] = o[r];
+      if (lh == 0) sL[qt][l31] = ls;
+    }
+    __syncthreads();
+    if (kt == 0 && iq < N) {
+      const float* r1 = &sRedO[qt][lane * 17];
+      const float l = ls + sL[qt][l31];
+      const float inv = rcp(l);
+      bf16_t* orow = out + (size_t)tq.tok * a.ldo + h * AD + 4 * lh;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        bf16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)((o[4 * q4 + e] + r1[4 * q4 + e]) * inv);
+        *reinterpret_cast<bf16x4*>(orow + 8 * q4) = o4;
+      }
+      if (lh == 0) a.lse[((size_t)win * a.heads + h) * N + iq] = m + __logf(l);
+    }
+  }
+}
+
 // Backward: one 256-thread workgroup (one wave per SIMD) per (window, head).  Phase A: lane = query i, the
 // four waves split the key range; phase B: lane = key j, the waves split the query range; per-wave
 // partial sums of dq / dk / dv meet in LDS and are added in a fixed order.  dS-derived sums for d(bias)
@@ -1994,6 +2138,7 @@ static int attn_grid_x(const uz_winattn_desc* d, int slots_per_cu) {
 // resident workgroups per CU (registers / LDS of the kernels below; check with the ISA when they change)
 constexpr int ATTN_SLOTS_FWD = 2;        // winattn_fwd_kernel: 186 VGPRs, 54 KB LDS
 constexpr int ATTN_SLOTS_FWD_MFMA = 1;   // winattn_fwd_mfma_kernel: 325 VGPRs
+constexpr int ATTN_SLOTS_FWD_MFMA2 = 3;  // winattn_fwd_mfma2_kernel: <= 168 VGPRs, 48 KB LDS
 constexpr int ATTN_SLOTS_BWD = 1;        // winattn_bwd_kernel: 152 KB LDS
 constexpr int ATTN_SLOTS_BWD_MFMA = 2;   // winattn_bwd_mfma_kernel: 256 VGPRs, 65 KB LDS
 
@@ -2016,7 +2161,11 @@ extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const f
   const dim3 grid(attn_grid_x(d, ATTN_SLOTS_FWD), d->heads), block(256);
   if (d->dtype == UZ_BF16 && !(uz_tune_flags() & 0x1000)) {
     // matrix-core path: one wave per (window, head), four per workgroup
-    hipLaunchKernelGGL(winattn_fwd_mfma_kernel, dim3(attn_mfma_grid_x(d), d->heads), dim3(256), 0, (hipStream_t)stream, a);
+    if (uz_tune_flags() & 0x4000)   // the one-wave-per-unit kernel, kept for A/B measurements
+      hipLaunchKernelGGL(winattn_fwd_mfma_kernel, dim3(attn_mfma_grid_x(d), d->heads), dim3(256), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(winattn_fwd_mfma2_kernel, dim3(attn_grid_x(d, ATTN_SLOTS_FWD_MFMA2), d->heads), dim3(256), 0,
+                         (hipStream_t)stream, a);
   } else if (d->dtype == UZ_BF16) {
     hipLaunchKernelGGL((winattn_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
   } else {
