@@ -410,12 +410,20 @@ def main():
             sec_per_launch = dom["ms"] * 1e-3 / dom["launches"]
             ach = flops_per_launch / sec_per_launch / 1e12
             peak = PEAK["mfma_bf16_tflops"] if run_dtype == torch.bfloat16 else PEAK["mfma_f32_tflops"]
-            roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                        "launches_per_step": dom["launches"] // nprof,
-                        "avg_launch_us": round(sec_per_launch * 1e6, 2),
-                        "algorithmic_gbytes_per_s": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
-                        "share_of_step": round(dom["ms"] / nprof / ms, 4)}
+            gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            # which roof bounds the kernel: its algorithmic intensity against the ridge point peak_flops / peak_bytes
+            ridge = peak * 1e12 / (PEAK["hbm_gbs"] * 1e9)
+            if dom["bytes"] > 0 and dom["flops"] / dom["bytes"] < ridge:
+                roofline = {"kernel": dom_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK["hbm_gbs"],
+                            "unit": "GB/s", "frac": round(gbs / PEAK["hbm_gbs"], 4), "traffic": traffic,
+                            "algorithmic_tflops": round(ach, 2)}
+            else:
+                roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                            "algorithmic_gbytes_per_s": round(gbs, 1)}
+            roofline.update({"launches_per_step": dom["launches"] // nprof,
+                             "avg_launch_us": round(sec_per_launch * 1e6, 2),
+                             "share_of_step": round(dom["ms"] / nprof / ms, 4)})
         line = {
             "metric": "images/sec (fwd+bwd) at B=16 3x256x256, 1/2/4/8 MI355X" if (args.model, args.size, args.batch) == ("unet", 256, 16)
                       else f"images/sec (fwd+bwd) {args.model} B={args.batch} 3x{args.size}x{args.size}",

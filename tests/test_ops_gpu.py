@@ -106,7 +106,10 @@ def test_wgrad3x3_lds_dma_kernel_shapes(dt, N, H, W, Cin, Cout):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("N,H,W,Ci,Cj", [(2, 8, 64, 64, 64), (1, 16, 16, 128, 128), (1, 6, 10, 64, 64),
-                                         (2, 4, 64, 32, 64), (1, 8, 32, 96, 40)])
+                                         (2, 4, 64, 32, 64), (1, 8, 32, 96, 40),
+                                         # token maps of swin_unet_v2 at 224 x 224 (flat walk, ragged last row of 64)
+                                         (3, 7, 7, 768, 768), (2, 14, 14, 384, 1152), (2, 56, 56, 96, 288),
+                                         (1, 5, 5, 96, 96)])
 def test_wgrad_one_tap(dt, N, H, W, Ci, Cj):
     """ntaps = 1 (1x1 convolution / the im2col'd first layer): out[i][j] = sum_p L[p,i] R[p,j]"""
     g = torch.Generator().manual_seed(10)

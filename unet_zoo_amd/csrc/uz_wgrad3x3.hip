@@ -299,11 +299,24 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   if (!((d->ntaps == 9 && d->dil == 1) || (d->ntaps == 1 && !up))) return 0;
   p->one_tap = d->ntaps == 1;
   if (d->Ci % 8 != 0 || d->Cj % 8 != 0) return 0;
-  const int W = d->W, H = d->H;
+  int W = d->W, H = d->H;
+  long long nimg = d->N;
+  if (p->one_tap) {
+    // no neighbourhood: the pixels are one flat list of N*H*W tokens, walked as rows of 64 whatever the map's
+    // shape (7 x 7, 14 x 14, 56 x 56 token maps of swin_unet_v2 at 224 x 224); the ragged last row reads
+    // past the buffers' bounds and is zero-filled by the DMA
+    const long long P = (long long)d->N * d->H * d->W;
+    if ((P + 63) / 64 >= (1LL << 24)) return 0;
+    W = 64;
+    H = (int)((P + 63) / 64);
+    nimg = 1;
+  }
   if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return 0;
   p->kw = W < 64 ? W : 64;
   p->kr = 64 / p->kw;
   if (H % p->kr != 0) return 0;
+  p->H = H;
+  p->W = W;
   const long long lbytes = ((long long)d->N * H * W - 1) * d->ldl * 2 + (long long)d->Ci * 2;
   const long long rbytes = ((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2;
   if (lbytes >= (1LL << 31) || rbytes >= (1LL << 31)) return 0;
@@ -320,7 +333,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   p->tiles_i = (d->Ci + b - 1) / b;
   p->tiles_j = (d->Cj + b - 1) / b;
   p->kg = 1;
-  p->units = (int)((long long)d->N * H * W / 64);
+  p->units = (int)(nimg * H * W / 64);
   const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : 1);
   // one workgroup per CU (160 KB LDS each): aim for a single full round of <= 256 workgroups
   long long split = base >= UZ_NUM_CU ? 1 : UZ_NUM_CU / base;
@@ -360,8 +373,8 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.r_up = d->taps_mode == UZ_TAPS_CONV_UP2 ? 1 : 0;
   a.flags = uz_tune_flags();
   a.N = d->N;
-  a.H = d->H;
-  a.W = d->W;
+  a.H = p.H;
+  a.W = p.W;
   a.Ci = d->Ci;
   a.ldl = d->ldl;
   a.Cj = d->Cj;
