@@ -317,7 +317,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   if (H % p->kr != 0) return 0;
   p->H = H;
   p->W = W;
-  const long long lbytes = ((long long)d->N * H * W - 1) * d->ldl * 2 + (long long)d->Ci * 2;
+  const long long lbytes = ((long long)d->N * d->H * d->W - 1) * d->ldl * 2 + (long long)d->Ci * 2;
   const long long rbytes = ((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2;
   if (lbytes >= (1LL << 31) || rbytes >= (1LL << 31)) return 0;
   p->big = (d->Ci % 128 == 0 && d->Cj % 128 == 0) ? 1 : 0;

@@ -246,8 +246,9 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
     W_ = Lt.W
     if (Lt.dtype == torch.bfloat16 and taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) and ((ntaps == 9 and dil == 1) or ntaps == 1)
-            and Lt.C % 8 == 0 and Rt.C % 8 == 0 and (W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0))
-            and Lt.H % (64 // min(W_, 64)) == 0):   # mirrors uz_wgrad3x3_plan()
+            and Lt.C % 8 == 0 and Rt.C % 8 == 0
+            and (ntaps == 1 or ((W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0)) and Lt.H % (64 // min(W_, 64)) == 0))):
+        # mirrors uz_wgrad3x3_plan() (one-tap problems walk the tokens as a flat list: any map shape)
         big = Lt.C % 128 == 0 and Rt.C % 128 == 0
         if ntaps == 1 and not big:   # mirrors uz_wgrad3x3_plan(): fewer operand re-reads with the larger tile
             t64 = Lt.C * ((Rt.C + 63) // 64) + Rt.C * ((Lt.C + 63) // 64)
