@@ -25,18 +25,21 @@ template <typename T> __device__ __forceinline__ void store_f(T* p, const float*
 
 // ------------------------------------------------------------------------------------------
 // BN finalize: reduce the conv kernel's partial rows and derive scale/shift + running stats.
-// One block of 1024 threads per 32 channels: thread (c = t & 31, g = t >> 5) sums rows g, g+32, ...
+// One block of 1024 threads per EW channels: thread (c = t % EW, g = t / EW) sums rows g, g + 1024/EW, ...
+// (EW = 8 when the rows are many: the kernel is a chain of dependent loads, 128 row groups shorten it)
 // ------------------------------------------------------------------------------------------
+template <int EW>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* __restrict__ part, int grid_m, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* scale, float* shift, float* mean, float* invstd) {
-  __shared__ double sh[2][32][33];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int NG = 1024 / EW;
+  __shared__ double sh[2][NG][EW + 1];
+  const int cl = threadIdx.x % EW, g = threadIdx.x / EW;
+  const int c = blockIdx.x * EW + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    for (int r = g; r < grid_m; r += 32) {
+    for (int r = g; r < grid_m; r += NG) {
       a1 += (double)part[((size_t)r * 2 + 0) * C + c];
       a2 += (double)part[((size_t)r * 2 + 1) * C + c];
     }
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   __syncthreads();
   if (g == 0 && c < C) {
     double t1 = 0.0, t2 = 0.0;
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < NG; ++r) {
       t1 += sh[0][r][cl];
       t2 += sh[1][r][cl];
     }
@@ -314,15 +317,17 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
 }
 
 // totals[2][C] (double) = sum over the partial rows; dbeta = totals[0], dgamma = totals[1]
+template <int EW>
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int rows,
                                                                int C, double* __restrict__ sums,
                                                                float* dgamma, float* dbeta) {
-  __shared__ double sh[2][32][33];
-  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int NG = 1024 / EW;
+  __shared__ double sh[2][NG][EW + 1];
+  const int cl = threadIdx.x % EW, g = threadIdx.x / EW;
+  const int c = blockIdx.x * EW + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    for (int r = g; r < rows; r += 32) {
+    for (int r = g; r < rows; r += NG) {
       a1 += (double)part[((size_t)r * 2 + 0) * C + c];
       a2 += (double)part[((size_t)r * 2 + 1) * C + c];
     }
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   __syncthreads();
   if (g == 0 && c < C) {
     double t1 = 0.0, t2 = 0.0;
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < NG; ++r) {
       t1 += sh[0][r][cl];
       t2 += sh[1][r][cl];
     }
@@ -777,9 +782,14 @@ extern "C" int uz_bn_finalize(const float* stats_partial, int grid_m, int C, dou
   UZ_REQUIRE(stats_partial && gamma && beta && scale && shift && mean && invstd, "uz_bn_finalize: null");
   UZ_REQUIRE(grid_m > 0 && C > 0 && count > 0, "uz_bn_finalize: bad shape");
   UZ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "uz_bn_finalize: running stats");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(uz_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream,
-                     stats_partial, grid_m, C, count, gamma, beta, eps, momentum, running_mean,
-                     running_var, scale, shift, mean, invstd);
+  if (grid_m >= 128 && C <= 512)
+    hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(uz_cdiv(C, 8)), dim3(1024), 0, (hipStream_t)stream,
+                       stats_partial, grid_m, C, count, gamma, beta, eps, momentum, running_mean,
+                       running_var, scale, shift, mean, invstd);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3(uz_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream,
+                       stats_partial, grid_m, C, count, gamma, beta, eps, momentum, running_mean,
+                       running_var, scale, shift, mean, invstd);
   UZ_LAUNCH_CHECK("uz_bn_finalize");
   return UZ_OK;
 }
@@ -931,8 +941,12 @@ extern "C" int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, cons
   if (rc2 != UZ_OK) return rc2;
   dim3 grid, block;
   bnbwd_shape(d, gpool != nullptr, &grid, &block);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(uz_cdiv(d->C, 32)), dim3(1024), 0, s,
-                     static_cast<const float*>(workspace), (int)grid.x, d->C, sums, dgamma, dbeta);
+  if ((int)grid.x >= 128 && d->C <= 512)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(uz_cdiv(d->C, 8)), dim3(1024), 0, s,
+                       static_cast<const float*>(workspace), (int)grid.x, d->C, sums, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3(uz_cdiv(d->C, 32)), dim3(1024), 0, s,
+                       static_cast<const float*>(workspace), (int)grid.x, d->C, sums, dgamma, dbeta);
   UZ_LAUNCH_CHECK("uz_bn_relu_bwd_reduce(finalize)");
   return UZ_OK;
 }

@@ -313,6 +313,13 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   }
   if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return 0;
   p->kw = W < 64 ? W : 64;
+  if (!p->one_tap && W >= 64 && !(d->Ci % 128 == 0 && d->Cj % 128 == 0)) {
+    // the 9-tap 64 x 64 kernel keeps all three tap rows in one R tile of (kr + 2) x (kw + 2) pixels per 64-pixel
+    // unit: a 1 x 64 strip re-reads x 3.1 times, 2 x 32 2.1 times, 4 x 16 1.7 times
+    // (measured on 64 -> 64 @ 256 x 256: 135.7 / 132.1 / 129.6 us -- the kernel is bound elsewhere)
+    const int f = (uz_tune_flags() >> 24) & 3;   // 0: default (16), 1: 64, 2: 32, 3: 16
+    p->kw = f == 1 ? 64 : f == 2 ? 32 : 16;
+  }
   p->kr = 64 / p->kw;
   if (H % p->kr != 0) return 0;
   p->H = H;

@@ -43,6 +43,7 @@ class _GraphFn(torch.autograd.Function):
         eng = Engine(model.run_dtype, x.device, model.training, record, model._grad_sink,
                      model._pack_cache, model.grads_in_place)
         outs = model.emit(eng, x)
+        eng.finish_forward()
         ctx.eng = eng if record else None
         ctx.plist = plist
         ctx.sink_done = model._grad_sink_done
@@ -134,6 +135,7 @@ class PhasedStep:
         self.eng = Engine(m.run_dtype, x.device, m.training, True, None, m._pack_cache, True)
         with torch.no_grad():
             outs = tuple(m.emit(self.eng, x))
+            self.eng.finish_forward()
         leaves = tuple(o.detach().requires_grad_(True) for o in outs)
         self.outputs = m.wrap_outputs(tuple(o.detach() for o in outs))
         with torch.enable_grad():
