@@ -87,7 +87,7 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
 
 // LDS-DMA pixel-major GEMM (uz_gemm_dma.hip): 1x1 / ConvTranspose fwd + dgrad, dispatched from uz_conv_igemm()
 struct UzGemmPlan {
-  int bn, bm, tiles_m, tiles_n, grid_m;
+  int bn, bm, nst, tiles_m, tiles_n, grid_m;
 };
 int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p);
 int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,

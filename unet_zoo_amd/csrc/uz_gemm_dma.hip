@@ -54,9 +54,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // (256, 3) is the throughput shape.  A GEMM whose 256-row tiling leaves most CUs idle (the 16x16 and 8x8
 // token maps of swin_unet_v2) is bound by the latency of its K loop -- slab s + 2 is requested when slab s is
 // consumed, so a step costs half a memory round trip whatever the tile -- and takes (128, 4): twice the
-// workgroups, and a third of a round trip per step.
+// workgroups, and a third of a round trip per step.  NST = 2 serves K <= 128 (at most two slabs, both requested
+// up front, the host guarantees it): 64 KB of LDS, so TWO workgroups share a CU and one's epilogue overlaps the
+// other's loads -- the full-resolution Linear layers of swin_unet_v2 (K = 96) are one short tile per workgroup.
 template <typename T, int BN, int BM, int NST>
-__global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
+__global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const GArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = 8 * VEC;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
   constexpr int NBP = BN / 64;    // B pieces per wave per stage
   constexpr int WM = BM / 64, WN = 8 / WM;        // waves: WM (M) x WN (N), wave tile 64 x BN / WN
   constexpr int WTN = BN / WN, TN = WTN / 32;
-  static_assert(TN >= 1 && (BM == 256 || BM == 128) && (NST == 3 || NST == 4), "unsupported tile");
+  static_assert(TN >= 1 && (BM == 256 || BM == 128) && NST >= 2 && NST <= 4, "unsupported tile");
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const GArgs a) {
         wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
-      if (s + NST - 1 < nsteps) issue(m0, (s + NST - 1) % NST, s + NST - 1);
+      if (NST > 2 && s + NST - 1 < nsteps) issue(m0, (s + NST - 1) % NST, s + NST - 1);
       const char* sA = smem + (s % NST) * STAGE;
       const char* sBt = sA + A_BYTES;
 #pragma unroll
@@ -378,8 +380,14 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
   p->tiles_n = (d->Nout + p->bn - 1) / p->bn;
   // latency shape (see the kernel): when 256-row tiles would occupy at most half of the CUs
   p->bm = (p->bn == 128 && ((M + 255) / 256) * p->tiles_n * 2 <= UZ_NUM_CU && !(uz_tune_flags() & 0x200000)) ? 128 : 256;
+  const int nsteps = d->ntaps * ((d->Cin + 8 * vec - 1) / (8 * vec));
+  p->nst = p->bm == 128 ? 4 : 3;
+  if (p->bn == 128 && nsteps <= 2 && !(uz_tune_flags() & 0x800000)) {   // two resident workgroups per CU
+    p->bm = 128;
+    p->nst = 2;
+  }
   p->tiles_m = (int)((M + p->bm - 1) / p->bm);
-  int cap = UZ_NUM_CU / p->tiles_n;
+  int cap = (p->nst == 2 ? 2 : 1) * UZ_NUM_CU / p->tiles_n;
   if (cap < 1) cap = 1;
   p->grid_m = p->tiles_m < cap ? p->tiles_m : cap;
   return 1;
@@ -389,6 +397,7 @@ template <typename T>
 static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
   dim3 grid(p.grid_m, p.tiles_n), block(512);
   if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3>), grid, block, 0, s, a);
+  else if (p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 2>), grid, block, 0, s, a);
   else if (p.bm == 128) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 4>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 256, 3>), grid, block, 0, s, a);
   UZ_LAUNCH_CHECK("uz_conv_igemm(gemm_dma)");
