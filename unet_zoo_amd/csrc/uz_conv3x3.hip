@@ -448,18 +448,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       const int cc = tid % CPR;
       const int n = n0 + cc * VEC;
       const bool dostats = !(a.flags & 2);
-      for (int m = tid / CPR; m < 256; m += 512 / CPR) {
+      // every thread reads back 256 * CPR / 512 chunks: all of them are requested before the first store (as a
+      // rolled loop each pass waited for its own LDS round trip: ~250 cycles x 8 per tile with every wave idle)
+      constexpr int NPASS = 256 * CPR / 512, RPP = 512 / CPR;
+      Vec16<T> vb[NPASS];
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k)
+        vb[k] = *reinterpret_cast<const Vec16<T>*>(sC + (tid / CPR + k * RPP) * RSC + cc * 16);
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k) {
+        const int m = tid / CPR + k * RPP;
         const int mt = m >> 5, ml = m & 31;
         const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
         const int pj = (TW == 32) ? ml : (ml & 15);
         const int hh = h0 + pi, ww = w0 + pj;
         if (hh < a.H && ww < a.W && n < a.Nout) {
-          const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(sC + m * RSC + cc * 16);
-          st16(yg + ((size_t)(img * a.H + hh) * a.W + ww) * a.ldy + n, v);
+          st16(yg + ((size_t)(img * a.H + hh) * a.W + ww) * a.ldy + n, vb[k]);
           if (dostats) {  // statistics of the stored values, pixels inside the image only
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-              const float fv = (float)v.v[e];
+              const float fv = (float)vb[k].v[e];
               sq1[e] += fv;
               sq2[e] += fv * fv;
             }

@@ -264,14 +264,20 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
       static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
       const int cc = tid % CPR;
       const bool cok = n0 + cc * VEC < a.Nout;
-      for (int ml = tid / CPR; ml < BM; ml += 512 / CPR) {
-        const long long orow = out_row(ml, ab);
+      // all of a thread's chunks are requested from LDS before the first store (see uz_conv3x3.hip)
+      constexpr int NPASS = BM * CPR / 512, RPP = 512 / CPR;
+      Vec16<T> vb[NPASS];
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k)
+        vb[k] = *reinterpret_cast<const Vec16<T>*>(sC + (tid / CPR + k * RPP) * RSC + cc * 16);
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k) {
+        const long long orow = out_row(tid / CPR + k * RPP, ab);
         if (orow >= 0 && cok) {
-          const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(sC + ml * RSC + cc * 16);
-          st16(yg + (size_t)orow * a.ldy + co0 + cc * VEC, v);
+          st16(yg + (size_t)orow * a.ldy + co0 + cc * VEC, vb[k]);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            const float fv = (float)v.v[e];
+            const float fv = (float)vb[k].v[e];
             sq1[e] += fv;
             sq2[e] += fv * fv;
           }
