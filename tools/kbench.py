@@ -3,7 +3,7 @@
 import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from unet_zoo_amd import _lib as L, ops
 
 DEV = "cuda"

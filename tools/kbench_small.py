@@ -1,7 +1,7 @@
 """Micro-benchmark of the small bandwidth-bound kernels at the B=16 256x256 UNet sizes."""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from unet_zoo_amd import _lib as L, ops
 
 DEV, dt = "cuda", torch.bfloat16
