@@ -152,7 +152,10 @@ def test_conv_reads_and_writes_channel_windows(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 10, 128, 64), (1, 4, 4, 256, 128)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 6, 10, 128, 64), (1, 4, 4, 256, 128),
+                                            # map widths the LDS-DMA weight-gradient kernel takes (gather mode)
+                                            (2, 16, 16, 256, 128), (1, 8, 32, 128, 64), (1, 4, 64, 64, 96),
+                                            (2, 2, 16, 384, 192)])
 def test_conv_transpose2x2_fwd_dgrad_wgrad(dt, N, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(4)
     x = rnd(dt, torch.randn(N, Cin, H, W, generator=g)).requires_grad_(True)

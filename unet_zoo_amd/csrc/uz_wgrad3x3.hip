@@ -35,6 +35,9 @@ struct Wg2Args {
   int upb;              // K-steps per split
   int tiles_j;
   int r_up;  // 1: R lives at (H/2, W/2) and is read through nearest x2 upsampling
+  int gather;   // 1: 2x2 gather (ConvTranspose2d k2 s2 / PatchExpand weight gradient): R lives on the (Hr, Wr) grid
+                // of 2H (+1) x 2W (+1) pixels and tap t = blockIdx.y reads pixel (2h + (t >> 1), 2w + (t & 1))
+  int Hr, Wr;
   int flags; // tuning switches (env UZ_TUNE): bit 2 = plain workgroup order
 };
 
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   }
   const int ti0 = (bx / a.tiles_j) * BI, tj0 = (bx % a.tiles_j) * BJ;
   const int ty_blk = (NTY == 1 && NTX == 3) ? by : 0;
+  const int ty_blk_g = (NTX == 1) ? by : 0;   // gather mode: the tap of this workgroup
   const int u_beg = bz * a.upb;
   const int u_end = (u_beg + a.upb < a.units) ? u_beg + a.upb : a.units;
   const int nu = u_end - u_beg;
@@ -167,6 +171,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
         if (a.r_up) {
           const int hh = h + p_rrel[i], ww = w0 + p_crel[i];
           rp = (unsigned)((img * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1));
+        } else if (a.gather) {
+          const int hh = h + p_rrel[i], ww = w0 + p_crel[i];
+          rp = (unsigned)((img * a.Hr + 2 * hh + (ty_blk_g >> 1)) * a.Wr + 2 * ww + (ty_blk_g & 1));
         }
         const unsigned off = ok ? rp * (unsigned)(a.ldr * 2) + p_coff[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
@@ -277,8 +284,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   for (int tt = 0; tt < NTW; ++tt) {
     const int tw = tg * NTW + tt;
     if (tw >= NTAP) continue;  // wave-uniform
-    const int tap = (NTY == 3 || NTX == 1) ? tw : ty_blk * 3 + tw;
-    float* slab = a.slab + ((size_t)bz * (NTX == 1 ? 1 : 9) + tap) * (size_t)a.Ci * a.Cj;
+    const int tap = (NTX == 1) ? ty_blk_g : ((NTY == 3) ? tw : ty_blk * 3 + tw);
+    float* slab = a.slab + ((size_t)bz * (NTX == 1 ? (a.gather ? 4 : 1) : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int cj = tj0 + wj * WTJ + l31;
@@ -295,13 +302,15 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
-  if (d->dtype != UZ_BF16 || !(d->taps_mode == UZ_TAPS_CONV || up)) return 0;
-  if (!((d->ntaps == 9 && d->dil == 1) || (d->ntaps == 1 && !up))) return 0;
-  p->one_tap = d->ntaps == 1;
+  const bool gather = d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && !(uz_tune_flags() & 0x4000000);
+  if (d->dtype != UZ_BF16 || !(d->taps_mode == UZ_TAPS_CONV || up || gather)) return 0;
+  if (!((d->ntaps == 9 && d->dil == 1) || (d->ntaps == 1 && !up) || gather)) return 0;
+  p->one_tap = d->ntaps == 1 || gather;   // gather: four one-tap problems, blockIdx.y = tap
+  p->gather = gather ? 1 : 0;
   if (d->Ci % 8 != 0 || d->Cj % 8 != 0) return 0;
   int W = d->W, H = d->H;
   long long nimg = d->N;
-  if (p->one_tap) {
+  if (p->one_tap && !gather) {
     // no neighbourhood: the pixels are one flat list of N*H*W tokens, walked as rows of 64 whatever the map's
     // shape (7 x 7, 14 x 14, 56 x 56 token maps of swin_unet_v2 at 224 x 224); the ragged last row reads
     // past the buffers' bounds and is zero-filled by the DMA
@@ -341,7 +350,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   p->tiles_j = (d->Cj + b - 1) / b;
   p->kg = 1;
   p->units = (int)(nimg * H * W / 64);
-  const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : 1);
+  const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : (gather ? 4 : 1));
   // one workgroup per CU (160 KB LDS each): aim for a single full round of <= 256 workgroups
   long long split = base >= UZ_NUM_CU ? 1 : UZ_NUM_CU / base;
   long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
@@ -378,6 +387,9 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.lbytes = (unsigned)(((long long)d->N * d->H * d->W - 1) * d->ldl * 2 + (long long)d->Ci * 2);
   a.rbytes = (unsigned)(((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2);
   a.r_up = d->taps_mode == UZ_TAPS_CONV_UP2 ? 1 : 0;
+  a.gather = p.gather;
+  a.Hr = d->Hr;
+  a.Wr = d->Wr;
   a.flags = uz_tune_flags();
   a.N = d->N;
   a.H = p.H;
@@ -394,7 +406,7 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.tiles_j = p.tiles_j;
   dim3 block(512);
   if (p.one_tap) {
-    dim3 grid(p.tiles_i * p.tiles_j, 1, p.split);
+    dim3 grid(p.tiles_i * p.tiles_j, p.gather ? 4 : 1, p.split);
     if (p.big) hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 1, 2, 4, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 1, 1, 2, 2, 2>), grid, block, 0, s, a);  // 4 waves idle: memory-bound
   } else if (p.big) {

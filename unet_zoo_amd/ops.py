@@ -245,16 +245,18 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
     kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
     W_ = Lt.W
-    if (Lt.dtype == torch.bfloat16 and taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) and ((ntaps == 9 and dil == 1) or ntaps == 1)
+    gather = taps_mode == L.TAPS_GATHER2X2 and ntaps == 4
+    if (Lt.dtype == torch.bfloat16 and (taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) or gather)
+            and ((ntaps == 9 and dil == 1) or ntaps == 1 or gather)
             and Lt.C % 8 == 0 and Rt.C % 8 == 0
             and (ntaps == 1 or ((W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0)) and Lt.H % (64 // min(W_, 64)) == 0))):
         # mirrors uz_wgrad3x3_plan() (one-tap problems walk the tokens as a flat list: any map shape)
         big = Lt.C % 128 == 0 and Rt.C % 128 == 0
-        if ntaps == 1 and not big:   # mirrors uz_wgrad3x3_plan(): fewer operand re-reads with the larger tile
+        if (ntaps == 1 or gather) and not big:   # mirrors uz_wgrad3x3_plan(): fewer operand re-reads with the larger tile
             t64 = Lt.C * ((Rt.C + 63) // 64) + Rt.C * ((Lt.C + 63) // 64)
             t128 = Lt.C * ((Rt.C + 127) // 128) + Rt.C * ((Lt.C + 127) // 128)
             big = t128 < t64
-        kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + ("_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
+        kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + ("_gather4" if gather else "_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
     with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
         L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
