@@ -414,7 +414,13 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
     hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>), grid, block, 0, s, a);
   } else {
     dim3 grid(p.tiles_i * p.tiles_j, 1, p.split);
-    hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 3, 2, 2, 2>), grid, block, 0, s, a);
+    // The kernel is bound by its transposed LDS reads (a 32 x 32 wave tile reads 1.2 KB per MFMA, every
+    // B fragment used once): 64-row wave tiles share each B fragment between two MFMAs (0.83 KB per MFMA) even
+    // though 4 tap groups leave 3 of 12 tap slots empty.  64->64 @256x256: 141.9 -> 129.6 us, 128->64: 229.8 -> 213.4.
+    if (a.flags & 0x8000000)
+      hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 3, 2, 2, 2>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 3, 1, 2, 4>), grid, block, 0, s, a);
   }
   UZ_LAUNCH_CHECK("uz_wgrad(3x3)");
   return UZ_OK;
