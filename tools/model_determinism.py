@@ -1,0 +1,54 @@
+"""Forward a model twice on the same batch and report the first conv_igemm call whose output differs."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import unet_zoo_amd
+from unet_zoo_amd import ops
+from oracle import torch_ref
+
+DEV = "cuda"
+torch.manual_seed(0)
+m = unet_zoo_amd.create_model("unet").to(DEV).train()
+x, _ = torch_ref.synthetic_batch(16, 3, 256, 256, seed=2)
+x = x.to(DEV)
+log = []
+orig = ops.conv_igemm
+
+
+def spy(xa, wp, bias, y, **kw):
+    r = orig(xa, wp, bias, y, **kw)
+    torch.cuda.synchronize()
+    log.append(((xa.N, xa.H, xa.W, xa.C, xa.ld, y.C, y.ld, kw.get("ntaps"), kw.get("taps_mode")),
+                y.buf[:, y.off:y.off + y.C].clone(), r.clone() if isinstance(r, torch.Tensor) else None))
+    return r
+
+
+ops.conv_igemm = spy
+import unet_zoo_amd.engine as E
+E.ops.conv_igemm = spy
+runs = []
+for rep in range(4):
+    log.clear()
+    with torch.no_grad():
+        m(x)
+    runs.append(list(log))
+for rep in range(1, 4):
+    for i, (a, b) in enumerate(zip(runs[0], runs[rep])):
+        same = torch.equal(a[1], b[1])
+        sst = a[2] is None or torch.equal(a[2], b[2])
+        if not (same and sst):
+            d = (a[1].float() - b[1].float()).abs()
+            print(f"run {rep}: call {i} {a[0]}: output equal {same} (max diff {d.max().item():.3g}, {int((d > 0).sum())} elements), stats equal {sst}")
+            N_, H_, W_ = a[0][0], a[0][1], a[0][2]
+            bad = (d > 0).nonzero()
+            pix = bad[:, 0].unique()
+            for p_ in pix[:12].tolist():
+                ch = bad[bad[:, 0] == p_, 1]
+                print(f"    pixel img {p_ // (H_ * W_)} h {p_ // W_ % H_} w {p_ % W_}: {len(ch)} channels {int(ch.min())}..{int(ch.max())}")
+                if p_ == pix[0].item():
+                    print("      run0:", a[1][p_, 44:64].float().tolist())
+                    print("      runN:", b[1][p_, 44:64].float().tolist())
+            break
+    else:
+        print(f"run {rep}: all {len(runs[0])} conv calls identical")

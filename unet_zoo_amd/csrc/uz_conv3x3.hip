@@ -442,6 +442,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
           }
         }
       }
+      // the staging writes must have EXECUTED, not just issued, before another wave reads them: s_barrier alone
+      // does not wait for the LDS queue.  (Found when a cross-tile prefetch of the next activation patch -- LDS-DMA
+      // traffic on the LDS write path during the epilogue -- made 8 pixels x 16 channels of one tile in a million read
+      // stale weight-slot bytes; the prefetch itself measured no gain and was dropped, the wait stays.)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       constexpr int CPR = BN * ES / 16;  // 16-byte chunks per pixel
       static_assert(512 % CPR == 0, "a thread keeps one channel chunk");

@@ -259,6 +259,9 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
             *reinterpret_cast<bf16x4*>(rowp + (wn * WTN + j * 32 + 8 * q + 4 * lh) * ES) = pk;
           }
       }
+      // the staging writes must have EXECUTED, not just issued, before another wave reads them: s_barrier alone
+      // does not wait for the LDS queue (it went unnoticed until LDS-DMA traffic shared the write path)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       constexpr int CPR = BN * ES / 16;
       static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
