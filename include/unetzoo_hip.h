@@ -272,6 +272,14 @@ int uz_bilinear_fwd(int dtype, const void* x, int ldx, long long x_img_stride, i
 /* its backward: g at (Ho, Wo) -> dx at (Hi, Wi), overwritten (gather form, deterministic) */
 int uz_bilinear_bwd(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi,
                     int C, void* dx, int lddx, long long dx_img_stride, int Ho, int Wo, void* stream);
+/* the same pair with the align_corners switch of F.interpolate / nn.Upsample (align_corners != 0:
+ * nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), nested_unet.py:32) */
+int uz_resize_bilinear_fwd(int dtype, const void* x, int ldx, long long x_img_stride, int N, int Hi, int Wi,
+                           int C, void* y, int ldy, long long y_img_stride, int Ho, int Wo, int align_corners,
+                           void* stream);
+int uz_resize_bilinear_bwd(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi,
+                           int C, void* dx, int lddx, long long dx_img_stride, int Ho, int Wo, int align_corners,
+                           void* stream);
 /* out = g0 + g1 + unpool(gp): total gradient of `act` consumed directly (g0, g1 may be NULL) and through
  * MaxPool2d(2,2) (gp at (H/2, W/2), routed to the first maximum of each window as ATen does). */
 int uz_pool_grad_combine(int dtype, int N, int H, int W, int C, const void* act, int lda, const void* g0,

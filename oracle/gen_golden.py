@@ -170,6 +170,36 @@ def write_u2net():
     print(tag, "loss", meta["loss"], "gnorm", gnorm)
 
 
+def write_nested_unet():
+    """nested_unet (UNet++): seed-0 NestedUNet(num_classes=1, in_channels=3), B=2 3x64x64 with
+    every number kept; and the deep-supervision variant's four maps (summed BCE) at the same size."""
+    mods = load_reference("nested_unet")
+    Ref = mods["nested_unet"].NestedUNet
+    torch.manual_seed(0)
+    model = Ref(num_classes=1, in_channels=3)
+    write_manifest(model, "nested_unet")
+    run_case(model, 2, 64, 64, "nested_unet_b2_64", full_logits=True, name="nested_unet",
+             bn_keys=("conv0_0.bn1", "conv2_0.bn2", "conv4_0.bn1", "conv1_2.bn1", "conv0_4.bn2"))
+    torch.manual_seed(0)
+    model = Ref(num_classes=2, in_channels=3, deep_supervision=True)
+    x, mask = synthetic_batch(2, 3, 32, 48, seed=3)
+    mask2 = torch.cat([mask, 1.0 - mask], 1)
+    model.train()
+    outs = model(x)
+    loss = sum(F.binary_cross_entropy_with_logits(o, mask2) for o in outs)
+    model.zero_grad()
+    loss.backward()
+    named = list(model.named_parameters())
+    meta = {"model": "nested_unet", "deep_supervision": True, "B": 2, "H": 32, "W": 48, "loss": loss.item(),
+            "global_grad_norm": torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)).item(),
+            "grad_l2": {n: p.grad.double().norm().item() for n, p in named}}
+    arrays = {f"train/{i}": o.detach().numpy() for i, o in enumerate(outs)}
+    np.savez_compressed(os.path.join(OUT, "nested_unet_ds_b2_32x48.npz"), **arrays)
+    with open(os.path.join(OUT, "nested_unet_ds_b2_32x48.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("nested_unet_ds", meta["loss"], meta["global_grad_norm"])
+
+
 def _timm_stand_in():
     """`swin_unet_v2.py:9` imports three helpers from timm, which this image lacks:
     to_2tuple, trunc_normal_ (= torch.nn.init.trunc_normal_) and DropPath (stochastic depth: per-sample
@@ -277,6 +307,10 @@ def main():
         torch.set_num_threads(8)
         write_u2net()
         return
+    if sys.argv[1:] == ["nested_unet"]:
+        torch.set_num_threads(8)
+        write_nested_unet()
+        return
     torch.set_num_threads(8)
     mods = load_reference("common_layers", "unet")
     RefUNet = mods["unet"].UNet
@@ -305,6 +339,7 @@ def main():
     run_case(model, 2, 256, 256, "unet_b2_256", full_logits=False)
     write_u2net()
     write_swin()
+    write_nested_unet()
 
 
 if __name__ == "__main__":

@@ -228,9 +228,9 @@ def u2net_forward(sd: State, x: torch.Tensor, training: bool) -> Dict[str, torch
 def model_loss(outputs, mask: torch.Tensor) -> torch.Tensor:
     """BCEWithLogits on a tensor output; on U2Net's dict the unit-weighted sum over the seven heads
     (unet_zoo/utils/training_loop.py:24-32, 60-64; every head is at the mask's resolution)."""
-    if isinstance(outputs, dict):
+    if isinstance(outputs, (dict, list, tuple)):   # u2net's seven heads; nested_unet's four under deep supervision
         total = None
-        for v in outputs.values():
+        for v in (outputs.values() if isinstance(outputs, dict) else outputs):
             l = F.binary_cross_entropy_with_logits(v, mask)
             total = l if total is None else total + l
         return total
@@ -374,8 +374,48 @@ def swin_unet_v2_forward(sd: State, x: torch.Tensor, training: bool, cfg: dict =
     return F.conv2d(t, sd["output.weight"])
 
 
+# ---------------------------------------------------------------------------------------------
+# UNet++ (unet_zoo/models/nested_unet.py)
+# ---------------------------------------------------------------------------------------------
+def vgg_block(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """VGGBlock.forward — nested_unet.py:13-22."""
+    x = conv_bn_relu(x, sd, f"{prefix}.conv1", f"{prefix}.bn1", training)
+    return conv_bn_relu(x, sd, f"{prefix}.conv2", f"{prefix}.bn2", training)
+
+
+def nested_unet_forward(sd: State, x: torch.Tensor, training: bool):
+    """NestedUNet.forward — nested_unet.py:72-105: x_{i,j} = VGG(cat[x_{i,0..j-1}, up(x_{i+1,j-1})]) with
+    up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (:32) and pool = MaxPool2d(2, 2) (:31);
+    four heads under deep supervision (present iff the state has `final1`), else `final` on x_{0,4}."""
+    def up(t):
+        return _q(F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True))
+
+    def pool(t):
+        return F.max_pool2d(t, 2, 2)
+
+    n = {}
+    n[0, 0] = vgg_block(x, sd, "conv0_0", training)
+    n[1, 0] = vgg_block(pool(n[0, 0]), sd, "conv1_0", training)
+    n[0, 1] = vgg_block(torch.cat([n[0, 0], up(n[1, 0])], 1), sd, "conv0_1", training)
+    n[2, 0] = vgg_block(pool(n[1, 0]), sd, "conv2_0", training)
+    n[1, 1] = vgg_block(torch.cat([n[1, 0], up(n[2, 0])], 1), sd, "conv1_1", training)
+    n[0, 2] = vgg_block(torch.cat([n[0, 0], n[0, 1], up(n[1, 1])], 1), sd, "conv0_2", training)
+    n[3, 0] = vgg_block(pool(n[2, 0]), sd, "conv3_0", training)
+    n[2, 1] = vgg_block(torch.cat([n[2, 0], up(n[3, 0])], 1), sd, "conv2_1", training)
+    n[1, 2] = vgg_block(torch.cat([n[1, 0], n[1, 1], up(n[2, 1])], 1), sd, "conv1_2", training)
+    n[0, 3] = vgg_block(torch.cat([n[0, 0], n[0, 1], n[0, 2], up(n[1, 2])], 1), sd, "conv0_3", training)
+    n[4, 0] = vgg_block(pool(n[3, 0]), sd, "conv4_0", training)
+    n[3, 1] = vgg_block(torch.cat([n[3, 0], up(n[4, 0])], 1), sd, "conv3_1", training)
+    n[2, 2] = vgg_block(torch.cat([n[2, 0], n[2, 1], up(n[3, 1])], 1), sd, "conv2_2", training)
+    n[1, 3] = vgg_block(torch.cat([n[1, 0], n[1, 1], n[1, 2], up(n[2, 2])], 1), sd, "conv1_3", training)
+    n[0, 4] = vgg_block(torch.cat([n[0, 0], n[0, 1], n[0, 2], n[0, 3], up(n[1, 3])], 1), sd, "conv0_4", training)
+    if "final1.weight" in sd:
+        return [F.conv2d(n[0, j], sd[f"final{j}.weight"], sd[f"final{j}.bias"]) for j in (1, 2, 3, 4)]
+    return F.conv2d(n[0, 4], sd["final.weight"], sd["final.bias"])
+
+
 FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward,
-            "swin_unet_v2": swin_unet_v2_forward}
+            "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward}
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":
@@ -405,6 +445,8 @@ def train_step_reference(model_name: str, sd: State, x: torch.Tensor, mask: torc
     names, grads = zip(*[(n, g) for n, g in zip(names, grads) if g is not None])  # swin: mlp / norm2 are unused
     if isinstance(logits, dict):
         logits = {k: v.detach() for k, v in logits.items()}
+    elif isinstance(logits, (list, tuple)):
+        logits = [v.detach() for v in logits]
     else:
         logits = logits.detach()
     return logits, loss.detach(), dict(zip(names, grads)), st

@@ -38,8 +38,9 @@ struct Tap2 {
   int i0, i1;
   float l0, l1;
 };
-__device__ __forceinline__ Tap2 bilinear_tap(int o, float scale, int in) {
-  float s = scale * ((float)o + 0.5f) - 0.5f;
+// align_corners=True (nn.Upsample(..., align_corners=True) of nested_unet.py:32): scale = (in-1)/(out-1), src = scale*dst.
+__device__ __forceinline__ Tap2 bilinear_tap(int o, float scale, int in, int ac) {
+  float s = ac ? scale * (float)o : scale * ((float)o + 0.5f) - 0.5f;
   if (s < 0.f) s = 0.f;
   Tap2 t;
   t.i0 = min((int)s, in - 1);
@@ -55,7 +56,8 @@ struct ResizeArgs {
   long long src_img, dst_img;  // image strides in elements
   int lds_, ldd;               // pixel strides in elements
   int N, Hi, Wi, Ho, Wo, C;
-  float sh, sw;                // Hi/Ho, Wi/Wo
+  float sh, sw;                // Hi/Ho, Wi/Wo; align_corners: (Hi-1)/(Ho-1), (Wi-1)/(Wo-1)
+  int ac;                      // align_corners
 };
 
 // forward: one thread per output pixel x VEC channels (VECP) or x 1 channel
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const ResizeArgs a) {
     u /= a.Wo;
     const int oh = (int)(u % a.Ho);
     const int n = (int)(u / a.Ho);
-    const Tap2 th = bilinear_tap(oh, a.sh, a.Hi), tw = bilinear_tap(ow, a.sw, a.Wi);
+    const Tap2 th = bilinear_tap(oh, a.sh, a.Hi, a.ac), tw = bilinear_tap(ow, a.sw, a.Wi, a.ac);
     const T* xb = x + (size_t)n * a.src_img + cc * VEC;
     const size_t p00 = ((size_t)th.i0 * a.Wi + tw.i0) * a.lds_, p01 = ((size_t)th.i0 * a.Wi + tw.i1) * a.lds_;
     const size_t p10 = ((size_t)th.i1 * a.Wi + tw.i0) * a.lds_, p11 = ((size_t)th.i1 * a.Wi + tw.i1) * a.lds_;
@@ -97,15 +99,26 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const ResizeArgs a) {
 }
 
 // candidate output range [lo, hi] whose taps can touch input index i
-__device__ __forceinline__ void cand_range(int i, float scale, int out, int& lo, int& hi) {
-  const float inv = 1.f / scale;
-  lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
-  hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+__device__ __forceinline__ void cand_range(int i, float scale, int out, int ac, int& lo, int& hi) {
+  if (ac) {
+    if (scale <= 0.f) {   // a single input row / column feeds every output
+      lo = 0;
+      hi = out - 1;
+      return;
+    }
+    const float inv = 1.f / scale;
+    lo = (int)floorf(((float)i - 1.f) * inv) - 1;
+    hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+  } else {
+    const float inv = 1.f / scale;
+    lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+    hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  }
   lo = max(lo, 0);
   hi = min(hi, out - 1);
 }
-__device__ __forceinline__ float tap_weight(int o, float scale, int in, int i) {
-  const Tap2 t = bilinear_tap(o, scale, in);
+__device__ __forceinline__ float tap_weight(int o, float scale, int in, int i, int ac) {
+  const Tap2 t = bilinear_tap(o, scale, in, ac);
   return (t.i0 == i ? t.l0 : 0.f) + (t.i1 == i ? t.l1 : 0.f);
 }
 
@@ -127,17 +140,17 @@ __global__ __launch_bounds__(256) void bilinear_bwd_vec_kernel(const ResizeArgs 
     const int ih = (int)(u % a.Hi);
     const int n = (int)(u / a.Hi);
     int hlo, hhi, wlo, whi;
-    cand_range(ih, a.sh, a.Ho, hlo, hhi);
-    cand_range(iw, a.sw, a.Wo, wlo, whi);
+    cand_range(ih, a.sh, a.Ho, a.ac, hlo, hhi);
+    cand_range(iw, a.sw, a.Wo, a.ac, wlo, whi);
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     const T* gb = g + (size_t)n * a.src_img + cc * VEC;
     for (int oh = hlo; oh <= hhi; ++oh) {
-      const float wy = tap_weight(oh, a.sh, a.Hi, ih);
+      const float wy = tap_weight(oh, a.sh, a.Hi, ih, a.ac);
       if (wy == 0.f) continue;
       for (int ow = wlo; ow <= whi; ++ow) {
-        const float wx = tap_weight(ow, a.sw, a.Wi, iw);
+        const float wx = tap_weight(ow, a.sw, a.Wi, iw, a.ac);
         if (wx == 0.f) continue;
         float v[VEC];
         load_f(gb + ((size_t)oh * a.Wo + ow) * a.lds_, v);
@@ -166,14 +179,14 @@ __global__ __launch_bounds__(256) void bilinear_bwd_wave_kernel(const ResizeArgs
     const int ih = (int)(u % a.Hi);
     const int n = (int)(u / a.Hi);
     int hlo, hhi, wlo, whi;
-    cand_range(ih, a.sh, a.Ho, hlo, hhi);
-    cand_range(iw, a.sw, a.Wo, wlo, whi);
+    cand_range(ih, a.sh, a.Ho, a.ac, hlo, hhi);
+    cand_range(iw, a.sw, a.Wo, a.ac, wlo, whi);
     const int nw = whi - wlo + 1, cnt = (hhi - hlo + 1) * nw;
     const T* gb = g + (size_t)n * a.src_img + c;
     float acc = 0.f;
     for (int k = lane; k < cnt; k += 64) {
       const int oh = hlo + k / nw, ow = wlo + k % nw;
-      const float wgt = tap_weight(oh, a.sh, a.Hi, ih) * tap_weight(ow, a.sw, a.Wi, iw);
+      const float wgt = tap_weight(oh, a.sh, a.Hi, ih, a.ac) * tap_weight(ow, a.sw, a.Wi, iw, a.ac);
       if (wgt != 0.f) acc = fmaf(wgt, (float)gb[((size_t)oh * a.Wo + ow) * a.lds_], acc);
     }
 #pragma unroll
@@ -557,12 +570,24 @@ inline bool vec_ok(int dtype, const void* a, const void* b, int lda, int ldb, lo
 
 }  // namespace
 
+static float resize_scale(int in, int out, int ac) {
+  if (!ac) return (float)in / (float)out;
+  return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;   // ATen: area_pixel_compute_scale
+}
+
 extern "C" int uz_bilinear_fwd(int dtype, const void* x, int ldx, long long x_img_stride, int N, int Hi, int Wi,
                                int C, void* y, int ldy, long long y_img_stride, int Ho, int Wo, void* stream) {
+  return uz_resize_bilinear_fwd(dtype, x, ldx, x_img_stride, N, Hi, Wi, C, y, ldy, y_img_stride, Ho, Wo, 0, stream);
+}
+
+extern "C" int uz_resize_bilinear_fwd(int dtype, const void* x, int ldx, long long x_img_stride, int N, int Hi, int Wi,
+                                      int C, void* y, int ldy, long long y_img_stride, int Ho, int Wo,
+                                      int align_corners, void* stream) {
   const int rc = resize_check("uz_bilinear_fwd", dtype, x, y, ldx, ldy, N, Hi, Wi, C, Ho, Wo);
   if (rc != UZ_OK) return rc;
-  ResizeArgs a{x, y, x_img_stride, y_img_stride, ldx, ldy, N, Hi, Wi, Ho, Wo, C, (float)Hi / (float)Ho,
-               (float)Wi / (float)Wo};
+  const int ac = align_corners ? 1 : 0;
+  ResizeArgs a{x, y, x_img_stride, y_img_stride, ldx, ldy, N, Hi, Wi, Ho, Wo, C, resize_scale(Hi, Ho, ac),
+               resize_scale(Wi, Wo, ac), ac};
   hipStream_t s = (hipStream_t)stream;
   const bool v = vec_ok(dtype, x, y, ldx, ldy, x_img_stride, y_img_stride, C);
   const int vec = dtype == UZ_BF16 ? 8 : 4;
@@ -581,10 +606,17 @@ extern "C" int uz_bilinear_fwd(int dtype, const void* x, int ldx, long long x_im
 
 extern "C" int uz_bilinear_bwd(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi,
                                int C, void* dx, int lddx, long long dx_img_stride, int Ho, int Wo, void* stream) {
+  return uz_resize_bilinear_bwd(dtype, g, ldg, g_img_stride, N, Hi, Wi, C, dx, lddx, dx_img_stride, Ho, Wo, 0, stream);
+}
+
+extern "C" int uz_resize_bilinear_bwd(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi,
+                                      int C, void* dx, int lddx, long long dx_img_stride, int Ho, int Wo,
+                                      int align_corners, void* stream) {
   const int rc = resize_check("uz_bilinear_bwd", dtype, g, dx, ldg, lddx, N, Hi, Wi, C, Ho, Wo);
   if (rc != UZ_OK) return rc;
-  ResizeArgs a{g, dx, g_img_stride, dx_img_stride, ldg, lddx, N, Hi, Wi, Ho, Wo, C, (float)Hi / (float)Ho,
-               (float)Wi / (float)Wo};
+  const int ac = align_corners ? 1 : 0;
+  ResizeArgs a{g, dx, g_img_stride, dx_img_stride, ldg, lddx, N, Hi, Wi, Ho, Wo, C, resize_scale(Hi, Ho, ac),
+               resize_scale(Wi, Wo, ac), ac};
   hipStream_t s = (hipStream_t)stream;
   const bool v = vec_ok(dtype, g, dx, ldg, lddx, g_img_stride, dx_img_stride, C);
   const int vec = dtype == UZ_BF16 ? 8 : 4;

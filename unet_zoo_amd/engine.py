@@ -642,22 +642,38 @@ class Engine:
             self.tape.append(bwd)
         return self.linear(o, attn.proj)
 
-    def resize_bilinear(self, x: Act, out: Act) -> Act:
-        """out = F.interpolate(x, size=out's, mode='bilinear', align_corners=False), written into its
-        concat slot.  Reference: _upsample_like (u2net.py:19-22)."""
+    def resize_bilinear(self, x: Act, out: Act, align_corners: bool = False) -> Act:
+        """out = F.interpolate(x, size=out's, mode='bilinear', align_corners=...), written into its
+        concat slot.  Reference: _upsample_like (u2net.py:19-22; align_corners=False),
+        nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (nested_unet.py:32)."""
         assert x.N == out.N and x.C == out.C
-        ops.bilinear_fwd(x, out)
+        ops.bilinear_fwd(x, out, align_corners)
         if self.record and x.needs_grad:
             def bwd():
                 gs = self._sum_grads(out, 1)
                 if not gs:
                     return
                 dx = self.new_act(x.N, x.H, x.W, x.C)
-                ops.bilinear_bwd(gs[0], dx)
+                ops.bilinear_bwd(gs[0], dx, align_corners)
                 x.add_grad(dx)
 
             self.tape.append(bwd)
         return out
+
+    def copy_into(self, src: Act, dst: Act) -> Act:
+        """dst (a slot of a concat buffer) = src: a tensor that appears in SEVERAL torch.cat calls of the
+        reference (UNet++'s dense skips, nested_unet.py:80-93) lives in the slot of its first consumer and is
+        copied into the others; the slot's gradient flows back to `src` without a copy."""
+        assert (src.N, src.H, src.W, src.C) == (dst.N, dst.H, dst.W, dst.C) and src.dtype == dst.dtype
+        dst.buf[:, dst.off:dst.off + dst.C].copy_(src.buf[:, src.off:src.off + src.C])
+        if self.record and src.needs_grad:
+            def bwd():
+                g = self._total_grad(dst)
+                if g is not None:
+                    src.add_grad(g)
+
+            self.tape.append(bwd)
+        return dst
 
     def u2net_heads(self, feats: Sequence[Act], sides: Sequence[nn.Conv2d], fuse: nn.Conv2d) -> List[torch.Tensor]:
         """The six 3x3 side heads, their bilinear resize to the first head's resolution, and the 1x1

@@ -17,6 +17,7 @@ from .unet import UNet
 from .attention_unet import AttentionUNet
 from .u2net import U2NET, U2NETP
 from .swin_unet_v2 import SwinTransformerSys
+from .nested_unet import NestedUNet
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
@@ -28,7 +29,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'unet_transformer': None,
     'uctransnet': None,
     'multiresunet': None,
-    'nested_unet': None,
+    'nested_unet': NestedUNet,
     'missformer': None,
     'vnet': None,
     'u2net': U2NET,
@@ -96,6 +97,10 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
         args.update(in_ch=in_channels, out_ch=num_classes)
     elif name == 'swin_unet_v2':
         args.update(img_size=image_size, in_chans=in_channels, num_classes=num_classes)
+    elif name == 'nested_unet':
+        # models/__init__.py:139-143: depth travels to the constructor (absorbed by **kwargs there)
+        args.update(in_channels=in_channels, num_classes=num_classes, depth=depth,
+                    deep_supervision=kwargs.pop('deep_supervision', False))
     else:
         args.update(in_channels=in_channels, num_classes=num_classes)
     args.update(kwargs)  # leftovers reach the constructor: unknown ones raise TypeError there
@@ -106,4 +111,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']

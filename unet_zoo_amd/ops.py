@@ -459,24 +459,24 @@ def sum2x2(du: Act, dx: Act) -> None:
 
 # ------------------------------------------------------------------------------------------------
 # U^2-Net pieces (u2net.py): bilinear resize, residual/pool gradient merge, side heads, fuse conv
-def bilinear_fwd(x: Act, out: Act) -> None:
-    """out = F.interpolate(x, size=(out.H, out.W), mode='bilinear', align_corners=False)"""
+def bilinear_fwd(x: Act, out: Act, align_corners: bool = False) -> None:
+    """out = F.interpolate(x, size=(out.H, out.W), mode='bilinear', align_corners=align_corners)"""
     assert x.N == out.N and x.C == out.C and x.dtype == out.dtype
     es = x.buf.element_size()
     with _Timed("bilinear_fwd", 0.0, es * (x.P + out.P) * x.C):
-        L.check(L.load().uz_bilinear_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.H * x.W * x.ld, x.N, x.H, x.W,
-                                         x.C, out.ptr(), out.ld, out.H * out.W * out.ld, out.H, out.W,
-                                         L.stream_ptr()), "uz_bilinear_fwd")
+        L.check(L.load().uz_resize_bilinear_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.H * x.W * x.ld, x.N, x.H, x.W,
+                                                x.C, out.ptr(), out.ld, out.H * out.W * out.ld, out.H, out.W,
+                                                int(align_corners), L.stream_ptr()), "uz_resize_bilinear_fwd")
 
 
-def bilinear_bwd(g: Act, dx: Act) -> None:
+def bilinear_bwd(g: Act, dx: Act, align_corners: bool = False) -> None:
     """dx (at the resize's input resolution) from g (at its output resolution)"""
     assert g.N == dx.N and g.C == dx.C and g.dtype == dx.dtype
     es = g.buf.element_size()
     with _Timed("bilinear_bwd", 0.0, es * (g.P + dx.P) * g.C):
-        L.check(L.load().uz_bilinear_bwd(L.dtype_code(g.dtype), g.ptr(), g.ld, g.H * g.W * g.ld, g.N, dx.H, dx.W,
-                                         g.C, dx.ptr(), dx.ld, dx.H * dx.W * dx.ld, g.H, g.W, L.stream_ptr()),
-                "uz_bilinear_bwd")
+        L.check(L.load().uz_resize_bilinear_bwd(L.dtype_code(g.dtype), g.ptr(), g.ld, g.H * g.W * g.ld, g.N, dx.H, dx.W,
+                                                g.C, dx.ptr(), dx.ld, dx.H * dx.W * dx.ld, g.H, g.W,
+                                                int(align_corners), L.stream_ptr()), "uz_resize_bilinear_bwd")
 
 
 def bilinear_planes(src_ptr: int, src_img: int, hi: int, wi: int, dst_ptr: int, dst_img: int, ho: int, wo: int,
