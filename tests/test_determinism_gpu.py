@@ -1,0 +1,75 @@
+"""GPU: every kernel of the path reduces in a fixed order (no floating-point atomics), so two identical train
+steps must agree bit for bit -- logits and every parameter gradient -- for each model family.  This is the test
+that exposes scheduling races (the LDS-queue race of the conv / GEMM epilogues)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import unet_zoo_amd
+from oracle import torch_ref
+
+DEV = "cuda"
+
+CASES = [
+    ("unet", dict(), 4, 128, 128),
+    ("attention_unet", dict(depth=5), 2, 128, 128),
+    ("u2net", dict(), 2, 128, 128),
+    ("nested_unet", dict(), 4, 128, 128),
+    ("swin_unet_v2", dict(image_size=128, window_size=8, drop_path_rate=0.0), 4, 128, 128),
+]
+
+
+def _loss(out, mask):
+    if isinstance(out, dict):
+        return sum(F.binary_cross_entropy_with_logits(v, mask) for v in out.values())
+    if isinstance(out, (list, tuple)):
+        return sum(F.binary_cross_entropy_with_logits(v, mask) for v in out)
+    return F.binary_cross_entropy_with_logits(out, mask)
+
+
+def _flat(out):
+    if isinstance(out, dict):
+        return torch.cat([v.detach().flatten() for v in out.values()])
+    if isinstance(out, (list, tuple)):
+        return torch.cat([v.detach().flatten() for v in out])
+    return out.detach().flatten()
+
+
+# the BASELINE shapes: races show up where kernels run many tiles per workgroup with the whole chip busy
+FULL = [
+    ("unet", dict(), 16, 256, 256),
+    ("swin_unet_v2", dict(image_size=256, window_size=8, drop_path_rate=0.0), 16, 256, 256),
+    ("swin_unet_v2", dict(image_size=224, window_size=7, drop_path_rate=0.0), 8, 224, 224),
+    ("attention_unet", dict(depth=5), 4, 512, 512),
+    ("u2net", dict(), 4, 512, 512),
+    ("nested_unet", dict(), 16, 256, 256),
+]
+
+
+@pytest.mark.parametrize("name,kw,B,H,W", FULL)
+def test_full_size_train_steps_agree_bitwise(name, kw, B, H, W):
+    test_two_identical_train_steps_agree_bitwise(name, kw, B, H, W, torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("name,kw,B,H,W", CASES)
+def test_two_identical_train_steps_agree_bitwise(name, kw, B, H, W, dtype):
+    x, mask = torch_ref.synthetic_batch(B, 3, H, W, seed=11)
+    x, mask = x.to(DEV), mask.to(DEV)
+    runs = []
+    for rep in range(3):
+        torch.manual_seed(0)
+        m = unet_zoo_amd.create_model(name, in_channels=3, num_classes=1, **kw)
+        m.run_dtype = dtype
+        m = m.to(DEV).train()
+        out = m(x)
+        _loss(out, mask).backward()
+        torch.cuda.synchronize()
+        runs.append((_flat(out).clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    for rep in (1, 2):
+        assert torch.equal(runs[0][0], runs[rep][0]), f"{name}: forward differs between identical runs"
+        assert runs[0][1].keys() == runs[rep][1].keys()
+        bad = [n for n in runs[0][1] if not torch.equal(runs[0][1][n], runs[rep][1][n])]
+        assert not bad, f"{name}: gradients differ between identical runs: {bad[:5]} ({len(bad)} tensors)"
