@@ -398,7 +398,9 @@ def main():
                 pmc = json.load(f)["kernels"]
             key = {"conv3x3_direct_bf16_bn128": "21conv3x3_direct_kernelIDF16bLi32ELi128ELb0EEEvNS_10DirectArgsE",
                    "wgrad3x3_bf16_128x128_3tap": "wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>"}.get(dom_name)
-            if key in pmc and args.model == "unet" and args.size == 256 and args.batch == 16:
+            full = next((k for k in pmc if key and key in k), None)   # the table is keyed by the full kernel name
+            if full is not None and args.model == "unet" and args.size == 256 and args.batch == 16:
+                key = full
                 traffic = {"hbm_read_mb_per_launch": pmc[key]["hbm_read_mb_per_launch_corrected"],
                            "hbm_write_mb_per_launch": pmc[key]["hbm_write_mb_per_launch"],
                            "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 2 ** 20, 2),
