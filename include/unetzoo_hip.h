@@ -199,8 +199,14 @@ typedef struct uz_bnbwd_desc {
   int dtype;
   int N, H, W, C;
   int ldy, ldg0, ldg1, ldgp, lddy;
-  int pool_ceil; /* geometry of gpool: 1 = (ceil(H/2), ceil(W/2)) with clipped border windows, 0 = (H/2, W/2) */
+  int pool_ceil; /* bit 0: geometry of gpool: 1 = (ceil(H/2), ceil(W/2)) with clipped border windows, 0 = (H/2, W/2);
+                  * bit 1: the forward was BatchNorm WITHOUT ReLU (uz_bn_relu_add_apply with the same bit; no pool) */
 } uz_bnbwd_desc;
+/* Statistics of a BatchNorm whose input is not a convolution output (pre-activation blocks, `ResidualConv`,
+ * common_layers.py:186-187): per-channel sum and sum of squares of x (P pixels, C channels, row stride ld) as
+ * partial rows [uz_colstats_rows()][2][C], the layout uz_bn_finalize() reads. */
+int uz_colstats_rows(int dtype, int P, int C);
+int uz_colstats(int dtype, const void* x, int ld, int P, int C, float* partial, void* stream);
 long long uz_bn_relu_bwd_workspace_bytes(const uz_bnbwd_desc* d, int has_pool_grad);
 int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, const float* scale,
                           const float* shift, const float* mean, const float* invstd, const void* g0,

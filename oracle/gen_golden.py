@@ -200,6 +200,17 @@ def write_nested_unet():
     print("nested_unet_ds", meta["loss"], meta["global_grad_norm"])
 
 
+def write_resunet():
+    """resunet: seed-0 ResUnet(in_channels=3, num_classes=1), B=2 3x64x64, every number kept."""
+    mods = load_reference("common_layers", "resunet")
+    torch.manual_seed(0)
+    model = mods["resunet"].ResUnet(in_channels=3, num_classes=1)
+    write_manifest(model, "resunet")
+    run_case(model, 2, 64, 64, "resunet_b2_64", full_logits=True, name="resunet",
+             bn_keys=("input_layer.1", "residual_conv_1.conv_block.0", "residual_conv_2.conv_skip.1",
+                      "bridge.conv_block.3", "up_residual_conv1.conv_block.0", "up_residual_conv3.conv_skip.1"))
+
+
 def _timm_stand_in():
     """`swin_unet_v2.py:9` imports three helpers from timm, which this image lacks:
     to_2tuple, trunc_normal_ (= torch.nn.init.trunc_normal_) and DropPath (stochastic depth: per-sample
@@ -307,6 +318,10 @@ def main():
         torch.set_num_threads(8)
         write_u2net()
         return
+    if sys.argv[1:] == ["resunet"]:
+        torch.set_num_threads(8)
+        write_resunet()
+        return
     if sys.argv[1:] == ["nested_unet"]:
         torch.set_num_threads(8)
         write_nested_unet()
@@ -340,6 +355,7 @@ def main():
     write_u2net()
     write_swin()
     write_nested_unet()
+    write_resunet()
 
 
 if __name__ == "__main__":

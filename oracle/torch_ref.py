@@ -414,8 +414,50 @@ def nested_unet_forward(sd: State, x: torch.Tensor, training: bool):
     return F.conv2d(n[0, 4], sd["final.weight"], sd["final.bias"])
 
 
+# ---------------------------------------------------------------------------------------------
+# ResUnet (unet_zoo/models/resunet.py, ResidualConv / UpsampleResUnet of common_layers.py:182-207)
+# ---------------------------------------------------------------------------------------------
+def _bn(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    y = F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                     sd[prefix + ".bias"], training=training, momentum=0.1, eps=1e-5)
+    if training and (prefix + ".num_batches_tracked") in sd:
+        sd[prefix + ".num_batches_tracked"] += 1
+    return y
+
+
+def residual_conv(x, sd: State, prefix: str, training: bool, stride: int) -> torch.Tensor:
+    """ResidualConv.forward — common_layers.py:185-199."""
+    cb, cs = prefix + ".conv_block", prefix + ".conv_skip"
+    h = _q(F.relu(_bn(x, sd, cb + ".0", training)))
+    h = _q(F.conv2d(h, _q(sd[cb + ".2.weight"]), None, stride=stride, padding=1))
+    h = _q(F.relu(_bn(h, sd, cb + ".3", training)))
+    h = _q(F.conv2d(h, _q(sd[cb + ".5.weight"]), None, padding=1))
+    s = _q(F.conv2d(_q(x), _q(sd[cs + ".0.weight"]), None, stride=stride))
+    s = _q(_bn(s, sd, cs + ".1", training))
+    return _q(h + s)
+
+
+def resunet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """ResUnet.forward — resunet.py:54-78."""
+    h = conv_bn_relu(x, sd, "input_layer.0", "input_layer.1", training)
+    h = _q(F.conv2d(h, _q(sd["input_layer.3.weight"]), sd["input_layer.3.bias"], padding=1))
+    sk = _q(F.conv2d(_q(x), _q(sd["input_skip.0.weight"]), sd["input_skip.0.bias"], padding=1))
+    x1 = _q(h + sk)
+    x2 = residual_conv(x1, sd, "residual_conv_1", training, 2)
+    x3 = residual_conv(x2, sd, "residual_conv_2", training, 2)
+    x4 = residual_conv(x3, sd, "bridge", training, 2)
+
+    def up(t, name):
+        return _q(F.conv_transpose2d(_q(t), _q(sd[name + ".upsample.weight"]), sd[name + ".upsample.bias"], stride=2))
+
+    x6 = residual_conv(torch.cat([up(x4, "upsample_1"), x3], 1), sd, "up_residual_conv1", training, 1)
+    x8 = residual_conv(torch.cat([up(x6, "upsample_2"), x2], 1), sd, "up_residual_conv2", training, 1)
+    x10 = residual_conv(torch.cat([up(x8, "upsample_3"), x1], 1), sd, "up_residual_conv3", training, 1)
+    return F.conv2d(x10, sd["output_layer.0.weight"], sd["output_layer.0.bias"])
+
+
 FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward,
-            "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward}
+            "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward, "resunet": resunet_forward}
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":

@@ -17,6 +17,7 @@ CASES = [
     ("attention_unet", dict(depth=5), 2, 128, 128),
     ("u2net", dict(), 2, 128, 128),
     ("nested_unet", dict(), 4, 128, 128),
+    ("resunet", dict(), 4, 128, 128),
     ("swin_unet_v2", dict(image_size=128, window_size=8, drop_path_rate=0.0), 4, 128, 128),
 ]
 
@@ -45,6 +46,7 @@ FULL = [
     ("attention_unet", dict(depth=5), 4, 512, 512),
     ("u2net", dict(), 4, 512, 512),
     ("nested_unet", dict(), 16, 256, 256),
+    ("resunet", dict(), 16, 256, 256),
 ]
 
 

@@ -36,7 +36,7 @@ EXPORTS = (
     "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd",
     "uz_ln_head_fwd", "uz_ln_head_bwd_workspace_bytes", "uz_ln_head_bwd", "uz_sum_rows_f32_ld",
     "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
-    "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_cpb_fwd", "uz_cpb_bwd",
+    "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_colstats_rows", "uz_colstats", "uz_cpb_fwd", "uz_cpb_bwd",
     "uz_cpb_fwd_batched", "uz_cpb_bwd_batched_workspace_bytes", "uz_cpb_bwd_batched",
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
 )
@@ -125,6 +125,8 @@ def load():
     lib.uz_winattn_fwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp]
     lib.uz_winattn_bwd_rows.argtypes = [POINTER(WinAttnDesc)]
     lib.uz_winattn_bwd.argtypes = [POINTER(WinAttnDesc), vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, vp]
+    lib.uz_colstats_rows.argtypes = [ip, ip, ip]
+    lib.uz_colstats.argtypes = [ip, vp, ip, ip, ip, vp, vp]
     lib.uz_cpb_fwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp]
     lib.uz_cpb_bwd.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, vp]
     lib.uz_cpb_fwd_batched.argtypes = [vp, ip, vp]

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
   // border is pooled only in ceil mode (MaxPool2d(2, 2, ceil_mode=True), u2net.py:30) and dropped in floor mode.
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CC = C / VEC;
+  const bool relu = !(pool_ceil & 2);   // bit 1 of the flag word: BatchNorm WITHOUT the ReLU (resunet's skip branch)
+  pool_ceil &= 1;
   const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
   const int Hp = pool_ceil ? Ho : H >> 1, Wp = pool_ceil ? Wo : W >> 1;
   const long long total = POOL ? (long long)N * Ho * Wo * CC : (long long)N * H * W * CC;
@@ -114,7 +116,10 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
       float v[VEC];
       load_f(y + (size_t)u * ldy + c0, v);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+      for (int i = 0; i < VEC; ++i) {
+        v[i] = fmaf(v[i], sc[i], sh[i]);
+        if (relu) v[i] = fmaxf(v[i], 0.f);
+      }
       if (res != nullptr) {
         float r[VEC];
         load_f(res + (size_t)u * ldr + c0, r);
@@ -191,7 +196,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
   const bool cok = cc < CC;
   const int c0 = (cok ? cc : 0) * VEC;
   const int Ho = (a.H + 1) >> 1, Wo = (a.W + 1) >> 1;   // window grid (ceil): every pixel in exactly one window
-  const int Hp = a.pool_ceil ? Ho : a.H >> 1, Wp = a.pool_ceil ? Wo : a.W >> 1;
+  const bool norelu = (a.pool_ceil & 2) != 0;           // bit 1: the forward had no ReLU (non-pool launches only)
+  const int Hp = (a.pool_ceil & 1) ? Ho : a.H >> 1, Wp = (a.pool_ceil & 1) ? Wo : a.W >> 1;
   const long long units = POOL ? (long long)a.N * Ho * Wo : (long long)a.N * a.H * a.W;
 
   float sc[VEC], sh[VEC], mu[VEC], is[VEC], k0[VEC], k1[VEC];
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float pre = fmaf(yv[k][i], sc[i], sh[i]);
-        const float dz = pre > 0.f ? gv[k][i] : 0.f;
+        const float dz = (norelu || pre > 0.f) ? gv[k][i] : 0.f;
         const float xh = (yv[k][i] - mu[i]) * is[i];
         if (PASS == 1) {
           S0[i] += dz;
@@ -568,6 +574,55 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   }
 }
 
+// per-channel sum and sum of squares of an arbitrary NHWC tensor, as partial rows [blockIdx.x][2][C] in the
+// layout uz_bn_finalize() reads (what the convolution epilogues produce for their own outputs): the statistics
+// of a BatchNorm whose input is not a convolution output (pre-activation blocks: ResidualConv, common_layers.py:186)
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ x, int ld, long long P, int C,
+                                                       float* __restrict__ out) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [blockDim.y][blockDim.x][2 * VEC]
+  const int CC = C / VEC;
+  const int cc = blockIdx.y * blockDim.x + threadIdx.x;
+  const bool cok = cc < CC;
+  const int c0 = (cok ? cc : 0) * VEC;
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = q[i] = 0.f;
+  const long long stride = (long long)gridDim.x * blockDim.y;
+  for (long long p = (long long)blockIdx.x * blockDim.y + threadIdx.y; p < P && cok; p += 4 * stride) {
+    float v[4][VEC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p + k * stride < P) {
+        load_f(x + (size_t)(p + k * stride) * ld + c0, v[k]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[k][i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        s[i] += v[k][i];
+        q[i] = fmaf(v[k][i], v[k][i], q[i]);
+      }
+  }
+  float* mine = red + ((size_t)threadIdx.y * blockDim.x + threadIdx.x) * (2 * VEC);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    mine[i] = s[i];
+    mine[VEC + i] = q[i];
+  }
+  __syncthreads();
+  for (int e = threadIdx.y; e < 2 * VEC; e += blockDim.y) {
+    float t = 0.f;
+    for (int r = 0; r < (int)blockDim.y; ++r) t += red[((size_t)r * blockDim.x + threadIdx.x) * (2 * VEC) + e];
+    if (cok) out[((size_t)blockIdx.x * 2 + e / VEC) * C + c0 + (e % VEC)] = t;
+  }
+}
+
 __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C,
                                                                float* __restrict__ out) {
   __shared__ double sh[32][33];
@@ -820,7 +875,7 @@ static int bn_relu_apply_t(const void* y, int ldy, const float* scale, const flo
   } else {
     const long long total = (long long)N * H * W * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, 0);
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 2);
   }
   UZ_LAUNCH_CHECK("uz_bn_relu_apply");
   return UZ_OK;
@@ -845,6 +900,7 @@ extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const flo
   UZ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "uz_bn_relu_apply: C=%d must be a multiple of %d", C, vec);
   UZ_REQUIRE(ldy % vec == 0 && lda % vec == 0 && ldy >= C && lda >= C, "uz_bn_relu_apply: bad ld");
   if (res != nullptr) UZ_REQUIRE(ldr % vec == 0 && ldr >= C, "uz_bn_relu_apply: bad ldr");
+  UZ_REQUIRE(!(pool_ceil & 2) || pooled == nullptr, "uz_bn_relu_apply: the no-ReLU form has no fused pool");
   if (pooled != nullptr) {
     UZ_REQUIRE(pool_ceil || (H >= 2 && W >= 2), "uz_bn_relu_apply: floor-mode pool of a %dx%d map is empty", H, W);
     UZ_REQUIRE(ldp % vec == 0 && ldp >= C, "uz_bn_relu_apply: bad ldp");
@@ -866,6 +922,7 @@ static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, c
     UZ_REQUIRE(d->ldgp % vec == 0 && d->ldgp >= d->C, "uz_bn_relu_bwd: bad ldgp");
   }
   UZ_REQUIRE(g0 || g1 || gp, "uz_bn_relu_bwd: no incoming gradient");
+  UZ_REQUIRE(!(d->pool_ceil & 2) || gp == nullptr, "uz_bn_relu_bwd: the no-ReLU form has no pool gradient");
   return UZ_OK;
 }
 
@@ -1080,6 +1137,31 @@ extern "C" int uz_colsum_ws(int dtype, const void* x, int ld, int P, int C, floa
   UZ_LAUNCH_CHECK("uz_colsum_ws");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(uz_cdiv(C, 32)), dim3(1024), 0, s, part, (int)grid.x, C, out);
   UZ_LAUNCH_CHECK("uz_colsum_ws(finalize)");
+  return UZ_OK;
+}
+
+extern "C" int uz_colstats_rows(int dtype, int P, int C) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_colstats_rows: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(P > 0 && C > 0 && C % vec == 0, "uz_colstats_rows: bad shape");
+  dim3 grid, block;
+  reduce_shape(C / vec, P, &grid, &block, 4);
+  return (int)grid.x;
+}
+
+extern "C" int uz_colstats(int dtype, const void* x, int ld, int P, int C, float* partial, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_colstats: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(x && partial && P > 0 && C > 0 && C % vec == 0 && ld % vec == 0 && ld >= C, "uz_colstats: bad args");
+  dim3 grid, block;
+  reduce_shape(C / vec, P, &grid, &block, 4);
+  const size_t shm = (size_t)256 * 2 * vec * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((colstats_kernel<bf16_t>), grid, block, shm, s, (const bf16_t*)x, ld, (long long)P, C, partial);
+  else
+    hipLaunchKernelGGL((colstats_kernel<float>), grid, block, shm, s, (const float*)x, ld, (long long)P, C, partial);
+  UZ_LAUNCH_CHECK("uz_colstats");
   return UZ_OK;
 }
 

@@ -392,6 +392,118 @@ class Engine:
         v2 = ops.bn_eval_scale(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
         return torch.cat([v2, bn.running_mean.reshape(1, -1), torch.rsqrt(bn.running_var + bn.eps).reshape(1, -1)])
 
+    # ------------------------------------------------------------------ pre-activation residual pieces (resunet)
+    def bn_act(self, x: Act, bn: nn.BatchNorm2d, relu: bool = True) -> Act:
+        """BatchNorm2d [+ ReLU] of a tensor that is NOT a convolution output, so nobody has its statistics yet:
+        `ResidualConv.conv_block[0:2]` and `conv_skip[1]` (common_layers.py:186-187, :195).  One statistics pass
+        (uz_colstats), then the same finalize / apply / two-pass backward kernels as the fused conv-BN-ReLU."""
+        C = bn.num_features
+        assert x.C == C
+        vec = self._bn_vectors(bn, ops.colstats(x) if self.training else None, x.P)
+        act = self.new_act(x.N, x.H, x.W, C)
+        ops.bn_relu_apply(x, vec[0], vec[1], act, relu=relu)
+        if self.record:
+            if not self.training:
+                raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+            self._bn_channels += C
+
+            def bwd():
+                gs = self._sum_grads(act, 2)
+                if not gs:
+                    return
+                dx = self.new_act(x.N, x.H, x.W, C)
+                dgamma, dbeta = self._dst(bn.weight), self._dst(bn.bias)
+                if dgamma is None:
+                    dgamma = torch.empty(C, dtype=torch.float32, device=self.device)
+                if dbeta is None:
+                    dbeta = torch.empty(C, dtype=torch.float32, device=self.device)
+                ops.bn_relu_bwd(x, vec, gs[0], gs[1] if len(gs) > 1 else None, None, self._bn_sums(C), dx, dgamma, dbeta,
+                                relu=relu)
+                self._give_grad(bn.weight, dgamma)
+                self._give_grad(bn.bias, dbeta)
+                if x.needs_grad:
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return act
+
+    def conv_plain(self, x: Act, conv: nn.Conv2d, *, im2col: bool = False) -> Act:
+        """Conv2d k3 p1 / k1 p0, stride 1, WITHOUT a following BatchNorm: the block tails and skip convolutions of
+        resunet (resunet.py:28-32, common_layers.py:191, :194 after uz-side subsampling).  `im2col`: x holds the
+        3x3 patches of the network input (input_im2col)."""
+        Cout = conv.out_channels
+        k = conv.kernel_size[0]
+        assert conv.kernel_size in ((3, 3), (1, 1)) and conv.dilation == (1, 1)
+        if im2col:
+            wp, ntaps = self._pack(conv.weight, L.PACK_IM2COL, x.C), 1
+        else:
+            assert conv.in_channels == x.C
+            wp, ntaps = self._pack(conv.weight, L.PACK_CONV_FWD), k * k
+        y = self.new_act(x.N, x.H, x.W, Cout)
+        ops.conv_igemm(x, wp, conv.bias.detach() if conv.bias is not None else None, y, ntaps=ntaps)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                if im2col:
+                    dwp = ops.wgrad(g, x, (Cout, x.C), ntaps=1)
+                    cin = conv.in_channels
+                    dw = dwp[:, :9 * cin].reshape(Cout, 9, cin).permute(0, 2, 1).reshape(conv.weight.shape)
+                    self._give_grad(conv.weight, dw.contiguous())
+                    return
+                self._give_grad(conv.weight, ops.wgrad(g, x, tuple(conv.weight.shape), ntaps=ntaps,
+                                                       out=self._dst(conv.weight)))
+                if x.needs_grad:
+                    dx = self.new_act(x.N, x.H, x.W, x.C)
+                    ops.conv_igemm(g, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=ntaps)
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def subsample2(self, x: Act) -> Act:
+        """out[n, h, w] = x[n, 2h, 2w]: what a stride-2 convolution keeps of its stride-1 result (3x3, padding 1) or
+        reads of its input (1x1); strided copy, the gradient is scattered back between zeros."""
+        N, H, W, C = x.N, x.H, x.W, x.C
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        out = self.new_act(N, Ho, Wo, C)
+        out.buf.view(N, Ho, Wo, out.ld)[..., out.off:out.off + C].copy_(
+            x.buf.view(N, H, W, x.ld)[:, ::2, ::2, x.off:x.off + C])
+        if self.record and x.needs_grad:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                dx = self.new_act(N, H, W, C)
+                dx.buf.zero_()
+                dx.buf.view(N, H, W, dx.ld)[:, ::2, ::2, dx.off:dx.off + C].copy_(
+                    g.buf.view(N, Ho, Wo, g.ld)[..., g.off:g.off + C])
+                x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return out
+
+    def add(self, a: Act, b: Act) -> Act:
+        """a + b (the residual sums, resunet.py:56, common_layers.py:199)"""
+        assert (a.N, a.H, a.W, a.C) == (b.N, b.H, b.W, b.C)
+        out = self.new_act(a.N, a.H, a.W, a.C)
+        ops.add_acts(a, b, out)
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                if a.needs_grad:
+                    a.add_grad(g)
+                if b.needs_grad:
+                    b.add_grad(g)
+
+            self.tape.append(bwd)
+        return out
+
     def conv_transpose2x2(self, x: Act, m: nn.ConvTranspose2d, out: Act) -> Act:
         """ConvTranspose2d(k=2, s=2) written straight into its slot of the concat buffer.
         Reference: UpSample_UNet.up (common_layers.py:104,108)."""

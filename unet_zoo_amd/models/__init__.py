@@ -18,6 +18,7 @@ from .attention_unet import AttentionUNet
 from .u2net import U2NET, U2NETP
 from .swin_unet_v2 import SwinTransformerSys
 from .nested_unet import NestedUNet
+from .resunet import ResUnet
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
@@ -35,7 +36,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'u2net': U2NET,
     'u2netp': U2NETP,
     'swin_unet_v2': SwinTransformerSys,
-    'resunet': None,
+    'resunet': ResUnet,
     'wranet': None,
     'egeunet': None,
     'unext': None,
@@ -97,6 +98,9 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
         args.update(in_ch=in_channels, out_ch=num_classes)
     elif name == 'swin_unet_v2':
         args.update(img_size=image_size, in_chans=in_channels, num_classes=num_classes)
+    elif name == 'resunet':
+        # models/__init__.py:167-170
+        args.update(in_channels=in_channels, num_classes=num_classes, filters=kwargs.pop('filters', [64, 128, 256, 512]))
     elif name == 'nested_unet':
         # models/__init__.py:139-143: depth travels to the constructor (absorbed by **kwargs there)
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth,
@@ -111,4 +115,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'list_models', 'hip_models', 'get_model_config', 'create_model']

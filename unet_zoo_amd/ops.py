@@ -277,6 +277,22 @@ def bn_finalize(stats: torch.Tensor, count: int, gamma, beta, eps: float, moment
     return vec
 
 
+def colstats(x: Act) -> torch.Tensor:
+    """partial rows (rows, 2, C) of per-channel sum / sum of squares of x, as bn_finalize() reads them"""
+    lib = L.load()
+    code = L.dtype_code(x.dtype)
+    rows = L.check_count(lib.uz_colstats_rows(code, x.P, x.C), "uz_colstats_rows")
+    part = torch.empty((rows, 2, x.C), dtype=torch.float32, device=x.buf.device)
+    with _Timed("colstats", 0.0, x.buf.element_size() * x.P * x.C):
+        L.check(lib.uz_colstats(code, x.ptr(), x.ld, x.P, x.C, part.data_ptr(), L.stream_ptr()), "uz_colstats")
+    return part
+
+
+def add_acts(a: Act, b: Act, out: Act) -> None:
+    """out = a + b (the residual sums of ResidualConv, common_layers.py:199)"""
+    pool_grad_combine(a, a, b, None, out)
+
+
 def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
     lib = L.load()
     C = gamma.numel()
@@ -288,8 +304,10 @@ def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
 
 
 def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
-                  pooled: Optional[Act] = None, res: Optional[Act] = None, pool_ceil: bool = False) -> None:
-    """act = relu(scale*y + shift) [+ res]; pooled = maxpool2x2(act) (floor or ceil output size)"""
+                  pooled: Optional[Act] = None, res: Optional[Act] = None, pool_ceil: bool = False,
+                  relu: bool = True) -> None:
+    """act = relu(scale*y + shift) [+ res]; pooled = maxpool2x2(act) (floor or ceil output size);
+    relu=False: plain BatchNorm (no pool)"""
     if pooled is not None:
         want = ((y.H + 1) // 2, (y.W + 1) // 2) if pool_ceil else (y.H // 2, y.W // 2)
         assert (pooled.H, pooled.W) == want, (pooled.H, pooled.W, want)
@@ -301,18 +319,20 @@ def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
                                          res.ptr() if res is not None else None,
                                          res.ld if res is not None else 0, act.ptr(), act.ld,
                                          pooled.ptr() if pooled is not None else None,
-                                         pooled.ld if pooled is not None else 0, int(pool_ceil), L.stream_ptr()),
+                                         pooled.ld if pooled is not None else 0, int(pool_ceil) | (0 if relu else 2),
+                                         L.stream_ptr()),
                 "uz_bn_relu_add_apply")
 
 
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
-                dbeta: torch.Tensor, pool_ceil: bool = False) -> None:
-    """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch."""
+                dbeta: torch.Tensor, pool_ceil: bool = False, relu: bool = True) -> None:
+    """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch; relu=False: the
+    forward was a plain BatchNorm"""
     lib = L.load()
     d = L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
                     g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
-                    gpool.ld if gpool is not None else 0, dy.ld, int(pool_ceil))
+                    gpool.ld if gpool is not None else 0, dy.ld, int(pool_ceil) | (0 if relu else 2))
     args = (y.ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
             g0.ptr() if g0 is not None else None, g1.ptr() if g1 is not None else None,
             gpool.ptr() if gpool is not None else None)
