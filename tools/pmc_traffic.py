@@ -1,5 +1,5 @@
 """Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; csv output) into profiles/r01_pmc_traffic.json.
-   python tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv"""
+   python tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv [out.json]"""
 import csv
 import json
 import sys
@@ -27,6 +27,7 @@ for k in sorted(set(fe) | set(wr)):
     out["kernels"][k] = {"launches": n, "fetch_size_kb_sum": round(fe[k][1], 3), "write_size_kb_sum": round(wr[k][1], 3),
                          "hbm_read_mb_per_launch_corrected": round(2 * fe[k][1] / 1024 / n, 2),
                          "hbm_write_mb_per_launch": round(wr[k][1] / 1024 / n, 2)}
-json.dump(out, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+OUT = sys.argv[3] if len(sys.argv) > 3 else "profiles/r01_pmc_traffic.json"
+json.dump(out, open(OUT, "w"), indent=1)
 for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["hbm_read_mb_per_launch_corrected"] * kv[1]["launches"])[:8]:
     print(k[:90], v)
