@@ -42,9 +42,13 @@ enum {
 enum {
   UZ_TAPS_CONV = 0,     /* ntaps = 1 (1x1) or 9 (3x3, dilation `dil`, zero padding `dil`) */
   UZ_TAPS_GATHER2X2 = 1, /* ntaps = 4: input pixel (2h+a, 2w+b), tap = 2a+b (ConvTranspose k2s2 dgrad) */
-  UZ_TAPS_CONV_UP2 = 2   /* 3x3 taps on the nearest-neighbour x2 upsampling of the input: the input tensor
+  UZ_TAPS_CONV_UP2 = 2,  /* 3x3 taps on the nearest-neighbour x2 upsampling of the input: the input tensor
                             lives at (H/2, W/2) and pixel (h, w) reads (h>>1, w>>1)
                             (nn.Upsample(scale_factor=2) + Conv2d, common_layers.py:69-72) */
+  UZ_TAPS_CONV_S2 = 3    /* ntaps = 9: Conv2d(k3, stride 2, padding 1): output pixel (h, w) reads input pixel
+                            (2h + ty - 1, 2w + tx - 1) of the (Hin, Win) grid, H = ceil(Hin / 2); zero outside
+                            (ResidualConv, common_layers.py:188).  uz_conv_igemm: forward; uz_wgrad: weight gradient
+                            (L = dy at (H, W), R = x at (Hr, Wr) = (Hin, Win)) */
 };
 enum {
   UZ_STORE_PLAIN = 0,    /* y[p*ldy + n] */

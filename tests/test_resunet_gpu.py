@@ -140,3 +140,28 @@ def test_resunet_registry_and_size_check():
     m = _model().to(DEV)
     with pytest.raises(ValueError):
         m(torch.zeros(1, 3, 36, 64, device=DEV))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 32, 32, 64, 128), (1, 64, 128, 128, 256), (1, 16, 32, 256, 512),
+                                            (1, 14, 10, 64, 64), (2, 8, 8, 96, 40)])
+def test_conv3x3_stride2_forward_and_weight_gradient(dt, N, H, W, Cin, Cout):
+    """UZ_TAPS_CONV_S2: Conv2d(k3, stride 2, padding 1) (ResidualConv, common_layers.py:188) on the LDS-DMA GEMM and
+    its weight gradient as a stride-2 gather (bf16 on map widths the LDS-DMA kernel takes)"""
+    from unet_zoo_amd import _lib as L
+    g = torch.Generator().manual_seed(83)
+    x = rnd(dt, torch.randn(N, Cin, H, W, generator=g)).requires_grad_(True)
+    w = rnd(dt, torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = rnd(dt, torch.randn(ref.shape, generator=g))
+    ref.backward(dy)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xa = act_from_nchw(x.detach().to(DEV), dt)
+    y = ops.new_act(N, Ho, Wo, Cout, dt, DEV)
+    wp = ops.pack_weights(w.detach().to(DEV), L.PACK_CONV_FWD, dt)
+    ops.conv_igemm(xa, wp, None, y, ntaps=9, taps_mode=L.TAPS_CONV_S2)
+    assert relerr(y.dense().cpu(), ref.detach()) < (2e-5 if dt == torch.float32 else 2e-2)
+    fast = dt == torch.bfloat16 and (Wo in (16, 32) or (Wo >= 64 and Wo % 64 == 0)) and Ho % (64 // min(Wo, 64)) == 0
+    if fast:
+        dw = ops.wgrad(act_from_nchw(dy.to(DEV), dt), xa, (Cout, Cin, 3, 3), ntaps=9, taps_mode=L.TAPS_CONV_S2)
+        assert relerr(dw.cpu(), w.grad) < 2e-2

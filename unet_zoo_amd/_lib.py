@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_voi
 import torch
 
 UZ_F32, UZ_BF16 = 0, 1
-TAPS_CONV, TAPS_GATHER2X2, TAPS_CONV_UP2 = 0, 1, 2
+TAPS_CONV, TAPS_GATHER2X2, TAPS_CONV_UP2, TAPS_CONV_S2 = 0, 1, 2, 3
 STORE_PLAIN, STORE_SHUFFLE2X2 = 0, 1
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD, PACK_IM2COL = range(5)
 

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
   // so the NEXT tile's first stages can be issued from the current tile's epilogue)
   auto issue = [&](int m0t, int stage, int s) {
       const int tap = s / ncb, cb = s - tap * ncb;
-      const int dpix = (a.mode == UZ_TAPS_CONV) ? 0 : (tap >> 1) * a.Win + (tap & 1);
+      const int dpix = (a.mode == UZ_TAPS_GATHER2X2) ? (tap >> 1) * a.Win + (tap & 1) : 0;
+      const int s2y = (tap * 11) >> 5, s2x = tap - 3 * s2y;   // UZ_TAPS_CONV_S2: tap = 3 ty + tx
       const int slab = cb * BK * ES;            // byte offset of the slab inside the tap's channels
       char* sA = smem + stage * STAGE;
       char* sBt = sA + A_BYTES;
@@ -149,7 +150,12 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
           } else {
             const int img = m / HW, rem = m - img * HW;
             const int h = rem / a.W, w = rem - h * a.W;
-            a_pix = (img * a.Hin + 2 * h) * a.Win + 2 * w;
+            if (a.mode == UZ_TAPS_CONV_S2) {   // stride 2, padding 1: (2h + ty - 1, 2w + tx - 1), zero outside
+              const int hh = 2 * h + s2y - 1, ww = 2 * w + s2x - 1;
+              if ((unsigned)hh < (unsigned)a.Hin && (unsigned)ww < (unsigned)a.Win) a_pix = (img * a.Hin + hh) * a.Win + ww;
+            } else {
+              a_pix = (img * a.Hin + 2 * h) * a.Win + 2 * w;
+            }
           }
         }
         const bool ok = a_pix >= 0 && slab + a_coff < cin_bytes;
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
 int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4, bk = 8 * vec;
   const bool conv1 = d->taps_mode == UZ_TAPS_CONV && d->ntaps == 1;
-  const bool gath = d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4;
+  const bool gath = (d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4) || (d->taps_mode == UZ_TAPS_CONV_S2 && d->ntaps == 9);
   if (!conv1 && !gath) return 0;
   (void)bk;
   if (d->Cin % vec != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;

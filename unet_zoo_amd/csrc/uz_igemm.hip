@@ -379,6 +379,11 @@ int make_plan(const uz_conv_desc* d, Plan* p) {
     UZ_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "uz_conv_igemm: ntaps=%d", d->ntaps);
     UZ_REQUIRE(d->Hin == d->H && d->Win == d->W, "uz_conv_igemm: conv taps need Hin==H, Win==W");
     UZ_REQUIRE(d->dil >= 1, "uz_conv_igemm: dil=%d", d->dil);
+  } else if (d->taps_mode == UZ_TAPS_CONV_S2) {
+    UzGemmPlan gs2_;
+    UZ_REQUIRE(d->ntaps == 9 && d->store_mode == UZ_STORE_PLAIN && d->H == (d->Hin + 1) / 2 && d->W == (d->Win + 1) / 2,
+               "uz_conv_igemm: stride-2 taps need ntaps=9, a plain store and H = ceil(Hin/2), W = ceil(Win/2)");
+    UZ_REQUIRE(uz_gemm_dma_plan(d, &gs2_), "uz_conv_igemm: stride-2 taps need the LDS-DMA GEMM (channel multiples, tensor < 2 GiB)");
   } else {
     UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4,
                "uz_conv_igemm: gather2x2 needs ntaps=4");

@@ -277,6 +277,11 @@ int make_plan(const uz_wgrad_desc* d, Plan* p) {
   } else if (d->taps_mode == UZ_TAPS_CONV_UP2) {
     UZ_REQUIRE(d->ntaps == 9 && d->dil == 1 && d->Hr * 2 == d->H && d->Wr * 2 == d->W,
                "uz_wgrad: upsampled R needs ntaps=9, dil=1, Hr=H/2, Wr=W/2");
+  } else if (d->taps_mode == UZ_TAPS_CONV_S2) {
+    UzWgrad2Plan s2p_;
+    UZ_REQUIRE(d->ntaps == 9 && d->H == (d->Hr + 1) / 2 && d->W == (d->Wr + 1) / 2,
+               "uz_wgrad: stride-2 taps need ntaps=9, H = ceil(Hr/2), W = ceil(Wr/2)");
+    UZ_REQUIRE(uz_wgrad3x3_plan(d, &s2p_), "uz_wgrad: stride-2 taps need the LDS-DMA kernel (bf16, W in {16, 32, 64k}, channel multiples of 8)");
   } else {
     UZ_REQUIRE(d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && (d->Hr == 2 * d->H || d->Hr == 2 * d->H + 1) &&
                    (d->Wr == 2 * d->W || d->Wr == 2 * d->W + 1),

@@ -36,7 +36,8 @@ struct Wg2Args {
   int tiles_j;
   int r_up;  // 1: R lives at (H/2, W/2) and is read through nearest x2 upsampling
   int gather;   // 1: 2x2 gather (ConvTranspose2d k2 s2 / PatchExpand weight gradient): R lives on the (Hr, Wr) grid
-                // of 2H (+1) x 2W (+1) pixels and tap t = blockIdx.y reads pixel (2h + (t >> 1), 2w + (t & 1))
+                // of 2H (+1) x 2W (+1) pixels and tap t = blockIdx.y reads pixel (2h + (t >> 1), 2w + (t & 1));
+                // 2: stride-2 3x3 convolution (UZ_TAPS_CONV_S2): tap t = 3 ty + tx reads (2h + ty - 1, 2w + tx - 1), zero outside
   int Hr, Wr;
   int flags; // tuning switches (env UZ_TUNE): bit 2 = plain workgroup order
 };
@@ -168,14 +169,20 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
       } else {
         unsigned rp = pix;
+        bool r_in = true;
         if (a.r_up) {
           const int hh = h + p_rrel[i], ww = w0 + p_crel[i];
           rp = (unsigned)((img * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1));
-        } else if (a.gather) {
+        } else if (a.gather == 1) {
           const int hh = h + p_rrel[i], ww = w0 + p_crel[i];
           rp = (unsigned)((img * a.Hr + 2 * hh + (ty_blk_g >> 1)) * a.Wr + 2 * ww + (ty_blk_g & 1));
+        } else if (a.gather == 2) {
+          const int gy = (ty_blk_g * 11) >> 5, gx = ty_blk_g - 3 * gy;
+          const int rh = 2 * (h + p_rrel[i]) + gy - 1, rw = 2 * (w0 + p_crel[i]) + gx - 1;
+          r_in = (unsigned)rh < (unsigned)a.Hr && (unsigned)rw < (unsigned)a.Wr;
+          rp = (unsigned)((img * a.Hr + rh) * a.Wr + rw);
         }
-        const unsigned off = ok ? rp * (unsigned)(a.ldr * 2) + p_coff[i] : OOB;
+        const unsigned off = (ok && r_in) ? rp * (unsigned)(a.ldr * 2) + p_coff[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
       }
     }
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
     const int tw = tg * NTW + tt;
     if (tw >= NTAP) continue;  // wave-uniform
     const int tap = (NTX == 1) ? ty_blk_g : ((NTY == 3) ? tw : ty_blk * 3 + tw);
-    float* slab = a.slab + ((size_t)bz * (NTX == 1 ? (a.gather ? 4 : 1) : 9) + tap) * (size_t)a.Ci * a.Cj;
+    float* slab = a.slab + ((size_t)bz * (NTX == 1 ? (a.gather == 1 ? 4 : (a.gather == 2 ? 9 : 1)) : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int cj = tj0 + wj * WTJ + l31;
@@ -302,11 +309,12 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
-  const bool gather = d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && !(uz_tune_flags() & 0x4000000);
+  const bool s2 = d->taps_mode == UZ_TAPS_CONV_S2 && d->ntaps == 9;
+  const bool gather = (d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && !(uz_tune_flags() & 0x4000000)) || s2;
   if (d->dtype != UZ_BF16 || !(d->taps_mode == UZ_TAPS_CONV || up || gather)) return 0;
   if (!((d->ntaps == 9 && d->dil == 1) || (d->ntaps == 1 && !up) || gather)) return 0;
-  p->one_tap = d->ntaps == 1 || gather;   // gather: four one-tap problems, blockIdx.y = tap
-  p->gather = gather ? 1 : 0;
+  p->one_tap = d->ntaps == 1 || gather;   // gather: four (nine) one-tap problems, blockIdx.y = tap
+  p->gather = s2 ? 2 : (gather ? 1 : 0);
   if (d->Ci % 8 != 0 || d->Cj % 8 != 0) return 0;
   int W = d->W, H = d->H;
   long long nimg = d->N;
@@ -350,7 +358,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   p->tiles_j = (d->Cj + b - 1) / b;
   p->kg = 1;
   p->units = (int)(nimg * H * W / 64);
-  const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : (gather ? 4 : 1));
+  const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : (gather ? d->ntaps : 1));
   // one workgroup per CU (160 KB LDS each): aim for a single full round of <= 256 workgroups
   long long split = base >= UZ_NUM_CU ? 1 : UZ_NUM_CU / base;
   long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
@@ -406,7 +414,7 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.tiles_j = p.tiles_j;
   dim3 block(512);
   if (p.one_tap) {
-    dim3 grid(p.tiles_i * p.tiles_j, p.gather ? 4 : 1, p.split);
+    dim3 grid(p.tiles_i * p.tiles_j, p.gather == 2 ? 9 : (p.gather ? 4 : 1), p.split);
     if (p.big) hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 1, 2, 4, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 1, 1, 2, 2, 2>), grid, block, 0, s, a);  // 4 waves idle: memory-bound
   } else if (p.big) {

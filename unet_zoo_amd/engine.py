@@ -464,6 +464,46 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    def conv3x3_s2(self, x: Act, conv: nn.Conv2d) -> Act:
+        """Conv2d(k3, stride 2, padding 1) without a BatchNorm behind it (ResidualConv.conv_block[2],
+        common_layers.py:188): forward on the LDS-DMA GEMM with UZ_TAPS_CONV_S2 (nine stride-2 taps, zero outside),
+        weight gradient by the LDS-DMA kernel's stride-2 gather (bf16, map widths 16 / 32 / 64k) -- no work on
+        pixels the stride skips.  The input gradient still takes the dense route: dy spread between zeros, then the
+        stride-1 input-gradient convolution (as does the fp32 weight gradient)."""
+        assert conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.in_channels == x.C
+        N, H, W, Cout = x.N, x.H, x.W, conv.out_channels
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = self.new_act(N, Ho, Wo, Cout)
+        ops.conv_igemm(x, self._pack(conv.weight, L.PACK_CONV_FWD), conv.bias.detach() if conv.bias is not None else None,
+                       y, ntaps=9, taps_mode=L.TAPS_CONV_S2)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                fast_w = self.dtype == torch.bfloat16 and (Wo in (16, 32) or (Wo >= 64 and Wo % 64 == 0)) \
+                    and Ho % (64 // min(Wo, 64)) == 0
+                gfull = None
+                if x.needs_grad or not fast_w:
+                    gfull = self.new_act(N, H, W, Cout)        # dy between zeros: the dense stride-1 gradient routes
+                    gfull.buf.zero_()
+                    gfull.buf.view(N, H, W, gfull.ld)[:, ::2, ::2, gfull.off:gfull.off + Cout].copy_(
+                        g.buf.view(N, Ho, Wo, g.ld)[..., g.off:g.off + Cout])
+                if fast_w:
+                    dw = ops.wgrad(g, x, tuple(conv.weight.shape), ntaps=9, taps_mode=L.TAPS_CONV_S2, out=self._dst(conv.weight))
+                else:
+                    dw = ops.wgrad(gfull, x, tuple(conv.weight.shape), ntaps=9, out=self._dst(conv.weight))
+                self._give_grad(conv.weight, dw)
+                if x.needs_grad:
+                    dx = self.new_act(N, H, W, x.C)
+                    ops.conv_igemm(gfull, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=9)
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
     def subsample2(self, x: Act) -> Act:
         """out[n, h, w] = x[n, 2h, 2w]: what a stride-2 convolution keeps of its stride-1 result (3x3, padding 1) or
         reads of its input (1x1); strided copy, the gradient is scattered back between zeros."""

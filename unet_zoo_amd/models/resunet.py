@@ -4,9 +4,10 @@ UpsampleResUnet of common_layers.py:182-207).
 Pre-activation residual blocks: BN -> ReLU -> Conv3x3(stride s) -> BN -> ReLU -> Conv3x3, plus a skip
 Conv1x1(stride s) -> BN, summed.  A BatchNorm here normalises a SUM (or the network input's first block), not a
 convolution output, so its statistics come from one extra pass (`Engine.bn_act`); the stride-1 middle pair
-Conv -> BN -> ReLU is the fused kernel of the other models.  Stride 2 (this round): the 3x3 convolution runs at
-stride 1 and keeps every second pixel, the 1x1 convolution reads every second pixel (`Engine.subsample2`) --
-exact, at 4x the multiply-adds of three layers; a strided tap mode of the direct convolution is the follow-up.
+Conv -> BN -> ReLU is the fused kernel of the other models.  Stride 2: the 3x3 convolution is a nine-tap strided
+gather on the LDS-DMA GEMM (`Engine.conv3x3_s2`, `UZ_TAPS_CONV_S2`), its weight gradient the same gather in the
+LDS-DMA weight-gradient kernel; only its input gradient takes the dense route (dy between zeros, stride-1
+convolution).  The 1x1 skip convolution reads every second pixel (`Engine.subsample2`).
 """
 from __future__ import annotations
 
@@ -45,7 +46,7 @@ class ResidualConv(nn.Module):
             h, _ = eng.conv_bn_relu(h, cb[2], cb[3])                       # Conv -> BN -> ReLU, fused statistics
             s = x
         else:
-            h = eng.bn_act(eng.subsample2(eng.conv_plain(h, cb[2])), cb[3], relu=True)
+            h = eng.bn_act(eng.conv3x3_s2(h, cb[2]), cb[3], relu=True)
             s = eng.subsample2(x)
         h = eng.conv_plain(h, cb[5])
         s = eng.bn_act(eng.conv_plain(s, cs[0]), cs[1], relu=False)

@@ -192,6 +192,8 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         N, H, W = x.N, x.H, x.W
     elif taps_mode == L.TAPS_CONV_UP2:       # x is the half-resolution tensor
         N, H, W = x.N, 2 * x.H, 2 * x.W
+    elif taps_mode == L.TAPS_CONV_S2:        # Conv2d(k3, stride 2, padding 1): ceil(H / 2)
+        N, H, W = x.N, (x.H + 1) // 2, (x.W + 1) // 2
     else:
         N, H, W = x.N, x.H // 2, x.W // 2
     shuffle = store_mode == L.STORE_SHUFFLE2X2   # destination grid may be one row / column larger (zero pad)
@@ -218,7 +220,8 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         kname = f"conv3x3_direct_{_tname(x.dtype)}_bn{bn}" + ("_resident" if (bn == 64 and x.C == 8 * vec) else "")
         if taps_mode == L.TAPS_CONV_UP2:
             kname += "_up2"
-    elif ((ntaps == 1 and taps_mode == L.TAPS_CONV) or (ntaps == 4 and taps_mode == L.TAPS_GATHER2X2)) \
+    elif ((ntaps == 1 and taps_mode == L.TAPS_CONV) or (ntaps == 4 and taps_mode == L.TAPS_GATHER2X2)
+          or (ntaps == 9 and taps_mode == L.TAPS_CONV_S2)) \
             and d.Nout % vec == 0 and y.ld % vec == 0 and (store_mode == L.STORE_PLAIN or co % 64 == 0):
         kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
     else:
@@ -245,7 +248,7 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
     kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
     W_ = Lt.W
-    gather = taps_mode == L.TAPS_GATHER2X2 and ntaps == 4
+    gather = (taps_mode == L.TAPS_GATHER2X2 and ntaps == 4) or (taps_mode == L.TAPS_CONV_S2 and ntaps == 9)
     if (Lt.dtype == torch.bfloat16 and (taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) or gather)
             and ((ntaps == 9 and dil == 1) or ntaps == 1 or gather)
             and Lt.C % 8 == 0 and Rt.C % 8 == 0
@@ -256,7 +259,7 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
             t64 = Lt.C * ((Rt.C + 63) // 64) + Rt.C * ((Lt.C + 63) // 64)
             t128 = Lt.C * ((Rt.C + 127) // 128) + Rt.C * ((Lt.C + 127) // 128)
             big = t128 < t64
-        kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + ("_gather4" if gather else "_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
+        kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + (("_gather%d" % ntaps) if gather else "_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
     with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
         L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
