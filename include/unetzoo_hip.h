@@ -290,6 +290,12 @@ int uz_resize_bilinear_fwd(int dtype, const void* x, int ldx, long long x_img_st
 int uz_resize_bilinear_bwd(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi,
                            int C, void* dx, int lddx, long long dx_img_stride, int Ho, int Wo, int align_corners,
                            void* stream);
+/* Pixel-grid moves of NHWC tensors (row strides lds / ldd in elements, C channels):
+ *   mode 0 copy (a tensor into its slot of a concat buffer: UNet++'s dense skips, nested_unet.py:80-93),
+ *   mode 1 dst[h, w] = src[2h, 2w]  (Hd = ceil(Hs/2): what a stride-2 convolution keeps or reads),
+ *   mode 2 dst[h, w] = (h, w even) ? src[h/2, w/2] : 0  (Hs = ceil(Hd/2): that selection's gradient). */
+int uz_resample2(int dtype, const void* src, int lds, int N, int Hs, int Ws, int C, void* dst, int ldd, int Hd,
+                 int Wd, int mode, void* stream);
 /* out = g0 + g1 + unpool(gp): total gradient of `act` consumed directly (g0, g1 may be NULL) and through
  * MaxPool2d(2,2) (gp at (H/2, W/2), routed to the first maximum of each window as ATen does). */
 int uz_pool_grad_combine(int dtype, int N, int H, int W, int C, const void* act, int lda, const void* g0,

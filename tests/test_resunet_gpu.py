@@ -165,3 +165,26 @@ def test_conv3x3_stride2_forward_and_weight_gradient(dt, N, H, W, Cin, Cout):
     if fast:
         dw = ops.wgrad(act_from_nchw(dy.to(DEV), dt), xa, (Cout, Cin, 3, 3), ntaps=9, taps_mode=L.TAPS_CONV_S2)
         assert relerr(dw.cpu(), w.grad) < 2e-2
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 64), (1, 7, 5, 32), (3, 16, 16, 96)])
+def test_pixel_grid_moves(dt, N, H, W, C):
+    """uz_resample2: copy into a wider buffer's slot, keep every second pixel, spread between zeros"""
+    g = torch.Generator().manual_seed(85)
+    x = rnd(dt, torch.randn(N, C, H, W, generator=g))
+    xa = act_from_nchw(x.to(DEV), dt)
+    full = ops.new_act(N, H, W, 2 * C, dt, DEV)
+    full.buf.fill_(-3.0)
+    ops.resample2(xa, full.window(C, C), ops.RESAMPLE_COPY)
+    assert torch.equal(full.window(C, C).dense().cpu(), x) and bool((full.buf[:, :C] == -3.0).all())
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    sub = ops.new_act(N, Ho, Wo, C, dt, DEV)
+    ops.resample2(xa, sub, ops.RESAMPLE_SUBSAMPLE)
+    assert torch.equal(sub.dense().cpu(), x[:, :, ::2, ::2])
+    back = ops.new_act(N, H, W, C, dt, DEV)
+    back.buf.fill_(7.0)
+    ops.resample2(sub, back, ops.RESAMPLE_ZERO_INSERT)
+    want = torch.zeros_like(x)
+    want[:, :, ::2, ::2] = x[:, :, ::2, ::2]
+    assert torch.equal(back.dense().cpu(), want)

@@ -28,7 +28,7 @@ EXPORTS = (
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_colsum",
     "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd", "uz_attn_bwd_psi", "uz_attn_bwd_reduce",
     "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum_rows_f32", "uz_sum2x2",
-    "uz_bn_relu_add_apply", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_resize_bilinear_fwd", "uz_resize_bilinear_bwd",
+    "uz_bn_relu_add_apply", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_resize_bilinear_fwd", "uz_resize_bilinear_bwd", "uz_resample2",
     "uz_pool_grad_combine",
     "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
@@ -171,6 +171,7 @@ def load():
     lib.uz_bilinear_bwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, vp]
     lib.uz_resize_bilinear_fwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, ip, vp]
     lib.uz_resize_bilinear_bwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, ip, vp]
+    lib.uz_resample2.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, ip, ip, ip, vp]
     lib.uz_pool_grad_combine.argtypes = [ip, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, vp, ip, vp, ip, ip, vp]
     lib.uz_sideconv3x3_fwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, vp, vp, vp, ll, vp]
     lib.uz_sideconv3x3_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]

@@ -196,6 +196,47 @@ __global__ __launch_bounds__(256) void bilinear_bwd_wave_kernel(const ResizeArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pixel-grid moves of NHWC tensors, 16 bytes per thread:
+//   mode 0  copy        dst[n, h, w] = src[n, h, w]                      (a tensor into its slot of a concat buffer)
+//   mode 1  subsample   dst[n, h, w] = src[n, 2h, 2w]                    (what a stride-2 convolution keeps / reads)
+//   mode 2  zero-insert dst[n, h, w] = (h, w even) ? src[n, h/2, w/2] : 0 (its gradient, spread back between zeros)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void resample2_kernel(const T* __restrict__ src, int lds_, int Hs, int Ws,
+                                                        T* __restrict__ dst, int ldd, int N, int Hd, int Wd, int C, int mode) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int CC = C / VEC;
+  const long long total = (long long)N * Hd * Wd * CC;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % CC);
+    long long u = idx / CC;
+    const int w = (int)(u % Wd);
+    u /= Wd;
+    const int h = (int)(u % Hd);
+    const int n = (int)(u / Hd);
+    Vec16<T> v;
+    bool take = true;
+    int hs = h, ws = w;
+    if (mode == 1) {
+      hs = 2 * h;
+      ws = 2 * w;
+    } else if (mode == 2) {
+      take = !((h | w) & 1);
+      hs = h >> 1;
+      ws = w >> 1;
+    }
+    if (take) {
+      v = ld16(src + (((size_t)n * Hs + hs) * Ws + ws) * lds_ + cc * VEC);
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v.v[i] = (T)0.f;
+    }
+    st16(dst + (((size_t)n * Hd + h) * Wd + w) * ldd + cc * VEC, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // out = g0 + g1 + unpool(gp): the total gradient of a tensor `act` that was consumed directly
 // (g0, g1; either may be null) and through MaxPool2d(2,2) (gp; routed to the FIRST maximum of each
 // window in (0,0),(0,1),(1,0),(1,1) order, the element ATen records).
@@ -630,6 +671,28 @@ extern "C" int uz_resize_bilinear_bwd(int dtype, const void* g, int ldg, long lo
     else hipLaunchKernelGGL((bilinear_bwd_wave_kernel<float>), grid, block, 0, s, a);
   }
   UZ_LAUNCH_CHECK("uz_bilinear_bwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_resample2(int dtype, const void* src, int lds_, int N, int Hs, int Ws, int C, void* dst, int ldd,
+                            int Hd, int Wd, int mode, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_resample2: bad dtype");
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(src && dst && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && C % vec == 0, "uz_resample2: bad shape");
+  UZ_REQUIRE(lds_ % vec == 0 && lds_ >= C && ldd % vec == 0 && ldd >= C, "uz_resample2: bad leading dimension");
+  UZ_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "uz_resample2: pointers must be 16-byte aligned");
+  if (mode == 0) UZ_REQUIRE(Hs == Hd && Ws == Wd, "uz_resample2: copy needs equal grids");
+  else if (mode == 1) UZ_REQUIRE(Hd == (Hs + 1) / 2 && Wd == (Ws + 1) / 2, "uz_resample2: subsample needs Hd = ceil(Hs/2)");
+  else if (mode == 2) UZ_REQUIRE(Hs == (Hd + 1) / 2 && Ws == (Wd + 1) / 2, "uz_resample2: zero-insert needs Hs = ceil(Hd/2)");
+  else UZ_REQUIRE(false, "uz_resample2: bad mode %d", mode);
+  const long long total = (long long)N * Hd * Wd * (C / vec);
+  const dim3 grid(grid_cap(total, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UZ_BF16)
+    hipLaunchKernelGGL((resample2_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)src, lds_, Hs, Ws, (bf16_t*)dst, ldd, N, Hd, Wd, C, mode);
+  else
+    hipLaunchKernelGGL((resample2_kernel<float>), grid, block, 0, s, (const float*)src, lds_, Hs, Ws, (float*)dst, ldd, N, Hd, Wd, C, mode);
+  UZ_LAUNCH_CHECK("uz_resample2");
   return UZ_OK;
 }
 

@@ -488,9 +488,7 @@ class Engine:
                 gfull = None
                 if x.needs_grad or not fast_w:
                     gfull = self.new_act(N, H, W, Cout)        # dy between zeros: the dense stride-1 gradient routes
-                    gfull.buf.zero_()
-                    gfull.buf.view(N, H, W, gfull.ld)[:, ::2, ::2, gfull.off:gfull.off + Cout].copy_(
-                        g.buf.view(N, Ho, Wo, g.ld)[..., g.off:g.off + Cout])
+                    ops.resample2(g, gfull, ops.RESAMPLE_ZERO_INSERT)
                 if fast_w:
                     dw = ops.wgrad(g, x, tuple(conv.weight.shape), ntaps=9, taps_mode=L.TAPS_CONV_S2, out=self._dst(conv.weight))
                 else:
@@ -510,17 +508,14 @@ class Engine:
         N, H, W, C = x.N, x.H, x.W, x.C
         Ho, Wo = (H + 1) // 2, (W + 1) // 2
         out = self.new_act(N, Ho, Wo, C)
-        out.buf.view(N, Ho, Wo, out.ld)[..., out.off:out.off + C].copy_(
-            x.buf.view(N, H, W, x.ld)[:, ::2, ::2, x.off:x.off + C])
+        ops.resample2(x, out, ops.RESAMPLE_SUBSAMPLE)
         if self.record and x.needs_grad:
             def bwd():
                 g = self._total_grad(out)
                 if g is None:
                     return
                 dx = self.new_act(N, H, W, C)
-                dx.buf.zero_()
-                dx.buf.view(N, H, W, dx.ld)[:, ::2, ::2, dx.off:dx.off + C].copy_(
-                    g.buf.view(N, Ho, Wo, g.ld)[..., g.off:g.off + C])
+                ops.resample2(g, dx, ops.RESAMPLE_ZERO_INSERT)
                 x.add_grad(dx)
 
             self.tape.append(bwd)
@@ -817,7 +812,7 @@ class Engine:
         reference (UNet++'s dense skips, nested_unet.py:80-93) lives in the slot of its first consumer and is
         copied into the others; the slot's gradient flows back to `src` without a copy."""
         assert (src.N, src.H, src.W, src.C) == (dst.N, dst.H, dst.W, dst.C) and src.dtype == dst.dtype
-        dst.buf[:, dst.off:dst.off + dst.C].copy_(src.buf[:, src.off:src.off + src.C])
+        ops.resample2(src, dst, ops.RESAMPLE_COPY)
         if self.record and src.needs_grad:
             def bwd():
                 g = self._total_grad(dst)

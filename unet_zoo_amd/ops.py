@@ -502,6 +502,18 @@ def bilinear_bwd(g: Act, dx: Act, align_corners: bool = False) -> None:
                                                 int(align_corners), L.stream_ptr()), "uz_resize_bilinear_bwd")
 
 
+RESAMPLE_COPY, RESAMPLE_SUBSAMPLE, RESAMPLE_ZERO_INSERT = 0, 1, 2
+
+
+def resample2(src: Act, dst: Act, mode: int) -> None:
+    """copy / keep every second pixel / spread between zeros (uz_resample2)"""
+    assert src.N == dst.N and src.C == dst.C and src.dtype == dst.dtype
+    es = src.buf.element_size()
+    with _Timed("resample2", 0.0, es * (min(src.P, dst.P) + dst.P) * src.C):
+        L.check(L.load().uz_resample2(L.dtype_code(src.dtype), src.ptr(), src.ld, src.N, src.H, src.W, src.C, dst.ptr(),
+                                      dst.ld, dst.H, dst.W, mode, L.stream_ptr()), "uz_resample2")
+
+
 def bilinear_planes(src_ptr: int, src_img: int, hi: int, wi: int, dst_ptr: int, dst_img: int, ho: int, wo: int,
                     n: int, backward: bool = False) -> None:
     """fp32 single-channel planes (the logit maps); strides in elements.  backward: src is the
