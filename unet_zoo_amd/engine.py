@@ -183,14 +183,15 @@ class Engine:
         self._sums_used += 2 * C
         return s
 
-    @staticmethod
-    def _sum_grads(a: Act, limit: int) -> List[Act]:
-        """Return at most `limit` same-resolution gradient sources (pre-adding the rest)."""
+    def _sum_grads(self, a: Act, limit: int) -> List[Act]:
+        """Return at most `limit` same-resolution gradient sources (pre-adding the rest: a tensor read by many
+        concats, UNet++'s dense skips, collects one gradient per reader)."""
         gs = list(a.grads)
         while len(gs) > limit:
             x, y = gs.pop(), gs.pop()
-            t = (x.buf[:, x.off:x.off + x.C].float() + y.buf[:, y.off:y.off + y.C].float()).to(x.dtype)
-            gs.append(Act(t.contiguous(), 0, x.C, x.N, x.H, x.W))
+            t = self.new_act(x.N, x.H, x.W, x.C)
+            ops.add_acts(x, y, t)
+            gs.append(t)
         return gs
 
     # ------------------------------------------------------------------ blocks
