@@ -46,31 +46,20 @@ class NestedUNet(HipModule):
         self.pool = nn.MaxPool2d(2, 2)
         self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
 
-        self.conv0_0 = VGGBlock(in_channels, nb[0], nb[0])
-        self.conv1_0 = VGGBlock(nb[0], nb[1], nb[1])
-        self.conv2_0 = VGGBlock(nb[1], nb[2], nb[2])
-        self.conv3_0 = VGGBlock(nb[2], nb[3], nb[3])
-        self.conv4_0 = VGGBlock(nb[3], nb[4], nb[4])
-
-        self.conv0_1 = VGGBlock(nb[0] + nb[1], nb[0], nb[0])
-        self.conv1_1 = VGGBlock(nb[1] + nb[2], nb[1], nb[1])
-        self.conv2_1 = VGGBlock(nb[2] + nb[3], nb[2], nb[2])
-        self.conv3_1 = VGGBlock(nb[3] + nb[4], nb[3], nb[3])
-
-        self.conv0_2 = VGGBlock(nb[0] * 2 + nb[1], nb[0], nb[0])
-        self.conv1_2 = VGGBlock(nb[1] * 2 + nb[2], nb[1], nb[1])
-        self.conv2_2 = VGGBlock(nb[2] * 2 + nb[3], nb[2], nb[2])
-
-        self.conv0_3 = VGGBlock(nb[0] * 3 + nb[1], nb[0], nb[0])
-        self.conv1_3 = VGGBlock(nb[1] * 3 + nb[2], nb[1], nb[1])
-
-        self.conv0_4 = VGGBlock(nb[0] * 4 + nb[1], nb[0], nb[0])
+        # node x_{i,j}: row i (resolution H >> i), column j (number of dense skips it reads).  Registered column by
+        # column, rows ascending -- the reference's construction order (nested_unet.py:34-57), which fixes both the
+        # state_dict order and the order the default initialisers draw from the RNG.
+        for j in range(5):
+            for i in range(5 - j):
+                if j == 0:
+                    cin = in_channels if i == 0 else nb[i - 1]
+                else:
+                    cin = nb[i] * j + nb[i + 1]
+                setattr(self, f"conv{i}_{j}", VGGBlock(cin, nb[i], nb[i]))
 
         if self.deep_supervision:
-            self.final1 = nn.Conv2d(nb[0], num_classes, kernel_size=1)
-            self.final2 = nn.Conv2d(nb[0], num_classes, kernel_size=1)
-            self.final3 = nn.Conv2d(nb[0], num_classes, kernel_size=1)
-            self.final4 = nn.Conv2d(nb[0], num_classes, kernel_size=1)
+            for j in range(1, 5):
+                setattr(self, f"final{j}", nn.Conv2d(nb[0], num_classes, kernel_size=1))
         else:
             self.final = nn.Conv2d(nb[0], num_classes, kernel_size=1)
 
@@ -105,17 +94,12 @@ class NestedUNet(HipModule):
         # backbone column and the nested nodes in the reference's order (nested_unet.py:74-93)
         cur = eng.input_im2col(x)
         pooled = None
-        blocks0 = (self.conv0_0, self.conv1_0, self.conv2_0, self.conv3_0, self.conv4_0)
-        dense = {(0, 1): self.conv0_1, (1, 1): self.conv1_1, (2, 1): self.conv2_1, (3, 1): self.conv3_1,
-                 (0, 2): self.conv0_2, (1, 2): self.conv1_2, (2, 2): self.conv2_2,
-                 (0, 3): self.conv0_3, (1, 3): self.conv1_3, (0, 4): self.conv0_4}
         for i in range(5):
             src = cur if i == 0 else pooled
-            node[(i, 0)], pooled = blocks0[i].emit(eng, src, out=home(i, 0), pool=(i < 4), im2col=(i == 0))
+            node[(i, 0)], pooled = getattr(self, f"conv{i}_0").emit(eng, src, out=home(i, 0), pool=(i < 4), im2col=(i == 0))
             for r in range(i - 1, -1, -1):               # the anti-diagonal that x_{i,0} completes
                 j = i - r
-                node[(r, j)], _ = dense[(r, j)].emit(eng, gather(r, j), out=home(r, j))
+                node[(r, j)], _ = getattr(self, f"conv{r}_{j}").emit(eng, gather(r, j), out=home(r, j))
         if self.deep_supervision:
-            heads = (self.final1, self.final2, self.final3, self.final4)
-            return tuple(eng.out_conv(node[(0, j + 1)], heads[j]) for j in range(4))
+            return tuple(eng.out_conv(node[(0, j)], getattr(self, f"final{j}")) for j in range(1, 5))
         return (eng.out_conv(node[(0, 4)], self.final),)

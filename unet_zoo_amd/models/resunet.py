@@ -75,28 +75,21 @@ class ResUnet(HipModule):
             self.final_conv_out_channels = num_classes
         else:
             self.final_conv_out_channels = 1
-        self.filters = list(filters)
-        self.input_layer = nn.Sequential(
-            nn.Conv2d(in_channels, filters[0], kernel_size=3, padding=1),
-            nn.BatchNorm2d(filters[0]),
-            nn.ReLU(),
-            nn.Conv2d(filters[0], filters[0], kernel_size=3, padding=1),
-        )
-        self.input_skip = nn.Sequential(
-            nn.Conv2d(in_channels, filters[0], kernel_size=3, padding=1)
-        )
-        self.residual_conv_1 = ResidualConv(filters[0], filters[1], 2, 1)
-        self.residual_conv_2 = ResidualConv(filters[1], filters[2], 2, 1)
-        self.bridge = ResidualConv(filters[2], filters[3], 2, 1)
-        self.upsample_1 = UpsampleResUnet(filters[3], filters[2], 2, 2)
-        self.up_residual_conv1 = ResidualConv(filters[2] + filters[2], filters[2], 1, 1)
-        self.upsample_2 = UpsampleResUnet(filters[2], filters[1], 2, 2)
-        self.up_residual_conv2 = ResidualConv(filters[1] + filters[1], filters[1], 1, 1)
-        self.upsample_3 = UpsampleResUnet(filters[1], filters[0], 2, 2)
-        self.up_residual_conv3 = ResidualConv(filters[0] + filters[0], filters[0], 1, 1)
-        self.output_layer = nn.Sequential(
-            nn.Conv2d(filters[0], self.final_conv_out_channels, 1, 1),
-        )
+        self.filters = f = list(filters)
+
+        def conv3(cin, cout):
+            return nn.Conv2d(cin, cout, kernel_size=3, padding=1)
+
+        # registration order = the reference's (resunet.py:26-52): it fixes the state_dict order and the order the
+        # default initialisers draw from the RNG
+        self.input_layer = nn.Sequential(conv3(in_channels, f[0]), nn.BatchNorm2d(f[0]), nn.ReLU(), conv3(f[0], f[0]))
+        self.input_skip = nn.Sequential(conv3(in_channels, f[0]))
+        for name, cin, cout in (("residual_conv_1", f[0], f[1]), ("residual_conv_2", f[1], f[2]), ("bridge", f[2], f[3])):
+            setattr(self, name, ResidualConv(cin, cout, 2, 1))
+        for k, (cin, cout) in enumerate(((f[3], f[2]), (f[2], f[1]), (f[1], f[0])), 1):
+            setattr(self, f"upsample_{k}", UpsampleResUnet(cin, cout, 2, 2))
+            setattr(self, f"up_residual_conv{k}", ResidualConv(cout + cout, cout, 1, 1))
+        self.output_layer = nn.Sequential(nn.Conv2d(f[0], self.final_conv_out_channels, 1, 1))
 
     def emit(self, eng: Engine, x: torch.Tensor):
         N, _, H, W = x.shape
