@@ -24,7 +24,7 @@ struct GArgs {
   const float* bias;
   float* stats;
   unsigned xbytes, wbytes;
-  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m, Hout, Wout;
+  int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m, Hout, Wout, dil;
 };
 
 template <typename T> struct Mma3;
@@ -145,8 +145,13 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
         const int a_coff = (((lane & 7) ^ ((row >> 1) & 7)) * VEC) * ES;
         int a_pix = -1;
         if (m < a.M) {
-          if (a.mode == UZ_TAPS_CONV) {
+          if (a.mode == UZ_TAPS_CONV && a.ntaps == 1) {
             a_pix = m;
+          } else if (a.mode == UZ_TAPS_CONV) {   // 3x3, dilation d, zero padding d (REBNCONV, u2net.py:10-13)
+            const int img = m / HW, rem = m - img * HW;
+            const int h = rem / a.W, w = rem - h * a.W;
+            const int hh = h + (s2y - 1) * a.dil, ww = w + (s2x - 1) * a.dil;
+            if ((unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W) a_pix = (img * a.H + hh) * a.W + ww;
           } else {
             const int img = m / HW, rem = m - img * HW;
             const int h = rem / a.W, w = rem - h * a.W;
@@ -376,8 +381,13 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
 int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4, bk = 8 * vec;
   const bool conv1 = d->taps_mode == UZ_TAPS_CONV && d->ntaps == 1;
+  // dilated 3x3 (the direct kernel takes dilation 1; REBNCONV with dirate 2 / 4 / 8, u2net.py:10-13): nine taps at
+  // (h + (ty-1) d, w + (tx-1) d), zero outside.  Measured on the u2net step against the first-generation kernel with
+  // its 9-way tap split: 27.8 vs 29.1 ms taking every dilated layer here, 28.8 ms taking only the large ones.
+  const bool conv9 = d->taps_mode == UZ_TAPS_CONV && d->ntaps == 9 && d->dil > 1 && d->store_mode == UZ_STORE_PLAIN &&
+                     !(uz_tune_flags() & 0x20000000);
   const bool gath = (d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4) || (d->taps_mode == UZ_TAPS_CONV_S2 && d->ntaps == 9);
-  if (!conv1 && !gath) return 0;
+  if (!conv1 && !gath && !conv9) return 0;
   (void)bk;
   if (d->Cin % vec != 0 || d->Nout % vec != 0 || d->ldy % vec != 0) return 0;
   const long long pin = (long long)d->N * d->Hin * d->Win;
@@ -446,6 +456,7 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x
   a.mode = d->taps_mode;
   a.store = d->store_mode;
   a.Co = d->Co;
+  a.dil = d->dil;
   a.tiles_m = p.tiles_m;
   return d->dtype == UZ_BF16 ? gemm_launch_t<bf16_t>(p, a, s) : gemm_launch_t<float>(p, a, s);
 }

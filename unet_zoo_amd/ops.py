@@ -221,7 +221,8 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         if taps_mode == L.TAPS_CONV_UP2:
             kname += "_up2"
     elif ((ntaps == 1 and taps_mode == L.TAPS_CONV) or (ntaps == 4 and taps_mode == L.TAPS_GATHER2X2)
-          or (ntaps == 9 and taps_mode == L.TAPS_CONV_S2)) \
+          or (ntaps == 9 and taps_mode == L.TAPS_CONV_S2)
+          or (ntaps == 9 and taps_mode == L.TAPS_CONV and dil > 1 and store_mode == L.STORE_PLAIN)) \
             and d.Nout % vec == 0 and y.ld % vec == 0 and (store_mode == L.STORE_PLAIN or co % 64 == 0):
         kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
     else:
