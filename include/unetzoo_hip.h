@@ -433,6 +433,48 @@ int uz_clip_adamw(float* p, const float* g, float* m, float* v, long long n, flo
                   float beta2, float eps, float weight_decay, float max_norm, float* step, void* workspace,
                   void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * MISSFormer / MiT blocks (unet_zoo/models/missformer.py).  uz_mit.hip
+ * ------------------------------------------------------------------------------------------- */
+/* nn.GELU() (erf form) of MixFFN_skip (missformer.py:196,206) on a (P, C) token tensor */
+int uz_gelu_fwd(int dtype, const void* x, int ldx, void* y, int ldy, long long P, int C, void* stream);
+int uz_gelu_bwd(int dtype, const void* x, int ldx, const void* g, int ldg, void* dx, int lddx, long long P,
+                int C, void* stream);
+/* DWConv: Conv2d(C, C, 3, 1, 1, groups=C) on NHWC tokens (missformer.py:168-177).  w_taps = the (C,1,3,3)
+ * parameter transposed to [9][C] fp32.  flags bit 0: y += x (the "dwconv(fc1) + fc1" of MixFFN_skip :205),
+ * bit 1: flipped taps (the gradient with respect to the input; bias NULL). */
+int uz_dwconv3x3(int dtype, const void* x, int ldx, const float* w_taps, const float* bias, void* y, int ldy,
+                 int N, int H, int W, int C, int flags, void* stream);
+/* partial sums part[rows][10][C] (taps 0..8, then the bias) of d(loss)/d(w_taps), d(loss)/d(bias); rows from
+ * uz_dwconv3x3_wgrad_rows(); reduce over rows with uz_sum_rows_f32. */
+int uz_dwconv3x3_wgrad_rows(int dtype, int N, int H, int W, int C);
+int uz_dwconv3x3_wgrad(int dtype, const void* x, int ldx, const void* g, int ldg, float* part, int N, int H,
+                       int W, int C, void* stream);
+/* dst[n, ho, wo, (ty*r + tx)*C + c] = src[n, ho*r + ty, wo*r + tx, c]: the input of a Conv2d(C, C', r, r)
+ * (EfficientSelfAtten.sr, missformer.py:17-18,26-27) as GEMM rows; inverse != 0 scatters such rows back. */
+int uz_space_to_depth(int dtype, const void* src, int lds, void* dst, int ldd, int N, int Ho, int Wo, int C, int r,
+                      int inverse, void* stream);
+/* im2col of the NCHW fp32 input for OverlapPatchEmbeddings' Conv2d(3, 64, 7, 4, 3) (missformer.py:242,312):
+ * out[(n, ho, wo)][(kh*k + kw)*C + c] in the run dtype, zero beyond k*k*C up to Kpad. */
+int uz_im2col_nchw(int dtype, const float* x_nchw, int N, int C, int H, int W, int k, int stride, int pad, int Kpad,
+                   void* out, void* stream);
+/* softmax(q k^T * scale) v per (image, head), head_dim 64 (missformer.py:21-39, :113-128).
+ * q / out: (B*N, ld) token tensors, head h in columns [64h, 64h+64).  Key j of image b is row
+ * ((j / kps) * B + b) * kps + j % kps of k / v (kps = NK: one [B][NK] block; the bridge attends to four
+ * blocks of kps rows, missformer.py:81-100).  lse: B*heads*N floats kept for the backward. */
+typedef struct uz_sra_desc {
+  int dtype, B, N, NK, heads, head_dim, kps;
+  int ldq, ldk, ldv, ldo;
+  float scale;
+} uz_sra_desc;
+int uz_sra_fwd(const uz_sra_desc* d, const void* q, const void* k, const void* v, void* out, float* lse,
+               void* stream);
+long long uz_sra_bwd_workspace_bytes(const uz_sra_desc* d);
+/* go = d(loss)/d(out); dq like q; dkv: dense (B*NK, 2*heads*64) rows laid out like the kv tensor, dK in the
+ * first heads*64 columns and dV in the rest (k = kv, v = kv + heads*64, ldk = ldv = 2*heads*64). */
+int uz_sra_bwd(const uz_sra_desc* d, const void* q, const void* k, const void* v, const void* o, const float* lse,
+               const void* go, int ldgo, void* dq, int lddq, void* dkv, int lddkv, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

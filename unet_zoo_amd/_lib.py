@@ -39,6 +39,8 @@ EXPORTS = (
     "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_colstats_rows", "uz_colstats", "uz_cpb_fwd", "uz_cpb_bwd",
     "uz_cpb_fwd_batched", "uz_cpb_bwd_batched_workspace_bytes", "uz_cpb_bwd_batched",
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
+    "uz_gelu_fwd", "uz_gelu_bwd", "uz_dwconv3x3", "uz_dwconv3x3_wgrad_rows", "uz_dwconv3x3_wgrad",
+    "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
 )
 
 
@@ -65,6 +67,11 @@ class LnDesc(Structure):
 
 class WinAttnDesc(Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "B", "H", "W", "C", "heads", "ws", "shift", "Nt", "ldq", "ldo")] \
+        + [("scale", c_float)]
+
+
+class SraDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("dtype", "B", "N", "NK", "heads", "head_dim", "kps", "ldq", "ldk", "ldv", "ldo")] \
         + [("scale", c_float)]
 
 
@@ -179,6 +186,16 @@ def load():
     lib.uz_fuse1x1_fwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, vp, vp]
     lib.uz_fuse1x1_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip]
     lib.uz_fuse1x1_bwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, POINTER(c_void_p), ip, vp, vp, vp, vp, vp]
+    lib.uz_gelu_fwd.argtypes = [ip, vp, ip, vp, ip, ll, ip, vp]
+    lib.uz_gelu_bwd.argtypes = [ip, vp, ip, vp, ip, vp, ip, ll, ip, vp]
+    lib.uz_dwconv3x3.argtypes = [ip, vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
+    lib.uz_dwconv3x3_wgrad_rows.argtypes = [ip, ip, ip, ip, ip]
+    lib.uz_dwconv3x3_wgrad.argtypes = [ip, vp, ip, vp, ip, vp, ip, ip, ip, ip, vp]
+    lib.uz_space_to_depth.argtypes = [ip, vp, ip, vp, ip, ip, ip, ip, ip, ip, ip, vp]
+    lib.uz_im2col_nchw.argtypes = [ip, vp, ip, ip, ip, ip, ip, ip, ip, ip, vp, vp]
+    lib.uz_sra_fwd.argtypes = [POINTER(SraDesc), vp, vp, vp, vp, vp, vp]
+    lib.uz_sra_bwd_workspace_bytes.argtypes = [POINTER(SraDesc)]
+    lib.uz_sra_bwd.argtypes = [POINTER(SraDesc), vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, ip, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("uz_last_error_string",):

@@ -769,3 +769,100 @@ def cpb_bwd_batched(mods) -> None:
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=mods[0]["idx"].device)
     L.check(lib.uz_cpb_bwd_batched(arr, len(mods), ws.data_ptr(), L.stream_ptr()), "uz_cpb_bwd_batched")
 
+
+
+# ------------------------------------------------------------------------------------------------
+# MISSFormer / MiT blocks (uz_mit.hip)
+def gelu_fwd(x: Act, y: Act) -> None:
+    assert (x.P, x.C) == (y.P, y.C) and x.dtype == y.dtype
+    with _Timed("gelu_fwd", 0.0, 2 * x.buf.element_size() * x.P * x.C):
+        L.check(L.load().uz_gelu_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, y.ptr(), y.ld, x.P, x.C, L.stream_ptr()),
+                "uz_gelu_fwd")
+
+
+def gelu_bwd(x: Act, g: Act, dx: Act) -> None:
+    assert (x.P, x.C) == (g.P, g.C) == (dx.P, dx.C) and x.dtype == g.dtype == dx.dtype
+    with _Timed("gelu_bwd", 0.0, 3 * x.buf.element_size() * x.P * x.C):
+        L.check(L.load().uz_gelu_bwd(L.dtype_code(x.dtype), x.ptr(), x.ld, g.ptr(), g.ld, dx.ptr(), dx.ld, x.P, x.C,
+                                     L.stream_ptr()), "uz_gelu_bwd")
+
+
+def dwconv3x3(x: Act, w_taps: torch.Tensor, bias: Optional[torch.Tensor], y: Act, *, skip: bool = False,
+              flip: bool = False) -> None:
+    """depthwise 3x3 (padding 1): w_taps [9, C] fp32; skip adds x; flip = gradient wrt the input"""
+    assert (x.N, x.H, x.W, x.C) == (y.N, y.H, y.W, y.C) and x.dtype == y.dtype
+    assert w_taps.shape == (9, x.C) and w_taps.dtype == torch.float32 and w_taps.is_contiguous()
+    assert bias is None or (bias.numel() == x.C and bias.dtype == torch.float32)
+    with _Timed("dwconv3x3", 18.0 * x.P * x.C, 2 * x.buf.element_size() * x.P * x.C):
+        L.check(L.load().uz_dwconv3x3(L.dtype_code(x.dtype), x.ptr(), x.ld, w_taps.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None, y.ptr(), y.ld, x.N, x.H, x.W, x.C,
+                                      (1 if skip else 0) | (2 if flip else 0), L.stream_ptr()), "uz_dwconv3x3")
+
+
+def dwconv3x3_wgrad(x: Act, g: Act) -> torch.Tensor:
+    """[10, C] fp32: rows 0..8 the tap gradients, row 9 the bias gradient"""
+    assert (x.N, x.H, x.W, x.C) == (g.N, g.H, g.W, g.C) and x.dtype == g.dtype
+    lib = L.load()
+    code = L.dtype_code(x.dtype)
+    rows = L.check_count(lib.uz_dwconv3x3_wgrad_rows(code, x.N, x.H, x.W, x.C), "uz_dwconv3x3_wgrad_rows")
+    part = torch.empty(rows, 10 * x.C, dtype=torch.float32, device=x.buf.device)
+    out = torch.empty(10, x.C, dtype=torch.float32, device=x.buf.device)
+    with _Timed("dwconv3x3_wgrad", 20.0 * x.P * x.C, 2 * x.buf.element_size() * x.P * x.C):
+        L.check(lib.uz_dwconv3x3_wgrad(code, x.ptr(), x.ld, g.ptr(), g.ld, part.data_ptr(), x.N, x.H, x.W, x.C,
+                                       L.stream_ptr()), "uz_dwconv3x3_wgrad")
+    sum_rows_f32(part, rows, out)
+    return out
+
+
+def space_to_depth(src: Act, dst: Act, r: int, inverse: bool = False) -> None:
+    """dst[n, ho, wo, (ty*r+tx)*C + c] = src[n, ho*r+ty, wo*r+tx, c]; inverse: the scatter back"""
+    fine, coarse = (dst, src) if inverse else (src, dst)
+    assert fine.N == coarse.N and fine.H == coarse.H * r and fine.W == coarse.W * r and coarse.C == r * r * fine.C
+    assert src.dtype == dst.dtype
+    with _Timed("space_to_depth", 0.0, 2 * src.buf.element_size() * fine.P * fine.C):
+        L.check(L.load().uz_space_to_depth(L.dtype_code(src.dtype), src.ptr(), src.ld, dst.ptr(), dst.ld, coarse.N,
+                                           coarse.H, coarse.W, fine.C, r, 1 if inverse else 0, L.stream_ptr()),
+                "uz_space_to_depth")
+
+
+def im2col_nchw(x: torch.Tensor, k: int, stride: int, pad: int, kpad: int, dtype: torch.dtype) -> Act:
+    L.require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = new_act(N, Ho, Wo, kpad, dtype, x.device, needs_grad=False)
+    L.check(L.load().uz_im2col_nchw(L.dtype_code(dtype), x.data_ptr(), N, C, H, W, k, stride, pad, kpad,
+                                    out.buf.data_ptr(), L.stream_ptr()), "uz_im2col_nchw")
+    return out
+
+
+def _sra_desc(q: Act, kv: Act, B: int, heads: int, kps: int, scale: float, ldo: int) -> "L.SraDesc":
+    C = heads * 64
+    assert q.C == C and kv.C == 2 * C and q.P % B == 0 and kv.P % B == 0 and q.dtype == kv.dtype
+    return L.SraDesc(L.dtype_code(q.dtype), B, q.P // B, kv.P // B, heads, 64, kps, q.ld, kv.ld, kv.ld, ldo, scale)
+
+
+def sra_fwd(q: Act, kv: Act, out: Act, B: int, heads: int, kps: int, scale: float) -> torch.Tensor:
+    """out = softmax(q k^T * scale) v per (image, head); kv = [k | v] rows (see uz_sra_fwd); returns lse"""
+    d = _sra_desc(q, kv, B, heads, kps, scale, out.ld)
+    assert out.P == q.P and out.C == q.C and out.dtype == q.dtype
+    lse = torch.empty(B * heads * d.N, dtype=torch.float32, device=q.buf.device)
+    es = q.buf.element_size()
+    with _Timed("sra_fwd", 4.0 * B * d.N * d.NK * q.C, es * (2 * q.P * q.C + kv.P * kv.C)):
+        L.check(L.load().uz_sra_fwd(byref(d), q.ptr(), kv.ptr(), kv.ptr() + q.C * es, out.ptr(),
+                                    lse.data_ptr(), L.stream_ptr()), "uz_sra_fwd")
+    return lse
+
+
+def sra_bwd(q: Act, kv: Act, out: Act, lse: torch.Tensor, go: Act, dq: Act, dkv: Act, B: int, heads: int, kps: int,
+            scale: float) -> None:
+    d = _sra_desc(q, kv, B, heads, kps, scale, out.ld)
+    assert dkv.P == kv.P and dkv.C == kv.C and dkv.ld == kv.C and dkv.off == 0 and dq.P == q.P and dq.C == q.C
+    lib = L.load()
+    wsb = L.check_count(lib.uz_sra_bwd_workspace_bytes(byref(d)), "uz_sra_bwd_workspace_bytes")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=q.buf.device)
+    es = q.buf.element_size()
+    with _Timed("sra_bwd", 10.0 * B * d.N * d.NK * q.C, es * (4 * q.P * q.C + 2 * kv.P * kv.C) + wsb):
+        L.check(lib.uz_sra_bwd(byref(d), q.ptr(), kv.ptr(), kv.ptr() + q.C * es, out.ptr(), lse.data_ptr(),
+                               go.ptr(), go.ld, dq.ptr(), dq.ld, dkv.ptr(), dkv.ld, ws.data_ptr(), L.stream_ptr()),
+                "uz_sra_bwd")
