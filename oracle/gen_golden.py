@@ -61,7 +61,7 @@ def run_case(model, B, H, W, tag, full_logits: bool, name: str = "unet",
     loss = F.binary_cross_entropy_with_logits(logits, mask)
     model.zero_grad()
     loss.backward()
-    named = list(model.named_parameters())
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]   # missformer: unused norm2/norm3
     gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)).item()
     arrays = {}
     meta = {
@@ -138,7 +138,7 @@ def write_u2net():
     loss = sum(F.binary_cross_entropy_with_logits(v, mask) for v in outs.values())
     model.zero_grad()
     loss.backward()
-    named = list(model.named_parameters())
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]   # missformer: unused norm2/norm3
     gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in named)).item()
     arrays = {}
     meta = {"model": "u2net", "B": B, "H": H, "W": W, "input_sha256": sha(x), "mask_sha256": sha(mask),
@@ -209,6 +209,17 @@ def write_resunet():
     run_case(model, 2, 64, 64, "resunet_b2_64", full_logits=True, name="resunet",
              bn_keys=("input_layer.1", "residual_conv_1.conv_block.0", "residual_conv_2.conv_skip.1",
                       "bridge.conv_block.3", "up_residual_conv1.conv_block.0", "up_residual_conv3.conv_skip.1"))
+
+
+def write_missformer():
+    """missformer: seed-0 MISSFormer(num_classes=1, in_channels=3, image_size=128) — the class is built
+    directly because create_model() drops image_size (models/__init__.py:145-148) — B=2 3x128x128, every number kept;
+    the manifest pins the seed-0 construction at the default image_size=512 as well (same parameter shapes)."""
+    mods = load_reference("missformer")
+    torch.manual_seed(0)
+    model = mods["missformer"].MISSFormer(num_classes=1, in_channels=3, image_size=128)
+    write_manifest(model, "missformer")
+    run_case(model, 2, 128, 128, "missformer_b2_128", full_logits=True, name="missformer", bn_keys=())
 
 
 def _timm_stand_in():
@@ -322,6 +333,10 @@ def main():
         torch.set_num_threads(8)
         write_resunet()
         return
+    if sys.argv[1:] == ["missformer"]:
+        torch.set_num_threads(8)
+        write_missformer()
+        return
     if sys.argv[1:] == ["nested_unet"]:
         torch.set_num_threads(8)
         write_nested_unet()
@@ -356,6 +371,7 @@ def main():
     write_swin()
     write_nested_unet()
     write_resunet()
+    write_missformer()
 
 
 if __name__ == "__main__":

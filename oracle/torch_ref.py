@@ -460,6 +460,113 @@ FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2n
             "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward, "resunet": resunet_forward}
 
 
+# ------------------------------------------------------------------------------------------------
+# MISSFormer (unet_zoo/models/missformer.py), restated on a state dict
+def _mf_linear(x, sd: State, prefix: str):
+    return _q(F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias")))
+
+
+def _mf_attention(x, kv_src, sd: State, prefix: str, heads: int):
+    """softmax(q k^T / sqrt(d)) v then proj (missformer.py:21-39 / :113-128); kv_src = the (reduced) tokens"""
+    B, N, C = x.shape
+    d = C // heads
+    q = _mf_linear(x, sd, prefix + ".q").reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kv = _mf_linear(kv_src, sd, prefix + ".kv").reshape(B, -1, 2, heads, d).permute(2, 0, 3, 1, 4)
+    attn = ((q @ kv[0].transpose(-2, -1)) * d ** -0.5).softmax(dim=-1)
+    o = _q((attn @ kv[1]).transpose(1, 2).reshape(B, N, C))
+    return _mf_linear(o, sd, prefix + ".proj")
+
+
+def _mf_reduce(x, sd: State, conv: str, H: int, W: int, r: int):
+    """Conv2d(C, C, r, r) of the tokens viewed as a map (missformer.py:26-27, :88-96)"""
+    B, N, C = x.shape
+    m = x.permute(0, 2, 1).reshape(B, C, H, W)
+    return _q(F.conv2d(m, sd[conv + ".weight"], sd[conv + ".bias"], stride=r).flatten(2).permute(0, 2, 1))
+
+
+def _mf_mixffn_skip(x, sd: State, prefix: str, H: int, W: int):
+    """missformer.py:203-208"""
+    f = _mf_linear(x, sd, prefix + ".fc1")
+    B, N, C = f.shape
+    dw = F.conv2d(f.transpose(1, 2).reshape(B, C, H, W), sd[prefix + ".dwconv.dwconv.weight"],
+                  sd[prefix + ".dwconv.dwconv.bias"], padding=1, groups=C).flatten(2).transpose(1, 2)
+    a = _q(F.gelu(_q(_layer_norm(_q(dw + f), sd, prefix + ".norm1"))))
+    return _mf_linear(a, sd, prefix + ".fc2")
+
+
+def _mf_block(x, sd: State, prefix: str, H: int, W: int, heads: int, r: int):
+    """TransformerBlock (missformer.py:265-268)"""
+    n1 = _q(_layer_norm(x, sd, prefix + ".norm1"))
+    red = _q(_layer_norm(_mf_reduce(n1, sd, prefix + ".attn.sr", H, W, r), sd, prefix + ".attn.norm")) if r > 1 else n1
+    tx = _q(x + _mf_attention(n1, red, sd, prefix + ".attn", heads))
+    return _q(tx + _mf_mixffn_skip(_q(_layer_norm(tx, sd, prefix + ".norm2")), sd, prefix + ".mlp", H, W))
+
+
+def _mf_expand(x, sd: State, prefix: str, H: int, W: int, r: int):
+    """PatchExpand / FinalPatchExpand_X4 (missformer.py:522-537, :549-564)"""
+    y = _mf_linear(x, sd, prefix + ".expand")
+    B, _, Ce = y.shape
+    c = Ce // (r * r)
+    y = y.reshape(B, H, W, r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(B, H * r * W * r, c)
+    return _q(_layer_norm(y, sd, prefix + ".norm"))
+
+
+def missformer_forward(sd: State, x: torch.Tensor, training: bool, image_size: int = 512) -> torch.Tensor:
+    """MISSFormer.forward (missformer.py:922-938) for the default B1 / mix_skip configuration"""
+    dims, ratios, heads = [64, 128, 320, 512], [8, 4, 2, 1], [1, 2, 5, 8]
+    if x.shape[1] == 1:
+        x = x.repeat(1, 3, 1, 1)
+    B = x.shape[0]
+    feats, t = [], x
+    for i in range(4):                                              # MiT.forward (:336-368)
+        pe = f"backbone.patch_embed{i + 1}"
+        k, s, p = (7, 4, 3) if i == 0 else (3, 2, 1)
+        m = _q(F.conv2d(t if i == 0 else t_map, sd[pe + ".proj.weight"], sd[pe + ".proj.bias"], stride=s, padding=p))
+        H, W = m.shape[2:]
+        t = _q(_layer_norm(m.flatten(2).transpose(1, 2), sd, pe + ".norm"))
+        j = 0
+        while f"backbone.block{i + 1}.{j}.norm1.weight" in sd:
+            t = _mf_block(t, sd, f"backbone.block{i + 1}.{j}", H, W, heads[i], ratios[i])
+            j += 1
+        t = _q(_layer_norm(t, sd, f"backbone.norm{i + 1}"))
+        t_map = t.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+        feats.append((t, H, W))
+    res = [(image_size // s, image_size // s) for s in (4, 8, 16, 32)]
+    cuts = [0]
+    for h, w in res:
+        cuts.append(cuts[-1] + h * w)
+    tok = None
+    for li in range(1, 5):                                          # BridgeLayer_4.forward (:665-702)
+        bp = f"bridge.bridge_layer{li}"
+        if tok is None:
+            tok = torch.cat([_mf_linear(f, sd, f"{bp}.proj_c{i + 1}") for i, (f, _, _) in enumerate(feats)], -2)
+        n1 = _q(_layer_norm(tok, sd, bp + ".norm1"))
+        red = []
+        for i, ((h, w), r) in enumerate(zip(res, ratios)):          # Scale_reduce (:81-100)
+            sl = n1[:, cuts[i]:cuts[i + 1], :]
+            red.append(_mf_reduce(sl, sd, f"{bp}.attn.scale_reduce.sr_convs.{i}", h, w, r) if r > 1 else sl)
+        red = _q(_layer_norm(torch.cat(red, -2), sd, bp + ".attn.scale_reduce.norm"))
+        tx1 = _q(tok + _mf_attention(n1, red, sd, bp + ".attn", 1))
+        tx = _q(_layer_norm(tx1, sd, bp + ".norm2"))
+        ffn = torch.cat([_mf_mixffn_skip(tx[:, cuts[i]:cuts[i + 1], :], sd, f"{bp}.mixffn{i + 1}", h, w)
+                         for i, (h, w) in enumerate(res)], -2)
+        tok = _q(tx1 + ffn)
+    skips = [_mf_linear(tok[:, cuts[i]:cuts[i + 1], :], sd, f"bridge.proj_back_c{i + 1}") for i in range(4)]   # :801-811
+    t = skips[3]
+    for k in (3, 2, 1, 0):                                          # SegU_decoder.forward (:602-633)
+        dp, (h, w) = f"decoder_{k}", res[k]
+        if k < 3:
+            t = _mf_linear(torch.cat([t, skips[k]], -1), sd, dp + ".concat_linear")
+        t = _mf_block(t, sd, dp + ".layer_former_1", h, w, heads[k], ratios[k])
+        t = _mf_block(t, sd, dp + ".layer_former_2", h, w, heads[k], ratios[k])
+        t = _mf_expand(t, sd, dp + ".layer_up", h, w, 4 if k == 0 else 2)
+    S = res[0][0] * 4
+    return F.conv2d(t.reshape(B, S, S, -1).permute(0, 3, 1, 2), sd["decoder_0.last_layer.weight"], sd["decoder_0.last_layer.bias"])
+
+
+FORWARDS["missformer"] = missformer_forward
+
+
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":
     out = OrderedDict()
     for k, v in sd.items():

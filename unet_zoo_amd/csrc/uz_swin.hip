@@ -87,8 +87,8 @@ struct LnArgs {
   int Hin, Win;           // grid of x: (Ho, Wo) plain, (2 Ho, 2 Wo) merge, (Ho / r, Wo / r) expand
 };
 
-constexpr int LN_MAXIT = 6;     // 16-byte chunks per lane: C <= 64 * 6 * 4 = 1536 in fp32
-constexpr int LN_MAXC = 1536;   // PatchMerging of the 384-channel stage: LayerNorm(4 * 384)
+constexpr int LN_MAXIT = 8;     // 16-byte chunks per lane: C <= 64 * 8 * 4 = 2048 in fp32
+constexpr int LN_MAXC = 2048;   // MixFFN_skip of MISSFormer's 512-channel stage: LayerNorm(4 * 512)
 
 // Unsigned division by a launch constant (n < 2^31): q = umulhi(n, m) >> s with m = ceil(2^(32+s) / d),
 // exact for every 31-bit n (Granlund & Montgomery); d = 1 is m = 0.  A runtime integer division costs ~25
@@ -1943,12 +1943,14 @@ void ln_launch(const uz_ln_desc* d, dim3 grid, dim3 block, size_t shm, hipStream
     if (its == 1) { if (u == 8) UZ_LN(bf16_t, 1, 8); else UZ_LN_U(bf16_t, 1); }
     else if (its == 2) UZ_LN_U(bf16_t, 2);
     else if (its == 3) UZ_LN_U(bf16_t, 3);
-    else UZ_LN(bf16_t, 6, 1);
+    else if (its <= 6) UZ_LN(bf16_t, 6, 1);
+    else UZ_LN(bf16_t, 8, 1);
   } else {
     if (its == 1) { if (u == 8) UZ_LN(float, 1, 8); else UZ_LN_U(float, 1); }
     else if (its == 2) UZ_LN_U(float, 2);
     else if (its == 3) UZ_LN_U(float, 3);
-    else UZ_LN(float, 6, 1);
+    else if (its <= 6) UZ_LN(float, 6, 1);
+    else UZ_LN(float, 8, 1);
   }
 #undef UZ_LN_U
 #undef UZ_LN

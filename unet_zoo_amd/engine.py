@@ -696,6 +696,170 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    # ---- MISSFormer / MiT blocks (missformer.py) ------------------------------------
+    def conv_input(self, x: torch.Tensor, conv: nn.Conv2d) -> Act:
+        """A strided k x k convolution of the NCHW fp32 network input as im2col + GEMM
+        (OverlapPatchEmbeddings.proj = Conv2d(3, 64, 7, 4, 3), missformer.py:242,312)."""
+        L.require_cuda(x)
+        k, st, pd = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        assert conv.kernel_size == (k, k) and conv.stride == (st, st) and conv.padding == (pd, pd) and x.shape[1] == conv.in_channels
+        K = k * k * conv.in_channels
+        kpad = _round_up(K, self.bk)
+        p = ops.im2col_nchw(x.contiguous().float(), k, st, pd, kpad, self.dtype)
+        y = self.new_act(p.N, p.H, p.W, conv.out_channels)
+        ops.conv_igemm(p, self._pack(conv.weight, L.PACK_IM2COL, kpad), conv.bias.detach() if conv.bias is not None else None,
+                       y, ntaps=1)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                dwp = ops.wgrad(g, p, (conv.out_channels, kpad), ntaps=1)
+                dw = dwp[:, :K].reshape(conv.out_channels, k * k, conv.in_channels).permute(0, 2, 1)
+                self._give_grad(conv.weight, dw.reshape(conv.weight.shape).contiguous())
+
+            self.tape.append(bwd)
+        return y
+
+    def patch_conv(self, x: Act, conv: nn.Conv2d, out: Optional[Act] = None) -> Act:
+        """Conv2d(C, C', r, r) with stride r (EfficientSelfAtten.sr / Scale_reduce.sr_convs, missformer.py:17,76):
+        space-to-depth, then the token GEMM over r*r*C columns; its input gradient is the transposed GEMM
+        scattered back (= ConvTranspose2d with the same weight)."""
+        r = conv.kernel_size[0]
+        assert conv.kernel_size == conv.stride == (r, r) and conv.padding == (0, 0) and conv.in_channels == x.C
+        assert x.H % r == 0 and x.W % r == 0, f"map {x.H}x{x.W} is not a multiple of the reduction ratio {r}"
+        Cout, T = conv.out_channels, r * r
+        xs = self.new_act(x.N, x.H // r, x.W // r, T * x.C)
+        ops.space_to_depth(x, xs, r)
+        y = out if out is not None else self.new_act(xs.N, xs.H, xs.W, Cout)
+        ops.conv_igemm(xs, self._pack(conv.weight, L.PACK_CONV_FWD), conv.bias.detach() if conv.bias is not None else None,
+                       y, ntaps=1)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                dwp = ops.wgrad(g, xs, (Cout, T * x.C), ntaps=1)                      # [co][tap*Ci + ci]
+                self._give_grad(conv.weight, dwp.view(Cout, T, x.C).permute(0, 2, 1).reshape(conv.weight.shape).contiguous())
+                if x.needs_grad:
+                    dxs = self.new_act(xs.N, xs.H, xs.W, xs.C)
+                    ops.conv_igemm(g, self._pack(conv.weight, L.PACK_CONVT_FWD), None, dxs, ntaps=1)
+                    dx = self.new_act(x.N, x.H, x.W, x.C)
+                    ops.space_to_depth(dxs, dx, r, inverse=True)
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def gelu(self, x: Act) -> Act:
+        """nn.GELU() (missformer.py:196)"""
+        y = self.new_act(x.N, x.H, x.W, x.C)
+        ops.gelu_fwd(x, y)
+        if self.record and x.needs_grad:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                ops.gelu_bwd(x, g, dx)
+                x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def dwconv_skip(self, x: Act, conv: nn.Conv2d) -> Act:
+        """DWConv(x) + x: the depthwise 3x3 of MixFFN_skip with its skip (missformer.py:168-177, :204-205)"""
+        C = x.C
+        assert conv.groups == C == conv.in_channels == conv.out_channels and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+        wt = conv.weight.detach().reshape(C, 9).t().contiguous()      # [9][C]
+        y = self.new_act(x.N, x.H, x.W, C)
+        ops.dwconv3x3(x, wt, conv.bias.detach() if conv.bias is not None else None, y, skip=True)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                dwb = ops.dwconv3x3_wgrad(x, g)
+                self._give_grad(conv.weight, dwb[:9].t().reshape(conv.weight.shape).contiguous())
+                if conv.bias is not None:
+                    self._give_grad(conv.bias, dwb[9].contiguous())
+                if x.needs_grad:
+                    dx = self.new_act(x.N, x.H, x.W, C)
+                    ops.dwconv3x3(g, wt, None, dx, skip=True, flip=True)
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def sr_attention(self, q: Act, kv: Act, B: int, heads: int, kps: int, scale: float,
+                     segments: Optional[Sequence[Tuple[int, int]]] = None) -> Act:
+        """softmax(q k^T * scale) v per (image, head), head_dim 64 (missformer.py:30-36, :122-125).  `segments`:
+        (first row, queries per image) of the row blocks of q that attend to the same keys (the bridge's four
+        scales, each stored [B][n_s]); default: q is one [B][N] block."""
+        if segments is None:
+            segments = [(0, q.P // B)]
+        out = self.new_act(q.N, q.H, q.W, q.C)
+        lses = []
+        for r0, n in segments:
+            lses.append(ops.sra_fwd(q.rows(r0, B, 1, n), kv, out.rows(r0, B, 1, n), B, heads, kps, scale))
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                dq = self.new_act(q.N, q.H, q.W, q.C)
+                for (r0, n), lse in zip(segments, lses):
+                    dkv = self.new_act(kv.N, kv.H, kv.W, kv.C)
+                    ops.sra_bwd(q.rows(r0, B, 1, n), kv, out.rows(r0, B, 1, n), lse, g.rows(r0, B, 1, n),
+                                dq.rows(r0, B, 1, n), dkv, B, heads, kps, scale)
+                    kv.add_grad(dkv)
+                q.add_grad(dq)
+
+            self.tape.append(bwd)
+        return out
+
+    def new_rows(self, shapes: Sequence[Tuple[int, int, int]], C: int) -> Tuple[Act, List[Act]]:
+        """One token buffer holding a concat along the token axis (torch.cat(..., -2), missformer.py:98,681,699),
+        block s = an (N, H, W, C) tensor written in place by its producer."""
+        total = sum(n * h * w for n, h, w in shapes)
+        full = self.new_act(1, 1, total, C)
+        parts, r0 = [], 0
+        for n, h, w in shapes:
+            parts.append((full.rows(r0, n, h, w), r0))
+            r0 += n * h * w
+        full.rparts = parts
+        return full, [p for p, _ in parts]
+
+    def row_views(self, flat: Act, shapes: Sequence[Tuple[int, int, int]]) -> List[Act]:
+        """The row blocks of `flat` as tensors of their own (the slices tx[:, a:b, :] of missformer.py:86,689-692);
+        their gradients are gathered into one buffer for `flat`."""
+        views, r0s, r0 = [], [], 0
+        for n, h, w in shapes:
+            views.append(flat.rows(r0, n, h, w))
+            r0s.append(r0)
+            r0 += n * h * w
+        assert r0 == flat.P
+        if self.record and flat.needs_grad:
+            def bwd():
+                gs = [self._total_grad(v) for v in views]
+                if all(g is None for g in gs):
+                    return
+                gflat = self.new_act(flat.N, flat.H, flat.W, flat.C)
+                for v, g, a in zip(views, gs, r0s):
+                    dst = gflat.rows(a, v.N, v.H, v.W)
+                    if g is None:
+                        dst.buf.zero_()
+                    else:
+                        ops.resample2(g, dst, ops.RESAMPLE_COPY)
+                flat.add_grad(gflat)
+
+            self.tape.append(bwd)
+        return views
+
     def finish_forward(self) -> None:
         """End of the forward: `num_batches_tracked += 1` of every train-mode BatchNorm (batchnorm.py of torch,
         as `nn.BatchNorm2d.forward` does) in ONE multi-tensor launch instead of one 5 us kernel per layer."""

@@ -19,6 +19,7 @@ from .u2net import U2NET, U2NETP
 from .swin_unet_v2 import SwinTransformerSys
 from .nested_unet import NestedUNet
 from .resunet import ResUnet
+from .missformer import MISSFormer
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
@@ -31,7 +32,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'uctransnet': None,
     'multiresunet': None,
     'nested_unet': NestedUNet,
-    'missformer': None,
+    'missformer': MISSFormer,
     'vnet': None,
     'u2net': U2NET,
     'u2netp': U2NETP,
@@ -101,6 +102,11 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     elif name == 'resunet':
         # models/__init__.py:167-170
         args.update(in_channels=in_channels, num_classes=num_classes, filters=kwargs.pop('filters', [64, 128, 256, 512]))
+    elif name == 'missformer':
+        # models/__init__.py:145-148: `image_size` is popped above and NOT forwarded, so the reference always builds
+        # MISSFormer for its default 512x512 (missformer.py:868); mirrored.  `depth` is absorbed by **kwargs there.
+        # Build the class directly (`MISSFormer(image_size=...)`) for another input size.
+        args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
     elif name == 'nested_unet':
         # models/__init__.py:139-143: depth travels to the constructor (absorbed by **kwargs there)
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth,
@@ -115,4 +121,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'list_models', 'hip_models', 'get_model_config', 'create_model']

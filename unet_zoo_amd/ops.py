@@ -18,7 +18,7 @@ from . import _lib as L
 class Act:
     """NHWC activation: element (pixel p, channel c) at ``buf[p, off + c]``; ``buf`` is (P, ld)."""
 
-    __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "needs_grad", "colsums")
+    __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "rparts", "needs_grad", "colsums")
 
     def __init__(self, buf: torch.Tensor, off: int, C: int, N: int, H: int, W: int,
                  needs_grad: bool = True):
@@ -27,6 +27,7 @@ class Act:
         self.buf, self.off, self.C, self.N, self.H, self.W = buf, off, C, N, H, W
         self.grads: List["Act"] = []        # gradient contributions (same resolution as self)
         self.parts: Optional[Sequence["Act"]] = None  # set on the full view of a concat buffer
+        self.rparts: Optional[Sequence[tuple]] = None  # (part, first row): a token-concat whose producers wrote row blocks
         self.needs_grad = needs_grad
         # optional (partials [G, 2, Ctot], channel offset): per-channel sums of this tensor that its
         # producing kernel delivered for free (used for ConvTranspose2d bias gradients)
@@ -53,6 +54,10 @@ class Act:
             w.colsums = (self.colsums[0], self.colsums[1] + off)
         return w
 
+    def rows(self, r0: int, N: int, H: int, W: int) -> "Act":
+        """rows [r0, r0 + N*H*W) as an (N, H, W, C) tensor of their own (token-concats along dim -2)"""
+        return Act(self.buf[r0:r0 + N * H * W], self.off, self.C, N, H, W, self.needs_grad)
+
     def channel_sums(self) -> Optional[torch.Tensor]:
         """sum over pixels per channel (fp32) if the producer recorded partial sums, else None"""
         if self.colsums is None:
@@ -67,6 +72,9 @@ class Act:
             for part in self.parts:
                 part.add_grad(g.window(o, part.C))
                 o += part.C
+        elif self.rparts is not None:
+            for part, r0 in self.rparts:
+                part.add_grad(g.rows(r0, part.N, part.H, part.W))
         else:
             self.grads.append(g)
 
