@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet", "u2net", "swin_unet_v2", "nested_unet", "resunet"],
+    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet", "u2net", "swin_unet_v2", "nested_unet", "resunet", "missformer"],
                     help="unet = BASELINE configs[1] (the headline metric); attention_unet = configs[2] with --size 512; "
                          "u2net = configs[4] with --size 512 --batch 8; swin_unet_v2 = the second north-star model at "
                          "--size 256 (window 8) or configs[3] with --size 224 --batch 32 (window 7)")

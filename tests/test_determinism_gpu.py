@@ -19,7 +19,15 @@ CASES = [
     ("nested_unet", dict(), 4, 128, 128),
     ("resunet", dict(), 4, 128, 128),
     ("swin_unet_v2", dict(image_size=128, window_size=8, drop_path_rate=0.0), 4, 128, 128),
+    ("missformer", dict(image_size=128), 2, 128, 128),
 ]
+
+
+def _create(name, kw):
+    if name == "missformer":      # create_model drops image_size (always 512, as the reference): build the class
+        from unet_zoo_amd.models.missformer import MISSFormer
+        return MISSFormer(num_classes=1, in_channels=3, **kw)
+    return unet_zoo_amd.create_model(name, in_channels=3, num_classes=1, **kw)
 
 
 def _loss(out, mask):
@@ -47,6 +55,7 @@ FULL = [
     ("u2net", dict(), 4, 512, 512),
     ("nested_unet", dict(), 16, 256, 256),
     ("resunet", dict(), 16, 256, 256),
+    ("missformer", dict(image_size=512), 4, 512, 512),
 ]
 
 
@@ -63,7 +72,7 @@ def test_two_identical_train_steps_agree_bitwise(name, kw, B, H, W, dtype):
     runs = []
     for rep in range(3):
         torch.manual_seed(0)
-        m = unet_zoo_amd.create_model(name, in_channels=3, num_classes=1, **kw)
+        m = _create(name, kw)
         m.run_dtype = dtype
         m = m.to(DEV).train()
         out = m(x)

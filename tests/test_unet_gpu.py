@@ -225,7 +225,7 @@ def test_in_place_gradient_mode_matches_autograd_mode():
         assert (p.grad - r).abs().max() <= 1e-4 * scale + 1e-9
 
 
-@pytest.mark.parametrize("name", ["unet", "attention_unet", "u2netp", "nested_unet", "resunet", "swin_unet_v2"])
+@pytest.mark.parametrize("name", ["unet", "attention_unet", "u2netp", "nested_unet", "resunet", "swin_unet_v2", "missformer"])
 def test_phased_backward_equals_one_shot_backward(name):
     """graph.PhasedStep (bench.py's multi-GPU graph mode): the backward cut into phases, each
     phase's parameters laid out contiguously in one flat buffer, gives bit-identical gradients to the
@@ -233,7 +233,11 @@ def test_phased_backward_equals_one_shot_backward(name):
     from unet_zoo_amd.graph import PhasedStep
     torch.manual_seed(0)
     kw = dict(image_size=64, window_size=4, drop_path_rate=0.0) if name == "swin_unet_v2" else {}
-    m = unet_zoo_amd.create_model(name, **kw).to(DEV).train()
+    if name == "missformer":       # the registry always builds the 512x512 model (as the reference): take the class
+        from unet_zoo_amd.models.missformer import MISSFormer
+        m = MISSFormer(image_size=64).to(DEV).train()
+    else:
+        m = unet_zoo_amd.create_model(name, **kw).to(DEV).train()
     x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=4)
     x, mask = x.to(DEV), mask.to(DEV)
 
