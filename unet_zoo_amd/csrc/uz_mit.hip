@@ -158,21 +158,48 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     const long long u = seg / WS;
     const int h = (int)(u % H), n = (int)(u / H);
     const int w0 = ws * DWG_SEG, w1 = min(W, w0 + DWG_SEG);
-    for (int w = w0; w < w1; ++w) {
+    // sliding 3x3 window: columns a = w-1, b = w, c = w+1 of rows h-1, h, h+1; every step loads one new
+    // column (3 vectors) and one gradient vector instead of nine inputs
+    const T* xr[3];
+    bool rv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hh = h + r - 1;
+      rv[r] = (unsigned)hh < (unsigned)H;
+      xr[r] = x + ((size_t)n * H + (rv[r] ? hh : h)) * W * ldx + c0;
+    }
+    auto column = [&](float (&col)[3][VEC], int ww) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (rv[r] && (unsigned)ww < (unsigned)W) load_f(xr[r] + (size_t)ww * ldx, col[r]);
+        else
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) col[r][i] = 0.f;
+      }
+    };
+    const T* gr = g + ((size_t)n * H + h) * W * ldg + c0;
+    auto pixel = [&](const float (&a)[3][VEC], const float (&b)[3][VEC], float (&c)[3][VEC], int w) {
+      column(c, w + 1);
       float gv[VEC];
-      load_f(g + (((size_t)n * H + h) * W + w) * ldg + c0, gv);
+      load_f(gr + (size_t)w * ldg, gv);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[9][i] += gv[i];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
-          float xv[VEC];
-          load_f(x + (((size_t)n * H + hh) * W + ww) * ldx + c0, xv);
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[t][i] = fmaf(gv[i], xv[i], acc[t][i]);
+        for (int i = 0; i < VEC; ++i) {
+          acc[3 * r + 0][i] = fmaf(gv[i], a[r][i], acc[3 * r + 0][i]);
+          acc[3 * r + 1][i] = fmaf(gv[i], b[r][i], acc[3 * r + 1][i]);
+          acc[3 * r + 2][i] = fmaf(gv[i], c[r][i], acc[3 * r + 2][i]);
         }
-      }
+    };
+    float A[3][VEC], B[3][VEC], Cc[3][VEC];
+    column(A, w0 - 1);
+    column(B, w0);
+    for (int w = w0; w < w1; w += 3) {
+      pixel(A, B, Cc, w);
+      if (w + 1 < w1) pixel(B, Cc, A, w + 1);
+      if (w + 2 < w1) pixel(Cc, A, B, w + 2);
     }
   }
   if (ls < pr) {
