@@ -45,9 +45,16 @@ CAPTURE_MODE = "thread_local"
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
 
 
+_LOSS_IMPL = "hip"
+
+
 def model_loss(out, mask):
     """BCEWithLogits (scripts/train.py:135); u2net's dict of seven heads: their unit-weighted sum
-    (unet_zoo/utils/training_loop.py:24-32, 60-64)."""
+    (unet_zoo/utils/training_loop.py:24-32, 60-64).  --loss hip (default): loss, its gradient and the step's Dice
+    metric (training_loop.py:113-124) from uz_bce_dice, device scalars; --loss torch: F.binary_cross_entropy_with_logits."""
+    if _LOSS_IMPL == "hip":
+        from unet_zoo_amd.loss import loss_and_dice
+        return loss_and_dice(out, mask)[0]
     if isinstance(out, dict):
         total = None
         for v in out.values():
@@ -141,9 +148,13 @@ def main():
     ap.add_argument("--phases", type=int, default=5,
                     help="N>1 ranks, graph mode: number of backward phases (hipGraphs) whose gradient "
                          "all-reduce overlaps the next phase; 1 = one all-reduce after the whole backward")
+    ap.add_argument("--loss", default="hip", choices=["hip", "torch"],
+                    help="hip = BCEWithLogits + Dice + gradient in one kernel pass (unet_zoo_amd.loss); torch = F.binary_cross_entropy_with_logits")
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="eager steps with per-launch HIP events, run after the timed region")
     args = ap.parse_args()
+    global _LOSS_IMPL
+    _LOSS_IMPL = args.loss
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

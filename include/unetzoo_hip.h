@@ -346,6 +346,8 @@ typedef struct uz_ln_desc {
   int ldx, ldy, ldr, ldg, lddx; /* row strides (elements) of x, y, res, g (grad of y), dx */
   int mode, r;
   float eps;
+  int act; /* 0: none; 1: exact GELU applied to the result (MixFFN_skip's act(norm1(.)), missformer.py:206;
+              no residual / image scale; backward through uz_layernorm_act_bwd) */
 } uz_ln_desc;
 int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
                      const void* res, const float* image_scale, void* y, float* stats, void* stream);
@@ -355,6 +357,9 @@ int uz_layernorm_bwd_rows(const uz_ln_desc* d); /* rows of `partial`; <0 on erro
  * add the rows with uz_sum_rows().  The residual branch's gradient is g itself. */
 int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* stats,
                      const void* g, const float* image_scale, void* dx, float* partial, void* stream);
+/* the same for act = 1: g is the gradient of GELU(LayerNorm(x)); beta rebuilds the pre-activation */
+int uz_layernorm_act_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
+                         const float* stats, const void* g, void* dx, float* partial, void* stream);
 /* LayerNorm followed by a 1x1 head (FinalPatchExpand_X4's norm + the `output` convolution of swin_unet_v2,
  * swin_unet_v2.py:385, :690, :753) without materialising the normalised tensor: logits (N, K, Ho, Wo) fp32 =
  * b[k] + sum_c w[k][c] LN(x)[token][c] with x addressed as in uz_layernorm_fwd (d->ldy / ldr / ldg unused),
@@ -474,6 +479,17 @@ long long uz_sra_bwd_workspace_bytes(const uz_sra_desc* d);
  * first heads*64 columns and dV in the rest (k = kv, v = kv + heads*64, ldk = ldv = 2*heads*64). */
 int uz_sra_bwd(const uz_sra_desc* d, const void* q, const void* k, const void* v, const void* o, const float* lse,
                const void* go, int ldgo, void* dq, int lddq, void* dkv, int lddkv, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss and metric of the training step on the device.  uz_loss.hip
+ * out2[0] = BCEWithLogitsLoss(logits, target) with mean reduction (scripts/train.py:135, training_loop.py:113-119),
+ * out2[1] = dice_coefficient(logits, target) of the thresholded prediction (utils/metrics.py:7-24: sigmoid > 0.5,
+ * epsilon 1e-7, 1.0 for an empty union); dlogits (may be NULL) = d(loss)/d(logits) = (sigmoid(x) - t) / n.
+ * n fp32 elements each; two launches, fixed summation order, no host synchronisation (the reference reads
+ * loss.item() / dc.item() every step, training_loop.py:123-124). */
+long long uz_bce_dice_workspace_bytes(long long n);
+int uz_bce_dice(const float* logits, const float* target, long long n, float* dlogits, float* out2, void* workspace,
+                void* stream);
 
 #ifdef __cplusplus
 }

@@ -136,3 +136,26 @@ def test_spatial_reduction_attention_forward_backward(dt, B, N, NK, heads, nseg)
     assert relerr(untokens(dq), q.grad) < tol
     dkv_ref = kv.grad.reshape(B, nseg, kps, 2 * C).permute(1, 0, 2, 3).reshape(1, nseg * B * kps, 2 * C)
     assert relerr(untokens(dkv), dkv_ref) < tol
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C", [64, 256, 1280, 2048])
+def test_layernorm_with_gelu_forward_backward(dt, C):
+    """act(norm1(.)) of MixFFN_skip (missformer.py:206) as one kernel each way (uz_ln_desc.act = 1)"""
+    g = torch.Generator().manual_seed(10)
+    B, N = 2, 37
+    x = rnd(dt, torch.randn(B, N, C, generator=g) * 1.3 + 0.2).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.3).requires_grad_(True)
+    go = rnd(dt, torch.randn(B, N, C, generator=g))
+    ref = F.gelu(F.layer_norm(x, (C,), gamma, beta, 1e-5))
+    ref.backward(go)
+    xa, ga = tokens(x.detach(), dt), tokens(go, dt)
+    y, dx = ops.new_act(B, 1, N, C, dt, DEV), ops.new_act(B, 1, N, C, dt, DEV)
+    gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+    stats = ops.layernorm_fwd(xa, gd, bd, y, gelu=True)
+    dgam, dbet = ops.layernorm_bwd(xa, gd, stats, ga, dx, gelu_beta=bd)
+    tol = 5e-6 if dt == torch.float32 else 1e-2
+    assert relerr(untokens(y), ref.detach()) < tol
+    assert relerr(untokens(dx), x.grad) < (2e-5 if dt == torch.float32 else 2e-2)
+    assert relerr(dgam.cpu(), gamma.grad) < 2e-4 and relerr(dbet.cpu(), beta.grad) < 2e-4

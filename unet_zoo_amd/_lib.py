@@ -33,7 +33,7 @@ EXPORTS = (
     "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
     "uz_conv_igemm_workspace_bytes", "uz_conv_igemm_ws_grid_m", "uz_conv_igemm_ws",
-    "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd",
+    "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd", "uz_layernorm_act_bwd",
     "uz_ln_head_fwd", "uz_ln_head_bwd_workspace_bytes", "uz_ln_head_bwd", "uz_sum_rows_f32_ld",
     "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
     "uz_colsum_workspace_bytes", "uz_colsum_ws", "uz_colstats_rows", "uz_colstats", "uz_cpb_fwd", "uz_cpb_bwd",
@@ -41,6 +41,7 @@ EXPORTS = (
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
     "uz_gelu_fwd", "uz_gelu_bwd", "uz_dwconv3x3", "uz_dwconv3x3_wgrad_rows", "uz_dwconv3x3_wgrad",
     "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
+    "uz_bce_dice_workspace_bytes", "uz_bce_dice",
 )
 
 
@@ -62,7 +63,7 @@ class BnBwdDesc(Structure):
 
 class LnDesc(Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "N", "Ho", "Wo", "C", "ldx", "ldy", "ldr", "ldg", "lddx", "mode", "r")] \
-        + [("eps", c_float)]
+        + [("eps", c_float), ("act", c_int)]
 
 
 class WinAttnDesc(Structure):
@@ -123,6 +124,7 @@ def load():
     lib.uz_conv_igemm_ws.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     lib.uz_patchify.argtypes = [ip, vp, ip, ip, ip, ip, ip, ip, vp, vp]
     lib.uz_layernorm_fwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_layernorm_act_bwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_layernorm_bwd_rows.argtypes = [POINTER(LnDesc)]
     lib.uz_layernorm_bwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_ln_head_fwd.argtypes = [POINTER(LnDesc), vp, vp, vp, vp, vp, ip, vp, vp, vp]
@@ -186,6 +188,8 @@ def load():
     lib.uz_fuse1x1_fwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, vp, vp]
     lib.uz_fuse1x1_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip]
     lib.uz_fuse1x1_bwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, POINTER(c_void_p), ip, vp, vp, vp, vp, vp]
+    lib.uz_bce_dice_workspace_bytes.argtypes = [ll]
+    lib.uz_bce_dice.argtypes = [vp, vp, ll, vp, vp, vp, vp]
     lib.uz_gelu_fwd.argtypes = [ip, vp, ip, vp, ip, ll, ip, vp]
     lib.uz_gelu_bwd.argtypes = [ip, vp, ip, vp, ip, vp, ip, ll, ip, vp]
     lib.uz_dwconv3x3.argtypes = [ip, vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]

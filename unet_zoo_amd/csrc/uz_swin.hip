@@ -83,6 +83,7 @@ struct LnArgs {
   float* partial;     // bwd: [gridDim.x][2][C] sums of g*xhat (dgamma) and g (dbeta)
   int N, Ho, Wo, C, ldx, ldy, ldr, ldg, lddx, mode, r;
   float eps;
+  int act;                // 1: GELU applied to the result (ACT instantiations)
   FastDiv fWo, fHo, fr;   // token index -> (image, row, column) and the expand sub-position without v_rcp sequences
   int Hin, Win;           // grid of x: (Ho, Wo) plain, (2 Ho, 2 Wo) merge, (Ho / r, Wo / r) expand
 };
@@ -162,7 +163,31 @@ template <> __device__ __forceinline__ void unpack_f<bf16_t>(const uint4& r, flo
 // (twice the registers), which costs the occupancy that the loads in flight were meant to buy
 __device__ __forceinline__ void pin(uint4& r) { asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); }
 
-template <typename T, bool BWD, int MAXIT, int U>
+// GELU (erf form, nn.GELU(): MixFFN_skip's act(norm1(.)), missformer.py:206) and its derivative.  erf by
+// Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, below fp32 resolution of the products it enters): one v_exp, one
+// v_rcp and five FMAs; its e^(-z^2/2) is also the density the derivative needs.  libdevice's erff costs ~3x that
+// and made the fused LayerNorm kernels ALU-bound.
+__device__ __forceinline__ void ln_gelu_parts(float z, float* cdf, float* pdf) {
+  const float x = fabsf(z) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);
+  const float e = __expf(-x * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float er = copysignf(1.f - poly * e, z);
+  *cdf = 0.5f * (1.f + er);
+  *pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float ln_gelu(float z) {
+  float c, p;
+  ln_gelu_parts(z, &c, &p);
+  return z * c;
+}
+__device__ __forceinline__ float ln_dgelu(float z) {
+  float c, p;
+  ln_gelu_parts(z, &c, &p);
+  return c + z * p;
+}
+
+template <typename T, bool BWD, int MAXIT, int U, bool ACT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       gam[it][e] = cc < CC ? a.gamma[cc * VEC + e] : 0.f;
-      bet[it][e] = (!BWD && cc < CC) ? a.beta[cc * VEC + e] : 0.f;
+      bet[it][e] = ((!BWD || ACT) && cc < CC) ? a.beta[cc * VEC + e] : 0.f;
       ag[it][e] = ab[it][e] = 0.f;
     }
   }
@@ -261,6 +286,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
             for (int e = 0; e < VEC; ++e) {
               o[e] = f * ((v[it][e] - mu) * rs * gam[it][e] + bet[it][e]);
               if (second != nullptr) o[e] += rv[e];
+              if constexpr (ACT) o[e] = ln_gelu(o[e]);
             }
             store_f(y + (size_t)t[u] * a.ldy + cc * VEC, o);
           }
@@ -283,6 +309,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
             for (int e = 0; e < VEC; ++e) {
               gv[it][e] *= f;
               xh[it][e] = (xh[it][e] - mean[u]) * rstd[u];
+              if constexpr (ACT) gv[it][e] *= ln_dgelu(xh[it][e] * gam[it][e] + bet[it][e]);
               ag[it][e] += gv[it][e] * xh[it][e];
               ab[it][e] += gv[it][e];
               const float gg = gv[it][e] * gam[it][e];
@@ -1936,7 +1963,11 @@ int ln_grid(const uz_ln_desc* d, bool bwd) {
 template <bool BWD>
 void ln_launch(const uz_ln_desc* d, dim3 grid, dim3 block, size_t shm, hipStream_t st, const LnArgs& a, int lpt) {
   const int its = ln_its(d), u = ln_unroll(d, BWD);
-#define UZ_LN(T, I, U) hipLaunchKernelGGL((layernorm_kernel<T, BWD, I, U>), grid, block, shm, st, a, lpt)
+#define UZ_LN(T, I, U)                                                                                   \
+  do {                                                                                                   \
+    if (a.act) hipLaunchKernelGGL((layernorm_kernel<T, BWD, I, U, true>), grid, block, shm, st, a, lpt); \
+    else hipLaunchKernelGGL((layernorm_kernel<T, BWD, I, U, false>), grid, block, shm, st, a, lpt);      \
+  } while (0)
 #define UZ_LN_U(T, I) \
   do { if (u == 1) UZ_LN(T, I, 1); else if (u == 4) UZ_LN(T, I, 4); else UZ_LN(T, I, 2); } while (0)
   if (d->dtype == UZ_BF16) {
@@ -1982,7 +2013,8 @@ extern "C" int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float*
   LnArgs a{};
   a.x = x; a.y = y; a.res = res; a.gamma = gamma; a.beta = beta; a.sb = image_scale; a.stats = stats;
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
-  a.mode = d->mode; a.r = d->r; a.eps = d->eps;
+  a.mode = d->mode; a.r = d->r; a.eps = d->eps; a.act = d->act;
+  UZ_REQUIRE(d->act == 0 || (d->act == 1 && !res && !image_scale), "uz_layernorm_fwd: act = %d (GELU = 1 takes no residual / image scale)", d->act);
   ln_geometry(d, &a);
   const dim3 grid(ln_grid(d, false)), block(256);
   const int lpt = ln_lpt(d);
@@ -1997,25 +2029,38 @@ extern "C" int uz_layernorm_bwd_rows(const uz_ln_desc* d) {
   return ln_grid(d, true);
 }
 
-extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* stats,
-                                const void* g, const float* image_scale, void* dx, float* partial, void* stream) {
-  const int rc = ln_check("uz_layernorm_bwd", d);
+static int ln_bwd_common(const char* fn, const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
+                         const float* stats, const void* g, const float* image_scale, void* dx, float* partial,
+                         void* stream) {
+  const int rc = ln_check(fn, d);
   if (rc != UZ_OK) return rc;
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
-  UZ_REQUIRE(x && gamma && stats && g && dx && partial, "uz_layernorm_bwd: null pointer");
-  UZ_REQUIRE(d->ldg % vec == 0 && d->ldg >= d->C && d->lddx % vec == 0, "uz_layernorm_bwd: bad ldg / lddx");
+  UZ_REQUIRE(x && gamma && stats && g && dx && partial, "%s: null pointer", fn);
+  UZ_REQUIRE(d->ldg % vec == 0 && d->ldg >= d->C && d->lddx % vec == 0, "%s: bad ldg / lddx", fn);
   LnArgs a{};
-  a.x = x; a.g = g; a.dx = dx; a.gamma = gamma; a.sb = image_scale; a.stats = const_cast<float*>(stats);
+  a.x = x; a.g = g; a.dx = dx; a.gamma = gamma; a.beta = beta; a.sb = image_scale; a.stats = const_cast<float*>(stats);
   a.partial = partial;
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.C = d->C; a.ldx = d->ldx; a.ldg = d->ldg; a.lddx = d->lddx;
-  a.mode = d->mode; a.r = d->r; a.eps = d->eps;
+  a.mode = d->mode; a.r = d->r; a.eps = d->eps; a.act = d->act;
   ln_geometry(d, &a);
   const dim3 grid(ln_grid(d, true)), block(256);
   const int lpt = ln_lpt(d);
   const size_t shm = (size_t)4 * (64 / lpt) * 2 * d->C * sizeof(float);
   ln_launch<true>(d, grid, block, shm, (hipStream_t)stream, a, lpt);
-  UZ_LAUNCH_CHECK("uz_layernorm_bwd");
+  UZ_LAUNCH_CHECK(fn);
   return UZ_OK;
+}
+
+extern "C" int uz_layernorm_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* stats,
+                                const void* g, const float* image_scale, void* dx, float* partial, void* stream) {
+  UZ_REQUIRE(d && d->act == 0, "uz_layernorm_bwd: an activation needs beta: call uz_layernorm_act_bwd");
+  return ln_bwd_common("uz_layernorm_bwd", d, x, gamma, nullptr, stats, g, image_scale, dx, partial, stream);
+}
+
+extern "C" int uz_layernorm_act_bwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
+                                    const float* stats, const void* g, void* dx, float* partial, void* stream) {
+  UZ_REQUIRE(d && d->act == 1 && beta, "uz_layernorm_act_bwd: act must be 1 (GELU) and beta given");
+  return ln_bwd_common("uz_layernorm_act_bwd", d, x, gamma, beta, stats, g, nullptr, dx, partial, stream);
 }
 
 // ---- LayerNorm + 1x1 head --------------------------------------------------------------------------

@@ -634,7 +634,7 @@ class Engine:
         return y
 
     def layer_norm(self, x: Act, ln: nn.LayerNorm, *, out: Optional[Act] = None, mode: int = L.LN_PLAIN, r: int = 1,
-                   residual: Optional[Act] = None, image_scale: Optional[torch.Tensor] = None) -> Act:
+                   residual: Optional[Act] = None, image_scale: Optional[torch.Tensor] = None, gelu: bool = False) -> Act:
         """out = [residual +] [image_scale[b] *] LayerNorm(x); mode folds PatchMerging's gather+concat
         (LN_MERGE) or PatchExpand's rearrange (LN_EXPAND, factor r) into the addressing."""
         C = ln.normalized_shape[0]
@@ -650,7 +650,7 @@ class Engine:
         y = out if out is not None else self.new_act(*shape, C)
         assert (y.N, y.H, y.W, y.C) == (*shape, C)
         gamma, beta = ln.weight.detach(), ln.bias.detach()
-        stats = ops.layernorm_fwd(x, gamma, beta, y, mode=mode, r=r, eps=ln.eps, res=residual, image_scale=image_scale)
+        stats = ops.layernorm_fwd(x, gamma, beta, y, mode=mode, r=r, eps=ln.eps, res=residual, image_scale=image_scale, gelu=gelu)
         if self.record:
             def bwd():
                 g = self._total_grad(y)
@@ -661,7 +661,7 @@ class Engine:
                 dx = self.new_act(x.N, x.H, x.W, x.C)
                 dgam, dbet = ops.layernorm_bwd(x, gamma, stats, g, dx, mode=mode, r=r, eps=ln.eps,
                                                image_scale=image_scale, dgamma=self._dst(ln.weight),
-                                               dbeta=self._dst(ln.bias))
+                                               dbeta=self._dst(ln.bias), gelu_beta=beta if gelu else None)
                 self._give_grad(ln.weight, dgam)
                 self._give_grad(ln.bias, dbet)
                 if x.needs_grad:

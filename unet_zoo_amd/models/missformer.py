@@ -144,7 +144,7 @@ class MixFFN_skip(nn.Module):
 
     def emit(self, eng: Engine, x: Act, out: Optional[Act] = None) -> Act:
         f = eng.linear(x, self.fc1)
-        a = eng.gelu(eng.layer_norm(eng.dwconv_skip(f, self.dwconv.dwconv), self.norm1))
+        a = eng.layer_norm(eng.dwconv_skip(f, self.dwconv.dwconv), self.norm1, gelu=True)   # act(norm1(.)) in one kernel
         return eng.linear(a, self.fc2, out=out)
 
 

@@ -608,14 +608,17 @@ def patchify(x: torch.Tensor, patch: int, kpad: int, dtype: torch.dtype) -> Act:
     return out
 
 
-def _ln_desc(x: Act, N: int, Ho: int, Wo: int, C: int, mode: int, r: int, eps: float, ldy=0, ldr=0, ldg=0, lddx=0):
-    return L.LnDesc(L.dtype_code(x.dtype), N, Ho, Wo, C, x.ld, ldy, ldr, ldg, lddx, mode, r, eps)
+def _ln_desc(x: Act, N: int, Ho: int, Wo: int, C: int, mode: int, r: int, eps: float, ldy=0, ldr=0, ldg=0, lddx=0, act=0):
+    return L.LnDesc(L.dtype_code(x.dtype), N, Ho, Wo, C, x.ld, ldy, ldr, ldg, lddx, mode, r, eps, act)
 
 
 def layernorm_fwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, out: Act, *, mode: int = L.LN_PLAIN, r: int = 1,
-                  eps: float = 1e-5, res: Optional[Act] = None, image_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = [res +] [image_scale[b] *] LayerNorm(x rows addressed by `mode`); returns the (P, 2) mean/rstd"""
-    d = _ln_desc(x, out.N, out.H, out.W, out.C, mode, r, eps, ldy=out.ld, ldr=res.ld if res is not None else 0)
+                  eps: float = 1e-5, res: Optional[Act] = None, image_scale: Optional[torch.Tensor] = None,
+                  gelu: bool = False) -> torch.Tensor:
+    """out = [res +] [image_scale[b] *] LayerNorm(x rows addressed by `mode`), or GELU(LayerNorm(x)); returns the
+    (P, 2) mean/rstd"""
+    d = _ln_desc(x, out.N, out.H, out.W, out.C, mode, r, eps, ldy=out.ld, ldr=res.ld if res is not None else 0,
+                 act=1 if gelu else 0)
     stats = torch.empty((out.P, 2), dtype=torch.float32, device=x.buf.device)
     es = x.buf.element_size()
     with _Timed("layernorm_fwd", 0.0, es * out.P * out.C * (2 + (res is not None))):
@@ -627,16 +630,23 @@ def layernorm_fwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, out: Act, *, 
 
 def layernorm_bwd(x: Act, gamma: torch.Tensor, stats: torch.Tensor, g: Act, dx: Act, *, mode: int = L.LN_PLAIN,
                   r: int = 1, eps: float = 1e-5, image_scale: Optional[torch.Tensor] = None,
-                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None):
-    """returns (dgamma, dbeta) fp32 (written into the given tensors when passed); dx is written with x's addressing"""
+                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                  gelu_beta: Optional[torch.Tensor] = None):
+    """returns (dgamma, dbeta) fp32 (written into the given tensors when passed); dx is written with x's addressing.
+    gelu_beta: the forward was GELU(LayerNorm(x)) with this beta"""
     lib = L.load()
-    d = _ln_desc(x, g.N, g.H, g.W, g.C, mode, r, eps, ldg=g.ld, lddx=dx.ld)
+    d = _ln_desc(x, g.N, g.H, g.W, g.C, mode, r, eps, ldg=g.ld, lddx=dx.ld, act=0 if gelu_beta is None else 1)
     rows = L.check_count(lib.uz_layernorm_bwd_rows(byref(d)), "uz_layernorm_bwd_rows")
     part = torch.empty((rows, 2, g.C), dtype=torch.float32, device=x.buf.device)
     es = x.buf.element_size()
     with _Timed("layernorm_bwd", 0.0, es * g.P * g.C * 3):
-        L.check(lib.uz_layernorm_bwd(byref(d), x.ptr(), gamma.data_ptr(), stats.data_ptr(), g.ptr(), _p(image_scale),
-                                     dx.ptr(), part.data_ptr(), L.stream_ptr()), "uz_layernorm_bwd")
+        if gelu_beta is not None:
+            assert image_scale is None
+            L.check(lib.uz_layernorm_act_bwd(byref(d), x.ptr(), gamma.data_ptr(), gelu_beta.data_ptr(), stats.data_ptr(),
+                                             g.ptr(), dx.ptr(), part.data_ptr(), L.stream_ptr()), "uz_layernorm_act_bwd")
+        else:
+            L.check(lib.uz_layernorm_bwd(byref(d), x.ptr(), gamma.data_ptr(), stats.data_ptr(), g.ptr(), _p(image_scale),
+                                         dx.ptr(), part.data_ptr(), L.stream_ptr()), "uz_layernorm_bwd")
     if dgamma is None:
         dgamma = torch.empty(g.C, dtype=torch.float32, device=x.buf.device)
     if dbeta is None:
