@@ -42,3 +42,9 @@ case(16, 32, 192)
 case(16, 16, 384)
 case(16, 8, 768)
 case(16, 256, 96, L.LN_EXPAND, 4, res=False)
+if "--missformer" in sys.argv:   # the B=8 512x512 missformer sizes (stage-1 tokens, MixFFN width, bridge rows)
+    case(8, 128, 64, res=False)
+    case(8, 128, 256, res=False)
+    case(8, 64, 128, res=False)
+    case(8, 64, 512, res=False)
+    case(8, 32, 1280, res=False)

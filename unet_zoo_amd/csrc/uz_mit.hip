@@ -73,12 +73,16 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, int 
 // One thread: 8 consecutive output pixels of a row x one 16-byte channel chunk; the 3 x 10 input vectors it
 // needs are each loaded once.
 // ---------------------------------------------------------------------------------------------
+#ifndef DW_SW
+#define DW_SW 6    // pixels per thread; measured on the missformer step (SW, waves/SIMD): (8,1) 2.24 ms, (8,2) 2.03, (6,2) 1.86, (4,3) 4.2 (spills)
+#define DW_OCC 2
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wt,
+__global__ __launch_bounds__(256, DW_OCC) void dwconv3x3_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, T* __restrict__ y, int ldy,
                                                         int N, int H, int W, int C, int flags) {
   constexpr int VEC = ElemTraits<T>::VEC;
-  constexpr int SW = 8;
+  constexpr int SW = DW_SW;
   const int CC = C / VEC, WS = (W + SW - 1) / SW;
   const long long total = (long long)N * H * WS * CC;
   const bool skip = flags & 1, flip = flags & 2;
@@ -96,22 +100,39 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
 #pragma unroll
       for (int i = 0; i < VEC; ++i) wr[t][i] = wp[i];
     }
-    float acc[SW][VEC];
+    float bv[VEC], acc[SW][VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) bv[i] = 0.f;
+    if (bias != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VEC; i += 4) *reinterpret_cast<f32x4*>(bv + i) = *reinterpret_cast<const f32x4*>(bias + c0 + i);
+    }
 #pragma unroll
     for (int o = 0; o < SW; ++o)
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[o][i] = bias ? bias[c0 + i] : 0.f;
+      for (int i = 0; i < VEC; ++i) acc[o][i] = bv[i];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
+      __builtin_amdgcn_sched_barrier(0);   // one row's loads in flight at a time (three rows at once cost 320 VGPRs)
       const int hh = h + dy - 1;
-      if ((unsigned)hh >= (unsigned)H) continue;
-      const T* row = x + ((size_t)n * H + hh) * W * ldx + c0;
+      const bool rok = (unsigned)hh < (unsigned)H;
+      const T* row = x + ((size_t)n * H + (rok ? hh : h)) * W * ldx + c0;
+      // all ten loads of the row are issued before the first use: addresses are clamped into the row and the
+      // out-of-range vectors zeroed afterwards (a branch per load would serialise their latencies)
+      Vec16<T> raw[SW + 2];
 #pragma unroll
       for (int j = 0; j < SW + 2; ++j) {
         const int ww = ws * SW - 1 + j;
-        if ((unsigned)ww >= (unsigned)W) continue;
+        raw[j] = ld16(row + (size_t)min(max(ww, 0), W - 1) * ldx);
+      }
+#pragma unroll
+      for (int j = 0; j < SW + 2; ++j) {
+        const int ww = ws * SW - 1 + j;
+        const bool ok = rok && (unsigned)ww < (unsigned)W;
+        __builtin_amdgcn_sched_barrier(0);   // convert one packed vector at a time (all ten at once: +80 VGPRs)
         float v[VEC];
-        load_f(row + (size_t)ww * ldx, v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = ok ? (float)raw[j].v[i] : 0.f;
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
           const int o = j - tx;   // output pixel ws*SW + o reads input column (ws*SW + o) + tx - 1
@@ -168,16 +189,20 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
       rv[r] = (unsigned)hh < (unsigned)H;
       xr[r] = x + ((size_t)n * H + (rv[r] ? hh : h)) * W * ldx + c0;
     }
-    auto column = [&](float (&col)[3][VEC], int ww) {
+    auto column = [&](float (&col)[3][VEC], int ww) {   // clamped address + select: the three loads issue together
+      const bool cok = (unsigned)ww < (unsigned)W;
+      const size_t off = (size_t)min(max(ww, 0), W - 1) * ldx;
+      Vec16<T> raw[3];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (rv[r] && (unsigned)ww < (unsigned)W) load_f(xr[r] + (size_t)ww * ldx, col[r]);
-        else
+      for (int r = 0; r < 3; ++r) raw[r] = ld16(xr[r] + off);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) col[r][i] = 0.f;
-      }
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) col[r][i] = (rv[r] && cok) ? (float)raw[r].v[i] : 0.f;
     };
     const T* gr = g + ((size_t)n * H + h) * W * ldg + c0;
+    // (loading column w+2 and the next gradient one pixel ahead of their use was measured slower: 1.56 vs 1.45 ms
+    // per missformer step, 217 vs 182 VGPRs)
     auto pixel = [&](const float (&a)[3][VEC], const float (&b)[3][VEC], float (&c)[3][VEC], int w) {
       column(c, w + 1);
       float gv[VEC];
@@ -842,7 +867,7 @@ extern "C" int uz_dwconv3x3(int dtype, const void* x, int ldx, const float* w_ta
   const int vec = dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(x && w_taps && y && N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "uz_dwconv3x3: bad shape");
   UZ_REQUIRE(ldx % vec == 0 && ldy % vec == 0 && ldx >= C && ldy >= C && (flags & ~3) == 0, "uz_dwconv3x3: bad strides / flags");
-  const long long total = (long long)N * H * ((W + 7) / 8) * (C / vec);
+  const long long total = (long long)N * H * ((W + DW_SW - 1) / DW_SW) * (C / vec);
   const dim3 grid(grid_cap(total, 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16) hipLaunchKernelGGL((dwconv3x3_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, ldx, w_taps, bias, (bf16_t*)y, ldy, N, H, W, C, flags);
