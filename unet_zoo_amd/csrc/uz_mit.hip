@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256, DW_OCC) void dwconv3x3_kernel(const T* __restr
 // Weight / bias gradient of the depthwise convolution: part[row][10][C], taps 0..8 then the bias; a
 // workgroup is (channel chunks) x (pixel segments of 32 along a row); segments are summed in LDS in a
 // fixed order, rows by uz_sum_rows_f32.
-constexpr int DWG_SEG = 32;
+#ifndef DWG_SEG_PX
+#define DWG_SEG_PX 32
+#endif
+constexpr int DWG_SEG = DWG_SEG_PX;
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ g,
                                                               int ldg, float* __restrict__ part, int N, int H, int W,

@@ -9,7 +9,7 @@ Tokens are NHWC activations, so every `permute / reshape / flatten` between the 
   * LayerNorm, PatchExpand / FinalPatchExpand_X4 with the rearrange folded into the GEMM store / the LayerNorm
     addressing, and the last 1x1 convolution fused behind the final LayerNorm (the kernels of swin_unet_v2);
   * the attention softmax(q k^T / 8) v with head_dim 64 against the reduced keys on MFMA (`uz_sra_*`);
-  * MixFFN_skip: fc1 -> depthwise 3x3 + skip -> LayerNorm -> GELU -> fc2 (`uz_dwconv3x3`, `uz_gelu_*`).
+  * MixFFN_skip: fc1 -> depthwise 3x3 + skip (`uz_dwconv3x3`) -> LayerNorm with the GELU folded in -> fc2.
 
 The bridge's token concat over the four scales (`torch.cat([c1f, c2f, c3f, c4f], -2)`, :681) is ONE buffer stored
 scale-major — block s holds the (B, n_s, 64) tokens of scale s — so the per-token layers run once over all
