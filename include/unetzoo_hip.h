@@ -491,6 +491,19 @@ long long uz_bce_dice_workspace_bytes(long long n);
 int uz_bce_dice(const float* logits, const float* target, long long n, float* dlogits, float* out2, void* workspace,
                 void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bias gradients of a whole backward pass (or phase) in two launches.  uz_colsum.hip
+ * out_i[c] = sum_p x_i[p*ld + c] (fp32) for n tensors of the run dtype: what `uz_colsum_ws` computes for one
+ * nn.Linear / Conv2d bias (db = sum over tokens of the output gradient), for all of them at once; `items` is a
+ * HOST array, copied into the kernel arguments (80 tensors per launch pair).  Deterministic. */
+typedef struct uz_colsum_item {
+  const void* x; /* (P, ld) rows, C <= ld columns used */
+  float* out;    /* C floats */
+  int P, C, ld, reserved;
+} uz_colsum_item;
+long long uz_colsum_batched_workspace_bytes(int dtype, const uz_colsum_item* items, int n);
+int uz_colsum_batched(int dtype, const uz_colsum_item* items, int n, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,3 +159,29 @@ def test_layernorm_with_gelu_forward_backward(dt, C):
     assert relerr(untokens(y), ref.detach()) < tol
     assert relerr(untokens(dx), x.grad) < (2e-5 if dt == torch.float32 else 2e-2)
     assert relerr(dgam.cpu(), gamma.grad) < 2e-4 and relerr(dbet.cpu(), beta.grad) < 2e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_batched_column_sums(dt):
+    """uz_colsum_batched: the bias gradients of a backward range in two launches (more than one launch pair's worth
+    of tensors, ragged row counts, a channel window of a wider buffer)"""
+    g = torch.Generator().manual_seed(12)
+    shapes = [(1, 1, 7, 8), (2, 5, 9, 64), (1, 64, 64, 320), (3, 16, 16, 2048), (2, 128, 128, 64), (1, 3, 1, 24)] * 15
+    acts, outs, refs = [], [], []
+    for i, (N, H, W, C) in enumerate(shapes):
+        t = rnd(dt, torch.randn(N, C, H, W, generator=g))
+        a = act_from_nchw(t.to(DEV), dt)
+        if i % 4 == 1:                      # the middle window of a 3x wider buffer
+            wide = ops.new_act(N, H, W, 3 * C, dt, DEV)
+            wide.buf.normal_()
+            wide.buf[:, C:2 * C] = a.buf
+            a = wide.window(C, C)
+        acts.append(a)
+        outs.append(torch.full((C,), float("nan"), device=DEV))
+        refs.append(t.double().sum(dim=(0, 2, 3)))
+    ops.colsum_batched(list(zip(acts, outs)))
+    again = [torch.empty_like(o) for o in outs]
+    ops.colsum_batched(list(zip(acts, again)))
+    for o, o2, r in zip(outs, again, refs):
+        assert torch.equal(o, o2)
+        assert (o.double().cpu() - r).abs().max() <= 2e-5 * (r.abs().max() + 1.0)

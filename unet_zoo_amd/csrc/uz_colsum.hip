@@ -1,0 +1,177 @@
+// Bias gradients of a whole backward (phase) in two launches: out_i[c] = sum_p x_i[p][c] for up to 96 tensors per
+// launch pair.  A token model pays one column sum per nn.Linear / strided convolution with a bias (missformer: 160
+// per step, swin_unet_v2: 28); as separate two-stage reductions they are ~11 us of launch latency each.  The
+// descriptors travel by value in the kernel arguments (no table upload, capturable in a hipGraph); every tensor
+// keeps its own fixed partition into row blocks and a fixed summation order, so results are bitwise reproducible.
+#include "uz_common.h"
+
+namespace {
+
+constexpr int CSB_MAX = 80;   // items per launch pair: 80 x 48 B + header < the 4 KB kernel-argument limit
+
+struct CsItem {
+  const void* x;
+  float* out;
+  int P, C, ld, gx;     // gx: row blocks (partial rows) of this tensor
+  int ccb, gy;          // channel chunks per workgroup (power of two <= 64), chunk groups
+  int blk0, fin0;       // first workgroup of this item in the reduce / finalize launch
+  int ws0, pad_;        // first float of its partial rows
+};
+struct CsBatch {
+  CsItem it[CSB_MAX];
+  int n, pad_[3];
+};
+
+template <typename T> __device__ __forceinline__ void load_f(const T* p, float* f) {
+  const Vec16<T> v = ld16(p);
+#pragma unroll
+  for (int i = 0; i < ElemTraits<T>::VEC; ++i) f[i] = (float)v.v[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const CsBatch b, float* __restrict__ ws) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  __shared__ __attribute__((aligned(16))) float red[256 * VEC];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
+  const CsItem& it = b.it[i];
+  const int local = blockIdx.x - it.blk0;
+  const int bx = local % it.gx, by = local / it.gx;
+  const int ccb = it.ccb, pr = 256 / ccb;
+  const int cx = threadIdx.x % ccb, ry = threadIdx.x / ccb;
+  const int CC = it.C / VEC, cc = by * ccb + cx;
+  const bool cok = cc < CC;
+  const T* x = static_cast<const T*>(it.x) + (cok ? cc : 0) * VEC;
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  const long long stride = (long long)it.gx * pr;
+  for (long long p = (long long)bx * pr + ry; p < it.P; p += 4 * stride) {
+    // four rows in flight: clamped address + select, the loads issue together
+    Vec16<T> raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long q = p + k * stride;
+      raw[k] = ld16(x + (size_t)(q < it.P ? q : it.P - 1) * it.ld);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = cok && p + k * stride < it.P;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[e] += ok ? (float)raw[k].v[e] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[(ry * ccb + cx) * VEC + e] = s[e];
+  __syncthreads();
+  // thread (cx, e) adds the pr rows in order
+  for (int e = ry; e < VEC; e += pr) {
+    float t = 0.f;
+    for (int r = 0; r < pr; ++r) t += red[(r * ccb + cx) * VEC + e];
+    if (cok) ws[(size_t)it.ws0 + (size_t)bx * it.C + cc * VEC + e] = t;
+  }
+}
+
+// one workgroup per (item, 32 columns): 32 row groups x 32 columns, then a fixed sum over the groups
+__global__ __launch_bounds__(1024) void colsum_batched_finalize_kernel(const CsBatch b, const float* __restrict__ ws) {
+  __shared__ double sh[32][33];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].fin0) ++i;
+  const CsItem& it = b.it[i];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = (blockIdx.x - it.fin0) * 32 + el;
+  double s = 0.0;
+  if (c < it.C)
+    for (int r = g; r < it.gx; r += 32) s += (double)ws[(size_t)it.ws0 + (size_t)r * it.C + c];
+  sh[g][el] = s;
+  __syncthreads();
+  if (g == 0 && c < it.C) {
+    double t = 0.0;
+    for (int r = 0; r < 32; ++r) t += sh[r][el];
+    it.out[c] = (float)t;
+  }
+}
+
+// fills the launch geometry of items[first, first + n); returns the number of partial floats
+long long cs_plan(int dtype, const uz_colsum_item* items, int n, CsBatch* b, int* blocks, int* fblocks) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  long long ws = 0;
+  int blk = 0, fin = 0;
+  b->n = n;
+  for (int i = 0; i < n; ++i) {
+    CsItem& it = b->it[i];
+    it.x = items[i].x;
+    it.out = items[i].out;
+    it.P = items[i].P;
+    it.C = items[i].C;
+    it.ld = items[i].ld;
+    const int CC = it.C / vec;
+    int ccb = 1;
+    while (ccb < CC && ccb < 64) ccb <<= 1;
+    it.ccb = ccb;
+    it.gy = (CC + ccb - 1) / ccb;
+    const int pr = 256 / ccb;
+    long long gx = ((long long)it.P + (long long)pr * 16 - 1) / ((long long)pr * 16);   // >= 16 rows per thread
+    const long long cap = 2LL * UZ_NUM_CU / it.gy > 0 ? 2LL * UZ_NUM_CU / it.gy : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    it.gx = (int)gx;
+    it.blk0 = blk;
+    it.fin0 = fin;
+    it.ws0 = (int)ws;
+    it.pad_ = 0;
+    blk += it.gx * it.gy;
+    fin += (it.C + 31) / 32;
+    ws += gx * it.C;
+  }
+  *blocks = blk;
+  *fblocks = fin;
+  return ws;
+}
+
+int cs_check(const char* fn, int dtype, const uz_colsum_item* items, int n) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "%s: bad dtype", fn);
+  UZ_REQUIRE(items != nullptr && n > 0, "%s: no items", fn);
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  for (int i = 0; i < n; ++i)
+    UZ_REQUIRE(items[i].x && items[i].out && items[i].P > 0 && items[i].C > 0 && items[i].C % vec == 0 &&
+                   items[i].ld % vec == 0 && items[i].ld >= items[i].C && ((uintptr_t)items[i].x & 15) == 0,
+               "%s: bad item %d (P=%d C=%d ld=%d)", fn, i, items[i].P, items[i].C, items[i].ld);
+  return UZ_OK;
+}
+
+}  // namespace
+
+extern "C" long long uz_colsum_batched_workspace_bytes(int dtype, const uz_colsum_item* items, int n) {
+  if (cs_check("uz_colsum_batched_workspace_bytes", dtype, items, n) != UZ_OK) return -1;
+  long long most = 0;
+  for (int first = 0; first < n; first += CSB_MAX) {
+    CsBatch b;
+    int blocks, fblocks;
+    const long long w = cs_plan(dtype, items + first, n - first < CSB_MAX ? n - first : CSB_MAX, &b, &blocks, &fblocks);
+    if (w >= (1LL << 31)) {
+      uz_set_error("uz_colsum_batched_workspace_bytes: partial rows exceed 2^31 floats");
+      return -1;
+    }
+    most = w > most ? w : most;
+  }
+  return most * (long long)sizeof(float);
+}
+
+extern "C" int uz_colsum_batched(int dtype, const uz_colsum_item* items, int n, void* workspace, void* stream) {
+  const int rc = cs_check("uz_colsum_batched", dtype, items, n);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(workspace != nullptr, "uz_colsum_batched: null workspace");
+  hipStream_t s = (hipStream_t)stream;
+  for (int first = 0; first < n; first += CSB_MAX) {   // launch pairs run in order on the stream: the workspace is reused
+    CsBatch b;
+    int blocks, fblocks;
+    cs_plan(dtype, items + first, n - first < CSB_MAX ? n - first : CSB_MAX, &b, &blocks, &fblocks);
+    if (dtype == UZ_BF16) hipLaunchKernelGGL((colsum_batched_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, b, (float*)workspace);
+    else hipLaunchKernelGGL((colsum_batched_kernel<float>), dim3(blocks), dim3(256), 0, s, b, (float*)workspace);
+    UZ_LAUNCH_CHECK("uz_colsum_batched");
+    hipLaunchKernelGGL(colsum_batched_finalize_kernel, dim3(fblocks), dim3(1024), 0, s, b, (const float*)workspace);
+    UZ_LAUNCH_CHECK("uz_colsum_batched(finalize)");
+  }
+  return UZ_OK;
+}

@@ -128,6 +128,7 @@ class Engine:
         self._heads: List[Tuple[Callable[..., None], int]] = []   # (backward fn, number of outputs)
         # (tape position, parameter) in the order gradients are produced; position len(tape) = heads
         self.grad_log: List[Tuple[int, nn.Parameter]] = []
+        self._pending_colsums: List[Tuple[int, nn.Parameter, Act]] = []   # bias gradients of the running backward range
         self._cpb: Dict[nn.Module, dict] = {}     # position_biases(): WindowAttention module -> batched entry
         self._bn_counters: List[torch.Tensor] = []  # num_batches_tracked of the train-mode BatchNorms seen
         self._cur_entry = -1
@@ -171,6 +172,24 @@ class Engine:
             self.param_grads[p] = g
         if self.grad_sink is not None:
             self.grad_sink(p, self.param_grads[p])
+
+    def _bias_grad(self, p: nn.Parameter, g: Act) -> None:
+        """d(loss)/d(bias) = column sums of the output gradient g: collected and computed for the whole backward
+        range in two launches (uz_colsum_batched) when backward_range() ends; g stays alive until then."""
+        self._pending_colsums.append((self._cur_entry, p, g))
+
+    def _flush_colsums(self) -> None:
+        pend, self._pending_colsums = self._pending_colsums, []
+        if not pend:
+            return
+        outs = []
+        for _, p, g in pend:
+            dst = self._dst(p)
+            outs.append(dst if dst is not None else torch.empty(g.C, dtype=torch.float32, device=self.device))
+        ops.colsum_batched([(g, o) for (_, _, g), o in zip(pend, outs)])
+        for (entry, p, _), o in zip(pend, outs):
+            self._cur_entry = entry          # the gradient belongs to the tape entry that produced g (PhasedStep.plan)
+            self._give_grad(p, o)
 
     def _pack(self, p: nn.Parameter, mode: int, kpad: int = 0) -> torch.Tensor:
         return self._cache.get(p, mode, kpad, self.dtype)
@@ -448,7 +467,7 @@ class Engine:
                 if g is None:
                     return
                 if conv.bias is not None:
-                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                    self._bias_grad(conv.bias, g)
                 if im2col:
                     dwp = ops.wgrad(g, x, (Cout, x.C), ntaps=1)
                     cin = conv.in_channels
@@ -483,7 +502,7 @@ class Engine:
                 if g is None:
                     return
                 if conv.bias is not None:
-                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                    self._bias_grad(conv.bias, g)
                 fast_w = self.dtype == torch.bfloat16 and (Wo in (16, 32) or (Wo >= 64 and Wo % 64 == 0)) \
                     and Ho % (64 // min(Wo, 64)) == 0
                 gfull = None
@@ -598,7 +617,7 @@ class Engine:
                 if g is None:
                     return
                 if lin.bias is not None:
-                    self._give_grad(lin.bias, ops.colsum(g, self._dst(lin.bias)))
+                    self._bias_grad(lin.bias, g)
                 self._give_grad(lin.weight, ops.wgrad(g, x, tuple(lin.weight.shape), ntaps=1,
                                                       out=self._dst(lin.weight)))
                 if x.needs_grad:
@@ -688,7 +707,7 @@ class Engine:
                 if g is None:
                     return
                 if conv.bias is not None:
-                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                    self._bias_grad(conv.bias, g)
                 dwp = ops.wgrad(g, p, (conv.out_channels, kpad), ntaps=1)
                 dw = dwp[:, :K].reshape(conv.out_channels, ps * ps, conv.in_channels).permute(0, 2, 1)
                 self._give_grad(conv.weight, dw.reshape(conv.weight.shape).contiguous())
@@ -715,7 +734,7 @@ class Engine:
                 if g is None:
                     return
                 if conv.bias is not None:
-                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                    self._bias_grad(conv.bias, g)
                 dwp = ops.wgrad(g, p, (conv.out_channels, kpad), ntaps=1)
                 dw = dwp[:, :K].reshape(conv.out_channels, k * k, conv.in_channels).permute(0, 2, 1)
                 self._give_grad(conv.weight, dw.reshape(conv.weight.shape).contiguous())
@@ -742,7 +761,7 @@ class Engine:
                 if g is None:
                     return
                 if conv.bias is not None:
-                    self._give_grad(conv.bias, ops.colsum(g, self._dst(conv.bias)))
+                    self._bias_grad(conv.bias, g)
                 dwp = ops.wgrad(g, xs, (Cout, T * x.C), ntaps=1)                      # [co][tap*Ci + ci]
                 self._give_grad(conv.weight, dwp.view(Cout, T, x.C).permute(0, 2, 1).reshape(conv.weight.shape).contiguous())
                 if x.needs_grad:
@@ -1146,4 +1165,5 @@ class Engine:
         for i in range(hi - 1, lo - 1, -1):
             self._cur_entry = i
             self.tape[i]()
+        self._flush_colsums()
         self._cur_entry = -1

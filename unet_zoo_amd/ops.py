@@ -408,6 +408,27 @@ def colsum(x: Act, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     return out
 
 
+def colsum_batched(pairs: Sequence) -> None:
+    """out[c] = sum over the tokens of x[:, c] for every (x: Act, out: fp32 tensor of x.C) pair, all tensors of one
+    run dtype per call group: two launches per 80 tensors (uz_colsum_batched)"""
+    by_dtype = {}
+    for x, out in pairs:
+        assert out.numel() == x.C and out.dtype == torch.float32 and out.is_contiguous()
+        by_dtype.setdefault(x.dtype, []).append((x, out))
+    lib = L.load()
+    for dt, group in by_dtype.items():
+        arr = (L.ColsumItem * len(group))()
+        nbytes = 0.0
+        for i, (x, out) in enumerate(group):
+            arr[i] = L.ColsumItem(x.ptr(), out.data_ptr(), x.P, x.C, x.ld, 0)
+            nbytes += x.buf.element_size() * x.P * x.C
+        code = L.dtype_code(dt)
+        wsb = L.check_count(lib.uz_colsum_batched_workspace_bytes(code, arr, len(group)), "uz_colsum_batched_workspace_bytes")
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=group[0][0].buf.device)
+        with _Timed("colsum_batched", 0.0, nbytes):
+            L.check(lib.uz_colsum_batched(code, arr, len(group), ws.data_ptr(), L.stream_ptr()), "uz_colsum_batched")
+
+
 # ------------------------------------------------------------------------------------------------
 # attention gate (AttentionBlock, attention_unet.py:34-40) and nearest-upsample backward
 def sum_rows(partial: torch.Tensor, rows: int, n: int) -> torch.Tensor:
