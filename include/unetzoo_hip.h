@@ -501,6 +501,15 @@ typedef struct uz_colsum_item {
   float* out;    /* C floats */
   int P, C, ld, reserved;
 } uz_colsum_item;
+/* uz_sum_rows_f32 for n partial buffers at once (the parameter gradients that kernels leave as per-workgroup rows:
+ * LayerNorm dgamma | dbeta, depthwise weight gradients): out0[e] / out1[e - n0] = sum_r partial[r*n + e]. */
+typedef struct uz_sum_rows_item {
+  const float* partial;
+  float* out0;
+  float* out1; /* may be NULL when n0 == n */
+  int rows, n, n0, reserved;
+} uz_sum_rows_item;
+int uz_sum_rows_f32_batched(const uz_sum_rows_item* items, int n, void* stream);
 long long uz_colsum_batched_workspace_bytes(int dtype, const uz_colsum_item* items, int n);
 int uz_colsum_batched(int dtype, const uz_colsum_item* items, int n, void* workspace, void* stream);
 

@@ -41,7 +41,7 @@ EXPORTS = (
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
     "uz_gelu_fwd", "uz_gelu_bwd", "uz_dwconv3x3", "uz_dwconv3x3_wgrad_rows", "uz_dwconv3x3_wgrad",
     "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
-    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched",
+    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched",
 )
 
 
@@ -74,6 +74,11 @@ class WinAttnDesc(Structure):
 class SraDesc(Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "B", "N", "NK", "heads", "head_dim", "kps", "ldq", "ldk", "ldv", "ldo")] \
         + [("scale", c_float)]
+
+
+class SumRowsItem(Structure):
+    _fields_ = [("partial", c_void_p), ("out0", c_void_p), ("out1", c_void_p), ("rows", c_int), ("n", c_int), ("n0", c_int),
+                ("reserved", c_int)]
 
 
 class ColsumItem(Structure):
@@ -192,6 +197,7 @@ def load():
     lib.uz_fuse1x1_fwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, vp, vp]
     lib.uz_fuse1x1_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip]
     lib.uz_fuse1x1_bwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, POINTER(c_void_p), ip, vp, vp, vp, vp, vp]
+    lib.uz_sum_rows_f32_batched.argtypes = [POINTER(SumRowsItem), ip, vp]
     lib.uz_colsum_batched_workspace_bytes.argtypes = [ip, POINTER(ColsumItem), ip]
     lib.uz_colsum_batched.argtypes = [ip, POINTER(ColsumItem), ip, vp, vp]
     lib.uz_bce_dice_workspace_bytes.argtypes = [ll]

@@ -142,6 +142,69 @@ int cs_check(const char* fn, int dtype, const uz_colsum_item* items, int n) {
 
 }  // namespace
 
+// ---- row sums of many partial buffers (LayerNorm dgamma | dbeta, depthwise weight gradients) in one launch -------
+namespace {
+constexpr int SRB_MAX = 80;
+struct SrItem {
+  const float* partial;
+  float *out0, *out1;
+  int rows, n, n0, blk0;
+};
+struct SrBatch {
+  SrItem it[SRB_MAX];
+  int n, pad_[3];
+};
+
+// the arithmetic of sum_rows_f32_kernel<32>: 32 row groups x 32 columns per workgroup, double accumulation
+__global__ __launch_bounds__(1024) void sum_rows_batched_kernel(const SrBatch b) {
+  __shared__ double sh[32][33];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
+  const SrItem& it = b.it[i];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int e = (blockIdx.x - it.blk0) * 32 + el;
+  double s = 0.0;
+  if (e < it.n)
+    for (int r = g; r < it.rows; r += 32) s += (double)it.partial[(size_t)r * it.n + e];
+  sh[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < it.n) {
+    double t = 0.0;
+    for (int r = 0; r < 32; ++r) t += sh[r][el];
+    if (e < it.n0) it.out0[e] = (float)t;
+    else it.out1[e - it.n0] = (float)t;
+  }
+}
+}  // namespace
+
+extern "C" int uz_sum_rows_f32_batched(const uz_sum_rows_item* items, int n, void* stream) {
+  UZ_REQUIRE(items != nullptr && n > 0, "uz_sum_rows_f32_batched: no items");
+  for (int i = 0; i < n; ++i)
+    UZ_REQUIRE(items[i].partial && items[i].out0 && items[i].rows > 0 && items[i].n > 0 && items[i].n0 >= 0 &&
+                   items[i].n0 <= items[i].n && (items[i].out1 || items[i].n0 == items[i].n),
+               "uz_sum_rows_f32_batched: bad item %d", i);
+  hipStream_t s = (hipStream_t)stream;
+  for (int first = 0; first < n; first += SRB_MAX) {
+    SrBatch b;
+    b.n = n - first < SRB_MAX ? n - first : SRB_MAX;
+    int blk = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const uz_sum_rows_item& src = items[first + i];
+      b.it[i].partial = src.partial;
+      b.it[i].out0 = src.out0;
+      b.it[i].out1 = src.out1;
+      b.it[i].rows = src.rows;
+      b.it[i].n = src.n;
+      b.it[i].n0 = src.n0;
+      b.it[i].blk0 = blk;
+      blk += (src.n + 31) / 32;
+    }
+    hipLaunchKernelGGL(sum_rows_batched_kernel, dim3(blk), dim3(1024), 0, s, b);
+    UZ_LAUNCH_CHECK("uz_sum_rows_f32_batched");
+  }
+  return UZ_OK;
+}
+
 extern "C" long long uz_colsum_batched_workspace_bytes(int dtype, const uz_colsum_item* items, int n) {
   if (cs_check("uz_colsum_batched_workspace_bytes", dtype, items, n) != UZ_OK) return -1;
   long long most = 0;

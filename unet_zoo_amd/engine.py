@@ -129,6 +129,8 @@ class Engine:
         # (tape position, parameter) in the order gradients are produced; position len(tape) = heads
         self.grad_log: List[Tuple[int, nn.Parameter]] = []
         self._pending_colsums: List[Tuple[int, nn.Parameter, Act]] = []   # bias gradients of the running backward range
+        self._pending_rowsums: List[Tuple[int, Callable[[], None]]] = []
+        self._rowsum_items: list = []
         self._cpb: Dict[nn.Module, dict] = {}     # position_biases(): WindowAttention module -> batched entry
         self._bn_counters: List[torch.Tensor] = []  # num_batches_tracked of the train-mode BatchNorms seen
         self._cur_entry = -1
@@ -178,7 +180,19 @@ class Engine:
         range in two launches (uz_colsum_batched) when backward_range() ends; g stays alive until then."""
         self._pending_colsums.append((self._cur_entry, p, g))
 
+    def _after_rowsums(self, fn: Callable[[], None]) -> None:
+        """run fn (the _give_grad calls of parameter gradients left as per-workgroup partial rows) once the batched row
+        sums of this backward range have been enqueued; ops take `defer=self._rowsum_items`"""
+        self._pending_rowsums.append((self._cur_entry, fn))
+
     def _flush_colsums(self) -> None:
+        if self._pending_rowsums:
+            items, self._rowsum_items = self._rowsum_items, []
+            after, self._pending_rowsums = self._pending_rowsums, []
+            ops.sum_rows_f32_batched(items)
+            for entry, fn in after:
+                self._cur_entry = entry
+                fn()
         pend, self._pending_colsums = self._pending_colsums, []
         if not pend:
             return
@@ -680,9 +694,9 @@ class Engine:
                 dx = self.new_act(x.N, x.H, x.W, x.C)
                 dgam, dbet = ops.layernorm_bwd(x, gamma, stats, g, dx, mode=mode, r=r, eps=ln.eps,
                                                image_scale=image_scale, dgamma=self._dst(ln.weight),
-                                               dbeta=self._dst(ln.bias), gelu_beta=beta if gelu else None)
-                self._give_grad(ln.weight, dgam)
-                self._give_grad(ln.bias, dbet)
+                                               dbeta=self._dst(ln.bias), gelu_beta=beta if gelu else None,
+                                               defer=self._rowsum_items)
+                self._after_rowsums(lambda: (self._give_grad(ln.weight, dgam), self._give_grad(ln.bias, dbet)))
                 if x.needs_grad:
                     x.add_grad(dx)
 
@@ -802,10 +816,14 @@ class Engine:
                 g = self._total_grad(y)
                 if g is None:
                     return
-                dwb = ops.dwconv3x3_wgrad(x, g)
-                self._give_grad(conv.weight, dwb[:9].t().reshape(conv.weight.shape).contiguous())
-                if conv.bias is not None:
-                    self._give_grad(conv.bias, dwb[9].contiguous())
+                dwb = ops.dwconv3x3_wgrad(x, g, defer=self._rowsum_items)
+
+                def give():
+                    self._give_grad(conv.weight, dwb[:9].t().reshape(conv.weight.shape).contiguous())
+                    if conv.bias is not None:
+                        self._give_grad(conv.bias, dwb[9].contiguous())
+
+                self._after_rowsums(give)
                 if x.needs_grad:
                     dx = self.new_act(x.N, x.H, x.W, C)
                     ops.dwconv3x3(g, wt, None, dx, skip=True, flip=True)

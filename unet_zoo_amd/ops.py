@@ -437,8 +437,27 @@ def sum_rows(partial: torch.Tensor, rows: int, n: int) -> torch.Tensor:
     return out
 
 
-def sum_rows_f32(partial: torch.Tensor, rows: int, out0: torch.Tensor, out1: Optional[torch.Tensor] = None) -> None:
-    """fp32 row sums written in place: the first out0.numel() elements to out0, the rest to out1"""
+def sum_rows_f32_batched(entries: Sequence) -> None:
+    """sum_rows_f32 for every (partial, rows, out0, out1) entry in one launch per 80 buffers"""
+    if not entries:
+        return
+    arr = (L.SumRowsItem * len(entries))()
+    for i, (partial, rows, out0, out1) in enumerate(entries):
+        n0 = out0.numel()
+        n = n0 + (out1.numel() if out1 is not None else 0)
+        assert partial.numel() == rows * n and partial.dtype == torch.float32
+        arr[i] = L.SumRowsItem(partial.data_ptr(), out0.data_ptr(), out1.data_ptr() if out1 is not None else None, rows, n, n0, 0)
+    with _Timed("sum_rows_batched", 0.0, 4.0 * sum(e[0].numel() for e in entries)):
+        L.check(L.load().uz_sum_rows_f32_batched(arr, len(entries), L.stream_ptr()), "uz_sum_rows_f32_batched")
+
+
+def sum_rows_f32(partial: torch.Tensor, rows: int, out0: torch.Tensor, out1: Optional[torch.Tensor] = None,
+                 defer: Optional[list] = None) -> None:
+    """fp32 row sums written in place: the first out0.numel() elements to out0, the rest to out1.
+    defer: a list -> nothing runs now; the entry is appended for sum_rows_f32_batched()"""
+    if defer is not None:
+        defer.append((partial, rows, out0, out1))
+        return
     n0 = out0.numel()
     n = n0 + (out1.numel() if out1 is not None else 0)
     assert partial.numel() == rows * n and partial.dtype == torch.float32
@@ -652,7 +671,7 @@ def layernorm_fwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, out: Act, *, 
 def layernorm_bwd(x: Act, gamma: torch.Tensor, stats: torch.Tensor, g: Act, dx: Act, *, mode: int = L.LN_PLAIN,
                   r: int = 1, eps: float = 1e-5, image_scale: Optional[torch.Tensor] = None,
                   dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
-                  gelu_beta: Optional[torch.Tensor] = None):
+                  gelu_beta: Optional[torch.Tensor] = None, defer: Optional[list] = None):
     """returns (dgamma, dbeta) fp32 (written into the given tensors when passed); dx is written with x's addressing.
     gelu_beta: the forward was GELU(LayerNorm(x)) with this beta"""
     lib = L.load()
@@ -672,7 +691,7 @@ def layernorm_bwd(x: Act, gamma: torch.Tensor, stats: torch.Tensor, g: Act, dx: 
         dgamma = torch.empty(g.C, dtype=torch.float32, device=x.buf.device)
     if dbeta is None:
         dbeta = torch.empty(g.C, dtype=torch.float32, device=x.buf.device)
-    sum_rows_f32(part, rows, dgamma, dbeta)
+    sum_rows_f32(part, rows, dgamma, dbeta, defer=defer)   # deferred: valid after sum_rows_f32_batched(defer)
     return dgamma, dbeta
 
 
@@ -838,8 +857,8 @@ def dwconv3x3(x: Act, w_taps: torch.Tensor, bias: Optional[torch.Tensor], y: Act
                                       (1 if skip else 0) | (2 if flip else 0), L.stream_ptr()), "uz_dwconv3x3")
 
 
-def dwconv3x3_wgrad(x: Act, g: Act) -> torch.Tensor:
-    """[10, C] fp32: rows 0..8 the tap gradients, row 9 the bias gradient"""
+def dwconv3x3_wgrad(x: Act, g: Act, defer: Optional[list] = None) -> torch.Tensor:
+    """[10, C] fp32: rows 0..8 the tap gradients, row 9 the bias gradient (defer: see sum_rows_f32)"""
     assert (x.N, x.H, x.W, x.C) == (g.N, g.H, g.W, g.C) and x.dtype == g.dtype
     lib = L.load()
     code = L.dtype_code(x.dtype)
@@ -849,7 +868,7 @@ def dwconv3x3_wgrad(x: Act, g: Act) -> torch.Tensor:
     with _Timed("dwconv3x3_wgrad", 20.0 * x.P * x.C, 2 * x.buf.element_size() * x.P * x.C):
         L.check(lib.uz_dwconv3x3_wgrad(code, x.ptr(), x.ld, g.ptr(), g.ld, part.data_ptr(), x.N, x.H, x.W, x.C,
                                        L.stream_ptr()), "uz_dwconv3x3_wgrad")
-    sum_rows_f32(part, rows, out)
+    sum_rows_f32(part, rows, out, defer=defer)
     return out
 
 
