@@ -86,6 +86,13 @@ typedef struct uz_conv_desc {
 int uz_conv_igemm_grid_m(const uz_conv_desc* d); /* number of stats partial rows; <0 on error */
 int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                   void* y, float* stats_partial, void* stream);
+/* y = conv(x) + bias + res: the same with an (M, ldres) tensor of the run dtype added in the epilogue (the result is
+ * rounded to the run dtype before the addition, as a separate add of the stored tensor would): the residual sums
+ * x + proj(.), tx + fc2(.) of a transformer block (missformer.py:266-267) and, in the backward, the sum of a tensor's
+ * gradients when the last contribution is an input-gradient GEMM.  Problems of the LDS-DMA GEMM (1x1 / Linear, the
+ * gather modes) with UZ_STORE_PLAIN; others: UZ_ENOTIMPL. */
+int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                      const void* res, int ldres, void* y, void* stream);
 /* Same with a scratch buffer: small-M 3x3 problems on the generic kernel (u2net's dilated layers at
  * <= 32x32 maps, u2net.py:196-201) split their nine taps across workgroups into fp32 partial tiles in
  * `workspace` and finish with a fixed-order reduce + bias + statistics pass.  workspace_bytes() == 0:

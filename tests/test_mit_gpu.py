@@ -185,3 +185,21 @@ def test_batched_column_sums(dt):
     for o, o2, r in zip(outs, again, refs):
         assert torch.equal(o, o2)
         assert (o.double().cpu() - r).abs().max() <= 2e-5 * (r.abs().max() + 1.0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("P,K,Nout", [(300, 64, 64), (1000, 320, 96), (77, 128, 512)])
+def test_linear_with_residual_in_the_gemm_epilogue(dt, P, K, Nout):
+    """uz_conv_igemm_res: y = x W^T + b + res, equal to the stored GEMM result plus res (same rounding)"""
+    from unet_zoo_amd import _lib as L
+    g = torch.Generator().manual_seed(13)
+    x = tokens(rnd(dt, torch.randn(1, P, K, generator=g)), dt)
+    res = tokens(rnd(dt, torch.randn(1, P, Nout, generator=g)), dt)
+    w = torch.randn(Nout, K, generator=g) * 0.1
+    b = torch.randn(Nout, generator=g).to(DEV)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt, 0)
+    y0, y1 = ops.new_act(1, 1, P, Nout, dt, DEV), ops.new_act(1, 1, P, Nout, dt, DEV)
+    ops.conv_igemm(x, wp, b, y0, ntaps=1)
+    ops.conv_igemm(x, wp, b, y1, ntaps=1, res=res)
+    ref = (y0.buf.float() + res.buf.float()).to(dt)
+    assert torch.equal(y1.buf, ref)

@@ -41,7 +41,7 @@ EXPORTS = (
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
     "uz_gelu_fwd", "uz_gelu_bwd", "uz_dwconv3x3", "uz_dwconv3x3_wgrad_rows", "uz_dwconv3x3_wgrad",
     "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
-    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched",
+    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res",
 )
 
 
@@ -128,6 +128,7 @@ def load():
     vp, ip, fp = c_void_p, c_int, c_float
     lib.uz_conv_igemm_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    lib.uz_conv_igemm_res.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, ip, vp, vp]
     lib.uz_conv_igemm_workspace_bytes.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm_ws_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm_ws.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]

@@ -23,6 +23,8 @@ struct GArgs {
   void* y;
   const float* bias;
   float* stats;
+  const void* res;   // optional (M, ldres) tensor added to the result (plain store only): residual sums, gradient sums
+  int ldres;
   unsigned xbytes, wbytes;
   int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m, Hout, Wout, dil;
 };
@@ -284,6 +286,19 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
 #pragma unroll
       for (int k = 0; k < NPASS; ++k)
         vb[k] = *reinterpret_cast<const Vec16<T>*>(sC + (tid / CPR + k * RPP) * RSC + cc * 16);
+      if (a.res != nullptr) {   // y = (x W^T + b) + res, rounded as a separate add of the stored result would be
+        const T* rg = static_cast<const T*>(a.res);
+        Vec16<T> rb[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+          const long long orow = out_row(tid / CPR + k * RPP, ab);
+          rb[k] = (orow >= 0 && cok) ? ld16(rg + (size_t)orow * a.ldres + co0 + cc * VEC) : zero16<T>();
+        }
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) vb[k].v[e] = (T)((float)vb[k].v[e] + (float)rb[k].v[e]);
+      }
 #pragma unroll
       for (int k = 0; k < NPASS; ++k) {
         const long long orow = out_row(tid / CPR + k * RPP, ab);
@@ -308,7 +323,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
             const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const long long orow = out_row(ml, ab);
             if (orow >= 0 && n0 + col < a.Nout) {
-              const T tv = (T)(acc[i][j][r] + bv[j]);
+              T tv = (T)(acc[i][j][r] + bv[j]);
+              if (a.res != nullptr) tv += static_cast<const T*>(a.res)[(size_t)orow * a.ldres + co0 + col];
               yg[(size_t)orow * a.ldy + co0 + col] = tv;
               const float fv = (float)tv;
               s1[j] += fv;
@@ -430,7 +446,7 @@ static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
 }
 
 int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
-                       const float* bias, void* y, float* stats, hipStream_t s) {
+                       const float* bias, void* y, float* stats, hipStream_t s, const void* res, int ldres) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   GArgs a;
   a.x = x;
@@ -438,6 +454,8 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x
   a.y = y;
   a.bias = bias;
   a.stats = stats;
+  a.res = res;
+  a.ldres = ldres;
   a.xbytes = (unsigned)(((long long)d->N * d->Hin * d->Win - 1) * d->ldx * es + (long long)d->Cin * es);
   a.wbytes = (unsigned)((long long)d->Nout * d->ntaps * d->Cin * es);
   a.M = d->N * d->H * d->W;

@@ -493,6 +493,25 @@ extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w
   return uz_conv_igemm_ws(d, x, w_packed, bias, y, stats_partial, nullptr, stream);
 }
 
+extern "C" int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                 const void* res, int ldres, void* y, void* stream) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(x && w_packed && y && res, "uz_conv_igemm_res: null pointer");
+  UZ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                 ((uintptr_t)res & 15) == 0, "uz_conv_igemm_res: x / w / y / res must be 16-byte aligned");
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(ldres >= d->Nout && ldres % vec == 0, "uz_conv_igemm_res: bad ldres %d", ldres);
+  UzDirectPlan dp;
+  UzGemmPlan gp;
+  if (d->store_mode != UZ_STORE_PLAIN || uz_direct_plan(d, &dp) || !uz_gemm_dma_plan(d, &gp)) {
+    uz_set_error("uz_conv_igemm_res: only problems of the LDS-DMA GEMM with a plain store take a residual");
+    return UZ_ENOTIMPL;
+  }
+  return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, nullptr, static_cast<hipStream_t>(stream), res, ldres);
+}
+
 extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed,
                                 const float* bias, void* y, float* stats_partial, void* workspace,
                                 void* stream) {

@@ -619,24 +619,30 @@ class Engine:
             gs.append(tot)
         return gs[0]
 
-    def linear(self, x: Act, lin: nn.Linear, out: Optional[Act] = None) -> Act:
-        """nn.Linear on a token tensor: y[p] = W x[p] + b, on the LDS-DMA GEMM (ntaps = 1)."""
+    def linear(self, x: Act, lin: nn.Linear, out: Optional[Act] = None, residual: Optional[Act] = None) -> Act:
+        """nn.Linear on a token tensor: y[p] = W x[p] + b [+ residual[p]], on the LDS-DMA GEMM (ntaps = 1); the
+        residual sum of a transformer block (x + proj(.), tx + fc2(.)) rides in the GEMM's epilogue.  In the
+        backward the input-gradient GEMM adds one gradient that x has already collected (its residual branch), so
+        the two are never summed by a separate pass."""
         assert lin.in_features == x.C
         y = out if out is not None else self.new_act(x.N, x.H, x.W, lin.out_features)
         ops.conv_igemm(x, self._pack(lin.weight, L.PACK_CONV_FWD), lin.bias.detach() if lin.bias is not None else None,
-                       y, ntaps=1)
+                       y, ntaps=1, res=residual)
         if self.record:
             def bwd():
                 g = self._total_grad(y)
                 if g is None:
                     return
+                if residual is not None and residual.needs_grad:
+                    residual.add_grad(g)
                 if lin.bias is not None:
                     self._bias_grad(lin.bias, g)
                 self._give_grad(lin.weight, ops.wgrad(g, x, tuple(lin.weight.shape), ntaps=1,
                                                       out=self._dst(lin.weight)))
                 if x.needs_grad:
+                    prev = x.grads.pop() if (x.grads and x.parts is None and x.rparts is None) else None
                     dx = self.new_act(x.N, x.H, x.W, x.C)
-                    ops.conv_igemm(g, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=1)
+                    ops.conv_igemm(g, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=1, res=prev)
                     x.add_grad(dx)
 
             self.tape.append(bwd)

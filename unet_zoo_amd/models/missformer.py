@@ -62,12 +62,12 @@ class EfficientSelfAtten(nn.Module):
             self.sr = nn.Conv2d(dim, dim, reduction_ratio, reduction_ratio)
             self.norm = nn.LayerNorm(dim)
 
-    def emit(self, eng: Engine, x: Act) -> Act:
+    def emit(self, eng: Engine, x: Act, residual: Optional[Act] = None) -> Act:
         q = eng.linear(x, self.q)
         red = eng.layer_norm(eng.patch_conv(x, self.sr), self.norm) if self.reduction_ratio > 1 else x
         kv = eng.linear(red, self.kv)
         o = eng.sr_attention(q, kv, x.N, self.head, kv.P // x.N, self.scale)
-        return eng.linear(o, self.proj)
+        return eng.linear(o, self.proj, residual=residual)
 
 
 class Scale_reduce(nn.Module):
@@ -95,7 +95,7 @@ class M_EfficientSelfAtten(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.scale_reduce = Scale_reduce(dim, reduction_ratios, patch_resolutions, mi_t_dims)
 
-    def emit(self, eng: Engine, x: Act, B: int) -> Act:
+    def emit(self, eng: Engine, x: Act, B: int, residual: Optional[Act] = None) -> Act:
         sr = self.scale_reduce
         res, ratios = sr.patch_resolutions, sr.reduction_ratios
         shapes = [(B, h, w) for h, w in res]
@@ -118,7 +118,7 @@ class M_EfficientSelfAtten(nn.Module):
             segs.append((r0, h * w))
             r0 += B * h * w
         o = eng.sr_attention(q, kv, B, self.head, kps, self.scale, segments=segs)
-        return eng.linear(o, self.proj)
+        return eng.linear(o, self.proj, residual=residual)
 
 
 class DWConv(nn.Module):
@@ -142,10 +142,10 @@ class MixFFN_skip(nn.Module):
         self.norm2 = nn.LayerNorm(c2)
         self.norm3 = nn.LayerNorm(c2)
 
-    def emit(self, eng: Engine, x: Act, out: Optional[Act] = None) -> Act:
+    def emit(self, eng: Engine, x: Act, out: Optional[Act] = None, residual: Optional[Act] = None) -> Act:
         f = eng.linear(x, self.fc1)
         a = eng.layer_norm(eng.dwconv_skip(f, self.dwconv.dwconv), self.norm1, gelu=True)   # act(norm1(.)) in one kernel
-        return eng.linear(a, self.fc2, out=out)
+        return eng.linear(a, self.fc2, out=out, residual=residual)
 
 
 class OverlapPatchEmbeddings(nn.Module):
@@ -175,8 +175,8 @@ class TransformerBlock(nn.Module):
         self.mlp = MixFFN_skip(dim, int(dim * 4))
 
     def emit(self, eng: Engine, x: Act) -> Act:
-        tx = eng.add(x, self.attn.emit(eng, eng.layer_norm(x, self.norm1)))
-        return eng.add(tx, self.mlp.emit(eng, eng.layer_norm(tx, self.norm2)))
+        tx = self.attn.emit(eng, eng.layer_norm(x, self.norm1), residual=x)          # x + attn(norm1(x)): GEMM epilogue
+        return self.mlp.emit(eng, eng.layer_norm(tx, self.norm2), residual=tx)       # tx + mlp(norm2(tx))
 
 
 class MiT(nn.Module):
@@ -292,7 +292,7 @@ class BridgeLayer_4(nn.Module):
                 eng.linear(c, getattr(self, f"proj_c{i + 1}"), out=slot)
         else:
             cat = inputs
-        tx1 = eng.add(cat, self.attn.emit(eng, eng.layer_norm(cat, self.norm1), B))
+        tx1 = self.attn.emit(eng, eng.layer_norm(cat, self.norm1), B, residual=cat)
         tx = eng.layer_norm(tx1, self.norm2)
         ffn, slots = eng.new_rows(shapes, self.common_bridge_dim)
         for i, (v, slot) in enumerate(zip(eng.row_views(tx, shapes), slots)):

@@ -192,8 +192,9 @@ def im2col3x3_nchw(x: torch.Tensor, kpad: int, dtype: torch.dtype) -> Act:
 def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Act, *,
                ntaps: int, dil: int = 1, taps_mode: int = L.TAPS_CONV,
                store_mode: int = L.STORE_PLAIN, nout: Optional[int] = None, co: int = 0,
-               want_stats: bool = False) -> Optional[torch.Tensor]:
-    """y = conv(x, w) + bias on the matrix cores; returns the BN partial-sum rows if asked."""
+               want_stats: bool = False, res: Optional[Act] = None) -> Optional[torch.Tensor]:
+    """y = conv(x, w) + bias [+ res] on the matrix cores; returns the BN partial-sum rows if asked.  res: a tensor
+    of y's shape added in the GEMM epilogue (uz_conv_igemm_res), or by a separate add where that kernel does not apply."""
     L.require_cuda(x.buf, w_packed, y.buf)
     lib = L.load()
     if taps_mode == L.TAPS_CONV:
@@ -235,10 +236,19 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
     else:
         kname = f"igemm_{_tname(x.dtype)}_128x{bn}" + ("_tapsplit" if ws is not None else "")
+    if res is not None:
+        assert (res.P, res.C) == (y.P, y.C) and res.dtype == y.dtype and not want_stats
+        if kname.startswith("gemm_dma") and store_mode == L.STORE_PLAIN:
+            with _Timed(kname, 2.0 * M * d.Nout * K, es * (x.P * x.C + 2 * M * d.Nout + d.Nout * K)):
+                L.check(lib.uz_conv_igemm_res(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), res.ptr(), res.ld, y.ptr(),
+                                              L.stream_ptr()), "uz_conv_igemm_res")
+            return None
     with _Timed(kname, 2.0 * M * d.Nout * K,
                         es * (x.P * x.C + M * d.Nout + d.Nout * K)):
         L.check(lib.uz_conv_igemm_ws(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), y.ptr(), _p(stats),
                                      _p(ws), L.stream_ptr()), "uz_conv_igemm_ws")
+    if res is not None:
+        add_acts(y, res, y)
     return stats
 
 
