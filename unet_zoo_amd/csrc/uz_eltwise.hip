@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
   const long long ustride = (long long)gridDim.x * blockDim.y;
   for (long long u = (long long)blockIdx.x * blockDim.y + threadIdx.y; u < units && cok;
        u += (POOL ? 1 : NPIX) * ustride) {
-    size_t p00;
+    size_t pix[NPIX];   // pixel of slot k; slots outside the map / past the end read a clamped pixel and are zeroed
     bool in[NPIX];
     size_t gpoff = 0;
     bool has_pool = false;
@@ -228,20 +228,47 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
       const long long t = u / Wo;
       const int ho = (int)(t % Ho);
       const int img = (int)(t / Ho);
-      p00 = ((size_t)img * a.H + 2 * ho) * a.W + 2 * wo;
 #pragma unroll
-      for (int k = 0; k < NPIX; ++k) in[k] = 2 * ho + (k >> 1) < a.H && 2 * wo + (k & 1) < a.W;
+      for (int k = 0; k < NPIX; ++k) {
+        const int hh = 2 * ho + (k >> 1), ww = 2 * wo + (k & 1);
+        in[k] = hh < a.H && ww < a.W;
+        pix[k] = ((size_t)img * a.H + min(hh, a.H - 1)) * a.W + min(ww, a.W - 1);
+      }
       has_pool = ho < Hp && wo < Wp;
       gpoff = (((size_t)img * Hp + ho) * Wp + wo) * a.ldgp;
     } else {
-      p00 = (size_t)u;
 #pragma unroll
-      for (int k = 0; k < NPIX; ++k) in[k] = u + k * ustride < units;
+      for (int k = 0; k < NPIX; ++k) {
+        const long long q = u + k * ustride;
+        in[k] = q < units;
+        pix[k] = (size_t)(in[k] ? q : units - 1);
+      }
+    }
+#ifndef UZ_BN_BRANCHY
+    // every load of the iteration is issued before the first use: a branch per slot put an s_waitcnt vmcnt(0)
+    // behind each slot's loads and the four slots ran one memory latency after the other
+    Vec16<T> yr[NPIX], g0r[NPIX], g1r[NPIX];
+#pragma unroll
+    for (int k = 0; k < NPIX; ++k) {
+      yr[k] = ld16(y + pix[k] * a.ldy + c0);
+      if (g0 != nullptr) g0r[k] = ld16(g0 + pix[k] * a.ldg0 + c0);
+      if (g1 != nullptr) g1r[k] = ld16(g1 + pix[k] * a.ldg1 + c0);
     }
     float yv[NPIX][VEC], gv[NPIX][VEC];
 #pragma unroll
+    for (int k = 0; k < NPIX; ++k)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        yv[k][i] = in[k] ? (float)yr[k].v[i] : 0.f;
+        float gsum = g0 != nullptr ? (float)g0r[k].v[i] : 0.f;
+        if (g1 != nullptr) gsum += (float)g1r[k].v[i];
+        gv[k][i] = in[k] ? gsum : 0.f;
+      }
+#else
+    float yv[NPIX][VEC], gv[NPIX][VEC];
+#pragma unroll
     for (int k = 0; k < NPIX; ++k) {
-      const size_t p = POOL ? p00 + (k >> 1) * a.W + (k & 1) : p00 + (size_t)k * ustride;
+      const size_t p = pix[k];
       if (!in[k]) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) yv[k][i] = gv[k][i] = 0.f;
@@ -261,6 +288,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
         for (int i = 0; i < VEC; ++i) gv[k][i] += t[i];
       }
     }
+#endif
     if constexpr (POOL) {
       if (gp != nullptr && has_pool) {
         float gpv[VEC];
@@ -299,8 +327,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
         }
       }
       if (PASS == 2) {
-        const size_t p = POOL ? p00 + (k >> 1) * a.W + (k & 1) : p00 + (size_t)k * ustride;
-        store_f(dy + p * a.lddy + c0, out);
+        store_f(dy + pix[k] * a.lddy + c0, out);
       }
     }
   }
