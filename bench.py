@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 outside a launcher starts N fresh rank processes itself (unet_zoo_amd.launch, before this
+process makes any GPU call) and relays rank 0's JSON line; with fewer than N visible GPUs it exits non-zero.
+The step is `unet_zoo_amd.GraphedStep` -- the product API a training loop calls -- not a harness private to this file.
+
 One "step" = the reference's whole training step (unet_zoo/utils/training_loop.py:112-121):
 zero_grad -> forward -> BCEWithLogits -> backward (-> RCCL gradient all-reduce) ->
 clip_grad_norm_(1.0) -> AdamW.  Inputs are synthetic and already resident in HBM.  `value` is
@@ -34,18 +38,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import unet_zoo_amd  # noqa: E402
-from unet_zoo_amd import ops  # noqa: E402
-from unet_zoo_amd.graph import PhasedStep
-from unet_zoo_amd.optim import FlatClipAdamW
+from unet_zoo_amd import launch, ops  # noqa: E402
 from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
+from unet_zoo_amd.step import GraphedStep  # noqa: E402
 
-# hipGraph capture checks only THIS thread's calls: the process-group watchdog thread polls its events
-# concurrently (legal for it, but fatal to a capture in the default "global" mode)
-CAPTURE_MODE = "thread_local"
+ABLATION_ENV = ("UZ_TUNE", "UZ_ATTN_GX", "UZ_WG_SPLIT")
 PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # MI355X_MICROARCH.md
 
 
 _LOSS_IMPL = "hip"
+
+
+def torch_criterion(out, mask):
+    """nn.BCEWithLogitsLoss as the reference applies it (scripts/train.py:135; dict outputs: training_loop.py:60-64)"""
+    if isinstance(out, dict):
+        total = None
+        for v in out.values():
+            l = F.binary_cross_entropy_with_logits(v, mask)
+            total = l if total is None else total + l
+        return total
+    return F.binary_cross_entropy_with_logits(out, mask)
 
 
 def model_loss(out, mask):
@@ -73,7 +85,7 @@ def make_model(model_name: str, hw: int):
     return unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1, **kw), kw
 
 
-def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
+def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet", threads: int = 16):
     """Reference step on the host CPU through the oracle (checker code, used here only as the
     reported baseline)."""
     from oracle import torch_ref
@@ -83,7 +95,7 @@ def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
         ncpu = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(16, ncpu)))
+    torch.set_num_threads(max(1, min(threads, ncpu)))
     torch.manual_seed(0)
     m, kw = make_model(model_name, hw)
     sd = m.state_dict()
@@ -123,43 +135,93 @@ def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
             "sample": f"{model_name} train step on CPU fp32, B={batch} 3x{hw}x{hw}, 1 warm-up + {steps} timed steps, median"}
 
 
+def time_graphed(gs, x, mask, steps, warmup, distributed, dev):
+    """W untimed + exactly K timed whole steps between barrier + synchronize; returns (max-over-ranks seconds,
+    seconds of K forward+backward(+all-reduce) replays alone)"""
+    for _ in range(max(warmup, 1)):      # the first call dry-runs, lays out the flat buffers and captures
+        gs(x, mask)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gs(x, mask)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        gs.forward_backward(x, mask)
+    torch.cuda.synchronize()
+    return elapsed, time.perf_counter() - t1
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--model", default="unet", choices=["unet", "attention_unet", "u2net", "swin_unet_v2", "nested_unet", "resunet", "missformer"],
+    ap.add_argument("--model", default="unet", choices=sorted(unet_zoo_amd.hip_models()),
                     help="unet = BASELINE configs[1] (the headline metric); attention_unet = configs[2] with --size 512; "
                          "u2net = configs[4] with --size 512 --batch 8; swin_unet_v2 = the second north-star model at "
                          "--size 256 (window 8) or configs[3] with --size 224 --batch 32 (window 7)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the whole step from one hipGraph (auto: try, fall back to eager)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--graph", default="on", choices=["on", "off"],
+                    help="on: unet_zoo_amd.GraphedStep (hipGraph replays); off: eager launches through autograd + "
+                         "torch's clip_grad_norm_ / AdamW (with N > 1: the bucket reducer of RcclDataParallel)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and use the multi-GPU launch strategy even for 1 rank")
-    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"],
-                    help="graph mode: flat = clip + AdamW as three launches on flat buffers (unet_zoo_amd.optim), "
-                         "torch = torch.nn.utils.clip_grad_norm_ + fused torch.optim.AdamW")
     ap.add_argument("--phases", type=int, default=5,
-                    help="N>1 ranks, graph mode: number of backward phases (hipGraphs) whose gradient "
+                    help="N>1 ranks: number of backward phases (hipGraphs) whose gradient "
                          "all-reduce overlaps the next phase; 1 = one all-reduce after the whole backward")
     ap.add_argument("--loss", default="hip", choices=["hip", "torch"],
-                    help="hip = BCEWithLogits + Dice + gradient in one kernel pass (unet_zoo_amd.loss); torch = F.binary_cross_entropy_with_logits")
+                    help="hip = BCEWithLogits + Dice + gradient in one kernel pass inside the graph (unet_zoo_amd.loss); "
+                         "torch = F.binary_cross_entropy_with_logits, evaluated eagerly between the graphs")
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="eager steps with per-launch HIP events, run after the timed region")
+    ap.add_argument("--fp32-steps", type=int, default=10,
+                    help="N=1, bf16 runs: also time this many steps of the SAME model in the fp32 run mode (the "
+                         "mode that meets the 1e-3 parity bound) and report fp32_images_per_s; 0 = skip")
     args = ap.parse_args()
     global _LOSS_IMPL
     _LOSS_IMPL = args.loss
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_dist:
+    # a measurement must not depend on the environment: the shipped library ignores these switches, and an
+    # ablation build (make ABLATE=1) is not what this file times
+    stray = [k for k in ABLATION_ENV if os.environ.get(k)]
+    if stray:
+        print(f"bench.py: refusing to run with ablation switches set in the environment: {stray}", file=sys.stderr)
+        sys.exit(2)
+
+    # ---- ranks: one process per GPU, started BEFORE this process touches the GPU ---------------------------
+    if not launch.under_launcher():
+        want = 1 if args.gpus is None else args.gpus
+        if want > 1:
+            sys.exit(launch.spawn_ranks(want, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+        if want < 1:
+            print(f"bench.py: --gpus must be >= 1, got {want}", file=sys.stderr)
+            sys.exit(2)
+    rank, local_rank, world = launch.rank_info()
+    if args.gpus is not None and args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU "
+              f"(python bench.py --gpus N does that itself)", file=sys.stderr)
+        sys.exit(2)
+    if unet_zoo_amd._lib.load().uz_build_ablate():
+        print("bench.py: libunetzoo_hip.so is an ablation build (make ABLATE=1); rebuild without it", file=sys.stderr)
+        sys.exit(2)
+    distributed = world > 1 or args.force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -174,221 +236,98 @@ def main():
     model, _ = make_model(args.model, args.size)
     model.run_dtype = run_dtype
     model = model.to(dev).train()
-    net = RcclDataParallel(model) if (world > 1 or args.force_dist) else model
     params = list(model.parameters())
-    use_graph = args.graph != "off"
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True, capturable=use_graph)
 
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(dev)
     mask = (torch.rand(args.batch, 1, args.size, args.size, generator=g) > 0.5).float().to(dev)
 
     fb_events = []
+    net = model
+    opt = None
 
-    def fwd_bwd(timed: bool = False):
+    def eager_step(timed: bool):
+        """the reference's loop body, launched eagerly (training_loop.py:112-121)"""
+        opt.zero_grad(set_to_none=True)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        out = net(x)
-        loss = model_loss(out, mask)
+        loss = model_loss(net(x), mask)
         loss.backward()
         if timed:
             e1.record()
             fb_events.append((e0, e1))
-        return loss
-
-    def opt_step():
-        torch.nn.utils.clip_grad_norm_(params, 1.0, foreach=True)
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0, foreach=True)
         opt.step()
-
-    def step(timed: bool):
-        opt.zero_grad(set_to_none=True)
-        loss = fwd_bwd(timed)
-        opt_step()
         return loss
 
-    # warm-up (eager, on a side stream so that a graph can be captured afterwards)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(args.warmup, 1)):
-            loss = step(False)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-
-    # ---- launch strategy ---------------------------------------------------------------------
-    #  The step is two hipGraphs: (zero + fwd + loss + bwd, gradients accumulated into one flat fp32
-    #  buffer) and (clip + AdamW).  With N > 1 ranks ONE eager RCCL all-reduce (AVG) of the flat
-    #  buffer runs between them: collectives stay out of graph capture.  (The bucket reducer that
-    #  overlaps all-reduce with backward, parallel.RcclDataParallel, is the eager path: --graph off.)
-    run_one = None
-    launch_mode = "eager"
-    distributed = world > 1 or args.force_dist
-    if use_graph:
-        try:
-            inner = net.module if isinstance(net, RcclDataParallel) else net
-            inner._grad_sink = None          # gradients are reduced from the flat buffer instead
-            inner._grad_sink_done = None
-            # parameters the graph never reaches (swin's mlp / norm2, swin_unet_v2.py:264-267) keep
-            # .grad = None exactly as in the reference, so clip and AdamW (incl. weight decay) skip them
-            used = [p for p in params if p.grad is not None]
-            for p in params:
-                p.grad = None
-            inner.grads_in_place = True      # kernels write straight into the views of `flat`
-            g_opt = torch.cuda.CUDAGraph()
-            optname = "clip+AdamW on flat buffers, 3 launches" if args.optimizer == "flat" else "torch clip_grad_norm_ + fused AdamW"
-
-            def lay_out(ordered):
-                """one flat gradient buffer in the given parameter order (+ the flat optimizer on it)"""
-                if args.optimizer == "flat":
-                    fo = FlatClipAdamW(ordered, lr=1e-4, weight_decay=1e-5, max_norm=1.0)
-                    inner._pack_cache.repoint()      # parameters moved into the flat buffer:
-                    inner._pack_cache.refresh(inner.run_dtype)   # new pointer tables, built outside any capture
-                    return fo.flat_g[:fo.n], fo.step
-                A = FlatClipAdamW.ALIGN
-                fl = torch.zeros(sum((p.numel() + A - 1) // A * A for p in ordered), dtype=torch.float32, device=dev)
-                o = 0
-                for p in ordered:
-                    p.grad = fl[o:o + p.numel()].view_as(p)
-                    o += (p.numel() + A - 1) // A * A
-                return fl, opt_step
-            if distributed and args.phases > 1:
-                # backward cut into phases, one hipGraph each; the gradients a phase completed are
-                # all-reduced (async RCCL) while the next phase's graph runs
-                ps = PhasedStep(inner, model_loss)
-                for p in used:
-                    p.grad = torch.zeros_like(p)
-                ps.forward(x, mask)          # eager dry run: which tape entry completes which parameter
-                ps.backward(ps.n_entries, 0, True)
-                # cut where the cumulative gradient bytes cross k/(K-1) * 85 %: the last phase (the
-                # high-resolution encoder layers: few parameters, long compute) hides the exchange
-                # of everything before it and leaves ~15 % of the bytes exposed
-                cuts, groups = ps.plan([0.85 * (i + 1) / (args.phases - 1) for i in range(args.phases - 1)])
-                ps.finish()
-                flat, do_opt = lay_out([p for grp in groups for p in grp])   # ordered by phase: one collective each
-                off, spans, A = 0, [], FlatClipAdamW.ALIGN
-                for grp in groups:
-                    k = sum((p.numel() + A - 1) // A * A for p in grp)
-                    spans.append((off, off + k))
-                    off += k
-                assert off == flat.numel()
-                graphs, pool = [], None
-                for k in range(len(groups)):
-                    gk = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gk, pool=pool, capture_error_mode=CAPTURE_MODE):
-                        if k == 0:
-                            static_loss = ps.forward(x, mask)
-                            out = ps.outputs
-                        ps.backward(cuts[k], cuts[k + 1], k == 0)
-                    pool = gk.pool()
-                    graphs.append(gk)
-                ps.finish()
-
-                def fb_replay():
-                    for gk in graphs:
-                        gk.replay()
-                with torch.cuda.graph(g_opt, capture_error_mode=CAPTURE_MODE):
-                    do_opt()
-
-                def run_one():
-                    works = []
-                    for gk, (a0, a1) in zip(graphs, spans):
-                        gk.replay()
-                        works.append(dist.all_reduce(flat[a0:a1], op=dist.ReduceOp.AVG, async_op=True))
-                    for w in works:
-                        w.wait()
-                    g_opt.replay()
-                mb = [round((a1 - a0) * 4 / 2 ** 20, 1) for a0, a1 in spans]
-                launch_mode = (f"{len(graphs)} hipGraphs (fwd + backward phases) with async RCCL all-reduce of "
-                               f"{mb} MB overlapped with the next phase + hipGraph({optname})")
-            else:
-                flat, do_opt = lay_out(used)  # .grad = views of one buffer -> one collective
-                g_fb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb, capture_error_mode=CAPTURE_MODE):
-                    out = inner(x)
-                    static_loss = model_loss(out, mask)
-                    static_loss.backward()   # every parameter gradient overwritten in place
-                fb_replay = g_fb.replay
-                with torch.cuda.graph(g_opt, capture_error_mode=CAPTURE_MODE):
-                    do_opt()
-                if distributed:
-                    def run_one():
-                        g_fb.replay()
-                        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-                        g_opt.replay()
-                    launch_mode = f"hipGraph(fwd+bwd) + eager RCCL all-reduce + hipGraph({optname})"
-                else:
-                    def run_one():
-                        g_fb.replay()
-                        g_opt.replay()
-                    launch_mode = f"hipGraph(fwd+bwd) + hipGraph({optname})"
-            run_one()                 # one untimed replay
-            torch.cuda.synchronize()
-            if os.environ.get("UZ_BENCH_DEBUG"):
-                for _ in range(4):
-                    run_one()
-                    torch.cuda.synchronize()
-                    print("# debug loss", float(static_loss.item()), float(model_loss(out, mask).item()),
-                          "grad norm", float(flat.norm().item()),
-                          file=sys.stderr, flush=True)
-        except Exception as e:  # noqa: BLE001
-            if args.graph == "on":
-                raise
-            run_one = None
-            launch_mode = "eager"
-            torch.cuda.synchronize()
-            for p in params:
-                p.grad = None
-            (net.module if isinstance(net, RcclDataParallel) else net).grads_in_place = False
-            if isinstance(net, RcclDataParallel):
-                net.module._grad_sink = net.reducer.push
-                net.module._grad_sink_done = net.reducer.finish
-            if rank == 0:
-                print(f"# hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches",
-                      file=sys.stderr, flush=True)
-
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if run_one is not None:
-        for _ in range(args.steps):
-            run_one()
-        # the loss is re-evaluated eagerly from the last replay's logits: the library's multi-block mean
-        # reduction inside a replayed hipGraph intermittently returned 0 on this stack (gradients are
-        # unaffected: they do not depend on the reduced value)
-        with torch.no_grad():
-            loss = model_loss(out, mask)
-    else:
-        for _ in range(args.steps):
-            loss = step(False)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    final_loss = float(loss.item())
+    gs = None
     fb_graph_ms = None
-    if run_one is not None:
+    loss_recheck = None
+    if args.graph == "on":
+        gs = GraphedStep(model, "bce_dice" if args.loss == "hip" else torch_criterion, lr=1e-4, weight_decay=1e-5,
+                         max_norm=1.0, phases=args.phases, data_parallel=distributed)
+        elapsed, fb_s = time_graphed(gs, x, mask, args.steps, args.warmup, distributed, dev)
+        fb_graph_ms = fb_s / args.steps * 1e3
+        launch_mode = gs.describe()
+        # the loss comes straight out of the replayed graph (uz_bce_dice: no library reduction, no memset node);
+        # re-evaluated eagerly from the same replay's logits it must be the same number
+        final_loss = float(gs.loss.item())
+        with torch.no_grad():
+            loss_recheck = float(torch_criterion(gs.outputs, mask).item())
+    else:
+        if distributed:
+            net = RcclDataParallel(model)
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True)
+        for _ in range(max(args.warmup, 1)):
+            eager_step(False)
+        if distributed:
+            dist.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        t0 = time.perf_counter()
         for _ in range(args.steps):
-            fb_replay()
+            loss = eager_step(False)
         torch.cuda.synchronize()
-        fb_graph_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        if distributed:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        final_loss = float(loss.item())
+        launch_mode = "eager launches (autograd node + torch clip_grad_norm_ + fused AdamW)"
 
     # per-launch HIP events (same process, same shapes, eager launches right after the timed steps)
-    for p in params:          # the eager profiling steps own their gradients again
+    net = model
+    if opt is None:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True)
+    model._grad_sink = None
+    model._grad_sink_done = None
+    for p in params:          # the eager profiling steps own their gradients
         p.grad = None
-    (net.module if isinstance(net, RcclDataParallel) else net).grads_in_place = False
     ops.profile_begin()
     for _ in range(args.profile_steps):
-        step(True)
+        eager_step(True)
     prof = ops.profile_end()
     nprof = max(args.profile_steps, 1)
+
+    # the same model in the fp32 run mode (exact-fp32 MFMA, the mode the parity tests bound at 1e-3)
+    fp32 = None
+    if world == 1 and not distributed and args.dtype == "bf16" and args.fp32_steps > 0 and gs is not None:
+        del opt
+        for p in params:
+            p.grad = None
+        torch.manual_seed(0)
+        m32, _ = make_model(args.model, args.size)
+        m32.run_dtype = torch.float32
+        m32 = m32.to(dev).train()
+        gs32 = GraphedStep(m32, "bce_dice" if args.loss == "hip" else torch_criterion, lr=1e-4, weight_decay=1e-5)
+        el32, _ = time_graphed(gs32, x, mask, args.fp32_steps, 2, False, dev)
+        fp32 = {"fp32_images_per_s": round(args.batch * args.fp32_steps / el32, 2),
+                "fp32_ms_per_step": round(el32 / args.fp32_steps * 1e3, 3), "fp32_steps": args.fp32_steps,
+                "fp32_loss": round(float(gs32.loss.item()), 5)}
+        del gs32, m32
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -405,7 +344,9 @@ def main():
         # prescribes for gfx950) -- counters cannot be read from inside this process
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc_file = next(n for n in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)["kernels"]
             key = {"conv3x3_direct_bf16_bn128": "21conv3x3_direct_kernelIDF16bLi32ELi128ELb0EEEvNS_10DirectArgsE",
                    "wgrad3x3_bf16_128x128_3tap": "wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>"}.get(dom_name)
@@ -415,8 +356,8 @@ def main():
                 traffic = {"hbm_read_mb_per_launch": pmc[key]["hbm_read_mb_per_launch_corrected"],
                            "hbm_write_mb_per_launch": pmc[key]["hbm_write_mb_per_launch"],
                            "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 2 ** 20, 2),
-                           "source": "profiles/r01_pmc_traffic.json"}
-        except (OSError, KeyError, ValueError):
+                           "source": f"profiles/{pmc_file}"}
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         if dom is not None:
             flops_per_launch = dom["flops"] / dom["launches"]
@@ -449,14 +390,19 @@ def main():
             "fwd_bwd_ms": round(fb_ms, 3) if fb_ms else None,
             "fwd_bwd_images_per_s": round(args.batch * world / (fb_ms * 1e-3), 2) if fb_ms else None,
             "loss": round(final_loss, 5),
+            "loss_eager_recheck": round(loss_recheck, 5) if loss_recheck is not None else None,
             "roofline": roofline,
             "launch": launch_mode,
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }
+        if fp32 is not None:
+            line.update(fp32)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps, args.model)
+            cb = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps, args.model)
+            cb["value_8_threads"] = cpu_baseline(args.cpu_batch, args.size, 1, args.model, threads=8)["value"]
+            line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
-    if world > 1 or args.force_dist:
+    if distributed:
         dist.destroy_process_group()
 
 

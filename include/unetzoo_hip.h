@@ -57,6 +57,10 @@ enum {
 
 int uz_abi_version(void);
 const char* uz_last_error_string(void);
+/* 1 when the library was built with -DUZ_ABLATE (the measurement build of tools/kbench.py, whose kernels honour the
+ * UZ_TUNE / UZ_ATTN_GX / UZ_WG_SPLIT environment switches), 0 for the shipped build, which never reads the
+ * environment.  bench.py refuses to time an ablation build. */
+int uz_build_ablate(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the matrix cores.

@@ -126,3 +126,71 @@ def test_single_process_reducer_is_a_no_op():
         red.push(p, g[p])
     red.finish(g)
     assert all(torch.equal(g[p], torch.ones_like(p)) for p in params)
+
+
+def _double_push_worker(rank, world, port, q):
+    """A parameter that receives TWO contributions per backward (the engine pushes the running sum each time)
+    and the in-place mode (grads[p] is None, the gradient lives in p.grad): ADVICE round 1."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = _make_params()
+        red = BucketReducer(params, bucket_bytes=1 << 10)      # several buckets
+        ok = True
+        shared = params[2]                                      # pushed twice per backward
+        for step in range(3):
+            grads = _grads_for(rank, step, params)
+            out = {}
+            for i in reversed(range(len(params))):
+                if params[i] is shared:
+                    half = grads[i] * 0.25
+                    red.push(shared, half)                      # first contribution: partial value
+                    # another parameter of the same bucket arrives in between
+                    continue
+                out[params[i]] = grads[i]
+                red.push(params[i], grads[i])
+            out[shared] = grads[2]
+            red.push(shared, grads[2])                          # running sum = the final gradient
+            red.finish(out)
+            for i, p in enumerate(params):
+                expect = sum(_grads_for(r, step, params)[i] for r in range(world)) / world
+                ok = ok and torch.allclose(out[p], expect, atol=1e-6)
+        # in-place mode: gradients sit in p.grad, the dict holds None
+        for step in range(3, 5):
+            grads = _grads_for(rank, step, params)
+            out = {}
+            for i in reversed(range(len(params))):
+                params[i].grad = grads[i].clone()
+                out[params[i]] = None
+                if params[i] is shared:
+                    red.push(shared, params[i].grad * 0.5)
+                red.push(params[i], params[i].grad)
+            red.finish(out)
+            for i, p in enumerate(params):
+                expect = sum(_grads_for(r, step, params)[i] for r in range(world)) / world
+                ok = ok and out[p] is None and torch.allclose(p.grad, expect, atol=1e-6)
+        # one contribution too many is an error, not a silent early launch
+        raised = False
+        try:
+            for _ in range(3):
+                red.push(shared, torch.zeros_like(shared))
+        except RuntimeError:
+            raised = True
+        q.put((rank, ok, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_counts_contributions_and_supports_in_place_grads():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_double_push_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok and raised for _, ok, raised in res), res

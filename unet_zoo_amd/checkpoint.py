@@ -1,51 +1,73 @@
-"""Checkpoint I/O with the reference's file format (unet_zoo/utils/multi_gpu.py:39-87).
+"""Checkpoint I/O in the reference's file format (unet_zoo/utils/multi_gpu.py:39-87).
 
-The HIP models register their parameters under the reference's names, shapes and order (the seed-0 manifests in
-tests/golden pin that), and the kernel-layout copies of the weights are rebuilt from the fp32 masters on the next
-forward, so a ``.pth`` written by the reference's ``save_model_state`` loads unmodified — and the other way round.
+A checkpoint is ``torch.save`` of the bare ``state_dict`` of the UNWRAPPED model.  The HIP models register their
+parameters under the reference's names, shapes and order (the seed-0 manifests in tests/golden pin that) and rebuild
+their kernel-layout weight copies from the fp32 masters on the next forward, so a ``.pth`` written by the reference
+loads here unmodified, and one written here loads in the reference.
+
+Behaviour kept from the reference's loader: a missing file leaves the model untouched (a warning, no exception);
+keys saved from a wrapper lose their ``module.`` prefix; a strict load is tried first and a non-strict one second; if
+both fail the model keeps its current weights.  The return value is the model that was passed in.
 """
 from __future__ import annotations
 
 import os
-from typing import Dict
+from collections import OrderedDict
+from typing import Dict, Mapping
 
 import torch
 import torch.nn as nn
 
+_PREFIX = "module."
+
+
+def _wrapper_types() -> tuple:
+    from .parallel import RcclDataParallel
+    return (nn.DataParallel, nn.parallel.DistributedDataParallel, RcclDataParallel)
+
 
 def _unwrap(model: nn.Module) -> nn.Module:
-    return model.module if hasattr(model, "module") and isinstance(model.module, nn.Module) else model
+    """the module inside a data-parallel wrapper (only the three wrapper classes: a model that merely HAS an
+    attribute called `module` is left alone)"""
+    return model.module if isinstance(model, _wrapper_types()) else model
 
 
-def strip_module_prefix(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    """keys saved from a DataParallel / DDP wrapper carry 'module.' (multi_gpu.py:44-53)"""
-    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+def strip_module_prefix(state_dict: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    out: Dict[str, torch.Tensor] = OrderedDict()
+    for key, value in state_dict.items():
+        out[key[len(_PREFIX):] if key.startswith(_PREFIX) else key] = value
+    return out
 
 
 def save_model_state(model: nn.Module, path: str) -> None:
-    """multi_gpu.py:39-42: the unwrapped model's state_dict"""
-    torch.save(_unwrap(model).state_dict(), path)
+    """Tensors are detached copies: after GraphedStep / FlatClipAdamW the parameters are views of one flat buffer,
+    and a saved view would drag the whole buffer's storage into the file."""
+    state = OrderedDict((k, v.detach().clone()) for k, v in _unwrap(model).state_dict().items())
+    torch.save(state, path)
+
+
+def _report(message: str) -> None:
+    print(message)
 
 
 def load_model_state(model: nn.Module, path: str, device) -> nn.Module:
-    """multi_gpu.py:55-87: missing file -> warning, model unchanged; strict load, then strict=False as a fallback"""
     if not os.path.exists(path):
-        print(f"Warning: Checkpoint file not found at {path}. Model weights not loaded.")
+        _report(f"Warning: no checkpoint at {path}; the model keeps its current weights.")
         return model
-    state_dict = strip_module_prefix(torch.load(path, map_location=device))
     target = _unwrap(model)
-    try:
-        target.load_state_dict(state_dict)
-        print(f"Model weights loaded successfully from {path} onto {device}.")
-    except RuntimeError as e:
-        print(f"Error loading state_dict: {e}")
-        print("Attempting to load with `strict=False` (might load partial weights).")
+    state = strip_module_prefix(torch.load(path, map_location=device))
+    loaded = False
+    for strict in (True, False):
         try:
-            target.load_state_dict(state_dict, strict=False)
-            print("Model weights loaded with strict=False (partial match).")
-        except Exception as e2:  # shape mismatches raise here too
-            print(f"Failed to load even with strict=False: {e2}")
-            print("Model state_dict could not be loaded. Model will use randomized weights.")
+            target.load_state_dict(state, strict=strict)
+        except Exception as err:  # noqa: BLE001  (size mismatches raise RuntimeError under either mode)
+            _report(f"load_state_dict(strict={strict}) failed for {path}: {err}")
+            continue
+        _report(f"Loaded {path} onto {device}" + ("." if strict else " with strict=False (partial match)."))
+        loaded = True
+        break
+    if not loaded:
+        _report(f"{path} could not be loaded; the model keeps its current weights.")
     cache = getattr(target, "_pack_cache", None)
     if cache is not None:
         cache.invalidate()      # kernel-layout copies are rebuilt from the loaded masters on the next forward

@@ -62,12 +62,20 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
 
 static inline int uz_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// tuning switches for in-process A/B measurements (tools/kbench.py): integer in env UZ_TUNE, default 0
+// Tuning / ablation switches for in-process A/B measurements (tools/kbench.py).  They exist only in a library
+// built with -DUZ_ABLATE (make ABLATE=1): the shipped libunetzoo_hip.so never reads the environment, its flags are
+// the constant 0, so no environment variable can change what a kernel computes or how it is launched.
 #include <stdlib.h>
+#ifdef UZ_ABLATE
 static inline int uz_tune_flags() {
   const char* e = getenv("UZ_TUNE");
   return e ? atoi(e) : 0;
 }
+static inline const char* uz_ablate_env(const char* name) { return getenv(name); }
+#else
+static inline int uz_tune_flags() { return 0; }
+static inline const char* uz_ablate_env(const char*) { return nullptr; }
+#endif
 
 // direct 3x3 convolution (uz_conv3x3.hip), dispatched from uz_conv_igemm()
 struct UzDirectPlan {

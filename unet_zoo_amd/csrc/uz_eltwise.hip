@@ -1319,6 +1319,13 @@ void uz_set_error(const char* fmt, ...) {
 }
 extern "C" const char* uz_last_error_string(void) { return g_err; }
 extern "C" int uz_abi_version(void) { return UZ_ABI_VERSION; }
+extern "C" int uz_build_ablate(void) {
+#ifdef UZ_ABLATE
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------
 // clip_grad_norm_ + AdamW over flat fp32 buffers (reference step tail, training_loop.py:119-121:

@@ -806,6 +806,12 @@ extern "C" int uz_fuse1x1_fwd(const float* d, int N, int HW, int Cc, int K, cons
   return UZ_OK;
 }
 
+__global__ void fuse_zero_kernel(float* __restrict__ a, int na, float* __restrict__ b, int nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) a[i] = 0.0f;
+  if (i < nb) b[i] = 0.0f;
+}
+
 extern "C" long long uz_fuse1x1_bwd_workspace_bytes(int N, int HW, int Cc, int K) {
   const int rc = fuse_check("uz_fuse1x1_bwd_workspace_bytes", N, HW, Cc, K);
   if (rc != UZ_OK) return rc;
@@ -833,9 +839,10 @@ extern "C" int uz_fuse1x1_bwd(const float* d, int N, int HW, int Cc, int K, cons
     hipLaunchKernelGGL(fuse_bwd_w_finalize_kernel, dim3(ne), dim3(64), 0, s, part, FUSE_CHUNKS, Cc, K, dw, db);
     UZ_LAUNCH_CHECK("uz_fuse1x1_bwd(finalize)");
   } else {
-    hipError_t e1 = hipMemsetAsync(dw, 0, sizeof(float) * K * Cc, s);
-    if (e1 == hipSuccess && db) e1 = hipMemsetAsync(db, 0, sizeof(float) * K, s);
-    UZ_REQUIRE(e1 == hipSuccess, "uz_fuse1x1_bwd: memset failed: %s", hipGetErrorString(e1));
+    // a kernel, not hipMemsetAsync: on this stack a memset NODE of a replayed hipGraph writes its value only in the
+    // first replay (tools/graph_canary.py), and every entry point must be capturable
+    hipLaunchKernelGGL(fuse_zero_kernel, dim3(uz_cdiv(K * Cc, 256)), dim3(256), 0, s, dw, K * Cc, db, db ? K : 0);
+    UZ_LAUNCH_CHECK("uz_fuse1x1_bwd(zero)");
   }
   return UZ_OK;
 }

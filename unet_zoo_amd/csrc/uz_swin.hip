@@ -2171,7 +2171,7 @@ static int attn_check(const char* fn, const uz_winattn_desc* d) {
 // windows of one head), so the grid must FIT: one workgroup more than the chip holds doubles the run time.
 // slots = resident workgroups per CU of the kernel; windows are dealt evenly (per-workgroup count first).
 static int attn_grid_fit(const uz_winattn_desc* d, long long units_x, int slots_per_cu) {
-  const char* e = getenv("UZ_ATTN_GX");   // measurement hook (tools/attn_bench.py)
+  const char* e = uz_ablate_env("UZ_ATTN_GX");   // measurement hook (tools/attn_bench.py)
   if (e && atoi(e) > 0) return (int)(atoi(e) < units_x ? atoi(e) : units_x);
   long long cap = (long long)UZ_NUM_CU * slots_per_cu / d->heads;
   if (cap < 1) cap = 1;

@@ -364,7 +364,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
   if (max_split > 256) max_split = 256;
   {
-    const char* e = getenv("UZ_WG_SPLIT");   // experiment hook: cap of the pixel split of one-tap problems
+    const char* e = uz_ablate_env("UZ_WG_SPLIT");   // experiment hook: cap of the pixel split of one-tap problems
     if (e && p->one_tap && atoi(e) > 0 && max_split > atoi(e)) max_split = atoi(e);
   }
   if (split > max_split) split = max_split;

@@ -128,20 +128,33 @@ class PhasedStep:
         self._gouts: Optional[Tuple[Optional[torch.Tensor], ...]] = None
 
     def forward(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        self.emit(x)
+        return self.loss(target)
+
+    def emit(self, x: torch.Tensor):
+        """the model's forward on a fresh engine; returns (and keeps as `outputs`) the wrapped outputs"""
         m = self.model
         L.load()
         L.require_cuda(x)
         m._pack_cache.refresh(m.run_dtype)
         self.eng = Engine(m.run_dtype, x.device, m.training, True, None, m._pack_cache, True)
         with torch.no_grad():
-            outs = tuple(m.emit(self.eng, x))
+            self._outs = tuple(m.emit(self.eng, x))
             self.eng.finish_forward()
-        leaves = tuple(o.detach().requires_grad_(True) for o in outs)
-        self.outputs = m.wrap_outputs(tuple(o.detach() for o in outs))
+        self.outputs = m.wrap_outputs(tuple(o.detach() for o in self._outs))
+        return self.outputs
+
+    def loss(self, target: torch.Tensor) -> torch.Tensor:
+        """loss_fn on the outputs of the last emit(); leaves d(loss)/d(output) for backward(..., heads=True)"""
+        leaves = tuple(o.detach().requires_grad_(True) for o in self._outs)
         with torch.enable_grad():
-            loss = self.loss_fn(m.wrap_outputs(leaves), target)
+            loss = self.loss_fn(self.model.wrap_outputs(leaves), target)
             self._gouts = torch.autograd.grad(loss, leaves, allow_unused=True)
         return loss.detach()
+
+    def set_output_grads(self, gouts: Sequence[Optional[torch.Tensor]]) -> None:
+        """use these tensors as d(loss)/d(output) (static buffers of a captured backward)"""
+        self._gouts = tuple(gouts)
 
     @property
     def n_entries(self) -> int:
@@ -155,6 +168,7 @@ class PhasedStep:
         self.eng.tape.clear()
         self.eng = None
         self._gouts = None
+        self._outs = None
 
     def plan(self, fractions: Sequence[float] = (0.45, 0.85)):
         """After one complete forward + backward(n_entries, 0, True): cut the backward where the

@@ -1,0 +1,144 @@
+"""One process per GPU: the launcher behind ``bench.py --gpus N`` and any ``ddp_rccl`` training script.
+
+The reference parallelises with a single-process ``nn.DataParallel`` wrapper
+(unet_zoo/utils/multi_gpu.py:20-31); here every GPU gets its own process and gradients meet in RCCL
+all-reduces.  ``spawn_ranks`` is what turns "run on N GPUs" into N processes:
+
+* it must be called BEFORE the calling process makes any GPU call (it only counts devices, which does not
+  initialise the runtime), because a process that has touched the GPU must not be duplicated or re-executed;
+* every child is a FRESH interpreter (``subprocess``, no fork of torch state) with ``RANK``, ``LOCAL_RANK``,
+  ``WORLD_SIZE``, ``MASTER_ADDR=127.0.0.1``, ``MASTER_PORT`` and ``HSA_ENABLE_IPC_MODE_LEGACY=0`` set — the same
+  contract ``python -m torch.distributed.run`` gives, so a script works under either;
+* rank 0's stdout is relayed verbatim (the one JSON line of bench.py), the other ranks' stdout goes to stderr with a
+  ``[rank k]`` prefix;
+* the exit code is non-zero when any rank fails (the survivors are terminated by their exact PIDs) and when fewer
+  than N GPUs are visible — never a silent single-rank run.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+import threading
+import time
+from typing import Dict, List, Optional, Sequence
+
+RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE")
+
+
+def visible_gpus() -> int:
+    """Number of visible GPUs WITHOUT initialising the HIP runtime in this process."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def under_launcher(env: Optional[Dict[str, str]] = None) -> bool:
+    """True inside a rank process (this launcher's or torch.distributed.run's)."""
+    env = os.environ if env is None else env
+    return "WORLD_SIZE" in env and "RANK" in env
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
+    """Environment of one rank (single node: LOCAL_RANK == RANK)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    return env
+
+
+def _pump(stream, sink, prefix: str) -> None:
+    for line in iter(stream.readline, ""):
+        sink.write(prefix + line)
+        sink.flush()
+    stream.close()
+
+
+def spawn_ranks(world: int, argv: Sequence[str], *, need_gpus: bool = True, port: Optional[int] = None,
+                env: Optional[Dict[str, str]] = None, poll_s: float = 0.1, stdout=None, stderr=None) -> int:
+    """Run ``argv`` as `world` rank processes; returns the exit code the caller should exit with.
+
+    argv        the child command line (e.g. [sys.executable, "bench.py", "--gpus", "4", ...])
+    need_gpus   refuse (exit code 2, message on stderr) when fewer than `world` GPUs are visible
+    """
+    stdout = sys.stdout if stdout is None else stdout
+    stderr = sys.stderr if stderr is None else stderr
+    if world < 1:
+        stderr.write(f"launch: --gpus must be >= 1, got {world}\n")
+        return 2
+    if under_launcher(env):
+        stderr.write("launch: already inside a rank process (RANK / WORLD_SIZE are set); refusing to nest\n")
+        return 2
+    if need_gpus:
+        have = visible_gpus()
+        if have < world:
+            stderr.write(f"launch: {world} ranks requested but only {have} GPU(s) visible; refusing to run "
+                         f"fewer ranks than asked (no number is reported)\n")
+            return 2
+    port = free_port() if port is None else port
+    procs: List[subprocess.Popen] = []
+    pumps: List[threading.Thread] = []
+    for r in range(world):
+        p = subprocess.Popen(list(argv), env=rank_env(r, world, port, env), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        out_sink, out_prefix = (stdout, "") if r == 0 else (stderr, f"[rank {r}] ")
+        for stream, sink, prefix in ((p.stdout, out_sink, out_prefix), (p.stderr, stderr, f"[rank {r}] " if world > 1 else "")):
+            t = threading.Thread(target=_pump, args=(stream, sink, prefix), daemon=True)
+            t.start()
+            pumps.append(t)
+    rc = 0
+    alive = set(range(world))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                stderr.write(f"launch: rank {r} exited with code {code}; stopping the other ranks\n")
+                for o in sorted(alive):          # exact PIDs of our own children, never a pattern
+                    procs[o].terminate()
+        if alive:
+            time.sleep(poll_s)
+            if rc != 0:
+                deadline = time.time() + 10.0
+                while any(procs[o].poll() is None for o in alive) and time.time() < deadline:
+                    time.sleep(poll_s)
+                for o in alive:
+                    if procs[o].poll() is None:
+                        procs[o].kill()
+    for t in pumps:
+        t.join(timeout=5.0)
+    return rc
+
+
+def rank_info(env: Optional[Dict[str, str]] = None):
+    """(rank, local_rank, world) of this process; (0, 0, 1) outside a launcher."""
+    env = os.environ if env is None else env
+    return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), int(env.get("WORLD_SIZE", "1"))
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    """python -m unet_zoo_amd.launch --gpus N script.py [script args]"""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m unet_zoo_amd.launch",
+                                 description="start one rank process per GPU of this node")
+    ap.add_argument("--gpus", type=int, required=True)
+    ap.add_argument("--cpu", action="store_true", help="do not require GPUs (gloo rehearsals)")
+    ap.add_argument("script")
+    ap.add_argument("args", nargs=argparse.REMAINDER)
+    a = ap.parse_args(argv)
+    return spawn_ranks(a.gpus, [sys.executable, a.script] + a.args, need_gpus=not a.cpu)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

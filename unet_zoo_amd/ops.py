@@ -63,7 +63,13 @@ class Act:
         if self.colsums is None:
             return None
         part, o = self.colsums
-        return part[:, 0, o:o + self.C].sum(0)
+        # own kernel rather than part[:, 0, o:o+C].sum(0): no library reduction on the (capturable) hot path --
+        # torch's multi-block reductions reset their semaphores with a memset node, which a replayed hipGraph
+        # executes correctly only once on this stack
+        out = torch.empty(self.C, dtype=torch.float32, device=part.device)
+        L.check(L.load().uz_sum_rows_f32_ld(part.data_ptr() + 4 * o, part.shape[1] * part.shape[2], part.shape[0],
+                                            self.C, out.data_ptr(), self.C, None, L.stream_ptr()), "uz_sum_rows_f32_ld")
+        return out
 
     def add_grad(self, g: "Act") -> None:
         """Register a gradient contribution; a concat view forwards channel windows to its parts."""

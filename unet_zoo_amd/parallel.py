@@ -34,6 +34,11 @@ class BucketReducer:
         self._where: Dict[nn.Parameter, tuple] = {}   # param -> (bucket index, offset)
         self._pending: List = []
         self._first_grads: Dict[nn.Parameter, torch.Tensor] = {}
+        # a parameter may receive several contributions in one backward (the engine calls push() with the running
+        # sum each time): the planning backward counts them, later backwards launch a bucket only when every
+        # member has received its LAST one
+        self._expect: Dict[nn.Parameter, int] = {}
+        self._got: Dict[nn.Parameter, int] = {}
         dev = self.params[0].device if self.params else torch.device("cpu")
         self._cuda = dev.type == "cuda"
         self._comm_stream = torch.cuda.Stream(device=dev) if self._cuda else None
@@ -59,7 +64,8 @@ class BucketReducer:
             for p in g:
                 self._where[p] = (bi, off)
                 off += p.numel()
-            self._buckets.append({"flat": flat, "members": g, "have": 0})
+            need = sum(self._expect[p] for p in g)
+            self._buckets.append({"flat": flat, "members": g, "need": need, "left": need})
         self._planned = True
 
     # -- per-backward API ------------------------------------------------------------------
@@ -71,12 +77,21 @@ class BucketReducer:
             if p not in self._first_grads:
                 self._order.append(p)
             self._first_grads[p] = g
+            self._expect[p] = self._expect.get(p, 0) + 1
             return
+        if p not in self._where:
+            raise RuntimeError("a parameter received a gradient that did not in the planning backward: the set of "
+                               "parameters receiving gradients changed between iterations")
         bi, off = self._where[p]
         b = self._buckets[bi]
+        got = self._got.get(p, 0) + 1
+        if got > self._expect[p]:
+            raise RuntimeError("a parameter received more gradient contributions than in the planning backward")
+        self._got[p] = got
+        # every contribution is the running sum: the last copy holds the final gradient
         b["flat"][off:off + p.numel()].copy_(g.reshape(-1))
-        b["have"] += 1
-        if b["have"] == len(b["members"]):
+        b["left"] -= 1
+        if b["left"] == 0:
             self._launch(b)
 
     def _launch(self, b: Dict) -> None:
@@ -108,7 +123,7 @@ class BucketReducer:
                 self._launch(b)
         else:
             for b in self._buckets:
-                if 0 < b["have"] < len(b["members"]):
+                if b["left"] != 0:
                     raise RuntimeError("a gradient bucket is incomplete: the set of parameters "
                                        "receiving gradients changed between iterations")
         inv = 1.0 / self.world
@@ -125,14 +140,23 @@ class BucketReducer:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         # hand out views of a per-bucket copy: the bucket buffers are overwritten by the next
         # backward, while .grad may live on (gradient accumulation)
-        outs = []
+        self._got.clear()
+        outs: List[Optional[torch.Tensor]] = [None] * len(self._buckets)
         for b in self._buckets:
-            b["have"] = 0
-            outs.append(b["flat"].clone())
+            b["left"] = b["need"]
         for p in list(grads.keys()):
-            if p in self._where:
-                bi, off = self._where[p]
-                grads[p] = outs[bi][off:off + p.numel()].view_as(p)
+            if p not in self._where:
+                continue
+            bi, off = self._where[p]
+            if grads[p] is None:
+                # in-place mode (HipModule.grads_in_place): the local gradient already sits in p.grad and autograd
+                # gets None for it, so the average goes back into p.grad -- handing it out would ADD it on top
+                if p.grad is not None:
+                    p.grad.copy_(self._buckets[bi]["flat"][off:off + p.numel()].view_as(p))
+                continue
+            if outs[bi] is None:
+                outs[bi] = self._buckets[bi]["flat"].clone()
+            grads[p] = outs[bi][off:off + p.numel()].view_as(p)
 
 
 class RcclDataParallel(nn.Module):
@@ -142,6 +166,9 @@ class RcclDataParallel(nn.Module):
 
     def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 25.0,
                  broadcast_from_rank0: bool = True):
+        """Parameters and buffers are broadcast from rank 0 ONCE here.  BatchNorm running statistics are then
+        updated from each rank's own shard and drift apart, exactly as the replicas of the reference's
+        nn.DataParallel do (only replica 0's statistics survive there): checkpoints are rank 0's to write."""
         super().__init__()
         self.module = module
         self.reducer = BucketReducer(list(module.parameters()), process_group, int(bucket_mb * (1 << 20)))
