@@ -272,3 +272,48 @@ def test_outconv_fwd_bwd(dt, K):
     assert relerr(dx.dense().cpu(), x.grad) < tol(dt)
     assert relerr(dw.cpu(), w.grad.reshape(K, C)) < 1e-4
     assert relerr(db.cpu(), b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,win,ups", [
+    (2, 16, 64, 64, 64, 0, False),      # the DoubleConv 64 -> 64 layer, several tiles per workgroup column
+    (1, 50, 70, 64, 64, 0, False),      # ragged in both directions
+    (3, 9, 40, 32, 64, 0, False),       # half a K slab (zero-filled by the descriptor range check)
+    (2, 24, 33, 16, 32, 0, False),      # Cin 16, Nout 32: tails on both sides
+    (1, 32, 32, 64, 128, 0, False),     # two workgroup columns of 64 output channels
+    (2, 12, 20, 64, 64, 0, False),      # W < 32: 16x16 patches
+    (1, 20, 36, 64, 192, 64, False),    # input is a channel window of a wider (NaN-poisoned) buffer
+    (2, 16, 48, 64, 64, 0, True),       # nearest x2 upsampled input (UpConvBlock)
+    (32, 32, 32, 64, 64, 0, False),     # more tiles than one wave of workgroups: the deferred epilogue of waves 4-7
+])
+def test_conv3x3_res64_register_resident_weights(N, H, W, Cin, Cout, win, ups):
+    """bf16, Cin <= 64: conv3x3_res64_kernel (weights in registers, wave-local epilogue, waves 4-7 half a tile
+    behind) against F.conv2d on the same rounded operands, with bias and the BatchNorm partial sums"""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    Hi, Wi = (H // 2, W // 2) if ups else (H, W)
+    x = rnd(dt, torch.randn(N, Cin, Hi, Wi, generator=g))
+    w = rnd(dt, torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05)
+    b = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    ref = F.conv2d(xin, w, b, padding=1)
+    xa = act_from_nchw(x.to(DEV), dt)
+    if win:
+        wide = torch.full((xa.P, Cin + 2 * win), float("nan"), dtype=dt, device=DEV)
+        wide[:, win:win + Cin] = xa.buf
+        xa = Act(wide, win, Cin, N, Hi, Wi)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt)
+    y = ops.new_act(N, H, W, Cout, dt, DEV)
+    y.buf.fill_(float("nan"))
+    stats = ops.conv_igemm(xa, wp, b.to(DEV), y, ntaps=9, want_stats=True,
+                           taps_mode=L.TAPS_CONV_UP2 if ups else L.TAPS_CONV)
+    got = y.dense().cpu()
+    assert torch.isfinite(got).all()
+    assert relerr(got, ref) < tol(dt)
+    s = stats.double().sum(0).cpu()
+    assert relerr(s[0], got.double().sum((0, 2, 3))) < 3e-3
+    assert relerr(s[1], (got.double() ** 2).sum((0, 2, 3))) < 1e-4
+    # bitwise repeatable (fixed reduction order, no atomics)
+    y2 = ops.new_act(N, H, W, Cout, dt, DEV)
+    stats2 = ops.conv_igemm(xa, wp, b.to(DEV), y2, ntaps=9, want_stats=True,
+                            taps_mode=L.TAPS_CONV_UP2 if ups else L.TAPS_CONV)
+    assert torch.equal(y.buf, y2.buf) and torch.equal(stats, stats2)

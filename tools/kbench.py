@@ -2,6 +2,9 @@
    python tools/kbench.py [conv|wgrad|all] [--tune A,B,...]   (UZ_TUNE variants measured interleaved)"""
 import os
 import sys
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the UZ_TUNE switches exist only in the ablation build (make -C unet_zoo_amd/csrc ABLATE=1)
+os.environ.setdefault("UNET_ZOO_AMD_LIB", os.path.join(_ROOT, "unet_zoo_amd", "libunetzoo_hip_ablate.so"))
 import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from unet_zoo_amd import _lib as L, ops
@@ -14,7 +17,7 @@ ONLY = os.environ.get("KB_ONLY")
 LAYERS = [("e1b", 256, 64, 64), ("e2a", 128, 64, 128), ("e2b", 128, 128, 128), ("e3a", 64, 128, 256),
           ("e3b", 64, 256, 256), ("e4a", 32, 256, 512), ("e4b", 32, 512, 512), ("bna", 16, 512, 1024),
           ("bnb", 16, 1024, 1024), ("d1a", 32, 1024, 512), ("d2a", 64, 512, 256), ("d3a", 128, 256, 128),
-          ("d4a", 256, 128, 64)]
+          ("d4a", 256, 128, 64), ("d4ad", 256, 64, 128), ("n32", 256, 32, 32)]
 
 def timeit(fn, n=20):
     fn(); torch.cuda.synchronize()

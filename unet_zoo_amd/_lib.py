@@ -18,7 +18,9 @@ STORE_PLAIN, STORE_SHUFFLE2X2 = 0, 1
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD, PACK_IM2COL = range(5)
 
 LIB_NAME = "libunetzoo_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# UNET_ZOO_AMD_LIB: another build of the same ABI (tools/kbench.py points it at the ablation build); the product
+# never sets it, and bench.py refuses a library whose uz_build_ablate() is 1
+LIB_PATH = os.environ.get("UNET_ZOO_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 # every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (

@@ -65,7 +65,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor's num_records (tensors < 2 GiB)
+constexpr unsigned OOB = 0x10000000u;  // beyond any descriptor's num_records (tensors < 2 GiB)
 
 template <typename T, int TW, int BN, bool BRES>
 __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs a) {
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     b_sw[j] = (brow >> 1) & 7;
   }
 
+  if ((a.flags & 0x20) && wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int ncb = (a.Cin + BK - 1) / BK;  // the last slab may be partial: channels >= Cin read as zero
   float s1[TN], s2[TN];
 #pragma unroll
@@ -354,33 +355,41 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
           int c0, t0, c1 = 0, t1 = 0;
           unit(L0, c0, t0);
           if (L1 < nsteps) unit(L1, c1, t1);
-          if (d + 1 < ndbl) {  // weight tiles of the next double-step into the other slot pair
-            const int s2 = ((d + 1) & 1) * 2;
-            int c, t;
-            unit(L0 + 2, c, t);
-            issue_b(s2, c, t);
-            if (L0 + 3 < nsteps) {
-              unit(L0 + 3, c, t);
-              issue_b(s2 + 1, c, t);
-            }
-          }
-          kprev = 0;
-          if (c0 != npslab) {
-            npslab = c0;
-            np = 0;
-          }
-          // both units of this double-step lie in slabs >= c0, so buffer (c0 + 1) & 1 (last read by slab
-          // c0 - 1) is free unless the second unit already belongs to slab c0 + 1 (t0 == 8: nothing left to issue)
-          if (c0 + 1 < ncb && t0 < 8) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-              if (np < APW) {
-                if (issue_a_piece(np, (c0 + 1) & 1, c0 + 1, img, h0, w0)) ++kprev;
-                ++np;
+          auto issue_next = [&]() {
+            if (d + 1 < ndbl) {  // weight tiles of the next double-step into the other slot pair
+              const int s2 = ((d + 1) & 1) * 2;
+              int c, t;
+              unit(L0 + 2, c, t);
+              issue_b(s2, c, t);
+              if (L0 + 3 < nsteps) {
+                unit(L0 + 3, c, t);
+                issue_b(s2 + 1, c, t);
               }
-          }
+            }
+            kprev = 0;
+            if (c0 != npslab) {
+              npslab = c0;
+              np = 0;
+            }
+            // both units of this double-step lie in slabs >= c0, so buffer (c0 + 1) & 1 (last read by slab
+            // c0 - 1) is free unless the second unit already belongs to slab c0 + 1 (t0 == 8: nothing left to issue)
+            if (c0 + 1 < ncb && t0 < 8) {
+#pragma unroll
+              for (int k = 0; k < 2; ++k)
+                if (np < APW) {
+                  if (issue_a_piece(np, (c0 + 1) & 1, c0 + 1, img, h0, w0)) ++kprev;
+                  ++np;
+                }
+            }
+          };
           const int s0 = (d & 1) * 2;
+          // the two waves of a SIMD (w, w + 4) run the same program in lockstep: with `late` the second one issues
+          // its LDS-DMA pieces AFTER its first unit, so one wave's issue runs beside the other's MFMAs
+          // (+2 ... 4.5 % on every non-resident layer; flag 0x10 of the ablation build switches it off)
+          const bool late = !(a.flags & 0x10) && wave >= 4;
+          if (!late) issue_next();
           compute(t0, c0 & 1, s0);
+          if (late) issue_next();
           if (L1 < nsteps) compute(t1, c1 & 1, s0 + 1);
         }
         cbuf = 0;
@@ -561,6 +570,284 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Resident-weight kernel, second generation (bf16, Cin <= 64 = one K slab, 64 output channels per
+// workgroup): the memory-bound DoubleConv layers (64 -> 64 at full resolution, common_layers.py:31)
+// and every other layer whose input has at most 64 channels.
+//
+//  * The workgroup's [64][9 * 64] weight matrix lives in REGISTERS, not LDS: wave (wm, wn) keeps the
+//    fragments of its 32 output channels for all nine taps (36 x 16 bytes per lane = 144 VGPRs, loaded
+//    once).  LDS then holds only activation patches, and a (tap, K-chunk) group costs the LDS one read
+//    per 32 MFMA cycles instead of 1.5.
+//  * The epilogue is WAVE-LOCAL: a wave transposes its own 64 pixel x 32 channel tile through a
+//    private 4 KB staging area (8-byte writes, 16-byte reads, no workgroup barrier) and stores 64
+//    contiguous bytes per pixel.
+//  * The two waves that share a SIMD (w and w + 4) run half a tile apart: waves 4-7 ("late") issue ALL
+//    LDS-DMA pieces of the next patch and then run the epilogue of the PREVIOUS tile while waves 0-3
+//    are in their MFMA stream; when waves 0-3 reach their epilogue, waves 4-7 are in theirs.  One
+//    s_barrier per tile, the matrix pipe of every SIMD has work the whole interval.
+//  * MFMA shape: S = 32 (v_mfma_f32_32x32x16_bf16) or S = 16 (v_mfma_f32_16x16x32_bf16), same LDS and
+//    register traffic; the chip holds a higher clock on the 16x16x32 stream.
+template <int TW, int S, int DEPTH>
+__global__ __launch_bounds__(512, 2) void conv3x3_res64_kernel(const DirectArgs a) {
+  typedef bf16_t T;
+  constexpr int VEC = 8, ES = 2, BK = 64;
+  // The patch is stored COLUMN-major with an odd column height: LDS row of patch pixel (pi, pj) = pj * PHP + pi,
+  // 16-byte chunks XOR-swizzled with key(pj) = (pj >> 1) & 7.  A tap (ty, tx) then moves a lane's read by
+  // ty * 128 bytes (an immediate offset of the ds_read) and selects one of three per-lane base registers (tx),
+  // the K chunk is one XOR with a constant: ~1 VALU per read instead of 5 -- with the weights in registers
+  // nothing else can stay hoisted, and two waves share a SIMD's issue port.  Odd PHP makes the row parity
+  // alternate along pj, which together with the key keeps every ds_read_b128 lane group conflict-free.
+  constexpr int TH = 256 / TW, PH = TH + 2, PW = TW + 2, PHP = PH | 1, PROWS = PW * PHP;
+  constexpr int APIECES = (PROWS + 7) / 8;
+  constexpr int A_BYTES = APIECES * 1024;
+  constexpr int MT = 64 / S, NT = 32 / S;        // MFMA tiles of a wave: 64 pixels x 32 channels
+  constexpr int KC = (S == 32) ? 16 : 32;        // K of one MFMA
+  constexpr int NKC = BK / KC;                   // K chunks per tap
+  constexpr int CPK = KC / 8;                    // 16-byte chunks per K chunk (lane / S selects one)
+  constexpr int NACC = (S == 32) ? 16 : 4;
+  typedef float accv_t __attribute__((ext_vector_type(NACC)));
+  // LDS: two activation patches | 8 wave-private staging areas | bias table [64] | per-thread statistics [512][16]
+  constexpr int OFF_BIAS = 2 * A_BYTES + 8 * 4096, OFF_STAT = OFF_BIAS + 256;
+  __shared__ __attribute__((aligned(16))) char smem[OFF_STAT + 512 * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool late = wave >= 4;
+  const int ls = lane % S, lq = lane / S;
+  const int n0 = blockIdx.y * 64;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
+  T* __restrict__ yg = static_cast<T*>(a.y);
+  char* const sCw = smem + 2 * A_BYTES + wave * 4096;
+
+  // ---- weights into registers: breg[tap][kc][u] = 8 K-elements of channel n0 + wn*32 + u*S + ls ----
+  bf16x8 breg[9][NKC][NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int n = n0 + wn * 32 + u * S + ls;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        const int kk = kc * KC + lq * 8;
+        const unsigned off = (n < a.Nout && kk < a.Cin) ? ((unsigned)n * (unsigned)a.K + tap * a.Cin + kk) * ES : OOB;
+        auto v = __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0);
+        breg[tap][kc][u] = *reinterpret_cast<bf16x8*>(&v);
+      }
+  }
+
+  // ---- per-lane constants ----------------------------------------------------------------------
+  int abase[MT][3];   // LDS byte offset of this lane's K-chunk-0 read of M tile t at tap (0, tx)
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = 64 * wm + t * S + ls;
+    const int pi = (TW == 32) ? (m >> 5) : (m >> 4), pj = (TW == 32) ? (m & 31) : (m & 15);
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) abase[t][tx] = ((pj + tx) * PHP + pi) * 128 + ((lq ^ (((pj + tx) >> 1) & 7)) << 4);
+  }
+  // registers are the scarce resource (144 hold weights): the bias sits in an LDS table and is the accumulators'
+  // initial value, the running BatchNorm sums of a thread live in LDS between epilogues
+  float* const sBias = reinterpret_cast<float*>(smem + OFF_BIAS);
+  f32x4* const sStat = reinterpret_cast<f32x4*>(smem + OFF_STAT + tid * 64);
+  if (tid < 64) sBias[tid] = (a.bias != nullptr && n0 + tid < a.Nout) ? a.bias[n0 + tid] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sStat[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto decode = [&](int tile, int& im, int& hh0, int& ww0) {
+    const int per = a.th_n * a.tw_n;
+    im = tile / per;
+    const int rem = tile - im * per;
+    const int ti = rem / a.tw_n;
+    hh0 = ti * TH;
+    ww0 = (rem - ti * a.tw_n) * TW;
+  };
+  // the four late waves bring the whole patch: piece = (wave - 4) + 4 i
+  auto issue_patch = [&](int buf, int im, int hh0, int ww0) {
+#pragma unroll 1
+    for (int piece = wave - 4; piece < APIECES; piece += 4) {
+      const int r = piece * 8 + (lane >> 3);
+      const int pj = r / PHP, pi = r - pj * PHP;
+      const int hh = hh0 - 1 + pi, ww = ww0 - 1 + pj;
+      const int ch = ((lane & 7) ^ ((pj >> 1) & 7)) * VEC;
+      const bool ok = r < PROWS && pi < PH && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && ch < a.Cin;
+      const unsigned pix = a.ups ? (unsigned)((im * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1))
+                                 : (unsigned)((im * a.H + hh) * a.W + ww);
+      const unsigned off = ok ? (pix * (unsigned)a.ldx + ch) * ES : OOB;
+      dma16(xr, smem + buf * A_BYTES + piece * 1024, off);
+    }
+  };
+
+  accv_t acc[MT][NT];
+  auto mma = [&](const bf16x8& w8, const bf16x8& x8, accv_t& c) {
+    if constexpr (S == 32) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w8, x8, c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w8, x8, c, 0, 0, 0);
+  };
+  // 9 * NKC groups as one software pipeline: group g + 1's MT reads are issued ahead of group g's MFMAs
+  auto compute_tile = [&](int abuf) {
+    const char* sA = smem + abuf * A_BYTES;
+    // a pipeline step = (tap, K chunk, pair of M tiles): 2 reads, 2 * NT MFMAs
+    // DEPTH register sets: a step's reads are issued DEPTH - 1 steps (64 MFMA cycles each) ahead of its MFMAs.
+    // The two waves of a SIMD compute at different times here, so a wave must cover its LDS latency alone.
+    constexpr int MP = MT / 2, NSTEP = 9 * NKC * MP;
+    bf16x8 af[DEPTH][2];
+    // keep the 3 * MT bases in registers and derive every other address next to its read (XOR + immediate
+    // offset): hoisted out of the tile loop the 9 * NKC * MT addresses would take as many registers as the weights
+    int ab[MT][3];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        ab[t][tx] = abase[t][tx];
+        asm volatile("" : "+v"(ab[t][tx]));
+      }
+    auto load_step = [&](int sidx, int set) {
+      const int g = sidx / MP, mp = sidx - g * MP;
+      const int tap = g / NKC, kc = g - tap * NKC;
+      const int ty = tap / 3, tx = tap - 3 * ty;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[set][i] = *reinterpret_cast<const bf16x8*>(sA + (ab[2 * mp + i][tx] ^ (kc * CPK * 16)) + ty * 128);
+      }
+    };
+    // step s + DEPTH - 1's reads are issued before step s's MFMAs; full scheduling barriers pin that
+    // order -- left alone, or with sched_group_barrier hints in a body this long, the scheduler folds the sets into
+    // one and every MFMA pair waits for an LDS round trip
+#pragma unroll
+    for (int p = 0; p < DEPTH - 1; ++p) load_step(p, p);
+#pragma unroll
+    for (int sidx = 0; sidx < NSTEP; ++sidx) {
+      if (sidx + DEPTH - 1 < NSTEP) load_step(sidx + DEPTH - 1, (sidx + DEPTH - 1) % DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+      const int g = sidx / MP, mp = sidx - g * MP;
+      const int tap = g / NKC, kc = g - tap * NKC;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) mma(breg[tap][kc][u], af[sidx % DEPTH][i], acc[2 * mp + i][u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // wave-local epilogue of the tile whose accumulators the wave holds
+  auto epilogue = [&](int im, int hh0, int ww0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int px = t * S + ls;
+      char* rowp = sCw + px * 64;
+      const int psw = (px >> 1) & 3;
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int q = 0; q < NACC / 4; ++q) {
+          bf16x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)acc[t][u][4 * q + e];
+          const int c0 = u * S + ((S == 32) ? (8 * q + 4 * lq) : (4 * lq));   // first of 4 consecutive channels
+          *reinterpret_cast<bf16x4*>(rowp + ((((c0 >> 3) ^ psw)) << 4) + (c0 & 4) * 2) = pk;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own writes have executed
+    Vec16<T> vb[4];
+    const int cc = lane & 3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int px = (lane >> 2) + 16 * k;
+      vb[k] = *reinterpret_cast<const Vec16<T>*>(sCw + px * 64 + ((cc ^ ((px >> 1) & 3)) << 4));
+    }
+    const int n = n0 + wn * 32 + cc * VEC;
+    float sq1[VEC], sq2[VEC];
+    {
+      const f32x4 s0 = sStat[0], s1 = sStat[1], s2 = sStat[2], s3 = sStat[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sq1[e] = s0[e];
+        sq1[4 + e] = s1[e];
+        sq2[e] = s2[e];
+        sq2[4 + e] = s3[e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int m = 64 * wm + (lane >> 2) + 16 * k;
+      const int pi = (TW == 32) ? (m >> 5) : (m >> 4), pj = (TW == 32) ? (m & 31) : (m & 15);
+      const int hh = hh0 + pi, ww = ww0 + pj;
+      if (hh < a.H && ww < a.W && n < a.Nout) {
+        if (!(a.flags & 0x1)) st16(yg + ((size_t)(im * a.H + hh) * a.W + ww) * a.ldy + n, vb[k]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float fv = (float)vb[k].v[e];
+          sq1[e] += fv;
+          sq2[e] += fv * fv;
+        }
+      }
+    }
+    sStat[0] = f32x4{sq1[0], sq1[1], sq1[2], sq1[3]};
+    sStat[1] = f32x4{sq1[4], sq1[5], sq1[6], sq1[7]};
+    sStat[2] = f32x4{sq2[0], sq2[1], sq2[2], sq2[3]};
+    sStat[3] = f32x4{sq2[4], sq2[5], sq2[6], sq2[7]};
+  };
+
+  int img = 0, h0 = 0, w0 = 0, pimg = 0, ph0 = 0, pw0 = 0;
+  if (late) {
+    decode(blockIdx.x, img, h0, w0);
+    issue_patch(0, img, h0, w0);
+  }
+  wait_vmcnt<0>();   // everyone's weight registers
+  int it = 0;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
+    decode(tile, img, h0, w0);
+    // late waves: this tile's patch pieces (issued a whole interval ago) have landed.  The early waves issued no DMA
+    // and must NOT wait here: their youngest memory operations are the previous tile's output stores
+    if (late) wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (late) {
+      const int next = tile + gridDim.x;
+      if (next < a.ntiles && !(a.flags & 0x2)) {
+        int im2, hh2, ww2;
+        decode(next, im2, hh2, ww2);
+        issue_patch((it + 1) & 1, im2, hh2, ww2);
+      }
+      if (it > 0) epilogue(pimg, ph0, pw0);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int q = 0; q < NACC / 4; ++q) {
+        // accumulator registers 4q .. 4q+3 of N tile u are 4 consecutive channels
+        const int c0 = wn * 32 + u * S + ((S == 32) ? (8 * q + 4 * lq) : (4 * lq));
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + c0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][u][4 * q + e] = b4[e];
+      }
+    compute_tile(it & 1);
+    if (!late) epilogue(img, h0, w0);
+    pimg = img;
+    ph0 = h0;
+    pw0 = w0;
+  }
+  if (late && it > 0) epilogue(pimg, ph0, pw0);
+
+  if (a.stats != nullptr) {
+    __syncthreads();
+    const float* red = reinterpret_cast<const float*>(smem + OFF_STAT);  // [512][2 * VEC]
+    if (tid < 128) {  // (which, channel): the 64 threads (4 wm x 16 lanes) that own this channel's chunk, fixed order
+      const int which = tid >> 6, ch = tid & 63;
+      const int cwn = ch >> 5, cc = (ch & 31) >> 3, e = ch & 7;
+      float t = 0.f;
+      for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < 16; ++l) {
+          const int th = ((k * 2 + cwn) << 6) + l * 4 + cc;
+          t += red[th * 2 * VEC + which * VEC + e];
+        }
+      if (n0 + ch < a.Nout) a.stats[((size_t)blockIdx.x * 2 + which) * a.Nout + n0 + ch] = t;
+    }
+  }
+}
+
 }  // namespace
 
 // ---- host side ------------------------------------------------------------------------------
@@ -582,6 +869,15 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
   p->bn = d->Nout <= 64 ? 64 : 128;
   if (p->bn == 128 && (long long)p->ntiles * ((d->Nout + 127) / 128) <= UZ_NUM_CU / 2) p->bn = 64;
   p->bres = (p->bn == 64 && d->Cin == bk) ? 1 : 0;
+  // bf16 with at most one 64-channel slab of input: weights in registers, 64 output channels per workgroup
+  // (conv3x3_res64_kernel); flag 0x40000000 of the ablation build keeps the first-generation kernels
+  // (64 -> 64 exactly stays on the LDS-resident kernel above: 88-91 us against 90-94 us at 256^2; the register
+  // kernel wins where that one does not apply: 64 -> 128 at 128^2 62 -> 49 us, Cin < 64, Nout > 64)
+  if (d->dtype == UZ_BF16 && d->Cin <= 64 && !(uz_tune_flags() & 0x40000000) &&
+      (!(d->Cin == 64 && d->Nout <= 64) || (uz_tune_flags() & 0x20000000))) {
+    p->bn = 64;
+    p->bres = 2;
+  }
   p->tiles_n = (d->Nout + p->bn - 1) / p->bn;
   int cap = UZ_NUM_CU / p->tiles_n;
   if (cap < 1) cap = 1;
@@ -592,6 +888,29 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
 template <typename T>
 static int direct_launch_t(const UzDirectPlan& p, const DirectArgs& a, hipStream_t s) {
   dim3 grid(p.grid_m, p.tiles_n), block(512);
+  if constexpr (sizeof(T) == 2) {
+    if (p.bres == 2) {
+      // measured (tools/kbench.py, 64 -> 64 at 256^2 and 64 -> 128 at 128^2): the 16x16x32 stream is no faster than
+      // 32x32x16 here (the kernel is bound by LDS-DMA issue and LDS latency, not by the matrix clock), and deeper
+      // read pipelines (3, 4 register sets) are slower (registers); the ablation build keeps the variants
+      const bool s16 = (a.flags & 0x10000000) != 0;
+      const int depth = (a.flags & 0x8000000) ? 3 : 2;
+#define UZ_RES64(TWv, Sv, Dv) hipLaunchKernelGGL((conv3x3_res64_kernel<TWv, Sv, Dv>), grid, block, 0, s, a)
+      if (p.tw == 32) {
+#ifdef UZ_ABLATE
+        if (s16) { if (depth == 3) UZ_RES64(32, 16, 3); else UZ_RES64(32, 16, 2); }
+        else if (depth == 3) UZ_RES64(32, 32, 3);
+        else
+#endif
+          UZ_RES64(32, 32, 2);
+      } else {
+        UZ_RES64(16, 32, 2);
+      }
+#undef UZ_RES64
+      UZ_LAUNCH_CHECK("uz_conv_igemm(direct3x3 res64)");
+      return UZ_OK;
+    }
+  }
   if (p.bn == 64) {
     if (p.bres) {
       if (p.tw == 32) hipLaunchKernelGGL((conv3x3_direct_kernel<T, 32, 64, true>), grid, block, 0, s, a);
