@@ -222,6 +222,21 @@ def write_missformer():
     run_case(model, 2, 128, 128, "missformer_b2_128", full_logits=True, name="missformer", bn_keys=())
 
 
+def write_transatt_unet():
+    """transatt_unet: seed-0 TransAttUNet(in_channels=3, num_classes=1), B=2 3x64x64, every number
+    kept.  The train-mode dropout on the channel-attention matrix (rate 0.1, transatt_unet.py:86-88) is switched
+    off for the fixture: its mask comes from the RNG stream, which no second implementation can share."""
+    mods = load_reference("common_layers", "transatt_unet")
+    torch.manual_seed(0)
+    model = mods["transatt_unet"].TransAttUNet(in_channels=3, num_classes=1)
+    write_manifest(model, "transatt_unet")
+    model.sdpa.dropout.p = 0.0
+    with torch.no_grad():
+        model.pam.gamma.fill_(0.5)      # the reference initialises it to 0, which hides the whole position-attention branch
+    run_case(model, 2, 64, 64, "transatt_unet_b2_64", full_logits=True, name="transatt_unet",
+             bn_keys=("inc.double_conv.1", "down4.maxpool_conv.1.double_conv.4", "up1.conv.double_conv.1", "up4.conv.double_conv.4"))
+
+
 def _timm_stand_in():
     """`swin_unet_v2.py:9` imports three helpers from timm, which this image lacks:
     to_2tuple, trunc_normal_ (= torch.nn.init.trunc_normal_) and DropPath (stochastic depth: per-sample
@@ -341,6 +356,10 @@ def main():
         torch.set_num_threads(8)
         write_nested_unet()
         return
+    if sys.argv[1:] == ["transatt_unet"]:
+        torch.set_num_threads(8)
+        write_transatt_unet()
+        return
     torch.set_num_threads(8)
     mods = load_reference("common_layers", "unet")
     RefUNet = mods["unet"].UNet
@@ -372,6 +391,7 @@ def main():
     write_nested_unet()
     write_resunet()
     write_missformer()
+    write_transatt_unet()
 
 
 if __name__ == "__main__":

@@ -456,6 +456,59 @@ def resunet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Tensor:
     return F.conv2d(x10, sd["output_layer.0.weight"], sd["output_layer.0.bias"])
 
 
+# ---------------------------------------------------------------------------------------------
+# TransAttUNet (unet_zoo/models/transatt_unet.py over DoubleConvo / Down / Up of common_layers.py:130-180)
+# ---------------------------------------------------------------------------------------------
+def double_convo(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """DoubleConvo.forward — common_layers.py:145-146 (``prefix`` ends in double_conv)."""
+    x = conv_bn_relu(x, sd, f"{prefix}.0", f"{prefix}.1", training)
+    return conv_bn_relu(x, sd, f"{prefix}.3", f"{prefix}.4", training)
+
+
+def up_bilinear_cat(x1, x2, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """Up.forward (bilinear) — common_layers.py:171-180: x2 up, centred zero pad, cat([x2, x1]), DoubleConvo."""
+    x1 = _q(F.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=True))
+    dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
+    x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return double_convo(torch.cat([x2, x1], 1), sd, f"{prefix}.conv.double_conv", training)
+
+
+def transatt_unet_forward(sd: State, x: torch.Tensor, training: bool, attn_dropout: float = 0.0) -> torch.Tensor:
+    """TransAttUNet.forward — transatt_unet.py:135-164 (bilinear=True).  `attn_dropout`: rate of the train-mode
+    dropout on the channel-attention matrix (reference default 0.1, transatt_unet.py:86-88; the goldens use 0)."""
+    def down(t, name):
+        return double_convo(F.max_pool2d(t, 2), sd, f"{name}.maxpool_conv.1.double_conv", training)
+
+    x1 = double_convo(x, sd, "inc.double_conv", training)
+    x2 = down(x1, "down1")
+    x3 = down(x2, "down2")
+    x4 = down(x3, "down3")
+    x5 = down(x4, "down4")
+    B, C, h, w = x5.shape
+    # PositionEmbeddingLearned.forward — :66-82
+    x_emb, y_emb = sd["pos.col_embed.weight"][:w], sd["pos.row_embed.weight"][:h]
+    pos = torch.cat([x_emb.unsqueeze(0).repeat(h, 1, 1), y_emb.unsqueeze(1).repeat(1, w, 1)], dim=-1)
+    x5 = _q(x5 + pos.permute(2, 0, 1).unsqueeze(0))
+    # PAM_Module.forward — :39-53
+    q = _q(F.conv2d(x5, _q(sd["pam.query_conv.weight"]), sd["pam.query_conv.bias"])).view(B, -1, h * w).permute(0, 2, 1)
+    k = _q(F.conv2d(x5, _q(sd["pam.key_conv.weight"]), sd["pam.key_conv.bias"])).view(B, -1, h * w)
+    v = _q(F.conv2d(x5, _q(sd["pam.value_conv.weight"]), sd["pam.value_conv.bias"])).view(B, -1, h * w)
+    attention = torch.softmax(torch.bmm(q, k), dim=-1)
+    pam = _q(torch.bmm(v, attention.permute(0, 2, 1)).view(B, C, h, w))
+    pam = _q(sd["pam.gamma"] * pam + x5)
+    # ScaledDotProductAttention.forward — :91-107, temperature = sqrt(512)
+    qq = x5.view(B, C, -1)
+    attn = torch.matmul(qq / (512 ** 0.5), qq.permute(0, 2, 1))
+    attn = F.dropout(F.softmax(attn, dim=-1), attn_dropout, training)
+    sdpa = _q(torch.matmul(attn, qq).view(B, C, h, w))
+    f = _q(sdpa + pam)
+    u = up_bilinear_cat(f, x4, sd, "up1", training)
+    u = up_bilinear_cat(u, x3, sd, "up2", training)
+    u = up_bilinear_cat(u, x2, sd, "up3", training)
+    u = up_bilinear_cat(u, x1, sd, "up4", training)
+    return F.conv2d(u, sd["outc.conv.weight"], sd["outc.conv.bias"])
+
+
 FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward,
             "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward, "resunet": resunet_forward}
 
@@ -565,6 +618,7 @@ def missformer_forward(sd: State, x: torch.Tensor, training: bool, image_size: i
 
 
 FORWARDS["missformer"] = missformer_forward
+FORWARDS["transatt_unet"] = transatt_unet_forward
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":

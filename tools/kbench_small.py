@@ -1,5 +1,7 @@
 """Micro-benchmark of the small bandwidth-bound kernels at the B=16 256x256 UNet sizes."""
+import os
 import sys
+os.environ.setdefault("UNET_ZOO_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unet_zoo_amd", "libunetzoo_hip_ablate.so"))
 import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from unet_zoo_amd import _lib as L, ops
@@ -42,3 +44,14 @@ dgb = torch.empty(2, 64, device=DEV)
 dy = ops.new_act(B, H, H, 64, dt, DEV)
 print("bn_relu_bwd (1 src)", timeit(lambda: ops.bn_relu_bwd(y, vec, x, None, None, sums, dy, dgb[0], dgb[1])))
 print("bn_relu_bwd (src+pool)", timeit(lambda: ops.bn_relu_bwd(y, vec, x, None, pooled, sums, dy, dgb[0], dgb[1])))
+
+for C, HH in ((64, 256), (128, 128), (256, 64), (512, 32)):
+    yy = ops.new_act(B, HH, HH, C, dt, DEV); yy.buf.normal_()
+    gg = ops.new_act(B, HH, HH, C, dt, DEV); gg.buf.normal_()
+    vv = torch.rand(4, C, device=DEV) + 0.5
+    ss = torch.zeros(2, C, dtype=torch.float64, device=DEV)
+    db = torch.empty(2, C, device=DEV)
+    dd = ops.new_act(B, HH, HH, C, dt, DEV)
+    for tune in os.environ.get("KB_TUNES", "0").split(","):
+        os.environ["UZ_TUNE"] = tune
+        print(f"bn_relu_bwd C={C} HW={HH} tune={tune}", timeit(lambda: ops.bn_relu_bwd(yy, vv, gg, None, None, ss, dd, db[0], db[1])))

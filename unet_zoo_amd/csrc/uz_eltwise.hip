@@ -956,7 +956,8 @@ static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, c
 static void bnbwd_shape(const uz_bnbwd_desc* d, bool pool, dim3* grid, dim3* block, int pass = 1) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   const long long units = pool ? (long long)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2) : (long long)d->N * d->H * d->W;
-  reduce_shape(d->C / vec, units, grid, block, pass == 2 ? 8 : 4);
+  const int f = uz_tune_flags() & 6;   // ablation build: workgroups per CU of the reduce pass (2: 8, 4: 6)
+  reduce_shape(d->C / vec, units, grid, block, pass == 2 ? 8 : (f == 2 ? 8 : f == 4 ? 6 : 4));
 }
 
 template <typename T, int PASS>

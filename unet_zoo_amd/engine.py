@@ -903,6 +903,94 @@ class Engine:
             self.tape.append(bwd)
         return views
 
+    # ------------------------------------------------------------------ library-GEMM glue (bottleneck attention)
+    @staticmethod
+    def _dense_nchw(a: Act) -> torch.Tensor:
+        """(N, C, H, W) fp32 copy of an activation"""
+        return a.buf.view(a.N, a.H, a.W, a.ld)[..., a.off:a.off + a.C].permute(0, 3, 1, 2).float()
+
+    @staticmethod
+    def _store_nchw(t: torch.Tensor, a: Act) -> None:
+        a.buf.view(a.N, a.H, a.W, a.ld)[..., a.off:a.off + a.C].copy_(t.permute(0, 2, 3, 1))
+
+    def torch_block(self, fn: Callable[..., torch.Tensor], inputs: Sequence[Act], params: Sequence[nn.Parameter],
+                    out: Act) -> Act:
+        """out = fn(*inputs_as_NCHW_fp32, *params) evaluated with PyTorch ops, differentiated by autograd.
+
+        For the handful of batched matrix products + softmax of the hybrids' BOTTLENECK attention (16x16 / 32x32
+        maps: < 0.1 % of a step's arithmetic; position / channel attention of transatt_unet.py:29-107, the
+        MultiHeadDense attention of unet_transformer.py:127-228): plain library GEMMs (rocBLAS through torch.bmm) are
+        what such small dense products are for; every convolution, normalisation and resampling around them stays on
+        the HIP kernels.  `fn` must not contain a reduction to a few values over a large tensor (those use a memset
+        node that hipGraph replay mishandles): scalar-parameter gradients go through
+        scale_residual() instead."""
+        xs = [self._dense_nchw(a) for a in inputs]
+        if self.record:
+            xs = [x.requires_grad_(a.needs_grad) for x, a in zip(xs, inputs)]
+            with torch.enable_grad():
+                y = fn(*xs, *params)
+            assert tuple(y.shape) == (out.N, out.C, out.H, out.W), (tuple(y.shape), (out.N, out.C, out.H, out.W))
+            self._store_nchw(y.detach(), out)
+
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                wrt = [x for x in xs if x.requires_grad] + [p for p in params if p.requires_grad]
+                grads = torch.autograd.grad(y, wrt, self._dense_nchw(g), allow_unused=True)
+                k = 0
+                for x, a in zip(xs, inputs):
+                    if not x.requires_grad:
+                        continue
+                    gx = grads[k]
+                    k += 1
+                    if gx is not None:
+                        da = self.new_act(a.N, a.H, a.W, a.C)
+                        self._store_nchw(gx, da)
+                        a.add_grad(da)
+                for p_ in params:
+                    if p_.requires_grad:
+                        gp = grads[k]
+                        k += 1
+                        self._give_grad(p_, gp if gp is not None else torch.zeros_like(p_))
+
+            self.tape.append(bwd)
+        else:
+            with torch.no_grad():
+                y = fn(*xs, *params)
+            self._store_nchw(y, out)
+        return out
+
+    def scale_residual(self, a: Act, gamma: nn.Parameter, x: Act) -> Act:
+        """gamma * a + x for a one-element parameter (PAM_Module's `self.gamma * out + x`, transatt_unet.py:51).
+        d(gamma) = <g, a> is reduced by this library's own row-sum kernel, not by a torch reduction."""
+        assert gamma.numel() == 1 and (a.N, a.H, a.W, a.C) == (x.N, x.H, x.W, x.C)
+        out = self.new_act(x.N, x.H, x.W, x.C)
+        av = a.buf[:, a.off:a.off + a.C]
+        xv = x.buf[:, x.off:x.off + x.C]
+        out.buf.copy_((xv.float() + av.float() * gamma.detach().float()).to(out.dtype))
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                gv = g.buf[:, g.off:g.off + g.C].float()
+                per_pixel = (gv * av.float()).sum(1).contiguous()          # [P]: one short reduction per row
+                dg = self._dst(gamma)
+                if dg is None:
+                    dg = torch.empty(1, dtype=torch.float32, device=self.device)
+                ops.sum_rows_f32(per_pixel, per_pixel.numel(), dg.view(1))
+                self._give_grad(gamma, dg.view(gamma.shape))
+                if x.needs_grad:
+                    x.add_grad(g)
+                if a.needs_grad:
+                    da = self.new_act(a.N, a.H, a.W, a.C)
+                    da.buf.copy_((gv * gamma.detach().float()).to(da.dtype))
+                    a.add_grad(da)
+
+            self.tape.append(bwd)
+        return out
+
     def finish_forward(self) -> None:
         """End of the forward: `num_batches_tracked += 1` of every train-mode BatchNorm (batchnorm.py of torch,
         as `nn.BatchNorm2d.forward` does) in ONE multi-tensor launch instead of one 5 us kernel per layer."""

@@ -20,12 +20,13 @@ from .swin_unet_v2 import SwinTransformerSys
 from .nested_unet import NestedUNet
 from .resunet import ResUnet
 from .missformer import MISSFormer
+from .transatt_unet import TransAttUNet
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'unet': UNet,
     'attention_unet': AttentionUNet,
-    'transatt_unet': None,
+    'transatt_unet': TransAttUNet,
     'raunet': None,
     'da_transformer': None,
     'unet_transformer': None,
@@ -107,6 +108,9 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
         # MISSFormer for its default 512x512 (missformer.py:868); mirrored.  `depth` is absorbed by **kwargs there.
         # Build the class directly (`MISSFormer(image_size=...)`) for another input size.
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
+    elif name == 'transatt_unet':
+        # models/__init__.py:104-107: `depth` travels to the constructor (absorbed by **kwargs there)
+        args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
     elif name == 'nested_unet':
         # models/__init__.py:139-143: depth travels to the constructor (absorbed by **kwargs there)
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth,
@@ -121,4 +125,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'TransAttUNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']

@@ -1,0 +1,195 @@
+"""TransAttUNet on the HIP engine (reference graph: unet_zoo/models/transatt_unet.py:109-164 over
+common_layers.py:130-180).
+
+Encoder ``inc`` + four ``Down`` (MaxPool2d(2) then DoubleConvo), a bottleneck that adds a learned position
+embedding and sums two attention branches -- ``PAM_Module`` (position attention: 1x1 q / k / v convolutions,
+softmax(q^T k), transatt_unet.py:29-53) and ``ScaledDotProductAttention`` (channel attention with train-mode
+dropout, :84-107) --, four ``Up`` (bilinear x2 with align_corners=True, ``cat([skip, up])``, DoubleConvo through
+``in // 2`` channels) and a 1x1 head.
+
+Every convolution, BatchNorm, pooling, resize and concat runs on the HIP kernels (the pool is fused into the BN/ReLU
+pass of the producing block, the skip and the upsampled tensor are written straight into their halves of one concat
+buffer).  The two attention cores at the 1/16-resolution bottleneck are batched matrix products + softmax on (h*w) x
+(h*w) and 512 x 512 matrices: library GEMMs through ``Engine.torch_block``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..engine import Engine
+from ..graph import HipModule
+from ..ops import Act
+from .blocks import OutConv
+
+
+class DoubleConvo(nn.Module):
+    """(Conv3x3 -> BN -> ReLU) x 2 through `mid_channels` (common_layers.py:130-146)"""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        if not mid_channels:
+            mid_channels = out_channels
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1), nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+
+    def emit(self, eng: Engine, x: Act, *, out: Optional[Act] = None, pool: bool = False,
+             im2col: bool = False) -> Tuple[Act, Optional[Act]]:
+        s = self.double_conv
+        mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col)
+        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool)
+
+
+class Down(nn.Module):
+    """MaxPool2d(2) then DoubleConvo (common_layers.py:148-158); the pool itself is fused into the PRODUCER of this
+    block's input, so emit() takes the pooled tensor"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConvo(in_channels, out_channels))
+
+    def emit(self, eng: Engine, pooled: Act, **kw):
+        return self.maxpool_conv[1].emit(eng, pooled, **kw)
+
+
+class Up(nn.Module):
+    """bilinear x2 (align_corners=True) or ConvTranspose2d, cat([skip, up]), DoubleConvo (common_layers.py:160-180)"""
+
+    def __init__(self, in_channels, out_channels, bilinear=True):
+        super().__init__()
+        self.bilinear = bilinear
+        if bilinear:
+            self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+            self.conv = DoubleConvo(in_channels, out_channels, in_channels // 2)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConvo(in_channels, out_channels)
+
+    def emit(self, eng: Engine, x1: Act, cat_full: Act, up_slot: Act) -> Act:
+        if self.bilinear:
+            eng.resize_bilinear(x1, up_slot, align_corners=True)
+        else:
+            eng.conv_transpose2x2(x1, self.up, up_slot)
+        act, _ = self.conv.emit(eng, cat_full)
+        return act
+
+
+class PAM_Module(nn.Module):
+    def __init__(self, in_dim):
+        super().__init__()
+        self.chanel_in = in_dim
+        self.query_conv = nn.Conv2d(in_dim, in_dim // 8, kernel_size=1)
+        self.key_conv = nn.Conv2d(in_dim, in_dim // 8, kernel_size=1)
+        self.value_conv = nn.Conv2d(in_dim, in_dim, kernel_size=1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+        self.softmax = nn.Softmax(dim=-1)
+
+    @staticmethod
+    def _core(q, k, v):
+        """energy[i, j] = q_i . k_j; out_i = sum_j softmax_j(energy)[i, j] v_j  (transatt_unet.py:41-49)"""
+        B, C, H, W = v.shape
+        qt = q.flatten(2).transpose(1, 2)                       # (B, N, C/8)
+        att = torch.softmax(torch.bmm(qt, k.flatten(2)), dim=-1)   # (B, N, N)
+        return torch.bmm(v.flatten(2), att.transpose(1, 2)).view(B, C, H, W)
+
+    def emit(self, eng: Engine, x: Act) -> Act:
+        q = eng.conv_plain(x, self.query_conv)
+        k = eng.conv_plain(x, self.key_conv)
+        v = eng.conv_plain(x, self.value_conv)
+        att = eng.torch_block(self._core, (q, k, v), (), eng.new_act(x.N, x.H, x.W, x.C))
+        return eng.scale_residual(att, self.gamma, x)
+
+
+class PositionEmbeddingLearned(nn.Module):
+    def __init__(self, num_pos_feats=256, len_embedding=32):
+        super().__init__()
+        self.row_embed = nn.Embedding(len_embedding, num_pos_feats)
+        self.col_embed = nn.Embedding(len_embedding, num_pos_feats)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    @staticmethod
+    def _add(x, row_w, col_w):
+        """x + cat([col_embed(i) over rows, row_embed(j) over columns]) (transatt_unet.py:66-82, :144-145)"""
+        h, w = x.shape[-2:]
+        x_emb, y_emb = col_w[:w], row_w[:h]
+        pos = torch.cat([x_emb.unsqueeze(0).expand(h, w, -1), y_emb.unsqueeze(1).expand(h, w, -1)], dim=-1)
+        return x + pos.permute(2, 0, 1).unsqueeze(0)
+
+    def emit(self, eng: Engine, x: Act) -> Act:
+        if x.H > self.row_embed.num_embeddings or x.W > self.col_embed.num_embeddings:
+            raise IndexError(f"position embedding holds {self.row_embed.num_embeddings} rows / columns, the bottleneck "
+                             f"map is {x.H}x{x.W} (input larger than 512x512)")
+        return eng.torch_block(self._add, (x,), (self.row_embed.weight, self.col_embed.weight),
+                               eng.new_act(x.N, x.H, x.W, x.C))
+
+
+class ScaledDotProductAttention(nn.Module):
+    def __init__(self, temperature, attn_dropout=0.1):
+        super().__init__()
+        self.temperature = temperature ** 0.5
+        self.dropout = nn.Dropout(attn_dropout)
+
+    def _core(self, x):
+        """channel attention: softmax((x / T) x^T) over channels, dropout, times x (transatt_unet.py:91-107)"""
+        B, d, H, W = x.shape
+        q = x.view(B, d, -1)
+        attn = torch.matmul(q / self.temperature, q.transpose(1, 2))
+        attn = F.dropout(F.softmax(attn, dim=-1), self.dropout.p, self.training)
+        return torch.matmul(attn, q).view(B, d, H, W)
+
+    def emit(self, eng: Engine, x: Act) -> Act:
+        return eng.torch_block(self._core, (x,), (), eng.new_act(x.N, x.H, x.W, x.C))
+
+
+class TransAttUNet(HipModule):
+    def __init__(self, in_channels=3, num_classes=1, bilinear=True, **kwargs):
+        super().__init__()
+        self.n_channels, self.n_classes, self.bilinear = in_channels, num_classes, bilinear
+        self.inc = DoubleConvo(in_channels, 64)
+        self.down1 = Down(64, 128)
+        self.down2 = Down(128, 256)
+        self.down3 = Down(256, 512)
+        factor = 2 if bilinear else 1
+        self.down4 = Down(512, 1024 // factor)
+        self.up1 = Up((1024 // factor) + 512, 512 // factor, bilinear)
+        self.up2 = Up((512 // factor) + 256, 256 // factor, bilinear)
+        self.up3 = Up((256 // factor) + 128, 128 // factor, bilinear)
+        self.up4 = Up((128 // factor) + 64, 64, bilinear)
+        self.outc = OutConv(64, num_classes)
+        self.pos = PositionEmbeddingLearned(256)
+        self.pam = PAM_Module(512)
+        self.sdpa = ScaledDotProductAttention(512)
+
+    def emit(self, eng: Engine, x: torch.Tensor):
+        N, _, H, W = x.shape
+        if H % 16 or W % 16:
+            raise ValueError(f"TransAttUNet needs H, W divisible by 16 (four 2x2 poolings and x2 upsamplings), got {H}x{W}")
+        factor = 2 if self.bilinear else 1
+        enc = (self.inc, self.down1, self.down2, self.down3)
+        skips_c = (64, 128, 256, 512)
+        ups = (self.up4, self.up3, self.up2, self.up1)         # indexed by encoder level
+        # channels of the tensor that arrives from below at encoder level lvl (after the optional ConvTranspose2d)
+        below_c = [128 // factor, 256 // factor, 512 // factor, 1024 // factor]
+        up_c = [c if self.bilinear else c // 2 for c in below_c]
+        cats = []
+        cur = eng.input_im2col(x)
+        for lvl, (blk, c) in enumerate(zip(enc, skips_c)):
+            full, (skip_slot, up_slot) = eng.new_cat(N, H >> lvl, W >> lvl, (c, up_c[lvl]))   # cat([x2, x1], 1)
+            cats.append((full, up_slot))
+            _, cur = blk.emit(eng, cur, out=skip_slot, pool=True, im2col=(lvl == 0))
+        x5, _ = self.down4.emit(eng, cur)
+        if x5.C != 512:
+            raise ValueError("the attention bottleneck of TransAttUNet is built for 512 channels: bilinear=True only, "
+                             "as in the reference (transatt_unet.py:135-141)")
+        x5 = self.pos.emit(eng, x5)
+        fused = eng.add(self.sdpa.emit(eng, x5), self.pam.emit(eng, x5))
+        cur = fused
+        for lvl in (3, 2, 1, 0):
+            full, up_slot = cats[lvl]
+            cur = ups[lvl].emit(eng, cur, full, up_slot)
+        return (self.outc.emit(eng, cur),)
