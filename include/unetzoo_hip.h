@@ -215,7 +215,9 @@ typedef struct uz_bnbwd_desc {
   int N, H, W, C;
   int ldy, ldg0, ldg1, ldgp, lddy;
   int pool_ceil; /* bit 0: geometry of gpool: 1 = (ceil(H/2), ceil(W/2)) with clipped border windows, 0 = (H/2, W/2);
-                  * bit 1: the forward was BatchNorm WITHOUT ReLU (uz_bn_relu_add_apply with the same bit; no pool) */
+                  * bit 1: the forward was BatchNorm WITHOUT ReLU (uz_bn_relu_add_apply with the same bit); with unit
+                  * scale and zero shift that pair is a stand-alone MaxPool2d(2) of an arbitrary tensor
+                  * (unet_transformer.py:151) */
 } uz_bnbwd_desc;
 /* Statistics of a BatchNorm whose input is not a convolution output (pre-activation blocks, `ResidualConv`,
  * common_layers.py:186-187): per-channel sum and sum of squares of x (P pixels, C channels, row stride ld) as

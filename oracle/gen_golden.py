@@ -237,6 +237,18 @@ def write_transatt_unet():
              bn_keys=("inc.double_conv.1", "down4.maxpool_conv.1.double_conv.4", "up1.conv.double_conv.1", "up4.conv.double_conv.4"))
 
 
+def write_unet_transformer():
+    """unet_transformer: seed-0 U_Transformer(in_channels=3, num_classes=1) with the default 64x64
+    attention grid, B=2 3x64x64, every number kept"""
+    mods = load_reference("common_layers", "unet_transformer")
+    torch.manual_seed(0)
+    model = mods["unet_transformer"].U_Transformer(in_channels=3, num_classes=1)
+    write_manifest(model, "unet_transformer")
+    run_case(model, 2, 64, 64, "unet_transformer_b2_64", full_logits=True, name="unet_transformer",
+             bn_keys=("inc.conv_op.1", "down3.maxpool_conv.1.double_conv.4", "up1.MHCA.Sconv_process.2",
+                      "up2.MHCA.conv_after_attention.1", "up3.MHCA.Yconv2_process.3", "up3.conv.4"))
+
+
 def _timm_stand_in():
     """`swin_unet_v2.py:9` imports three helpers from timm, which this image lacks:
     to_2tuple, trunc_normal_ (= torch.nn.init.trunc_normal_) and DropPath (stochastic depth: per-sample
@@ -356,6 +368,10 @@ def main():
         torch.set_num_threads(8)
         write_nested_unet()
         return
+    if sys.argv[1:] == ["unet_transformer"]:
+        torch.set_num_threads(8)
+        write_unet_transformer()
+        return
     if sys.argv[1:] == ["transatt_unet"]:
         torch.set_num_threads(8)
         write_transatt_unet()
@@ -392,6 +408,7 @@ def main():
     write_resunet()
     write_missformer()
     write_transatt_unet()
+    write_unet_transformer()
 
 
 if __name__ == "__main__":

@@ -509,6 +509,73 @@ def transatt_unet_forward(sd: State, x: torch.Tensor, training: bool, attn_dropo
     return F.conv2d(u, sd["outc.conv.weight"], sd["outc.conv.bias"])
 
 
+# ---------------------------------------------------------------------------------------------
+# U-Transformer (unet_zoo/models/unet_transformer.py)
+# ---------------------------------------------------------------------------------------------
+def _pos_enc_2d(inv_freq: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """PositionalEncodingPermute2D(x) for x (b, ch, H, W) — unet_transformer.py:83-116: channels [0, n) from the row
+    index, [n, 2n) from the column index, n = ceil(ch / 2), truncated to ch."""
+    b, ch, H, W = x.shape
+    n = 2 * inv_freq.numel()
+    sx = torch.einsum("i,j->ij", torch.arange(H, dtype=torch.float32), inv_freq)
+    sy = torch.einsum("i,j->ij", torch.arange(W, dtype=torch.float32), inv_freq)
+    emb = torch.zeros(H, W, 2 * n)
+    emb[:, :, :n] = torch.cat((sx.sin(), sx.cos()), -1).unsqueeze(1)
+    emb[:, :, n:2 * n] = torch.cat((sy.sin(), sy.cos()), -1)
+    return emb[None, :, :, :ch].repeat(b, 1, 1, 1).permute(0, 3, 1, 2)
+
+
+def _conv1x1_bn_relu(x, sd: State, conv: str, bn: str, training: bool) -> torch.Tensor:
+    y = _q(F.conv2d(_q(x), _q(sd[conv + ".weight"]), sd.get(conv + ".bias")))
+    return _q(F.relu(_bn(y, sd, bn, training)))
+
+
+def _dense_attention(Qs, Ks, Vs, sd: State, prefix: str) -> torch.Tensor:
+    """MultiHeadDense q / k / v, softmax over dim=1 (the QUERY axis), A V — unet_transformer.py:127-137, :208-219"""
+    b, c, h, w = Qs.shape
+    Q = torch.bmm(Qs.flatten(2).permute(0, 2, 1), sd[prefix + ".query.weight"].repeat(b, 1, 1))
+    K = torch.bmm(Ks.flatten(2).permute(0, 2, 1), sd[prefix + ".key.weight"].repeat(b, 1, 1))
+    V = torch.bmm(Vs.flatten(2).permute(0, 2, 1), sd[prefix + ".value.weight"].repeat(b, 1, 1))
+    A = torch.softmax(torch.bmm(Q, K.permute(0, 2, 1)) / (c ** 0.5), dim=1)
+    return torch.bmm(A, V).permute(0, 2, 1).reshape(b, c, h, w)
+
+
+def transformer_up(Y, S, sd: State, prefix: str, training: bool, res=(64, 64)) -> torch.Tensor:
+    """TransformerUp.forward — unet_transformer.py:250-253 over MultiHeadCrossAttention.forward :179-228"""
+    m = prefix + ".MHCA"
+    S_pe = _q(S + _pos_enc_2d(sd[m + ".Spe.penc.inv_freq"], S))
+    Sp = _conv1x1_bn_relu(F.max_pool2d(S_pe, 2), sd, m + ".Sconv_process.1", m + ".Sconv_process.2", training)
+    Y_pe = _q(Y + _pos_enc_2d(sd[m + ".Ype.penc.inv_freq"], Y))
+    Yp = _conv1x1_bn_relu(Y_pe, sd, m + ".Yconv_process.0", m + ".Yconv_process.1", training)
+    qk = F.adaptive_avg_pool2d(Yp, res)
+    low = _q(_dense_attention(qk, qk, F.adaptive_avg_pool2d(Sp, res), sd, m))
+    z = _q(F.interpolate(low, size=(2 * Y.shape[2], 2 * Y.shape[3]), mode="bilinear", align_corners=True))
+    z = _conv1x1_bn_relu(z, sd, m + ".conv_after_attention.0", m + ".conv_after_attention.1", training)
+    y2 = _q(F.interpolate(Y_pe, scale_factor=2, mode="bilinear", align_corners=True))
+    y2 = _q(F.conv2d(y2, _q(sd[m + ".Yconv2_process.1.weight"]), sd[m + ".Yconv2_process.1.bias"], padding=1))
+    y2 = _conv1x1_bn_relu(y2, sd, m + ".Yconv2_process.2", m + ".Yconv2_process.3", training)
+    x = torch.cat([z, y2], 1)
+    x = conv_bn_relu(x, sd, prefix + ".conv.0", prefix + ".conv.1", training)
+    return conv_bn_relu(x, sd, prefix + ".conv.3", prefix + ".conv.4", training)
+
+
+def unet_transformer_forward(sd: State, x: torch.Tensor, training: bool, res=(64, 64)) -> torch.Tensor:
+    """U_Transformer.forward — unet_transformer.py:273-283"""
+    def down(t, name):
+        return double_convo(F.max_pool2d(t, 2), sd, f"{name}.maxpool_conv.1.double_conv", training)
+
+    x1 = double_conv(x, sd, "inc.conv_op", training)
+    x2 = down(x1, "down1")
+    x3 = down(x2, "down2")
+    x4 = down(x3, "down3")
+    x4p = _q(x4 + _pos_enc_2d(sd["MHSA.pe.penc.inv_freq"], x4))
+    x4 = _q(_dense_attention(x4p, x4p, x4p, sd, "MHSA"))
+    y = transformer_up(x4, x3, sd, "up1", training, res)
+    y = transformer_up(y, x2, sd, "up2", training, res)
+    y = transformer_up(y, x1, sd, "up3", training, res)
+    return F.conv2d(y, sd["outc.conv.weight"], sd["outc.conv.bias"])
+
+
 FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward,
             "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward, "resunet": resunet_forward}
 
@@ -619,6 +686,7 @@ def missformer_forward(sd: State, x: torch.Tensor, training: bool, image_size: i
 
 FORWARDS["missformer"] = missformer_forward
 FORWARDS["transatt_unet"] = transatt_unet_forward
+FORWARDS["unet_transformer"] = unet_transformer_forward
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":
@@ -633,7 +701,7 @@ def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, tor
 
 def _is_buffer(key: str) -> bool:
     return key.endswith(("running_mean", "running_var", "num_batches_tracked", "attn_mask",
-                         "log_relative_position_index"))
+                         "log_relative_position_index", "inv_freq"))
 
 
 def train_step_reference(model_name: str, sd: State, x: torch.Tensor, mask: torch.Tensor, **fw_kwargs):

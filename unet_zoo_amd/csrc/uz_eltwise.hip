@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
         if (res != nullptr) load_f(res + p * ldr + c0, r);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+          v[i] = fmaf(v[i], sc[i], sh[i]);
+          if (relu) v[i] = fmaxf(v[i], 0.f);
           if (res != nullptr) v[i] = (float)(T)(v[i] + r[i]);  // the pool sees the stored value
           m[i] = (k == 0) ? v[i] : fmaxf(m[i], v[i]);
         }
@@ -295,11 +296,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
         load_f(gp + gpoff + c0, gpv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          float best = fmaxf(fmaf(yv[0][i], sc[i], sh[i]), 0.f);
+          float best = fmaf(yv[0][i], sc[i], sh[i]);
+          if (!norelu) best = fmaxf(best, 0.f);
           int bk = 0;
 #pragma unroll
           for (int k = 1; k < 4; ++k) {
-            const float v = fmaxf(fmaf(yv[k][i], sc[i], sh[i]), 0.f);
+            float v = fmaf(yv[k][i], sc[i], sh[i]);
+            if (!norelu) v = fmaxf(v, 0.f);
             if (in[k] && v > best) {
               best = v;
               bk = k;
@@ -927,7 +930,6 @@ extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const flo
   UZ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "uz_bn_relu_apply: C=%d must be a multiple of %d", C, vec);
   UZ_REQUIRE(ldy % vec == 0 && lda % vec == 0 && ldy >= C && lda >= C, "uz_bn_relu_apply: bad ld");
   if (res != nullptr) UZ_REQUIRE(ldr % vec == 0 && ldr >= C, "uz_bn_relu_apply: bad ldr");
-  UZ_REQUIRE(!(pool_ceil & 2) || pooled == nullptr, "uz_bn_relu_apply: the no-ReLU form has no fused pool");
   if (pooled != nullptr) {
     UZ_REQUIRE(pool_ceil || (H >= 2 && W >= 2), "uz_bn_relu_apply: floor-mode pool of a %dx%d map is empty", H, W);
     UZ_REQUIRE(ldp % vec == 0 && ldp >= C, "uz_bn_relu_apply: bad ldp");
@@ -949,7 +951,6 @@ static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, c
     UZ_REQUIRE(d->ldgp % vec == 0 && d->ldgp >= d->C, "uz_bn_relu_bwd: bad ldgp");
   }
   UZ_REQUIRE(g0 || g1 || gp, "uz_bn_relu_bwd: no incoming gradient");
-  UZ_REQUIRE(!(d->pool_ceil & 2) || gp == nullptr, "uz_bn_relu_bwd: the no-ReLU form has no pool gradient");
   return UZ_OK;
 }
 

@@ -256,9 +256,10 @@ class Engine:
             wp = self._pack(conv.weight, L.PACK_IM2COL, x.C)
             ntaps = 1
         else:
-            assert conv.kernel_size == (3, 3) and conv.in_channels == x.C
+            assert conv.kernel_size in ((3, 3), (1, 1)) and conv.in_channels == x.C
             wp = self._pack(conv.weight, L.PACK_CONV_FWD)
-            ntaps = 9
+            ntaps = 9 if conv.kernel_size == (3, 3) else 1     # 1x1 + BN + ReLU: unet_transformer.py:150-177
+            assert ntaps == 9 or not upsample
         y = self.new_act(N, H, W, Cout)
         bias = conv.bias.detach() if conv.bias is not None else None
         stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, taps_mode=tmode,
@@ -322,7 +323,7 @@ class Engine:
                     dw = dwp[:, :9 * cin].reshape(Cout, 9, cin).permute(0, 2, 1).reshape(conv.weight.shape)
                     self._give_grad(conv.weight, dw.contiguous())
                 else:
-                    self._give_grad(conv.weight, ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=9,
+                    self._give_grad(conv.weight, ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=ntaps,
                                                            dil=dil, taps_mode=tmode,
                                                            out=self._dst(conv.weight)))
                     if x.needs_grad and upsample:
@@ -339,7 +340,7 @@ class Engine:
                         # epilogue; a ConvTranspose2d feeding x takes its bias gradient from them
                         want = x.parts is not None
                         part = ops.conv_igemm(dy, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx,
-                                              ntaps=9, dil=dil, want_stats=want)
+                                              ntaps=ntaps, dil=dil, want_stats=want)
                         if want:
                             dx.colsums = (part, 0)
                         x.add_grad(dx)
@@ -902,6 +903,43 @@ class Engine:
 
             self.tape.append(bwd)
         return views
+
+    def add_const(self, x: Act, const_map: torch.Tensor) -> Act:
+        """x + c for a parameter-free (H*W, C) map c broadcast over the batch: the sinusoidal position encodings
+        `x + self.pe(x)` of unet_transformer.py:133-134, :181-185.  The gradient passes through unchanged."""
+        assert const_map.shape == (x.H * x.W, x.C), (tuple(const_map.shape), (x.H * x.W, x.C))
+        out = self.new_act(x.N, x.H, x.W, x.C, x.needs_grad)
+        xv = x.buf.view(x.N, x.H * x.W, x.ld)[..., x.off:x.off + x.C]
+        out.buf.view(x.N, x.H * x.W, x.C).copy_(xv.float() + const_map.to(self.device, torch.float32))
+        if self.record and x.needs_grad:
+            def bwd():
+                g = self._total_grad(out)
+                if g is not None:
+                    x.add_grad(g)
+
+            self.tape.append(bwd)
+        return out
+
+    def max_pool2x2(self, x: Act) -> Act:
+        """nn.MaxPool2d(2) of a tensor that is not a BatchNorm/ReLU output (`Sconv_process[0]`,
+        unet_transformer.py:151): the fused kernel with unit scale, zero shift and no ReLU, writing `x` back in place;
+        the backward routes each window's gradient to its first maximum (uz_pool_grad_combine)."""
+        assert x.H >= 2 and x.W >= 2
+        one = torch.ones(x.C, dtype=torch.float32, device=self.device)
+        zero = torch.zeros(x.C, dtype=torch.float32, device=self.device)
+        pooled = self.new_act(x.N, x.H // 2, x.W // 2, x.C, x.needs_grad)
+        ops.bn_relu_apply(x, one, zero, x, pooled, relu=False)
+        if self.record and x.needs_grad:
+            def bwd():
+                g = self._total_grad(pooled)
+                if g is None:
+                    return
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                ops.pool_grad_combine(x, None, None, g, dx)
+                x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return pooled
 
     # ------------------------------------------------------------------ library-GEMM glue (bottleneck attention)
     @staticmethod

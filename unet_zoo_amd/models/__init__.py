@@ -21,6 +21,7 @@ from .nested_unet import NestedUNet
 from .resunet import ResUnet
 from .missformer import MISSFormer
 from .transatt_unet import TransAttUNet
+from .unet_transformer import U_Transformer
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
@@ -29,7 +30,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'transatt_unet': TransAttUNet,
     'raunet': None,
     'da_transformer': None,
-    'unet_transformer': None,
+    'unet_transformer': U_Transformer,
     'uctransnet': None,
     'multiresunet': None,
     'nested_unet': NestedUNet,
@@ -125,4 +126,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'TransAttUNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'TransAttUNet', 'U_Transformer', 'list_models', 'hip_models', 'get_model_config', 'create_model']
