@@ -526,6 +526,16 @@ int uz_sum_rows_f32_batched(const uz_sum_rows_item* items, int n, void* stream);
 long long uz_colsum_batched_workspace_bytes(int dtype, const uz_colsum_item* items, int n);
 int uz_colsum_batched(int dtype, const uz_colsum_item* items, int n, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Residual sums with ReLU: out = relu(a + b) (b may be NULL) and its gradient dx = g * [out > 0], which both
+ * summands receive.  Replaces `x = x + temp; x = F.relu(x)` of Multiresblock.forward and `x = x + shortcut;
+ * x = F.relu(x)` of Respath.forward (unet_zoo/models/multiresunet.py:79-80, 127-129, 133-135).
+ * ------------------------------------------------------------------------------------------- */
+int uz_add_relu(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, long long P, int C,
+                void* stream);
+int uz_relu_bwd(int dtype, const void* out, int ldo, const void* g, int ldg, void* dx, int lddx, long long P, int C,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

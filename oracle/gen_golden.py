@@ -249,6 +249,17 @@ def write_unet_transformer():
                       "up2.MHCA.conv_after_attention.1", "up3.MHCA.Yconv2_process.3", "up3.conv.4"))
 
 
+def write_multiresunet():
+    """multiresunet: seed-0 MultiResUnet(in_channels=3, num_classes=1), B=2 3x64x64, every number kept"""
+    mods = load_reference("multiresunet")
+    torch.manual_seed(0)
+    model = mods["multiresunet"].MultiResUnet(in_channels=3, num_classes=1)
+    write_manifest(model, "multiresunet")
+    run_case(model, 2, 64, 64, "multiresunet_b2_64", full_logits=True, name="multiresunet",
+             bn_keys=("multiresblock1.conv2d_bn_1x1.batchnorm", "multiresblock1.batch_norm1", "respath1.blocks.2.2",
+                      "multiresblock5.conv2d_bn_7x7.batchnorm", "multiresblock9.batch_norm1", "conv_final.batchnorm"))
+
+
 def _timm_stand_in():
     """`swin_unet_v2.py:9` imports three helpers from timm, which this image lacks:
     to_2tuple, trunc_normal_ (= torch.nn.init.trunc_normal_) and DropPath (stochastic depth: per-sample
@@ -372,6 +383,10 @@ def main():
         torch.set_num_threads(8)
         write_unet_transformer()
         return
+    if sys.argv[1:] == ["multiresunet"]:
+        torch.set_num_threads(8)
+        write_multiresunet()
+        return
     if sys.argv[1:] == ["transatt_unet"]:
         torch.set_num_threads(8)
         write_transatt_unet()
@@ -409,6 +424,7 @@ def main():
     write_missformer()
     write_transatt_unet()
     write_unet_transformer()
+    write_multiresunet()
 
 
 if __name__ == "__main__":

@@ -576,6 +576,68 @@ def unet_transformer_forward(sd: State, x: torch.Tensor, training: bool, res=(64
     return F.conv2d(y, sd["outc.conv.weight"], sd["outc.conv.bias"])
 
 
+# ---------------------------------------------------------------------------------------------
+# MultiResUNet (unet_zoo/models/multiresunet.py)
+# ---------------------------------------------------------------------------------------------
+def _bn_plain(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """nn.BatchNorm2d(C, affine=False) — multiresunet.py:22, :69, :104, :116"""
+    y = F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], None, None, training=training,
+                     momentum=0.1, eps=1e-5)
+    if training and (prefix + ".num_batches_tracked") in sd:
+        sd[prefix + ".num_batches_tracked"] += 1
+    return y
+
+
+def conv2d_batchnorm(x, sd: State, prefix: str, training: bool, relu: bool) -> torch.Tensor:
+    """Conv2d_batchnorm.forward — multiresunet.py:24-31"""
+    w = sd[prefix + ".conv1.weight"]
+    y = _q(F.conv2d(_q(x), _q(w), sd[prefix + ".conv1.bias"], padding=w.shape[-1] // 2))
+    y = _bn_plain(y, sd, prefix + ".batchnorm", training)
+    return _q(F.relu(y) if relu else y)
+
+
+def multiresblock(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """Multiresblock.forward — multiresunet.py:71-83 (batch_norm1 is applied twice)"""
+    temp = conv2d_batchnorm(x, sd, prefix + ".conv2d_bn_1x1", training, False)
+    a = conv2d_batchnorm(x, sd, prefix + ".conv2d_bn_3x3", training, True)
+    b = conv2d_batchnorm(a, sd, prefix + ".conv2d_bn_5x5", training, True)
+    c = conv2d_batchnorm(b, sd, prefix + ".conv2d_bn_7x7", training, True)
+    y = _q(_bn_plain(torch.cat([a, b, c], 1), sd, prefix + ".batch_norm1", training))
+    y = _q(F.relu(y + temp))
+    return _q(_bn_plain(y, sd, prefix + ".batch_norm1", training))
+
+
+def respath(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """Respath.forward — multiresunet.py:121-137"""
+    stages = [(prefix + ".conv2d_bn_1x1_initial", prefix + ".conv2d_bn_3x3_initial", prefix + ".batch_norm_initial")]
+    i = 0
+    while f"{prefix}.blocks.{i}.0.conv1.weight" in sd:
+        stages.append((f"{prefix}.blocks.{i}.0", f"{prefix}.blocks.{i}.1", f"{prefix}.blocks.{i}.2"))
+        i += 1
+    for c1, c3, bn in stages:
+        shortcut = conv2d_batchnorm(x, sd, c1, training, False)
+        y = conv2d_batchnorm(x, sd, c3, training, True)
+        x = _q(_bn_plain(_q(F.relu(y + shortcut)), sd, bn, training))
+    return x
+
+
+def multiresunet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """MultiResUnet.forward — multiresunet.py:199-240"""
+    m1 = multiresblock(x, sd, "multiresblock1", training)
+    r1 = respath(m1, sd, "respath1", training)
+    m2 = multiresblock(F.max_pool2d(m1, 2, 2), sd, "multiresblock2", training)
+    r2 = respath(m2, sd, "respath2", training)
+    m3 = multiresblock(F.max_pool2d(m2, 2, 2), sd, "multiresblock3", training)
+    r3 = respath(m3, sd, "respath3", training)
+    m4 = multiresblock(F.max_pool2d(m3, 2, 2), sd, "multiresblock4", training)
+    r4 = respath(m4, sd, "respath4", training)
+    y = multiresblock(F.max_pool2d(m4, 2, 2), sd, "multiresblock5", training)
+    for i, skip in ((6, r4), (7, r3), (8, r2), (9, r1)):
+        up = _q(F.conv_transpose2d(_q(y), _q(sd[f"upsample{i}.weight"]), sd[f"upsample{i}.bias"], stride=2))
+        y = multiresblock(torch.cat([up, skip], 1), sd, f"multiresblock{i}", training)
+    return conv2d_batchnorm(y, sd, "conv_final", training, False)
+
+
 FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward,
             "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward, "resunet": resunet_forward}
 
@@ -687,6 +749,7 @@ def missformer_forward(sd: State, x: torch.Tensor, training: bool, image_size: i
 FORWARDS["missformer"] = missformer_forward
 FORWARDS["transatt_unet"] = transatt_unet_forward
 FORWARDS["unet_transformer"] = unet_transformer_forward
+FORWARDS["multiresunet"] = multiresunet_forward
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":

@@ -156,6 +156,8 @@ class Engine:
         return None
 
     def _give_grad(self, p: nn.Parameter, g: Optional[torch.Tensor]) -> None:
+        if not isinstance(p, nn.Parameter):
+            return      # constant stand-ins (gamma = 1 / beta = 0 of an affine-free BatchNorm): nothing to train
         self.grad_log.append((self._cur_entry, p))
         if self.grads_in_place and p.grad is not None:
             if g is None:
@@ -238,14 +240,15 @@ class Engine:
 
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
                      pool: bool = False, im2col: bool = False, upsample: bool = False,
-                     residual: Optional[Act] = None, pool_ceil: bool = False) -> Tuple[Act, Optional[Act]]:
+                     residual: Optional[Act] = None, pool_ceil: bool = False, relu: bool = True) -> Tuple[Act, Optional[Act]]:
         """[nearest x2 upsample ->] Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
 
         Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
         u2net.py:10-17), DownSample's pool (common_layers.py:90-95) and UpConvBlock
         (common_layers.py:69-76: the upsampled tensor is never materialised, the convolution reads
         the half-resolution input at (h>>1, w>>1)).  `residual` is added AFTER the ReLU and before
-        the pool (the RSU tail `hx1d + hxin`, u2net.py:74).  Returns (act, pooled)."""
+        the pool (the RSU tail `hx1d + hxin`, u2net.py:74).  relu=False: Conv -> BatchNorm only
+        (Conv2d_batchnorm(activation='None'), multiresunet.py:26-31).  Returns (act, pooled)."""
         N, H, W = x.N, x.H, x.W
         if upsample:
             H, W = 2 * H, 2 * W
@@ -278,7 +281,8 @@ class Engine:
             pooled = self.new_act(N, (H + 1) // 2, (W + 1) // 2, Cout)
         else:
             pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
-        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil)
+        assert relu or residual is None
+        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu)
 
         if self.record:
             if not self.training:
@@ -310,7 +314,7 @@ class Engine:
                     dgamma = torch.empty(Cout, dtype=torch.float32, device=self.device)
                 if dbeta is None:
                     dbeta = torch.empty(Cout, dtype=torch.float32, device=self.device)
-                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil)
+                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil, relu=relu)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:
@@ -428,15 +432,17 @@ class Engine:
         return torch.cat([v2, bn.running_mean.reshape(1, -1), torch.rsqrt(bn.running_var + bn.eps).reshape(1, -1)])
 
     # ------------------------------------------------------------------ pre-activation residual pieces (resunet)
-    def bn_act(self, x: Act, bn: nn.BatchNorm2d, relu: bool = True) -> Act:
+    def bn_act(self, x: Act, bn: nn.BatchNorm2d, relu: bool = True, pool: bool = False):
         """BatchNorm2d [+ ReLU] of a tensor that is NOT a convolution output, so nobody has its statistics yet:
         `ResidualConv.conv_block[0:2]` and `conv_skip[1]` (common_layers.py:186-187, :195).  One statistics pass
-        (uz_colstats), then the same finalize / apply / two-pass backward kernels as the fused conv-BN-ReLU."""
+        (uz_colstats), then the same finalize / apply / two-pass backward kernels as the fused conv-BN-ReLU.
+        pool=True: also MaxPool2d(2, 2) of the result, returned as (act, pooled) (multiresunet.py:83, :201-202)."""
         C = bn.num_features
         assert x.C == C
         vec = self._bn_vectors(bn, ops.colstats(x) if self.training else None, x.P)
         act = self.new_act(x.N, x.H, x.W, C)
-        ops.bn_relu_apply(x, vec[0], vec[1], act, relu=relu)
+        pooled = self.new_act(x.N, x.H // 2, x.W // 2, C) if pool else None
+        ops.bn_relu_apply(x, vec[0], vec[1], act, pooled, relu=relu)
         if self.record:
             if not self.training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
@@ -444,7 +450,8 @@ class Engine:
 
             def bwd():
                 gs = self._sum_grads(act, 2)
-                if not gs:
+                gp = self._sum_grads(pooled, 1)[0] if (pooled is not None and pooled.grads) else None
+                if not gs and gp is None:
                     return
                 dx = self.new_act(x.N, x.H, x.W, C)
                 dgamma, dbeta = self._dst(bn.weight), self._dst(bn.bias)
@@ -452,15 +459,15 @@ class Engine:
                     dgamma = torch.empty(C, dtype=torch.float32, device=self.device)
                 if dbeta is None:
                     dbeta = torch.empty(C, dtype=torch.float32, device=self.device)
-                ops.bn_relu_bwd(x, vec, gs[0], gs[1] if len(gs) > 1 else None, None, self._bn_sums(C), dx, dgamma, dbeta,
-                                relu=relu)
+                ops.bn_relu_bwd(x, vec, gs[0] if gs else None, gs[1] if len(gs) > 1 else None, gp, self._bn_sums(C), dx,
+                                dgamma, dbeta, relu=relu)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if x.needs_grad:
                     x.add_grad(dx)
 
             self.tape.append(bwd)
-        return act
+        return (act, pooled) if pool else act
 
     def conv_plain(self, x: Act, conv: nn.Conv2d, *, im2col: bool = False) -> Act:
         """Conv2d k3 p1 / k1 p0, stride 1, WITHOUT a following BatchNorm: the block tails and skip convolutions of
@@ -573,6 +580,51 @@ class Engine:
 
             self.tape.append(bwd)
         return out
+
+    def add_relu(self, a: Act, b: Act) -> Act:
+        """relu(a + b): `x = x + temp; x = F.relu(x)` (multiresunet.py:79-80, 127-129, 133-135)"""
+        assert (a.N, a.H, a.W, a.C) == (b.N, b.H, b.W, b.C)
+        out = self.new_act(a.N, a.H, a.W, a.C)
+        ops.add_relu(a, b, out)
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                d = self.new_act(a.N, a.H, a.W, a.C)
+                ops.relu_bwd(out, g, d)
+                if a.needs_grad:
+                    a.add_grad(d)
+                if b.needs_grad:
+                    b.add_grad(d)
+
+            self.tape.append(bwd)
+        return out
+
+    def input_nhwc(self, x: torch.Tensor, cpad: int = 8) -> Act:
+        """Network input (N, C, H, W) fp32 as an NHWC activation whose channels are zero-padded to `cpad` (a model whose
+        first layer is not one 3x3 convolution: two convolutions read the image in multiresunet.py:74-76)."""
+        L.require_cuda(x)
+        N, C, H, W = x.shape
+        a = self.new_act(N, H, W, _round_up(C, cpad), needs_grad=False)
+        a.buf.zero_()
+        a.buf.view(N, H, W, a.C)[..., :C].copy_(x.permute(0, 2, 3, 1))
+        return a
+
+    def act_to_logits(self, x: Act, K: int) -> torch.Tensor:
+        """the first K channels of an activation as the model output (N, K, H, W) fp32: a head that ends in a
+        BatchNorm rather than in a bare 1x1 convolution (`conv_final`, multiresunet.py:196-197, :238)"""
+        assert K <= x.C
+        logits = x.buf.view(x.N, x.H, x.W, x.ld)[..., x.off:x.off + K].permute(0, 3, 1, 2).float().contiguous()
+        if self.record:
+            def bwd(g_logits: torch.Tensor):
+                g = self.new_act(x.N, x.H, x.W, x.C)
+                g.buf.zero_()
+                g.buf.view(x.N, x.H, x.W, x.C)[..., :K].copy_(g_logits.permute(0, 2, 3, 1))
+                x.add_grad(g)
+
+            self._heads.append((bwd, 1))
+        return logits
 
     def conv_transpose2x2(self, x: Act, m: nn.ConvTranspose2d, out: Act) -> Act:
         """ConvTranspose2d(k=2, s=2) written straight into its slot of the concat buffer.
@@ -1033,7 +1085,15 @@ class Engine:
         """End of the forward: `num_batches_tracked += 1` of every train-mode BatchNorm (batchnorm.py of torch,
         as `nn.BatchNorm2d.forward` does) in ONE multi-tensor launch instead of one 5 us kernel per layer."""
         if self._bn_counters:
-            torch._foreach_add_(self._bn_counters, 1)
+            # a module applied twice in one forward (Multiresblock.batch_norm1, multiresunet.py:77, :81) counts twice
+            uniq: Dict[int, list] = {}
+            for t in self._bn_counters:
+                uniq.setdefault(id(t), [t, 0])[1] += 1
+            by_count: Dict[int, list] = {}
+            for t, k in uniq.values():
+                by_count.setdefault(k, []).append(t)
+            for k, ts in by_count.items():
+                torch._foreach_add_(ts, k)
             self._bn_counters = []
 
     def position_biases(self, attns: Sequence[Tuple[nn.Module, int]]) -> None:

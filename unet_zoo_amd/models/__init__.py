@@ -22,6 +22,7 @@ from .resunet import ResUnet
 from .missformer import MISSFormer
 from .transatt_unet import TransAttUNet
 from .unet_transformer import U_Transformer
+from .multiresunet import MultiResUnet
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
@@ -32,7 +33,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'da_transformer': None,
     'unet_transformer': U_Transformer,
     'uctransnet': None,
-    'multiresunet': None,
+    'multiresunet': MultiResUnet,
     'nested_unet': NestedUNet,
     'missformer': MISSFormer,
     'vnet': None,
@@ -109,6 +110,9 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
         # MISSFormer for its default 512x512 (missformer.py:868); mirrored.  `depth` is absorbed by **kwargs there.
         # Build the class directly (`MISSFormer(image_size=...)`) for another input size.
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
+    elif name == 'multiresunet':
+        # models/__init__.py:134-137: `depth` travels to the constructor (absorbed by **kwargs there)
+        args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
     elif name == 'transatt_unet':
         # models/__init__.py:104-107: `depth` travels to the constructor (absorbed by **kwargs there)
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
@@ -126,4 +130,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'TransAttUNet', 'U_Transformer', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'TransAttUNet', 'U_Transformer', 'MultiResUnet', 'list_models', 'hip_models', 'get_model_config', 'create_model']

@@ -321,6 +321,22 @@ def add_acts(a: Act, b: Act, out: Act) -> None:
     pool_grad_combine(a, a, b, None, out)
 
 
+def add_relu(a: Act, b: Optional[Act], out: Act) -> None:
+    """out = relu(a + b) (multiresunet.py:79-80, 127-129)"""
+    assert (a.P, a.C) == (out.P, out.C) and (b is None or (b.P, b.C) == (a.P, a.C))
+    with _Timed("add_relu", 0.0, a.buf.element_size() * a.P * a.C * (2 + (b is not None))):
+        L.check(L.load().uz_add_relu(L.dtype_code(a.dtype), a.ptr(), a.ld, b.ptr() if b is not None else None,
+                                     b.ld if b is not None else 0, out.ptr(), out.ld, a.P, a.C, L.stream_ptr()), "uz_add_relu")
+
+
+def relu_bwd(out: Act, g: Act, dx: Act) -> None:
+    """dx = g * [out > 0]"""
+    assert (out.P, out.C) == (g.P, g.C) == (dx.P, dx.C)
+    with _Timed("relu_bwd", 0.0, out.buf.element_size() * out.P * out.C * 3):
+        L.check(L.load().uz_relu_bwd(L.dtype_code(out.dtype), out.ptr(), out.ld, g.ptr(), g.ld, dx.ptr(), dx.ld, out.P,
+                                     out.C, L.stream_ptr()), "uz_relu_bwd")
+
+
 def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
     lib = L.load()
     C = gamma.numel()
