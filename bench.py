@@ -82,6 +82,8 @@ def make_model(model_name: str, hw: int):
     kw = {}
     if model_name == "swin_unet_v2":
         kw = {"image_size": hw, "window_size": 7 if (hw // 4) % 7 == 0 else 8}
+    elif model_name == "uctransnet":
+        kw = {"image_size": hw}
     return unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1, **kw), kw
 
 

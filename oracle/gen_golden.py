@@ -260,6 +260,27 @@ def write_multiresunet():
                       "multiresblock5.conv2d_bn_7x7.batchnorm", "multiresblock9.batch_norm1", "conv_final.batchnorm"))
 
 
+def write_uctransnet():
+    """uctransnet: seed-0 UCTransNet(get_uctransnet_config(), img_size=64), B=2 3x64x64, every number
+    kept; the transformer's dropouts (embeddings 0.1, MLP 0.1, uctransnet.py:16-18) are switched off for the fixture
+    (their masks come from the RNG stream); a second manifest pins the seed-0 construction at img_size=256."""
+    mods = load_reference("common_layers", "uctransnet")
+    U = mods["uctransnet"]
+    torch.manual_seed(0)
+    write_manifest(U.UCTransNet(U.get_uctransnet_config(), in_channels=3, num_classes=1, img_size=256), "uctransnet_256")
+    torch.manual_seed(0)
+    model = U.UCTransNet(U.get_uctransnet_config(), in_channels=3, num_classes=1, img_size=64)
+    write_manifest(model, "uctransnet_64")
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    with torch.no_grad():       # zero position embeddings (the reference's initial value) would leave their path untested
+        for i in range(4):
+            getattr(model.mtc, f"embeddings_{i + 1}").position_embeddings.normal_(0.0, 0.5, generator=torch.Generator().manual_seed(10 + i))
+    run_case(model, 2, 64, 64, "uctransnet_b2_64", full_logits=True, name="uctransnet",
+             bn_keys=("inc.norm", "down4.nConvs.1.norm", "mtc.reconstruct_1.norm", "mtc.reconstruct_4.norm", "up4.nConvs.0.norm", "up1.nConvs.1.norm"))
+
+
 def _timm_stand_in():
     """`swin_unet_v2.py:9` imports three helpers from timm, which this image lacks:
     to_2tuple, trunc_normal_ (= torch.nn.init.trunc_normal_) and DropPath (stochastic depth: per-sample
@@ -383,6 +404,10 @@ def main():
         torch.set_num_threads(8)
         write_unet_transformer()
         return
+    if sys.argv[1:] == ["uctransnet"]:
+        torch.set_num_threads(8)
+        write_uctransnet()
+        return
     if sys.argv[1:] == ["multiresunet"]:
         torch.set_num_threads(8)
         write_multiresunet()
@@ -425,6 +450,7 @@ def main():
     write_transatt_unet()
     write_unet_transformer()
     write_multiresunet()
+    write_uctransnet()
 
 
 if __name__ == "__main__":

@@ -638,6 +638,85 @@ def multiresunet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Te
     return conv2d_batchnorm(y, sd, "conv_final", training, False)
 
 
+# ---------------------------------------------------------------------------------------------
+# UCTransNet (unet_zoo/models/uctransnet.py); transformer dropouts off (rates 0.1 / 0.0 / 0.1 in the reference config)
+# ---------------------------------------------------------------------------------------------
+def _uct_convs(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """_make_nConv(.., nb_Conv=2) of ConvBatchNorm — uctransnet.py:372-395"""
+    i = 0
+    while f"{prefix}.{i}.conv.weight" in sd:
+        x = conv_bn_relu(x, sd, f"{prefix}.{i}.conv", f"{prefix}.{i}.norm", training)
+        i += 1
+    return x
+
+
+def _uct_ln(x, sd: State, prefix: str):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-6)
+
+
+def _uct_block(embs, sd: State, p: str, heads: int = 4):
+    """Block_ViT.forward — uctransnet.py:260-301 over Attention_org.forward :126-226 and Mlp.forward :241-247"""
+    kv = sum(e.shape[-1] for e in embs)
+    emb_all = _uct_ln(torch.cat(embs, dim=2), sd, p + ".attn_norm")
+    a = p + ".channel_attn"
+    K = torch.stack([F.linear(emb_all, sd[f"{a}.key.{h}.weight"]) for h in range(heads)], dim=1)
+    Vt = torch.stack([F.linear(emb_all, sd[f"{a}.value.{h}.weight"]) for h in range(heads)], dim=1).transpose(-1, -2)
+    out = []
+    for i, e in enumerate(embs):
+        cx = _uct_ln(e, sd, f"{p}.attn_norm{i + 1}")
+        Q = torch.stack([F.linear(cx, sd[f"{a}.query{i + 1}.{h}.weight"]) for h in range(heads)], dim=1).transpose(-1, -2)
+        scores = torch.matmul(Q, K) / (kv ** 0.5)
+        probs = torch.softmax(F.instance_norm(scores), dim=3)                  # nn.InstanceNorm2d(heads), no affine
+        ctx = torch.matmul(probs, Vt).permute(0, 3, 2, 1).contiguous().mean(dim=3)
+        cx = e + F.linear(ctx, sd[f"{a}.out{i + 1}.weight"])
+        h1 = F.gelu(F.linear(_uct_ln(cx, sd, f"{p}.ffn_norm{i + 1}"), sd[f"{p}.ffn{i + 1}.fc1.weight"], sd[f"{p}.ffn{i + 1}.fc1.bias"]))
+        out.append(F.linear(h1, sd[f"{p}.ffn{i + 1}.fc2.weight"], sd[f"{p}.ffn{i + 1}.fc2.bias"]) + cx)
+    return out
+
+
+def _uct_up(x, skip, sd: State, prefix: str, training: bool) -> torch.Tensor:
+    """UpBlock_attention.forward — uctransnet.py:434-440 with CCA.forward :417-427"""
+    up = _q(F.interpolate(x, scale_factor=2, mode="nearest"))
+    ax = F.linear(skip.mean((2, 3)), sd[prefix + ".coatt.mlp_x.1.weight"], sd[prefix + ".coatt.mlp_x.1.bias"])
+    ag = F.linear(up.mean((2, 3)), sd[prefix + ".coatt.mlp_g.1.weight"], sd[prefix + ".coatt.mlp_g.1.bias"])
+    scale = torch.sigmoid((ax + ag) / 2.0)
+    att = _q(F.relu(skip * scale[:, :, None, None]))
+    return _uct_convs(torch.cat([att, up], 1), sd, prefix + ".nConvs", training)
+
+
+def uctransnet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Tensor:
+    """UCTransNet.forward — uctransnet.py:476-496 (vis=False), ChannelTransformer.forward :338-363"""
+    x1 = conv_bn_relu(x, sd, "inc.conv", "inc.norm", training)
+    x2 = _uct_convs(F.max_pool2d(x1, 2), sd, "down1.nConvs", training)
+    x3 = _uct_convs(F.max_pool2d(x2, 2), sd, "down2.nConvs", training)
+    x4 = _uct_convs(F.max_pool2d(x3, 2), sd, "down3.nConvs", training)
+    x5 = _uct_convs(F.max_pool2d(x4, 2), sd, "down4.nConvs", training)
+    ens, patch, embs = [x1, x2, x3, x4], (32, 16, 8, 4), []
+    for i, (en, p_) in enumerate(zip(ens, patch)):
+        e = _q(F.conv2d(_q(en), _q(sd[f"mtc.embeddings_{i + 1}.patch_embeddings.weight"]),
+                        sd[f"mtc.embeddings_{i + 1}.patch_embeddings.bias"], stride=p_))
+        embs.append(e.flatten(2).transpose(-1, -2) + sd[f"mtc.embeddings_{i + 1}.position_embeddings"])
+    li = 0
+    while f"mtc.encoder.layer.{li}.attn_norm.weight" in sd:
+        embs = _uct_block(embs, sd, f"mtc.encoder.layer.{li}")
+        li += 1
+    refined = []
+    for i, (e, en, p_) in enumerate(zip(embs, ens, patch)):
+        e = _q(_uct_ln(e, sd, f"mtc.encoder.encoder_norm{i + 1}"))
+        B, n, c = e.shape
+        h = int(n ** 0.5)
+        t = F.interpolate(e.permute(0, 2, 1).contiguous().view(B, c, h, h), scale_factor=p_, mode="nearest")
+        r = f"mtc.reconstruct_{i + 1}"
+        t = F.conv2d(t, _q(sd[r + ".conv.weight"]), sd[r + ".conv.bias"])
+        t = F.relu(_bn(t, sd, r + ".norm", training))
+        refined.append(_q(_q(t) + en))
+    y = _uct_up(x5, refined[3], sd, "up4", training)
+    y = _uct_up(y, refined[2], sd, "up3", training)
+    y = _uct_up(y, refined[1], sd, "up2", training)
+    y = _uct_up(y, refined[0], sd, "up1", training)
+    return F.conv2d(y, sd["outc.weight"], sd["outc.bias"])
+
+
 FORWARDS = {"unet": unet_forward, "attention_unet": attention_unet_forward, "u2net": u2net_forward,
             "swin_unet_v2": swin_unet_v2_forward, "nested_unet": nested_unet_forward, "resunet": resunet_forward}
 
@@ -750,6 +829,7 @@ FORWARDS["missformer"] = missformer_forward
 FORWARDS["transatt_unet"] = transatt_unet_forward
 FORWARDS["unet_transformer"] = unet_transformer_forward
 FORWARDS["multiresunet"] = multiresunet_forward
+FORWARDS["uctransnet"] = uctransnet_forward
 
 
 def clone_state(sd: State, requires_grad: bool = False) -> "OrderedDict[str, torch.Tensor]":

@@ -240,7 +240,8 @@ class Engine:
 
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
                      pool: bool = False, im2col: bool = False, upsample: bool = False,
-                     residual: Optional[Act] = None, pool_ceil: bool = False, relu: bool = True) -> Tuple[Act, Optional[Act]]:
+                     residual: Optional[Act] = None, pool_ceil: bool = False, relu: bool = True,
+                     stat_repeat: int = 1) -> Tuple[Act, Optional[Act]]:
         """[nearest x2 upsample ->] Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
 
         Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
@@ -248,7 +249,10 @@ class Engine:
         (common_layers.py:69-76: the upsampled tensor is never materialised, the convolution reads
         the half-resolution input at (h>>1, w>>1)).  `residual` is added AFTER the ReLU and before
         the pool (the RSU tail `hx1d + hxin`, u2net.py:74).  relu=False: Conv -> BatchNorm only
-        (Conv2d_batchnorm(activation='None'), multiresunet.py:26-31).  Returns (act, pooled)."""
+        (Conv2d_batchnorm(activation='None'), multiresunet.py:26-31).  stat_repeat = k: the reference applies this
+        layer to a tensor in which every pixel of x occurs k times (a nearest-neighbour upsampling in front of a 1x1
+        convolution, uctransnet.py:75-80); batch mean, biased variance and all gradients are those of x, only the
+        sample count of the running variance's unbiased factor is k times larger.  Returns (act, pooled)."""
         N, H, W = x.N, x.H, x.W
         if upsample:
             H, W = 2 * H, 2 * W
@@ -269,8 +273,8 @@ class Engine:
                                want_stats=self.training)
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
-            vec = ops.bn_finalize(stats, y.P, bn.weight.detach(), bn.bias.detach(), bn.eps, mom,
-                                  bn.running_mean, bn.running_var)
+            vec = ops.bn_finalize(stats if stat_repeat == 1 else stats * float(stat_repeat), y.P * stat_repeat,
+                                  bn.weight.detach(), bn.bias.detach(), bn.eps, mom, bn.running_mean, bn.running_var)
             if bn.num_batches_tracked is not None:
                 self._bn_counters.append(bn.num_batches_tracked)   # bumped together in finish_forward()
         else:
@@ -1004,30 +1008,42 @@ class Engine:
         a.buf.view(a.N, a.H, a.W, a.ld)[..., a.off:a.off + a.C].copy_(t.permute(0, 2, 3, 1))
 
     def torch_block(self, fn: Callable[..., torch.Tensor], inputs: Sequence[Act], params: Sequence[nn.Parameter],
-                    out: Act) -> Act:
-        """out = fn(*inputs_as_NCHW_fp32, *params) evaluated with PyTorch ops, differentiated by autograd.
+                    out):
+        """out = fn(*inputs_as_NCHW_fp32, *params) evaluated with PyTorch ops, differentiated by autograd; `out` is one
+        activation or a sequence of them (fn then returns a tuple).
 
         For the handful of batched matrix products + softmax of the hybrids' BOTTLENECK attention (16x16 / 32x32
-        maps: < 0.1 % of a step's arithmetic; position / channel attention of transatt_unet.py:29-107, the
-        MultiHeadDense attention of unet_transformer.py:127-228): plain library GEMMs (rocBLAS through torch.bmm) are
-        what such small dense products are for; every convolution, normalisation and resampling around them stays on
-        the HIP kernels.  `fn` must not contain a reduction to a few values over a large tensor (those use a memset
-        node that hipGraph replay mishandles): scalar-parameter gradients go through
-        scale_residual() instead."""
+        maps or a few dozen tokens: < 0.1 % of a step's arithmetic; position / channel attention of
+        transatt_unet.py:29-107, the MultiHeadDense attention of unet_transformer.py:127-228, the channel
+        transformer of uctransnet.py:86-330): plain library GEMMs (rocBLAS through torch.bmm) are what such small dense
+        products are for; every convolution, normalisation and resampling around them stays on the HIP kernels.  `fn`
+        must not contain a reduction to a few values over a large tensor (those use a memset node that hipGraph
+        replay mishandles): scalar-parameter gradients go through scale_residual() instead."""
+        outs = list(out) if isinstance(out, (list, tuple)) else [out]
         xs = [self._dense_nchw(a) for a in inputs]
+
+        def run():
+            y = fn(*xs, *params)
+            ys = list(y) if isinstance(y, (list, tuple)) else [y]
+            assert len(ys) == len(outs)
+            for t, o in zip(ys, outs):
+                assert tuple(t.shape) == (o.N, o.C, o.H, o.W), (tuple(t.shape), (o.N, o.C, o.H, o.W))
+            return ys
+
         if self.record:
             xs = [x.requires_grad_(a.needs_grad) for x, a in zip(xs, inputs)]
             with torch.enable_grad():
-                y = fn(*xs, *params)
-            assert tuple(y.shape) == (out.N, out.C, out.H, out.W), (tuple(y.shape), (out.N, out.C, out.H, out.W))
-            self._store_nchw(y.detach(), out)
+                ys = run()
+            for t, o in zip(ys, outs):
+                self._store_nchw(t.detach(), o)
 
             def bwd():
-                g = self._total_grad(out)
-                if g is None:
+                gs = [self._total_grad(o) for o in outs]
+                if all(g is None for g in gs):
                     return
+                live = [(t, self._dense_nchw(g)) for t, g in zip(ys, gs) if g is not None]
                 wrt = [x for x in xs if x.requires_grad] + [p for p in params if p.requires_grad]
-                grads = torch.autograd.grad(y, wrt, self._dense_nchw(g), allow_unused=True)
+                grads = torch.autograd.grad([t for t, _ in live], wrt, [g for _, g in live], allow_unused=True)
                 k = 0
                 for x, a in zip(xs, inputs):
                     if not x.requires_grad:
@@ -1047,8 +1063,92 @@ class Engine:
             self.tape.append(bwd)
         else:
             with torch.no_grad():
-                y = fn(*xs, *params)
-            self._store_nchw(y, out)
+                ys = run()
+            for t, o in zip(ys, outs):
+                self._store_nchw(t, o)
+        return out
+
+    def upsample_nearest(self, x: Act, factor: int, out: Act, add: Optional[Act] = None) -> Act:
+        """out = nearest-neighbour upsampling of x by an integer factor (+ add): nn.Upsample(scale_factor=f) of
+        uctransnet.py:75, :435 and the residual `x1 + en1` of :358-361.  Streaming glue on the native layout (a
+        broadcast copy); the backward sums each f x f block in two short reductions (f elements each)."""
+        f = factor
+        assert (out.N, out.H, out.W, out.C) == (x.N, x.H * f, x.W * f, x.C)
+        src = x.buf.view(x.N, x.H, 1, x.W, 1, x.ld)[..., x.off:x.off + x.C]
+        dst = out.buf.view(x.N, x.H, f, x.W, f, out.ld)[..., out.off:out.off + x.C]
+        if add is None:
+            dst.copy_(src.expand(x.N, x.H, f, x.W, f, x.C))
+        else:
+            assert (add.N, add.H, add.W, add.C) == (out.N, out.H, out.W, out.C)
+            av = add.buf.view(x.N, x.H, f, x.W, f, add.ld)[..., add.off:add.off + x.C]
+            dst.copy_(av.float() + src.float())
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                if add is not None and add.needs_grad:
+                    add.add_grad(g)
+                if x.needs_grad:
+                    gv = g.buf.view(x.N, x.H, f, x.W, f, g.ld)[..., g.off:g.off + x.C].float()
+                    dx = self.new_act(x.N, x.H, x.W, x.C)
+                    dx.buf.view(x.N, x.H, x.W, x.C).copy_(gv.sum(4).sum(2))
+                    x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return out
+
+    def cca_gate(self, g_low: Act, x: Act, lin_x: nn.Linear, lin_g: nn.Linear, out: Act) -> Act:
+        """CCA.forward (uctransnet.py:417-427): out = relu(x * sigmoid((mlp_x(avgpool(x)) + mlp_g(avgpool(g))) / 2)).
+        `g_low` is the decoder tensor BEFORE its nearest x2 upsampling (the global average is the same).  The global
+        averages and the gradient of the per-(image, channel) scale are reduced by uz_colsum_batched; the two Linear
+        layers on (N, C) vectors are torch ops; the gating itself is elementwise on the native layout."""
+        N, C = x.N, x.C
+        assert lin_x.in_features == C and lin_x.out_features == C and lin_g.out_features == C and lin_g.in_features == g_low.C
+
+        def image_means(a: Act) -> torch.Tensor:
+            sums = torch.empty((a.N, a.C), dtype=torch.float32, device=self.device)
+            hw = a.H * a.W
+            ops.colsum_batched([(a.rows(i * hw, 1, a.H, a.W), sums[i]) for i in range(a.N)])
+            return sums / float(hw)
+
+        ax, ag = image_means(x), image_means(g_low)
+        if self.record:
+            ax.requires_grad_(True)
+            ag.requires_grad_(True)
+        with torch.set_grad_enabled(self.record):
+            att = (torch.nn.functional.linear(ax, lin_x.weight, lin_x.bias) + torch.nn.functional.linear(ag, lin_g.weight, lin_g.bias)) / 2.0
+            scale = torch.sigmoid(att)                                         # (N, C)
+        xv = x.buf.view(N, x.H * x.W, x.ld)[..., x.off:x.off + C]
+        ov = out.buf.view(N, x.H * x.W, out.ld)[..., out.off:out.off + C]
+        ov.copy_(torch.relu(xv.float() * scale.detach()[:, None, :]))
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                gv = g.buf.view(N, x.H * x.W, g.ld)[..., g.off:g.off + C].float()
+                m = gv * (ov > 0)                                              # gradient behind the ReLU
+                prod = self.new_act(N, x.H, x.W, C)
+                prod.buf.view(N, x.H * x.W, C).copy_(m * xv.float())
+                dscale = torch.empty((N, C), dtype=torch.float32, device=self.device)
+                hw = x.H * x.W
+                ops.colsum_batched([(prod.rows(i * hw, 1, x.H, x.W), dscale[i]) for i in range(N)])
+                params = [lin_x.weight, lin_x.bias, lin_g.weight, lin_g.bias]
+                gr = torch.autograd.grad(scale, [ax, ag] + params, dscale)
+                for p_, gp in zip(params, gr[2:]):
+                    self._give_grad(p_, gp)
+                if x.needs_grad:
+                    dx = self.new_act(N, x.H, x.W, C)
+                    dx.buf.view(N, hw, C).copy_(m * scale.detach()[:, None, :] + gr[0][:, None, :] / float(hw))
+                    x.add_grad(dx)
+                if g_low.needs_grad:
+                    dg = self.new_act(g_low.N, g_low.H, g_low.W, g_low.C)
+                    ghw = g_low.H * g_low.W
+                    dg.buf.view(N, ghw, g_low.C).copy_((gr[1] / float(ghw))[:, None, :].expand(N, ghw, g_low.C))
+                    g_low.add_grad(dg)
+
+            self.tape.append(bwd)
         return out
 
     def scale_residual(self, a: Act, gamma: nn.Parameter, x: Act) -> Act:

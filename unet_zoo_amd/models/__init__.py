@@ -23,6 +23,7 @@ from .missformer import MISSFormer
 from .transatt_unet import TransAttUNet
 from .unet_transformer import U_Transformer
 from .multiresunet import MultiResUnet
+from .uctransnet import UCTransNet, get_uctransnet_config
 
 # every name the reference registers (models/__init__.py:27-52); value = constructor or None
 _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
@@ -32,7 +33,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'raunet': None,
     'da_transformer': None,
     'unet_transformer': U_Transformer,
-    'uctransnet': None,
+    'uctransnet': UCTransNet,
     'multiresunet': MultiResUnet,
     'nested_unet': NestedUNet,
     'missformer': MISSFormer,
@@ -52,7 +53,7 @@ _model_entries: Dict[str, Optional[Callable[..., nn.Module]]] = {
     'logo': None,
 }
 
-_config_functions: Dict[str, Callable[..., Dict[str, Any]]] = {}
+_config_functions: Dict[str, Callable[..., Dict[str, Any]]] = {'uctransnet': get_uctransnet_config}
 
 
 def list_models() -> List[str]:
@@ -110,6 +111,10 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
         # MISSFormer for its default 512x512 (missformer.py:868); mirrored.  `depth` is absorbed by **kwargs there.
         # Build the class directly (`MISSFormer(image_size=...)`) for another input size.
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
+    elif name == 'uctransnet':
+        # models/__init__.py:125-132, :225-226: the built-in config, img_size from image_size, `vis` from the kwargs
+        args.update(config=get_uctransnet_config(), in_channels=in_channels, num_classes=num_classes,
+                    img_size=image_size, vis=kwargs.pop('vis', False))
     elif name == 'multiresunet':
         # models/__init__.py:134-137: `depth` travels to the constructor (absorbed by **kwargs there)
         args.update(in_channels=in_channels, num_classes=num_classes, depth=depth)
@@ -130,4 +135,4 @@ def create_model(model_name: str, pretrained: bool = False, **kwargs) -> nn.Modu
     return model
 
 
-__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'TransAttUNet', 'U_Transformer', 'MultiResUnet', 'list_models', 'hip_models', 'get_model_config', 'create_model']
+__all__ = ['UNet', 'AttentionUNet', 'U2NET', 'U2NETP', 'SwinTransformerSys', 'NestedUNet', 'ResUnet', 'MISSFormer', 'TransAttUNet', 'U_Transformer', 'MultiResUnet', 'UCTransNet', 'list_models', 'hip_models', 'get_model_config', 'create_model']

@@ -1,0 +1,336 @@
+"""UCTransNet on the HIP engine (reference graph: unet_zoo/models/uctransnet.py:453-496).
+
+A UNet with 16 ... 128 channels whose four skip connections pass through a Channel Transformer (``mtc``, :312-363: patch
+embeddings of the four scales onto one token grid, four ``Block_ViT`` layers of channel-wise cross attention and MLPs,
+``Reconstruct`` back to each scale) and whose decoder gates each refined skip with a channel attention (``CCA``, :398-427)
+before the concat.
+
+On the HIP kernels: ConvBatchNorm / DownBlock / decoder convolutions (Conv3x3 + BN + ReLU, pools fused into the
+producer), the patch-embedding convolutions (kernel = stride = patch: space-to-depth + GEMM), ``Reconstruct``'s
+Conv1x1 + BN + ReLU -- evaluated on the TOKEN grid: nearest upsampling replicates every pixel, which leaves the batch
+mean and the biased variance unchanged and commutes with ReLU; only the unbiased-variance factor of the running
+statistics sees the larger count, which ``stat_repeat`` restores --, the global-average / scale-gradient reductions of
+CCA, the 1x1 head.  The Channel Transformer itself works on (image_size / 32)^2 tokens of 16 ... 240 channels: library
+GEMMs, LayerNorm and softmax through ``Engine.torch_block``, written so that no reduction to a few values over a large
+tensor occurs (instance-norm moments and Linear biases go through matrix products).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..engine import Engine
+from ..graph import HipModule
+from ..ops import Act
+
+
+class ConfigDict(dict):
+    """attribute access on a dict (common_layers.py:6-18)"""
+
+    def __getattr__(self, key):
+        if key in self:
+            return self[key]
+        raise AttributeError(f"'ConfigDict' object has no attribute '{key}'")
+
+    def __setattr__(self, key, value):
+        self[key] = value
+
+
+def get_uctransnet_config():
+    """uctransnet.py:12-31"""
+    config = ConfigDict()
+    config.base_channel = 16
+    config.transformer = ConfigDict()
+    config.transformer.embeddings_dropout_rate = 0.1
+    config.transformer.attention_dropout_rate = 0.0
+    config.transformer.dropout_rate = 0.1
+    config.transformer.num_heads = 4
+    config.transformer.num_layers = 4
+    config.KV_size = sum(config.base_channel * (2 ** i) for i in range(4))
+    config.patch_sizes = (32, 16, 8, 4)
+    config.expand_ratio = 4
+    config.vis = False
+    return config
+
+
+def _linear(x, lin: nn.Linear):
+    """x W^T + b with the bias inside the matrix product: its gradient comes out of the GEMM, not out of a
+    column-sum reduction (see Engine.torch_block)"""
+    if lin.bias is None:
+        return x @ lin.weight.t()
+    ones = x.new_ones(x.shape[:-1] + (1,))
+    return torch.cat([x, ones], -1) @ torch.cat([lin.weight.t(), lin.bias[None, :]], 0)
+
+
+def _instance_norm_rows(s, eps=1e-5):
+    """nn.InstanceNorm2d(heads) on (B, heads, C, KV) scores (uctransnet.py:118, :176): per (image, head) mean and
+    biased variance over the (C, KV) plane, the two moments taken by matrix products with a ones vector"""
+    B, Hh, C, KV = s.shape
+    flat = s.reshape(B * Hh, C * KV)
+    ones = flat.new_ones(C * KV, 1)
+    n = float(C * KV)
+    mean = (flat @ ones) / n
+    cen = flat - mean
+    var = ((cen * cen) @ ones) / n
+    return (cen * torch.rsqrt(var + eps)).reshape(B, Hh, C, KV)
+
+
+class Channel_Embeddings(nn.Module):
+    def __init__(self, config, patchsize, img_size, in_channels):
+        super().__init__()
+        n_patches = (img_size // patchsize) * (img_size // patchsize)
+        self.patch_embeddings = nn.Conv2d(in_channels, in_channels, kernel_size=patchsize, stride=patchsize)
+        self.position_embeddings = nn.Parameter(torch.zeros(1, n_patches, in_channels))
+        self.dropout = nn.Dropout(config.transformer["embeddings_dropout_rate"])
+
+
+class Reconstruct(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, scale_factor):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, padding=1 if kernel_size == 3 else 0)
+        self.norm = nn.BatchNorm2d(out_channels)
+        self.activation = nn.ReLU(inplace=True)
+        self.scale_factor = scale_factor
+
+
+class Attention_org(nn.Module):
+    def __init__(self, config, vis, channel_num):
+        super().__init__()
+        self.vis, self.KV_size, self.channel_num = vis, config.KV_size, channel_num
+        self.num_attention_heads = config.transformer["num_heads"]
+        self.query1, self.query2, self.query3, self.query4 = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.key, self.value = nn.ModuleList(), nn.ModuleList()
+        for _ in range(config.transformer["num_heads"]):
+            # constructed in the reference's order (uctransnet.py:104-116): the initialisers draw from the RNG
+            qs = [nn.Linear(c, c, bias=False) for c in channel_num]
+            key = nn.Linear(self.KV_size, self.KV_size, bias=False)
+            value = nn.Linear(self.KV_size, self.KV_size, bias=False)
+            for lst, q in zip((self.query1, self.query2, self.query3, self.query4), qs):
+                lst.append(copy.deepcopy(q))
+            self.key.append(copy.deepcopy(key))
+            self.value.append(copy.deepcopy(value))
+        self.psi = nn.InstanceNorm2d(self.num_attention_heads)
+        self.softmax = nn.Softmax(dim=3)
+        self.out1 = nn.Linear(channel_num[0], channel_num[0], bias=False)
+        self.out2 = nn.Linear(channel_num[1], channel_num[1], bias=False)
+        self.out3 = nn.Linear(channel_num[2], channel_num[2], bias=False)
+        self.out4 = nn.Linear(channel_num[3], channel_num[3], bias=False)
+        self.attn_dropout = nn.Dropout(config.transformer["attention_dropout_rate"])
+        self.proj_dropout = nn.Dropout(config.transformer["attention_dropout_rate"])
+
+    def run(self, embs, emb_all):
+        """uctransnet.py:126-226 for four scales; softmax over the KV channels of instance-normalised scores"""
+        K = torch.stack([_linear(emb_all, k) for k in self.key], dim=1)                    # (B, h, n, KV)
+        Vt = torch.stack([_linear(emb_all, v) for v in self.value], dim=1).transpose(-1, -2)  # (B, h, KV, n)
+        outs = []
+        for emb, queries, out in zip(embs, (self.query1, self.query2, self.query3, self.query4),
+                                     (self.out1, self.out2, self.out3, self.out4)):
+            Q = torch.stack([_linear(emb, q) for q in queries], dim=1).transpose(-1, -2)    # (B, h, C, n)
+            scores = torch.matmul(Q, K) / math.sqrt(self.KV_size)                           # (B, h, C, KV)
+            probs = F.dropout(torch.softmax(_instance_norm_rows(scores), dim=3), self.attn_dropout.p, self.training)
+            ctx = torch.matmul(probs, Vt).permute(0, 3, 2, 1).mean(dim=3)                   # (B, n, C)
+            outs.append(F.dropout(_linear(ctx, out), self.proj_dropout.p, self.training))
+        return outs
+
+
+class Mlp(nn.Module):
+    def __init__(self, config, in_channel, mlp_channel):
+        super().__init__()
+        self.fc1 = nn.Linear(in_channel, mlp_channel)
+        self.fc2 = nn.Linear(mlp_channel, in_channel)
+        self.act_fn = nn.GELU()
+        self.dropout = nn.Dropout(config.transformer["dropout_rate"])
+        nn.init.xavier_uniform_(self.fc1.weight)
+        nn.init.xavier_uniform_(self.fc2.weight)
+        nn.init.normal_(self.fc1.bias, std=1e-6)
+        nn.init.normal_(self.fc2.bias, std=1e-6)
+
+    def run(self, x):
+        x = F.dropout(F.gelu(_linear(x, self.fc1)), self.dropout.p, self.training)
+        return F.dropout(_linear(x, self.fc2), self.dropout.p, self.training)
+
+
+class Block_ViT(nn.Module):
+    def __init__(self, config, vis, channel_num):
+        super().__init__()
+        r = config.expand_ratio
+        for i, c in enumerate(channel_num):
+            setattr(self, f"attn_norm{i + 1}", nn.LayerNorm(c, eps=1e-6))
+        self.attn_norm = nn.LayerNorm(config.KV_size, eps=1e-6)
+        self.channel_attn = Attention_org(config, vis, channel_num)
+        for i, c in enumerate(channel_num):
+            setattr(self, f"ffn_norm{i + 1}", nn.LayerNorm(c, eps=1e-6))
+        for i, c in enumerate(channel_num):
+            setattr(self, f"ffn{i + 1}", Mlp(config, c, c * r))
+
+    def run(self, embs):
+        """uctransnet.py:260-301"""
+        emb_all = self.attn_norm(torch.cat(embs, dim=2))
+        cx = [getattr(self, f"attn_norm{i + 1}")(e) for i, e in enumerate(embs)]
+        cx = self.channel_attn.run(cx, emb_all)
+        cx = [o + c for o, c in zip(embs, cx)]
+        return [getattr(self, f"ffn{i + 1}").run(getattr(self, f"ffn_norm{i + 1}")(c)) + c for i, c in enumerate(cx)]
+
+
+class Encoder(nn.Module):
+    def __init__(self, config, vis, channel_num):
+        super().__init__()
+        self.vis = vis
+        self.layer = nn.ModuleList()
+        for i, c in enumerate(channel_num):
+            setattr(self, f"encoder_norm{i + 1}", nn.LayerNorm(c, eps=1e-6))
+        for _ in range(config.transformer["num_layers"]):
+            self.layer.append(copy.deepcopy(Block_ViT(config, vis, channel_num)))
+
+    def run(self, embs):
+        for blk in self.layer:
+            embs = blk.run(embs)
+        return [getattr(self, f"encoder_norm{i + 1}")(e) for i, e in enumerate(embs)]
+
+
+class ChannelTransformer(nn.Module):
+    def __init__(self, config, vis, img_size, channel_num=(64, 128, 256, 512), patchSize=(32, 16, 8, 4)):
+        super().__init__()
+        self.patch = tuple(patchSize)
+        for i in range(4):
+            setattr(self, f"embeddings_{i + 1}", Channel_Embeddings(config, patchSize[i], img_size=img_size // (2 ** i),
+                                                                    in_channels=channel_num[i]))
+        self.encoder = Encoder(config, vis, channel_num)
+        for i in range(4):
+            setattr(self, f"reconstruct_{i + 1}", Reconstruct(channel_num[i], channel_num[i], kernel_size=1,
+                                                              scale_factor=(patchSize[i], patchSize[i])))
+
+    def _tokens(self, *args):
+        """position embeddings + dropout, the encoder; (B, C, h, w) maps in and out (uctransnet.py:50-55, :304-330)"""
+        maps, pos = args[:4], args[4:8]
+        embs = []
+        for i, (m, p) in enumerate(zip(maps, pos)):
+            emb = getattr(self, f"embeddings_{i + 1}")
+            t = m.flatten(2).transpose(-1, -2) + p
+            embs.append(F.dropout(t, emb.dropout.p, self.training))
+        B, _, h, w = maps[0].shape
+        return tuple(e.permute(0, 2, 1).reshape(B, -1, h, w) for e in self.encoder.run(embs))
+
+    def emit(self, eng: Engine, ens: List[Act], outs: List[Act]) -> List[Act]:
+        toks = []
+        for i, en in enumerate(ens):
+            emb = getattr(self, f"embeddings_{i + 1}")
+            if (en.H // self.patch[i]) * (en.W // self.patch[i]) != emb.position_embeddings.shape[1] or en.H % self.patch[i]:
+                raise ValueError(f"UCTransNet was built for img_size {int(math.sqrt(emb.position_embeddings.shape[1])) * self.patch[i] * 2 ** i}"
+                                 f" (square); got a {en.H * 2 ** i}x{en.W * 2 ** i} input")
+            toks.append(eng.patch_conv(en, emb.patch_embeddings))
+        pos = [getattr(self, f"embeddings_{i + 1}").position_embeddings for i in range(4)]
+        others = [p for n, p in self.encoder.named_parameters()]
+        enc = [eng.new_act(t.N, t.H, t.W, t.C) for t in toks]
+        eng.torch_block(lambda *a: self._tokens(*a[:8]), toks, pos + others, enc)
+        for i, (e, en, out) in enumerate(zip(enc, ens, outs)):
+            rec = getattr(self, f"reconstruct_{i + 1}")
+            f = self.patch[i]
+            r, _ = eng.conv_bn_relu(e, rec.conv, rec.norm, stat_repeat=f * f)      # on the token grid (module docstring)
+            eng.upsample_nearest(r, f, out, add=en)                                 # nn.Upsample(scale_factor=p) ... + en
+        return outs
+
+
+class ConvBatchNorm(nn.Module):
+    def __init__(self, in_channels, out_channels, activation='ReLU'):
+        super().__init__()
+        if activation.lower() != 'relu':
+            raise NotImplementedError("UCTransNet is built with ReLU activations (uctransnet.py:365-370 default)")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.norm = nn.BatchNorm2d(out_channels)
+        self.activation = nn.ReLU()
+
+
+def _make_nConv(in_channels, out_channels, nb_Conv, activation='ReLU'):
+    layers = [ConvBatchNorm(in_channels, out_channels, activation)]
+    for _ in range(nb_Conv - 1):
+        layers.append(ConvBatchNorm(out_channels, out_channels, activation))
+    return nn.Sequential(*layers)
+
+
+def _emit_convs(eng: Engine, x: Act, convs: nn.Sequential, *, out: Optional[Act] = None, pool: bool = False, im2col: bool = False):
+    pooled = None
+    for i, cb in enumerate(convs):
+        last = i == len(convs) - 1
+        x, pooled = eng.conv_bn_relu(x, cb.conv, cb.norm, out=out if last else None, pool=pool and last,
+                                     im2col=im2col and i == 0)
+    return x, pooled
+
+
+class DownBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, nb_Conv, activation='ReLU'):
+        super().__init__()
+        self.maxpool = nn.MaxPool2d(2)
+        self.nConvs = _make_nConv(in_channels, out_channels, nb_Conv, activation)
+
+
+class Flatten(nn.Module):
+    def forward(self, x):
+        return x.view(x.size(0), -1)
+
+
+class CCA(nn.Module):
+    def __init__(self, F_g, F_x):
+        super().__init__()
+        self.mlp_x = nn.Sequential(Flatten(), nn.Linear(F_x, F_x))
+        self.mlp_g = nn.Sequential(Flatten(), nn.Linear(F_g, F_x))
+        self.relu = nn.ReLU(inplace=True)
+
+
+class UpBlock_attention(nn.Module):
+    def __init__(self, in_channels, out_channels, nb_Conv, activation='ReLU'):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=2)
+        self.coatt = CCA(F_g=in_channels // 2, F_x=in_channels // 2)
+        self.nConvs = _make_nConv(in_channels, out_channels, nb_Conv, activation)
+
+    def emit(self, eng: Engine, x: Act, skip: Act) -> Act:
+        full, (att_slot, up_slot) = eng.new_cat(skip.N, skip.H, skip.W, (skip.C, x.C))     # cat([skip_x_att, up], 1)
+        eng.upsample_nearest(x, 2, up_slot)
+        eng.cca_gate(x, skip, self.coatt.mlp_x[1], self.coatt.mlp_g[1], att_slot)
+        y, _ = _emit_convs(eng, full, self.nConvs)
+        return y
+
+
+class UCTransNet(HipModule):
+    def __init__(self, config, in_channels=3, num_classes=1, img_size=224, vis=False, **kwargs):
+        super().__init__()
+        if vis:
+            raise NotImplementedError("vis=True (returning the attention maps, uctransnet.py:493-494) is not built")
+        self.vis, self.n_channels, self.n_classes, self.img_size = vis, in_channels, num_classes, img_size
+        c = config.base_channel
+        self.inc = ConvBatchNorm(in_channels, c)
+        self.down1 = DownBlock(c, c * 2, nb_Conv=2)
+        self.down2 = DownBlock(c * 2, c * 4, nb_Conv=2)
+        self.down3 = DownBlock(c * 4, c * 8, nb_Conv=2)
+        self.down4 = DownBlock(c * 8, c * 8, nb_Conv=2)
+        self.mtc = ChannelTransformer(config, vis, img_size, channel_num=[c, c * 2, c * 4, c * 8], patchSize=config.patch_sizes)
+        self.up4 = UpBlock_attention(c * 16, c * 4, nb_Conv=2)
+        self.up3 = UpBlock_attention(c * 8, c * 2, nb_Conv=2)
+        self.up2 = UpBlock_attention(c * 4, c, nb_Conv=2)
+        self.up1 = UpBlock_attention(c * 2, c, nb_Conv=2)
+        self.outc = nn.Conv2d(c, num_classes, kernel_size=(1, 1), stride=(1, 1))
+
+    def emit(self, eng: Engine, x: torch.Tensor):
+        N, _, H, W = x.shape
+        if (H, W) != (self.img_size, self.img_size):
+            raise ValueError(f"UCTransNet was built for {self.img_size}x{self.img_size} inputs (its position embeddings "
+                             f"fix the token grid), got {H}x{W}")
+        x1, p1 = eng.conv_bn_relu(eng.input_im2col(x), self.inc.conv, self.inc.norm, pool=True, im2col=True)
+        x2, p2 = _emit_convs(eng, p1, self.down1.nConvs, pool=True)
+        x3, p3 = _emit_convs(eng, p2, self.down2.nConvs, pool=True)
+        x4, p4 = _emit_convs(eng, p3, self.down3.nConvs, pool=True)
+        x5, _ = _emit_convs(eng, p4, self.down4.nConvs)
+        ens = [x1, x2, x3, x4]
+        refined = self.mtc.emit(eng, ens, [eng.new_act(e.N, e.H, e.W, e.C) for e in ens])
+        y = self.up4.emit(eng, x5, refined[3])
+        y = self.up3.emit(eng, y, refined[2])
+        y = self.up2.emit(eng, y, refined[1])
+        y = self.up1.emit(eng, y, refined[0])
+        return (eng.out_conv(y, self.outc),)
