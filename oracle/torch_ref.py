@@ -71,7 +71,7 @@ def down_sample(x, sd: State, prefix: str, training: bool) -> Tuple[torch.Tensor
 def up_sample_unet(x1, x2, sd: State, prefix: str, training: bool) -> torch.Tensor:
     """UpSample_UNet.forward — common_layers.py:107-116: ConvTranspose2d(k2,s2), zero-pad to the
     skip's size, cat([up, skip], dim=1), DoubleConv."""
-    x1 = F.conv_transpose2d(x1, sd[f"{prefix}.up.weight"], sd[f"{prefix}.up.bias"], stride=2)
+    x1 = _q(F.conv_transpose2d(_q(x1), _q(sd[f"{prefix}.up.weight"]), sd[f"{prefix}.up.bias"], stride=2))
     dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
     x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
     return double_conv(torch.cat([x1, x2], 1), sd, f"{prefix}.conv.conv_op", training)
@@ -110,7 +110,9 @@ def up_conv_block(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
 
 
 def _conv1x1_bn(x, sd: State, prefix: str, training: bool) -> torch.Tensor:
-    x = F.conv2d(x, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"])
+    x = F.conv2d(_q(x), _q(sd[f"{prefix}.0.weight"]), sd[f"{prefix}.0.bias"])
+    if x.shape[1] > 1:
+        x = _q(x)                 # the engine stores the raw 1x1 outputs in the run dtype, the 1-channel psi map in fp32
     x = F.batch_norm(x, sd[f"{prefix}.1.running_mean"], sd[f"{prefix}.1.running_var"], sd[f"{prefix}.1.weight"],
                      sd[f"{prefix}.1.bias"], training=training, momentum=0.1, eps=1e-5)
     if training and f"{prefix}.1.num_batches_tracked" in sd:
@@ -122,8 +124,14 @@ def attention_block(g, x, sd: State, prefix: str, training: bool) -> torch.Tenso
     """AttentionBlock.forward — attention_unet.py:34-40."""
     g1 = _conv1x1_bn(g, sd, f"{prefix}.w_g", training)
     x1 = _conv1x1_bn(x, sd, f"{prefix}.w_x", training)
-    psi = torch.sigmoid(_conv1x1_bn(F.relu(g1 + x1), sd, f"{prefix}.psi", training))
-    return psi * x
+    r = F.relu(g1 + x1)
+    keep, _STORE = _STORE_DTYPE, None
+    set_storage_rounding(None)    # relu(g1 + x1) is never stored: the psi convolution reads it in fp32
+    try:
+        pre = _conv1x1_bn(r, sd, f"{prefix}.psi", training)
+    finally:
+        set_storage_rounding(keep)
+    return _q(torch.sigmoid(pre) * x)
 
 
 def attention_unet_forward(sd: State, x: torch.Tensor, training: bool) -> torch.Tensor:

@@ -286,9 +286,15 @@ def test_u2net_fp32_step_matches_reference_golden(golden_dir):
         assert abs(int((v > 0).sum()) - meta["eval_positive_pixels"][k]) <= 4
 
 
-@pytest.mark.parametrize("name,K,H,W", [("u2netp", 2, 96, 64), ("u2netp", 1, 64, 64), ("u2net", 1, 64, 96)])
+@pytest.mark.parametrize("name,K,H,W", [("u2netp", 2, 96, 64), ("u2netp", 1, 64, 64), ("u2net", 1, 64, 96),
+                                        ("u2net", 1, 32, 64)])
 def test_u2net_family_fp32_against_oracle(name, K, H, W):
-    """other member / two classes / non-square: compare with the CPU oracle on the same weights"""
+    """other member / two classes / non-square: compare with the CPU oracle on the same weights.
+
+    The bound of every head is max(1e-3, 4 x the reference graph's OWN fp32-vs-fp64 spread on this input), computed
+    here.  At 2 x 32 x 64 the innermost RSU maps are 1 x 2 pixels, their BatchNorms see four samples, and the reference
+    evaluated in fp32 differs from itself in fp64 by 3.4 % on `main` (16 % on the 1 x 2 layers; 1.4e-4 at 64 x 96): the
+    5 % seen there in round 1 was the conditioning of the network, not a kernel fault on small maps."""
     torch.manual_seed(3)
     m = unet_zoo_amd.create_model(name, in_channels=3, num_classes=K)
     m.run_dtype = torch.float32
@@ -304,10 +310,18 @@ def test_u2net_family_fp32_against_oracle(name, K, H, W):
     rloss = torch_ref.model_loss(ref, mask)
     names = [k for k, v in st.items() if v.requires_grad]
     rg = dict(zip(names, torch.autograd.grad(rloss, [st[k] for k in names])))
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    with torch.no_grad():
+        r64 = torch_ref.u2net_forward(torch_ref.clone_state(sd64), x.double(), True)
+    spread = {k: ((ref[k].detach().double() - r64[k]).abs().max() / r64[k].abs().max()).item() for k in ref}
+    ill = max(spread.values()) > 2.5e-4
     for k in ref:
         got, want = outs[k].detach().cpu(), ref[k].detach()
-        assert (got - want).abs().max() <= 1e-3 * want.abs().max(), k
-    assert abs(loss.item() - rloss.item()) < 2e-5
+        assert (got - want).abs().max() <= max(1e-3, 4 * spread[k]) * want.abs().max(), (k, spread[k])
+    assert abs(loss.item() - rloss.item()) < (2e-5 if not ill else 40 * max(spread.values()) * rloss.item())
+    if ill:
+        assert (H, W) == (32, 64) and spread["main"] > 1e-2      # the documented case, nothing else
+        return
     keep = [n for n, _ in m.named_parameters() if not n.endswith("conv_s1.bias")]
     gflat = torch.cat([dict(m.named_parameters())[n].grad.flatten().cpu() for n in keep])
     rflat = torch.cat([rg[n].flatten() for n in keep])

@@ -128,9 +128,15 @@ def test_against_oracle_on_other_shape_and_classes(dtype):
     logits = m(x.to(DEV))
     F.binary_cross_entropy_with_logits(logits, t.to(DEV)).backward()
     st = torch_ref.clone_state(sd, requires_grad=True)
-    ref = torch_ref.unet_forward(st, x, True)
-    F.binary_cross_entropy_with_logits(ref, t).backward()
-    rel = 1e-3 if dtype == torch.float32 else 8e-2
+    # bf16: the oracle rounds to bf16 where the engine stores bf16 (tests/test_bf16_rounded_oracle_gpu.py has the
+    # layer-by-layer version); what is left is summation order and half-way roundings
+    torch_ref.set_storage_rounding(None if dtype == torch.float32 else torch.bfloat16)
+    try:
+        ref = torch_ref.unet_forward(st, x, True)
+        F.binary_cross_entropy_with_logits(ref, t).backward()
+    finally:
+        torch_ref.set_storage_rounding(None)
+    rel = 1e-3 if dtype == torch.float32 else 2e-2
     assert (logits.detach().cpu() - ref.detach()).abs().max() <= rel * ref.detach().abs().max()
     dots = []
     for name, p in m.named_parameters():
@@ -141,16 +147,14 @@ def test_against_oracle_on_other_shape_and_classes(dtype):
         if dtype == torch.float32:
             assert err <= 2e-2, (name, err.item())
         else:
-            # bf16 storage of the pre-BN tensor flips the ReLU mask of every element whose
-            # pre-activation is within 2^-9 relative of zero (~0.3 % of them); each flip is a
-            # 100 % change of that element's gradient, i.e. ~sqrt(0.3 %) = 5 % noise per layer
-            # against the fp32 reference (every bf16 kernel alone is exact to rounding, see
-            # test_ops_gpu.py).  The direction of the gradient is what is compared here.
+            # against the storage-rounded oracle the ReLU masks are (nearly) the same on both sides; round 1 compared
+            # with the fp32 reference, where ~0.3 % of the masks flip, and had to accept cosine 0.75 per layer
             cos = F.cosine_similarity(p.grad.cpu().flatten(), rg.flatten(), dim=0)
-            assert cos >= 0.75, (name, cos.item())
+            if rg.norm() > 2e-3 * torch.sqrt(sum((v.grad.double() ** 2).sum() for v in st.values() if v.grad is not None)):
+                assert cos >= 0.9, (name, cos.item())
         dots.append((p.grad.cpu().flatten(), rg.flatten()))
     a, b = torch.cat([d[0] for d in dots]), torch.cat([d[1] for d in dots])
-    assert F.cosine_similarity(a, b, dim=0) >= (0.9999 if dtype == torch.float32 else 0.9)
+    assert F.cosine_similarity(a, b, dim=0) >= (0.9999 if dtype == torch.float32 else 0.99)
 
 
 def test_full_size_properties_bf16():
