@@ -536,6 +536,23 @@ int uz_add_relu(int dtype, const void* a, int lda, const void* b, int ldb, void*
 int uz_relu_bwd(int dtype, const void* out, int ldo, const void* g, int ldg, void* dx, int lddx, long long P, int C,
                 void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline on the GPU (BoneDataset.__getitem__, unet_zoo/data/datasets.py:40-59):
+ *   transforms.Resize((512, 512)) on a PIL image = Pillow's antialiased two-pass BILINEAR resample of 8-bit pixels in
+ *   22-bit fixed point (Pillow src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
+ *   ImagingResampleHorizontal_8bpc / Vertical_8bpc), then ToTensor (p / 255) and Normalize((v - mean) / std) for the
+ *   image, `> 0.5` for the mask.  Bit-exact with Pillow + torch on the CPU.
+ * uz_pil_resample_h_u8: dst[h][x][c] (uint8, HWC) for x < Wout from src (H, Win, C) uint8; `bounds` = Wout pairs
+ *   (first tap, tap count), `kk` = Wout rows of `ksize` fixed-point coefficients (device pointers, built on the host).
+ * uz_pil_resample_v_f32: the vertical pass over (Hin, W, C) uint8 fused with the conversion: mode 0 writes
+ *   out[c][y][x] = (p / 255 - mean[c]) / std[c] (fp32, CHW), mode 1 (C = 1) out = (p / 255 > 0.5).  mean / std: HOST
+ *   pointers to C floats.
+ * ------------------------------------------------------------------------------------------- */
+int uz_pil_resample_h_u8(const void* src, int H, int Win, int C, const int* bounds, const int* kk, int ksize, int Wout,
+                         void* dst, void* stream);
+int uz_pil_resample_v_f32(const void* src, int Hin, int W, int C, const int* bounds, const int* kk, int ksize, int Hout,
+                          const float* mean_host, const float* std_host, int mode, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

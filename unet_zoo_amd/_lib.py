@@ -44,7 +44,7 @@ EXPORTS = (
     "uz_gelu_fwd", "uz_gelu_bwd", "uz_dwconv3x3", "uz_dwconv3x3_wgrad_rows", "uz_dwconv3x3_wgrad",
     "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
     "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res",
-    "uz_add_relu", "uz_relu_bwd",
+    "uz_add_relu", "uz_relu_bwd", "uz_pil_resample_h_u8", "uz_pil_resample_v_f32",
 )
 
 
@@ -218,6 +218,8 @@ def load():
     lib.uz_sra_bwd.argtypes = [POINTER(SraDesc), vp, vp, vp, vp, vp, vp, ip, vp, ip, vp, ip, vp, vp]
     lib.uz_add_relu.argtypes = [ip, vp, ip, vp, ip, vp, ip, ll, ip, vp]
     lib.uz_relu_bwd.argtypes = [ip, vp, ip, vp, ip, vp, ip, ll, ip, vp]
+    lib.uz_pil_resample_h_u8.argtypes = [vp, ip, ip, ip, vp, vp, ip, ip, vp, vp]
+    lib.uz_pil_resample_v_f32.argtypes = [vp, ip, ip, ip, vp, vp, ip, ip, POINTER(c_float), POINTER(c_float), ip, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("uz_last_error_string",):

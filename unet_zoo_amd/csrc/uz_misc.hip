@@ -105,3 +105,88 @@ extern "C" int uz_relu_bwd(int dtype, const void* out, int ldo, const void* g, i
   UZ_LAUNCH_CHECK("uz_relu_bwd");
   return UZ_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Input pipeline (unet_zoo/data/datasets.py:40-59): transforms.Resize((512, 512)) of a PIL image -- Pillow's
+// two-pass antialiased BILINEAR resample of 8-bit images in 22-bit fixed point, restated bit for bit --, ToTensor,
+// Normalize(mean, std) for the image, `> 0.5` for the mask.  The coefficient tables (Pillow's precompute_coeffs +
+// normalize_coeffs_8bpc, src/libImaging/Resample.c) come from the host; the passes are integer arithmetic.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int PIL_PRECISION_BITS = 32 - 8 - 2;
+
+__device__ __forceinline__ int pil_clip8(int v) {
+  v >>= PIL_PRECISION_BITS;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// dst[h][x][c] = clip8(2^21 + sum_t src[h][xmin(x) + t][c] * kk[x][t])      (ImagingResampleHorizontal_8bpc)
+__global__ __launch_bounds__(256) void pil_resample_h_kernel(const unsigned char* __restrict__ src, int H, int Win, int C,
+                                                             const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                             int ksize, int Wout, unsigned char* __restrict__ dst) {
+  const long long total = (long long)H * Wout;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % Wout);
+    const long long h = idx / Wout;
+    const int xmin = bounds[2 * x], xmax = bounds[2 * x + 1];
+    const int* k = kk + (long long)x * ksize;
+    const unsigned char* row = src + (h * Win + xmin) * C;
+    for (int c = 0; c < C; ++c) {
+      int ss = 1 << (PIL_PRECISION_BITS - 1);
+      for (int t = 0; t < xmax; ++t) ss += (int)row[t * C + c] * k[t];
+      dst[(h * Wout + x) * C + c] = (unsigned char)pil_clip8(ss);
+    }
+  }
+}
+
+// vertical pass fused with ToTensor + Normalize (mode 0: out[c][y][x] = (p / 255 - mean[c]) / std[c], fp32 in torch's
+// operation order) or with the mask threshold (mode 1: out = p / 255 > 0.5)      (ImagingResampleVertical_8bpc)
+__global__ __launch_bounds__(256) void pil_resample_v_kernel(const unsigned char* __restrict__ src, int Hin, int W, int C,
+                                                             const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                             int ksize, int Hout, float m0, float m1, float m2, float s0,
+                                                             float s1, float s2, int mode, float* __restrict__ out) {
+  const long long total = (long long)Hout * W;
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % W);
+    const int y = (int)(idx / W);
+    const int ymin = bounds[2 * y], ymax = bounds[2 * y + 1];
+    const int* k = kk + (long long)y * ksize;
+    for (int c = 0; c < C; ++c) {
+      int ss = 1 << (PIL_PRECISION_BITS - 1);
+      for (int t = 0; t < ymax; ++t) ss += (int)src[((long long)(ymin + t) * W + x) * C + c] * k[t];
+      const float v = (float)pil_clip8(ss) / 255.0f;
+      out[((long long)c * Hout + y) * W + x] = mode == 0 ? (v - mean[c]) / sd[c] : (v > 0.5f ? 1.0f : 0.0f);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int uz_pil_resample_h_u8(const void* src, int H, int Win, int C, const int* bounds, const int* kk, int ksize,
+                                    int Wout, void* dst, void* stream) {
+  UZ_REQUIRE(src && bounds && kk && dst && H > 0 && Win > 0 && Wout > 0 && C >= 1 && C <= 4 && ksize >= 1,
+             "uz_pil_resample_h_u8: bad arguments");
+  hipLaunchKernelGGL(pil_resample_h_kernel, dim3(grid_for((long long)H * Wout)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)src, H, Win, C, bounds, kk, ksize, Wout, (unsigned char*)dst);
+  UZ_LAUNCH_CHECK("uz_pil_resample_h_u8");
+  return UZ_OK;
+}
+
+extern "C" int uz_pil_resample_v_f32(const void* src, int Hin, int W, int C, const int* bounds, const int* kk, int ksize,
+                                     int Hout, const float* mean_host, const float* std_host, int mode, float* out,
+                                     void* stream) {
+  UZ_REQUIRE(src && bounds && kk && out && Hin > 0 && W > 0 && Hout > 0 && C >= 1 && C <= 3 && ksize >= 1 &&
+                 (mode == 0 || mode == 1), "uz_pil_resample_v_f32: bad arguments");
+  UZ_REQUIRE(mode == 1 || (mean_host && std_host), "uz_pil_resample_v_f32: mode 0 needs mean and std");
+  float m[3] = {0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f};
+  if (mode == 0)
+    for (int c = 0; c < C; ++c) {
+      m[c] = mean_host[c];
+      s[c] = std_host[c];
+    }
+  hipLaunchKernelGGL(pil_resample_v_kernel, dim3(grid_for((long long)Hout * W)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)src, Hin, W, C, bounds, kk, ksize, Hout, m[0], m[1], m[2], s[0], s[1], s[2], mode,
+                     out);
+  UZ_LAUNCH_CHECK("uz_pil_resample_v_f32");
+  return UZ_OK;
+}
