@@ -272,7 +272,7 @@ def swin_attention_mask(H: int, W: int, ws: int, shift: int) -> torch.Tensor:
     return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
 
 
-def swin_window_attention(xw, sd: State, prefix: str, heads: int, mask):
+def swin_window_attention(xw, sd: State, prefix: str, heads: int, mask, qk_scale=None):
     """WindowAttention.forward — swin_unet_v2.py:127-159: cosine attention with a learned per-entry
     temperature tau (clipped at 0.01), continuous position bias from the log-spaced offsets through
     cpb = Linear(2,256)-ReLU-Linear(256,heads), optional shift mask, softmax, @v, proj."""
@@ -280,7 +280,7 @@ def swin_window_attention(xw, sd: State, prefix: str, heads: int, mask):
     d = C // heads
     qkv = F.linear(xw, sd[prefix + ".qkv.weight"], sd.get(prefix + ".qkv.bias"))
     qkv = qkv.reshape(B_, N, 3, heads, d).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0] * d ** -0.5, qkv[1], qkv[2]
+    q, k, v = qkv[0] * (qk_scale or d ** -0.5), qkv[1], qkv[2]       # self.scale = qk_scale or head_dim ** -0.5 (:94)
     attn = torch.einsum("bhqd,bhkd->bhqk", q, k) / torch.maximum(
         q.norm(dim=-1, keepdim=True) * k.norm(dim=-1, keepdim=True).transpose(-2, -1),
         torch.tensor(1e-6, dtype=q.dtype))
@@ -298,7 +298,7 @@ def swin_window_attention(xw, sd: State, prefix: str, heads: int, mask):
 
 
 def swin_block(x, sd: State, prefix: str, H: int, W: int, heads: int, ws: int, shift: int,
-               drop_scale=None):
+               drop_scale=None, qk_scale=None):
     """SwinTransformerBlock.forward — swin_unet_v2.py:240-269.  NOTE: the reference returns after
     `shortcut + drop_path(norm1(attention))`; its mlp / norm2 members are never called.
     drop_scale: per-sample (B,) factor of the stochastic-depth branch (None = identity)."""
@@ -310,7 +310,7 @@ def swin_block(x, sd: State, prefix: str, H: int, W: int, heads: int, ws: int, s
         xs = torch.roll(xs, shifts=(-shift, -shift), dims=(1, 2))
     xw = xs.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
     mask = swin_attention_mask(H, W, ws, shift) if shift > 0 else None
-    aw = swin_window_attention(xw, sd, prefix + ".attn", heads, mask)
+    aw = swin_window_attention(xw, sd, prefix + ".attn", heads, mask, qk_scale)
     xs = aw.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
     if shift > 0:
         xs = torch.roll(xs, shifts=(shift, shift), dims=(1, 2))
@@ -353,13 +353,15 @@ def swin_unet_v2_forward(sd: State, x: torch.Tensor, training: bool, cfg: dict =
     # PatchEmbed (:548-556): Conv2d(k=s=patch) -> tokens -> LayerNorm
     t = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
     t = _layer_norm(t, sd, "patch_embed.norm")
+    if "absolute_pos_embed" in sd:                            # ape=True (:713-715); pos_drop: rate 0 here
+        t = t + sd["absolute_pos_embed"]
     skips = []
     for i in range(nl):                                       # forward_features (:711-723)
         skips.append(t)
         r = R >> i
         for b in range(depths[i]):
             pre = f"layers.{i}.blocks.{b}"
-            t = swin_block(t, sd, pre, r, r, heads[i], ws, 0 if b % 2 == 0 else ws // 2, ds.get(pre))
+            t = swin_block(t, sd, pre, r, r, heads[i], ws, 0 if b % 2 == 0 else ws // 2, ds.get(pre), cfg.get("qk_scale"))
         if i < nl - 1:
             t = swin_patch_merging(t, sd, f"layers.{i}.downsample", r, r)
     t = _layer_norm(t, sd, "norm")
@@ -373,7 +375,7 @@ def swin_unet_v2_forward(sd: State, x: torch.Tensor, training: bool, cfg: dict =
         t = F.linear(t, sd[f"concat_back_dim.{inx}.weight"], sd[f"concat_back_dim.{inx}.bias"])
         for b in range(depths[lvl]):
             pre = f"layers_up.{inx}.blocks.{b}"
-            t = swin_block(t, sd, pre, r, r, heads[lvl], ws, 0 if b % 2 == 0 else ws // 2, ds.get(pre))
+            t = swin_block(t, sd, pre, r, r, heads[lvl], ws, 0 if b % 2 == 0 else ws // 2, ds.get(pre), cfg.get("qk_scale"))
         if inx < nl - 1:
             t = swin_patch_expand(t, sd, f"layers_up.{inx}.upsample", r, r, 2)
     t = _layer_norm(t, sd, "norm_up")
@@ -763,12 +765,24 @@ def _mf_mixffn_skip(x, sd: State, prefix: str, H: int, W: int):
     return _mf_linear(a, sd, prefix + ".fc2")
 
 
+def _mf_mixffn(x, sd: State, prefix: str, H: int, W: int):
+    """MixFFN.forward — missformer.py:186-189 (token_mlp='mix')"""
+    f = _mf_linear(x, sd, prefix + ".fc1")
+    B, N, C = f.shape
+    dw = F.conv2d(f.transpose(1, 2).reshape(B, C, H, W), sd[prefix + ".dwconv.dwconv.weight"],
+                  sd[prefix + ".dwconv.dwconv.bias"], padding=1, groups=C).flatten(2).transpose(1, 2)
+    return _mf_linear(_q(F.gelu(_q(dw))), sd, prefix + ".fc2")
+
+
 def _mf_block(x, sd: State, prefix: str, H: int, W: int, heads: int, r: int):
     """TransformerBlock (missformer.py:265-268)"""
     n1 = _q(_layer_norm(x, sd, prefix + ".norm1"))
     red = _q(_layer_norm(_mf_reduce(n1, sd, prefix + ".attn.sr", H, W, r), sd, prefix + ".attn.norm")) if r > 1 else n1
     tx = _q(x + _mf_attention(n1, red, sd, prefix + ".attn", heads))
-    return _q(tx + _mf_mixffn_skip(_q(_layer_norm(tx, sd, prefix + ".norm2")), sd, prefix + ".mlp", H, W))
+    n2 = _q(_layer_norm(tx, sd, prefix + ".norm2"))
+    if prefix + ".mlp.norm1.weight" in sd:         # token_mlp='mix_skip' (the default)
+        return _q(tx + _mf_mixffn_skip(n2, sd, prefix + ".mlp", H, W))
+    return _q(tx + _mf_mixffn(n2, sd, prefix + ".mlp", H, W))
 
 
 def _mf_expand(x, sd: State, prefix: str, H: int, W: int, r: int):

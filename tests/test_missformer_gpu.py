@@ -112,3 +112,31 @@ def test_missformer_registry_builds_for_512_like_the_reference():
     assert relerr(logits.detach().cpu(), ref) < 6e-2
     F.binary_cross_entropy_with_logits(logits, mask.to(DEV)).backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_token_mlp_modes_mix_and_fc():
+    """MISSFormer(token_mlp_mode=...) (missformer.py:253-263): 'mix' = MixFFN (no skip, no LayerNorm) against the
+    oracle in fp32; 'fc' constructs and fails on the first forward with the reference's own TypeError"""
+    from unet_zoo_amd.models import MISSFormer
+    torch.manual_seed(0)
+    m = MISSFormer(num_classes=1, in_channels=3, token_mlp_mode="mix", image_size=128)
+    m.run_dtype = torch.float32
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert not any(".mlp.norm1." in k for k in sd if k.startswith("backbone.block"))
+    m = m.to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(2, 3, 128, 128, seed=3)
+    ref_logits, ref_loss, ref_grads, _ = torch_ref.train_step_reference("missformer", sd, x, mask, image_size=128)
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, mask.to(DEV))
+    loss.backward()
+    assert (logits.detach().cpu() - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    named = dict(m.named_parameters())
+    assert {n for n, p in named.items() if p.grad is not None} == set(ref_grads)
+    for n, g in ref_grads.items():
+        want = g.double().norm().item()
+        assert abs(named[n].grad.double().norm().item() - want) <= 2e-2 * want + 1e-6, n
+    torch.manual_seed(0)
+    fc = MISSFormer(num_classes=1, in_channels=3, token_mlp_mode="fc", image_size=128).to(DEV)
+    with pytest.raises(TypeError):
+        fc(x.to(DEV))

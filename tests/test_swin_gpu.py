@@ -409,3 +409,65 @@ def test_continuous_position_bias_batched_launch():
     ops.cpb_bwd(one["idx"], one["w1"], one["b1"], one["w2"], one["G"], *single)
     for k, t in zip(("dw1", "db1", "dw2", "db2"), single):
         assert relerr(one[k], t) < 1e-5
+
+
+def test_swin_options_ape_qk_scale_other_head_width_against_oracle():
+    """constructor options the reference accepts beyond its defaults (swin_unet_v2.py:596-700): ape=True, qk_scale,
+    head_dim 16 (num_heads doubled) -- the window core then runs through the library-GEMM path -- fp32 against the
+    oracle, gradients of the absolute position embedding and tau included"""
+    torch.manual_seed(0)
+    kw = dict(image_size=64, window_size=4, drop_path_rate=0.0, ape=True, qk_scale=0.2, num_heads=[6, 12, 24, 48])
+    m = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, **kw)
+    m.run_dtype = torch.float32
+    with torch.no_grad():
+        m.absolute_pos_embed.normal_(0.0, 0.5, generator=torch.Generator().manual_seed(3))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert "absolute_pos_embed" in sd and tuple(sd["absolute_pos_embed"].shape) == (1, 256, 96)
+    m = m.to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=4)
+    cfg = torch_ref.swin_config(sd, 64, window_size=4, num_heads=(6, 12, 24, 48))
+    cfg["qk_scale"] = 0.2
+    ref_logits, ref_loss, ref_grads, _ = torch_ref.train_step_reference("swin_unet_v2", sd, x, mask, cfg=cfg)
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, mask.to(DEV))
+    loss.backward()
+    assert (logits.detach().cpu() - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    named = dict(m.named_parameters())
+    assert {n for n, p in named.items() if p.grad is not None} == set(ref_grads)
+    for n, g in ref_grads.items():
+        want = g.double().norm().item()
+        assert abs(named[n].grad.double().norm().item() - want) <= 2e-2 * want + 1e-6, n
+    for n in ("absolute_pos_embed", "layers.0.blocks.1.attn.tau", "layers.2.blocks.0.attn.cpb.fc2.weight"):
+        assert (named[n].grad.cpu() - ref_grads[n]).abs().max() <= 2e-2 * ref_grads[n].abs().max() + 1e-8, n
+
+
+def test_swin_dropout_options_train_and_are_off_in_eval():
+    """drop_rate (after the embedding and after the attention projection) and attn_drop_rate (inside the window core):
+    masks from torch's generator, reproducible under a seed, identity in eval mode, and the step still trains -- also
+    replayed from hipGraphs"""
+    kw = dict(image_size=64, window_size=4, drop_rate=0.1, attn_drop_rate=0.1, ape=True)
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, **kw).to(DEV)
+    x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=4)
+    x, mask = x.to(DEV), mask.to(DEV)
+    m.train()
+    outs = []
+    for seed in (1, 1, 2):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            outs.append(m(x).clone())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x), m(x)
+    assert torch.equal(e1, e2)
+    torch.manual_seed(0)
+    m0 = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, image_size=64, window_size=4, ape=True).to(DEV).eval()
+    m0.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        assert torch.equal(m0(x), e1)                     # eval mode: the dropout options change nothing
+    m.train()
+    gs = unet_zoo_amd.GraphedStep(m, "bce_dice", lr=1e-3)
+    losses = [gs(x, mask).item() for _ in range(10)]
+    assert all(np.isfinite(losses)) and min(losses[5:]) < losses[0]

@@ -106,6 +106,42 @@ class PackCache:
         self._table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._total, self._n, self._table_dtype = begin, len(generic), dtype
 
+def _window_core_torch(qkv, tau, w1, b1, w2, b2, rel_index, heads: int, ws: int, shift: int, scale: float, p_drop: float):
+    """WindowAttention.forward between its qkv and proj Linears, with the caller's roll / window_partition /
+    window_reverse / mask (swin_unet_v2.py:127-159, :246-262), on the (N, 3C, H, W) qkv map"""
+    import torch.nn.functional as F
+    N, C3, H, W = qkv.shape
+    C, d, n = C3 // 3, C3 // 3 // heads, ws * ws
+    t = qkv.permute(0, 2, 3, 1)
+    if shift > 0:
+        t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+    t = t.reshape(N, H // ws, ws, W // ws, ws, C3).permute(0, 1, 3, 2, 4, 5).reshape(-1, n, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0] * scale, t[1], t[2]
+    attn = (q @ k.transpose(-2, -1)) / torch.clamp(q.norm(dim=-1, keepdim=True) * k.norm(dim=-1, keepdim=True).transpose(-2, -1), min=1e-6)
+    attn = attn / torch.clip(tau[:, :n, :n].unsqueeze(0), min=0.01)
+    idx = rel_index[:n, :n].to(qkv.device)
+    bias = F.linear(F.relu(F.linear(idx, w1, b1)), w2, b2)                      # (n, n, heads)
+    attn = attn + bias.permute(2, 0, 1).unsqueeze(0)
+    if shift > 0:
+        img = torch.zeros(1, H, W, 1, device=qkv.device)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.view(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, n)
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)           # (nW, n, n)
+        nW = am.shape[0]
+        attn = (attn.view(-1, nW, heads, n, n) + am.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
+    attn = F.dropout(attn.softmax(dim=-1), p_drop, p_drop > 0.0)
+    o = (attn @ v).transpose(1, 2).reshape(-1, n, C)
+    o = o.view(N, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, C)
+    if shift > 0:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o.permute(0, 3, 1, 2)
+
+
 class Engine:
     def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
                  grad_sink: Optional[Callable[[nn.Parameter, torch.Tensor], None]] = None,
@@ -867,13 +903,14 @@ class Engine:
             self.tape.append(bwd)
         return y
 
-    def dwconv_skip(self, x: Act, conv: nn.Conv2d) -> Act:
-        """DWConv(x) + x: the depthwise 3x3 of MixFFN_skip with its skip (missformer.py:168-177, :204-205)"""
+    def dwconv_skip(self, x: Act, conv: nn.Conv2d, skip: bool = True) -> Act:
+        """DWConv(x) + x: the depthwise 3x3 of MixFFN_skip with its skip (missformer.py:168-177, :204-205);
+        skip=False: the bare DWConv of MixFFN (:186-189)"""
         C = x.C
         assert conv.groups == C == conv.in_channels == conv.out_channels and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
         wt = conv.weight.detach().reshape(C, 9).t().contiguous()      # [9][C]
         y = self.new_act(x.N, x.H, x.W, C)
-        ops.dwconv3x3(x, wt, conv.bias.detach() if conv.bias is not None else None, y, skip=True)
+        ops.dwconv3x3(x, wt, conv.bias.detach() if conv.bias is not None else None, y, skip=skip)
         if self.record:
             def bwd():
                 g = self._total_grad(y)
@@ -889,7 +926,7 @@ class Engine:
                 self._after_rowsums(give)
                 if x.needs_grad:
                     dx = self.new_act(x.N, x.H, x.W, C)
-                    ops.dwconv3x3(g, wt, None, dx, skip=True, flip=True)
+                    ops.dwconv3x3(g, wt, None, dx, skip=skip, flip=True)
                     x.add_grad(dx)
 
             self.tape.append(bwd)
@@ -972,6 +1009,50 @@ class Engine:
                 g = self._total_grad(out)
                 if g is not None:
                     x.add_grad(g)
+
+            self.tape.append(bwd)
+        return out
+
+    def add_param_map(self, x: Act, p: nn.Parameter, out: Optional[Act] = None) -> Act:
+        """x + p for a (1, H*W, C) parameter broadcast over the batch: `x = x + self.absolute_pos_embed`
+        (swin_unet_v2.py:714-715).  d(p) = sum over the batch of the incoming gradient (N terms per element)."""
+        assert tuple(p.shape) == (1, x.H * x.W, x.C), (tuple(p.shape), (1, x.H * x.W, x.C))
+        out = out if out is not None else self.new_act(x.N, x.H, x.W, x.C)
+        xv = x.buf.view(x.N, x.H * x.W, x.ld)[..., x.off:x.off + x.C]
+        out.buf.view(x.N, x.H * x.W, out.ld)[..., out.off:out.off + x.C].copy_(xv.float() + p.detach()[0])
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                gv = g.buf.view(x.N, x.H * x.W, g.ld)[..., g.off:g.off + x.C].float()
+                self._give_grad(p, gv.sum(0, keepdim=True))
+                if x.needs_grad:
+                    x.add_grad(g)
+
+            self.tape.append(bwd)
+        return out
+
+    def dropout(self, x: Act, p: float, out: Optional[Act] = None) -> Act:
+        """nn.Dropout(p) in training mode (identity otherwise): Bernoulli(1 - p) mask from torch's generator, scaled by
+        1 / (1 - p); the same mask multiplies the gradient (swin_unet_v2.py:158, :716)."""
+        if p <= 0.0 or not self.training:
+            if out is not None and out is not x:
+                return self.copy_into(x, out)
+            return x
+        out = out if out is not None else self.new_act(x.N, x.H, x.W, x.C)
+        keep = (torch.rand((x.P, x.C), device=self.device) >= p).to(x.dtype)
+        keep.mul_(1.0 / (1.0 - p))
+        xv = x.buf[:, x.off:x.off + x.C]
+        out.buf[:, out.off:out.off + x.C].copy_(xv * keep)
+        if self.record and x.needs_grad:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                dx.buf.copy_(g.buf[:, g.off:g.off + g.C] * keep)
+                x.add_grad(dx)
 
             self.tape.append(bwd)
         return out
@@ -1242,6 +1323,15 @@ class Engine:
         the kernel's d(bias)."""
         N = ws * ws
         qkv = self.linear(x, attn.qkv)
+        p_attn = attn.attn_drop.p if self.training else 0.0
+        if p_attn > 0.0 or x.C // heads != 32:
+            # options the fused kernels do not take (attention dropout acts inside the softmax-times-V product; head
+            # widths other than 32): the window core through library GEMMs, roll / partition / mask spelled out
+            o = self.torch_block(lambda t, tau_, w1, b1, w2, b2: _window_core_torch(
+                t, tau_, w1, b1, w2, b2, attn.log_relative_position_index, heads, ws, shift, attn.scale, p_attn),
+                (qkv,), (attn.tau, attn.cpb.fc1.weight, attn.cpb.fc1.bias, attn.cpb.fc2.weight, attn.cpb.fc2.bias),
+                self.new_act(x.N, x.H, x.W, x.C))
+            return self.dropout(self.linear(o, attn.proj), attn.proj_drop.p)
         cpb = attn.cpb
         pre = self._cpb.get(attn)                      # evaluated by position_biases() at the start of the forward
         if pre is not None and pre["N"] == N:
@@ -1253,7 +1343,7 @@ class Engine:
             bias = ops.cpb_fwd(idx, w1, b1, w2, b2).view(heads, N, N)
         tau = attn.tau.detach()
         o = self.new_act(x.N, x.H, x.W, x.C)
-        lse = ops.winattn_fwd(qkv, tau, bias, o, heads, ws, shift)
+        lse = ops.winattn_fwd(qkv, tau, bias, o, heads, ws, shift, scale=attn.scale)
         if self.record:
             def bwd():
                 g = self._total_grad(o)
@@ -1262,7 +1352,7 @@ class Engine:
                 dqkv = self.new_act(qkv.N, qkv.H, qkv.W, qkv.C)
                 whole = tuple(attn.tau.shape) == (heads, N, N)
                 dbias, dtau = ops.winattn_bwd(qkv, tau, bias, o, lse, g, dqkv, heads, ws, shift,
-                                              dtau=self._dst(attn.tau) if whole else None)
+                                              dtau=self._dst(attn.tau) if whole else None, scale=attn.scale)
                 qkv.add_grad(dqkv)
                 if not whole:                                                   # window clipped to the map size
                     full = torch.zeros_like(attn.tau)
@@ -1281,7 +1371,7 @@ class Engine:
                     self._give_grad(p_, g_)
 
             self.tape.append(bwd)
-        return self.linear(o, attn.proj)
+        return self.dropout(self.linear(o, attn.proj), attn.proj_drop.p)
 
     def resize_bilinear(self, x: Act, out: Act, align_corners: bool = False) -> Act:
         """out = F.interpolate(x, size=out's, mode='bilinear', align_corners=...), written into its

@@ -148,6 +148,36 @@ class MixFFN_skip(nn.Module):
         return eng.linear(a, self.fc2, out=out, residual=residual)
 
 
+class MixFFN(nn.Module):
+    """missformer.py:179-190: fc1 -> depthwise 3x3 -> GELU -> fc2 (token_mlp='mix')"""
+
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.fc1 = nn.Linear(c1, c2)
+        self.dwconv = DWConv(c2)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(c2, c1)
+
+    def emit(self, eng: Engine, x: Act, out: Optional[Act] = None, residual: Optional[Act] = None) -> Act:
+        a = eng.gelu(eng.dwconv_skip(eng.linear(x, self.fc1), self.dwconv.dwconv, skip=False))
+        return eng.linear(a, self.fc2, out=out, residual=residual)
+
+
+class MLP_FFN(nn.Module):
+    """missformer.py:210-221 (token_mlp='fc').  The reference constructs it, but TransformerBlock.forward calls
+    `self.mlp(x, H, W)` (:267) while MLP_FFN.forward takes only x: a TypeError on the first forward -- mirrored."""
+
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.fc1 = nn.Linear(c1, c2)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(c2, c1)
+
+    def emit(self, eng: Engine, x: Act, out: Optional[Act] = None, residual: Optional[Act] = None) -> Act:
+        raise TypeError("MLP_FFN.forward() takes 2 positional arguments but 4 were given "
+                        "(token_mlp='fc' fails the same way in the reference: missformer.py:216 vs :267)")
+
+
 class OverlapPatchEmbeddings(nn.Module):
     """missformer.py:238-250"""
 
@@ -170,9 +200,12 @@ class TransformerBlock(nn.Module):
         self.norm1 = nn.LayerNorm(dim)
         self.attn = EfficientSelfAtten(dim, head, reduction_ratio)
         self.norm2 = nn.LayerNorm(dim)
-        if token_mlp != 'mix_skip':
-            raise NotImplementedError(f"token_mlp='{token_mlp}': only MISSFormer's default 'mix_skip' is built")
-        self.mlp = MixFFN_skip(dim, int(dim * 4))
+        if token_mlp == 'mix':                       # missformer.py:258-263
+            self.mlp = MixFFN(dim, int(dim * 4))
+        elif token_mlp == 'mix_skip':
+            self.mlp = MixFFN_skip(dim, int(dim * 4))
+        else:
+            self.mlp = MLP_FFN(dim, int(dim * 4))
 
     def emit(self, eng: Engine, x: Act) -> Act:
         tx = self.attn.emit(eng, eng.layer_norm(x, self.norm1), residual=x)          # x + attn(norm1(x)): GEMM epilogue

@@ -104,12 +104,11 @@ class WindowAttention(nn.Module):
     def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
         self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
-        if dim // num_heads != 32 or dim % num_heads:
-            raise NotImplementedError(f"window attention kernel needs head_dim 32, got dim={dim}, heads={num_heads}")
-        if qk_scale is not None:
-            # the scale cancels in q.k / (|q||k|) except inside the 1e-6 clamp; only the default is wired
-            raise NotImplementedError("qk_scale override is not implemented")
-        self.scale = (dim // num_heads) ** -0.5
+        if dim % num_heads:
+            raise ValueError(f"dim {dim} is not divisible by num_heads {num_heads}")
+        # head_dim 32 runs on the fused MFMA / VALU kernels; other widths and attention dropout take the engine's
+        # library-GEMM window core.  (qk_scale cancels in q.k / (|q||k|) except inside the 1e-6 clamp.)
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
         ch, cw = torch.arange(window_size[0]), torch.arange(window_size[1])
         coords = torch.stack(torch.meshgrid([ch, cw], indexing="ij")).flatten(1)
         rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
@@ -136,8 +135,6 @@ class SwinTransformerBlock(nn.Module):
             self.shift_size = 0
             self.window_size = min(input_resolution)
         assert 0 <= self.shift_size < self.window_size
-        if drop or attn_drop:
-            raise NotImplementedError("dropout inside the Swin blocks is not implemented (reference default 0)")
         self.norm1 = norm_layer(dim)
         self.attn = WindowAttention(dim, _pair(self.window_size), num_heads, qkv_bias, qk_scale, attn_drop, drop)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
@@ -296,8 +293,8 @@ class SwinTransformerSys(HipModule):
                  qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False,
                  patch_norm=True, use_checkpoint=False, final_upsample="expand_first", **kwargs):
         super().__init__()
-        if ape or drop_rate or attn_drop_rate or not patch_norm or final_upsample != "expand_first":
-            raise NotImplementedError("only the reference's default ape / dropout / patch_norm / final_upsample are implemented")
+        if not patch_norm or final_upsample != "expand_first":
+            raise NotImplementedError("only the reference's default patch_norm / final_upsample are implemented")
         self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
         self.ape, self.patch_norm = ape, patch_norm
         self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
@@ -306,6 +303,9 @@ class SwinTransformerSys(HipModule):
                                       norm_layer=norm_layer if patch_norm else None)
         res = self.patch_embed.patches_resolution
         self.patches_resolution = res
+        if self.ape:                                  # swin_unet_v2.py:624-626
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches, embed_dim))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
         self.pos_drop = nn.Dropout(p=drop_rate)
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
         nl = self.num_layers
@@ -359,8 +359,18 @@ class SwinTransformerSys(HipModule):
         for lvl in range(nl - 1):
             cats.append(eng.new_cat(N, R[0] >> lvl, R[1] >> lvl, (E << lvl, E << lvl)))
         DropPath.draw_all(self, N, eng.device, eng.training)
-        eng.position_biases([(m.attn, m.window_size) for m in self.modules() if isinstance(m, SwinTransformerBlock)])
-        t = self.patch_embed.emit(eng, x, out=cats[0][1][1])
+        # (only the blocks whose window core runs on the fused kernels: Engine.window_attention sends the others --
+        # head_dim != 32, attention dropout in training -- through its library-GEMM core, position MLP included)
+        eng.position_biases([(m.attn, m.window_size) for m in self.modules() if isinstance(m, SwinTransformerBlock)
+                             and m.dim // m.num_heads == 32 and not (eng.training and m.attn.attn_drop.p > 0)])
+        skip0 = cats[0][1][1]
+        if self.ape or (self.pos_drop.p > 0 and eng.training):     # x + absolute_pos_embed, pos_drop (:713-716)
+            t = self.patch_embed.emit(eng, x)
+            if self.ape:
+                t = eng.add_param_map(t, self.absolute_pos_embed, out=None if self.pos_drop.p > 0 else skip0)
+            t = eng.dropout(t, self.pos_drop.p, out=skip0)
+        else:
+            t = self.patch_embed.emit(eng, x, out=skip0)
         for i, layer in enumerate(self.layers):                 # forward_features (:711-723)
             nxt = cats[i + 1][1][1] if i + 1 < nl - 1 else None  # stage i's output is stage i+1's skip
             t = layer.emit(eng, t, out=nxt)

@@ -777,14 +777,15 @@ def ln_head_bwd(x: Act, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor
     return tuple(outs)
 
 
-def _attn_desc(qkv: Act, heads: int, ws: int, shift: int, Nt: int, ldo: int):
+def _attn_desc(qkv: Act, heads: int, ws: int, shift: int, Nt: int, ldo: int, scale: Optional[float] = None):
     C = qkv.C // 3
     return L.WinAttnDesc(L.dtype_code(qkv.dtype), qkv.N, qkv.H, qkv.W, C, heads, ws, shift, Nt, qkv.ld, ldo,
-                         float((C // heads) ** -0.5))
+                         float((C // heads) ** -0.5 if scale is None else scale))
 
 
-def winattn_fwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, heads: int, ws: int, shift: int) -> torch.Tensor:
-    d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld)
+def winattn_fwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, heads: int, ws: int, shift: int,
+                scale: Optional[float] = None) -> torch.Tensor:
+    d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld, scale)
     nwin = qkv.N * (qkv.H // ws) * (qkv.W // ws)
     lse = torch.empty((nwin, heads, ws * ws), dtype=torch.float32, device=qkv.buf.device)
     assert tau.dtype == torch.float32 and tau.is_contiguous() and bias.shape == (heads, ws * ws, ws * ws)
@@ -795,10 +796,10 @@ def winattn_fwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, heads
 
 
 def winattn_bwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, lse: torch.Tensor, dout: Act, dqkv: Act,
-                heads: int, ws: int, shift: int, dtau: Optional[torch.Tensor] = None):
+                heads: int, ws: int, shift: int, dtau: Optional[torch.Tensor] = None, scale: Optional[float] = None):
     """returns (dbias, dtau) as (heads, N, N) fp32; dtau is written into the given tensor when passed"""
     lib = L.load()
-    d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld)
+    d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld, scale)
     rows = L.check_count(lib.uz_winattn_bwd_rows(byref(d)), "uz_winattn_bwd_rows")
     N = ws * ws
     part = torch.empty((rows, 2, heads, N, N), dtype=torch.float32, device=qkv.buf.device)
