@@ -66,6 +66,14 @@ static inline int uz_cdiv(long long a, long long b) { return (int)((a + b - 1) /
 // built with -DUZ_ABLATE (make ABLATE=1): the shipped libunetzoo_hip.so never reads the environment, its flags are
 // the constant 0, so no environment variable can change what a kernel computes or how it is launched.
 #include <stdlib.h>
+// Device code reads a kernel's `flags` argument through UZ_KFLAGS(a): the argument itself in the ablation build, the
+// literal 0 in the shipped build, so that every ablation branch (and the register copies its control flow costs: 32
+// v_mov_b64 per (tap, slab) unit in the direct convolution) is compiled out of the shipped kernels.
+#ifdef UZ_ABLATE
+#define UZ_KFLAGS(a) ((a).flags)
+#else
+#define UZ_KFLAGS(a) 0
+#endif
 #ifdef UZ_ABLATE
 static inline int uz_tune_flags() {
   const char* e = getenv("UZ_TUNE");

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     b_sw[j] = (brow >> 1) & 7;
   }
 
-  if ((a.flags & 0x20) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if ((UZ_KFLAGS(a) & 0x20) && wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int ncb = (a.Cin + BK - 1) / BK;  // the last slab may be partial: channels >= Cin read as zero
   float s1[TN], s2[TN];
 #pragma unroll
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       arow[i] = prow * 128;
       asw[i] = (prow >> 1) & 7;
     }
-    if (a.flags & 0x300) {  // ablations (tools/kbench.py): 0x100 LDS reads without MFMAs, 0x200 MFMAs without LDS reads
-      if (a.flags & 0x100) {
+    if (UZ_KFLAGS(a) & 0x300) {  // ablations (tools/kbench.py): 0x100 LDS reads without MFMAs, 0x200 MFMAs without LDS reads
+      if (UZ_KFLAGS(a) & 0x100) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int lc = 2 * q + lh;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       __builtin_amdgcn_s_barrier();  // previous tile (its C staging reads) is finished everywhere
 #pragma unroll
       for (int i = 0; i < APW; ++i) issue_a_piece(i, 0, 0, img, h0, w0);
-      if (!(a.flags & 0x800)) {   // (0x800: the one-tap-per-barrier loop below, kept for A/B measurements)
+      if (!(UZ_KFLAGS(a) & 0x800)) {   // (0x800: the one-tap-per-barrier loop below, kept for A/B measurements)
         // ---- two (slab, tap) units per barrier: weight tiles in two slots of two, the pair for
         // double-step d + 1 issued during d; halo pieces of the next slab (<= 2 per double-step) are issued
         // AFTER the weight tiles so that the counted wait at the next barrier may leave them in flight
@@ -386,7 +386,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
           // the two waves of a SIMD (w, w + 4) run the same program in lockstep: with `late` the second one issues
           // its LDS-DMA pieces AFTER its first unit, so one wave's issue runs beside the other's MFMAs
           // (+2 ... 4.5 % on every non-resident layer; flag 0x10 of the ablation build switches it off)
-          const bool late = !(a.flags & 0x10) && wave >= 4;
+          const bool late = !(UZ_KFLAGS(a) & 0x10) && wave >= 4;
+          // (measured and rejected in round 2: the double-step's fragment reads as one explicit software pipeline, two
+          // register sets with the order pinned by scheduling barriers -- 5 ... 40 % slower on every layer than the
+          // compiler's own read -> wait -> MFMA groups, whose waits the partner wave of the SIMD covers)
           if (!late) issue_next();
           compute(t0, c0 & 1, s0);
           if (late) issue_next();
@@ -405,12 +408,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
         } else {
           wait_vmcnt<0>();
         }
-        if (!(a.flags & 0x400)) __builtin_amdgcn_s_barrier();
+        if (!(UZ_KFLAGS(a) & 0x400)) __builtin_amdgcn_s_barrier();
         // next slab's halo patch (one piece per step) BEFORE the weight tile of step s + 2: the
         // counted wait above relies on the weight pieces being the youngest operations
         // ablation bits: 0x40 no weight DMA, 0x80 no halo DMA after the first slab, 0x400 no barrier
-        if (tap < APW && cb + 1 < ncb && !(a.flags & 0x80)) issue_a_piece(tap, (cb + 1) & 1, cb + 1, img, h0, w0);
-        if (s + 2 < nsteps && !(a.flags & 0x40)) issue_b(tap2 % 3, cb2, tap2);
+        if (tap < APW && cb + 1 < ncb && !(UZ_KFLAGS(a) & 0x80)) issue_a_piece(tap, (cb + 1) & 1, cb + 1, img, h0, w0);
+        if (s + 2 < nsteps && !(UZ_KFLAGS(a) & 0x40)) issue_b(tap2 % 3, cb2, tap2);
         compute(tap, cb & 1, tap % 3);
         if (++tap == 9) {
           tap = 0;
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     }
 
     // ---- epilogue: bias + statistics from registers ------------------------------------------
-    if (a.flags & 1) {
+    if (UZ_KFLAGS(a) & 1) {
       asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][0][3]));
     } else if constexpr (sizeof(T) == 2) {
       constexpr int RSC = BN * ES + 16;  // C staging row stride (bytes)
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
       const int cc = tid % CPR;
       const int n = n0 + cc * VEC;
-      const bool dostats = !(a.flags & 2);
+      const bool dostats = !(UZ_KFLAGS(a) & 2);
       // every thread reads back 256 * CPR / 512 chunks: all of them are requested before the first store (as a
       // rolled loop each pass waited for its own LDS round trip: ~250 cycles x 8 per tile with every wave idle)
       constexpr int NPASS = 256 * CPR / 512, RPP = 512 / CPR;
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_res64_kernel(const DirectArgs 
       const int pi = (TW == 32) ? (m >> 5) : (m >> 4), pj = (TW == 32) ? (m & 31) : (m & 15);
       const int hh = hh0 + pi, ww = ww0 + pj;
       if (hh < a.H && ww < a.W && n < a.Nout) {
-        if (!(a.flags & 0x1)) st16(yg + ((size_t)(im * a.H + hh) * a.W + ww) * a.ldy + n, vb[k]);
+        if (!(UZ_KFLAGS(a) & 0x1)) st16(yg + ((size_t)(im * a.H + hh) * a.W + ww) * a.ldy + n, vb[k]);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float fv = (float)vb[k].v[e];
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_res64_kernel(const DirectArgs 
     __builtin_amdgcn_s_barrier();
     if (late) {
       const int next = tile + gridDim.x;
-      if (next < a.ntiles && !(a.flags & 0x2)) {
+      if (next < a.ntiles && !(UZ_KFLAGS(a) & 0x2)) {
         int im2, hh2, ww2;
         decode(next, im2, hh2, ww2);
         issue_patch((it + 1) & 1, im2, hh2, ww2);

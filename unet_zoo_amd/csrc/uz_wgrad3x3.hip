@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (NTY == 1 && NTX == 3) {
     const int U = gridDim.x * gridDim.z;           // (tile, z) pairs
-    if ((U & 7) == 0 && !(a.flags & 4)) {
+    if ((U & 7) == 0 && !(UZ_KFLAGS(a) & 4)) {
       const int id = blockIdx.x + gridDim.x * (blockIdx.y + 3 * blockIdx.z);
       const int xcd = id & 7, j = id >> 3;
       by = j % 3;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 
   if (nu > 0) issue(0, u_beg);
   if (nu > 1) issue(1, u_beg + 1);
-  if (!(a.flags & 8)) {
+  if (!(UZ_KFLAGS(a) & 8)) {
     // two K-steps (2 x 64 pixels) per barrier: the pair for double-step d + 1 streams in while d computes
     const int nd = (nu + 1) >> 1;
 #pragma unroll 1
