@@ -44,7 +44,14 @@ struct Wg2Args {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+template <int V> struct IntC { static constexpr int value = V; };
 constexpr unsigned OOB = 0x80000000u;
+#ifndef UZ_WG_PPS
+#define UZ_WG_PPS 5    // DMA pieces per sub-step slot: one K-step of the wave per slot
+#endif
+#ifndef UZ_WG_LATE
+#define UZ_WG_LATE 2   // sub-steps by which the second wave of a SIMD trails the first with its DMA pieces
+#endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -53,11 +60,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // Transposed LDS reads are issued from inline asm: for the ds_read_tr builtin hipcc (ROCm 7.2)
 // inserts `s_waitcnt vmcnt(0)` before every read while LDS-DMA is in flight, which serialises the
 // whole pipeline; asm reads are invisible to that pass, their lgkmcnt is counted by hand below.
-template <int OFF>
+template <int OFF, int OFF0 = 0>
 __device__ __forceinline__ void tr_pair(bf16x4& lo, bf16x4& hi, unsigned lds_addr) {
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                : "=&v"(lo), "=&v"(hi)
-               : "v"(lds_addr), "i"(OFF));
+               : "v"(lds_addr), "i"(OFF0), "i"(OFF0 + OFF));
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
@@ -66,7 +73,10 @@ __device__ __forceinline__ void pin(bf16x4& v) { asm volatile("" : "+v"(v)); }
 
 // BI x BJ channel tile, NTY kernel rows per workgroup (1 -> blockIdx.y selects the row; 3 -> all),
 // 8 waves = WI x WJ x TG (TG tap groups share the NTX*NTY taps of the workgroup)
-template <int BI, int BJ, int NTY, int NTX, int WI, int WJ, int TG>
+// MODE: how the x operand is addressed -- 0 as stored, 1 through nearest x2 upsampling (Wg2Args::r_up), 2 / 3 the
+// 2x2 / stride-2 3x3 gathers (Wg2Args::gather 1 / 2).  Compile-time: the pieces are issued from ten places of the
+// unrolled double-step, each would carry the three-way branch.
+template <int BI, int BJ, int NTY, int NTX, int WI, int WJ, int TG, int MODE>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   static_assert(WI * WJ * TG == 8, "8 waves");
   static_assert((NTX == 3) || (NTX == 1 && NTY == 1), "1 tap or 3/9 taps");
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   constexpr int RPX = (NTY == 1) ? 72 : 200;            // R tile capacity in pixels
   constexpr int NRP = RPX / RPPR;
   constexpr int PPW = 5;                                // pieces per wave per stage (40 slots)
-  static_assert(NLP + NRP <= 8 * PPW, "stage layout");
+  static_assert(NLP + NRP <= 8 * PPW && NLP % 8 == 0, "stage layout");
   constexpr int STAGE = 8 * PPW * 1024;
   constexpr int WTI = BI / WI, WTJ = BJ / WJ, TI = WTI / 32, TJ = WTJ / 32;
   constexpr int NTAP = NTX * NTY;               // taps of the workgroup
@@ -152,40 +162,57 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 
   const int upi = (a.H * a.W) >> 6;  // K-steps per image
   const int upr = a.W / KW;          // K-steps per row block (1 unless W > 64)
-  auto issue = [&](int stage, int u) {
-    const int img = u / upi;
+  // position of K-step u: image, first row, first column
+  auto locate = [&](int u, int& img, int& h, int& w0) __attribute__((always_inline)) {
+    img = u / upi;
     const int rem = u - img * upi;
     const int rb = rem / upr;
-    const int h = rb * a.KR, w0 = (rem - rb * upr) * KW;
-    const int base = (img * a.H + h) * a.W + w0;
-    char* sbase = smem + stage * STAGE;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int q = wave + 8 * i;
-      const bool ok = (unsigned)(h + p_rrel[i]) < (unsigned)a.H && (unsigned)(w0 + p_crel[i]) < (unsigned)a.W;
-      const unsigned pix = (unsigned)(base + p_delta[i]);
-      if (q < NLP) {
-        const unsigned off = ok ? pix * (unsigned)(a.ldl * 2) + p_coff[i] : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
-      } else {
-        unsigned rp = pix;
-        bool r_in = true;
-        if (a.r_up) {
-          const int hh = h + p_rrel[i], ww = w0 + p_crel[i];
-          rp = (unsigned)((img * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1));
-        } else if (a.gather == 1) {
-          const int hh = h + p_rrel[i], ww = w0 + p_crel[i];
-          rp = (unsigned)((img * a.Hr + 2 * hh + (ty_blk_g >> 1)) * a.Wr + 2 * ww + (ty_blk_g & 1));
-        } else if (a.gather == 2) {
-          const int gy = (ty_blk_g * 11) >> 5, gx = ty_blk_g - 3 * gy;
-          const int rh = 2 * (h + p_rrel[i]) + gy - 1, rw = 2 * (w0 + p_crel[i]) + gx - 1;
-          r_in = (unsigned)rh < (unsigned)a.Hr && (unsigned)rw < (unsigned)a.Wr;
-          rp = (unsigned)((img * a.Hr + rh) * a.Wr + rw);
-        }
-        const unsigned off = (ok && r_in) ? rp * (unsigned)(a.ldr * 2) + p_coff[i] : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(sbase + q * 1024), 16, off, 0, 0, 0);
-      }
-    }
+    h = rb * a.KR;
+    w0 = (rem - rb * upr) * KW;
+  };
+  // DMA piece I (of this wave's PPW) of the K-step at (image IMG, row H0, column W0) into STAGE.  Whether a piece
+  // belongs to the dy or to the x tile is decided at compile time: written as a run-time `q < NLP` branch, hipcc
+  // (ROCm 7.2) merges the two buffer_load ... lds calls and picks the descriptor by a computed offset into the lambda
+  // capture block, which then -- with the kernel arguments and every per-lane table behind it -- stays in scratch.
+#define UZ_WG_ISSUE_PIECE(I, STAGE_, IMG, H0, W0)                                                                   \
+  do {                                                                                                              \
+    constexpr int i_ = (I);                                                                                         \
+    const int img_ = (IMG), h_ = (H0), w0_ = (W0);                                                                  \
+    char* sbase_ = smem + (STAGE_) * STAGE;                                                                         \
+    const int q_ = wave + 8 * i_;                                                                                   \
+    const bool ok_ = (unsigned)(h_ + p_rrel[i_]) < (unsigned)a.H && (unsigned)(w0_ + p_crel[i_]) < (unsigned)a.W;   \
+    const unsigned pix_ = (unsigned)((img_ * a.H + h_) * a.W + w0_ + p_delta[i_]);                                  \
+    if constexpr (8 * i_ < NLP) { /* NLP % 8 == 0: a piece index is all-L or all-R for every wave */                \
+      const unsigned off_ = ok_ ? pix_ * (unsigned)(a.ldl * 2) + p_coff[i_] : OOB;                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(lr, (lds_ptr_t)(sbase_ + q_ * 1024), 16, off_, 0, 0, 0);            \
+    } else {                                                                                                        \
+      unsigned rp_ = pix_;                                                                                          \
+      bool r_in_ = true;                                                                                            \
+      if constexpr (MODE == 1) {                                                                                           \
+        const int hh = h_ + p_rrel[i_], ww = w0_ + p_crel[i_];                                                      \
+        rp_ = (unsigned)((img_ * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1));                                 \
+      } else if constexpr (MODE == 2) {                                                                             \
+        const int hh = h_ + p_rrel[i_], ww = w0_ + p_crel[i_];                                                      \
+        rp_ = (unsigned)((img_ * a.Hr + 2 * hh + (ty_blk_g >> 1)) * a.Wr + 2 * ww + (ty_blk_g & 1));                \
+      } else if constexpr (MODE == 3) {                                                                             \
+        const int gy = (ty_blk_g * 11) >> 5, gx = ty_blk_g - 3 * gy;                                                \
+        const int rh = 2 * (h_ + p_rrel[i_]) + gy - 1, rw = 2 * (w0_ + p_crel[i_]) + gx - 1;                        \
+        r_in_ = (unsigned)rh < (unsigned)a.Hr && (unsigned)rw < (unsigned)a.Wr;                                     \
+        rp_ = (unsigned)((img_ * a.Hr + rh) * a.Wr + rw);                                                           \
+      }                                                                                                             \
+      const unsigned off_ = (ok_ && r_in_) ? rp_ * (unsigned)(a.ldr * 2) + p_coff[i_] : OOB;                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(sbase_ + q_ * 1024), 16, off_, 0, 0, 0);            \
+    }                                                                                                               \
+  } while (0)
+  auto issue = [&](int stage, int u) {
+    int img, h, w0;
+    locate(u, img, h, w0);
+    static_assert(PPW == 5, "explicit piece list");
+    UZ_WG_ISSUE_PIECE(0, stage, img, h, w0);
+    UZ_WG_ISSUE_PIECE(1, stage, img, h, w0);
+    UZ_WG_ISSUE_PIECE(2, stage, img, h, w0);
+    UZ_WG_ISSUE_PIECE(3, stage, img, h, w0);
+    UZ_WG_ISSUE_PIECE(4, stage, img, h, w0);
   };
 
   f32x16 acc[TI][NTW];
@@ -216,74 +243,141 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
     return (r + tyo) * PWR + c0 + tx;
   };
 
-  auto compute = [&](int stage) {
-    const unsigned sL = smem_u + stage * STAGE;
-    const unsigned sR = sL + NLP * 1024;
-#pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {
-      const int k0 = ks * 16;
-      const int r = k0 >> a.kw_log2, c0 = k0 & (KW - 1);
-      bf16x4 alo[TI], ahi[TI], blo[2], bhi[2];
+  // Read addresses do not depend on the K-step: the dy block of sub-step ks is a constant 16 * RBL bytes further on
+  // (immediate offset), and the x block of (sub-step, tap) sits at a per-lane offset worked out once here -- the
+  // swizzle key is the pixel row, which moves with the tap shift and the runtime row length.  That leaves one
+  // v_add per transposed-read pair in the loop (it was 22 VALU instructions per sub-step, beside 6 MFMAs).
+  unsigned aoff[TI], boff[4][NTW];
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
-        tr_pair<4 * RBL>(alo[i], ahi[i], tr_addr(sL, k0 + lk, wi * WTI + i * 32 + lcol, RBL, CPRL == 16));
-      tr_pair<4 * RBR>(blo[0], bhi[0], tr_addr(sR, tap_shift(0, r, c0) + lk, wj * WTJ + lcol, RBR, CPRR == 16));
+  for (int i = 0; i < TI; ++i) aoff[i] = tr_addr(0u, lk, wi * WTI + i * 32 + lcol, RBL, CPRL == 16);
 #pragma unroll
-      for (int tt = 0; tt < NTW; ++tt) {
-        if (tt + 1 < NTW) {
-          tr_pair<4 * RBR>(blo[(tt + 1) & 1], bhi[(tt + 1) & 1],
-                           tr_addr(sR, tap_shift(tt + 1, r, c0) + lk, wj * WTJ + lcol, RBR, CPRR == 16));
-          wait_lgkm<2>();  // everything but the pair just issued has returned (LDS returns in order)
-        } else {
-          wait_lgkm<0>();
+  for (int ks = 0; ks < 4; ++ks) {
+    const int k0 = ks * 16;
+    const int r = k0 >> a.kw_log2, c0 = k0 & (KW - 1);
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+      boff[ks][tt] = NLP * 1024 + tr_addr(0u, tap_shift(tt, r, c0) + lk, wj * WTJ + lcol, RBR, CPRR == 16);
+  }
+
+  // The fragments of sub-step k + 1 (its dy pair(s) and its first x pair) are requested before the last MFMAs of
+  // sub-step k, across the two K-steps of a double-step: a wave meets a bare LDS latency once per double-step, not
+  // once per sub-step.  Register sets alternate with the sub-step parity.
+  constexpr int NB = NTW == 1 ? 2 : NTW;   // x-fragment registers: pair (ks, tt) lives in slot (ks * NTW + tt) % NB
+  bf16x4 alo[2][TI], ahi[2][TI], blo[NB], bhi[NB];
+  auto fetch_first = [&](auto KS, unsigned sL) __attribute__((always_inline)) {
+    constexpr int ks = decltype(KS)::value;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) tr_pair<4 * RBL, ks * 16 * RBL>(alo[ks & 1][i], ahi[ks & 1][i], sL + aoff[i]);
+    tr_pair<4 * RBR>(blo[(ks * NTW) % NB], bhi[(ks * NTW) % NB], sL + boff[ks][0]);
+  };
+  // The 2 x PPW DMA pieces a wave owes to the NEXT double-step go out UZ_WG_PPS at a time, slot k before sub-step k
+  // of the current one (pieces 0 .. PPW - 1: K-step A, the rest: K-step B).  The second wave of a SIMD (waves 4-7)
+  // trails the first by UZ_WG_LATE sub-steps, so the two never sit in an issue burst together.  Measured on UNet
+  // layer shapes (B = 16, same box): two pieces per slot 96.5 us on 256 -> 256 @ 64 x 64, five per slot 87-92 us
+  // whatever the lag (lag 2: 89.0, lag 0: 91.7, all ten at once + lag 4: 89.7) -- the pieces must leave EARLY, the
+  // double-step waits on their arrival, not on their issue slots.
+  int imgA = 0, hA = 0, wA = 0, imgB = 0, hB = 0, wB = 0;
+  bool haveA = false, haveB = false, late = false;
+  int nxt_stage = 0;
+#define UZ_WG_PIECE(J)                                                     \
+  if constexpr ((J) >= 0 && (J) < PPW) {                                   \
+    if (haveA) UZ_WG_ISSUE_PIECE((J), nxt_stage, imgA, hA, wA);                         \
+  } else if constexpr ((J) >= PPW && (J) < 2 * PPW) {                      \
+    if (haveB) UZ_WG_ISSUE_PIECE((J) - PPW, nxt_stage + 1, imgB, hB, wB);                \
+  }
+  auto dma_slot = [&](auto N) __attribute__((always_inline)) {   // N: sub-step of the double-step about to start (0 .. 7)
+    constexpr int n = decltype(N)::value;
+#define UZ_WG_SLOT(K)                                                                \
+    UZ_WG_PIECE(UZ_WG_PPS * (K))                                                       \
+    if constexpr (UZ_WG_PPS > 1) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 1) }                  \
+    if constexpr (UZ_WG_PPS > 2) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 2) }                  \
+    if constexpr (UZ_WG_PPS > 3) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 3) }                  \
+    if constexpr (UZ_WG_PPS > 4) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 4) }                  \
+    if constexpr (UZ_WG_PPS > 5) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 5) }                  \
+    if constexpr (UZ_WG_PPS > 6) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 6) }                  \
+    if constexpr (UZ_WG_PPS > 7) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 7) }                  \
+    if constexpr (UZ_WG_PPS > 8) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 8) }                  \
+    if constexpr (UZ_WG_PPS > 9) { UZ_WG_PIECE(UZ_WG_PPS * (K) + 9) }
+    if (late) {   // wave-uniform
+      UZ_WG_SLOT(n - UZ_WG_LATE)
+    } else {
+      UZ_WG_SLOT(n)
+    }
+#undef UZ_WG_SLOT
+  };
+#undef UZ_WG_PIECE
+#undef UZ_WG_ISSUE_PIECE
+
+  // sub-step ks of the stage at sL; `pf`: request sub-step (ks + 1) & 3 of the stage at sLn meanwhile
+  auto kstep = [&](auto KS, unsigned sL, unsigned sLn, bool pf) __attribute__((always_inline)) {
+    constexpr int ks = decltype(KS)::value, cur = ks & 1;
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) {
+      if (tt + 1 < NTW) {
+        tr_pair<4 * RBR>(blo[(ks * NTW + tt + 1) % NB], bhi[(ks * NTW + tt + 1) % NB], sL + boff[ks][tt + 1]);
+        wait_lgkm<2>();  // everything but the pair just issued has returned (LDS returns in order)
+      } else if (pf) {
+        fetch_first(IntC<(ks + 1) & 3>{}, sLn);
+        wait_lgkm<2 * TI + 2>();
+      } else {
+        wait_lgkm<0>();
+      }
+      if (tt == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          pin(alo[cur][i]);
+          pin(ahi[cur][i]);
         }
-        if (tt == 0) {
+      }
+      const int slot = (ks * NTW + tt) % NB;   // folds: ks, tt and NB are compile-time under the unroll
+      pin(blo[slot]);
+      pin(bhi[slot]);
+      const bf16x8 bfr = __builtin_shufflevector(blo[slot], bhi[slot], 0, 1, 2, 3, 4, 5, 6, 7);
+      if (NTAP % TG == 0 || tg * NTW + tt < NTAP) {  // wave-uniform
 #pragma unroll
-          for (int i = 0; i < TI; ++i) {
-            pin(alo[i]);
-            pin(ahi[i]);
-          }
-        }
-        pin(blo[tt & 1]);
-        pin(bhi[tt & 1]);
-        const bf16x8 bfr = __builtin_shufflevector(blo[tt & 1], bhi[tt & 1], 0, 1, 2, 3, 4, 5, 6, 7);
-        if (NTAP % TG == 0 || tg * NTW + tt < NTAP) {  // wave-uniform
-#pragma unroll
-          for (int i = 0; i < TI; ++i) {
-            const bf16x8 afr = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i][tt], 0, 0, 0);
-          }
+        for (int i = 0; i < TI; ++i) {
+          const bf16x8 afr = __builtin_shufflevector(alo[cur][i], ahi[cur][i], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[i][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i][tt], 0, 0, 0);
         }
       }
     }
   };
+  // the four sub-steps of one K-step (HALF 0 / 1 of the double-step); `more`: another K-step (stage at sLn)
+  // follows without a barrier
+  auto compute = [&](auto HALF, unsigned sL, unsigned sLn, bool more, bool mm) __attribute__((always_inline)) {
+    constexpr int n0 = decltype(HALF)::value * 4;
+    dma_slot(IntC<n0 + 0>{});
+    if (mm) kstep(IntC<0>{}, sL, sL, true);
+    dma_slot(IntC<n0 + 1>{});
+    if (mm) kstep(IntC<1>{}, sL, sL, true);
+    dma_slot(IntC<n0 + 2>{});
+    if (mm) kstep(IntC<2>{}, sL, sL, true);
+    dma_slot(IntC<n0 + 3>{});
+    if (mm) kstep(IntC<3>{}, sL, sLn, more);
+  };
 
   if (nu > 0) issue(0, u_beg);
   if (nu > 1) issue(1, u_beg + 1);
-  if (!(UZ_KFLAGS(a) & 8)) {
+  {
     // two K-steps (2 x 64 pixels) per barrier: the pair for double-step d + 1 streams in while d computes
     const int nd = (nu + 1) >> 1;
+    late = wave >= 4 && !(UZ_KFLAGS(a) & 16);
+    const bool dma = !(UZ_KFLAGS(a) & 32), mm = !(UZ_KFLAGS(a) & 64);   // measurement only: one half of the loop
 #pragma unroll 1
     for (int d = 0; d < nd; ++d) {
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      const int nxt = ((d + 1) & 1) * 2;
-      if (2 * d + 2 < nu) issue(nxt, u_beg + 2 * d + 2);
-      if (2 * d + 3 < nu) issue(nxt + 1, u_beg + 2 * d + 3);
-      compute((d & 1) * 2);
-      if (2 * d + 1 < nu) compute((d & 1) * 2 + 1);
+      nxt_stage = ((d + 1) & 1) * 2;
+      const unsigned s0 = smem_u + (d & 1) * 2 * STAGE, s1 = s0 + STAGE;
+      const bool two = 2 * d + 1 < nu;
+      haveA = dma && 2 * d + 2 < nu;
+      haveB = dma && 2 * d + 3 < nu;
+      if (haveA) locate(u_beg + 2 * d + 2, imgA, hA, wA);
+      if (haveB) locate(u_beg + 2 * d + 3, imgB, hB, wB);
+      if (mm) fetch_first(IntC<0>{}, s0);
+      compute(IntC<0>{}, s0, s1, two, mm);
+      compute(IntC<1>{}, s1, s1, false, mm && two);
     }
-  } else
-#pragma unroll 1
-  for (int s = 0; s < nu; ++s) {
-    if (s + 1 < nu) {
-      wait_vmcnt<PPW>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (s + 2 < nu) issue((s + 2) % 3, u_beg + s + 2);
-    compute(s % 3);
   }
 
   // ---- partial slab [split][tap][Ci][Cj] ----------------------------------------------------------
@@ -417,23 +511,36 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.upb = p.upb;
   a.tiles_j = p.tiles_j;
   dim3 block(512);
+  const int mode = a.r_up ? 1 : (p.gather == 1 ? 2 : (p.gather == 2 ? 3 : 0));
+#define UZ_WG_LAUNCH(MODE_, ...) \
+  hipLaunchKernelGGL((wgrad3x3_kernel<__VA_ARGS__, MODE_>), grid, block, 0, s, a)
   if (p.one_tap) {
+    UZ_REQUIRE(mode != 1, "uz_wgrad(3x3): one-tap problems have no upsampled form");
     dim3 grid(p.tiles_i * p.tiles_j, p.gather == 2 ? 9 : (p.gather ? 4 : 1), p.split);
-    if (p.big) hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 1, 2, 4, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 1, 1, 2, 2, 2>), grid, block, 0, s, a);  // 4 waves idle: memory-bound
+    if (p.big) {
+      if (mode == 0) UZ_WG_LAUNCH(0, 128, 128, 1, 1, 2, 4, 1);
+      else if (mode == 2) UZ_WG_LAUNCH(2, 128, 128, 1, 1, 2, 4, 1);
+      else UZ_WG_LAUNCH(3, 128, 128, 1, 1, 2, 4, 1);
+    } else {   // 4 waves idle: memory-bound
+      if (mode == 0) UZ_WG_LAUNCH(0, 64, 64, 1, 1, 2, 2, 2);
+      else if (mode == 2) UZ_WG_LAUNCH(2, 64, 64, 1, 1, 2, 2, 2);
+      else UZ_WG_LAUNCH(3, 64, 64, 1, 1, 2, 2, 2);
+    }
   } else if (p.big) {
+    UZ_REQUIRE(mode <= 1, "uz_wgrad(3x3): gathers are one-tap problems");
     dim3 grid(p.tiles_i * p.tiles_j, 3, p.split);
-    hipLaunchKernelGGL((wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>), grid, block, 0, s, a);
+    if (mode == 0) UZ_WG_LAUNCH(0, 128, 128, 1, 3, 2, 4, 1);
+    else UZ_WG_LAUNCH(1, 128, 128, 1, 3, 2, 4, 1);
   } else {
+    UZ_REQUIRE(mode <= 1, "uz_wgrad(3x3): gathers are one-tap problems");
     dim3 grid(p.tiles_i * p.tiles_j, 1, p.split);
     // The kernel is bound by its transposed LDS reads (a 32 x 32 wave tile reads 1.2 KB per MFMA, every
     // B fragment used once): 64-row wave tiles share each B fragment between two MFMAs (0.83 KB per MFMA) even
     // though 4 tap groups leave 3 of 12 tap slots empty.  64->64 @256x256: 141.9 -> 129.6 us, 128->64: 229.8 -> 213.4.
-    if (a.flags & 0x8000000)
-      hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 3, 2, 2, 2>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((wgrad3x3_kernel<64, 64, 3, 3, 1, 2, 4>), grid, block, 0, s, a);
+    if (mode == 0) UZ_WG_LAUNCH(0, 64, 64, 3, 3, 1, 2, 4);
+    else UZ_WG_LAUNCH(1, 64, 64, 3, 3, 1, 2, 4);
   }
+#undef UZ_WG_LAUNCH
   UZ_LAUNCH_CHECK("uz_wgrad(3x3)");
   return UZ_OK;
 }
