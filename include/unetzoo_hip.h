@@ -106,6 +106,18 @@ long long uz_conv_igemm_workspace_bytes(const uz_conv_desc* d);
 int uz_conv_igemm_ws_grid_m(const uz_conv_desc* d);
 int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                      void* y, float* stats_partial, void* workspace, void* stream);
+/* Input-gradient convolution with the first pass of the BatchNorm backward fused into its epilogue.
+ * y = conv(x, w) is the gradient of an activation a = relu(bn(bn_y)) (common_layers.py:28-33: the Conv -> BN -> ReLU
+ * whose output feeds only this convolution's forward).  Instead of the statistics of y the kernel writes, per
+ * workgroup row of `partial` ([uz_conv_igemm_ws_grid_m()][2][Nout], the layout of uz_bn_relu_bwd_reduce's
+ * workspace), sum(dz) and sum(dz * xhat) over its pixels with dz = y * [scale * bn_y + shift > 0] (y as stored,
+ * i.e. rounded to the tensor dtype) and xhat = (bn_y - mean) * invstd: uz_bn_bwd_finalize() then stands in for
+ * uz_bn_relu_bwd_reduce() and the activation gradient is not read a second time.  bf16 problems of the direct 3x3
+ * kernels whose epilogue is staged through LDS (uz_conv_igemm_bnred_supported() == 1); others: UZ_ENOTIMPL. */
+int uz_conv_igemm_bnred_supported(const uz_conv_desc* d);
+int uz_conv_igemm_bnred(const uz_conv_desc* d, const void* x, const void* w_packed, void* y, const void* bn_y,
+                        int ld_bny, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        float* partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient (reduction over pixels), fp32 output in the reference's parameter layout.
@@ -233,6 +245,9 @@ int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const float* sca
                          const float* shift, const float* mean, const float* invstd, const void* g0,
                          const void* g1, const void* gpool, const double* sums, double count,
                          void* dy, void* stream);
+/* The finalize half of uz_bn_relu_bwd_reduce() alone: sums[2][C] (double), dbeta = sums[0], dgamma = sums[1] from
+ * `rows` partial rows [rows][2][C] written by uz_conv_igemm_bnred(). */
+int uz_bn_bwd_finalize(const float* partial, int rows, int C, double* sums, float* dgamma, float* dbeta, void* stream);
 
 /* 1x1 convolution with few outputs (OutConv, common_layers.py:125), NCHW fp32 logits.
  *   out[n, k, h, w] = b[k] + sum_c x[p, c] * w[k, c],  k < Kout <= 8 */

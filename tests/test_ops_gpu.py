@@ -317,3 +317,46 @@ def test_conv3x3_res64_register_resident_weights(N, H, W, Cin, Cout, win, ups):
     stats2 = ops.conv_igemm(xa, wp, b.to(DEV), y2, ntaps=9, want_stats=True,
                             taps_mode=L.TAPS_CONV_UP2 if ups else L.TAPS_CONV)
     assert torch.equal(y.buf, y2.buf) and torch.equal(stats, stats2)
+
+
+@pytest.mark.parametrize("N,H,W,C,Cn", [
+    (2, 24, 40, 64, 64),      # LDS-resident 64 -> 64 kernel, ragged 8x32 patches
+    (1, 40, 72, 128, 128),    # streaming kernel, two channel slabs
+    (3, 16, 16, 256, 128),    # 16x16 patches, 256 -> 128 (the gradient of a 128 -> 256 convolution)
+    (2, 9, 20, 192, 72),      # channel tail inside the 128-wide tile, ragged rows
+])
+def test_bn_backward_reduction_in_the_input_gradient_epilogue(N, H, W, C, Cn):
+    """uz_conv_igemm_bnred: the input-gradient convolution of the SECOND half of a DoubleConv (common_layers.py:31-33)
+    leaves, beside the gradient g of the middle activation relu(bn(y)), the partial rows of sum(dz) and sum(dz * xhat)
+    of that BatchNorm's backward.  The gradient must be bit-identical to the plain kernel's, the finalized sums (and
+    with them dgamma, dbeta and dy) must agree with the stand-alone reduction pass to fp32 summation noise."""
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(11)
+    dyb = act_from_nchw(rnd(dt, torch.randn(N, C, H, W, generator=gen)).to(DEV), dt)      # gradient of conv b's output
+    wb = torch.randn(Cn, C, 3, 3, generator=gen) * 0.05                                     # dgrad weights: C -> Cn
+    wp = ops.pack_weights(wb.to(DEV), L.PACK_CONV_FWD, dt)
+    y = act_from_nchw(rnd(dt, torch.randn(N, Cn, H, W, generator=gen) * 2 + 0.3).to(DEV), dt)   # pre-BN output of conv a
+    gamma = (torch.rand(Cn, generator=gen) + 0.5).to(DEV)
+    beta = (torch.randn(Cn, generator=gen) * 0.2).to(DEV)
+    yd = y.dense().double()
+    stats = torch.stack([yd.sum((0, 2, 3)), (yd ** 2).sum((0, 2, 3))]).float().reshape(1, 2, Cn)
+    vec = ops.bn_finalize(stats, N * H * W, gamma, beta, 1e-5, 0.1, torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV))
+
+    g_plain = ops.new_act(N, H, W, Cn, dt, DEV)
+    ops.conv_igemm(dyb, wp, None, g_plain, ntaps=9)
+    g_fused = ops.new_act(N, H, W, Cn, dt, DEV)
+    part = ops.conv_igemm(dyb, wp, None, g_fused, ntaps=9, bnred=(y, vec))
+    assert part is not None and part.shape[1:] == (2, Cn)
+    assert torch.equal(g_plain.dense(), g_fused.dense())
+
+    def bwd(partials):
+        sums = torch.zeros(2, Cn, dtype=torch.float64, device=DEV)
+        dx = ops.new_act(N, H, W, Cn, dt, DEV)
+        dgb = torch.empty(2, Cn, device=DEV)
+        ops.bn_relu_bwd(y, vec, g_fused, None, None, sums, dx, dgb[0], dgb[1], partials=partials)
+        return sums.clone(), dx.dense().float(), dgb.clone()
+
+    s0, dx0, dgb0 = bwd(None)
+    s1, dx1, dgb1 = bwd(part)
+    assert relerr(s1, s0) < 2e-5 and relerr(dgb1, dgb0) < 2e-5
+    assert relerr(dx1, dx0) < 1e-2      # bf16 outputs: a last-place flip where the two sums differ in fp32 noise

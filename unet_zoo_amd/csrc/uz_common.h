@@ -90,8 +90,14 @@ struct UzDirectPlan {
   int tw, bn, bres, th_n, tw_n, ntiles, tiles_n, grid_m;
 };
 int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p);
+// operands of the BatchNorm-backward reduction fused into the epilogue (uz_conv_igemm_bnred)
+struct UzBnRed {
+  const void* y;
+  int ldy;
+  const float *scale, *shift, *mean, *invstd;
+};
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
-                     const float* bias, void* y, float* stats, hipStream_t s);
+                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br = nullptr);
 
 // 3x3 weight gradient with LDS-DMA pipeline (uz_wgrad3x3.hip), dispatched from uz_wgrad()
 struct UzWgrad2Plan {

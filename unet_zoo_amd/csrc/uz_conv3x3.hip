@@ -34,6 +34,15 @@ struct DirectArgs {
   int th_n, tw_n, ntiles;
   int flags;  // tuning/ablation switches (env UZ_TUNE, tools/kbench.py); 0 in production
   int ups;    // 1: the input lives at (H/2, W/2) and is read through nearest x2 upsampling
+  // BatchNorm-backward reduction fused into the epilogue (uz_conv_igemm_bnred): this launch computes the gradient g
+  // of the activation relu(bn(bn_y)); instead of the statistics of its own output the workgroup rows of `stats`
+  // receive sum(dz) and sum(dz * xhat) with dz = g * [bn_scale * bn_y + bn_shift > 0], xhat = (bn_y - mean) * invstd
+  const void* bn_y;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  int ld_bny;
 };
 
 template <typename T> struct Mma2;
@@ -66,8 +75,25 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 constexpr unsigned OOB = 0x10000000u;  // beyond any descriptor's num_records (tensors < 2 GiB)
+#ifndef UZ_CONV_SKEL
+#define UZ_CONV_SKEL 0   // measurement builds (-DUZ_CONV_SKEL=bits): 1 no fragment reads, 2 no MFMAs, 4 no DMA past the first double-step, 8 no epilogue
+#endif
 
-template <typename T, int TW, int BN, bool BRES>
+// Fragment reads of the streaming kernel's double-step are issued from inline asm with hand-counted lgkmcnt waits:
+// left to the compiler every ds_read_b128 group is followed by `s_waitcnt lgkmcnt(0)` and two MFMAs, i.e. a bare LDS
+// round trip per K-chunk; as asm the reads of chunk g + 1 leave before the MFMAs of chunk g.
+__device__ __forceinline__ void lds_read16(f32x4& dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int V> struct IntC { static constexpr int value = V; };
+__device__ __forceinline__ void pin16(f32x4& v) { asm volatile("" : "+v"(v)); }
+
+// BNRED: the epilogue accumulates the BatchNorm-backward sums of DirectArgs::bn_* instead of output statistics (a
+// separate instantiation: the extra live registers of that epilogue must not weigh on the plain kernels; no bias)
+template <typename T, int TW, int BN, bool BRES, bool BNRED = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int ES = (int)sizeof(T);
@@ -125,6 +151,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
   }
 
   if ((UZ_KFLAGS(a) & 0x20) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if ((UZ_KFLAGS(a) & 0x2000) && wave < 4) __builtin_amdgcn_s_setprio(1);
   const int ncb = (a.Cin + BK - 1) / BK;  // the last slab may be partial: channels >= Cin read as zero
   float s1[TN], s2[TN];
 #pragma unroll
@@ -222,6 +249,72 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     }
   };
 
+  // ---- the double-step as one read pipeline (streaming path) ----------------------------------------------
+  // chunk g = 0 .. 7 of the double-step = K-chunk g & 3 of unit g >> 2; set g & 1 of the fragment registers.
+  typedef __attribute__((address_space(3))) char* lds_char_ptr;
+  const unsigned smem_u = (unsigned)(size_t)(lds_char_ptr)smem;
+  unsigned boffq[4][TN];   // weight fragment of K-chunk q, N tile j, relative to the slot (tap-invariant)
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      boffq[q][j] = smem_u + 2 * A_BYTES + b_frag_off[j] + (((2 * q + lh) ^ b_sw[j]) << 4);
+  struct UnitAddr { unsigned arow[2]; int asw[2]; unsigned bbase; };
+  auto unit_addr = [&](int tap, int abuf, int bslot) __attribute__((always_inline)) {
+    UnitAddr u;
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int prow = (f_pi[i] + ty) * PW + f_pj + tx;
+      u.arow[i] = smem_u + abuf * A_BYTES + prow * 128;
+      u.asw[i] = (prow >> 1) & 7;
+    }
+    u.bbase = bslot * B_STAGE;
+    return u;
+  };
+  constexpr int RPC = 2 + TN;   // LDS reads per K-chunk
+  // ---- unit-sized segments ---------------------------------------------------------------------------------------
+  // A wave requests the sixteen fragments of a whole unit (64 VGPRs, inline-asm ds_read_b128 with hand-counted
+  // lgkmcnt waits), then issues its sixteen MFMAs, K-chunk q as soon as its four fragments are in.
+  // Measured with compile-time variants of this kernel on 256 -> 256 @ 64 x 64 (B = 16; -DUZ_CONV_SKEL): skeleton
+  // (no reads, MFMAs, DMA) 15 us, + fragment reads 38 us, + MFMAs instead 53 us, reads AND MFMAs 68-73 us, + the
+  // LDS-DMA stream 82-84 us: read time adds to MFMA time almost in full.  Tried against that, all within +-5 % of each
+  // other: the compiler's own read -> wait -> 2 MFMA groups (round 1), reads of chunk g + 1 ahead of the MFMAs of chunk g,
+  // reads of chunk g + 2 between the MFMAs of chunk g, these unit-long segments (best by 2-4 % on the 128- and
+  // 256-channel layers), s_setprio for either half of the waves, accumulators in AGPRs (30-60 % slower: copies in the
+  // epilogue and a 128-VGPR budget).
+  f32x4 ua[4][2], ub[4][TN];
+  auto read_unit = [&](const UnitAddr& u) __attribute__((always_inline)) {
+    if (UZ_CONV_SKEL & 1) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lc = 2 * q + lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) lds_read16(ua[q][i], u.arow[i] + ((lc ^ u.asw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) lds_read16(ub[q][j], boffq[q][j] + u.bbase);
+    }
+  };
+  auto mma_unit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q == 0) wait_lgkm<3 * RPC>();
+      else if (q == 1) wait_lgkm<2 * RPC>();
+      else if (q == 2) wait_lgkm<RPC>();
+      else wait_lgkm<0>();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pin16(ua[q][i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) pin16(ub[q][j]);
+      if (UZ_CONV_SKEL & 2) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          Mma2<T>::run(*reinterpret_cast<const Vec16<T>*>(&ua[q][i]), *reinterpret_cast<const Vec16<T>*>(&ub[q][j]), acc[i][j]);
+    }
+  };
+
   // Resident-weight tiles have only two MFMAs per fragment set (wave tile 64x32), too few to
   // cover an LDS round trip: walk the 36 (tap, K-chunk) groups of a tile as ONE software pipeline,
   // group g+1's three ds_read_b128 issued ahead of group g's MFMAs (two register sets; the order is
@@ -280,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
   // bf16 path (transposed accumulators): accumulator register r of N tile j is channel
   // wn*WTN + 32 j + (r & 3) + 8 (r >> 2) + 4 lh
   float bq[TN][16];
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2 && !BNRED) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -356,6 +449,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
           unit(L0, c0, t0);
           if (L1 < nsteps) unit(L1, c1, t1);
           auto issue_next = [&]() {
+            if (UZ_CONV_SKEL & 4) return;   // measurement build: no DMA after the first double-step
             if (d + 1 < ndbl) {  // weight tiles of the next double-step into the other slot pair
               const int s2 = ((d + 1) & 1) * 2;
               int c, t;
@@ -387,13 +481,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
           // its LDS-DMA pieces AFTER its first unit, so one wave's issue runs beside the other's MFMAs
           // (+2 ... 4.5 % on every non-resident layer; flag 0x10 of the ablation build switches it off)
           const bool late = !(UZ_KFLAGS(a) & 0x10) && wave >= 4;
-          // (measured and rejected in round 2: the double-step's fragment reads as one explicit software pipeline, two
-          // register sets with the order pinned by scheduling barriers -- 5 ... 40 % slower on every layer than the
-          // compiler's own read -> wait -> MFMA groups, whose waits the partner wave of the SIMD covers)
-          if (!late) issue_next();
-          compute(t0, c0 & 1, s0);
-          if (late) issue_next();
-          if (L1 < nsteps) compute(t1, c1 & 1, s0 + 1);
+          // (measured and rejected in round 2: the same read pipeline written with plain loads and the order pinned by
+          // scheduling barriers -- 5 ... 40 % slower on every layer than the compiler's own read -> wait -> MFMA groups)
+          const bool two = L1 < nsteps;
+          if (UZ_KFLAGS(a) & 0x300) {   // ablations of compute()
+            if (!late) issue_next();
+            compute(t0, c0 & 1, s0);
+            if (late) issue_next();
+            if (two) compute(t1, c1 & 1, s0 + 1);
+          } else {
+            const UnitAddr u0 = unit_addr(t0, c0 & 1, s0), u1 = unit_addr(t1, c1 & 1, s0 + 1);
+            if (!(UZ_CONV_SKEL & 16) || d == 0) read_unit(u0);   // (16: real fragments once per tile, then MFMAs only)
+            if (!late) issue_next();
+            mma_unit();
+            __builtin_amdgcn_sched_barrier(0);
+            if (two && !(UZ_CONV_SKEL & 16)) read_unit(u1);
+            if (late) issue_next();
+            if (two) mma_unit();
+          }
         }
         cbuf = 0;
       } else {
@@ -429,11 +534,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
     }
 
     // ---- epilogue: bias + statistics from registers ------------------------------------------
-    if (UZ_KFLAGS(a) & 1) {
+    if (((UZ_KFLAGS(a) & 1) | (UZ_CONV_SKEL & 8)) != 0) {
       asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][0][3]));
     } else if constexpr (sizeof(T) == 2) {
       constexpr int RSC = BN * ES + 16;  // C staging row stride (bytes)
       static_assert(256 * RSC <= A_BYTES * 2, "C staging must fit the A buffers");
+      constexpr int CPR = BN * ES / 16;  // 16-byte chunks per pixel
+      static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
+      constexpr int NPASS = 256 * CPR / 512, RPP = 512 / CPR;
+      const int cc = tid % CPR;
+      const int n = n0 + cc * VEC;
+      // fused BatchNorm-backward reduction: the pre-activation values of this thread's read-back pixels are requested
+      // now, a staging round trip ahead of their use
+      Vec16<T> yb[NPASS];
+      if constexpr (BNRED) {
+        const T* __restrict__ by = static_cast<const T*>(a.bn_y);
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+          const int m = tid / CPR + k * RPP;
+          const int mt = m >> 5, ml = m & 31;
+          const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
+          const int pj = (TW == 32) ? ml : (ml & 15);
+          const int hh = min(h0 + pi, a.H - 1), ww = min(w0 + pj, a.W - 1);   // clamped: unused outside the image
+          yb[k] = ld16(by + ((size_t)(img * a.H + hh) * a.W + ww) * a.ld_bny + (n < a.Nout ? n : 0));
+        }
+      }
       __builtin_amdgcn_s_barrier();  // every wave has finished reading A/B of this tile
       char* sC = smem + ((BRES ? cbuf : 0) * A_BYTES);
       if (BRES) static_assert(256 * (64 * 2 + 16) <= A_BYTES, "C staging must fit one A buffer");
@@ -449,7 +574,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
           for (int q = 0; q < 4; ++q) {
             bf16x4 pk;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[i][j][4 * q + e] + bq[j][4 * q + e]);
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(BNRED ? acc[i][j][4 * q + e] : acc[i][j][4 * q + e] + bq[j][4 * q + e]);
             *reinterpret_cast<bf16x4*>(rowp + (wn * WTN + j * 32 + 8 * q + 4 * lh) * ES) = pk;
           }
         }
@@ -460,14 +585,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       // stale weight-slot bytes; the prefetch itself measured no gain and was dropped, the wait stays.)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      constexpr int CPR = BN * ES / 16;  // 16-byte chunks per pixel
-      static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
-      const int cc = tid % CPR;
-      const int n = n0 + cc * VEC;
       const bool dostats = !(UZ_KFLAGS(a) & 2);
+      float bsc[VEC], bsh[VEC], bmu[VEC], bis[VEC];   // (loaded here: the accumulators are dead by now)
+      if constexpr (BNRED) {
+        const int ch0 = (n < a.Nout) ? n : 0;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {   // channel chunks start at multiples of 8: 16-byte aligned
+          *reinterpret_cast<f32x4*>(&bsc[e]) = *reinterpret_cast<const f32x4*>(a.bn_scale + ch0 + e);
+          *reinterpret_cast<f32x4*>(&bsh[e]) = *reinterpret_cast<const f32x4*>(a.bn_shift + ch0 + e);
+          *reinterpret_cast<f32x4*>(&bmu[e]) = *reinterpret_cast<const f32x4*>(a.bn_mean + ch0 + e);
+          *reinterpret_cast<f32x4*>(&bis[e]) = *reinterpret_cast<const f32x4*>(a.bn_invstd + ch0 + e);
+        }
+      }
       // every thread reads back 256 * CPR / 512 chunks: all of them are requested before the first store (as a
       // rolled loop each pass waited for its own LDS round trip: ~250 cycles x 8 per tile with every wave idle)
-      constexpr int NPASS = 256 * CPR / 512, RPP = 512 / CPR;
       Vec16<T> vb[NPASS];
 #pragma unroll
       for (int k = 0; k < NPASS; ++k)
@@ -481,7 +612,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
         const int hh = h0 + pi, ww = w0 + pj;
         if (hh < a.H && ww < a.W && n < a.Nout) {
           st16(yg + ((size_t)(img * a.H + hh) * a.W + ww) * a.ldy + n, vb[k]);
-          if (dostats) {  // statistics of the stored values, pixels inside the image only
+          if constexpr (BNRED) {   // sums of the BatchNorm backward, from the gradient values as stored
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float yv = (float)yb[k].v[e];
+              const float dz = fmaf(yv, bsc[e], bsh[e]) > 0.f ? (float)vb[k].v[e] : 0.f;
+              sq1[e] += dz;
+              sq2[e] += dz * ((yv - bmu[e]) * bis[e]);
+            }
+          } else if (dostats) {  // statistics of the stored values, pixels inside the image only
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
               const float fv = (float)vb[k].v[e];
@@ -914,6 +1053,17 @@ static int direct_launch_t(const UzDirectPlan& p, const DirectArgs& a, hipStream
       return UZ_OK;
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    if (a.bn_y != nullptr) {
+#define UZ_BNRED(TWv, BNv, RESv) hipLaunchKernelGGL((conv3x3_direct_kernel<T, TWv, BNv, RESv, true>), grid, block, 0, s, a)
+      if (p.bn == 64 && p.bres) { if (p.tw == 32) UZ_BNRED(32, 64, true); else UZ_BNRED(16, 64, true); }
+      else if (p.bn == 64) { if (p.tw == 32) UZ_BNRED(32, 64, false); else UZ_BNRED(16, 64, false); }
+      else { if (p.tw == 32) UZ_BNRED(32, 128, false); else UZ_BNRED(16, 128, false); }
+#undef UZ_BNRED
+      UZ_LAUNCH_CHECK("uz_conv_igemm_bnred(direct3x3)");
+      return UZ_OK;
+    }
+  }
   if (p.bn == 64) {
     if (p.bres) {
       if (p.tw == 32) hipLaunchKernelGGL((conv3x3_direct_kernel<T, 32, 64, true>), grid, block, 0, s, a);
@@ -931,9 +1081,17 @@ static int direct_launch_t(const UzDirectPlan& p, const DirectArgs& a, hipStream
 }
 
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
-                     const float* bias, void* y, float* stats, hipStream_t s) {
+                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   DirectArgs a;
+  a.bn_y = br ? br->y : nullptr;
+  a.bn_scale = br ? br->scale : nullptr;
+  a.bn_shift = br ? br->shift : nullptr;
+  a.bn_mean = br ? br->mean : nullptr;
+  a.bn_invstd = br ? br->invstd : nullptr;
+  a.ld_bny = br ? br->ldy : 0;
+  if (br) UZ_REQUIRE(d->dtype == UZ_BF16 && p.bres != 2 && stats != nullptr,
+                     "uz_conv_igemm_bnred: bf16 direct 3x3 kernels with LDS-staged epilogue only");
   a.x = x;
   a.w = w;
   a.y = y;

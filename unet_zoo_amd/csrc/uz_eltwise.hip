@@ -1007,6 +1007,14 @@ static BnBwdArgs bnbwd_args(const uz_bnbwd_desc* d, const void* y, const float* 
   return a;
 }
 
+static void bnbwd_finalize(const float* partial, int rows, int C, double* sums, float* dgamma, float* dbeta,
+                           hipStream_t s) {
+  if (rows >= 128 && C <= 512)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(uz_cdiv(C, 8)), dim3(1024), 0, s, partial, rows, C, sums, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3(uz_cdiv(C, 32)), dim3(1024), 0, s, partial, rows, C, sums, dgamma, dbeta);
+}
+
 extern "C" long long uz_bn_relu_bwd_workspace_bytes(const uz_bnbwd_desc* d, int has_pool_grad) {
   UZ_REQUIRE(d != nullptr && d->C > 0 && d->N > 0 && d->H > 0 && d->W > 0, "uz_bn_relu_bwd_workspace_bytes: bad descriptor");
   UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "uz_bn_relu_bwd_workspace_bytes: bad dtype");
@@ -1031,13 +1039,17 @@ extern "C" int uz_bn_relu_bwd_reduce(const uz_bnbwd_desc* d, const void* y, cons
   if (rc2 != UZ_OK) return rc2;
   dim3 grid, block;
   bnbwd_shape(d, gpool != nullptr, &grid, &block);
-  if ((int)grid.x >= 128 && d->C <= 512)
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<8>, dim3(uz_cdiv(d->C, 8)), dim3(1024), 0, s,
-                       static_cast<const float*>(workspace), (int)grid.x, d->C, sums, dgamma, dbeta);
-  else
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<32>, dim3(uz_cdiv(d->C, 32)), dim3(1024), 0, s,
-                       static_cast<const float*>(workspace), (int)grid.x, d->C, sums, dgamma, dbeta);
+  bnbwd_finalize(static_cast<const float*>(workspace), (int)grid.x, d->C, sums, dgamma, dbeta, s);
   UZ_LAUNCH_CHECK("uz_bn_relu_bwd_reduce(finalize)");
+  return UZ_OK;
+}
+
+extern "C" int uz_bn_bwd_finalize(const float* partial, int rows, int C, double* sums, float* dgamma, float* dbeta,
+                                  void* stream) {
+  UZ_REQUIRE(partial && sums && rows > 0 && C > 0, "uz_bn_bwd_finalize: bad arguments");
+  UZ_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "uz_bn_bwd_finalize: dgamma/dbeta");
+  bnbwd_finalize(partial, rows, C, sums, dgamma, dbeta, (hipStream_t)stream);
+  UZ_LAUNCH_CHECK("uz_bn_bwd_finalize");
   return UZ_OK;
 }
 

@@ -512,6 +512,32 @@ extern "C" int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const voi
   return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, nullptr, static_cast<hipStream_t>(stream), res, ldres);
 }
 
+extern "C" int uz_conv_igemm_bnred_supported(const uz_conv_desc* d) {
+  UzDirectPlan dp;
+  return (d != nullptr && d->dtype == UZ_BF16 && uz_direct_plan(d, &dp) && dp.bres != 2) ? 1 : 0;
+}
+
+extern "C" int uz_conv_igemm_bnred(const uz_conv_desc* d, const void* x, const void* w_packed, void* y,
+                                   const void* bn_y, int ld_bny, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, float* partial, void* stream) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(x && w_packed && y && bn_y && scale && shift && mean && invstd && partial,
+             "uz_conv_igemm_bnred: null pointer");
+  UZ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                 ((uintptr_t)bn_y & 15) == 0, "uz_conv_igemm_bnred: x / w / y / bn_y must be 16-byte aligned");
+  UZ_REQUIRE(ld_bny >= d->Nout && ld_bny % 8 == 0, "uz_conv_igemm_bnred: bad ld_bny %d", ld_bny);
+  UzDirectPlan dp;
+  if (!uz_conv_igemm_bnred_supported(d) || !uz_direct_plan(d, &dp)) {
+    uz_set_error("uz_conv_igemm_bnred: only bf16 problems of the direct 3x3 kernels with the LDS-staged epilogue "
+                 "(ask uz_conv_igemm_bnred_supported)");
+    return UZ_ENOTIMPL;
+  }
+  const UzBnRed br = {bn_y, ld_bny, scale, shift, mean, invstd};
+  return uz_direct_launch(d, dp, x, w_packed, nullptr, y, partial, static_cast<hipStream_t>(stream), &br);
+}
+
 extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed,
                                 const float* bias, void* y, float* stats_partial, void* workspace,
                                 void* stream) {

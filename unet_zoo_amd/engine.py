@@ -277,7 +277,7 @@ class Engine:
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
                      pool: bool = False, im2col: bool = False, upsample: bool = False,
                      residual: Optional[Act] = None, pool_ceil: bool = False, relu: bool = True,
-                     stat_repeat: int = 1) -> Tuple[Act, Optional[Act]]:
+                     stat_repeat: int = 1, sole_reader: bool = False) -> Tuple[Act, Optional[Act]]:
         """[nearest x2 upsample ->] Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
 
         Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
@@ -288,7 +288,10 @@ class Engine:
         (Conv2d_batchnorm(activation='None'), multiresunet.py:26-31).  stat_repeat = k: the reference applies this
         layer to a tensor in which every pixel of x occurs k times (a nearest-neighbour upsampling in front of a 1x1
         convolution, uctransnet.py:75-80); batch mean, biased variance and all gradients are those of x, only the
-        sample count of the running variance's unbiased factor is k times larger.  Returns (act, pooled)."""
+        sample count of the running variance's unbiased factor is k times larger.  sole_reader: the caller states
+        that nothing but this convolution reads x (the middle tensor of a DoubleConv): if x is itself the output of a
+        Conv -> BN -> ReLU, the first pass of ITS BatchNorm backward then rides in the epilogue of this layer's
+        input-gradient convolution (uz_conv_igemm_bnred) instead of re-reading the gradient.  Returns (act, pooled)."""
         N, H, W = x.N, x.H, x.W
         if upsample:
             H, W = 2 * H, 2 * W
@@ -323,6 +326,8 @@ class Engine:
             pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
         assert relu or residual is None
         ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu)
+        if self.record and self.training and relu and pooled is None and residual is None and stat_repeat == 1:
+            act.bn_src = (y, vec)      # what a sole reader's input-gradient kernel needs (see sole_reader)
 
         if self.record:
             if not self.training:
@@ -354,7 +359,10 @@ class Engine:
                     dgamma = torch.empty(Cout, dtype=torch.float32, device=self.device)
                 if dbeta is None:
                     dbeta = torch.empty(Cout, dtype=torch.float32, device=self.device)
-                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil, relu=relu)
+                # g0 came from a sole reader's input-gradient kernel with the reduction already done in its epilogue
+                parts = getattr(g0, "bn_partials", None) if (g1 is None and gp is None and residual is None) else None
+                ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil, relu=relu,
+                                partials=parts)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:
@@ -383,10 +391,13 @@ class Engine:
                         # per-channel sums of dx come for free from the kernel's statistics
                         # epilogue; a ConvTranspose2d feeding x takes its bias gradient from them
                         want = x.parts is not None
+                        src = getattr(x, "bn_src", None) if (sole_reader and not want) else None
                         part = ops.conv_igemm(dy, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx,
-                                              ntaps=ntaps, dil=dil, want_stats=want)
+                                              ntaps=ntaps, dil=dil, want_stats=want, bnred=src)
                         if want:
                             dx.colsums = (part, 0)
+                        elif src is not None and part is not None:
+                            dx.bn_partials = part
                         x.add_grad(dx)
 
             self.tape.append(bwd)

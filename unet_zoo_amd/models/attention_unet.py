@@ -30,7 +30,7 @@ class ConvBlock(nn.Module):
     def emit(self, eng: Engine, x: Act, *, pool: bool = False, im2col: bool = False):
         s = self.conv
         mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col)
-        return eng.conv_bn_relu(mid, s[3], s[4], pool=pool)
+        return eng.conv_bn_relu(mid, s[3], s[4], pool=pool, sole_reader=True)
 
 
 class UpConvBlock(nn.Module):

@@ -33,7 +33,7 @@ class DoubleConv(nn.Module):
              im2col: bool = False) -> Tuple[Act, Optional[Act]]:
         s = self.conv_op
         mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col)
-        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool)
+        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True)
 
 
 class DownSample(nn.Module):

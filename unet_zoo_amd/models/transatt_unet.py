@@ -41,7 +41,7 @@ class DoubleConvo(nn.Module):
              im2col: bool = False) -> Tuple[Act, Optional[Act]]:
         s = self.double_conv
         mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col)
-        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool)
+        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True)
 
 
 class Down(nn.Module):

@@ -18,7 +18,8 @@ from . import _lib as L
 class Act:
     """NHWC activation: element (pixel p, channel c) at ``buf[p, off + c]``; ``buf`` is (P, ld)."""
 
-    __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "rparts", "needs_grad", "colsums")
+    __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "rparts", "needs_grad", "colsums", "bn_src",
+                 "bn_partials")
 
     def __init__(self, buf: torch.Tensor, off: int, C: int, N: int, H: int, W: int,
                  needs_grad: bool = True):
@@ -198,9 +199,13 @@ def im2col3x3_nchw(x: torch.Tensor, kpad: int, dtype: torch.dtype) -> Act:
 def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Act, *,
                ntaps: int, dil: int = 1, taps_mode: int = L.TAPS_CONV,
                store_mode: int = L.STORE_PLAIN, nout: Optional[int] = None, co: int = 0,
-               want_stats: bool = False, res: Optional[Act] = None) -> Optional[torch.Tensor]:
+               want_stats: bool = False, res: Optional[Act] = None,
+               bnred: Optional[tuple] = None) -> Optional[torch.Tensor]:
     """y = conv(x, w) + bias [+ res] on the matrix cores; returns the BN partial-sum rows if asked.  res: a tensor
-    of y's shape added in the GEMM epilogue (uz_conv_igemm_res), or by a separate add where that kernel does not apply."""
+    of y's shape added in the GEMM epilogue (uz_conv_igemm_res), or by a separate add where that kernel does not apply.
+    bnred = (bn_y, vec): y is the gradient of relu(bn(bn_y)); the kernel's epilogue accumulates the two sums of that
+    BatchNorm's backward (uz_conv_igemm_bnred) and their partial rows are returned -- or None when the problem is not
+    one of the kernels that can (the caller then runs the stand-alone reduction)."""
     L.require_cuda(x.buf, w_packed, y.buf)
     lib = L.load()
     if taps_mode == L.TAPS_CONV:
@@ -242,6 +247,20 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
     else:
         kname = f"igemm_{_tname(x.dtype)}_128x{bn}" + ("_tapsplit" if ws is not None else "")
+    if bnred is not None:
+        assert bias is None and res is None and not want_stats
+        bn_y, vec4 = bnred
+        if not lib.uz_conv_igemm_bnred_supported(byref(d)) or (bn_y.P, bn_y.C) != (y.P, y.C):
+            bnred = None
+        else:
+            gm = L.check_count(lib.uz_conv_igemm_ws_grid_m(byref(d)), "uz_conv_igemm_ws_grid_m")
+            part = torch.empty((gm, 2, d.Nout), dtype=torch.float32, device=x.buf.device)
+            with _Timed(kname + "_bnred", 2.0 * M * d.Nout * K, es * (x.P * x.C + 2 * M * d.Nout + d.Nout * K)):
+                L.check(lib.uz_conv_igemm_bnred(byref(d), x.ptr(), w_packed.data_ptr(), y.ptr(), bn_y.ptr(), bn_y.ld,
+                                                vec4[0].data_ptr(), vec4[1].data_ptr(), vec4[2].data_ptr(),
+                                                vec4[3].data_ptr(), part.data_ptr(), L.stream_ptr()),
+                        "uz_conv_igemm_bnred")
+            return part
     if res is not None:
         assert (res.P, res.C) == (y.P, y.C) and res.dtype == y.dtype and not want_stats
         if kname.startswith("gemm_dma") and store_mode == L.STORE_PLAIN:
@@ -370,9 +389,11 @@ def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
 
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
-                dbeta: torch.Tensor, pool_ceil: bool = False, relu: bool = True) -> None:
+                dbeta: torch.Tensor, pool_ceil: bool = False, relu: bool = True,
+                partials: Optional[torch.Tensor] = None) -> None:
     """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch; relu=False: the
-    forward was a plain BatchNorm"""
+    forward was a plain BatchNorm.  partials: the rows of the first pass as left by the convolution that produced g0
+    (conv_igemm(bnred=...)): only their fixed-order sum is launched instead of the reduction pass."""
     lib = L.load()
     d = L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
                     g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
@@ -383,12 +404,17 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
     s = L.stream_ptr()
     nsrc = (g0 is not None) + (g1 is not None) + 0.25 * (gpool is not None)
     es = y.buf.element_size()
-    wsb = L.check_count(lib.uz_bn_relu_bwd_workspace_bytes(byref(d), int(gpool is not None)),
-                        "uz_bn_relu_bwd_workspace_bytes")
-    ws = torch.empty(wsb // 4, dtype=torch.float32, device=y.buf.device)
-    with _Timed("bn_relu_bwd_reduce", 0.0, es * y.P * y.C * (1 + nsrc)):
-        L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, ws.data_ptr(), sums.data_ptr(),
-                                          dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_reduce")
+    if partials is not None:
+        assert relu and g1 is None and gpool is None and partials.shape[1:] == (2, y.C) and partials.is_contiguous()
+        L.check(lib.uz_bn_bwd_finalize(partials.data_ptr(), partials.shape[0], y.C, sums.data_ptr(),
+                                       dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_bwd_finalize")
+    else:
+        wsb = L.check_count(lib.uz_bn_relu_bwd_workspace_bytes(byref(d), int(gpool is not None)),
+                            "uz_bn_relu_bwd_workspace_bytes")
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=y.buf.device)
+        with _Timed("bn_relu_bwd_reduce", 0.0, es * y.P * y.C * (1 + nsrc)):
+            L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, ws.data_ptr(), sums.data_ptr(),
+                                              dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_reduce")
     with _Timed("bn_relu_bwd_apply", 0.0, es * y.P * y.C * (2 + nsrc)):
         L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(), s),
                 "uz_bn_relu_bwd_apply")
