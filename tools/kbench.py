@@ -53,6 +53,17 @@ def main():
                 if what in ("wgrad", "all"):
                     us = timeit(lambda: ops.wgrad(dy, x, (cout, cin, 3, 3), ntaps=9))
                     res.append((t, "wgrad", us))
+        if what in ("wgrad", "all") and len(tunes) > 1:      # the variants must agree (fp32 summation order aside)
+            ref = None
+            for t in tunes:
+                os.environ["UZ_TUNE"] = t
+                o = ops.wgrad(dy, x, (cout, cin, 3, 3), ntaps=9).double()
+                if ref is None:
+                    ref = o
+                else:
+                    err = ((o - ref).abs().max() / ref.abs().max()).item()
+                    if err > 1e-4:
+                        print(f"  !! wgrad[{t}] differs from wgrad[{tunes[0]}]: rel {err:.2e}", flush=True)
         out = {}
         for t, k, us in res:
             out.setdefault((t, k), []).append(us)

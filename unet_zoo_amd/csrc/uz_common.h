@@ -102,6 +102,7 @@ int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x
 // 3x3 weight gradient with LDS-DMA pipeline (uz_wgrad3x3.hip), dispatched from uz_wgrad()
 struct UzWgrad2Plan {
   int big, one_tap, gather, kw, kr, tiles_i, tiles_j, kg, units, upb, split, nslabs, H, W;
+  int wide9;   // nine taps on a 128 (dy) x 64 (x) channel tile
 };
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,

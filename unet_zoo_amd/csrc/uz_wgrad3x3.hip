@@ -85,22 +85,30 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   constexpr int CPRL = RBL / 16, CPRR = RBR / 16;       // 16-byte chunks per row
   constexpr int RPPL = 1024 / RBL, RPPR = 1024 / RBR;   // pixel rows per 1 KiB DMA piece
   constexpr int NLP = 64 / RPPL;                        // L pieces per stage
-  constexpr int RPX = (NTY == 1) ? 72 : 200;            // R tile capacity in pixels
+  // R tile capacity in pixels (128 x 64 tile: strips of <= 32 columns; 64 x 128: 4 x 16 strips only)
+  constexpr int RPX = (NTY == 1) ? 72 : (BI == 128 ? 136 : (BJ == 128 ? 108 : 200));
   constexpr int NRP = RPX / RPPR;
   constexpr int PPW = 5;                                // pieces per wave per stage (40 slots)
   static_assert(NLP + NRP <= 8 * PPW && NLP % 8 == 0, "stage layout");
   constexpr int STAGE = 8 * PPW * 1024;
   constexpr int WTI = BI / WI, WTJ = BJ / WJ, TI = WTI / 32, TJ = WTJ / 32;
   constexpr int NTAP = NTX * NTY;               // taps of the workgroup
-  constexpr int NTW = (NTAP + TG - 1) / TG;     // taps per wave
+  constexpr int NTW = (NTAP + TG - 1) / TG;     // taps per wave (at most)
   static_assert(TJ == 1, "one 32-channel R tile per wave");
   __shared__ __attribute__((aligned(16))) char smem[4 * STAGE];  // all 160 KiB: two slots of two K-steps
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tg = wave / (WI * WJ), wij = wave % (WI * WJ);
+  // Nine taps over four tap groups (the 64 x 64 tile): 3 + 2 + 2 + 2, and the two waves of SIMD s (waves s, s + 4)
+  // take groups {0, 1} or {2, 3}: 5 / 5 / 4 / 4 tap units per SIMD.  (Three taps each for groups 0-2 and an idle
+  // fourth group put 6 / 6 / 3 / 3 on the SIMDs: the matrix pipes of two of them ran half empty.)
+  constexpr bool UNEVEN = (NTX * NTY == 9 && TG == 4 && WI * WJ == 2);
+  const int tg = UNEVEN ? ((wave >> 1) & 1) * 2 + (wave >> 2) : wave / (WI * WJ);
+  const int wij = UNEVEN ? (wave & 1) : wave % (WI * WJ);
   const int wi = wij / WJ, wj = wij % WJ;
   const int l31 = lane & 31, lh = lane >> 5;
+  const int tap0 = UNEVEN ? (tg == 0 ? 0 : 1 + 2 * tg) : tg * NTW;                        // first tap of this wave
+  const int ntw_me = UNEVEN ? (tg == 0 ? 3 : 2) : (NTAP - tap0 < NTW ? NTAP - tap0 : NTW);   // and how many (wave-uniform)
   // work item = (channel tile, kernel row ty, pixel split z).  The three kernel rows of one
   // (tile, z) read the same dy tile and overlapping x rows: give them workgroup ids that differ by
   // multiples of 8 so that they share an XCD (one L2) and run at about the same time (speed only).
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   };
   // (row offset, column shift) of the wave's tt-th tap inside the R tile
   auto tap_shift = [&](int tt, int r, int c0) -> int {
-    const int tap = tg * NTW + tt;
+    const int tap = (tap0 + tt < NTAP) ? tap0 + tt : NTAP - 1;   // (slots past the wave's last tap read a valid address, unused)
     const int tyo = (NTY == 3) ? (tap * 11) >> 5 : 0;          // tap / 3 for tap in 0..8
     const int tx = (NTX == 3) ? tap - 3 * ((tap * 11) >> 5) : 0;
     return (r + tyo) * PWR + c0 + tx;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
       pin(blo[slot]);
       pin(bhi[slot]);
       const bf16x8 bfr = __builtin_shufflevector(blo[slot], bhi[slot], 0, 1, 2, 3, 4, 5, 6, 7);
-      if (NTAP % TG == 0 || tg * NTW + tt < NTAP) {  // wave-uniform
+      if ((NTAP % TG == 0 && !UNEVEN) || tt < ntw_me) {  // wave-uniform
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
           const bf16x8 afr = __builtin_shufflevector(alo[cur][i], ahi[cur][i], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -383,8 +391,8 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   // ---- partial slab [split][tap][Ci][Cj] ----------------------------------------------------------
 #pragma unroll
   for (int tt = 0; tt < NTW; ++tt) {
-    const int tw = tg * NTW + tt;
-    if (tw >= NTAP) continue;  // wave-uniform
+    const int tw = tap0 + tt;
+    if (tt >= ntw_me) continue;  // wave-uniform
     const int tap = (NTX == 1) ? ty_blk_g : ((NTY == 3) ? tw : ty_blk * 3 + tw);
     float* slab = a.slab + ((size_t)bz * (NTX == 1 ? (a.gather == 1 ? 4 : (a.gather == 2 ? 9 : 1)) : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
@@ -424,7 +432,23 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   }
   if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return 0;
   p->kw = W < 64 ? W : 64;
-  if (!p->one_tap && W >= 64 && !(d->Ci % 128 == 0 && d->Cj % 128 == 0)) {
+  // Nine taps per workgroup on a 128 x 64 (dy x x) or 64 x 128 channel tile: the x tile (strips of 4 x 16 pixels +
+  // halo) serves nine taps instead of three -- 3.2 KB of LDS-DMA per MFLOP instead of 5.2 -- at 160 accumulator
+  // registers per wave.  Measured against the 128 x 128 three-tap tile / the 64 x 64 nine-tap tile (B = 16, same box):
+  // 64 <-> 128 channels @ 256 x 256 201-208 -> 161-167 us; 1024 -> 512 @ 32 x 32 159 -> 146; 1024 -> 1024 @ 16 x 16
+  // 93 -> 90; but 5-10 % SLOWER on the 128 ... 512-channel layers at 32 x 32 ... 128 x 128, which keep three taps.
+  {
+    const int f = uz_tune_flags();   // ablation build: 0x100000 / 0x400000 force a form where it applies, 0x800000 neither
+    const bool ok9 = !p->one_tap && !gather && !(f & 0x800000);
+    p->wide9 = 0;
+    const bool many_pixels = (long long)d->N * d->H * d->W >= (1LL << 19);   // (64 -> 128 @ 128 x 128, B = 16: 59.5 -> 62.0 us)
+    if (ok9 && d->Ci % 128 == 0 && d->Cj % 64 == 0 &&
+        ((d->Cj == 64 && many_pixels) || (d->Cj >= 1024 && d->Ci >= 512) || (f & 0x100000)))
+      p->wide9 = 1;
+    else if (ok9 && d->Ci == 64 && d->Cj % 128 == 0) p->wide9 = 2;
+  }
+  if (p->wide9 && W >= 32) p->kw = ((uz_tune_flags() & 0x200000) && p->wide9 == 1) ? 32 : 16;   // (2 x 32 strips: no gain)
+  if (!p->wide9 && !p->one_tap && W >= 64 && !(d->Ci % 128 == 0 && d->Cj % 128 == 0)) {
     // the 9-tap 64 x 64 kernel keeps all three tap rows in one R tile of (kr + 2) x (kw + 2) pixels per 64-pixel
     // unit: a 1 x 64 strip re-reads x 3.1 times, 2 x 32 2.1 times, 4 x 16 1.7 times
     // (measured on 64 -> 64 @ 256 x 256: 135.7 / 132.1 / 129.6 us -- the kernel is bound elsewhere)
@@ -438,7 +462,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   const long long lbytes = ((long long)d->N * d->H * d->W - 1) * d->ldl * 2 + (long long)d->Ci * 2;
   const long long rbytes = ((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2;
   if (lbytes >= (1LL << 31) || rbytes >= (1LL << 31)) return 0;
-  p->big = (d->Ci % 128 == 0 && d->Cj % 128 == 0) ? 1 : 0;
+  p->big = (d->Ci % 128 == 0 && d->Cj % 128 == 0 && !p->wide9) ? 1 : 0;
   if (p->one_tap && !p->big) {
     // one-tap problems (nn.Linear weight gradients: 288 x 96, 96 x 96 ...) are bound by re-reading the
     // operands, once per tile of the OTHER operand: take the 128 x 128 tile (channel tails are zero-filled)
@@ -448,8 +472,8 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
     if (t128 < t64) p->big = 1;
   }
   const int b = p->big ? 128 : 64;
-  p->tiles_i = (d->Ci + b - 1) / b;
-  p->tiles_j = (d->Cj + b - 1) / b;
+  p->tiles_i = (d->Ci + (p->wide9 == 1 ? 128 : b) - 1) / (p->wide9 == 1 ? 128 : b);
+  p->tiles_j = (d->Cj + (p->wide9 == 2 ? 128 : b) - 1) / (p->wide9 == 2 ? 128 : b);
   p->kg = 1;
   p->units = (int)(nimg * H * W / 64);
   const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : (gather ? d->ntaps : 1));
@@ -537,7 +561,13 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
     // The kernel is bound by its transposed LDS reads (a 32 x 32 wave tile reads 1.2 KB per MFMA, every
     // B fragment used once): 64-row wave tiles share each B fragment between two MFMAs (0.83 KB per MFMA) even
     // though 4 tap groups leave 3 of 12 tap slots empty.  64->64 @256x256: 141.9 -> 129.6 us, 128->64: 229.8 -> 213.4.
-    if (mode == 0) UZ_WG_LAUNCH(0, 64, 64, 3, 3, 1, 2, 4);
+    if (p.wide9 == 1) {
+      if (mode == 0) UZ_WG_LAUNCH(0, 128, 64, 3, 3, 2, 2, 2);
+      else UZ_WG_LAUNCH(1, 128, 64, 3, 3, 2, 2, 2);
+    } else if (p.wide9 == 2) {
+      if (mode == 0) UZ_WG_LAUNCH(0, 64, 128, 3, 3, 1, 4, 2);
+      else UZ_WG_LAUNCH(1, 64, 128, 3, 3, 1, 4, 2);
+    } else if (mode == 0) UZ_WG_LAUNCH(0, 64, 64, 3, 3, 1, 2, 4);
     else UZ_WG_LAUNCH(1, 64, 64, 3, 3, 1, 2, 4);
   }
 #undef UZ_WG_LAUNCH
