@@ -47,12 +47,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   sh[0][g][cl] = a1;
   sh[1][g][cl] = a2;
   __syncthreads();
-  if (g == 0 && c < C) {
-    double t1 = 0.0, t2 = 0.0;
-    for (int r = 0; r < NG; ++r) {
-      t1 += sh[0][r][cl];
-      t2 += sh[1][r][cl];
+  // fixed-order pairwise tree over the NG row groups (the pairing does not depend on timing: deterministic); a single
+  // thread walking the NG partial sums cost 4 of this kernel's 5 microseconds
+#pragma unroll
+  for (int st = NG / 2; st > 0; st >>= 1) {
+    if (g < st) {
+      sh[0][g][cl] += sh[0][g + st][cl];
+      sh[1][g][cl] += sh[1][g + st][cl];
     }
+    __syncthreads();
+  }
+  if (g == 0 && c < C) {
+    const double t1 = sh[0][0][cl], t2 = sh[1][0][cl];
     const double m = t1 / count;
     double var = t2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -375,12 +381,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   sh[0][g][cl] = a1;
   sh[1][g][cl] = a2;
   __syncthreads();
-  if (g == 0 && c < C) {
-    double t1 = 0.0, t2 = 0.0;
-    for (int r = 0; r < NG; ++r) {
-      t1 += sh[0][r][cl];
-      t2 += sh[1][r][cl];
+  // fixed-order pairwise tree over the NG row groups (the pairing does not depend on timing: deterministic); a single
+  // thread walking the NG partial sums cost 4 of this kernel's 5 microseconds
+#pragma unroll
+  for (int st = NG / 2; st > 0; st >>= 1) {
+    if (g < st) {
+      sh[0][g][cl] += sh[0][g + st][cl];
+      sh[1][g][cl] += sh[1][g + st][cl];
     }
+    __syncthreads();
+  }
+  if (g == 0 && c < C) {
+    const double t1 = sh[0][0][cl], t2 = sh[1][0][cl];
     sums[c] = t1;
     sums[C + c] = t2;
     if (dgamma != nullptr) {
@@ -547,9 +559,13 @@ __global__ __launch_bounds__(1024) void outconv_bwd_finalize_kernel(const float*
     for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * ne + e];
   sh[g][el] = s;
   __syncthreads();
+#pragma unroll
+  for (int st = 16; st > 0; st >>= 1) {   // fixed-order pairwise tree
+    if (g < st) sh[g][el] += sh[g + st][el];
+    __syncthreads();
+  }
   if (g == 0 && e < ne) {
-    double t = 0.0;
-    for (int r = 0; r < 32; ++r) t += sh[r][el];
+    const double t = sh[0][el];
     const int k = e / (C + 1), c = e - k * (C + 1);
     if (c < C) dw[k * C + c] = (float)t;
     else db[k] = (float)t;
