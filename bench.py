@@ -350,8 +350,12 @@ def main():
                             if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)["kernels"]
-            key = {"conv3x3_direct_bf16_bn128": "21conv3x3_direct_kernelIDF16bLi32ELi128ELb0EEEvNS_10DirectArgsE",
-                   "wgrad3x3_bf16_128x128_3tap": "wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>"}.get(dom_name)
+            # (round-1 / round-2 spellings of the same kernels: round 2 added template parameters)
+            keys = {"conv3x3_direct_bf16_bn128": ("21conv3x3_direct_kernelIDF16bLi32ELi128ELb0ELb0EEEvNS_10DirectArgsE",
+                                                  "21conv3x3_direct_kernelIDF16bLi32ELi128ELb0EEEvNS_10DirectArgsE"),
+                    "wgrad3x3_bf16_128x128_3tap": ("wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1, 0>",
+                                                   "wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>")}.get(dom_name, ())
+            key = next((c for c in keys if any(c in k for k in pmc)), None)
             full = next((k for k in pmc if key and key in k), None)   # the table is keyed by the full kernel name
             if full is not None and args.model == "unet" and args.size == 256 and args.batch == 16:
                 key = full

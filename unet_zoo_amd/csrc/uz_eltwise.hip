@@ -816,8 +816,10 @@ __global__ void im2col3x3_kernel(const float* __restrict__ x, int N, int C, int 
 }
 
 // small compile-time C (the RGB / grey network input): one thread per pixel.  For a fixed
-// (tap, channel) consecutive lanes read consecutive w of the NCHW image (coalesced 4-byte loads);
-// each thread then writes its whole row in 16-byte pieces (a wave writes one contiguous span).
+// (tap, channel) consecutive lanes read consecutive w of the NCHW image (coalesced 4-byte loads).  The Kpad-wide
+// rows are then exchanged through a wave-private LDS strip so that consecutive LANES store consecutive 16-byte pieces
+// (a wave-store = one contiguous span; every lane writing its own 64-byte row in four 16-byte stores at a 64-byte lane
+// stride ran at 1.1 TB/s).
 template <typename T, int C>
 __global__ __launch_bounds__(256) void im2col3x3_smallc_kernel(const float* __restrict__ x, int N, int H,
                                                                int W, int Kpad, T* __restrict__ dst,
@@ -825,20 +827,31 @@ __global__ __launch_bounds__(256) void im2col3x3_smallc_kernel(const float* __re
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int K = 9 * C;
   constexpr int MAXCH = 64 / VEC;  // Kpad <= 64
+  constexpr int ROWB = MAXCH * 16 + 16;   // LDS row pitch in bytes (+16: the 16-byte pieces of a row group spread over banks)
+  __shared__ __attribute__((aligned(16))) char strip[4][64 * ROWB];
   const int nch = Kpad / VEC;
-  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
-       p += (long long)gridDim.x * blockDim.x) {
-    const int w0 = (int)(p % W);
-    const long long q = p / W;
-    const int h0 = (int)(q % H);
-    const int img = (int)(q / H);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  char* mine = strip[wv];
+  // whole waves walk the pixel range together (the exchange is wave-wide): p0 = first pixel of this wave's group of 64
+  for (long long p0 = ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63)); p0 < npix;
+       p0 += (long long)gridDim.x * blockDim.x) {
+    const long long p = p0 + lane;
     float row[K];
+    if (p < npix) {
+      const int w0 = (int)(p % W);
+      const long long q = p / W;
+      const int h0 = (int)(q % H);
+      const int img = (int)(q / H);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int hh = h0 + t / 3 - 1, ww = w0 + t % 3 - 1;
-      const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+      for (int t = 0; t < 9; ++t) {
+        const int hh = h0 + t / 3 - 1, ww = w0 + t % 3 - 1;
+        const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
 #pragma unroll
-      for (int c = 0; c < C; ++c) row[t * C + c] = ok ? x[(((size_t)img * C + c) * H + hh) * W + ww] : 0.f;
+        for (int c = 0; c < C; ++c) row[t * C + c] = ok ? x[(((size_t)img * C + c) * H + hh) * W + ww] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) row[k] = 0.f;
     }
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch) {
@@ -846,9 +859,21 @@ __global__ __launch_bounds__(256) void im2col3x3_smallc_kernel(const float* __re
         Vec16<T> v;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) v.v[e] = (ch * VEC + e < K) ? (T)row[(ch * VEC + e < K) ? ch * VEC + e : 0] : (T)0.f;
-        st16(dst + (size_t)p * Kpad + ch * VEC, v);
+        *reinterpret_cast<Vec16<T>*>(mine + lane * ROWB + ch * 16) = v;
       }
     }
+    // (one wave: program order + the LDS queue's in-order completion make the writes visible to the reads below)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // piece j of the wave's 64 * nch sixteen-byte pieces: pixel j / nch, chunk j % nch -> global byte offset 16 j
+    const int total = 64 * nch;
+    for (int j = lane; j < total; j += 64) {
+      const int px = j / nch, ch = j - px * nch;
+      if (p0 + px < npix) {
+        const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + px * ROWB + ch * 16);
+        st16(dst + (size_t)(p0 + px) * Kpad + ch * VEC, v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next group's writes
   }
 }
 
