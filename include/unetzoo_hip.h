@@ -113,7 +113,9 @@ int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed,
  * workspace), sum(dz) and sum(dz * xhat) over its pixels with dz = y * [scale * bn_y + shift > 0] (y as stored,
  * i.e. rounded to the tensor dtype) and xhat = (bn_y - mean) * invstd: uz_bn_bwd_finalize() then stands in for
  * uz_bn_relu_bwd_reduce() and the activation gradient is not read a second time.  bf16 problems of the direct 3x3
- * kernels whose epilogue is staged through LDS (uz_conv_igemm_bnred_supported() == 1); others: UZ_ENOTIMPL. */
+ * kernels whose epilogue is staged through LDS and of the LDS-DMA GEMM with UZ_STORE_PLAIN (the 2x2-gather input
+ * gradient of ConvTranspose2d k2 s2, common_layers.py:104: the decoder blocks' last BatchNorm)
+ * (uz_conv_igemm_bnred_supported() == 1); others: UZ_ENOTIMPL. */
 int uz_conv_igemm_bnred_supported(const uz_conv_desc* d);
 int uz_conv_igemm_bnred(const uz_conv_desc* d, const void* x, const void* w_packed, void* y, const void* bn_y,
                         int ld_bny, const float* scale, const float* shift, const float* mean, const float* invstd,

@@ -360,3 +360,35 @@ def test_bn_backward_reduction_in_the_input_gradient_epilogue(N, H, W, C, Cn):
     s1, dx1, dgb1 = bwd(part)
     assert relerr(s1, s0) < 2e-5 and relerr(dgb1, dgb0) < 2e-5
     assert relerr(dx1, dx0) < 1e-2      # bf16 outputs: a last-place flip where the two sums differ in fp32 noise
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Co", [(2, 16, 24, 128, 64), (1, 8, 8, 1024, 512), (2, 9, 13, 256, 128)])
+def test_bn_backward_reduction_in_the_conv_transpose_input_gradient(N, H, W, Cin, Co):
+    """the same fusion on the LDS-DMA GEMM: the 2x2-gather input gradient of ConvTranspose2d(k2, s2)
+    (common_layers.py:104) produces the gradient of the decoder block / bottleneck output below it"""
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(12)
+    g_up = act_from_nchw(rnd(dt, torch.randn(N, Co, 2 * H, 2 * W, generator=gen)).to(DEV), dt)   # gradient of the ConvT output
+    w = torch.randn(Cin, Co, 2, 2, generator=gen) * 0.05
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONVT_DGRAD, dt)
+    y = act_from_nchw(rnd(dt, torch.randn(N, Cin, H, W, generator=gen) * 2 + 0.3).to(DEV), dt)
+    gamma = (torch.rand(Cin, generator=gen) + 0.5).to(DEV)
+    beta = (torch.randn(Cin, generator=gen) * 0.2).to(DEV)
+    yd = y.dense().double()
+    stats = torch.stack([yd.sum((0, 2, 3)), (yd ** 2).sum((0, 2, 3))]).float().reshape(1, 2, Cin)
+    vec = ops.bn_finalize(stats, N * H * W, gamma, beta, 1e-5, 0.1, torch.zeros(Cin, device=DEV), torch.ones(Cin, device=DEV))
+    g_plain = ops.new_act(N, H, W, Cin, dt, DEV)
+    ops.conv_igemm(g_up, wp, None, g_plain, ntaps=4, taps_mode=L.TAPS_GATHER2X2)
+    g_fused = ops.new_act(N, H, W, Cin, dt, DEV)
+    part = ops.conv_igemm(g_up, wp, None, g_fused, ntaps=4, taps_mode=L.TAPS_GATHER2X2, bnred=(y, vec))
+    assert part is not None and part.shape[1:] == (2, Cin)
+    assert torch.equal(g_plain.dense(), g_fused.dense())
+    out = []
+    for partials in (None, part):
+        sums = torch.zeros(2, Cin, dtype=torch.float64, device=DEV)
+        dx = ops.new_act(N, H, W, Cin, dt, DEV)
+        dgb = torch.empty(2, Cin, device=DEV)
+        ops.bn_relu_bwd(y, vec, g_fused, None, None, sums, dx, dgb[0], dgb[1], partials=partials)
+        out.append((sums.clone(), dx.dense().float(), dgb.clone()))
+    assert relerr(out[1][0], out[0][0]) < 2e-5 and relerr(out[1][2], out[0][2]) < 2e-5
+    assert relerr(out[1][1], out[0][1]) < 1e-2

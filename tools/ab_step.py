@@ -1,0 +1,58 @@
+"""A/B timing of the graphed UNet step in ONE process on ONE box (boxes differ by +-10 % on the MFMA kernels, so
+separate runs cannot resolve a 1 % change): every variant = (name, {Engine class attribute: value}), measured interleaved.
+   python tools/ab_step.py [--model unet] [--rounds 3]"""
+import argparse
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import unet_zoo_amd
+from unet_zoo_amd.engine import Engine
+
+VARIANTS = [("fused conv + convT", dict(fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+            ("fused conv only", dict(fuse_bn_reduce=True, fuse_bn_reduce_convt=False)),
+            ("two-pass everywhere", dict(fuse_bn_reduce=False, fuse_bn_reduce_convt=False))]
+
+
+def build(attrs, model_name, B, S):
+    for k, v in attrs.items():
+        setattr(Engine, k, v)
+    torch.manual_seed(0)
+    kw = dict(image_size=S) if model_name in ("swin_unet_v2", "uctransnet") else {}
+    model = unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1, **kw).cuda()
+    model.run_dtype = torch.bfloat16
+    step = unet_zoo_amd.GraphedStep(model, "bce_dice", lr=1e-4, weight_decay=1e-2, max_norm=1.0)
+    x = torch.randn(B, 3, S, S, device="cuda")
+    t = (torch.rand(B, 1, S, S, device="cuda") > 0.5).float()
+    for _ in range(3):
+        step(x, t)
+    torch.cuda.synchronize()
+    return step, x, t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="unet")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    a = ap.parse_args()
+    built = [(name, build(attrs, a.model, a.batch, a.size)) for name, attrs in VARIANTS]
+    best = {name: 1e9 for name, _ in VARIANTS}
+    for r in range(a.rounds):
+        for name, (step, x, t) in built:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step(x, t)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / a.steps * 1e3
+            best[name] = min(best[name], ms)
+            print(f"round {r} {name:24s} {ms:7.3f} ms/step", flush=True)
+    for name, ms in best.items():
+        print(f"best  {name:24s} {ms:7.3f} ms/step")
+
+
+main()

@@ -115,4 +115,4 @@ struct UzGemmPlan {
 int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p);
 int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
                        const float* bias, void* y, float* stats, hipStream_t s, const void* res = nullptr,
-                       int ldres = 0);
+                       int ldres = 0, const UzBnRed* br = nullptr);

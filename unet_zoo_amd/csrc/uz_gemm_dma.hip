@@ -25,6 +25,11 @@ struct GArgs {
   float* stats;
   const void* res;   // optional (M, ldres) tensor added to the result (plain store only): residual sums, gradient sums
   int ldres;
+  // BatchNorm-backward reduction in the epilogue (uz_conv_igemm_bnred, see uz_conv3x3.hip): y is the gradient of
+  // relu(bn(bn_y)); the rows of `stats` receive sum(dz), sum(dz * xhat) instead of output statistics (plain store only)
+  const void* bn_y;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+  int ld_bny;
   unsigned xbytes, wbytes;
   int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m, Hout, Wout, dil;
 };
@@ -59,7 +64,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // workgroups, and a third of a round trip per step.  NST = 2 serves K <= 128 (at most two slabs, both requested
 // up front, the host guarantees it): 64 KB of LDS, so TWO workgroups share a CU and one's epilogue overlaps the
 // other's loads -- the full-resolution Linear layers of swin_unet_v2 (K = 96) are one short tile per workgroup.
-template <typename T, int BN, int BM, int NST>
+template <typename T, int BN, int BM, int NST, bool BNRED = false>
 __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const GArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int ES = (int)sizeof(T);
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
   // bf16 path: bias of accumulator register r of N tile j (channel wn*WTN + 32 j + (r&3) + 8(r>>2) + 4 lh) and
   // the statistics of this thread's fixed 16-byte channel chunk in the coalesced read-back
   float bq[TN][16], sq1[VEC], sq2[VEC];
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2 && !BNRED) {   // (the fused-reduction launches carry no bias)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
           for (int q = 0; q < 4; ++q) {
             bf16x4 pk;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[i][j][4 * q + e] + bq[j][4 * q + e]);
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(BNRED ? acc[i][j][4 * q + e] : acc[i][j][4 * q + e] + bq[j][4 * q + e]);
             *reinterpret_cast<bf16x4*>(rowp + (wn * WTN + j * 32 + 8 * q + 4 * lh) * ES) = pk;
           }
       }
@@ -286,6 +291,22 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
 #pragma unroll
       for (int k = 0; k < NPASS; ++k)
         vb[k] = *reinterpret_cast<const Vec16<T>*>(sC + (tid / CPR + k * RPP) * RSC + cc * 16);
+      Vec16<T> yb[NPASS];
+      float bsc[VEC], bsh[VEC];   // (sum(dz * y) is accumulated here; mean / invstd enter once, in the row written at the end)
+      if constexpr (BNRED) {   // pre-activation values of this thread's pixels and the channel constants
+        const T* by = static_cast<const T*>(a.bn_y);
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+          const long long orow = out_row(tid / CPR + k * RPP, 0);
+          yb[k] = (orow >= 0 && cok) ? ld16(by + (size_t)orow * a.ld_bny + n0 + cc * VEC) : zero16<T>();
+        }
+        const int ch0 = cok ? n0 + cc * VEC : 0;
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+          *reinterpret_cast<f32x4*>(&bsc[e]) = *reinterpret_cast<const f32x4*>(a.bn_scale + ch0 + e);
+          *reinterpret_cast<f32x4*>(&bsh[e]) = *reinterpret_cast<const f32x4*>(a.bn_shift + ch0 + e);
+        }
+      }
       if (a.res != nullptr) {   // y = (x W^T + b) + res, rounded as a separate add of the stored result would be
         const T* rg = static_cast<const T*>(a.res);
         Vec16<T> rb[NPASS];
@@ -304,11 +325,21 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
         const long long orow = out_row(tid / CPR + k * RPP, ab);
         if (orow >= 0 && cok) {
           st16(yg + (size_t)orow * a.ldy + co0 + cc * VEC, vb[k]);
+          if constexpr (BNRED) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float yv = (float)yb[k].v[e];
+              const float dz = fmaf(yv, bsc[e], bsh[e]) > 0.f ? (float)vb[k].v[e] : 0.f;
+              sq1[e] += dz;
+              sq2[e] += dz * yv;
+            }
+          } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const float fv = (float)vb[k].v[e];
             sq1[e] += fv;
             sq2[e] += fv * fv;
+          }
           }
         }
       }
@@ -353,6 +384,13 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
         const int cc = ch / VEC, e = ch - cc * VEC;
         float t = 0.f;
         for (int k = cc; k < 512; k += CPR) t += red[k * 2 * VEC + which * VEC + e];
+        if constexpr (BNRED) {   // sum(dz * xhat) = invstd * (sum(dz * y) - mean * sum(dz))
+          if (which == 1 && n0 + ch < a.Nout) {
+            float t0 = 0.f;
+            for (int k = cc; k < 512; k += CPR) t0 += red[k * 2 * VEC + e];
+            t = a.bn_invstd[n0 + ch] * (t - a.bn_mean[n0 + ch] * t0);
+          }
+        }
         if (n0 + ch < a.Nout) a.stats[((size_t)blockIdx.x * 2 + which) * a.Nout + n0 + ch] = t;
       }
     }
@@ -437,6 +475,16 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
 template <typename T>
 static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
   dim3 grid(p.grid_m, p.tiles_n), block(512);
+  if constexpr (sizeof(T) == 2) {
+    if (a.bn_y != nullptr) {
+      if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3, true>), grid, block, 0, s, a);
+      else if (p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 2, true>), grid, block, 0, s, a);
+      else if (p.bm == 128) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 4, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 256, 3, true>), grid, block, 0, s, a);
+      UZ_LAUNCH_CHECK("uz_conv_igemm_bnred(gemm_dma)");
+      return UZ_OK;
+    }
+  }
   if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3>), grid, block, 0, s, a);
   else if (p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 2>), grid, block, 0, s, a);
   else if (p.bm == 128) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 4>), grid, block, 0, s, a);
@@ -446,9 +494,18 @@ static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
 }
 
 int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
-                       const float* bias, void* y, float* stats, hipStream_t s, const void* res, int ldres) {
+                       const float* bias, void* y, float* stats, hipStream_t s, const void* res, int ldres,
+                       const UzBnRed* br) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   GArgs a;
+  a.bn_y = br ? br->y : nullptr;
+  a.bn_scale = br ? br->scale : nullptr;
+  a.bn_shift = br ? br->shift : nullptr;
+  a.bn_mean = br ? br->mean : nullptr;
+  a.bn_invstd = br ? br->invstd : nullptr;
+  a.ld_bny = br ? br->ldy : 0;
+  if (br) UZ_REQUIRE(d->dtype == UZ_BF16 && d->store_mode == UZ_STORE_PLAIN && stats != nullptr && res == nullptr,
+                     "uz_conv_igemm_bnred: bf16 LDS-DMA GEMMs with a plain store only");
   a.x = x;
   a.w = w;
   a.y = y;

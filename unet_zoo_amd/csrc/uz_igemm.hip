@@ -514,7 +514,10 @@ extern "C" int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const voi
 
 extern "C" int uz_conv_igemm_bnred_supported(const uz_conv_desc* d) {
   UzDirectPlan dp;
-  return (d != nullptr && d->dtype == UZ_BF16 && uz_direct_plan(d, &dp) && dp.bres != 2) ? 1 : 0;
+  UzGemmPlan gp;
+  if (d == nullptr || d->dtype != UZ_BF16) return 0;
+  if (uz_direct_plan(d, &dp)) return dp.bres != 2 ? 1 : 0;
+  return (d->store_mode == UZ_STORE_PLAIN && uz_gemm_dma_plan(d, &gp)) ? 1 : 0;
 }
 
 extern "C" int uz_conv_igemm_bnred(const uz_conv_desc* d, const void* x, const void* w_packed, void* y,
@@ -529,13 +532,17 @@ extern "C" int uz_conv_igemm_bnred(const uz_conv_desc* d, const void* x, const v
                  ((uintptr_t)bn_y & 15) == 0, "uz_conv_igemm_bnred: x / w / y / bn_y must be 16-byte aligned");
   UZ_REQUIRE(ld_bny >= d->Nout && ld_bny % 8 == 0, "uz_conv_igemm_bnred: bad ld_bny %d", ld_bny);
   UzDirectPlan dp;
-  if (!uz_conv_igemm_bnred_supported(d) || !uz_direct_plan(d, &dp)) {
-    uz_set_error("uz_conv_igemm_bnred: only bf16 problems of the direct 3x3 kernels with the LDS-staged epilogue "
-                 "(ask uz_conv_igemm_bnred_supported)");
+  UzGemmPlan gp;
+  if (!uz_conv_igemm_bnred_supported(d)) {
+    uz_set_error("uz_conv_igemm_bnred: only bf16 problems of the direct 3x3 kernels with the LDS-staged epilogue and of "
+                 "the LDS-DMA GEMM with a plain store (ask uz_conv_igemm_bnred_supported)");
     return UZ_ENOTIMPL;
   }
   const UzBnRed br = {bn_y, ld_bny, scale, shift, mean, invstd};
-  return uz_direct_launch(d, dp, x, w_packed, nullptr, y, partial, static_cast<hipStream_t>(stream), &br);
+  if (uz_direct_plan(d, &dp))
+    return uz_direct_launch(d, dp, x, w_packed, nullptr, y, partial, static_cast<hipStream_t>(stream), &br);
+  UZ_REQUIRE(uz_gemm_dma_plan(d, &gp), "uz_conv_igemm_bnred: no plan");
+  return uz_gemm_dma_launch(d, gp, x, w_packed, nullptr, y, partial, static_cast<hipStream_t>(stream), nullptr, 0, &br);
 }
 
 extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed,

@@ -143,6 +143,12 @@ def _window_core_torch(qkv, tau, w1, b1, w2, b2, rel_index, heads: int, ws: int,
 
 
 class Engine:
+    # the BatchNorm-backward reduction of a sole-reader activation rides in the epilogue of the 3x3 input-gradient
+    # convolution / of the ConvTranspose input-gradient GEMM that produces its gradient (class-level so that
+    # tools/ab_step.py can time both ways in one process; no environment switch)
+    fuse_bn_reduce = True
+    fuse_bn_reduce_convt = True
+
     def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
                  grad_sink: Optional[Callable[[nn.Parameter, torch.Tensor], None]] = None,
                  pack_cache: Optional[PackCache] = None, grads_in_place: bool = False):
@@ -391,7 +397,7 @@ class Engine:
                         # per-channel sums of dx come for free from the kernel's statistics
                         # epilogue; a ConvTranspose2d feeding x takes its bias gradient from them
                         want = x.parts is not None
-                        src = getattr(x, "bn_src", None) if (sole_reader and not want) else None
+                        src = getattr(x, "bn_src", None) if (sole_reader and not want and self.fuse_bn_reduce) else None
                         part = ops.conv_igemm(dy, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx,
                                               ntaps=ntaps, dil=dil, want_stats=want, bnred=src)
                         if want:
@@ -677,9 +683,11 @@ class Engine:
             self._heads.append((bwd, 1))
         return logits
 
-    def conv_transpose2x2(self, x: Act, m: nn.ConvTranspose2d, out: Act) -> Act:
+    def conv_transpose2x2(self, x: Act, m: nn.ConvTranspose2d, out: Act, sole_reader: bool = False) -> Act:
         """ConvTranspose2d(k=2, s=2) written straight into its slot of the concat buffer.
-        Reference: UpSample_UNet.up (common_layers.py:104,108)."""
+        Reference: UpSample_UNet.up (common_layers.py:104,108).  sole_reader: nothing else reads x (the output of the
+        decoder block / bottleneck below): the BatchNorm-backward reduction of the layer that produced x then rides in
+        the epilogue of this layer's input-gradient GEMM (see conv_bn_relu)."""
         assert m.kernel_size == (2, 2) and m.stride == (2, 2) and m.in_channels == x.C
         Co = m.out_channels
         # an odd skip size leaves one row / column that the reference fills with F.pad zeros
@@ -703,8 +711,11 @@ class Engine:
                                                     taps_mode=L.TAPS_GATHER2X2, out=self._dst(m.weight)))
                 if x.needs_grad:
                     dx = self.new_act(x.N, x.H, x.W, x.C)
-                    ops.conv_igemm(g, self._pack(m.weight, L.PACK_CONVT_DGRAD), None, dx, ntaps=4,
-                                   taps_mode=L.TAPS_GATHER2X2)
+                    src = getattr(x, "bn_src", None) if (sole_reader and self.fuse_bn_reduce_convt) else None
+                    part = ops.conv_igemm(g, self._pack(m.weight, L.PACK_CONVT_DGRAD), None, dx, ntaps=4,
+                                          taps_mode=L.TAPS_GATHER2X2, bnred=src)
+                    if src is not None and part is not None:
+                        dx.bn_partials = part
                     x.add_grad(dx)
 
             self.tape.append(bwd)

@@ -61,7 +61,7 @@ class UpSample_UNet(nn.Module):
     def emit(self, eng: Engine, x: Act, cat_full: Act, up_slot: Act) -> Act:
         # odd skip sizes: the transposed convolution lands top-left, the remaining row / column is the
         # reference's F.pad zeros (common_layers.py:110-113); handled inside conv_transpose2x2
-        eng.conv_transpose2x2(x, self.up, up_slot)
+        eng.conv_transpose2x2(x, self.up, up_slot, sole_reader=True)
         act, _ = self.conv.emit(eng, cat_full)
         return act
 
