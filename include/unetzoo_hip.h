@@ -261,6 +261,14 @@ long long uz_outconv_bwd_workspace_bytes(int dtype, int N, int HW, int C, int Ko
 int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w, int Kout,
                    const float* g_nchw, void* dx, int lddx, float* dw, float* db, void* workspace,
                    void* stream);
+/* uz_outconv_bwd with the first pass of a BatchNorm backward in the same pass over the pixels (bf16): x = relu(bn(bn_y))
+ * feeds only this head, so the gradient dx it writes is the whole gradient of that activation; bn_partial receives
+ * [uz_outconv_bwd_rows()][2][C] partial rows for uz_bn_bwd_finalize() (see uz_conv_igemm_bnred). */
+int uz_outconv_bwd_rows(int dtype, int N, int HW, int C);
+int uz_outconv_bwd_bnred(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w, int Kout,
+                         const float* g_nchw, void* dx, int lddx, float* dw, float* db, void* workspace,
+                         const void* bn_y, int ld_bny, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, float* bn_partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Additive attention gate (AttentionBlock.forward, attention_unet.py:34-40), everything except the

@@ -392,3 +392,36 @@ def test_bn_backward_reduction_in_the_conv_transpose_input_gradient(N, H, W, Cin
         out.append((sums.clone(), dx.dense().float(), dgb.clone()))
     assert relerr(out[1][0], out[0][0]) < 2e-5 and relerr(out[1][2], out[0][2]) < 2e-5
     assert relerr(out[1][1], out[0][1]) < 1e-2
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 24, 40, 64, 1), (1, 17, 9, 128, 3)])
+def test_bn_backward_reduction_in_the_head_gradient(N, H, W, C, K):
+    """uz_outconv_bwd_bnred: the 1x1 head's input gradient (common_layers.py:125) and the BatchNorm-backward sums of the
+    block that feeds it in one pass"""
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(13)
+    y = act_from_nchw(rnd(dt, torch.randn(N, C, H, W, generator=gen) * 2 + 0.3).to(DEV), dt)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=gen) * 0.2).to(DEV)
+    yd = y.dense().double()
+    stats = torch.stack([yd.sum((0, 2, 3)), (yd ** 2).sum((0, 2, 3))]).float().reshape(1, 2, C)
+    vec = ops.bn_finalize(stats, N * H * W, gamma, beta, 1e-5, 0.1, torch.zeros(C, device=DEV), torch.ones(C, device=DEV))
+    act = ops.new_act(N, H, W, C, dt, DEV)
+    ops.bn_relu_apply(y, vec[0], vec[1], act, None)
+    w = (torch.randn(K, C, generator=gen) * 0.2).to(DEV)
+    g = torch.randn(N, K, H, W, generator=gen).to(DEV)
+    dx0 = ops.new_act(N, H, W, C, dt, DEV)
+    dw0, db0 = ops.outconv_bwd(act, w, g, dx0)
+    dx1 = ops.new_act(N, H, W, C, dt, DEV)
+    dw1, db1 = ops.outconv_bwd(act, w, g, dx1, bnred=(y, vec))
+    assert torch.equal(dx0.dense(), dx1.dense()) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    part = dx1.bn_partials
+    out = []
+    for partials in (None, part):
+        sums = torch.zeros(2, C, dtype=torch.float64, device=DEV)
+        d = ops.new_act(N, H, W, C, dt, DEV)
+        dgb = torch.empty(2, C, device=DEV)
+        ops.bn_relu_bwd(y, vec, dx1, None, None, sums, d, dgb[0], dgb[1], partials=partials)
+        out.append((sums.clone(), d.dense().float(), dgb.clone()))
+    assert relerr(out[1][0], out[0][0]) < 2e-5 and relerr(out[1][2], out[0][2]) < 2e-5
+    assert relerr(out[1][1], out[0][1]) < 1e-2

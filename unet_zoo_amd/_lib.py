@@ -27,7 +27,8 @@ EXPORTS = (
     "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_conv_igemm_grid_m", "uz_conv_igemm",
     "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
-    "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_colsum",
+    "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_outconv_bwd_rows", "uz_outconv_bwd_bnred",
+    "uz_colsum",
     "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd", "uz_attn_bwd_psi", "uz_attn_bwd_reduce",
     "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum_rows_f32", "uz_sum2x2",
     "uz_bn_relu_add_apply", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_resize_bilinear_fwd", "uz_resize_bilinear_bwd", "uz_resample2",
@@ -178,6 +179,8 @@ def load():
     lib.uz_outconv_fwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
     lib.uz_outconv_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]
     lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp, vp]
+    lib.uz_outconv_bwd_rows.argtypes = [ip, ip, ip, ip]
+    lib.uz_outconv_bwd_bnred.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp, vp, ip, vp, vp, vp, vp, vp, vp]
     lib.uz_colsum.argtypes = [ip, vp, ip, ip, ip, vp, vp]
     lib.uz_colsum_workspace_bytes.argtypes = [ip, ip, ip]
     lib.uz_colsum_ws.argtypes = [ip, vp, ip, ip, ip, vp, vp, vp]

@@ -451,12 +451,17 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T, int KOUT>
+// BNRED: x = relu(bn(bn_y)) has no other reader: the two sums of that BatchNorm's backward over this workgroup's pixels
+// (of dz = dx * [scale * bn_y + shift > 0], dx as stored) go to bnpart[blockIdx.x][2][C] (uz_outconv_bwd_bnred)
+template <typename T, int KOUT, bool BNRED = false>
 __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ x, int ldx, int N,
                                                           int HW, int C, const float* __restrict__ w,
                                                           const float* __restrict__ g,
                                                           T* __restrict__ dx, int lddx,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, const T* __restrict__ bn_y = nullptr, int ld_bny = 0,
+                                                          const float* __restrict__ bn_scale = nullptr, const float* __restrict__ bn_shift = nullptr,
+                                                          const float* __restrict__ bn_mean = nullptr, const float* __restrict__ bn_invstd = nullptr,
+                                                          float* __restrict__ bnpart = nullptr) {
   // partial[blockIdx.x][k][C + 1]: per-workgroup sums of g*x (C values) and g (1 value); a second
   // kernel adds the rows (float atomics onto the 65 hot addresses serialised: 425 us -> this form)
   constexpr int VEC = ElemTraits<T>::VEC;
@@ -477,8 +482,20 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
       aw[k][i] = 0.f;
     }
   }
+  float bsc[VEC], bsh[VEC], bmu[VEC], bis[VEC], S0[VEC], S1[VEC];
+  if constexpr (BNRED) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int ch = live ? sub * VEC + i : 0;
+      bsc[i] = bn_scale[ch];
+      bsh[i] = bn_shift[ch];
+      bmu[i] = bn_mean[ch];
+      bis[i] = bn_invstd[ch];
+      S0[i] = S1[i] = 0.f;
+    }
+  }
   for (int p0 = blockIdx.x * ppb * UNR; p0 < P; p0 += gridDim.x * ppb * UNR) {
-    float v[UNR][VEC], gk[UNR][KOUT];
+    float v[UNR][VEC], gk[UNR][KOUT], yv[UNR][VEC];
     int pp[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {   // all loads first: UNR pixels in flight
@@ -487,6 +504,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
       if (pp[u] >= 0) {
         if (live) {
           load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
+          if constexpr (BNRED) load_f(bn_y + (size_t)p * ld_bny + sub * VEC, yv[u]);
         } else {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
@@ -517,6 +535,35 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
         }
       }
       if (dx != nullptr && pp[u] >= 0 && live) store_f(dx + (size_t)pp[u] * lddx + sub * VEC, d);
+      if constexpr (BNRED) {
+        if (pp[u] >= 0 && live) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const float dz = fmaf(yv[u][i], bsc[i], bsh[i]) > 0.f ? (float)(T)d[i] : 0.f;   // the gradient as stored
+            S0[i] += dz;
+            S1[i] += dz * ((yv[u][i] - bmu[i]) * bis[i]);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (BNRED) {   // block reduction over the pixel lanes, one partial row per workgroup (deterministic)
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) red[threadIdx.x * 9 + i] = which ? S1[i] : S0[i];
+      __syncthreads();
+      if (pl == 0 && live) {
+        float t[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) t[i] = 0.f;
+        for (int r = 0; r < ppb; ++r)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) t[i] += red[(r * LPP + sub) * 9 + i];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) bnpart[((size_t)blockIdx.x * 2 + which) * C + sub * VEC + i] = t[i];
+      }
     }
   }
   // block reduction over the ppb pixel lanes that share `sub`
@@ -1149,6 +1196,36 @@ extern "C" long long uz_outconv_bwd_workspace_bytes(int dtype, int N, int HW, in
   UZ_REQUIRE(N > 0 && HW > 0 && Kout >= 1 && Kout <= OUTCONV_MAXK && C % vec == 0 && C / vec <= 64,
              "uz_outconv_bwd_workspace_bytes: bad shape");
   return (long long)outconv_bwd_grid(dtype, N, HW, C) * Kout * (C + 1) * (long long)sizeof(float);
+}
+
+extern "C" int uz_outconv_bwd_rows(int dtype, int N, int HW, int C) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_outconv_bwd_rows: bad dtype");
+  return outconv_bwd_grid(dtype, N, HW, C);
+}
+
+extern "C" int uz_outconv_bwd_bnred(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,
+                                    int Kout, const float* g_nchw, void* dx, int lddx, float* dw, float* db,
+                                    void* workspace, const void* bn_y, int ld_bny, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, float* bn_partial,
+                                    void* stream) {
+  UZ_REQUIRE(dtype == UZ_BF16, "uz_outconv_bwd_bnred: bf16 only");
+  UZ_REQUIRE(x && w && g_nchw && dw && db && workspace && dx && bn_y && scale && shift && mean && invstd && bn_partial,
+             "uz_outconv_bwd_bnred: null pointer");
+  UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_bwd_bnred: Kout=%d", Kout);
+  UZ_REQUIRE(C % 8 == 0 && C / 8 <= 64, "uz_outconv_bwd_bnred: C=%d unsupported", C);
+  UZ_REQUIRE(ldx % 8 == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C && ld_bny % 8 == 0 && ld_bny >= C && N > 0 && HW > 0 &&
+                 (long long)N * HW < (1LL << 31), "uz_outconv_bwd_bnred: bad shape");
+  const int g = outconv_bwd_grid(dtype, N, HW, C);
+  float* part = static_cast<float*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT, true>), dim3((unsigned)g), dim3(256), 0, s,
+                                          (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, part,
+                                          (const bf16_t*)bn_y, ld_bny, scale, shift, mean, invstd, bn_partial))
+  UZ_LAUNCH_CHECK("uz_outconv_bwd_bnred");
+  const int ne = Kout * (C + 1);
+  hipLaunchKernelGGL(outconv_bwd_finalize_kernel, dim3(uz_cdiv(ne, 32)), dim3(1024), 0, s, part, g, Kout, C, dw, db);
+  UZ_LAUNCH_CHECK("uz_outconv_bwd_bnred(finalize)");
+  return UZ_OK;
 }
 
 extern "C" int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,

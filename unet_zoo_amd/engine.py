@@ -1501,8 +1501,9 @@ class Engine:
             self._heads.append((bwd, len(outs)))
         return outs
 
-    def out_conv(self, x: Act, conv: nn.Conv2d) -> torch.Tensor:
-        """1x1 convolution to the logits, (N, K, H, W) fp32.  Reference: OutConv (common_layers.py:125)."""
+    def out_conv(self, x: Act, conv: nn.Conv2d, sole_reader: bool = False) -> torch.Tensor:
+        """1x1 convolution to the logits, (N, K, H, W) fp32.  Reference: OutConv (common_layers.py:125).  sole_reader: as
+        in conv_bn_relu (the last decoder block's output feeds only the head)."""
         assert conv.kernel_size == (1, 1) and conv.in_channels == x.C
         K = conv.out_channels
         w = conv.weight.detach().reshape(K, x.C)
@@ -1513,8 +1514,9 @@ class Engine:
                 dx = self.new_act(x.N, x.H, x.W, x.C) if x.needs_grad else None
                 dwt = self._dst(conv.weight)
                 dbt = self._dst(conv.bias) if conv.bias is not None else None
+                src = getattr(x, "bn_src", None) if (sole_reader and self.fuse_bn_reduce_convt) else None
                 dw, db = ops.outconv_bwd(x, w, g_logits.contiguous().float(), dx,
-                                         dwt.view(K, x.C) if dwt is not None else None, dbt)
+                                         dwt.view(K, x.C) if dwt is not None else None, dbt, bnred=src)
                 self._give_grad(conv.weight, dwt if dwt is not None else dw.reshape(conv.weight.shape))
                 if conv.bias is not None:
                     self._give_grad(conv.bias, db)

@@ -115,4 +115,4 @@ class AttentionUNet(HipModule):
             d = up.emit(eng, cur, up_slot)
             att.emit(eng, d, skip, gated_slot)
             cur, _ = conv.emit(eng, full)
-        return (eng.out_conv(cur, self.conv_1x1),)
+        return (eng.out_conv(cur, self.conv_1x1, sole_reader=True),)

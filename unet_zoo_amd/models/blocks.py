@@ -74,4 +74,4 @@ class OutConv(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
 
     def emit(self, eng: Engine, x: Act):
-        return eng.out_conv(x, self.conv)
+        return eng.out_conv(x, self.conv, sole_reader=True)   # every model that uses this head feeds it from its last decoder block only

@@ -431,7 +431,10 @@ def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act],
-                dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None):
+                dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
+                bnred: Optional[tuple] = None):
+    """bnred = (bn_y, vec): x = relu(bn(bn_y)) is read by this head only; the BatchNorm-backward sums of dx are taken in
+    the same pass (uz_outconv_bwd_bnred) and their partial rows left in dx.bn_partials (bf16 only; else ignored)"""
     lib = L.load()
     K = w.shape[0]
     assert g.dtype == torch.float32 and g.is_contiguous() and g.shape == (x.N, K, x.H, x.W)
@@ -444,6 +447,16 @@ def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act],
     wsb = L.check_count(lib.uz_outconv_bwd_workspace_bytes(code, x.N, x.H * x.W, x.C, K),
                         "uz_outconv_bwd_workspace_bytes")
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    if bnred is not None and dx is not None and x.dtype == torch.bfloat16 and (bnred[0].P, bnred[0].C) == (x.P, x.C):
+        bn_y, vec4 = bnred
+        rows = L.check_count(lib.uz_outconv_bwd_rows(code, x.N, x.H * x.W, x.C), "uz_outconv_bwd_rows")
+        part = torch.empty((rows, 2, x.C), dtype=torch.float32, device=dev)
+        L.check(lib.uz_outconv_bwd_bnred(code, x.ptr(), x.ld, x.N, x.H * x.W, x.C, w.data_ptr(), K, g.data_ptr(),
+                                         dx.ptr(), dx.ld, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), bn_y.ptr(), bn_y.ld,
+                                         vec4[0].data_ptr(), vec4[1].data_ptr(), vec4[2].data_ptr(), vec4[3].data_ptr(),
+                                         part.data_ptr(), L.stream_ptr()), "uz_outconv_bwd_bnred")
+        dx.bn_partials = part
+        return dw.view(K, x.C), db
     L.check(lib.uz_outconv_bwd(code, x.ptr(), x.ld, x.N, x.H * x.W, x.C, w.data_ptr(), K, g.data_ptr(),
                                dx.ptr() if dx is not None else None,
                                dx.ld if dx is not None else 0, dw.data_ptr(), db.data_ptr(),
