@@ -1350,7 +1350,10 @@ extern "C" int uz_pack_weights(int dtype, int mode, const float* w, int Co, int 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_conv3x3_tiled_kernel(const uz_pack3x3_item* __restrict__ items,
                                                                  int n, int total_tiles) {
-  __shared__ float tile[9][32][33];
+  // [tap][co][ci] with rows of 33 and tap planes of 32 * 33 + 4 floats: the staging writes walk tap fastest, and a plane
+  // stride that is a multiple of 32 banks put the nine taps of one (co, ci) on ONE bank (9-way conflict on every write)
+  constexpr int TP = 32 * 33 + 4;
+  __shared__ float tile[9 * TP];
   for (int gt = blockIdx.x; gt < total_tiles; gt += gridDim.x) {
     int lo = 0, hi = n - 1;  // item that owns global tile gt (tile_begin is a prefix sum)
     while (lo < hi) {
@@ -1364,18 +1367,41 @@ __global__ __launch_bounds__(256) void pack_conv3x3_tiled_kernel(const uz_pack3x
     T* __restrict__ dd = static_cast<T*>(it.dst_dgrad);
     const int co0 = (tl / tiles_ci) * 32, ci0 = (tl % tiles_ci) * 32;
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+    // all 36 loads of a thread are requested before the first LDS write: as a rolled loop every pass waited for its own
+    // memory round trip (36 in a row: the kernel ran at 102 us for 124 MB)
+    float stage[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      const int co_l = e / 288, r = e - co_l * 288;
+      stage[i] = it.src[((size_t)(co0 + co_l) * it.Ci + ci0) * 9 + r];
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      const int e = threadIdx.x + 256 * i;
       const int co_l = e / 288, r = e - co_l * 288;
       const int ci_l = r / 9, tap = r - ci_l * 9;
-      tile[tap][co_l][ci_l] = it.src[((size_t)(co0 + co_l) * it.Ci + ci0) * 9 + r];
+      tile[tap * TP + co_l * 33 + ci_l] = stage[i];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 9 * 1024; e += 256) {
-      const int x = e & 31, y = (e >> 5) & 31, tap = e >> 10;
-      if (df != nullptr)  // x = ci, y = co
-        df[(size_t)(co0 + y) * 9 * it.Ci + tap * it.Ci + ci0 + x] = (T)tile[tap][y][x];
-      if (dd != nullptr)  // x = co, y = ci
-        dd[(size_t)(ci0 + y) * 9 * it.Co + (8 - tap) * it.Co + co0 + x] = (T)tile[tap][x][y];
+    // sixteen-byte stores (bf16: 8 values, fp32: 4): piece = (row, part) with row = (y, tap), 32 / VEC parts per row.
+    // (Two-byte stores, one value per lane, ran this kernel at 2.4 TB/s.)
+    constexpr int VEC = ElemTraits<T>::VEC, PPR = 32 / VEC;
+    for (int e = threadIdx.x; e < 9 * 32 * PPR; e += 256) {
+      const int part = e % PPR, row = e / PPR;
+      const int y = row & 31, tap = row >> 5;
+      if (df != nullptr) {  // y = co, the part's values run over ci
+        Vec16<T> v;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v.v[k] = (T)tile[tap * TP + y * 33 + part * VEC + k];
+        st16(df + (size_t)(co0 + y) * 9 * it.Ci + tap * it.Ci + ci0 + part * VEC, v);
+      }
+      if (dd != nullptr) {  // y = ci, the part's values run over co
+        Vec16<T> v;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v.v[k] = (T)tile[tap * TP + (part * VEC + k) * 33 + y];
+        st16(dd + (size_t)(ci0 + y) * 9 * it.Co + (8 - tap) * it.Co + co0 + part * VEC, v);
+      }
     }
   }
 }
