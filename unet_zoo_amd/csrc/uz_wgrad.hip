@@ -238,7 +238,18 @@ __global__ __launch_bounds__(64 * ZG) void wgrad_reduce_kernel(const float* __re
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = 0.f;
   if (e < CiCj) {
-    for (int z = zg; z < split; z += ZG) {
+    // two splits' loads in flight per pass (same summation order): a pass is one memory round trip
+    int z = zg;
+    for (; z + ZG < split; z += 2 * ZG) {
+      float a0[NT], a1[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a0[t] = slab[((size_t)z * NT + t) * CiCj + e];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a1[t] = slab[((size_t)(z + ZG) * NT + t) * CiCj + e];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = (acc[t] + a0[t]) + a1[t];
+    }
+    if (z < split) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] += slab[((size_t)z * NT + t) * CiCj + e];
     }
