@@ -425,3 +425,28 @@ def test_bn_backward_reduction_in_the_head_gradient(N, H, W, C, K):
         out.append((sums.clone(), d.dense().float(), dgb.clone()))
     assert relerr(out[1][0], out[0][0]) < 2e-5 and relerr(out[1][2], out[0][2]) < 2e-5
     assert relerr(out[1][1], out[0][1]) < 1e-2
+
+
+def test_conv3x3_padding_of_a_tensor_beyond_256_mib():
+    """zero padding is produced by out-of-range buffer offsets: the sentinel offset must lie beyond the END of the tensor
+    for every size the plan accepts (< 2 GiB), not just beyond 256 MiB (found in round 2: the first level of
+    attention_unet at B = 16, 512 x 512 is 537 MB)"""
+    dt = torch.bfloat16
+    N, H, W, Cin, Cout = 1, 1040, 1040, 128, 8          # 277 MB input
+    gen = torch.Generator().manual_seed(14)
+    x = rnd(dt, torch.randn(N, Cin, H, W, generator=gen))
+    w = rnd(dt, torch.randn(Cout, Cin, 3, 3, generator=gen) * 0.05)
+    xa = act_from_nchw(x.to(DEV), dt)
+    assert xa.buf.numel() * 2 > (1 << 28)
+    ya = ops.new_act(N, H, W, Cout, dt, DEV)
+    ops.conv_igemm(xa, ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt), None, ya, ntaps=9)
+    got = ya.dense().float().cpu()
+    # the image border (where the padding enters) and an interior band, against F.conv2d on the same rounded operands
+    ref_top = F.conv2d(x[:, :, :3, :], w, padding=(1, 1))[:, :, :2, :]
+    assert relerr(got[:, :, :2, :], ref_top) < tol(dt)
+    ref_bot = F.conv2d(x[:, :, -3:, :], w, padding=(1, 1))[:, :, -2:, :]
+    assert relerr(got[:, :, -2:, :], ref_bot) < tol(dt)
+    ref_left = F.conv2d(x[:, :, 500:540, :3], w, padding=(0, 1))[:, :, :, :2]
+    assert relerr(got[:, :, 501:539, :2], ref_left) < tol(dt)
+    ref_right = F.conv2d(x[:, :, 500:540, -3:], w, padding=(0, 1))[:, :, :, -2:]
+    assert relerr(got[:, :, 501:539, -2:], ref_right) < tol(dt)

@@ -74,7 +74,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr unsigned OOB = 0x10000000u;  // beyond any descriptor's num_records (tensors < 2 GiB)
+constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor's num_records (tensors < 2 GiB; it was 2^28 until round 2: inside every tensor of 256 MiB or more, whose zero padding then read real pixels -- tests/test_ops_gpu.py::test_conv3x3_padding_of_a_tensor_beyond_256_mib)
 #ifndef UZ_CONV_SKEL
 #define UZ_CONV_SKEL 0   // measurement builds (-DUZ_CONV_SKEL=bits): 1 no fragment reads, 2 no MFMAs, 4 no DMA past the first double-step, 8 no epilogue
 #endif
