@@ -30,6 +30,7 @@ struct DirectArgs {
   const float* bias;
   float* stats;
   unsigned xbytes, wbytes;
+  unsigned ybytes;   // size of y when < 2 GiB (buffer stores with a counted wait, see the streaming epilogue), else 0
   int N, H, W, Cin, ldx, Nout, ldy, K;
   int th_n, tw_n, ntiles;
   int flags;  // tuning/ablation switches (env UZ_TUNE, tools/kbench.py); 0 in production
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
   T* __restrict__ yg = static_cast<T*>(a.y);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
 
   // ---- DMA pieces --------------------------------------------------------------------------
   // A piece p = wave + 8 i covers patch rows 8p .. 8p+7; this lane: row 8p + (lane>>3), physical
@@ -191,64 +193,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
   };
 
   f32x16 acc[2][TN];
-  // One (tap, slab) step.  (Measured and rejected: placing the step's LDS-DMA pieces between the
-  // K-chunks, staggered between the two waves of a SIMD, instead of at the head of the step: 13-15 %
-  // slower on every non-resident layer.)
-  auto compute = [&](int tap, int abuf, int bslot) {
-    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;  // tap in 0..8
-    const char* sA = smem + abuf * A_BYTES;
-    const char* sBs = sB + bslot * B_STAGE;
-    int arow[2], asw[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int prow = (f_pi[i] + ty) * PW + f_pj + tx;
-      arow[i] = prow * 128;
-      asw[i] = (prow >> 1) & 7;
-    }
-    if (UZ_KFLAGS(a) & 0x300) {  // ablations (tools/kbench.py): 0x100 LDS reads without MFMAs, 0x200 MFMAs without LDS reads
-      if (UZ_KFLAGS(a) & 0x100) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int lc = 2 * q + lh;
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(sA + arow[i] + ((lc ^ asw[i]) << 4));
-            asm volatile("" ::"v"(*reinterpret_cast<f32x4*>(&t)));
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(sBs + b_frag_off[j] + ((lc ^ b_sw[j]) << 4));
-            asm volatile("" ::"v"(*reinterpret_cast<f32x4*>(&t)));
-          }
-        }
-      } else {
-        Vec16<T> z = zero16<T>();
-        asm volatile("" : "+v"(*reinterpret_cast<f32x4*>(&z)));
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) Mma2<T>::run(z, z, acc[i][j]);
-      }
-      return;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int lc = 2 * q + lh;
-      Vec16<T> af[2], bf[TN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const Vec16<T>*>(sA + arow[i] + ((lc ^ asw[i]) << 4));
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const Vec16<T>*>(sBs + b_frag_off[j] + ((lc ^ b_sw[j]) << 4));
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Mma2<T>::run(af[i], bf[j], acc[i][j]);
-    }
-  };
-
   // ---- the double-step as one read pipeline (streaming path) ----------------------------------------------
   // chunk g = 0 .. 7 of the double-step = K-chunk g & 3 of unit g >> 2; set g & 1 of the fragment registers.
   typedef __attribute__((address_space(3))) char* lds_char_ptr;
@@ -389,6 +333,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
   for (int e = 0; e < VEC; ++e) sq1[e] = sq2[e] = 0.f;
 
   int it = 0;
+  int par = 0, dpar = 0;   // streaming path: halo buffer of slab 0 / slot pair of double-step 0 of the current tile
+  bool pre = false;        // ... whose first patch and weight pair the previous tile has already requested
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, ++it) {
     decode(tile, img, h0, w0);
 #pragma unroll
@@ -398,7 +344,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int cbuf;  // A buffer that holds the C staging area afterwards
+    int cbuf;       // A buffer that holds the C staging area afterwards
+    int cpair = 0;  // streaming path: slot pair that holds the staging rows the A buffer has no room for
     if constexpr (BRES) {
       // this tile's patch (and the weights) were waited for before the previous epilogue's stores
       // were issued, so those stores may still be in flight here: only the barrier is needed
@@ -414,123 +361,102 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       wait_vmcnt<0>();  // next tile's patch has landed (it had the whole tap loop to arrive)
       cbuf = it & 1;
     } else {
+      // ---- streaming path: the (slab, tap) units of ALL tiles of this workgroup form one stream ----------------------
+      // Two units per barrier: weight tiles in two slot pairs, the pair for double-step d + 1 issued during d; halo
+      // pieces of the next slab (<= 2 per double-step) issued AFTER the weight tiles so that the counted wait at the next
+      // barrier may leave them in flight.  During a tile's LAST slab the pieces are those of the NEXT tile's first slab,
+      // and its last double-step issues the next tile's first weight pair: the next tile starts without a DMA round
+      // trip (2.5-3.4 us per tile).  `par` / `dpar`: which halo buffer holds slab 0 and which slot pair holds
+      // double-step 0 of the current tile; the epilogue stages C in the halo buffer and the slot pair that the last slab
+      // / double-step have just released (the other ones hold the prefetch).
       const int nsteps = ncb * 9;
-      __builtin_amdgcn_s_barrier();  // previous tile (its C staging reads) is finished everywhere
+      const int ndbl = (nsteps + 1) >> 1;
+      constexpr int NSTORE = 256 * (BN * ES / 16) / 512;   // epilogue stores per wave (= NPASS there)
+      auto unit = [&](int L, int& c, int& t) {
+        c = L / 9;
+        t = L - 9 * c;
+      };
+      const int next = tile + gridDim.x;
+      const bool has_next = next < a.ntiles && !(UZ_CONV_SKEL & 32) && !(UZ_KFLAGS(a) & 0x4000);   // (0x4000: no cross-tile prefetch)
+      int nim = 0, nh0 = 0, nw0 = 0;
+      if (has_next) decode(next, nim, nh0, nw0);
+      int kprev = 0;       // halo pieces this wave issued after the last weight tile
+      if (!pre) {
+        __builtin_amdgcn_s_barrier();  // previous tile (its C staging reads) is finished everywhere
 #pragma unroll
-      for (int i = 0; i < APW; ++i) issue_a_piece(i, 0, 0, img, h0, w0);
-      if (!(UZ_KFLAGS(a) & 0x800)) {   // (0x800: the one-tap-per-barrier loop below, kept for A/B measurements)
-        // ---- two (slab, tap) units per barrier: weight tiles in two slots of two, the pair for
-        // double-step d + 1 issued during d; halo pieces of the next slab (<= 2 per double-step) are issued
-        // AFTER the weight tiles so that the counted wait at the next barrier may leave them in flight
-        auto unit = [&](int L, int& c, int& t) {
-          c = L / 9;
-          t = L - 9 * c;
-        };
-        const int ndbl = (nsteps + 1) >> 1;
-        {
-          int c, t;
-          unit(0, c, t);
-          issue_b(0, c, t);
-          if (nsteps > 1) {
-            unit(1, c, t);
-            issue_b(1, c, t);
-          }
-        }
-        int kprev = 0;       // halo pieces this wave issued after the last weight tile
-        int np = 0, npslab = 0;  // next halo piece of slab npslab + 1
+        for (int i = 0; i < APW; ++i) issue_a_piece(i, par, 0, img, h0, w0);
+        issue_b(dpar * 2, 0, 0);
+        if (nsteps > 1) issue_b(dpar * 2 + 1, 0, 1);
+      }
+      int np = 0, npslab = 0;  // next halo piece of slab npslab + 1
 #pragma unroll 1
-        for (int d = 0; d < ndbl; ++d) {
-          if (kprev == 0) wait_vmcnt<0>();
-          else if (kprev == 1) wait_vmcnt<1>();
-          else wait_vmcnt<2>();
-          __builtin_amdgcn_s_barrier();
-          const int L0 = 2 * d, L1 = L0 + 1;
-          int c0, t0, c1 = 0, t1 = 0;
-          unit(L0, c0, t0);
-          if (L1 < nsteps) unit(L1, c1, t1);
-          auto issue_next = [&]() {
-            if (UZ_CONV_SKEL & 4) return;   // measurement build: no DMA after the first double-step
-            if (d + 1 < ndbl) {  // weight tiles of the next double-step into the other slot pair
-              const int s2 = ((d + 1) & 1) * 2;
-              int c, t;
-              unit(L0 + 2, c, t);
-              issue_b(s2, c, t);
-              if (L0 + 3 < nsteps) {
-                unit(L0 + 3, c, t);
-                issue_b(s2 + 1, c, t);
+      for (int d = 0; d < ndbl; ++d) {
+        // (d == 0 of a prefetched tile: the previous epilogue's stores are younger than the prefetch -- wait for all)
+        if (d == 0 && pre && a.ybytes != 0 && sizeof(T) == 2 && !(UZ_KFLAGS(a) & 1)) wait_vmcnt<NSTORE>();
+        else if (kprev == 0 || d == 0) wait_vmcnt<0>();
+        else if (kprev == 1) wait_vmcnt<1>();
+        else wait_vmcnt<2>();
+        __builtin_amdgcn_s_barrier();
+        const int L0 = 2 * d, L1 = L0 + 1;
+        int c0, t0, c1 = 0, t1 = 0;
+        unit(L0, c0, t0);
+        if (L1 < nsteps) unit(L1, c1, t1);
+        auto issue_next = [&]() {
+          if (UZ_CONV_SKEL & 4) return;   // measurement build: no DMA after the first double-step
+          if (d + 1 < ndbl) {  // weight tiles of the next double-step into the other slot pair
+            const int s2 = ((d + 1 + dpar) & 1) * 2;
+            int c, t;
+            unit(L0 + 2, c, t);
+            issue_b(s2, c, t);
+            if (L0 + 3 < nsteps) {
+              unit(L0 + 3, c, t);
+              issue_b(s2 + 1, c, t);
+            }
+          } else if (has_next) {   // the next tile's first double-step
+            const int s2 = ((ndbl + dpar) & 1) * 2;
+            issue_b(s2, 0, 0);
+            if (nsteps > 1) issue_b(s2 + 1, 0, 1);
+          }
+          kprev = 0;
+          if (c0 != npslab) {
+            npslab = c0;
+            np = 0;
+          }
+          // both units of this double-step lie in slabs >= c0, so the halo buffer of slab c0 + 1 (last read by slab
+          // c0 - 1, or by the previous tile's epilogue) is free unless the second unit already belongs to slab c0 + 1
+          // (t0 == 8: nothing left to issue)
+          if (t0 < 8 && (c0 + 1 < ncb || has_next)) {
+            const bool nxt = c0 + 1 == ncb;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              if (np < APW) {
+                const bool did = nxt ? issue_a_piece(np, (ncb + par) & 1, 0, nim, nh0, nw0)
+                                     : issue_a_piece(np, (c0 + 1 + par) & 1, c0 + 1, img, h0, w0);
+                if (did) ++kprev;
+                ++np;
               }
-            }
-            kprev = 0;
-            if (c0 != npslab) {
-              npslab = c0;
-              np = 0;
-            }
-            // both units of this double-step lie in slabs >= c0, so buffer (c0 + 1) & 1 (last read by slab
-            // c0 - 1) is free unless the second unit already belongs to slab c0 + 1 (t0 == 8: nothing left to issue)
-            if (c0 + 1 < ncb && t0 < 8) {
-#pragma unroll
-              for (int k = 0; k < 2; ++k)
-                if (np < APW) {
-                  if (issue_a_piece(np, (c0 + 1) & 1, c0 + 1, img, h0, w0)) ++kprev;
-                  ++np;
-                }
-            }
-          };
-          const int s0 = (d & 1) * 2;
-          // the two waves of a SIMD (w, w + 4) run the same program in lockstep: with `late` the second one issues
-          // its LDS-DMA pieces AFTER its first unit, so one wave's issue runs beside the other's MFMAs
-          // (+2 ... 4.5 % on every non-resident layer; flag 0x10 of the ablation build switches it off)
-          const bool late = !(UZ_KFLAGS(a) & 0x10) && wave >= 4;
-          // (measured and rejected in round 2: the same read pipeline written with plain loads and the order pinned by
-          // scheduling barriers -- 5 ... 40 % slower on every layer than the compiler's own read -> wait -> MFMA groups)
-          const bool two = L1 < nsteps;
-          if (UZ_KFLAGS(a) & 0x300) {   // ablations of compute()
-            if (!late) issue_next();
-            compute(t0, c0 & 1, s0);
-            if (late) issue_next();
-            if (two) compute(t1, c1 & 1, s0 + 1);
-          } else {
-            const UnitAddr u0 = unit_addr(t0, c0 & 1, s0), u1 = unit_addr(t1, c1 & 1, s0 + 1);
-            if (!(UZ_CONV_SKEL & 16) || d == 0) read_unit(u0);   // (16: real fragments once per tile, then MFMAs only)
-            if (!late) issue_next();
-            mma_unit();
-            __builtin_amdgcn_sched_barrier(0);
-            if (two && !(UZ_CONV_SKEL & 16)) read_unit(u1);
-            if (late) issue_next();
-            if (two) mma_unit();
           }
-        }
-        cbuf = 0;
-      } else {
-      issue_b(0, 0, 0);
-      issue_b(1, 0, 1);
-      int tap = 0, cb = 0;    // (slab, tap) of step s
-      int tap2 = 2, cb2 = 0;  // ... of step s + 2
-#pragma unroll 1
-      for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) {
-          wait_vmcnt<NBP>();  // everything but the newest weight tile (step s+1) has landed
-        } else {
-          wait_vmcnt<0>();
-        }
-        if (!(UZ_KFLAGS(a) & 0x400)) __builtin_amdgcn_s_barrier();
-        // next slab's halo patch (one piece per step) BEFORE the weight tile of step s + 2: the
-        // counted wait above relies on the weight pieces being the youngest operations
-        // ablation bits: 0x40 no weight DMA, 0x80 no halo DMA after the first slab, 0x400 no barrier
-        if (tap < APW && cb + 1 < ncb && !(UZ_KFLAGS(a) & 0x80)) issue_a_piece(tap, (cb + 1) & 1, cb + 1, img, h0, w0);
-        if (s + 2 < nsteps && !(UZ_KFLAGS(a) & 0x40)) issue_b(tap2 % 3, cb2, tap2);
-        compute(tap, cb & 1, tap % 3);
-        if (++tap == 9) {
-          tap = 0;
-          ++cb;
-        }
-        if (++tap2 == 9) {
-          tap2 = 0;
-          ++cb2;
-        }
+        };
+        const int s0 = ((d + dpar) & 1) * 2;
+        // the two waves of a SIMD (w, w + 4) run the same program in lockstep: with `late` the second one issues
+        // its LDS-DMA pieces AFTER its first unit, so one wave's issue runs beside the other's MFMAs
+        // (+2 ... 4.5 % on every non-resident layer; flag 0x10 of the ablation build switches it off)
+        const bool late = !(UZ_KFLAGS(a) & 0x10) && wave >= 4;
+        const bool two = L1 < nsteps;
+        const UnitAddr u0 = unit_addr(t0, (c0 + par) & 1, s0), u1 = unit_addr(t1, (c1 + par) & 1, s0 + 1);
+        if (!(UZ_CONV_SKEL & 16) || d == 0) read_unit(u0);   // (16: real fragments once per tile, then MFMAs only)
+        if (!late) issue_next();
+        mma_unit();
+        __builtin_amdgcn_sched_barrier(0);
+        if (two && !(UZ_CONV_SKEL & 16)) read_unit(u1);
+        if (late) issue_next();
+        if (two) mma_unit();
       }
-      cbuf = 0;
-      }
+      cbuf = (ncb - 1 + par) & 1;            // halo buffer of the last slab: free for the C staging
+      cpair = (ndbl - 1 + dpar) & 1;         // slot pair of the last double-step: the staging's second segment
+      par = (ncb + par) & 1;
+      dpar = (ndbl + dpar) & 1;
+      pre = has_next;
     }
 
     // ---- epilogue: bias + statistics from registers ------------------------------------------
@@ -538,7 +464,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][0][3]));
     } else if constexpr (sizeof(T) == 2) {
       constexpr int RSC = BN * ES + 16;  // C staging row stride (bytes)
-      static_assert(256 * RSC <= A_BYTES * 2, "C staging must fit the A buffers");
       constexpr int CPR = BN * ES / 16;  // 16-byte chunks per pixel
       static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
       constexpr int NPASS = 256 * CPR / 512, RPP = 512 / CPR;
@@ -560,14 +485,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
         }
       }
       __builtin_amdgcn_s_barrier();  // every wave has finished reading A/B of this tile
-      char* sC = smem + ((BRES ? cbuf : 0) * A_BYTES);
-      if (BRES) static_assert(256 * (64 * 2 + 16) <= A_BYTES, "C staging must fit one A buffer");
+      // staging rows 0 .. R0 - 1 in halo buffer `cbuf`, the rest (BN = 128: 95 rows) in slot pair `cpair`
+      constexpr int R0 = (A_BYTES / RSC < 256) ? A_BYTES / RSC : 256;
+      static_assert(BRES ? R0 == 256 : (256 - R0) * RSC <= 2 * B_STAGE, "C staging must fit a halo buffer + a slot pair");
+      char* const sC0 = smem + cbuf * A_BYTES;
+      char* const sC1 = sB + cpair * 2 * B_STAGE - R0 * RSC;   // row r >= R0 at sC1 + r * RSC
+      auto stage_row = [&](int r) -> char* { return (R0 == 256 || r < R0 ? sC0 : sC1) + r * RSC; };
       // stage: lane = pixel (l31) of M tile mt, register quad q = 4 consecutive channels -> one
       // 8-byte LDS write (was: 64 two-byte writes per lane with sub-dword bank conflicts)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int mt = 2 * wm + i;
-        char* rowp = sC + (mt * 32 + l31) * RSC;
+        char* rowp = stage_row(mt * 32 + l31);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -602,7 +531,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
       Vec16<T> vb[NPASS];
 #pragma unroll
       for (int k = 0; k < NPASS; ++k)
-        vb[k] = *reinterpret_cast<const Vec16<T>*>(sC + (tid / CPR + k * RPP) * RSC + cc * 16);
+        vb[k] = *reinterpret_cast<const Vec16<T>*>(stage_row(tid / CPR + k * RPP) + cc * 16);
 #pragma unroll
       for (int k = 0; k < NPASS; ++k) {
         const int m = tid / CPR + k * RPP;
@@ -610,8 +539,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_direct_kernel(const DirectArgs
         const int pi = (TW == 32) ? mt : 2 * mt + (ml >> 4);
         const int pj = (TW == 32) ? ml : (ml & 15);
         const int hh = h0 + pi, ww = w0 + pj;
-        if (hh < a.H && ww < a.W && n < a.Nout) {
+        const bool inside = hh < a.H && ww < a.W && n < a.Nout;
+        if (!BRES && a.ybytes != 0) {
+          // a buffer store, executed by every wave with out-of-image lanes sent out of range: exactly NPASS
+          // vector-memory operations per wave follow the prefetched LDS-DMA pieces, so the next tile's first barrier
+          // can wait with vmcnt(NPASS) instead of draining these stores
+          const unsigned off = inside ? (unsigned)((((img * a.H + hh) * a.W + ww) * a.ldy + n) * ES) : OOB;
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&vb[k]), yr, off, 0, 0);
+        } else if (inside) {
           st16(yg + ((size_t)(img * a.H + hh) * a.W + ww) * a.ldy + n, vb[k]);
+        }
+        if (inside) {
           if constexpr (BNRED) {   // sums of the BatchNorm backward, from the gradient values as stored
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -1098,6 +1037,10 @@ int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x
   a.bias = bias;
   a.stats = stats;
   a.xbytes = (unsigned)(((long long)d->N * d->Hin * d->Win - 1) * d->ldx * es + (long long)d->Cin * es);
+  {
+    const long long yb = ((long long)d->N * d->H * d->W - 1) * d->ldy * es + (long long)d->Nout * es;
+    a.ybytes = yb < (1LL << 31) ? (unsigned)yb : 0u;
+  }
   a.ups = d->taps_mode == UZ_TAPS_CONV_UP2 ? 1 : 0;
   a.wbytes = (unsigned)((long long)d->Nout * 9 * d->Cin * es);
   a.N = d->N;
