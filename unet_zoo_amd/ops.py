@@ -304,6 +304,12 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
             t128 = Lt.C * ((Rt.C + 127) // 128) + Rt.C * ((Lt.C + 127) // 128)
             big = t128 < t64
         kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + (("_gather%d" % ntaps) if gather else "_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
+        if ntaps == 9 and not gather:   # the nine-tap 128 x 64 / 64 x 128 tiles of uz_wgrad3x3_plan()
+            P_ = Lt.N * Lt.H * Lt.W
+            if Lt.C % 128 == 0 and Rt.C % 64 == 0 and ((Rt.C == 64 and P_ >= (1 << 19)) or (Rt.C >= 1024 and Lt.C >= 512)):
+                kname = "wgrad3x3_bf16_128x64_9tap"
+            elif Lt.C == 64 and Rt.C % 128 == 0:
+                kname = "wgrad3x3_bf16_64x128_9tap"
     with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
         L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
