@@ -17,7 +17,7 @@ run nested_unet_256 --model nested_unet
 run resunet_256 --model resunet
 run swin_unet_v2_256 --model swin_unet_v2 --size 256
 run swin_unet_v2_224 --model swin_unet_v2 --size 224 --batch 32
-run missformer_512 --model missformer --size 512
+run missformer_512 --model missformer --size 512 --batch 8
 run transatt_unet_256 --model transatt_unet
 run unet_transformer_256 --model unet_transformer
 run multiresunet_256 --model multiresunet

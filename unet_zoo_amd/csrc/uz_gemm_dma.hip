@@ -465,6 +465,9 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
     p->bm = 128;
     p->nst = 2;
   }
+  // 64 output channels and at most two K slabs (the first convolution through im2col: K = 32; ConvTranspose 128 -> 64):
+  // a tile is one load, a few MFMAs and a 32 KB store burst -- two workgroups per CU (80 KB of LDS each) overlap them
+  if (p->bn == 64 && nsteps <= 2 && !(uz_tune_flags() & 0x1000000)) p->nst = 2;
   p->tiles_m = (int)((M + p->bm - 1) / p->bm);
   int cap = (p->nst == 2 ? 2 : 1) * UZ_NUM_CU / p->tiles_n;
   if (cap < 1) cap = 1;
@@ -477,7 +480,8 @@ static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
   dim3 grid(p.grid_m, p.tiles_n), block(512);
   if constexpr (sizeof(T) == 2) {
     if (a.bn_y != nullptr) {
-      if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3, true>), grid, block, 0, s, a);
+      if (p.bn == 64 && p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 2, true>), grid, block, 0, s, a);
+      else if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3, true>), grid, block, 0, s, a);
       else if (p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 2, true>), grid, block, 0, s, a);
       else if (p.bm == 128) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 4, true>), grid, block, 0, s, a);
       else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 256, 3, true>), grid, block, 0, s, a);
@@ -485,7 +489,8 @@ static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
       return UZ_OK;
     }
   }
-  if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3>), grid, block, 0, s, a);
+  if (p.bn == 64 && p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 2>), grid, block, 0, s, a);
+  else if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3>), grid, block, 0, s, a);
   else if (p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 2>), grid, block, 0, s, a);
   else if (p.bm == 128) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 4>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 256, 3>), grid, block, 0, s, a);
