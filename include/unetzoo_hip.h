@@ -57,6 +57,14 @@ enum {
 
 int uz_abi_version(void);
 const char* uz_last_error_string(void);
+/* Measurement hook (bench.py's per-launch profile, tools/): between uz_profile_arm(e0, e1) and uz_profile_disarm() the
+ * kernel launches made by THIS thread through the library record the two hipEvent_t handles at the kernels' own begin
+ * and end timestamps (first launch: both; later launches: the end event only), so hipEventElapsedTime(e0, e1) is the
+ * duration from the first kernel's begin to the last kernel's end -- what a kernel trace reports, without the dispatch
+ * latency that events recorded around a launch include.  Not to be armed during stream capture.  uz_profile_disarm()
+ * returns the number of launches seen. */
+int uz_profile_arm(void* start_event, void* stop_event);
+int uz_profile_disarm(void);
 /* 1 when the library was built with -DUZ_ABLATE (the measurement build of tools/kbench.py, whose kernels honour the
  * UZ_TUNE / UZ_ATTN_GX / UZ_WG_SPLIT environment switches), 0 for the shipped build, which never reads the
  * environment.  bench.py refuses to time an ablation build. */

@@ -11,6 +11,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
+// ---- measurement hook (uz_profile_arm / uz_profile_disarm, include/unetzoo_hip.h) --------------------------------------
+// While a thread is armed, the kernel launches of this library record the caller's event pair at the kernel's own begin
+// and end (hipExtLaunchKernelGGL): the first launch records both, later launches of the same armed scope move only the
+// end event -- the pair then brackets first-kernel-begin to last-kernel-end without the dispatch latency that events
+// recorded around a launch include.  Unarmed (always so inside graph capture) launches are plain <<< >>> launches.
+#include <hip/hip_ext.h>
+bool uz_prof_take(hipEvent_t* e0, hipEvent_t* e1);   // true while armed; *e0 = nullptr from the second launch on
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...)                                              \
+  do {                                                                                                       \
+    hipEvent_t uz_e0_, uz_e1_;                                                                               \
+    if (uz_prof_take(&uz_e0_, &uz_e1_))                                                                      \
+      hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (shm), (stream), uz_e0_, uz_e1_, 0, __VA_ARGS__);   \
+    else                                                                                                     \
+      kern<<<dim3(grid), dim3(block), (shm), (stream)>>>(__VA_ARGS__);                                       \
+  } while (0)
+
 #define UZ_WAVE 64
 #define UZ_NUM_CU 256
 #define UZ_NUM_XCD 8

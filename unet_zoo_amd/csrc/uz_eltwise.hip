@@ -1243,9 +1243,9 @@ extern "C" int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, 
   float* part = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16) {
-    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, part))
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, part, (const bf16_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr))
   } else {
-    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<float, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, g_nchw, (float*)dx, lddx, part))
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<float, KOUT>), dim3((unsigned)g), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, g_nchw, (float*)dx, lddx, part, (const float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr))
   }
   UZ_LAUNCH_CHECK("uz_outconv_bwd");
   const int ne = Kout * (C + 1);
@@ -1476,6 +1476,29 @@ void uz_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* uz_last_error_string(void) { return g_err; }
+
+// ---- measurement hook (see uz_common.h) ------------------------------------------------------------------------------
+static thread_local hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
+static thread_local int g_prof_launches = -1;   // -1: not armed
+bool uz_prof_take(hipEvent_t* e0, hipEvent_t* e1) {
+  if (g_prof_launches < 0) return false;
+  *e0 = g_prof_launches == 0 ? g_prof_e0 : nullptr;
+  *e1 = g_prof_e1;
+  ++g_prof_launches;
+  return true;
+}
+extern "C" int uz_profile_arm(void* start_event, void* stop_event) {
+  UZ_REQUIRE(start_event && stop_event, "uz_profile_arm: null event");
+  g_prof_e0 = (hipEvent_t)start_event;
+  g_prof_e1 = (hipEvent_t)stop_event;
+  g_prof_launches = 0;
+  return UZ_OK;
+}
+extern "C" int uz_profile_disarm(void) {
+  const int n = g_prof_launches;
+  g_prof_launches = -1;
+  return n < 0 ? 0 : n;   // kernel launches recorded since uz_profile_arm
+}
 extern "C" int uz_abi_version(void) { return UZ_ABI_VERSION; }
 extern "C" int uz_build_ablate(void) {
 #ifdef UZ_ABLATE

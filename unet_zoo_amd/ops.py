@@ -136,22 +136,29 @@ def profile_end() -> dict:
 
 
 class _Timed:
-    __slots__ = ("name", "flops", "bytes", "e0")
+    __slots__ = ("name", "flops", "bytes", "e0", "e1")
 
     def __init__(self, name: str, flops: float, nbytes: float):
         self.name, self.flops, self.bytes = name, flops, nbytes
 
     def __enter__(self):
         if _prof_on:
+            # both events exist (recorded once) before the library re-records them at the kernels' own begin / end
+            # (uz_profile_arm: hipExtLaunchKernelGGL start / stop events) -- the bracket is then first-kernel-begin to
+            # last-kernel-end, as a kernel trace reports it, without the dispatch latency of an event recorded in front
             self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
+            self.e1.record()
+            L.check(L.load().uz_profile_arm(self.e0.cuda_event, self.e1.cuda_event), "uz_profile_arm")
         return self
 
     def __exit__(self, *exc):
         if _prof_on:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            _prof_log.append((self.name, self.e0, e1, self.flops, self.bytes))
+            n = L.load().uz_profile_disarm()
+            if n == 0:          # nothing was launched through the library inside this scope: plain bracket
+                self.e1.record()
+            _prof_log.append((self.name, self.e0, self.e1, self.flops, self.bytes))
         return False
 
 
