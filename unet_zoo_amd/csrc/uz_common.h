@@ -116,6 +116,15 @@ struct UzBnRed {
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
                      const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br = nullptr);
 
+// direct 3x3 convolution, ping-pong schedule on 512-pixel x 128-channel tiles (uz_conv3x3_pp.hip); uz_direct_plan()
+// hands the descriptors it takes over with bres = 3
+struct UzPpPlan {
+  int th_n, tw_n, ntiles, tiles_n, grid_m;
+};
+int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p);
+int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const void* w, const float* bias, void* y,
+                 float* stats, hipStream_t s, const UzBnRed* br = nullptr);
+
 // 3x3 weight gradient with LDS-DMA pipeline (uz_wgrad3x3.hip), dispatched from uz_wgrad()
 struct UzWgrad2Plan {
   int big, one_tap, gather, kw, kr, tiles_i, tiles_j, kg, units, upb, split, nslabs, H, W;

@@ -942,6 +942,20 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
   const long long xbytes = ((long long)d->N * d->Hin * d->Win - 1) * d->ldx * es + (long long)d->Cin * es;
   const long long wbytes = (long long)d->Nout * 9 * d->Cin * es;
   if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31)) return 0;
+  {
+    UzPpPlan pp;   // third generation (uz_conv3x3_pp.hip): >= 128 output channels and enough 512-pixel tiles for every CU
+    if (uz_pp_plan(d, &pp)) {
+      p->tw = 32;
+      p->bn = 128;
+      p->bres = 3;
+      p->th_n = pp.th_n;
+      p->tw_n = pp.tw_n;
+      p->ntiles = pp.ntiles;
+      p->tiles_n = pp.tiles_n;
+      p->grid_m = pp.grid_m;
+      return 1;
+    }
+  }
   p->tw = d->W >= 32 ? 32 : 16;
   const int th = 256 / p->tw;
   p->th_n = (d->H + th - 1) / th;
@@ -1022,6 +1036,10 @@ static int direct_launch_t(const UzDirectPlan& p, const DirectArgs& a, hipStream
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
                      const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
+  if (p.bres == 3) {
+    UzPpPlan pp = {p.th_n, p.tw_n, p.ntiles, p.tiles_n, p.grid_m};
+    return uz_pp_launch(d, pp, x, w, bias, y, stats, s, br);
+  }
   DirectArgs a;
   a.bn_y = br ? br->y : nullptr;
   a.bn_scale = br ? br->scale : nullptr;
