@@ -92,9 +92,12 @@ constexpr int pp_wait_nonext(int t) {
 static_assert(pp_wait_normal(0) == 4 && pp_wait_normal(3) == 7 && pp_wait_normal(8) == 3, "wait table");
 static_assert(pp_wait_nonext(0) == 3 && pp_wait_nonext(5) == 2 && pp_wait_nonext(7) == 0, "wait table");
 
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff) {
-  // one wave-instruction: lane i writes LDS bytes [base + 16 i, +16) with the 16 bytes at voff (zeros when out of range)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, 0, 0, 0);
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff, unsigned soff) {
+  // one wave-instruction: lane i writes LDS bytes [base + 16 i, +16) with the 16 bytes at voff + soff (zeros when out of
+  // range; masked lanes carry voff = OOB, which is out of range whether or not the scalar offset takes part in the check).
+  // The wave-uniform part of the address (tap, channel slab) travels in the scalar offset: added to the lane offsets it
+  // would be hoisted out of the tile loop as one more register per tap.
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt range");
@@ -108,10 +111,14 @@ __device__ __forceinline__ void pin16(f32x4& v) { asm volatile("" : "+v"(v)); }
 template <int V> struct IntC { static constexpr int value = V; };
 
 #ifndef UZ_PP_SKEL
-#define UZ_PP_SKEL 0   // measurement builds: 1 no fragment reads, 2 no MFMAs, 4 no DMA after the prologue, 8 no epilogue
+#define UZ_PP_SKEL 0   // measurement builds: 1 no fragment reads, 2 no MFMAs, 4 no DMA after the prologue, 8 no epilogue,
+                      // 16 fragment reads in a tile's first unit only, 32 no s_setprio, 64 no lgkmcnt wait before the barrier
+                      // (after it instead), 128 both groups in lockstep (timing only)
 #endif
 
-template <bool BNRED>
+// S16: v_mfma_f32_16x16x32_bf16 (a unit = 32 MFMAs of 16 cycles) instead of 32x32x16 (16 of 32 cycles): same fragment
+// bytes and accumulator count, half the accumulator traffic per flop; the chip holds a higher clock on that stream.
+template <bool BNRED, bool S16>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   typedef bf16_t T;
   constexpr int ES = 2, VEC = 8;
@@ -129,50 +136,71 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   const unsigned smem_u = (unsigned)(size_t)(lds_char_ptr)smem;
 
   // ---- fragment read addresses -------------------------------------------------------------------------------------
-  // patch pixel (pi, pj) lives in LDS row pj * PHP + pi; 16-byte chunk c of a row is stored at chunk c ^ key(pj),
-  // key(pj) = (pj >> 2) & 3.  A lane reads pixel column l31 + tx: one base per (tx, K chunk q); the patch row
-  // 4 wm + i + ty is an immediate offset.  Weight rows: channel wn * 64 + 32 j + l31, key = (row >> 2) & 3.
+  // patch pixel (pi, pj) lives in LDS row pj * PHP + pi; weight rows are output channels.  A row's four 16-byte chunks
+  // are permuted with a key of the patch column / channel (swz()), the same on the DMA source side and on the read.
+  // 32x32x16: a lane reads pixel column l31 + tx, K chunk 2 q + lh: one base per (tx, q); the patch row 4 wm + i + ty
+  // is an immediate offset.  16x16x32: a lane reads pixel column (lane & 15) + 16 h + tx, K chunk lane >> 4: one base
+  // per tx; patch row and column half h are immediate offsets (16 columns further the key is the same).
+  // XOR with (col >> 2) & 3 is conflict-free for the 32-row reads at every tap shift; the 16-row reads (two K chunks per
+  // 16-lane group) need the rotation by 2 * (col >> 2).
+  auto swz = [](int chunk, int col) { return S16 ? ((chunk + 2 * (col >> 2)) & 3) : (chunk ^ ((col >> 2) & 3)); };
+  auto unswz = [](int phys, int col) { return S16 ? ((phys - 2 * (col >> 2)) & 3) : (phys ^ ((col >> 2) & 3)); };
+  const int l15 = lane & 15, lq = lane >> 4;
   unsigned a_base[3][2], b_base[2];
 #pragma unroll
   for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int pj = l31 + tx;
-      a_base[tx][q] = smem_u + (pj * PHP + 4 * wm) * RB + (((2 * q + lh) ^ ((pj >> 2) & 3)) << 4);
+      if constexpr (S16) {
+        const int pj = l15 + tx;
+        a_base[tx][q] = smem_u + (pj * PHP + 4 * wm) * RB + (swz(lq, pj) << 4);
+      } else {
+        const int pj = l31 + tx;
+        a_base[tx][q] = smem_u + (pj * PHP + 4 * wm) * RB + (swz(2 * q + lh, pj) << 4);
+      }
     }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int brow = wn * 64 + l31;
-    b_base[q] = smem_u + OFF_B + brow * RB + (((2 * q + lh) ^ ((brow >> 2) & 3)) << 4);
+    if constexpr (S16) {
+      const int brow = wn * 64 + l15;
+      b_base[q] = smem_u + OFF_B + brow * RB + (swz(lq, brow) << 4);
+    } else {
+      const int brow = wn * 64 + l31;
+      b_base[q] = smem_u + OFF_B + brow * RB + (swz(2 * q + lh, brow) << 4);
+    }
   }
   // ---- LDS-DMA source offsets --------------------------------------------------------------------------------------
   // weight piece `wave` of a slot: rows 16 wave + (lane >> 2), this lane fetches the chunk that belongs at (lane & 3)
   unsigned bvoff;
   {
     const int brow = wave * 16 + (lane >> 2);
-    bvoff = (n0 + brow < a.Nout) ? ((unsigned)(n0 + brow) * (unsigned)a.K * ES + (((lane & 3) ^ ((brow >> 2) & 3)) << 4)) : OOB;
+    bvoff = (n0 + brow < a.Nout) ? ((unsigned)(n0 + brow) * (unsigned)a.K * ES + (unswz(lane & 3, brow) << 4)) : OOB;
   }
   unsigned avoff[APW];   // halo pieces wave + 8 k of the tile whose patches are being requested (channel slab 0)
   auto compute_avoff = [&](int im, int hh0, int ww0) {
+    // (an opaque copy of the lane id: everything below is tile-invariant up to the last two lines, and hoisted out of the
+    // tile loop it would hold a dozen registers through the main loop -- the kernel then spills its DMA offsets)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int k = 0; k < APW; ++k) {
-      const int r = (wave + 8 * k) * 16 + (lane >> 2);
+      const int r = (wave + 8 * k) * 16 + (ln >> 2);
       const int pj = r / PHP, pi = r - pj * PHP;
       const int hh = hh0 - 1 + pi, ww = ww0 - 1 + pj;
       const bool ok = r < PROWS && pi < PH && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
       const unsigned pix = a.ups ? (unsigned)((im * (a.H >> 1) + (hh >> 1)) * (a.W >> 1) + (ww >> 1))
                                  : (unsigned)((im * a.H + hh) * a.W + ww);
-      avoff[k] = ok ? (pix * (unsigned)a.ldx + (((lane & 3) ^ ((pj >> 2) & 3)) << 3)) * ES : OOB;
+      avoff[k] = ok ? (pix * (unsigned)a.ldx + (unswz(ln & 3, pj) << 3)) * ES : OOB;
     }
   };
   auto issue_a = [&](auto kc, int buf, int cslab) {
     constexpr int k = decltype(kc)::value;
     const int piece = wave + 8 * k;
     char* dst = piece < APIECES ? smem + buf * A_BYTES + piece * 1024 : smem + OFF_SCR;
-    dma16(xr, dst, avoff[k] + (unsigned)(cslab * KU * ES));
+    dma16(xr, dst, avoff[k], (unsigned)(cslab * KU * ES));
   };
   auto issue_b = [&](int slot, int cslab, int tap) {
-    dma16(wr, smem + OFF_B + slot * B_SLOT + wave * 1024, bvoff + (unsigned)((tap * a.Cin + cslab * KU) * ES));
+    dma16(wr, smem + OFF_B + slot * B_SLOT + wave * 1024, bvoff, (unsigned)((tap * a.Cin + cslab * KU) * ES));
   };
   auto decode = [&](int tile, int& im, int& hh0, int& ww0) {
     const int per = a.th_n * a.tw_n;
@@ -188,11 +216,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   if (tid < BN) sBias[tid] = (!BNRED && a.bias != nullptr && n0 + tid < a.Nout) ? a.bias[n0 + tid] : 0.f;
 
   const int ncb = a.Cin / KU;
+  // 32x32x16: acc[i][j] = patch row 4 wm + i x channels 32 j (16 registers); fa[q][i], fb[q][j]
+  // 16x16x32: accs[2 i + h][ct] = patch row i, column half h x channels 16 ct (4 registers); fa[h][i], fb[ct >> 1][ct & 1]
   f32x16 acc[4][2];
+  f32x4 accs[S16 ? 8 : 1][4];
   f32x4 fa[2][4], fb[2][2];
-  float sq1[VEC], sq2[VEC];   // this lane's channel chunk (lane & 7) of the read-back phase, accumulated over the tiles
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) sq1[e] = sq2[e] = 0.f;
+  {   // running BatchNorm sums of this lane (channel chunk lane & 7 of the read-back phase): zero, in the staging strip
+    f32x4* sp = reinterpret_cast<f32x4*>(smem + OFF_STG + wave * STG_W + lane * 64);
+    sp[0] = sp[1] = sp[2] = sp[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   int apar = 0;    // patch buffer of the current slab
   int bslot = 0;   // weight slot of the current unit
@@ -217,30 +249,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     constexpr int t = decltype(tc)::value;
     constexpr bool INIT = decltype(initc)::value != 0;
     constexpr int ty = t / 3, tx = t - 3 * ty;
-    if (grp == 1) __builtin_amdgcn_s_barrier();
+    if (grp == 1 && !(UZ_PP_SKEL & 128)) __builtin_amdgcn_s_barrier();
     // ---- read phase (the other group computes) ----
     f32x16 cinit[2];
+    f32x4 cinit4[4];
     if constexpr (INIT) {
+      if constexpr (S16) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int ct = 0; ct < 4; ++ct) cinit4[ct] = *reinterpret_cast<const f32x4*>(sBias + wn * 64 + ct * 16 + 4 * lq);
+      } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + wn * 64 + j * 32 + 8 * q + 4 * lh);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) cinit[j][4 * q + e] = b4[e];
-        }
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + wn * 64 + j * 32 + 8 * q + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cinit[j][4 * q + e] = b4[e];
+          }
+      }
     }
-    if (!(UZ_PP_SKEL & 1)) {
+    if (!(UZ_PP_SKEL & 1) && (!(UZ_PP_SKEL & 16) || INIT)) {
       const unsigned aoff = (unsigned)(apar * A_BYTES), boff = (unsigned)(bslot * B_SLOT);
+      if constexpr (S16) {
+        const unsigned va = a_base[tx][0] + aoff, vb = b_base[0] + boff;
+        lds_read16<(0 + ty) * RB>(fa[0][0], va);
+        lds_read16<(0 + ty) * RB + 16 * PHP * RB>(fa[1][0], va);
+        lds_read16<0>(fb[0][0], vb);
+        lds_read16<16 * RB>(fb[0][1], vb);
+        lds_read16<32 * RB>(fb[1][0], vb);
+        lds_read16<48 * RB>(fb[1][1], vb);
+        lds_read16<(1 + ty) * RB>(fa[0][1], va);
+        lds_read16<(1 + ty) * RB + 16 * PHP * RB>(fa[1][1], va);
+        lds_read16<(2 + ty) * RB>(fa[0][2], va);
+        lds_read16<(2 + ty) * RB + 16 * PHP * RB>(fa[1][2], va);
+        lds_read16<(3 + ty) * RB>(fa[0][3], va);
+        lds_read16<(3 + ty) * RB + 16 * PHP * RB>(fa[1][3], va);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned va = a_base[tx][q] + aoff, vb = b_base[q] + boff;
-        lds_read16<(0 + ty) * RB>(fa[q][0], va);
-        lds_read16<(1 + ty) * RB>(fa[q][1], va);
-        lds_read16<(2 + ty) * RB>(fa[q][2], va);
-        lds_read16<(3 + ty) * RB>(fa[q][3], va);
-        lds_read16<0>(fb[q][0], vb);
-        lds_read16<32 * RB>(fb[q][1], vb);
+        for (int q = 0; q < 2; ++q) {
+          const unsigned va = a_base[tx][q] + aoff, vb = b_base[q] + boff;
+          lds_read16<(0 + ty) * RB>(fa[q][0], va);
+          lds_read16<(1 + ty) * RB>(fa[q][1], va);
+          lds_read16<(2 + ty) * RB>(fa[q][2], va);
+          lds_read16<(3 + ty) * RB>(fa[q][3], va);
+          lds_read16<0>(fb[q][0], vb);
+          lds_read16<32 * RB>(fb[q][1], vb);
+        }
       }
     }
     const bool nonext = last && !has_next;
@@ -268,8 +322,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
         else wait_vmcnt<NW>();
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(UZ_PP_SKEL & 64)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (UZ_PP_SKEL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- compute phase ----
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -280,24 +335,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!(UZ_PP_SKEL & 2)) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
+      if (!(UZ_PP_SKEL & 32)) __builtin_amdgcn_s_setprio(1);
+      if constexpr (S16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[q][j]);
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[q][i]);
-            if (INIT && q == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, cinit[j], 0, 0, 0);
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[i][j], 0, 0, 0);
-          }
-      __builtin_amdgcn_s_setprio(0);
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[ct >> 1][ct & 1]);
+              const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[h][i]);
+              accs[2 * i + h][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, INIT ? cinit4[ct] : accs[2 * i + h][ct], 0, 0, 0);
+            }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[q][j]);
+              const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[q][i]);
+              if (INIT && q == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, cinit[j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[i][j], 0, 0, 0);
+            }
+      }
+      if (!(UZ_PP_SKEL & 32)) __builtin_amdgcn_s_setprio(0);
     } else if (INIT) {
+      if constexpr (S16) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int pt = 0; pt < 8; ++pt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = cinit[j];
+          for (int ct = 0; ct < 4; ++ct) accs[pt][ct] = cinit4[ct];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = cinit[j];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     bslot = bslot + 1 == NSLOT ? 0 : bslot + 1;
@@ -306,19 +381,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   // group 1 at the top of unit(); after a tile's last unit group 0 still executes it (group 1's matching one opens the
   // next tile), so both groups meet 18 * ncb barriers per tile
   auto tail_barrier = [&]() {
-    if (grp == 0) __builtin_amdgcn_s_barrier();
+    if (grp == 0 && !(UZ_PP_SKEL & 128)) __builtin_amdgcn_s_barrier();
   };
 
   // ---- wave-local epilogue ---------------------------------------------------------------------------------------------
   auto epilogue = [&](int im, int hh0, int ww0) {
     if (UZ_PP_SKEL & 8) {
+      if constexpr (S16) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+        for (int pt = 0; pt < 8; ++pt) asm volatile("" ::"v"(accs[pt][0]), "v"(accs[pt][1]), "v"(accs[pt][2]), "v"(accs[pt][3]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
+      }
       return;
     }
     char* const stg = smem + OFF_STG + wave * STG_W;
-    const int cc = lane & 7;
+    int ln = lane;   // opaque: the address arithmetic of the epilogue must not live in registers through the main loop
+    asm volatile("" : "+v"(ln));
+    const int l31 = ln & 31, lh = ln >> 5, l15 = ln & 15, lq = ln >> 4;
+    const int cc = ln & 7;
     const int nch = n0 + wn * 64 + cc * VEC;
+    // this lane's running sums live in the staging strip between epilogues (16 registers the main loop needs)
+    float sq1[VEC], sq2[VEC];
+    {
+      const f32x4* sp = reinterpret_cast<const f32x4*>(stg + ln * 64);
+      const f32x4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sq1[e] = s0[e];
+        sq1[4 + e] = s1[e];
+        sq2[e] = s2[e];
+        sq2[4 + e] = s3[e];
+      }
+    }
     float bsc[VEC], bsh[VEC], bmu[VEC], bis[VEC];
     if constexpr (BNRED) {
       const int ch0 = nch < a.Nout ? nch : 0;
@@ -338,28 +434,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
         const T* __restrict__ by = static_cast<const T*>(a.bn_y);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int hc = min(hh, a.H - 1), wc = min(ww0 + (lane >> 3) + 8 * k, a.W - 1);   // clamped: unused outside the image
+          const int hc = min(hh, a.H - 1), wc = min(ww0 + (ln >> 3) + 8 * k, a.W - 1);   // clamped: unused outside the image
           yb[k] = ld16(by + ((size_t)(im * a.H + hc) * a.W + wc) * a.ld_bny + (nch < a.Nout ? nch : 0));
         }
       }
-      // stage: lane = pixel l31 of this patch row, register quad q of N tile j = 4 consecutive channels
+      // stage: a lane holds 4 consecutive channels of one pixel per register quad -> one 8-byte LDS write
+      if constexpr (S16) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          bf16x4 pk;
+          for (int ct = 0; ct < 4; ++ct) {
+            bf16x4 pk;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)acc[i][j][4 * q + e];
-          *reinterpret_cast<bf16x4*>(stg + l31 * STG_ROW + (32 * j + 8 * q + 4 * lh) * ES) = pk;
-        }
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)accs[2 * i + h][ct][e];
+            *reinterpret_cast<bf16x4*>(stg + (16 * h + l15) * STG_ROW + (16 * ct + 4 * lq) * ES) = pk;
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)acc[i][j][4 * q + e];
+            *reinterpret_cast<bf16x4*>(stg + l31 * STG_ROW + (32 * j + 8 * q + 4 * lh) * ES) = pk;
+          }
+      }
       // read back: lane = (pixel (lane >> 3) + 8 k, channel chunk lane & 7); LDS operations of one wave execute in order
       Vec16<T> vb[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        vb[k] = *reinterpret_cast<const Vec16<T>*>(stg + ((lane >> 3) + 8 * k) * STG_ROW + cc * 16);
+        vb[k] = *reinterpret_cast<const Vec16<T>*>(stg + ((ln >> 3) + 8 * k) * STG_ROW + cc * 16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int ww = ww0 + (lane >> 3) + 8 * k;
+        const int ww = ww0 + (ln >> 3) + 8 * k;
         const bool inside = hh < a.H && ww < a.W && nch < a.Nout;
         // buffer stores executed by every lane (outside the image: out of range): exactly NSTORE vector-memory
         // operations per wave and tile, which the counted waits of the next tile's first units allow for
@@ -384,6 +492,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
           }
         }
       }
+    }
+    {
+      f32x4* sp = reinterpret_cast<f32x4*>(stg + ln * 64);
+      sp[0] = f32x4{sq1[0], sq1[1], sq1[2], sq1[3]};
+      sp[1] = f32x4{sq1[4], sq1[5], sq1[6], sq1[7]};
+      sp[2] = f32x4{sq2[0], sq2[1], sq2[2], sq2[3]};
+      sp[3] = f32x4{sq2[4], sq2[5], sq2[6], sq2[7]};
     }
   };
 
@@ -421,13 +536,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   if (a.stats != nullptr) {
     wait_vmcnt<0>();
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [512][2 * VEC]
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      red[tid * 2 * VEC + e] = sq1[e];
-      red[tid * 2 * VEC + VEC + e] = sq2[e];
-    }
-    __syncthreads();
+    // thread `th` left its sums [2][VEC] at strip(th >> 6) + (th & 63) * 64
+    auto red = [&](int th, int idx) { return reinterpret_cast<const float*>(smem + OFF_STG + (th >> 6) * STG_W + (th & 63) * 64)[idx]; };
     if (tid < 2 * BN) {
       const int which = tid / BN, ch = tid - which * BN;
       const int cwn = ch >> 6, cc = (ch & 63) >> 3, e = ch & 7;
@@ -435,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       for (int m = 0; m < 4; ++m)
         for (int l = 0; l < 8; ++l) {
           const int th = ((2 * m + cwn) << 6) + l * 8 + cc;
-          t += red[th * 2 * VEC + which * VEC + e];
+          t += red(th, which * VEC + e);
         }
       if (n0 + ch < a.Nout) a.stats[((size_t)blockIdx.x * 2 + which) * a.Nout + n0 + ch] = t;
     }
@@ -506,8 +616,16 @@ int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const 
   a.ld_bny = br ? br->ldy : 0;
   if (br) UZ_REQUIRE(stats != nullptr, "uz_conv_igemm_bnred: partial rows missing");
   dim3 grid(p.grid_m, p.tiles_n), block(512);
-  if (br) hipLaunchKernelGGL((conv3x3_pp_kernel<true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv3x3_pp_kernel<false>), grid, block, 0, s, a);
+#ifdef UZ_ABLATE
+  if (uz_tune_flags() & 0x4000000) {   // the 32x32x16 stream
+    if (br) hipLaunchKernelGGL((conv3x3_pp_kernel<true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_pp_kernel<false, false>), grid, block, 0, s, a);
+    UZ_LAUNCH_CHECK("uz_conv_igemm(direct3x3 ping-pong 32x32x16)");
+    return UZ_OK;
+  }
+#endif
+  if (br) hipLaunchKernelGGL((conv3x3_pp_kernel<true, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv3x3_pp_kernel<false, true>), grid, block, 0, s, a);
   UZ_LAUNCH_CHECK("uz_conv_igemm(direct3x3 ping-pong)");
   return UZ_OK;
 }
