@@ -96,6 +96,12 @@ typedef struct uz_conv_desc {
 } uz_conv_desc;
 
 int uz_conv_igemm_grid_m(const uz_conv_desc* d); /* number of stats partial rows; <0 on error */
+/* Name of the kernel family the library's own plan picks for this descriptor (what uz_conv_igemm_ws() will launch;
+ * `with_workspace` != 0: called with a workspace), e.g. "conv3x3_pp512_bf16", "conv3x3_pp256_bf16", "conv3x3_direct_bf16_bn128",
+ * "conv3x3_direct_bf16_bn64_resident", "conv3x3_res64_bf16", "gemm_dma_bf16", "igemm_f32_128x64_tapsplit"; a "_up2"
+ * suffix marks the nearest-upsampled input.  Measurement code (bench.py's per-family roofline) labels launches with
+ * it instead of mirroring the plan.  Writes at most cap - 1 characters + NUL, returns the full length, < 0 on error. */
+int uz_conv_igemm_kernel_name(const uz_conv_desc* d, int with_workspace, char* buf, int cap);
 int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                   void* y, float* stats_partial, void* stream);
 /* y = conv(x) + bias + res: the same with an (M, ldres) tensor of the run dtype added in the epilogue (the result is

@@ -105,6 +105,7 @@ static inline const char* uz_ablate_env(const char*) { return nullptr; }
 // direct 3x3 convolution (uz_conv3x3.hip), dispatched from uz_conv_igemm()
 struct UzDirectPlan {
   int tw, bn, bres, th_n, tw_n, ntiles, tiles_n, grid_m;
+  int ppcfg;   // bres == 3: the ping-pong configuration (UZ_PP_*)
 };
 int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p);
 // operands of the BatchNorm-backward reduction fused into the epilogue (uz_conv_igemm_bnred)
@@ -118,8 +119,12 @@ int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x
 
 // direct 3x3 convolution, ping-pong schedule on 512-pixel x 128-channel tiles (uz_conv3x3_pp.hip); uz_direct_plan()
 // hands the descriptors it takes over with bres = 3
+enum { UZ_PP_512 = 0,      // 16 x 32 pixels x 128 channels
+       UZ_PP_512X64 = 1,   // 16 x 32 pixels x 64 channels
+       UZ_PP_256 = 2,      // 8 x 32 pixels x 128 channels
+       UZ_PP_256W16 = 3 }; // 16 x 16 pixels x 128 channels
 struct UzPpPlan {
-  int th_n, tw_n, ntiles, tiles_n, grid_m;
+  int cfg, bn, th_n, tw_n, ntiles, tiles_n, grid_m;
 };
 int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p);
 int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const void* w, const float* bias, void* y,

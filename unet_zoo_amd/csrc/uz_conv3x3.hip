@@ -943,11 +943,12 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
   const long long wbytes = (long long)d->Nout * 9 * d->Cin * es;
   if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31)) return 0;
   {
-    UzPpPlan pp;   // third generation (uz_conv3x3_pp.hip): >= 128 output channels and enough 512-pixel tiles for every CU
+    UzPpPlan pp;   // third generation (uz_conv3x3_pp.hip): bf16, input channels in multiples of 32
     if (uz_pp_plan(d, &pp)) {
-      p->tw = 32;
-      p->bn = 128;
+      p->tw = pp.cfg == UZ_PP_256W16 ? 16 : 32;
+      p->bn = pp.bn;
       p->bres = 3;
+      p->ppcfg = pp.cfg;
       p->th_n = pp.th_n;
       p->tw_n = pp.tw_n;
       p->ntiles = pp.ntiles;
@@ -1037,7 +1038,7 @@ int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x
                      const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   if (p.bres == 3) {
-    UzPpPlan pp = {p.th_n, p.tw_n, p.ntiles, p.tiles_n, p.grid_m};
+    UzPpPlan pp = {p.ppcfg, p.bn, p.th_n, p.tw_n, p.ntiles, p.tiles_n, p.grid_m};
     return uz_pp_launch(d, pp, x, w, bias, y, stats, s, br);
   }
   DirectArgs a;

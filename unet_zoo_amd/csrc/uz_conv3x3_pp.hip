@@ -1,25 +1,35 @@
 // Direct 3x3 convolution, third generation ("ping-pong"), bf16, gfx950 (MI355X), NHWC.
 //
-// Stands in for nn.Conv2d(k=3, padding=1) forward and its input gradient on the layers with at least 128 output
-// channels and enough pixels to give every CU a 512-pixel tile (reference: unet_zoo/models/common_layers.py:28,31,47,52,71;
-// autograd a19).  Same arithmetic as uz_conv3x3.hip (bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16,
-// result rounded once to bf16, BatchNorm sums of the STORED values), a different schedule:
+// Stands in for nn.Conv2d(k=3, padding=1) forward and its input gradient (reference:
+// unet_zoo/models/common_layers.py:28,31,47,52,71; autograd a19) wherever the input channels come in multiples of 32.
+// Same arithmetic as uz_conv3x3.hip (bf16 operands, fp32 accumulation on the matrix cores, result rounded once to bf16,
+// BatchNorm sums of the STORED values), a different schedule:
 //
-//  * Workgroup tile 512 pixels (16 x 32 patch) x 128 output channels, 8 waves as 4 (pixels) x 2 (channels), wave tile
-//    128 pixels x 64 channels: 6 fragment reads per 8 MFMAs (the 64 x 64 wave tile of the second generation: 8 per 8)
-//    and 24.5 KB of LDS-DMA per 64-deep K step of 256 MFMAs (there: 20.7 KB per 128 MFMAs).
-//  * K unit = (tap, 32 input channels).  The halo patch of a 32-channel slab is 34 x 19 rows of 64 bytes (column-major
-//    with an odd column height, so that a tap and an M tile are immediate offsets of the ds_read and the XOR swizzle key
-//    depends on the patch column only); two patch buffers, five weight slots of [128][64 B].
+//  * K unit = (tap, 32 input channels).  The halo patch of a 32-channel slab is PW x PHP rows of 64 bytes, column-major
+//    with an odd column height PHP: a tap, a patch row and a 16-column step are immediate offsets of the ds_read, the
+//    swizzle key depends on the patch column only.  Two patch buffers; a ring of weight tiles [BN][64 B] per unit.
+//  * v_mfma_f32_16x16x32_bf16 with the weights as the row operand: a lane owns 4 consecutive channels of one pixel per
+//    accumulator.  A 16-pixel tile is 16 consecutive patch columns of one patch row; the four 16-byte chunks of an LDS row
+//    are rotated by 2 * (column >> 2), which keeps every ds_read_b128 lane group conflict-free at every tap shift.
+//    (Measured against the 32x32x16 stream on the same tiles, same box, bit-identical results: 1186 -> 1255 TFLOP/s over
+//    the twelve unet layers of the first configuration -- the chip holds a higher clock on the stream that moves half the
+//    accumulator bytes per flop.  MFMAs alone on real data, no fragment reads, no DMA: 1500 TFLOP/s = the ceiling of this
+//    structure at the clock the chip holds.)
 //  * PING-PONG: the two waves that share a SIMD (w, w + 4) never compute at the same time.  Between two s_barriers one
-//    group issues its 16 MFMAs of a unit while the other reads the 12 fragments of its next unit from LDS and issues its
-//    LDS-DMA pieces (one weight piece per unit, one halo piece in six of nine units), then the roles swap.  The matrix
-//    pipe of a SIMD sees one back-to-back MFMA stream; fragment reads, address arithmetic, DMA issue and the counted
-//    s_waitcnt vmcnt(N) all sit in the other wave's half.
+//    group issues the MFMAs of a phase while the other reads the fragments of its next phase from LDS and issues its
+//    LDS-DMA pieces, then the roles swap.  (Lockstep, one barrier per phase: 8 % slower.  DMA issue moved into the MFMA
+//    stream: 7 % slower.  s_setprio, and where the lgkmcnt wait sits: nothing.)
 //  * The unit stream runs across the tiles of a workgroup: the last slab of a tile requests the first patch and the first
 //    weight tiles of the next one.  The epilogue is wave-local (no barrier): 32-pixel rounds through a private 4.5 KB
 //    staging strip, 16-byte buffer stores of full 128-byte lines, statistics from the stored values; both groups run it
-//    in the same barrier interval (the group that finished first starts it while the other one computes its last unit).
+//    in the same barrier interval.
+//
+// Tile configurations (template parameters TH x TW pixels, WM x WN waves, UPP units per phase):
+//   16 x 32, 4 x 2, 1   512 pixels x 128 channels, wave 128 x 64: the layers with >= 128 output channels and enough
+//                       pixels for one tile per CU (6 fragment reads per 16 MFMA cycles x 32, 24.5 KB of DMA per K = 64)
+//   16 x 32, 8 x 1, 3   512 pixels x 64 channels, wave 64 x 64, a phase = one tap row: 64 output channels
+//    8 x 32, 4 x 2, 3   256 pixels x 128 channels, wave 64 x 64: 32 x 32 ... maps, where 512-pixel tiles leave CUs idle
+//   16 x 16, 4 x 2, 3   256 pixels (one 16 x 16 map) x 128 channels
 #include "uz_common.h"
 
 namespace {
@@ -46,51 +56,98 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr unsigned OOB = 0x80000000u;   // beyond any descriptor's num_records (tensors < 2 GiB), also after adding a slab offset
+constexpr unsigned OOB = 0x80000000u;   // beyond any descriptor's num_records (tensors < 2 GiB)
+constexpr int RB = 64;                  // bytes per LDS row = 32 channels
+constexpr int KU = 32;                  // K per unit
+constexpr int STG_ROW = 144;            // staging row: 64 channels + 16 bytes
+constexpr int STG_W = 32 * STG_ROW;     // a wave's staging strip: 32 pixels (also parks its 64 x 64 B of running sums)
 
-constexpr int TH = 16, TW = 32, PH = TH + 2, PW = TW + 2, PHP = PH | 1;   // 18 x 34 halo patch, columns of 19 rows
-constexpr int RB = 64;                                                   // bytes per LDS row = 32 channels
-constexpr int KU = 32;                                                   // K per unit
-constexpr int PROWS = PW * PHP;                                          // 646
-constexpr int APIECES = (PROWS * RB + 1023) / 1024;                      // 41 pieces of 1 KB (16 rows)
-constexpr int A_BYTES = APIECES * 1024;
-constexpr int APW = (APIECES + 7) / 8;                                   // 6 pieces per wave and slab (the tail ones are dummies)
-constexpr int BN = 128;
-constexpr int B_SLOT = BN * RB;                                          // 8 KB = 8 pieces, one per wave
-constexpr int NSLOT = 5, DPF = NSLOT - 1;                                // weight tiles are requested DPF units ahead
-constexpr int OFF_B = 2 * A_BYTES;
-constexpr int STG_ROW = 144;                                             // staging row: 64 channels + 16 bytes
-constexpr int STG_W = 32 * STG_ROW;
-constexpr int OFF_STG = OFF_B + NSLOT * B_SLOT;
-constexpr int OFF_SCR = OFF_STG + 8 * STG_W;                             // 1 KB that swallows the dummy pieces
-constexpr int OFF_BIAS = OFF_SCR + 1024;
-constexpr int SMEM_BYTES = OFF_BIAS + BN * 4;
-static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
-constexpr int NSTORE = 16;                                               // epilogue stores per wave and tile
+template <int TH_, int TW_, int WM_, int WN_, int UPP_>
+struct PpCfg {
+  static constexpr int TH = TH_, TW = TW_, WM = WM_, WN = WN_, UPP = UPP_;
+  static_assert(WM * WN == 8 && (TW == 32 || TW == 16) && TH % WM == 0 && 9 % UPP == 0, "tile configuration");
+  static constexpr int PH = TH + 2, PW = TW + 2, PHP = PH | 1;
+  static constexpr int PROWS = PW * PHP;
+  static constexpr int APIECES = (PROWS * RB + 1023) / 1024;   // 1 KB pieces (16 rows) of a patch
+  static constexpr int A_BYTES = APIECES * 1024;
+  static constexpr int APW = (APIECES + 7) / 8;                // pieces per wave and slab (beyond APIECES: dummies)
+  static constexpr int BN = 64 * WN;
+  static constexpr int B_UNIT = BN * RB;                       // weight tile of a unit
+  static constexpr int BPU = B_UNIT / 1024;                    // pieces per unit (8 or 4)
+  static constexpr int NPH = 9 / UPP;                          // phases per slab
+  static constexpr int BPP = UPP * BPU;                        // weight pieces per phase
+  static constexpr int NBJ = (BPP + 7) / 8;                    // ... per wave (the last round may cover waves 0-3 only)
+  static constexpr int NSLOT = UPP == 1 ? 5 : 3;               // weight ring, in phases
+  static constexpr int DPH = NSLOT - 1;                        // weight tiles are requested DPH phases ahead
+  static constexpr int ROWS_W = TH / WM;                       // patch rows of a wave
+  static constexpr int HALVES = TW / 16;
+  static constexpr int PT = ROWS_W * HALVES;                   // 16-pixel tiles of a wave
+  static constexpr int CT = 4;                                 // 16-channel tiles of a wave
+  static_assert(PT % 2 == 0, "epilogue rounds are 32 pixels");
+  static constexpr int NSTORE = 2 * PT;                        // epilogue stores per wave and tile
+  static constexpr int OFF_B = 2 * A_BYTES;
+  static constexpr int OFF_STG = OFF_B + NSLOT * UPP * B_UNIT;
+  static constexpr int OFF_SCR = OFF_STG + 8 * STG_W;          // 1 KB that swallows the dummy pieces
+  static constexpr int OFF_BIAS = OFF_SCR + 1024;
+  static constexpr int SMEM_BYTES = OFF_BIAS + BN * 4;
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(UPP * (PT + CT) * 4 + PT * CT * 4 <= 200, "register budget: fragments + accumulators");
 
-// vmcnt(N) at the end of the read phase of the unit with tap t: everything this wave requested for unit + 1 has landed.
-// A wave's request sequence per unit is [weight piece of unit + DPF][halo piece t of the next slab, t < APW]; the
-// weight piece of unit + 1 was requested DPF - 1 units ago, so the requests that may stay in flight are the DPF - 1
-// younger weight pieces and the halo pieces requested in units t - (DPF - 1) .. t; before a slab's first unit the whole
-// patch of that slab must be in: nothing younger than the three weight pieces after the last halo piece.
-constexpr int pp_wait_normal(int t) {
-  int n = DPF - 1;
-  for (int k = t - (DPF - 1); k <= t; ++k) {
-    const int kk = (k + 9) % 9;
-    if (kk < APW) ++n;
+  // halo pieces a wave requests in phase p (for the next slab): none in a slab's last phase when a slab has few phases
+  // (they must have landed when that phase ends)
+  static constexpr int na(int p) {
+    if (NPH == 9) return p < APW ? 1 : 0;
+    const int first = (APW + NPH - 2) / (NPH - 1);
+    int left = APW;
+    for (int k = 0; k < NPH - 1; ++k) {
+      const int n = left < first ? left : first;
+      if (k == p) return n;
+      left -= n;
+    }
+    return 0;
   }
-  if (t == 8) n = 8 - APW + 1 < n ? 8 - APW + 1 : n;   // units APW .. 8 requested weight pieces only
-  return n;
-}
-// last slab of a workgroup's last tile: no halo pieces, no weight pieces beyond the last unit
-constexpr int pp_wait_nonext(int t) {
-  int n = 0;
-  for (int k = t - (DPF - 2); k <= t; ++k)
-    if (k + DPF <= 8) ++n;     // (k < 0: a unit of the previous slab, which requested its weight piece)
-  return n;
-}
-static_assert(pp_wait_normal(0) == 4 && pp_wait_normal(3) == 7 && pp_wait_normal(8) == 3, "wait table");
-static_assert(pp_wait_nonext(0) == 3 && pp_wait_nonext(5) == 2 && pp_wait_nonext(7) == 0, "wait table");
+  static constexpr int na_before(int p) {   // halo pieces requested in phases < p of the same slab
+    int n = 0;
+    for (int k = 0; k < p; ++k) n += na(k);
+    return n;
+  }
+  static constexpr int nb(int grp) {   // weight pieces a wave of group grp requests per phase
+    int n = 0;
+    for (int j = 0; j < NBJ; ++j)
+      if (grp * 4 + 8 * j < BPP) ++n;   // (piece index = wave + 8 j; the waves of a group have the same count)
+    return n;
+  }
+  // vmcnt(N) at the end of the read phase p.  A wave requests per phase [its weight pieces of phase p + DPH][its halo pieces
+  // na(p) of the next slab].  Before the barrier that precedes any read of phase p + 1, the wave's own pieces of phase
+  // p + 1 (requested in phase p + 1 - DPH) must have landed: what may stay in flight is everything younger.  Before a
+  // slab's first phase the whole patch of that slab must be in as well.
+  static constexpr int wait_normal(int p, int grp) {
+    int n = na((p + 1 - DPH + 9 * NPH) % NPH);
+    for (int k = p + 2 - DPH; k <= p; ++k) n += nb(grp) + na((k + 9 * NPH) % NPH);
+    if (p == NPH - 1) {
+      int last = 0;
+      for (int k = 0; k < NPH; ++k)
+        if (na(k) > 0) last = k;
+      const int m = (NPH - 1 - last) * nb(grp);
+      if (m < n) n = m;
+    }
+    return n;
+  }
+  // last slab of a workgroup's last tile: no halo pieces, no weight pieces beyond the last phase
+  static constexpr int wait_nonext(int p, int grp) {
+    int n = 0;
+    if (p + 1 - DPH < 0) n += na((p + 1 - DPH + 9 * NPH) % NPH);   // (a phase of the previous slab: that one was normal)
+    for (int k = p + 2 - DPH; k <= p; ++k) {
+      if (k < 0) n += nb(grp) + na((k + 9 * NPH) % NPH);
+      else if (k + DPH < NPH) n += nb(grp);
+    }
+    return n;
+  }
+};
+typedef PpCfg<16, 32, 4, 2, 1> Cfg512;
+static_assert(Cfg512::wait_normal(0, 0) == 4 && Cfg512::wait_normal(3, 1) == 7 && Cfg512::wait_normal(8, 0) == 3, "wait table");
+static_assert(Cfg512::wait_nonext(0, 0) == 3 && Cfg512::wait_nonext(5, 0) == 2 && Cfg512::wait_nonext(7, 1) == 0, "wait table");
+static_assert(Cfg512::SMEM_BYTES == 163328 && Cfg512::NSTORE == 16, "512 x 128 configuration");
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff, unsigned soff) {
   // one wave-instruction: lane i writes LDS bytes [base + 16 i, +16) with the 16 bytes at voff + soff (zeros when out of
@@ -112,23 +169,25 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 #ifndef UZ_PP_SKEL
 #define UZ_PP_SKEL 0   // measurement builds: 1 no fragment reads, 2 no MFMAs, 4 no DMA after the prologue, 8 no epilogue,
-                      // 16 fragment reads in a tile's first unit only, 32 no s_setprio, 64 no lgkmcnt wait before the barrier
-                      // (after it instead), 128 both groups in lockstep (timing only)
+                      // 16 fragment reads in a tile's first phase only, 128 both groups in lockstep (timing only)
 #endif
 
-// S16: v_mfma_f32_16x16x32_bf16 (a unit = 32 MFMAs of 16 cycles) instead of 32x32x16 (16 of 32 cycles): same fragment
-// bytes and accumulator count, half the accumulator traffic per flop; the chip holds a higher clock on that stream.
-template <bool BNRED, bool S16>
+template <typename C, bool BNRED>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   typedef bf16_t T;
   constexpr int ES = 2, VEC = 8;
-  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
+  constexpr int TH = C::TH, TW = C::TW, PH = C::PH, PHP = C::PHP, PROWS = C::PROWS, APIECES = C::APIECES, A_BYTES = C::A_BYTES;
+  constexpr int APW = C::APW, BN = C::BN, B_UNIT = C::B_UNIT, BPU = C::BPU, NPH = C::NPH, BPP = C::BPP, NBJ = C::NBJ;
+  constexpr int NSLOT = C::NSLOT, DPH = C::DPH, UPP = C::UPP, ROWS_W = C::ROWS_W, HALVES = C::HALVES, PT = C::PT, CT = C::CT;
+  constexpr int OFF_B = C::OFF_B, OFF_STG = C::OFF_STG, OFF_SCR = C::OFF_SCR, OFF_BIAS = C::OFF_BIAS, NSTORE = C::NSTORE;
+  constexpr int SLOT_BYTES = UPP * B_UNIT;
+  __shared__ __attribute__((aligned(1024))) char smem[C::SMEM_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                  // ping-pong group: waves w and w + 4 share a SIMD
-  const int wm = wave >> 1, wn = wave & 1;    // wave tile: patch rows 4 wm .. 4 wm + 3, channels 64 wn .. 64 wn + 63
-  const int l31 = lane & 31, lh = lane >> 5;
+  const int grp = wave >> 2;                                  // ping-pong group: waves w and w + 4 share a SIMD
+  const int wm = C::WN == 2 ? wave >> 1 : wave, wn = C::WN == 2 ? wave & 1 : 0;   // wave tile: patch rows ROWS_W wm .., channels 64 wn ..
+  const int l15 = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
@@ -136,44 +195,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   const unsigned smem_u = (unsigned)(size_t)(lds_char_ptr)smem;
 
   // ---- fragment read addresses -------------------------------------------------------------------------------------
-  // patch pixel (pi, pj) lives in LDS row pj * PHP + pi; weight rows are output channels.  A row's four 16-byte chunks
-  // are permuted with a key of the patch column / channel (swz()), the same on the DMA source side and on the read.
-  // 32x32x16: a lane reads pixel column l31 + tx, K chunk 2 q + lh: one base per (tx, q); the patch row 4 wm + i + ty
-  // is an immediate offset.  16x16x32: a lane reads pixel column (lane & 15) + 16 h + tx, K chunk lane >> 4: one base
-  // per tx; patch row and column half h are immediate offsets (16 columns further the key is the same).
-  // XOR with (col >> 2) & 3 is conflict-free for the 32-row reads at every tap shift; the 16-row reads (two K chunks per
-  // 16-lane group) need the rotation by 2 * (col >> 2).
-  auto swz = [](int chunk, int col) { return S16 ? ((chunk + 2 * (col >> 2)) & 3) : (chunk ^ ((col >> 2) & 3)); };
-  auto unswz = [](int phys, int col) { return S16 ? ((phys - 2 * (col >> 2)) & 3) : (phys ^ ((col >> 2) & 3)); };
-  const int l15 = lane & 15, lq = lane >> 4;
-  unsigned a_base[3][2], b_base[2];
+  // patch pixel (pi, pj) lives in LDS row pj * PHP + pi; weight rows are output channels.  A row's four 16-byte chunks are
+  // rotated by 2 * (col >> 2), col = patch column / channel, on the DMA source side and on the read alike.  A lane reads
+  // pixel column (lane & 15) + 16 h + tx, K chunk lane >> 4: one base per tx; patch row and column half h are immediate
+  // offsets (16 columns further the rotation is the same).
+  auto swz = [](int chunk, int col) { return (chunk + 2 * (col >> 2)) & 3; };
+  auto unswz = [](int phys, int col) { return (phys - 2 * (col >> 2)) & 3; };
+  unsigned a_base[3], b_base;
 #pragma unroll
-  for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if constexpr (S16) {
-        const int pj = l15 + tx;
-        a_base[tx][q] = smem_u + (pj * PHP + 4 * wm) * RB + (swz(lq, pj) << 4);
-      } else {
-        const int pj = l31 + tx;
-        a_base[tx][q] = smem_u + (pj * PHP + 4 * wm) * RB + (swz(2 * q + lh, pj) << 4);
-      }
-    }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if constexpr (S16) {
-      const int brow = wn * 64 + l15;
-      b_base[q] = smem_u + OFF_B + brow * RB + (swz(lq, brow) << 4);
-    } else {
-      const int brow = wn * 64 + l31;
-      b_base[q] = smem_u + OFF_B + brow * RB + (swz(2 * q + lh, brow) << 4);
-    }
+  for (int tx = 0; tx < 3; ++tx) {
+    const int pj = l15 + tx;
+    a_base[tx] = smem_u + (pj * PHP + ROWS_W * wm) * RB + (swz(lq, pj) << 4);
+  }
+  {
+    const int brow = wn * 64 + l15;
+    b_base = smem_u + OFF_B + brow * RB + (swz(lq, brow) << 4);
   }
   // ---- LDS-DMA source offsets --------------------------------------------------------------------------------------
-  // weight piece `wave` of a slot: rows 16 wave + (lane >> 2), this lane fetches the chunk that belongs at (lane & 3)
+  // weight piece wave + 8 j of a phase: unit (wave + 8 j) / BPU, rows 16 ((wave + 8 j) % BPU) + (lane >> 2): the row part is
+  // the same for every j (BPU divides 8); this lane fetches the chunk that belongs at (lane & 3)
   unsigned bvoff;
   {
-    const int brow = wave * 16 + (lane >> 2);
+    const int brow = (wave % BPU) * 16 + (lane >> 2);
     bvoff = (n0 + brow < a.Nout) ? ((unsigned)(n0 + brow) * (unsigned)a.K * ES + (unswz(lane & 3, brow) << 4)) : OOB;
   }
   unsigned avoff[APW];   // halo pieces wave + 8 k of the tile whose patches are being requested (channel slab 0)
@@ -195,12 +238,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   };
   auto issue_a = [&](auto kc, int buf, int cslab) {
     constexpr int k = decltype(kc)::value;
-    const int piece = wave + 8 * k;
-    char* dst = piece < APIECES ? smem + buf * A_BYTES + piece * 1024 : smem + OFF_SCR;
-    dma16(xr, dst, avoff[k], (unsigned)(cslab * KU * ES));
+    if constexpr (k < APW) {
+      const int piece = wave + 8 * k;
+      char* dst = piece < APIECES ? smem + buf * A_BYTES + piece * 1024 : smem + OFF_SCR;
+      dma16(xr, dst, avoff[k], (unsigned)(cslab * KU * ES));
+    }
   };
-  auto issue_b = [&](int slot, int cslab, int tap) {
-    dma16(wr, smem + OFF_B + slot * B_SLOT + wave * 1024, bvoff, (unsigned)((tap * a.Cin + cslab * KU) * ES));
+  // weight pieces of phase ph (units UPP ph .. UPP ph + UPP - 1 of slab cslab) into ring slot `slot`
+  auto issue_b = [&](int slot, int cslab, int ph) {
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const int idx = wave + 8 * j;
+      if (idx < BPP) {   // wave-uniform
+        const int tap = UPP * ph + idx / BPU;
+        dma16(wr, smem + OFF_B + slot * SLOT_BYTES + idx * 1024, bvoff, (unsigned)((tap * a.Cin + cslab * KU) * ES));
+      }
+    }
   };
   auto decode = [&](int tile, int& im, int& hh0, int& ww0) {
     const int per = a.th_n * a.tw_n;
@@ -211,195 +264,156 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     ww0 = (rem - ti * a.tw_n) * TW;
   };
 
-  // bias table (fp32, 128 channels of this workgroup): the accumulators' initial value
+  // bias table (fp32, the channels of this workgroup): the accumulators' initial value
   float* const sBias = reinterpret_cast<float*>(smem + OFF_BIAS);
   if (tid < BN) sBias[tid] = (!BNRED && a.bias != nullptr && n0 + tid < a.Nout) ? a.bias[n0 + tid] : 0.f;
-
-  const int ncb = a.Cin / KU;
-  // 32x32x16: acc[i][j] = patch row 4 wm + i x channels 32 j (16 registers); fa[q][i], fb[q][j]
-  // 16x16x32: accs[2 i + h][ct] = patch row i, column half h x channels 16 ct (4 registers); fa[h][i], fb[ct >> 1][ct & 1]
-  f32x16 acc[4][2];
-  f32x4 accs[S16 ? 8 : 1][4];
-  f32x4 fa[2][4], fb[2][2];
   {   // running BatchNorm sums of this lane (channel chunk lane & 7 of the read-back phase): zero, in the staging strip
     f32x4* sp = reinterpret_cast<f32x4*>(smem + OFF_STG + wave * STG_W + lane * 64);
     sp[0] = sp[1] = sp[2] = sp[3] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  const int ncb = a.Cin / KU;
+  // acc[pt][ct]: 16-pixel tile pt = HALVES * (patch row of the wave) + column half, 16-channel tile ct
+  f32x4 acc[PT][CT];
+  f32x4 fa[UPP][PT], fb[UPP][CT];
+
   int apar = 0;    // patch buffer of the current slab
-  int bslot = 0;   // weight slot of the current unit
+  int bslot = 0;   // weight slot of the current phase
   int img = 0, h0 = 0, w0 = 0, nim = 0, nh0 = 0, nw0 = 0;
 
-  // ---- prologue: first patch, first DPF weight tiles ------------------------------------------------------------------
+  // ---- prologue: first patch, first DPH weight phases -------------------------------------------------------------------
+  static_assert(DPH <= NPH, "the weight prefetch spans at most one slab boundary");
   if ((int)blockIdx.x < a.ntiles) {
     decode(blockIdx.x, img, h0, w0);
     compute_avoff(img, h0, w0);
     issue_a(IntC<0>(), 0, 0); issue_a(IntC<1>(), 0, 0); issue_a(IntC<2>(), 0, 0);
     issue_a(IntC<3>(), 0, 0); issue_a(IntC<4>(), 0, 0); issue_a(IntC<5>(), 0, 0);
+    static_assert(APW <= 6, "prologue issues six halo pieces per wave");
 #pragma unroll
-    for (int u = 0; u < DPF; ++u) issue_b(u, 0, u);
+    for (int u = 0; u < DPH; ++u) issue_b(u, 0, u);
   }
   wait_vmcnt<0>();
   __syncthreads();
 
-  // ---- one unit ---------------------------------------------------------------------------------------------------------
+  // ---- one phase ---------------------------------------------------------------------------------------------------------
   // c: slab of this tile, first: c == 0 (the previous tile's stores are among the young requests), last: c == ncb - 1,
-  // has_next: another tile follows.  INIT: first unit of a tile (the MFMAs start from the bias).
-  auto unit = [&](auto tc, auto initc, int c, bool first, bool last, bool has_next) __attribute__((always_inline)) {
-    constexpr int t = decltype(tc)::value;
+  // has_next: another tile follows.  INIT: first phase of a tile (the MFMAs start from the bias).
+  auto phase = [&](auto pc, auto initc, int c, bool first, bool last, bool has_next) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
     constexpr bool INIT = decltype(initc)::value != 0;
-    constexpr int ty = t / 3, tx = t - 3 * ty;
     if (grp == 1 && !(UZ_PP_SKEL & 128)) __builtin_amdgcn_s_barrier();
     // ---- read phase (the other group computes) ----
-    f32x16 cinit[2];
-    f32x4 cinit4[4];
+    f32x4 cinit[CT];
     if constexpr (INIT) {
-      if constexpr (S16) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) cinit4[ct] = *reinterpret_cast<const f32x4*>(sBias + wn * 64 + ct * 16 + 4 * lq);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sBias + wn * 64 + j * 32 + 8 * q + 4 * lh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cinit[j][4 * q + e] = b4[e];
-          }
-      }
+      for (int ct = 0; ct < CT; ++ct) cinit[ct] = *reinterpret_cast<const f32x4*>(sBias + wn * 64 + ct * 16 + 4 * lq);
     }
     if (!(UZ_PP_SKEL & 1) && (!(UZ_PP_SKEL & 16) || INIT)) {
-      const unsigned aoff = (unsigned)(apar * A_BYTES), boff = (unsigned)(bslot * B_SLOT);
-      if constexpr (S16) {
-        const unsigned va = a_base[tx][0] + aoff, vb = b_base[0] + boff;
-        lds_read16<(0 + ty) * RB>(fa[0][0], va);
-        lds_read16<(0 + ty) * RB + 16 * PHP * RB>(fa[1][0], va);
-        lds_read16<0>(fb[0][0], vb);
-        lds_read16<16 * RB>(fb[0][1], vb);
-        lds_read16<32 * RB>(fb[1][0], vb);
-        lds_read16<48 * RB>(fb[1][1], vb);
-        lds_read16<(1 + ty) * RB>(fa[0][1], va);
-        lds_read16<(1 + ty) * RB + 16 * PHP * RB>(fa[1][1], va);
-        lds_read16<(2 + ty) * RB>(fa[0][2], va);
-        lds_read16<(2 + ty) * RB + 16 * PHP * RB>(fa[1][2], va);
-        lds_read16<(3 + ty) * RB>(fa[0][3], va);
-        lds_read16<(3 + ty) * RB + 16 * PHP * RB>(fa[1][3], va);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const unsigned va = a_base[tx][q] + aoff, vb = b_base[q] + boff;
-          lds_read16<(0 + ty) * RB>(fa[q][0], va);
-          lds_read16<(1 + ty) * RB>(fa[q][1], va);
-          lds_read16<(2 + ty) * RB>(fa[q][2], va);
-          lds_read16<(3 + ty) * RB>(fa[q][3], va);
-          lds_read16<0>(fb[q][0], vb);
-          lds_read16<32 * RB>(fb[q][1], vb);
+      const unsigned aoff = (unsigned)(apar * A_BYTES), boff = (unsigned)(bslot * SLOT_BYTES);
+      const unsigned vb = b_base + boff;
+      auto read_unit = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < UPP) {
+          constexpr int t = UPP * p + k, ty = t / 3, tx = t - 3 * ty;
+          const unsigned va = a_base[tx] + aoff;
+          auto rd_a = [&](auto ptc) __attribute__((always_inline)) {
+            constexpr int pt = decltype(ptc)::value;
+            if constexpr (pt < PT) lds_read16<(pt / HALVES + ty) * RB + (pt % HALVES) * 16 * PHP * RB>(fa[k][pt], va);
+          };
+          rd_a(IntC<0>()); rd_a(IntC<1>());
+          lds_read16<k * B_UNIT + 0 * 16 * RB>(fb[k][0], vb);
+          lds_read16<k * B_UNIT + 1 * 16 * RB>(fb[k][1], vb);
+          lds_read16<k * B_UNIT + 2 * 16 * RB>(fb[k][2], vb);
+          lds_read16<k * B_UNIT + 3 * 16 * RB>(fb[k][3], vb);
+          rd_a(IntC<2>()); rd_a(IntC<3>()); rd_a(IntC<4>()); rd_a(IntC<5>()); rd_a(IntC<6>()); rd_a(IntC<7>());
         }
-      }
+      };
+      read_unit(IntC<0>()); read_unit(IntC<1>()); read_unit(IntC<2>());
     }
     const bool nonext = last && !has_next;
     if (!(UZ_PP_SKEL & 4)) {
-      // weight piece of unit + DPF
-      constexpr int tn = (t + DPF) % 9;
-      constexpr bool wrap = t + DPF >= 9;
-      int sl = bslot + DPF;
+      // weight pieces of phase p + DPH
+      constexpr int pn = (p + DPH) % NPH;
+      constexpr bool wrap = p + DPH >= NPH;
+      int sl = bslot + DPH;
       sl = sl >= NSLOT ? sl - NSLOT : sl;
-      if (!wrap) issue_b(sl, c, tn);
-      else if (!last) issue_b(sl, c + 1, tn);
-      else if (has_next) issue_b(sl, 0, tn);
-      // halo piece t of the next slab (of this tile, or slab 0 of the next tile: avoff then holds that tile's offsets)
-      if constexpr (t < APW) {
-        if (!nonext) issue_a(IntC<t>(), apar ^ 1, last ? 0 : c + 1);
+      if (!wrap) issue_b(sl, c, pn);
+      else if (!last) issue_b(sl, c + 1, pn);
+      else if (has_next) issue_b(sl, 0, pn);
+      // halo pieces of the next slab (of this tile, or slab 0 of the next tile: avoff then holds that tile's offsets)
+      if (!nonext) {
+        constexpr int k0 = C::na_before(p), kn = C::na(p);
+        const int cs = last ? 0 : c + 1;
+        if constexpr (kn > 0) issue_a(IntC<k0>(), apar ^ 1, cs);
+        if constexpr (kn > 1) issue_a(IntC<k0 + 1>(), apar ^ 1, cs);
+        if constexpr (kn > 2) issue_a(IntC<k0 + 2>(), apar ^ 1, cs);
+        static_assert(kn <= 3, "at most three halo pieces per wave and phase");
       }
     }
     {
-      constexpr int NW = pp_wait_normal(t), NN = pp_wait_nonext(t);
-      if (nonext) {
-        if (t <= DPF - 2 && first) wait_vmcnt<NN + NSTORE>();
-        else wait_vmcnt<NN>();
-      } else {
-        if (t <= DPF - 2 && first) wait_vmcnt<NW + NSTORE>();
-        else wait_vmcnt<NW>();
-      }
+      auto waits = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int NW = C::wait_normal(p, g), NN = C::wait_nonext(p, g);
+        if (nonext) {
+          if (p <= DPH - 2 && first) wait_vmcnt<NN + NSTORE>();
+          else wait_vmcnt<NN>();
+        } else {
+          if (p <= DPH - 2 && first) wait_vmcnt<NW + NSTORE>();
+          else wait_vmcnt<NW>();
+        }
+      };
+      if (C::nb(0) == C::nb(1) || grp == 0) waits(IntC<0>());
+      else waits(IntC<1>());
     }
-    if (!(UZ_PP_SKEL & 64)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (UZ_PP_SKEL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- compute phase ----
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int k = 0; k < UPP; ++k) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pin16(fa[q][i]);
+      for (int pt = 0; pt < PT; ++pt) pin16(fa[k][pt]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) pin16(fb[q][j]);
+      for (int ct = 0; ct < CT; ++ct) pin16(fb[k][ct]);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!(UZ_PP_SKEL & 2)) {
-      if (!(UZ_PP_SKEL & 32)) __builtin_amdgcn_s_setprio(1);
-      if constexpr (S16) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int k = 0; k < UPP; ++k)
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+        for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-              const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[ct >> 1][ct & 1]);
-              const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[h][i]);
-              accs[2 * i + h][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, INIT ? cinit4[ct] : accs[2 * i + h][ct], 0, 0, 0);
-            }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[q][j]);
-              const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[q][i]);
-              if (INIT && q == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, cinit[j], 0, 0, 0);
-              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[i][j], 0, 0, 0);
-            }
-      }
-      if (!(UZ_PP_SKEL & 32)) __builtin_amdgcn_s_setprio(0);
+          for (int ct = 0; ct < CT; ++ct) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[k][ct]);
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[k][pt]);
+            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, (INIT && k == 0) ? cinit[ct] : acc[pt][ct], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
     } else if (INIT) {
-      if constexpr (S16) {
 #pragma unroll
-        for (int pt = 0; pt < 8; ++pt)
+      for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) accs[pt][ct] = cinit4[ct];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = cinit[j];
-      }
+        for (int ct = 0; ct < CT; ++ct) acc[pt][ct] = cinit[ct];
     }
     __builtin_amdgcn_sched_barrier(0);
     bslot = bslot + 1 == NSLOT ? 0 : bslot + 1;
-  };
-  // the barrier after a compute phase is the partner's barrier before its next read phase: group 0 executes it here,
-  // group 1 at the top of unit(); after a tile's last unit group 0 still executes it (group 1's matching one opens the
-  // next tile), so both groups meet 18 * ncb barriers per tile
-  auto tail_barrier = [&]() {
+    // the barrier after a compute phase is the partner's barrier before its next read phase: group 0 executes it here,
+    // group 1 at the top of the next phase; after a tile's last phase group 0 still executes it (group 1's matching one
+    // opens the next tile), so both groups meet the same number of barriers per tile
     if (grp == 0 && !(UZ_PP_SKEL & 128)) __builtin_amdgcn_s_barrier();
   };
 
   // ---- wave-local epilogue ---------------------------------------------------------------------------------------------
   auto epilogue = [&](int im, int hh0, int ww0) {
     if (UZ_PP_SKEL & 8) {
-      if constexpr (S16) {
 #pragma unroll
-        for (int pt = 0; pt < 8; ++pt) asm volatile("" ::"v"(accs[pt][0]), "v"(accs[pt][1]), "v"(accs[pt][2]), "v"(accs[pt][3]));
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][0]), "v"(acc[i][1]));
-      }
+      for (int pt = 0; pt < PT; ++pt) asm volatile("" ::"v"(acc[pt][0]), "v"(acc[pt][1]), "v"(acc[pt][2]), "v"(acc[pt][3]));
       return;
     }
     char* const stg = smem + OFF_STG + wave * STG_W;
     int ln = lane;   // opaque: the address arithmetic of the epilogue must not live in registers through the main loop
     asm volatile("" : "+v"(ln));
-    const int l31 = ln & 31, lh = ln >> 5, l15 = ln & 15, lq = ln >> 4;
+    const int e15 = ln & 15, eq = ln >> 4;
     const int cc = ln & 7;
     const int nch = n0 + wn * 64 + cc * VEC;
     // this lane's running sums live in the staging strip between epilogues (16 registers the main loop needs)
@@ -426,40 +440,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
         *reinterpret_cast<f32x4*>(&bis[e]) = *reinterpret_cast<const f32x4*>(a.bn_invstd + ch0 + e);
       }
     }
+    // a round = two 16-pixel tiles = 32 pixels: one patch row (TW 32) or two (TW 16)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int hh = hh0 + 4 * wm + i;
+    for (int r = 0; r < PT / 2; ++r) {
+      // pixel q = 0 .. 31 of the round
+      auto pix_h = [&](int q) { return hh0 + ROWS_W * wm + (TW == 32 ? r : 2 * r + (q >> 4)); };
+      auto pix_w = [&](int q) { return ww0 + (TW == 32 ? q : (q & 15)); };
       Vec16<T> yb[4];
       if constexpr (BNRED) {
         const T* __restrict__ by = static_cast<const T*>(a.bn_y);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int hc = min(hh, a.H - 1), wc = min(ww0 + (ln >> 3) + 8 * k, a.W - 1);   // clamped: unused outside the image
+          const int q = (ln >> 3) + 8 * k;
+          const int hc = min(pix_h(q), a.H - 1), wc = min(pix_w(q), a.W - 1);   // clamped: unused outside the image
           yb[k] = ld16(by + ((size_t)(im * a.H + hc) * a.W + wc) * a.ld_bny + (nch < a.Nout ? nch : 0));
         }
       }
-      // stage: a lane holds 4 consecutive channels of one pixel per register quad -> one 8-byte LDS write
-      if constexpr (S16) {
+      // stage: a lane holds 4 consecutive channels of one pixel per accumulator -> one 8-byte LDS write
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            bf16x4 pk;
+        for (int ct = 0; ct < CT; ++ct) {
+          bf16x4 pk;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)accs[2 * i + h][ct][e];
-            *reinterpret_cast<bf16x4*>(stg + (16 * h + l15) * STG_ROW + (16 * ct + 4 * lq) * ES) = pk;
-          }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            bf16x4 pk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)acc[i][j][4 * q + e];
-            *reinterpret_cast<bf16x4*>(stg + l31 * STG_ROW + (32 * j + 8 * q + 4 * lh) * ES) = pk;
-          }
-      }
+          for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)acc[2 * r + h][ct][e];
+          *reinterpret_cast<bf16x4*>(stg + (16 * h + e15) * STG_ROW + (16 * ct + 4 * eq) * ES) = pk;
+        }
       // read back: lane = (pixel (lane >> 3) + 8 k, channel chunk lane & 7); LDS operations of one wave execute in order
       Vec16<T> vb[4];
 #pragma unroll
@@ -467,10 +473,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
         vb[k] = *reinterpret_cast<const Vec16<T>*>(stg + ((ln >> 3) + 8 * k) * STG_ROW + cc * 16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int ww = ww0 + (ln >> 3) + 8 * k;
+        const int q = (ln >> 3) + 8 * k;
+        const int hh = pix_h(q), ww = pix_w(q);
         const bool inside = hh < a.H && ww < a.W && nch < a.Nout;
         // buffer stores executed by every lane (outside the image: out of range): exactly NSTORE vector-memory
-        // operations per wave and tile, which the counted waits of the next tile's first units allow for
+        // operations per wave and tile, which the counted waits of the next tile's first phases allow for
         const unsigned off = inside ? (unsigned)((((im * a.H + hh) * a.W + ww) * a.ldy + nch) * ES) : OOB;
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&vb[k]), yr, off, 0, 0);
         if (inside) {
@@ -512,17 +519,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       const bool first = c == 0, last = c == ncb - 1;
       // from the last slab on, the halo requests are those of the next tile's first patch
       if (last && has_next) compute_avoff(nim, nh0, nw0);
-      if (first) unit(IntC<0>(), IntC<1>(), c, first, last, has_next);
-      else unit(IntC<0>(), IntC<0>(), c, first, last, has_next);
-      tail_barrier();
-      unit(IntC<1>(), IntC<0>(), c, first, last, has_next); tail_barrier();
-      unit(IntC<2>(), IntC<0>(), c, first, last, has_next); tail_barrier();
-      unit(IntC<3>(), IntC<0>(), c, first, last, has_next); tail_barrier();
-      unit(IntC<4>(), IntC<0>(), c, first, last, has_next); tail_barrier();
-      unit(IntC<5>(), IntC<0>(), c, first, last, has_next); tail_barrier();
-      unit(IntC<6>(), IntC<0>(), c, first, last, has_next); tail_barrier();
-      unit(IntC<7>(), IntC<0>(), c, first, last, has_next); tail_barrier();
-      unit(IntC<8>(), IntC<0>(), c, first, last, has_next); tail_barrier();
+      if (first) phase(IntC<0>(), IntC<1>(), c, first, last, has_next);
+      else phase(IntC<0>(), IntC<0>(), c, first, last, has_next);
+      phase(IntC<1>(), IntC<0>(), c, first, last, has_next);
+      phase(IntC<2>(), IntC<0>(), c, first, last, has_next);
+      if constexpr (NPH == 9) {
+        phase(IntC<3>(), IntC<0>(), c, first, last, has_next);
+        phase(IntC<4>(), IntC<0>(), c, first, last, has_next);
+        phase(IntC<5>(), IntC<0>(), c, first, last, has_next);
+        phase(IntC<6>(), IntC<0>(), c, first, last, has_next);
+        phase(IntC<7>(), IntC<0>(), c, first, last, has_next);
+        phase(IntC<8>(), IntC<0>(), c, first, last, has_next);
+      }
+      static_assert(NPH == 9 || NPH == 3, "phases per slab");
       apar ^= 1;
     }
     if constexpr (BNRED) wait_vmcnt<0>();   // (the epilogue's own loads would make the compiler wait for everything anyway)
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     w0 = nw0;
   }
 
-  // ---- statistics: fixed-order sum over the 32 lanes (4 waves x 8 pixel groups) that own a channel chunk ---------------------
+  // ---- statistics: fixed-order sum over the lanes that own a channel chunk ---------------------------------------------------
   if (a.stats != nullptr) {
     wait_vmcnt<0>();
     __syncthreads();
@@ -542,43 +551,62 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       const int which = tid / BN, ch = tid - which * BN;
       const int cwn = ch >> 6, cc = (ch & 63) >> 3, e = ch & 7;
       float t = 0.f;
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < C::WM; ++m)
         for (int l = 0; l < 8; ++l) {
-          const int th = ((2 * m + cwn) << 6) + l * 8 + cc;
-          t += red(th, which * VEC + e);
+          const int w = C::WN == 2 ? 2 * m + cwn : m;
+          t += red((w << 6) + l * 8 + cc, which * VEC + e);
         }
       if (n0 + ch < a.Nout) a.stats[((size_t)blockIdx.x * 2 + which) * a.Nout + n0 + ch] = t;
     }
   }
 }
 
+typedef PpCfg<16, 32, 8, 1, 3> Cfg512x64;
+typedef PpCfg<8, 32, 4, 2, 3> Cfg256;
+typedef PpCfg<16, 16, 4, 2, 3> Cfg256w16;
+
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------------------------------------
-// returns 1 and fills the plan when the ping-pong kernel takes this descriptor
+// returns 1 and fills the plan when a ping-pong configuration takes this descriptor
 int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p) {
   const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
   if (d->dtype != UZ_BF16) return 0;
   if (!(d->taps_mode == UZ_TAPS_CONV || up) || d->ntaps != 9 || d->dil != 1 || d->store_mode != UZ_STORE_PLAIN) return 0;
   if (up && ((d->H & 1) || (d->W & 1) || d->Hin * 2 != d->H || d->Win * 2 != d->W)) return 0;
   if (d->Cin % KU != 0 || d->Nout % 8 != 0 || d->ldy % 8 != 0 || d->ldx % 8 != 0) return 0;
-  if (d->Nout < 128 || d->W < 32 || d->H < 16) return 0;
   const long long xbytes = ((long long)d->N * d->Hin * d->Win - 1) * d->ldx * 2 + (long long)d->Cin * 2;
   const long long wbytes = (long long)d->Nout * 9 * d->Cin * 2;
   const long long ybytes = ((long long)d->N * d->H * d->W - 1) * d->ldy * 2 + (long long)d->Nout * 2;
   if (xbytes >= (1LL << 31) || wbytes >= (1LL << 31) || ybytes >= (1LL << 31)) return 0;
-  p->th_n = (d->H + TH - 1) / TH;
-  p->tw_n = (d->W + TW - 1) / TW;
-  p->ntiles = d->N * p->th_n * p->tw_n;
-  p->tiles_n = (d->Nout + BN - 1) / BN;
-  // worth it when the 512-pixel tiles still fill the chip: compare the rounds of the two tilings, the ping-pong
-  // round counted at 2 x 0.8 of a second-generation round (twice the pixels, measured ~20 % more MFMA throughput)
-  const long long t512 = (long long)p->ntiles * p->tiles_n;
-  const int tw2 = 32, th2 = 8;
-  const long long t256 = (long long)d->N * ((d->H + th2 - 1) / th2) * ((d->W + tw2 - 1) / tw2) * p->tiles_n;
-  const long long r512 = (t512 + UZ_NUM_CU - 1) / UZ_NUM_CU, r256 = (t256 + UZ_NUM_CU - 1) / UZ_NUM_CU;
-  if (!(uz_tune_flags() & 0x1000000) && r512 * 16 >= r256 * 10) return 0;
   if (uz_tune_flags() & 0x2000000) return 0;   // ablation build: keep the second-generation kernels
+  auto tiles = [&](int th, int tw) { return (long long)d->N * ((d->H + th - 1) / th) * ((d->W + tw - 1) / tw); };
+  auto rounds = [&](long long t) { return (t + UZ_NUM_CU - 1) / UZ_NUM_CU; };
+  int cfg = -1;
+  if (d->Nout >= 128) {
+    const int tn = (d->Nout + 127) / 128;
+    if (d->W >= 32 && d->H >= 8) {
+      // 512-pixel tiles when they still fill the chip: a round of them counted at 2 x 0.8 of a 256-pixel round (twice
+      // the pixels, ~20 % more throughput: fewer DMA bytes and fragment reads per MFMA)
+      const long long r512 = rounds(tiles(16, 32) * tn), r256 = rounds(tiles(8, 32) * tn);
+      cfg = (d->H >= 16 && (r512 * 16 < r256 * 10 || (uz_tune_flags() & 0x1000000))) ? UZ_PP_512 : UZ_PP_256;
+      if (cfg == UZ_PP_256 && (uz_tune_flags() & 0x8000000)) cfg = -1;   // ablation build: 256-pixel tiles on the old kernels
+    } else if (d->W >= 9 && d->W <= 16 && d->H >= 8) {
+      cfg = UZ_PP_256W16;
+      if (uz_tune_flags() & 0x8000000) cfg = -1;
+    }
+  } else if (d->Nout > 32 && d->W >= 32 && d->H >= 16) {
+    // 64 output channels: 512-pixel tiles; small problems stay on the second-generation kernels
+    if (tiles(16, 32) >= UZ_NUM_CU / 2 && !(uz_tune_flags() & 0x10000000)) cfg = UZ_PP_512X64;
+  }
+  if (cfg < 0) return 0;
+  const int th = cfg == UZ_PP_256 ? 8 : 16, tw = cfg == UZ_PP_256W16 ? 16 : 32, bn = cfg == UZ_PP_512X64 ? 64 : 128;
+  p->cfg = cfg;
+  p->bn = bn;
+  p->th_n = (d->H + th - 1) / th;
+  p->tw_n = (d->W + tw - 1) / tw;
+  p->ntiles = d->N * p->th_n * p->tw_n;
+  p->tiles_n = (d->Nout + bn - 1) / bn;
   int cap = UZ_NUM_CU / p->tiles_n;
   if (cap < 1) cap = 1;
   p->grid_m = p->ntiles < cap ? p->ntiles : cap;
@@ -616,16 +644,19 @@ int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const 
   a.ld_bny = br ? br->ldy : 0;
   if (br) UZ_REQUIRE(stats != nullptr, "uz_conv_igemm_bnred: partial rows missing");
   dim3 grid(p.grid_m, p.tiles_n), block(512);
-#ifdef UZ_ABLATE
-  if (uz_tune_flags() & 0x4000000) {   // the 32x32x16 stream
-    if (br) hipLaunchKernelGGL((conv3x3_pp_kernel<true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_pp_kernel<false, false>), grid, block, 0, s, a);
-    UZ_LAUNCH_CHECK("uz_conv_igemm(direct3x3 ping-pong 32x32x16)");
-    return UZ_OK;
+#define UZ_PP_GO(CFG)                                                                          \
+  do {                                                                                         \
+    if (br) hipLaunchKernelGGL((conv3x3_pp_kernel<CFG, true>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((conv3x3_pp_kernel<CFG, false>), grid, block, 0, s, a);            \
+  } while (0)
+  switch (p.cfg) {
+    case UZ_PP_512: UZ_PP_GO(Cfg512); break;
+    case UZ_PP_512X64: UZ_PP_GO(Cfg512x64); break;
+    case UZ_PP_256: UZ_PP_GO(Cfg256); break;
+    case UZ_PP_256W16: UZ_PP_GO(Cfg256w16); break;
+    default: UZ_REQUIRE(false, "uz_conv_igemm(direct3x3 ping-pong): bad configuration %d", p.cfg);
   }
-#endif
-  if (br) hipLaunchKernelGGL((conv3x3_pp_kernel<true, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv3x3_pp_kernel<false, true>), grid, block, 0, s, a);
+#undef UZ_PP_GO
   UZ_LAUNCH_CHECK("uz_conv_igemm(direct3x3 ping-pong)");
   return UZ_OK;
 }

@@ -15,6 +15,7 @@
 // Each block walks several M tiles (persistent over M) so the per-channel BatchNorm partial
 // sums stay in registers and leave the block once, as one deterministic partial row.
 #include "uz_common.h"
+#include <string.h>
 
 namespace {
 
@@ -470,6 +471,31 @@ extern "C" int uz_conv_igemm_grid_m(const uz_conv_desc* d) {
   UzGemmPlan gp;
   if (uz_gemm_dma_plan(d, &gp)) return gp.grid_m;
   return p.grid_m;
+}
+
+extern "C" int uz_conv_igemm_kernel_name(const uz_conv_desc* d, int with_workspace, char* buf, int cap) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(buf != nullptr && cap > 0, "uz_conv_igemm_kernel_name: no buffer");
+  const char* dt = d->dtype == UZ_BF16 ? "bf16" : "f32";
+  char name[96];
+  UzDirectPlan dp;
+  UzGemmPlan gp;
+  if (uz_direct_plan(d, &dp)) {
+    const char* up = d->taps_mode == UZ_TAPS_CONV_UP2 ? "_up2" : "";
+    static const char* const ppn[4] = {"pp512", "pp512x64", "pp256", "pp256w16"};
+    if (dp.bres == 3) snprintf(name, sizeof(name), "conv3x3_%s_%s%s", ppn[dp.ppcfg & 3], dt, up);
+    else if (dp.bres == 2) snprintf(name, sizeof(name), "conv3x3_res64_%s%s", dt, up);
+    else snprintf(name, sizeof(name), "conv3x3_direct_%s_bn%d%s%s", dt, dp.bn, dp.bres == 1 ? "_resident" : "", up);
+  } else if (uz_gemm_dma_plan(d, &gp)) {
+    snprintf(name, sizeof(name), "gemm_dma_%s", dt);
+  } else {
+    snprintf(name, sizeof(name), "igemm_%s_128x%d%s", dt, p.bn, (p.split > 1 && with_workspace) ? "_tapsplit" : "");
+  }
+  const int len = (int)strlen(name);
+  snprintf(buf, (size_t)cap, "%s", name);
+  return len;
 }
 
 extern "C" long long uz_conv_igemm_workspace_bytes(const uz_conv_desc* d) {

@@ -203,6 +203,16 @@ def im2col3x3_nchw(x: torch.Tensor, kpad: int, dtype: torch.dtype) -> Act:
     return out
 
 
+def conv_kernel_name(d, with_workspace: bool = False) -> str:
+    """uz_conv_igemm_kernel_name(): the kernel family the library's plan picks for a ConvDesc (labels of the per-kernel
+    timing of bench.py; tests use it to assert which generation they exercise)"""
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    L.check_count(L.load().uz_conv_igemm_kernel_name(byref(d), 1 if with_workspace else 0, buf, 96),
+                  "uz_conv_igemm_kernel_name")
+    return buf.value.decode()
+
+
 def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: Act, *,
                ntaps: int, dil: int = 1, taps_mode: int = L.TAPS_CONV,
                store_mode: int = L.STORE_PLAIN, nout: Optional[int] = None, co: int = 0,
@@ -236,24 +246,7 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     wsb = L.check_count(lib.uz_conv_igemm_workspace_bytes(byref(d)), "uz_conv_igemm_workspace_bytes")
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.buf.device) if wsb > 0 else None
     M, K, es = N * H * W, ntaps * x.C, x.buf.element_size()
-    bn = 64 if d.Nout <= 64 else 128
-    vec = 16 // es
-    if (taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) and ntaps == 9 and dil == 1 and store_mode == L.STORE_PLAIN
-            and d.Nout % vec == 0 and y.ld % vec == 0):   # mirrors uz_direct_plan()
-        tw_ = 32 if W >= 32 else 16
-        ntl = N * ((H + 256 // tw_ - 1) // (256 // tw_)) * ((W + tw_ - 1) // tw_)
-        if bn == 128 and ntl * ((d.Nout + 127) // 128) <= 128:
-            bn = 64
-        kname = f"conv3x3_direct_{_tname(x.dtype)}_bn{bn}" + ("_resident" if (bn == 64 and x.C == 8 * vec) else "")
-        if taps_mode == L.TAPS_CONV_UP2:
-            kname += "_up2"
-    elif ((ntaps == 1 and taps_mode == L.TAPS_CONV) or (ntaps == 4 and taps_mode == L.TAPS_GATHER2X2)
-          or (ntaps == 9 and taps_mode == L.TAPS_CONV_S2)
-          or (ntaps == 9 and taps_mode == L.TAPS_CONV and dil > 1 and store_mode == L.STORE_PLAIN)) \
-            and d.Nout % vec == 0 and y.ld % vec == 0 and (store_mode == L.STORE_PLAIN or co % 64 == 0):
-        kname = f"gemm_dma_{_tname(x.dtype)}"            # mirrors uz_gemm_dma_plan()
-    else:
-        kname = f"igemm_{_tname(x.dtype)}_128x{bn}" + ("_tapsplit" if ws is not None else "")
+    kname = conv_kernel_name(d, ws is not None)   # the family the library's own plan launches for this descriptor
     if bnred is not None:
         assert bias is None and res is None and not want_stats
         bn_y, vec4 = bnred
