@@ -37,18 +37,29 @@ def kernel_of(N, H, W, Cin, ldx, Cout, ldy, up=False):
 
 
 CASES = [
-    # N, H, W, Cin, Cout, xwin, ups
-    (3, 128, 256, 64, 128, 0, False),     # 192 tiles on 256 CUs: one tile per workgroup (drain path), two slabs
-    (7, 128, 256, 32, 128, 0, False),     # 448 tiles: two tiles for some workgroups, ONE slab per tile (first == last)
-    (2, 120, 250, 96, 200, 0, False),     # ragged rows and columns, three slabs, channel tail in the second N tile
-    (6, 112, 224, 128, 136, 32, False),   # input = channel window of a wider NaN-poisoned buffer; 8-channel tail tile
-    (3, 128, 256, 64, 128, 0, True),      # nearest x2 upsampled input
-    (4, 64, 64, 256, 1024, 0, False),     # eight slabs, eight N tiles (the unet 512 -> 1024 input-gradient shape class)
+    # configuration, N, H, W, Cin, Cout, xwin, ups
+    ("pp512", 3, 128, 256, 64, 128, 0, False),     # 192 tiles on 256 CUs: one tile per workgroup (drain path), two slabs
+    ("pp512", 7, 128, 256, 32, 128, 0, False),     # 448 tiles: two tiles for some workgroups, ONE slab per tile (first == last)
+    ("pp512", 2, 120, 250, 96, 200, 0, False),     # ragged rows and columns, three slabs, channel tail in the second N tile
+    ("pp512", 6, 112, 224, 128, 136, 32, False),   # input = channel window of a wider NaN-poisoned buffer; 8-channel tail tile
+    ("pp512", 3, 128, 256, 64, 128, 0, True),      # nearest x2 upsampled input
+    ("pp512", 4, 64, 64, 256, 1024, 0, False),     # eight slabs, eight N tiles (the unet 512 -> 1024 input-gradient shape class)
+    ("pp512x64", 3, 128, 256, 128, 64, 0, False),  # 64 output channels: eight waves along the pixels, phases of one tap row
+    ("pp512x64", 2, 120, 250, 64, 40, 32, False),  # ragged, channel tail, window; one tile per workgroup
+    ("pp512x64", 9, 128, 256, 32, 64, 0, False),   # 576 tiles: up to three per workgroup, one slab per tile
+    ("pp256", 2, 40, 72, 128, 256, 0, False),      # 8 x 32 patches, ragged both ways, two N tiles
+    ("pp256", 1, 32, 32, 64, 128, 0, False),       # four tiles
+    ("pp256", 16, 32, 32, 256, 512, 0, False),     # unet level 4 at batch 16: one tile per workgroup, eight slabs
+    ("pp256", 2, 48, 64, 32, 128, 0, True),        # upsampled input, one slab
+    ("pp256", 40, 32, 32, 96, 512, 64, False),     # 160 tiles x 4 N tiles: the grid is capped at 64 workgroups per N tile, 2-3 tiles each
+    ("pp256w16", 4, 16, 16, 256, 384, 0, False),   # one 16 x 16 map per tile
+    ("pp256w16", 3, 12, 14, 128, 136, 0, False),   # ragged 16 x 16 patches, channel tail
+    ("pp256w16", 70, 16, 16, 64, 512, 0, False),   # 70 x 4 tiles: the grid is capped at 64 workgroups per N tile
 ]
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,win,ups", CASES)
-def test_pp_conv3x3_fwd_bias_stats(N, H, W, Cin, Cout, win, ups):
+@pytest.mark.parametrize("cfg,N,H,W,Cin,Cout,win,ups", CASES)
+def test_pp_conv3x3_fwd_bias_stats(cfg, N, H, W, Cin, Cout, win, ups):
     g = torch.Generator().manual_seed(21)
     Hi, Wi = (H // 2, W // 2) if ups else (H, W)
     x = rnd(torch.randn(N, Cin, Hi, Wi, generator=g))
@@ -65,7 +76,7 @@ def test_pp_conv3x3_fwd_bias_stats(N, H, W, Cin, Cout, win, ups):
     # the output is a channel window of a wider buffer too: the neighbours must stay untouched
     ywide = torch.full((N * H * W, Cout + 16), 7.0, dtype=dt, device=DEV)
     y = Act(ywide, 8, Cout, N, H, W)
-    assert kernel_of(N, H, W, Cin, xa.ld, Cout, y.ld, ups).startswith("conv3x3_pp")
+    assert kernel_of(N, H, W, Cin, xa.ld, Cout, y.ld, ups) == f"conv3x3_{cfg}_bf16" + ("_up2" if ups else "")
     stats = ops.conv_igemm(xa, wp, b.to(DEV), y, ntaps=9, want_stats=True,
                            taps_mode=L.TAPS_CONV_UP2 if ups else L.TAPS_CONV)
     got = y.dense().cpu()
@@ -102,8 +113,11 @@ def test_pp_conv3x3_exact_on_small_integers():
 
 
 @pytest.mark.parametrize("N,H,W,C,Cn", [
-    (3, 128, 256, 64, 128),     # one tile per workgroup
-    (6, 112, 224, 128, 136),    # two tiles for some, ragged, channel tail
+    (3, 128, 256, 64, 128),     # pp512, one tile per workgroup
+    (6, 112, 224, 128, 136),    # pp512, two tiles for some, ragged, channel tail
+    (3, 128, 256, 64, 64),      # pp512x64
+    (16, 32, 32, 128, 128),     # pp256
+    (5, 16, 16, 256, 256),      # pp256w16
 ])
 def test_pp_bn_backward_reduction_in_the_input_gradient_epilogue(N, H, W, C, Cn):
     """uz_conv_igemm_bnred on the ping-pong kernel: the gradient must be bit-identical to the plain launch, the
@@ -136,9 +150,15 @@ def test_pp_bn_backward_reduction_in_the_input_gradient_epilogue(N, H, W, C, Cn)
     assert relerr(out[1][1], out[0][1]) < 1e-2
 
 
-def test_pp_plan_leaves_small_problems_to_the_other_kernels():
-    """the plan hands a descriptor to the ping-pong kernel only when its 512-pixel tiles fill the chip"""
-    assert not kernel_of(1, 16, 32, 64, 64, 128, 128).startswith("conv3x3_pp")       # one tile
-    assert not kernel_of(16, 32, 32, 512, 512, 512, 512).startswith("conv3x3_pp")    # 128 tiles of 512 pixels on 256 CUs
-    assert not kernel_of(16, 256, 256, 64, 64, 64, 64).startswith("conv3x3_pp")      # 64 output channels
-    assert kernel_of(16, 128, 128, 128, 128, 128, 128).startswith("conv3x3_pp")      # unet level 2 at batch 16
+def test_pp_plan_picks_a_configuration_per_problem():
+    """uz_pp_plan(): 512-pixel tiles where they fill the chip, 256-pixel tiles on the small maps, 16 x 16 patches on
+    16-wide maps, the 64-channel configuration for 64 output channels; everything else stays on the other kernels"""
+    assert kernel_of(16, 128, 128, 128, 128, 128, 128) == "conv3x3_pp512_bf16"        # unet level 2 at batch 16
+    assert kernel_of(16, 32, 32, 512, 512, 512, 512) == "conv3x3_pp256_bf16"          # level 4: 128 tiles of 512 pixels would idle half the CUs
+    assert kernel_of(16, 16, 16, 1024, 1024, 1024, 1024) == "conv3x3_pp256w16_bf16"   # level 5
+    assert kernel_of(16, 256, 256, 128, 128, 64, 64) == "conv3x3_pp512x64_bf16"       # decoder level 1
+    assert not kernel_of(1, 32, 32, 64, 64, 64, 64).startswith("conv3x3_pp")          # 64 channels, two tiles
+    assert not kernel_of(2, 64, 64, 16, 16, 128, 128).startswith("conv3x3_pp")        # 16 input channels (u2net)
+    d = L.ConvDesc(L.dtype_code(torch.float32), 16, 128, 128, 128, 128, 128, 128, 128, 128, 9, L.TAPS_CONV, 1,
+                   L.STORE_PLAIN, 0, 0, 0)
+    assert not ops.conv_kernel_name(d).startswith("conv3x3_pp")                       # the fp32 parity mode
