@@ -346,12 +346,16 @@ def main():
         # prescribes for gfx950) -- counters cannot be read from inside this process
         traffic = None
         try:
-            pmc_file = next(n for n in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+            pmc_file = next(n for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", n)))
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)["kernels"]
             # (round-1 / round-2 spellings of the same kernels: round 2 added template parameters)
-            keys = {"conv3x3_direct_bf16_bn128": ("21conv3x3_direct_kernelIDF16bLi32ELi128ELb0ELb0EEEvNS_10DirectArgsE",
+            # (the family names are the library's own, uz_conv_igemm_kernel_name(); the PMC table is keyed by kernel symbol)
+            keys = {"conv3x3_pp512_bf16": ("PpCfg<16, 32, 4, 2, 1>, false>",),
+                    "conv3x3_pp512x64_bf16": ("PpCfg<16, 32, 8, 1, 3>, false>",),
+                    "conv3x3_pp256_bf16": ("PpCfg<8, 32, 4, 2, 3>, false>",),
+                    "conv3x3_direct_bf16_bn128": ("21conv3x3_direct_kernelIDF16bLi32ELi128ELb0ELb0EEEvNS_10DirectArgsE",
                                                   "21conv3x3_direct_kernelIDF16bLi32ELi128ELb0EEEvNS_10DirectArgsE"),
                     "wgrad3x3_bf16_128x128_3tap": ("wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1, 0>",
                                                    "wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>")}.get(dom_name, ())

@@ -109,3 +109,55 @@ def test_launch_module_cli(tmp_path):
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
     assert r.returncode == 0, r.stderr
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 2
+
+
+SLEEPER = textwrap.dedent('''
+    import os, sys, time
+    open(os.path.join(sys.argv[1], "pid_%s" % os.environ["RANK"]), "w").write(str(os.getpid()))
+    time.sleep(120)
+''')
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    # a zombie still answers kill(0): look at its state
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().split(") ")[1][0] != "Z"
+    except OSError:
+        return False
+
+
+@pytest.mark.parametrize("sig", ["TERM", "KILL"])
+def test_a_killed_launcher_leaves_no_rank_process_behind(tmp_path, sig):
+    """SIGTERM to `python -m unet_zoo_amd.launch` (a harness timeout, an operator) must take the rank processes down
+    with it -- they would otherwise keep their GPUs and sit in a rendezvous or a collective; SIGKILL too (the children
+    ask the kernel for SIGTERM on the launcher's death)"""
+    import signal as _signal
+    import time
+    script = os.path.join(tmp_path, "sleeper.py")
+    with open(script, "w") as f:
+        f.write(SLEEPER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.Popen([sys.executable, "-m", "unet_zoo_amd.launch", "--gpus", "2", "--cpu", script, str(tmp_path)],
+                         env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        deadline = time.time() + 60
+        while time.time() < deadline and not all(os.path.exists(os.path.join(tmp_path, f"pid_{r}")) for r in (0, 1)):
+            time.sleep(0.1)
+        pids = [int(open(os.path.join(tmp_path, f"pid_{r}")).read()) for r in (0, 1)]
+        assert all(_alive(q) for q in pids)
+        p.send_signal(_signal.SIGTERM if sig == "TERM" else _signal.SIGKILL)
+        rc = p.wait(timeout=30)
+        assert rc == (128 + _signal.SIGTERM if sig == "TERM" else -_signal.SIGKILL)
+        deadline = time.time() + 15
+        while time.time() < deadline and any(_alive(q) for q in pids):
+            time.sleep(0.1)
+        assert not any(_alive(q) for q in pids), "rank processes outlived the launcher"
+    finally:
+        if p.poll() is None:
+            p.kill()

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import os
 import socket
+import signal
 import subprocess
 import sys
 import threading
@@ -61,6 +62,15 @@ def _pump(stream, sink, prefix: str) -> None:
     stream.close()
 
 
+def _die_with_parent() -> None:
+    """child side, before exec: have the kernel send SIGTERM when the launcher dies (even by SIGKILL) -- Linux prctl"""
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(1, signal.SIGTERM)   # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
 def spawn_ranks(world: int, argv: Sequence[str], *, need_gpus: bool = True, port: Optional[int] = None,
                 env: Optional[Dict[str, str]] = None, poll_s: float = 0.1, stdout=None, stderr=None) -> int:
     """Run ``argv`` as `world` rank processes; returns the exit code the caller should exit with.
@@ -85,37 +95,69 @@ def spawn_ranks(world: int, argv: Sequence[str], *, need_gpus: bool = True, port
     port = free_port() if port is None else port
     procs: List[subprocess.Popen] = []
     pumps: List[threading.Thread] = []
-    for r in range(world):
-        p = subprocess.Popen(list(argv), env=rank_env(r, world, port, env), stdout=subprocess.PIPE,
-                             stderr=subprocess.PIPE, text=True, bufsize=1)
-        procs.append(p)
-        out_sink, out_prefix = (stdout, "") if r == 0 else (stderr, f"[rank {r}] ")
-        for stream, sink, prefix in ((p.stdout, out_sink, out_prefix), (p.stderr, stderr, f"[rank {r}] " if world > 1 else "")):
-            t = threading.Thread(target=_pump, args=(stream, sink, prefix), daemon=True)
-            t.start()
-            pumps.append(t)
     rc = 0
-    alive = set(range(world))
-    while alive:
-        for r in sorted(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                stderr.write(f"launch: rank {r} exited with code {code}; stopping the other ranks\n")
-                for o in sorted(alive):          # exact PIDs of our own children, never a pattern
-                    procs[o].terminate()
-        if alive:
+    stop = {"sig": 0}
+
+    def _on_signal(signum, _frame):      # SIGTERM / SIGINT to the launcher: stop the ranks, then leave with 128 + signum
+        stop["sig"] = signum
+
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGINT):
+            old_handlers[sg] = signal.signal(sg, _on_signal)
+
+    def _stop_children(grace_s: float = 10.0) -> None:
+        """terminate, then kill, every child still alive -- by the exact PIDs this function started, never a pattern"""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        deadline = time.time() + grace_s
+        while any(p.poll() is None for p in live) and time.time() < deadline:
             time.sleep(poll_s)
+        for p in live:
+            if p.poll() is None:
+                p.kill()
+        for p in live:
+            try:
+                p.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                pass
+
+    try:
+        for r in range(world):
+            p = subprocess.Popen(list(argv), env=rank_env(r, world, port, env), stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE, text=True, bufsize=1, preexec_fn=_die_with_parent)
+            procs.append(p)
+            out_sink, out_prefix = (stdout, "") if r == 0 else (stderr, f"[rank {r}] ")
+            for stream, sink, prefix in ((p.stdout, out_sink, out_prefix),
+                                         (p.stderr, stderr, f"[rank {r}] " if world > 1 else "")):
+                t = threading.Thread(target=_pump, args=(stream, sink, prefix), daemon=True)
+                t.start()
+                pumps.append(t)
+        alive = set(range(world))
+        while alive:
+            if stop["sig"]:
+                stderr.write(f"launch: signal {stop['sig']}; stopping the ranks\n")
+                rc = 128 + stop["sig"]
+                break
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    stderr.write(f"launch: rank {r} exited with code {code}; stopping the other ranks\n")
             if rc != 0:
-                deadline = time.time() + 10.0
-                while any(procs[o].poll() is None for o in alive) and time.time() < deadline:
-                    time.sleep(poll_s)
-                for o in alive:
-                    if procs[o].poll() is None:
-                        procs[o].kill()
+                break
+            if alive:
+                time.sleep(poll_s)
+    finally:
+        # whatever ended the loop -- a failed rank, a signal, Popen raising for rank k > 0, an exception in here --
+        # no rank process outlives the launcher
+        _stop_children()
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     for t in pumps:
         t.join(timeout=5.0)
     return rc
