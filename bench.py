@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import unet_zoo_amd  # noqa: E402
-from unet_zoo_amd import launch, ops  # noqa: E402
+from unet_zoo_amd import _lib as L, launch, ops  # noqa: E402
 from unet_zoo_amd.parallel import RcclDataParallel  # noqa: E402
 from unet_zoo_amd.step import GraphedStep  # noqa: E402
 
@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--phases", type=int, default=5,
                     help="N>1 ranks: number of backward phases (hipGraphs) whose gradient "
                          "all-reduce overlaps the next phase; 1 = one all-reduce after the whole backward")
+    ap.add_argument("--cu-reserve", type=int, default=None,
+                    help="CUs the persistent convolution / GEMM / weight-gradient grids leave free for RCCL's kernels "
+                         "(uz_set_cu_reserve); default: 0 for one rank, the library default otherwise")
     ap.add_argument("--loss", default="hip", choices=["hip", "torch"],
                     help="hip = BCEWithLogits + Dice + gradient in one kernel pass inside the graph (unet_zoo_amd.loss); "
                          "torch = F.binary_cross_entropy_with_logits, evaluated eagerly between the graphs")
@@ -268,7 +271,7 @@ def main():
     loss_recheck = None
     if args.graph == "on":
         gs = GraphedStep(model, "bce_dice" if args.loss == "hip" else torch_criterion, lr=1e-4, weight_decay=1e-5,
-                         max_norm=1.0, phases=args.phases, data_parallel=distributed)
+                         max_norm=1.0, phases=args.phases, data_parallel=distributed, cu_reserve=args.cu_reserve)
         elapsed, fb_s = time_graphed(gs, x, mask, args.steps, args.warmup, distributed, dev)
         fb_graph_ms = fb_s / args.steps * 1e3
         launch_mode = gs.describe()
@@ -403,6 +406,7 @@ def main():
             "loss_eager_recheck": round(loss_recheck, 5) if loss_recheck is not None else None,
             "roofline": roofline,
             "launch": launch_mode,
+            "cu_reserve": L.get_cu_reserve(),
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }
         if fp32 is not None:

@@ -69,6 +69,14 @@ int uz_profile_disarm(void);
  * UZ_TUNE / UZ_ATTN_GX / UZ_WG_SPLIT environment switches), 0 for the shipped build, which never reads the
  * environment.  bench.py refuses to time an ablation build. */
 int uz_build_ablate(void);
+/* Hold `n` of the 256 CUs back from the library's persistent grids (0 <= n <= 128; default 0): the convolution, GEMM and
+ * weight-gradient kernels run one 160 KB workgroup per CU, so a collective launched beside the backward (RCCL all-reduce
+ * of a finished gradient span; reference seam unet_zoo/utils/multi_gpu.py:20-31) finds no CU to start on
+ * until a kernel boundary.  With a reserve every plan sizes its grid -- and its statistics / slab partition, so call it
+ * BEFORE querying *_grid_m / *_workspace_bytes -- for 256 - n CUs.  Process-wide; results stay equal up to the fp32
+ * order of the per-workgroup partial sums.  uz_get_cu_reserve() returns the current value. */
+int uz_set_cu_reserve(int n);
+int uz_get_cu_reserve(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the matrix cores.

@@ -60,3 +60,4 @@ def test_two_rank_graphed_step_equals_mean_of_shard_gradients(tmp_path, model_na
         err = (g - want).abs().max().item() / (want.abs().max().item() + 1e-12)
         worst = max(worst, err)
     assert worst < 1e-5, worst
+

@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("UNET_ZOO_AMD_LIB") or os.path.join(os.path.dirname(os
 
 # every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_conv_igemm_grid_m", "uz_conv_igemm",
+    "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_set_cu_reserve", "uz_get_cu_reserve", "uz_conv_igemm_grid_m", "uz_conv_igemm",
     "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_outconv_bwd_rows", "uz_outconv_bwd_bnred",
@@ -131,6 +131,8 @@ def load():
     lib.uz_abi_version.restype = c_int
     lib.uz_last_error_string.restype = c_char_p
     vp, ip, fp = c_void_p, c_int, c_float
+    lib.uz_set_cu_reserve.argtypes = [c_int]
+    lib.uz_get_cu_reserve.argtypes = []
     lib.uz_conv_igemm_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     lib.uz_conv_igemm_res.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, ip, vp, vp]
@@ -256,6 +258,16 @@ def check_count(rc: int, what: str) -> int:
     if rc < 0:
         _fail(rc, what)
     return rc
+
+
+def set_cu_reserve(n: int) -> None:
+    """uz_set_cu_reserve(): size every persistent grid of the library for 256 - n CUs (process-wide; call before any
+    plan is queried / any graph is captured)"""
+    check(load().uz_set_cu_reserve(int(n)), "uz_set_cu_reserve")
+
+
+def get_cu_reserve() -> int:
+    return int(load().uz_get_cu_reserve())
 
 
 def stream_ptr() -> int:

@@ -29,8 +29,13 @@ bool uz_prof_take(hipEvent_t* e0, hipEvent_t* e1);   // true while armed; *e0 = 
   } while (0)
 
 #define UZ_WAVE 64
-#define UZ_NUM_CU 256
+#define UZ_NUM_CU_HW 256
 #define UZ_NUM_XCD 8
+// CUs the plans size their grids for: all 256, or fewer while uz_set_cu_reserve(n) holds some back for the kernels of
+// another stream (RCCL's all-reduce beside the backward: the convolution / GEMM / weight-gradient kernels are persistent
+// grids of one 160 KB workgroup per CU, which leave a collective no CU to start on until the next kernel boundary)
+int uz_num_cu();
+#define UZ_NUM_CU (uz_num_cu())
 
 void uz_set_error(const char* fmt, ...);
 

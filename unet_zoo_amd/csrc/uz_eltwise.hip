@@ -1467,6 +1467,17 @@ extern "C" int uz_im2col3x3_nchw(int dtype, const float* x_nchw, int N, int C, i
   return UZ_OK;
 }
 
+// ---- CUs held back from the persistent grids (process-wide: set once, before the plans are queried) --------------------
+#include <atomic>
+static std::atomic<int> g_cu_reserve{0};
+int uz_num_cu() { return UZ_NUM_CU_HW - g_cu_reserve.load(std::memory_order_relaxed); }
+extern "C" int uz_set_cu_reserve(int n) {
+  UZ_REQUIRE(n >= 0 && n <= UZ_NUM_CU_HW / 2, "uz_set_cu_reserve: %d not in 0 .. %d", n, UZ_NUM_CU_HW / 2);
+  g_cu_reserve.store(n, std::memory_order_relaxed);
+  return UZ_OK;
+}
+extern "C" int uz_get_cu_reserve(void) { return g_cu_reserve.load(std::memory_order_relaxed); }
+
 // ---- error string -------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 void uz_set_error(const char* fmt, ...) {

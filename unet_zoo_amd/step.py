@@ -61,8 +61,16 @@ class _ShapeGraphs:
 class GraphedStep:
     def __init__(self, model: nn.Module, criterion: Union[str, Callable] = "bce_dice", *, lr: float = 1e-4,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-5,
-                 max_norm: float = 1.0, phases: int = 5, process_group=None, data_parallel: Optional[bool] = None):
+                 max_norm: float = 1.0, phases: int = 5, process_group=None, data_parallel: Optional[bool] = None,
+                 cu_reserve: Optional[int] = None):
+        """cu_reserve: CUs the library's persistent grids leave free (uz_set_cu_reserve; process-wide, applied here,
+        before anything is planned or captured) so that the all-reduce of a finished gradient span can start while the
+        next backward phase runs -- convolution / GEMM / weight-gradient kernels otherwise hold every CU with one
+        160 KB workgroup until a kernel boundary.  None leaves the library's setting alone (default 0)."""
         self.model = _unwrap(model)
+        if cu_reserve is not None:
+            from . import _lib
+            _lib.set_cu_reserve(cu_reserve)
         if isinstance(criterion, str):
             if criterion != "bce_dice":
                 raise ValueError(f"unknown built-in criterion {criterion!r}; pass 'bce_dice' or a callable")
