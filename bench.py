@@ -87,6 +87,53 @@ def make_model(model_name: str, hw: int):
     return unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1, **kw), kw
 
 
+def device_state(dev_index: int = 0) -> dict:
+    """Clocks, power and temperature of the GPU this rank runs on, best effort and OUTSIDE the timed region: the sysfs
+    files of the card whose PCI address matches the HIP device (current pp_dpm_* level, hwmon power / temperatures),
+    else `rocm-smi --json`.  Evidence for the box-to-box spread of the MFMA-bound kernels: the
+    number that matters is `mfma_clock` below (the clock held UNDER matrix load), these are its context."""
+    import glob
+    out = {}
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", 0))
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        card = next((c for c in cards if want in os.path.realpath(c)), None)
+        if card is None and len(cards) == 1:
+            card = cards[0]
+        if card:
+            out["pci"] = os.path.basename(os.path.realpath(card))
+            for f in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk"):
+                try:
+                    cur = [l for l in open(os.path.join(card, f)).read().splitlines() if l.strip().endswith("*")]
+                    if cur:
+                        out[f[7:] + "_mhz"] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit()))
+                except (OSError, ValueError, IndexError):
+                    pass
+            for hw in glob.glob(os.path.join(card, "hwmon", "hwmon*")):
+                for f, key, div in (("power1_average", "power_w", 1e6), ("power1_input", "power_w", 1e6), ("power1_cap", "power_cap_w", 1e6),
+                                    ("temp1_input", "temp_edge_c", 1e3), ("temp2_input", "temp_junction_c", 1e3),
+                                    ("temp3_input", "temp_mem_c", 1e3), ("freq1_input", "sclk_hwmon_mhz", 1e6)):
+                    try:
+                        out.setdefault(key, round(int(open(os.path.join(hw, f)).read()) / div, 1))
+                    except (OSError, ValueError):
+                        pass
+    except Exception as e:      # noqa: BLE001  (best effort: never fail the benchmark over a sensor)
+        out["error"] = repr(e)[:120]
+    if len(out) <= 1:
+        import subprocess
+        try:
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True,
+                               text=True, timeout=20)
+            js = json.loads(r.stdout)
+            k = sorted(js)[dev_index] if js else None
+            if k:
+                out["rocm_smi"] = {a: b for a, b in js[k].items() if any(t in a.lower() for t in ("sclk", "mclk", "fclk", "power", "temperature"))}
+        except Exception as e:  # noqa: BLE001
+            out["rocm_smi_error"] = repr(e)[:120]
+    return out
+
+
 def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet", threads: int = 16):
     """Reference step on the host CPU through the oracle (checker code, used here only as the
     reported baseline)."""
@@ -269,6 +316,7 @@ def main():
     gs = None
     fb_graph_ms = None
     loss_recheck = None
+    dev_before = device_state(dev.index or 0) if rank == 0 else None
     if args.graph == "on":
         gs = GraphedStep(model, "bce_dice" if args.loss == "hip" else torch_criterion, lr=1e-4, weight_decay=1e-5,
                          max_norm=1.0, phases=args.phases, data_parallel=distributed, cu_reserve=args.cu_reserve)
@@ -303,6 +351,7 @@ def main():
         final_loss = float(loss.item())
         launch_mode = "eager launches (autograd node + torch clip_grad_norm_ + fused AdamW)"
 
+    dev_after = device_state(dev.index or 0) if rank == 0 else None
     # per-launch HIP events (same process, same shapes, eager launches right after the timed steps)
     net = model
     if opt is None:
@@ -334,6 +383,12 @@ def main():
                 "fp32_loss": round(float(gs32.loss.item()), 5)}
         del gs32, m32
 
+    mfma_clock = None
+    if rank == 0 and world == 1:
+        try:
+            mfma_clock = L.mfma_clock_ghz()      # ~1 s of dense MFMAs, after everything that is timed
+        except Exception as e:                   # noqa: BLE001
+            mfma_clock = {"error": repr(e)[:120]}
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
@@ -407,6 +462,7 @@ def main():
             "roofline": roofline,
             "launch": launch_mode,
             "cu_reserve": L.get_cu_reserve(),
+            "device": {"before_timed_steps": dev_before, "after_timed_steps": dev_after, "mfma_clock": mfma_clock},
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }
         if fp32 is not None:

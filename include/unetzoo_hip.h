@@ -75,6 +75,12 @@ int uz_build_ablate(void);
  * until a kernel boundary.  With a reserve every plan sizes its grid -- and its statistics / slab partition, so call it
  * BEFORE querying *_grid_m / *_workspace_bytes -- for 256 - n CUs.  Process-wide; results stay equal up to the fp32
  * order of the per-workgroup partial sums.  uz_get_cu_reserve() returns the current value. */
+/* Measurement: the shader clock this device holds under a dense bf16 MFMA stream (the quantity that sets every
+ * MFMA-bound kernel's time and differs between devices -- MI355X_MICROARCH.md "DVFS give-back").  `workgroups` blocks of
+ * 512 threads issue 8 * iters v_mfma_f32_16x16x32_bf16 per wave on random operands; block b writes
+ * out_pairs[2 b] = shader cycles (s_memtime), out_pairs[2 b + 1] = 100 MHz ticks (s_memrealtime) of its loop
+ * (uint64, device memory).  clock [GHz] = cycles / ticks / 10.  bench.py reports the median after a settling run. */
+int uz_clock_probe(int iters, void* out_pairs, int workgroups, void* stream);
 int uz_set_cu_reserve(int n);
 int uz_get_cu_reserve(void);
 

@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("UNET_ZOO_AMD_LIB") or os.path.join(os.path.dirname(os
 
 # every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_set_cu_reserve", "uz_get_cu_reserve", "uz_conv_igemm_grid_m", "uz_conv_igemm",
+    "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_set_cu_reserve", "uz_get_cu_reserve", "uz_clock_probe", "uz_conv_igemm_grid_m", "uz_conv_igemm",
     "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_outconv_bwd_rows", "uz_outconv_bwd_bnred",
@@ -132,6 +132,7 @@ def load():
     lib.uz_last_error_string.restype = c_char_p
     vp, ip, fp = c_void_p, c_int, c_float
     lib.uz_set_cu_reserve.argtypes = [c_int]
+    lib.uz_clock_probe.argtypes = [c_int, vp, c_int, vp]
     lib.uz_get_cu_reserve.argtypes = []
     lib.uz_conv_igemm_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
@@ -268,6 +269,33 @@ def set_cu_reserve(n: int) -> None:
 
 def get_cu_reserve() -> int:
     return int(load().uz_get_cu_reserve())
+
+
+def mfma_clock_ghz(settle_s: float = 0.6, iters: int = 40000) -> dict:
+    """uz_clock_probe(): shader clock held under a dense bf16 MFMA stream on every CU, after `settle_s` seconds of that
+    same load (the DVFS controller needs time); median / min / max over the 256 workgroups of the last launch, and the
+    bf16 TFLOP/s the probe itself sustained.  Runs ~1 s; bench.py calls it OUTSIDE the timed region."""
+    import time
+    lib = load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = torch.zeros(256, 2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + settle_s
+    while time.perf_counter() < t_end:
+        for _ in range(4):
+            check(lib.uz_clock_probe(iters, out.data_ptr(), 256, stream_ptr()), "uz_clock_probe")
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.uz_clock_probe(iters, out.data_ptr(), 256, stream_ptr()), "uz_clock_probe")
+    e1.record()
+    torch.cuda.synchronize()
+    o = out.double().cpu()
+    ghz = (o[:, 0] / o[:, 1] / 10.0)
+    flops = 256.0 * 8 * iters * 8 * 2.0 * 16 * 16 * 32
+    return {"median_ghz": round(float(ghz.median()), 4), "min_ghz": round(float(ghz.min()), 4),
+            "max_ghz": round(float(ghz.max()), 4),
+            "probe_tflops": round(flops / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)}
 
 
 def stream_ptr() -> int:

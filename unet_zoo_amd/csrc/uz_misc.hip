@@ -160,7 +160,53 @@ __global__ __launch_bounds__(256) void pil_resample_v_kernel(const unsigned char
     }
   }
 }
+// ---- measurement: the clock the chip holds under a dense MFMA stream ---------------------------------------------------
+// Eight waves per CU (two per SIMD) issue v_mfma_f32_16x16x32_bf16 back to back on pseudo-random operands kept in
+// registers; wave 0 of each workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz) around the loop.
+// clock = d(memtime) / d(memrealtime) x 100 MHz.  MI355X_MICROARCH.md, "DVFS give-back" (5), (6): this is the quantity
+// that differs between devices (1.51-1.69 GHz measured there on one binary), and with it every MFMA-bound kernel.
+__global__ __launch_bounds__(512, 2) void clock_probe_kernel(unsigned long long* __restrict__ out, int iters, unsigned seed) {
+  const int tid = threadIdx.x;
+  unsigned h = (blockIdx.x * 512u + tid) * 2654435761u + seed;
+  bf16x8 a[8], b[8];   // eight independent operand pairs: every MFMA of the loop body toggles its operand lines
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h = h * 1664525u + 1013904223u;
+      a[k][e] = (bf16_t)(((int)(h >> 8) & 0xffff) * (2.0f / 65536.0f) - 1.0f);
+      h = h * 1664525u + 1013904223u;
+      b[k][e] = (bf16_t)(((int)(h >> 8) & 0xffff) * (2.0f / 65536.0f) - 1.0f);
+    }
+  f32x4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], b[k], acc[k], 0, 0, 0);
+  }
+  f32x4 s = acc[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += acc[k];
+  asm volatile("" ::"v"(s));
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) {
+    out[2 * blockIdx.x + 0] = t1 - t0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
 }  // namespace
+
+extern "C" int uz_clock_probe(int iters, void* out_pairs, int workgroups, void* stream) {
+  UZ_REQUIRE(out_pairs != nullptr && iters > 0 && workgroups > 0 && workgroups <= 4096, "uz_clock_probe: bad arguments");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream,
+                     static_cast<unsigned long long*>(out_pairs), iters, 12345u);
+  UZ_LAUNCH_CHECK("uz_clock_probe");
+  return UZ_OK;
+}
 
 extern "C" int uz_pil_resample_h_u8(const void* src, int H, int Win, int C, const int* bounds, const int* kk, int ksize,
                                     int Wout, void* dst, void* stream) {
