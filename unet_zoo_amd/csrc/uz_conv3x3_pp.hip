@@ -22,7 +22,10 @@
 //  * The unit stream runs across the tiles of a workgroup: the last slab of a tile requests the first patch and the first
 //    weight tiles of the next one.  The epilogue is wave-local (no barrier): 32-pixel rounds through a private 4.5 KB
 //    staging strip, 16-byte buffer stores of full 128-byte lines, statistics from the stored values; both groups run it
-//    in the same barrier interval.
+//    in the same barrier interval.  (Tried on the 64-accumulator configurations and dropped: outputs packed to bf16 at
+//    the tile's end, the two store rounds run at the head of the next tile's first two read phases -- bit-identical,
+//    but 64 -> 64 @ 256 x 256 86 -> 100 us, 128 -> 64 137 -> 151: a round is longer than the 768-cycle compute phase it
+//    was meant to hide under, so it only moved the exposed time and added the packing.)
 //
 // Tile configurations (template parameters TH x TW pixels, WM x WN waves, UPP units per phase):
 //   16 x 32, 4 x 2, 1   512 pixels x 128 channels, wave 128 x 64: the layers with >= 128 output channels and enough
