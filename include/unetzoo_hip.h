@@ -69,6 +69,9 @@ int uz_profile_disarm(void);
  * UZ_TUNE / UZ_ATTN_GX / UZ_WG_SPLIT environment switches), 0 for the shipped build, which never reads the
  * environment.  bench.py refuses to time an ablation build. */
 int uz_build_ablate(void);
+/* sha256 (hex) of the kernel sources the library was built from (csrc/Makefile: $(HASHED), concatenated in that order):
+ * lets a test tell a stale build -- the library is a build artefact outside the repository's history. */
+const char* uz_source_hash(void);
 /* Hold `n` of the 256 CUs back from the library's persistent grids (0 <= n <= 128; default 0): the convolution, GEMM and
  * weight-gradient kernels run one 160 KB workgroup per CU, so a collective launched beside the backward (RCCL all-reduce
  * of a finished gradient span; reference seam unet_zoo/utils/multi_gpu.py:20-31) finds no CU to start on

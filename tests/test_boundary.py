@@ -87,3 +87,23 @@ def test_bad_descriptor_is_rejected_without_a_gpu():
     d = _lib.ConvDesc(_lib.UZ_BF16, 1, 8, 8, 8, 8, 20, 24, 64, 64, 9, 0, 1, 0, 0)  # Cin % 8 != 0
     assert lib.uz_conv_igemm_grid_m(ctypes.byref(d)) == -1
     assert b"Cin" in lib.uz_last_error_string()
+
+
+def test_library_is_the_build_of_the_sources_in_the_tree():
+    """libunetzoo_hip.so is a build artefact (git-ignored; it travels to the GPU box as it is): uz_source_hash() must be
+    the sha256 of the kernel sources as they are in the tree now, in the Makefile's order -- a stale library would
+    otherwise be tested and timed in place of the code under review (it happened in round 3: a reverted experiment
+    stayed in the .so for a dozen measurements)"""
+    import hashlib
+    import re
+    from unet_zoo_amd import _lib as L
+    csrc = os.path.join(ROOT, "unet_zoo_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^SRCS = (.*)$", mk, re.M).group(1).split()
+    files = [os.path.join(csrc, f) for f in srcs] + [os.path.join(csrc, "uz_common.h"),
+                                                      os.path.join(ROOT, "include", "unetzoo_hip.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(f, "rb").read())
+    got = L.load().uz_source_hash().decode()
+    assert got == h.hexdigest(), "libunetzoo_hip.so is stale: run `make -C unet_zoo_amd/csrc` (or __graft_entry__.build())"

@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("UNET_ZOO_AMD_LIB") or os.path.join(os.path.dirname(os
 
 # every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_set_cu_reserve", "uz_get_cu_reserve", "uz_clock_probe", "uz_conv_igemm_grid_m", "uz_conv_igemm",
+    "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_source_hash", "uz_set_cu_reserve", "uz_get_cu_reserve", "uz_clock_probe", "uz_conv_igemm_grid_m", "uz_conv_igemm",
     "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_outconv_bwd_rows", "uz_outconv_bwd_bnred",
@@ -130,6 +130,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.uz_abi_version.restype = c_int
     lib.uz_last_error_string.restype = c_char_p
+    lib.uz_source_hash.restype = c_char_p
+    lib.uz_source_hash.argtypes = []
     vp, ip, fp = c_void_p, c_int, c_float
     lib.uz_set_cu_reserve.argtypes = [c_int]
     lib.uz_clock_probe.argtypes = [c_int, vp, c_int, vp]
@@ -235,7 +237,7 @@ def load():
     lib.uz_pil_resample_v_f32.argtypes = [vp, ip, ip, ip, vp, vp, ip, ip, POINTER(c_float), POINTER(c_float), ip, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("uz_last_error_string",):
+        if name not in ("uz_last_error_string", "uz_source_hash"):
             fn.restype = ctypes.c_longlong if name.endswith("_workspace_bytes") else c_int
     if lib.uz_abi_version() != 1:
         raise HipLibraryError("libunetzoo_hip.so ABI version mismatch; rebuild it")
