@@ -1,1 +1,1 @@
-extern "C" const char* uz_source_hash(void) { return "0337b6f8c3f3a2c4c08709e7abdaf5f1b09f7da1a007676575ea6b4bdfc020c2"; }
+extern "C" const char* uz_source_hash(void) { return "702bd7f0a8a9f4c1a66f5aa50fba74f0bb5929efd93ac3895d7370ebc2f26ea1"; }

@@ -20,6 +20,10 @@
 // distinct banks for any tap shift.
 // Each (split, k-group) writes a coalesced fp32 slab [tap][Ci][Cj]; uz_wgrad's reduce kernel sums
 // the slabs in fixed order and transposes to OIHW.
+// (Round 3 tried the ping-pong schedule of uz_conv3x3_pp.hip on the 128 x 128 three-tap configuration -- one wave group
+// reads all 40 transposed fragments of a K-step and issues its five DMA pieces while the other issues 24 MFMAs: correct,
+// 5-10 % SLOWER on every layer (profiles/r03_wgrad_pingpong_rejected.txt).  With 40 KB of LDS-DMA and 20 KB of transposed
+// reads per wave and 768 MFMA cycles the read phase is the longer one; the interleaved issue below hides more of it.)
 #include "uz_common.h"
 
 namespace {
