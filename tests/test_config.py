@@ -92,6 +92,15 @@ def test_additive_keys_dtype_and_ddp_rccl(tmp_path, monkeypatch):
     c = Config(_cfg(tmp_path / "r1", gpu__use_multi_gpu=True, gpu__multi_gpu_strategy="ddp_rccl", gpu__gpu_ids=[0, 1]))
     assert (c.RANK, c.LOCAL_RANK, c.WORLD_SIZE) == (1, 1, 2)
     assert not os.path.exists(c.OVERALL_LOG_DIR)             # rank 0 creates the run directories
+    # gpu.gpu_ids places the ranks (rank r on gpu_ids[r], as the reference places its replicas); every rank of one
+    # launch derives the same run directory from the launcher's UZ_RUN_TIMESTAMP
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("UZ_RUN_TIMESTAMP", "20260101-000000")
+    c = Config(_cfg(tmp_path / "r1b", gpu__use_multi_gpu=True, gpu__multi_gpu_strategy="ddp_rccl", gpu__gpu_ids=[2, 3]))
+    assert c.DEVICE == torch.device("cuda", 3)
+    assert c.RUN_TIMESTAMP == "20260101-000000" and c.BASE_RUN_DIR.endswith("overall_runs_20260101-000000")
+    with pytest.raises(ValueError):
+        Config(_cfg(tmp_path / "r1c", gpu__use_multi_gpu=True, gpu__multi_gpu_strategy="ddp_rccl", gpu__gpu_ids=[0, 1, 2]))
 
 
 def test_load_config_from_file(tmp_path):

@@ -18,6 +18,12 @@ CASES = [
     ("nested_unet", {}, 2, 64),
     ("resunet", {}, 2, 64),
     ("missformer", {"image_size": 128}, 2, 128),
+    # the four compositions of round 2 (their attention cores run as torch ops inside the captured graphs: the
+    # capture-time memset check of step.py applies to them first of all)
+    ("transatt_unet", {}, 2, 64),
+    ("unet_transformer", {}, 2, 64),
+    ("multiresunet", {}, 2, 64),
+    ("uctransnet", {"image_size": 64}, 2, 64),
 ]
 
 
@@ -29,6 +35,10 @@ def _make(name, kw, dtype):
     else:
         m = unet_zoo_amd.create_model(name, in_channels=3, num_classes=1, **kw)
     m.run_dtype = dtype
+    if name == "uctransnet":          # dropout draws from the generator: the two runs would see different masks
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
     return m.cuda().train()
 
 
@@ -140,3 +150,31 @@ def test_loss_in_the_graph_is_the_loss_of_the_replayed_logits():
         want = F.binary_cross_entropy_with_logits(gs.outputs, t).item()
         assert abs(loss.item() - want) < 1e-5, (i, loss.item(), want)
         assert loss.item() > 0.1
+
+
+def test_capture_check_sees_memset_nodes():
+    """step._memset_nodes(): the guard GraphedStep applies to every graph it captures must really list the nodes -- a
+    multi-block torch reduction resets its semaphores with hipMemsetAsync (the node that acts only in the first replay
+    on this stack), an elementwise op does not"""
+    from unet_zoo_amd import step as S
+    big = torch.randn(1 << 24, device="cuda")
+    out = torch.zeros((), device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        big.sum()                                   # warm-up outside capture (allocations, lazy init)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g1 = S._new_graph()
+    with torch.cuda.graph(g1, capture_error_mode=S.CAPTURE_MODE):
+        out.copy_(big.sum())
+    n1 = S._memset_nodes(g1)
+    g2 = S._new_graph()
+    with torch.cuda.graph(g2, capture_error_mode=S.CAPTURE_MODE):
+        big.mul_(1.0)
+    n2 = S._memset_nodes(g2)
+    assert n1 is not None and n2 is not None, "the runtime handle of a captured graph could not be inspected"
+    assert n2 == 0
+    assert n1 >= 1, "a split reduction without a memset node: the canary of DESIGN.md 5a no longer applies -- re-check"
+    with pytest.raises(RuntimeError, match="memset node"):
+        S._check_capture(g1, "test graph")

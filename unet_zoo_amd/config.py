@@ -88,7 +88,10 @@ class Config:
         self.MODELS_TO_TRAIN: List[str] = list(models.get("names", []) or [])
         self.MODEL_PARAMS: Dict[str, Dict[str, Any]] = copy.deepcopy(models.get("params", {}) or {})
 
-        self.RUN_TIMESTAMP = cfg.get("run_timestamp") or datetime.datetime.now().strftime("%Y%m%d-%H%M%S_fallback")
+        # every rank of one launch must agree on the run directory: the launcher exports one UZ_RUN_TIMESTAMP
+        # (launch.rank_env); ranks started across a second boundary would otherwise derive different names
+        self.RUN_TIMESTAMP = (cfg.get("run_timestamp") or os.environ.get("UZ_RUN_TIMESTAMP")
+                              or datetime.datetime.now().strftime("%Y%m%d-%H%M%S_fallback"))
         self.BASE_RUN_DIR = os.path.join(self.WORKING_DIR, f"overall_runs_{self.RUN_TIMESTAMP}")
         self.OVERALL_LOG_DIR = os.path.join(self.BASE_RUN_DIR, "overall_logs")
         self.TENSORBOARD_BASE_DIR = os.path.join(self.BASE_RUN_DIR, "tensorboard_logs")
@@ -111,6 +114,12 @@ class Config:
         if n == 0:
             return torch.device("cpu")         # models raise on a CPU input: there is no fallback path
         if self.ddp and self.WORLD_SIZE > 1:
+            # one rank per entry of gpu.gpu_ids, as the reference places its replicas (GPU_IDS, multi_gpu.py:20-31):
+            # rank r runs on gpu_ids[r]; a list of another length is a configuration error, not something to guess at
+            if self.GPU_IDS:
+                if len(self.GPU_IDS) != self.WORLD_SIZE:
+                    raise ValueError(f"gpu.gpu_ids has {len(self.GPU_IDS)} entries for {self.WORLD_SIZE} ranks")
+                return torch.device("cuda", self.GPU_IDS[self.LOCAL_RANK])
             return torch.device("cuda", self.LOCAL_RANK)
         if self.USE_MULTI_GPU and self.GPU_IDS:
             return torch.device("cuda", self.GPU_IDS[0])

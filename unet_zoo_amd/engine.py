@@ -204,7 +204,16 @@ class Engine:
         if self.grads_in_place and p.grad is not None:
             if g is None:
                 return                               # analytically zero and p.grad was never touched
-            if g.data_ptr() != p.grad.data_ptr():
+            if p in self.param_grads:
+                # a parameter used by two layers of the graph: its second contribution.  Kernels that write into
+                # p.grad itself (uz_wgrad with out=p.grad, the batched column sums) would have overwritten the first
+                # one -- there is no accumulate form of them -- so that case is refused rather than silently halved;
+                # a contribution that arrives in its own tensor is added (eager mode sums them the same way).
+                if g.data_ptr() == p.grad.data_ptr():
+                    raise RuntimeError("a parameter shared by two layers received its second gradient in place: "
+                                       "shared parameters are not supported by the in-place (graphed) backward")
+                p.grad.add_(g.reshape(p.grad.shape))
+            elif g.data_ptr() != p.grad.data_ptr():
                 p.grad.copy_(g.reshape(p.grad.shape))
             self.param_grads[p] = None               # autograd must not add it a second time
             if self.grad_sink is not None:
@@ -1063,17 +1072,19 @@ class Engine:
                 return self.copy_into(x, out)
             return x
         out = out if out is not None else self.new_act(x.N, x.H, x.W, x.C)
-        keep = (torch.rand((x.P, x.C), device=self.device) >= p).to(x.dtype)
-        keep.mul_(1.0 / (1.0 - p))
+        # a 0/1 mask; the scale 1 / (1 - p) is applied in fp32 (in bf16 1.1111 rounds to 1.1094: every kept activation and
+        # its gradient would come out 0.16 % low against nn.Dropout)
+        keep = (torch.rand((x.P, x.C), device=self.device) >= p).to(torch.float32)
+        scale = 1.0 / (1.0 - p)
         xv = x.buf[:, x.off:x.off + x.C]
-        out.buf[:, out.off:out.off + x.C].copy_(xv * keep)
+        out.buf[:, out.off:out.off + x.C].copy_((xv.float() * keep).mul_(scale))
         if self.record and x.needs_grad:
             def bwd():
                 g = self._total_grad(out)
                 if g is None:
                     return
                 dx = self.new_act(x.N, x.H, x.W, x.C)
-                dx.buf.copy_(g.buf[:, g.off:g.off + g.C] * keep)
+                dx.buf.copy_((g.buf[:, g.off:g.off + g.C].float() * keep).mul_(scale))
                 x.add_grad(dx)
 
             self.tape.append(bwd)

@@ -46,11 +46,19 @@ def free_port() -> int:
         return int(s.getsockname()[1])
 
 
+_LAUNCH_STAMP = None
+
+
 def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
-    """Environment of one rank (single node: LOCAL_RANK == RANK)."""
+    """Environment of one rank (single node: LOCAL_RANK == RANK).  UZ_RUN_TIMESTAMP: one value for every rank of this
+    launcher process (config.Config derives the run directory from it)."""
+    global _LAUNCH_STAMP
+    if _LAUNCH_STAMP is None:
+        _LAUNCH_STAMP = time.strftime("%Y%m%d-%H%M%S")
     env = dict(os.environ if base is None else base)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("UZ_RUN_TIMESTAMP", _LAUNCH_STAMP)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
     return env
 

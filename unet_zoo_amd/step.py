@@ -46,6 +46,56 @@ from .optim import FlatClipAdamW
 CAPTURE_MODE = "thread_local"
 
 
+_HIP = None
+
+
+def _memset_nodes(graph: "torch.cuda.CUDAGraph") -> Optional[int]:
+    """number of memset nodes in a captured graph (None when the runtime handle cannot be inspected).  On this stack a
+    memset node of a replayed hipGraph writes its value in the FIRST replay only (tools/graph_canary.py):
+    a library reduction that resets its semaphores with hipMemsetAsync gives right numbers once and silently wrong
+    gradients afterwards -- so a capture that contains one is refused instead of trusted by convention."""
+    global _HIP
+    import ctypes
+    try:
+        raw = graph.raw_cuda_graph()
+        if _HIP is None:
+            _HIP = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_size_t(0)
+        if _HIP.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+            return None
+        if n.value == 0:
+            return 0
+        nodes = (ctypes.c_void_p * n.value)()
+        if _HIP.hipGraphGetNodes(ctypes.c_void_p(raw), nodes, ctypes.byref(n)) != 0:
+            return None
+        count = 0
+        for i in range(n.value):
+            t = ctypes.c_int(-1)
+            if _HIP.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+                return None
+            if t.value == 2:          # hipGraphNodeTypeMemset
+                count += 1
+        return count
+    except Exception:                 # noqa: BLE001  (older torch without raw_cuda_graph, no libamdhip64: cannot inspect)
+        return None
+
+
+def _new_graph() -> "torch.cuda.CUDAGraph":
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)     # keeps the hipGraph_t so that its nodes can be listed
+    except TypeError:
+        return torch.cuda.CUDAGraph()
+
+
+def _check_capture(graph: "torch.cuda.CUDAGraph", what: str) -> None:
+    n = _memset_nodes(graph)
+    if n:
+        raise RuntimeError(f"GraphedStep: the captured {what} contains {n} memset node(s); on this stack a replayed "
+                           f"memset node acts only once (DESIGN.md 5a) -- a library reduction / zero-fill by "
+                           f"hipMemsetAsync was captured.  Keep it out of the graph (criterion as a callable runs "
+                           f"eagerly) or replace it with a kernel.")
+
+
 def _unwrap(model: nn.Module) -> HipModule:
     inner = model.module if hasattr(model, "module") and isinstance(model.module, HipModule) else model
     if not isinstance(inner, HipModule):
@@ -158,9 +208,10 @@ class GraphedStep:
         self._capture_opt()
 
     def _capture_opt(self) -> None:
-        self._g_opt = torch.cuda.CUDAGraph()
+        self._g_opt = _new_graph()
         with torch.cuda.graph(self._g_opt, capture_error_mode=CAPTURE_MODE):
             self.opt.step()
+        _check_capture(self._g_opt, "optimizer graph")
 
     def set_lr(self, lr: float) -> None:
         """Learning-rate change (the reference's DiceScheduler, utils/lr_scheduler.py:70-81): the rate is a kernel
@@ -189,21 +240,23 @@ class GraphedStep:
         else:
             # forward graph; the criterion runs eagerly on its static outputs; the backward graphs read static
             # d(loss)/d(output) buffers
-            g.fwd = torch.cuda.CUDAGraph()
+            g.fwd = _new_graph()
             with torch.cuda.graph(g.fwd, capture_error_mode=CAPTURE_MODE):
                 ps.emit(g.x)
+            _check_capture(g.fwd, "forward graph")
             pool = g.fwd.pool()
             g.outputs = ps.outputs
             g.gouts = [torch.zeros_like(o) for o in ps._outs]
             ps.set_output_grads(g.gouts)
         for k in range(len(cuts) - 1):
-            gk = torch.cuda.CUDAGraph()
+            gk = _new_graph()
             with torch.cuda.graph(gk, pool=pool, capture_error_mode=CAPTURE_MODE):
                 if k == 0 and self._fused_loss:
                     g.loss = ps.forward(g.x, g.t)
                     g.outputs = ps.outputs
                     g.dice = dice_box[-1].detach()
                 ps.backward(cuts[k], cuts[k + 1], k == 0)
+            _check_capture(gk, f"backward phase {k}")
             pool = gk.pool()
             g.phases.append(gk)
         g.ps = ps            # keeps the loss function / output leaves for the eager criterion
