@@ -224,8 +224,10 @@ def main():
                          "--size 256 (window 8) or configs[3] with --size 224 --batch 32 (window 7)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=None,
+                    help="batch of the CPU baseline (default: the configuration's own batch, capped at 16 -- unet B=16: "
+                         "~6 s per step on the 16 host threads of a one-GPU box)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU steps after one warm-up (median)")
     ap.add_argument("--graph", default="on", choices=["on", "off"],
                     help="on: unet_zoo_amd.GraphedStep (hipGraph replays); off: eager launches through autograd + "
                          "torch's clip_grad_norm_ / AdamW (with N > 1: the bucket reducer of RcclDataParallel)")
@@ -468,8 +470,10 @@ def main():
         if fp32 is not None:
             line.update(fp32)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_batch, args.size, args.cpu_steps, args.model)
-            cb["value_8_threads"] = cpu_baseline(args.cpu_batch, args.size, 1, args.model, threads=8)["value"]
+            cpu_b = args.cpu_batch if args.cpu_batch else min(args.batch, 16)
+            cb = cpu_baseline(cpu_b, args.size, args.cpu_steps, args.model)
+            # (8 threads, to compare with the survey's anchors: a quarter of the batch keeps the default run short)
+            cb["value_8_threads"] = cpu_baseline(max(cpu_b // 4, 1), args.size, 1, args.model, threads=8)["value"]
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if distributed:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the DEFAULT bench command (graph replays + the eager, event-bracketed profile steps)
-# and the dominant kernel's average duration in each part of the trace beside the bench line's own figure.
+# and the dominant kernel family's average duration in each part of the trace beside the bench line's own figure.
 # usage (on the GPU box): bash tools/prof_default.sh  -> gpurun_out/prof_default_bench.json, gpurun_out/prof_default_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_default; mkdir -p gpurun_out/prof_default
@@ -11,13 +11,23 @@ python3 - <<'PY'
 import sqlite3, glob, json
 db = glob.glob("gpurun_out/prof_default/*.db") + glob.glob("gpurun_out/prof_default/*/*.db")
 c = sqlite3.connect(db[0])
-rows = [r for r in c.execute("select start, duration/1000.0 from kernels where name like '%conv3x3_direct_kernelIDF16bLi32ELi128ELb0ELb0%' order by start")]
-n = len(rows)
-last = rows[-85:]      # 5 eager profile steps x 17 launches
-first = rows[:-85]
-print("launches", n, "all avg", sum(r[1] for r in rows) / n)
-print("last 85 (eager profile steps) avg", sum(r[1] for r in last) / len(last))
-print("before (graph replays + capture) avg", sum(r[1] for r in first) / len(first))
 d = json.loads(open("gpurun_out/prof_default_bench.json").read().strip().splitlines()[-1])
-print("bench roofline avg_launch_us", d["roofline"]["avg_launch_us"], "launches/step", d["roofline"]["launches_per_step"], "ms", d["ms_per_step"])
+fam = d["roofline"]["kernel"]
+# kernel symbol of the family the bench line names (uz_conv_igemm_kernel_name() -> template arguments)
+pat = {"conv3x3_pp512_bf16": "%PpCfg<16, 32, 4, 2, 1>, false>%", "conv3x3_pp512x64_bf16": "%PpCfg<16, 32, 8, 1, 3>, false>%",
+       "conv3x3_pp256_bf16": "%PpCfg<8, 32, 4, 2, 3>, false>%"}.get(fam)
+if pat is None:
+    print("no symbol pattern for family", fam)
+    raise SystemExit
+rows = [r for r in c.execute("select start, duration/1000.0 from kernels where name like ? order by start", (pat,))]
+per_step = d["roofline"]["launches_per_step"]
+n_eager = 5 * per_step                      # --profile-steps 5, after the timed graph replays
+eager, before = rows[-n_eager:], rows[:-n_eager]
+replays = before[-5 * per_step:]            # the last five graph replays of the timed region
+print("family", fam, "launches in the trace", len(rows), "per step", per_step)
+print("last 5 graph replays (the timed region): avg %.2f us" % (sum(r[1] for r in replays) / len(replays)))
+print("eager profile steps (what bench.py's events bracket): avg %.2f us" % (sum(r[1] for r in eager) / len(eager)))
+print("bench.py roofline.avg_launch_us %.2f (HIP events, same run)  ms_per_step %.3f" % (d["roofline"]["avg_launch_us"], d["ms_per_step"]))
+a, b = sum(r[1] for r in replays) / len(replays), d["roofline"]["avg_launch_us"]
+print("eager-event figure vs graph replay: %+.1f %%" % ((b / a - 1) * 100))
 PY
