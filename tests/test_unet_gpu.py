@@ -319,3 +319,44 @@ def test_unet_sizes_not_divisible_by_16(H, W):
     sd = m.state_dict()
     for k in ("down_convolution_1.conv.conv_op.1", "bottle_neck.conv_op.4", "up_convolution_4.conv.conv_op.4"):
         np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), st[k + ".running_var"].numpy(), rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["unet", "resunet"])
+def test_backward_through_eval_mode_batchnorm_matches_the_oracle(name):
+    """model.eval() + loss.backward() -- fine-tuning with frozen BatchNorm, which the reference's nn.Modules allow
+    (running statistics as constants: dy = scale * g * mask, the conv bias receives a gradient): fp32 run mode against
+    autograd on the oracle in eval mode, every parameter"""
+    torch.manual_seed(3)
+    m = unet_zoo_amd.create_model(name, in_channels=3, num_classes=1)
+    m.run_dtype = torch.float32
+    # running statistics that are not the identity, so that the test sees them used
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.05)
+                mod.running_var.uniform_(0.5, 1.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    t = (torch.rand(2, 1, 64, 64, generator=g) > 0.5).float()
+    logits = m(x.to(DEV))
+    F.binary_cross_entropy_with_logits(logits, t.to(DEV)).backward()
+    st = torch_ref.clone_state(sd, requires_grad=True)
+    ref = torch_ref.FORWARDS[name](st, x, False)
+    F.binary_cross_entropy_with_logits(ref, t).backward()
+    assert (logits.detach().cpu() - ref.detach()).abs().max() <= 1e-3 * ref.detach().abs().max()
+    checked = 0
+    for pname, p in m.named_parameters():
+        rg = st[pname].grad
+        assert p.grad is not None, pname
+        if rg.abs().max() < 1e-7:
+            continue
+        err = (p.grad.cpu() - rg).norm() / rg.norm()
+        assert err <= 2e-2, (pname, err.item())
+        checked += 1
+    assert checked > 20
+    # the running statistics did not move
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            assert torch.equal(v.cpu(), sd[k]), k

@@ -332,8 +332,7 @@ class Engine:
             if bn.num_batches_tracked is not None:
                 self._bn_counters.append(bn.num_batches_tracked)   # bumped together in finish_forward()
         else:
-            vec = ops.bn_eval_scale(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                                    bn.running_var, bn.eps)
+            vec = self._bn_vectors(bn, None, y.P)      # running statistics: (scale, shift, mean, invstd)
         act = out if out is not None else self.new_act(N, H, W, Cout)
         if pool and pool_ceil:
             pooled = self.new_act(N, (H + 1) // 2, (W + 1) // 2, Cout)
@@ -344,12 +343,8 @@ class Engine:
         if self.record and self.training and relu and pooled is None and residual is None and stat_repeat == 1:
             act.bn_src = (y, vec)      # what a sole reader's input-gradient kernel needs (see sole_reader)
 
+        frozen = not self.training     # model.eval() + backward(): BatchNorm is an affine map of constants
         if self.record:
-            if not self.training:
-                raise NotImplementedError(
-                    "backward through eval-mode BatchNorm is not implemented; call model.train() "
-                    "or wrap evaluation in torch.no_grad() as the reference does "
-                    "(training_loop.py:159)")
             self._bn_channels += Cout
 
             def bwd():
@@ -377,13 +372,16 @@ class Engine:
                 # g0 came from a sole reader's input-gradient kernel with the reduction already done in its epilogue
                 parts = getattr(g0, "bn_partials", None) if (g1 is None and gp is None and residual is None) else None
                 ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil, relu=relu,
-                                partials=parts)
+                                partials=parts, frozen=frozen)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:
-                    # d(bias) = sum_p dy == 0 analytically under train-mode BN (the batch mean
-                    # removes any per-channel constant); the reference's value is rounding noise.
-                    self._give_grad(conv.bias, None)
+                    if frozen:
+                        self._bias_grad(conv.bias, dy)     # running statistics do not cancel a per-channel constant
+                    else:
+                        # d(bias) = sum_p dy == 0 analytically under train-mode BN (the batch mean
+                        # removes any per-channel constant); the reference's value is rounding noise.
+                        self._give_grad(conv.bias, None)
                 if im2col:
                     dwp = ops.wgrad(dy, x, (Cout, x.C), ntaps=1)
                     cin = conv.in_channels
@@ -445,7 +443,9 @@ class Engine:
 
         if self.record:
             if not self.training:
-                raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
+                raise NotImplementedError("backward through the eval-mode BatchNorms of an attention gate is not "
+                                          "implemented (its fused backward kernels use the batch-statistics form); "
+                                          "conv / stand-alone BatchNorm layers do support model.eval() + backward()")
 
             def bwd():
                 dout = self._sum_grads(out, 1)
@@ -509,9 +509,8 @@ class Engine:
         act = self.new_act(x.N, x.H, x.W, C)
         pooled = self.new_act(x.N, x.H // 2, x.W // 2, C) if pool else None
         ops.bn_relu_apply(x, vec[0], vec[1], act, pooled, relu=relu)
+        frozen = not self.training
         if self.record:
-            if not self.training:
-                raise NotImplementedError("backward through eval-mode BatchNorm is not implemented")
             self._bn_channels += C
 
             def bwd():
@@ -526,7 +525,7 @@ class Engine:
                 if dbeta is None:
                     dbeta = torch.empty(C, dtype=torch.float32, device=self.device)
                 ops.bn_relu_bwd(x, vec, gs[0] if gs else None, gs[1] if len(gs) > 1 else None, gp, self._bn_sums(C), dx,
-                                dgamma, dbeta, relu=relu)
+                                dgamma, dbeta, relu=relu, frozen=frozen)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if x.needs_grad:

@@ -396,10 +396,14 @@ def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
                 dbeta: torch.Tensor, pool_ceil: bool = False, relu: bool = True,
-                partials: Optional[torch.Tensor] = None) -> None:
+                partials: Optional[torch.Tensor] = None, frozen: bool = False) -> None:
     """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch; relu=False: the
     forward was a plain BatchNorm.  partials: the rows of the first pass as left by the convolution that produced g0
-    (conv_igemm(bnred=...)): only their fixed-order sum is launched instead of the reduction pass."""
+    (conv_igemm(bnred=...)): only their fixed-order sum is launched instead of the reduction pass.
+    frozen: the forward used RUNNING statistics (model.eval(); fine-tuning with frozen BatchNorm, which the reference
+    allows): vec holds (scale, shift, running_mean, 1/sqrt(running_var + eps)); mean and variance are constants, so
+    dy = scale * g * mask without the two batch-correction terms -- the same kernels with the sums zeroed between the
+    passes; dgamma = sum g*mask*xhat and dbeta = sum g*mask are the first pass's results as they are."""
     lib = L.load()
     d = L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
                     g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
@@ -421,6 +425,8 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
         with _Timed("bn_relu_bwd_reduce", 0.0, es * y.P * y.C * (1 + nsrc)):
             L.check(lib.uz_bn_relu_bwd_reduce(byref(d), *args, ws.data_ptr(), sums.data_ptr(),
                                               dgamma.data_ptr(), dbeta.data_ptr(), s), "uz_bn_relu_bwd_reduce")
+    if frozen:
+        sums.zero_()
     with _Timed("bn_relu_bwd_apply", 0.0, es * y.P * y.C * (2 + nsrc)):
         L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(), s),
                 "uz_bn_relu_bwd_apply")
