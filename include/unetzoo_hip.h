@@ -609,6 +609,46 @@ int uz_pil_resample_h_u8(const void* src, int H, int Win, int C, const int* boun
 int uz_pil_resample_v_f32(const void* src, int Hin, int W, int C, const int* bounds, const int* kk, int ksize, int Hout,
                           const float* mean_host, const float* std_host, int mode, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense token attention (U-Transformer's MultiHeadSelfAttention / MultiHeadCrossAttention,
+ * unet_zoo/models/unet_transformer.py:126-137, :190-213; TransAttUNet's PAM_Module and ScaledDotProductAttention,
+ * unet_zoo/models/transatt_unet.py:41-49, :91-107): torch.bmm + nn.Softmax on (b, tokens, tokens) matrices.
+ *
+ * uz_gemm_nt: y_b[m][n] = sum_k x_b[m][k] * w_b[n][k] (+ bias[n]) (+ res_b[m][n]) for b < batch -- the LDS-DMA GEMM of
+ *   uz_conv_igemm's 1x1 path with a matrix index on the grid.  Strides (ldx, ldw, ldy, ldres: rows; xb, wb, yb, resb:
+ *   matrices; 0 = one operand shared by the batch) in ELEMENTS, all multiples of 16 bytes; one matrix < 2 GB.
+ *   Replaces torch.bmm(Q, K^T), torch.bmm(A, V) and the MultiHeadDense products x @ W (:24-27) and their gradients
+ *   with respect to the left operand; the gradients that contract over the ROWS of both operands (dV = A^T dO,
+ *   dK = dS^T Q, dW = X^T dQ) are uz_wgrad with ntaps = 1.
+ * uz_softmax_fwd: s_b <- softmax(scale * s_b) in place over axis 0 (every COLUMN sums to one: nn.Softmax(dim=1) of a
+ *   (b, rows, cols) tensor, unet_transformer.py:123) or axis 1 (rows; at most 2048 bf16 / 1024 fp32 columns).
+ * uz_softmax_bwd: g_b <- a_b * (g_b - dot) * scale in place, a = the softmax output, dot = sum of a * g along the
+ *   normalised axis.  Axis 0: `dot` is a (batch, cols) fp32 buffer, computed by a first pass unless dot_given != 0
+ *   (attention knows it more cheaply: sum_q A[q][k] dA[q][k] = dV[k] . V[k]); axis 1: computed in registers.
+ * uz_adaptive_avgpool_fwd / _bwd: F.adaptive_avg_pool2d on NHWC maps (:196-198) and its gradient (accumulate != 0: added
+ *   to dx).  uz_rowdot_f32: out[r] = sum_c a[r][c] * b[r][c] (a fp32, b run dtype).  uz_cast_rows: dst = (run dtype) src
+ *   row by row (accumulate != 0: dst += src): the fp32 results of uz_wgrad back into activations.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct uz_gemm_desc {
+  int dtype, batch, M, N, K;
+  int ldx, ldw, ldy, ldres;
+  long long xb, wb, yb, resb;
+} uz_gemm_desc;
+int uz_gemm_nt(const uz_gemm_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y,
+               void* stream);
+int uz_softmax_fwd(int dtype, void* s, int ld, long long sb, int batch, int rows, int cols, int axis, float scale,
+                   void* stream);
+int uz_softmax_bwd(int dtype, const void* a, void* g, int ld, long long sb, int batch, int rows, int cols, int axis,
+                   float scale, float* dot, int dot_given, void* stream);
+int uz_adaptive_avgpool_fwd(int dtype, const void* x, int ldx, int N, int Hi, int Wi, int C, void* y, int ldy, int Ho,
+                            int Wo, void* stream);
+int uz_adaptive_avgpool_bwd(int dtype, const void* g, int ldg, int N, int Hi, int Wi, int C, void* dx, int lddx, int Ho,
+                            int Wo, int accumulate, void* stream);
+int uz_rowdot_f32(int dtype, const float* a, int lda, const void* b, int ldb, long long rows, int C, float* out,
+                  void* stream);
+int uz_cast_rows(int dtype, const float* src, int lds, void* dst, int ldd, long long rows, int C, int accumulate,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,175 @@
+"""GPU: the dense token attention of U-Transformer on the library's own kernels: batched NT products
+(uz_gemm_nt), softmax over either axis and its gradient, F.adaptive_avg_pool2d, and Engine.token_attention as a whole
+against torch autograd on the formula of unet_zoo/models/unet_transformer.py:126-137 / :200-213."""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from unet_zoo_amd import ops
+from unet_zoo_amd.engine import Engine
+from unet_zoo_amd.ops import Act, act_from_nchw
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("batch,M,N,K,pad,shared_x,shared_w", [
+    (1, 300, 72, 40, 0, False, False),       # one matrix, ragged M tile, N below one tile
+    (3, 200, 136, 72, 8, False, False),      # batch, row strides longer than the rows, partial N tile
+    (4, 64, 512, 128, 0, True, False),       # x shared by the batch (the transposed projections)
+    (2, 520, 256, 512, 16, False, True),     # w shared, several K slabs, three M tiles
+    (16, 96, 96, 64, 0, False, False),       # many small matrices
+])
+def test_gemm_nt_matches_bmm(dt, batch, M, N, K, pad, shared_x, shared_w):
+    g = torch.Generator().manual_seed(batch * 1000 + M)
+    ldx, ldw, ldy = K + pad, K + pad, N + pad
+    x = torch.randn(1 if shared_x else batch, M, ldx, generator=g).to(dt).to(DEV)
+    w = torch.randn(1 if shared_w else batch, N, ldw, generator=g).to(dt).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(batch, M, ldy, generator=g).to(dt).to(DEV)
+    y = torch.full((batch, M, ldy), 7.0, dtype=dt, device=DEV)
+    ops.gemm_nt(dt, batch, M, N, K, x.data_ptr(), ldx, 0 if shared_x else M * ldx, w.data_ptr(), ldw, 0 if shared_w else N * ldw,
+                y.data_ptr(), ldy, M * ldy, bias=bias, res_ptr=res.data_ptr(), ldres=ldy, resb=M * ldy)
+    prod = torch.matmul(x[..., :K].double(), w[..., :K].double().transpose(1, 2)) + bias.double()
+    if dt == torch.bfloat16:
+        prod = prod.to(dt).double()                     # the product is rounded to the run dtype before the residual add
+    ref = prod + res[..., :N].double()
+    tol = 1e-5 if dt == torch.float32 else 1.2e-2
+    assert relerr(y[..., :N].cpu(), ref.cpu()) < tol
+    if pad:
+        assert torch.all(y[..., N:] == 7.0)            # nothing written beyond the N columns
+    y2 = torch.empty((batch, M, ldy), dtype=dt, device=DEV)
+    ops.gemm_nt(dt, batch, M, N, K, x.data_ptr(), ldx, 0 if shared_x else M * ldx, w.data_ptr(), ldw, 0 if shared_w else N * ldw,
+                y2.data_ptr(), ldy, M * ldy)
+    ref2 = torch.matmul(x[..., :K].double(), w[..., :K].double().transpose(1, 2))
+    assert relerr(y2[..., :N].cpu(), ref2.cpu()) < tol
+
+
+def test_gemm_nt_refuses_what_it_cannot_address():
+    from unet_zoo_amd._lib import HipLibraryError
+    t = torch.zeros(64, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(HipLibraryError):
+        ops.gemm_nt(torch.bfloat16, 1, 64, 64, 60, t.data_ptr(), 64, 0, t.data_ptr(), 64, 0, t.data_ptr(), 64, 0)   # K % 8
+    with pytest.raises(HipLibraryError):
+        ops.gemm_nt(torch.bfloat16, 1, 64, 64, 64, t.data_ptr(), 32, 0, t.data_ptr(), 64, 0, t.data_ptr(), 64, 0)   # ldx < K
+    with pytest.raises(HipLibraryError):
+        ops.gemm_nt(torch.bfloat16, 1, 64, 64, 64, t.data_ptr() + 2, 64, 0, t.data_ptr(), 64, 0, t.data_ptr(), 64, 0)   # alignment
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("axis,B,R,C", [(0, 3, 384, 384), (0, 2, 1000, 136), (0, 1, 5, 8), (1, 3, 256, 256), (1, 2, 77, 512),
+                                        (1, 1, 9, 1024)])
+def test_softmax_forward_and_gradient(dt, axis, B, R, C):
+    g = torch.Generator().manual_seed(R + C)
+    s = (3.0 * torch.randn(B, R, C, generator=g)).to(dt)
+    scale = 0.37
+    a_ref = torch.softmax(s.double() * scale, dim=1 + axis)
+    a = s.clone().to(DEV)
+    ops.softmax_fwd(a, axis, scale)
+    tol = 2e-6 if dt == torch.float32 else 6e-3
+    assert relerr(a.cpu(), a_ref) < tol
+    sums = a.double().sum(dim=1 + axis).cpu()
+    assert (sums - 1).abs().max() < (1e-5 if dt == torch.float32 else 2e-2)
+    da = torch.randn(B, R, C, generator=g).to(dt)
+    ad = a.double().cpu()
+    ref = ad * (da.double() - (ad * da.double()).sum(dim=1 + axis, keepdim=True)) * scale
+    gdev = da.clone().to(DEV)
+    ops.softmax_bwd(a, gdev, axis, scale)
+    assert relerr(gdev.cpu(), ref) < (1e-5 if dt == torch.float32 else 1e-2)
+    if axis == 0:          # the caller may hand the column sums over
+        dot = (ad * da.double()).sum(dim=1).float().to(DEV).contiguous()
+        g2 = da.clone().to(DEV)
+        ops.softmax_bwd(a, g2, 0, scale, dot)
+        assert relerr(g2.cpu(), ref) < (1e-5 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo", [(32, 32, 64, 64), (128, 128, 64, 64), (12, 20, 16, 24), (7, 9, 3, 4), (16, 24, 16, 24)])
+def test_adaptive_avg_pool_matches_torch(dt, Hi, Wi, Ho, Wo):
+    g = torch.Generator().manual_seed(Hi * Wo)
+    N, C = 2, 24
+    x = torch.randn(N, C, Hi, Wi, generator=g).to(dt).float()
+    xr = x.clone().requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xr, (Ho, Wo))
+    dy = torch.randn(ref.shape, generator=g).to(dt).float()
+    ref.backward(dy)
+    eng = Engine(dt, torch.device(DEV), True, True)
+    xa = act_from_nchw(x.to(DEV), dt)
+    y = eng.adaptive_avg_pool(xa, Ho, Wo)
+    if (Hi, Wi) == (Ho, Wo):
+        assert y is xa
+        return
+    tol = 1e-6 if dt == torch.float32 else 6e-3
+    assert relerr(y.dense().cpu(), ref.detach()) < tol
+    y.add_grad(act_from_nchw(dy.to(DEV), dt))
+    eng.backward_range(None, len(eng.tape), 0)
+    assert relerr(xa.grads[0].dense().cpu(), xr.grad) < tol
+
+
+def _attention_reference(xq, xv, wq, wk, wv):
+    """unet_transformer.py:126-137 on (b, c, h, w) sources"""
+    b, c, h, w = xq.shape
+    tq = xq.flatten(2).permute(0, 2, 1)
+    tv = xv.flatten(2).permute(0, 2, 1)
+    Q, K, V = tq @ wq, tq @ wk, tv @ wv
+    A = torch.softmax(torch.bmm(Q, K.permute(0, 2, 1)) / math.sqrt(c), dim=1)
+    return torch.bmm(A, V).permute(0, 2, 1).reshape(b, c, h, w)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,c,H,W,self_attn", [(2, 64, 16, 24, False), (3, 128, 8, 8, True), (2, 256, 32, 32, False),
+                                                (1, 72, 5, 8, False)])
+def test_token_attention_forward_and_backward_match_autograd(dt, B, c, H, W, self_attn):
+    g = torch.Generator().manual_seed(c + H)
+    xq = torch.randn(B, c, H, W, generator=g).to(dt).float()
+    xv = xq if self_attn else torch.randn(B, c, H, W, generator=g).to(dt).float()
+    ws = [nn.Parameter((torch.randn(c, c, generator=g) * (1.5 / math.sqrt(c))).to(dt).float()) for _ in range(3)]
+    xq_r = xq.double().clone().requires_grad_(True)
+    xv_r = xq_r if self_attn else xv.double().clone().requires_grad_(True)
+    ws_r = [w.detach().double().clone().requires_grad_(True) for w in ws]
+    ref = _attention_reference(xq_r, xv_r, *ws_r)
+    dy = torch.randn(ref.shape, generator=g).to(dt).double()
+    ref.backward(dy)
+
+    ws_d = [nn.Parameter(w.detach().to(DEV)) for w in ws]
+    eng = Engine(dt, torch.device(DEV), True, True)
+    qa = act_from_nchw(xq.to(DEV), dt)
+    va = qa if self_attn else act_from_nchw(xv.to(DEV), dt)
+    out = eng.token_attention(qa, va, *ws_d, eng.new_act(B, H, W, c))
+    ftol, gtol = (2e-5, 1e-4) if dt == torch.float32 else (2e-2, 4e-2)
+    assert relerr(out.dense().cpu(), ref.detach()) < ftol
+    out.add_grad(act_from_nchw(dy.float().to(DEV), dt))
+    eng.backward_range(None, len(eng.tape), 0)
+
+    def l2(a, b):
+        return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+    for w_d, w_r, name in zip(ws_d, ws_r, ("wq", "wk", "wv")):
+        e = l2(eng.param_grads[w_d].cpu(), w_r.grad)
+        assert e < gtol, (name, e)
+    gq = qa.grads[0].dense().cpu() if len(qa.grads) == 1 else sum(a.dense().cpu() for a in qa.grads)
+    assert l2(gq, xq_r.grad) < gtol
+    if not self_attn:
+        assert l2(va.grads[0].dense().cpu(), xv_r.grad) < gtol
+
+
+def test_rowdot_and_cast_rows():
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(300, 136, generator=g).to(DEV)
+    b = torch.randn(300, 136, generator=g).to(torch.bfloat16).to(DEV)
+    out = ops.rowdot_f32(a, b)
+    assert relerr(out.cpu(), (a.double() * b.double()).sum(1).cpu()) < 1e-5
+    dst = ops.new_act(3, 10, 10, 136, torch.bfloat16, DEV)
+    ops.cast_rows(a, dst)
+    assert torch.equal(dst.buf, a.to(torch.bfloat16))
+    ops.cast_rows(a, dst, accumulate=True)
+    assert torch.equal(dst.buf, (a.to(torch.bfloat16).float() + a).to(torch.bfloat16))

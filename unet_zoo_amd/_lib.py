@@ -47,6 +47,8 @@ EXPORTS = (
     "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
     "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res",
     "uz_add_relu", "uz_relu_bwd", "uz_pil_resample_h_u8", "uz_pil_resample_v_f32",
+    "uz_gemm_nt", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd", "uz_adaptive_avgpool_bwd",
+    "uz_rowdot_f32", "uz_cast_rows",
 )
 
 
@@ -79,6 +81,11 @@ class WinAttnDesc(Structure):
 class SraDesc(Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "B", "N", "NK", "heads", "head_dim", "kps", "ldq", "ldk", "ldv", "ldo")] \
         + [("scale", c_float)]
+
+
+class GemmDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("dtype", "batch", "M", "N", "K", "ldx", "ldw", "ldy", "ldres")] \
+        + [(n, ctypes.c_longlong) for n in ("xb", "wb", "yb", "resb")]
 
 
 class SumRowsItem(Structure):
@@ -235,6 +242,13 @@ def load():
     lib.uz_relu_bwd.argtypes = [ip, vp, ip, vp, ip, vp, ip, ll, ip, vp]
     lib.uz_pil_resample_h_u8.argtypes = [vp, ip, ip, ip, vp, vp, ip, ip, vp, vp]
     lib.uz_pil_resample_v_f32.argtypes = [vp, ip, ip, ip, vp, vp, ip, ip, POINTER(c_float), POINTER(c_float), ip, vp, vp]
+    lib.uz_gemm_nt.argtypes = [POINTER(GemmDesc), vp, vp, vp, vp, vp, vp]
+    lib.uz_softmax_fwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, c_float, vp]
+    lib.uz_softmax_bwd.argtypes = [ip, vp, vp, ip, ll, ip, ip, ip, ip, c_float, vp, ip, vp]
+    lib.uz_adaptive_avgpool_fwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, ip, ip, vp]
+    lib.uz_adaptive_avgpool_bwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, ip, ip, ip, vp]
+    lib.uz_rowdot_f32.argtypes = [ip, vp, ip, vp, ip, ll, ip, vp, vp]
+    lib.uz_cast_rows.argtypes = [ip, vp, ip, vp, ip, ll, ip, ip, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("uz_last_error_string", "uz_source_hash"):

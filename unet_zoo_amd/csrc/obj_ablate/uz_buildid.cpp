@@ -1,1 +1,1 @@
-extern "C" const char* uz_source_hash(void) { return "702bd7f0a8a9f4c1a66f5aa50fba74f0bb5929efd93ac3895d7370ebc2f26ea1"; }
+extern "C" const char* uz_source_hash(void) { return "4351658698f7590e6fbf376fc36b865cc03b36a04f80023a82a6792e8efae26b"; }

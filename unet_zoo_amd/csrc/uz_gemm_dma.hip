@@ -32,6 +32,10 @@ struct GArgs {
   int ld_bny;
   unsigned xbytes, wbytes;
   int M, H, W, Hin, Win, Cin, ldx, Nout, ldy, K, ntaps, mode, store, Co, tiles_m, Hout, Wout, dil;
+  // batched products (uz_gemm_nt): blockIdx.z = matrix index, byte strides between consecutive matrices (0 = shared
+  // operand); ldw = row stride of w in elements (the convolution paths: K)
+  int ldw;
+  long long xb, wb, yb, resb;
 };
 
 template <typename T> struct Mma3;
@@ -82,9 +86,13 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * BN;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.wbytes, 0x00020000);
-  T* __restrict__ yg = static_cast<T*>(a.y);
+  const long long bz = blockIdx.z;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(static_cast<const char*>(a.x)) + bz * a.xb, 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(static_cast<const char*>(a.w)) + bz * a.wb, 0, a.wbytes, 0x00020000);
+  T* __restrict__ yg = reinterpret_cast<T*>(static_cast<char*>(a.y) + bz * a.yb);
+  const T* __restrict__ resg = a.res ? reinterpret_cast<const T*>(static_cast<const char*>(a.res) + bz * a.resb) : nullptr;
   const int HW = a.H * a.W;
   const int ncb = (a.Cin + BK - 1) / BK;  // the last slab of a tap may be partial: zero-filled
   const int nsteps = a.ntaps * ncb;
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
 #pragma unroll
   for (int i = 0; i < NBP; ++i) {
     const int n = (wave + 8 * i) * 8 + (lane >> 3);
-    b_row_off[i] = (n0 + n < a.Nout) ? (unsigned)(n0 + n) * (unsigned)a.K * ES : OOB;
+    b_row_off[i] = (n0 + n < a.Nout) ? (unsigned)(n0 + n) * (unsigned)a.ldw * ES : OOB;
     b_coff[i] = (((lane & 7) ^ ((n >> 1) & 7)) * VEC) * ES;
   }
   const int cin_bytes = a.Cin * ES;
@@ -307,8 +315,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
           *reinterpret_cast<f32x4*>(&bsh[e]) = *reinterpret_cast<const f32x4*>(a.bn_shift + ch0 + e);
         }
       }
-      if (a.res != nullptr) {   // y = (x W^T + b) + res, rounded as a separate add of the stored result would be
-        const T* rg = static_cast<const T*>(a.res);
+      if (resg != nullptr) {   // y = (x W^T + b) + res, rounded as a separate add of the stored result would be
+        const T* rg = resg;
         Vec16<T> rb[NPASS];
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
             const long long orow = out_row(ml, ab);
             if (orow >= 0 && n0 + col < a.Nout) {
               T tv = (T)(acc[i][j][r] + bv[j]);
-              if (a.res != nullptr) tv += static_cast<const T*>(a.res)[(size_t)orow * a.ldres + co0 + col];
+              if (resg != nullptr) tv += resg[(size_t)orow * a.ldres + co0 + col];
               yg[(size_t)orow * a.ldy + co0 + col] = tv;
               const float fv = (float)tv;
               s1[j] += fv;
@@ -476,8 +484,8 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
 }
 
 template <typename T>
-static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
-  dim3 grid(p.grid_m, p.tiles_n), block(512);
+static int gemm_launch_grid(const UzGemmPlan& p, const GArgs& a, dim3 grid, hipStream_t s) {
+  dim3 block(512);
   if constexpr (sizeof(T) == 2) {
     if (a.bn_y != nullptr) {
       if (p.bn == 64 && p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 2, true>), grid, block, 0, s, a);
@@ -496,6 +504,11 @@ static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 256, 3>), grid, block, 0, s, a);
   UZ_LAUNCH_CHECK("uz_conv_igemm(gemm_dma)");
   return UZ_OK;
+}
+
+template <typename T>
+static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
+  return gemm_launch_grid<T>(p, a, dim3(p.grid_m, p.tiles_n), s);
 }
 
 int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
@@ -538,5 +551,88 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x
   a.Co = d->Co;
   a.dil = d->dil;
   a.tiles_m = p.tiles_m;
+  a.ldw = a.K;
+  a.xb = a.wb = a.yb = a.resb = 0;
   return d->dtype == UZ_BF16 ? gemm_launch_t<bf16_t>(p, a, s) : gemm_launch_t<float>(p, a, s);
+}
+
+// ---- uz_gemm_nt: batched y_b = x_b w_b^T (+ bias, + res_b) on the same kernel --------------------------------------
+static int gemm_nt_plan(const uz_gemm_desc* d, UzGemmPlan* p) {
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4;
+  UZ_REQUIRE(d->dtype == UZ_BF16 || d->dtype == UZ_F32, "uz_gemm_nt: dtype");
+  UZ_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->M >= 1 && d->N >= 1 && d->K >= 1, "uz_gemm_nt: empty problem");
+  UZ_REQUIRE(d->K % vec == 0 && d->N % vec == 0 && d->ldx % vec == 0 && d->ldw % vec == 0 && d->ldy % vec == 0 &&
+                 d->ldres % vec == 0,
+             "uz_gemm_nt: K, N and the row strides must be multiples of 16 bytes");
+  UZ_REQUIRE(d->ldx >= d->K && d->ldw >= d->K && d->ldy >= d->N, "uz_gemm_nt: row strides shorter than the rows");
+  UZ_REQUIRE(d->xb % vec == 0 && d->wb % vec == 0 && d->yb % vec == 0 && d->resb % vec == 0,
+             "uz_gemm_nt: matrix strides must be multiples of 16 bytes");
+  const long long xbytes = ((long long)d->M - 1) * d->ldx * es + (long long)d->K * es;
+  const long long wbytes = ((long long)d->N - 1) * d->ldw * es + (long long)d->K * es;
+  UZ_REQUIRE(xbytes < (1LL << 31) && wbytes < (1LL << 31), "uz_gemm_nt: one matrix must stay below 2 GB");
+  p->bn = d->N <= 64 ? 64 : 128;
+  p->tiles_n = (d->N + p->bn - 1) / p->bn;
+  const long long per = (long long)p->tiles_n * d->batch;
+  p->bm = (p->bn == 128 && (((long long)d->M + 255) / 256) * per * 2 <= UZ_NUM_CU) ? 128 : 256;
+  const int nsteps = (d->K + 8 * vec - 1) / (8 * vec);
+  p->nst = p->bm == 128 ? 4 : 3;
+  if (nsteps <= 2) {
+    if (p->bn == 128) p->bm = 128;
+    p->nst = 2;
+  }
+  p->tiles_m = (d->M + p->bm - 1) / p->bm;
+  long long cap = (p->nst == 2 ? 2 : 1) * (long long)UZ_NUM_CU / per;
+  if (cap < 1) cap = 1;
+  p->grid_m = p->tiles_m < cap ? p->tiles_m : (int)cap;
+  return UZ_OK;
+}
+
+extern "C" int uz_gemm_nt(const uz_gemm_desc* d, const void* x, const void* w, const float* bias, const void* res,
+                          void* y, void* stream) {
+  UZ_REQUIRE(d && x && w && y, "uz_gemm_nt: null pointer");
+  UzGemmPlan p;
+  const int rc = gemm_nt_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "uz_gemm_nt: operands must be 16-byte aligned");
+  const int es = d->dtype == UZ_BF16 ? 2 : 4;
+  GArgs a;
+  a.bn_y = nullptr;
+  a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr;
+  a.ld_bny = 0;
+  a.x = x;
+  a.w = w;
+  a.y = y;
+  a.bias = bias;
+  a.stats = nullptr;
+  a.res = res;
+  a.ldres = d->ldres;
+  a.xbytes = (unsigned)(((long long)d->M - 1) * d->ldx * es + (long long)d->K * es);
+  a.wbytes = (unsigned)(((long long)d->N - 1) * d->ldw * es + (long long)d->K * es);
+  a.M = d->M;
+  a.H = 1;
+  a.W = d->M;
+  a.Hin = 1;
+  a.Win = d->M;
+  a.Hout = 2;
+  a.Wout = 2 * d->M;
+  a.Cin = d->K;
+  a.ldx = d->ldx;
+  a.Nout = d->N;
+  a.ldy = d->ldy;
+  a.K = d->K;
+  a.ntaps = 1;
+  a.mode = UZ_TAPS_CONV;
+  a.store = UZ_STORE_PLAIN;
+  a.Co = d->N;
+  a.dil = 1;
+  a.tiles_m = p.tiles_m;
+  a.ldw = d->ldw;
+  a.xb = d->xb * es;
+  a.wb = d->wb * es;
+  a.yb = d->yb * es;
+  a.resb = d->resb * es;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(p.grid_m, p.tiles_n, d->batch), block(512);
+  if (d->dtype == UZ_BF16) return gemm_launch_grid<bf16_t>(p, a, grid, s);
+  return gemm_launch_grid<float>(p, a, grid, s);
 }

@@ -1,0 +1,463 @@
+// Pieces of the dense token attention of U-Transformer / TransAttUNet around the batched matrix products
+// (uz_gemm_nt for the NT products, uz_wgrad's one-tap kernel for the TN products):
+//   * softmax over either axis of a batch of (rows, cols) score matrices, in place, and its gradient
+//     (unet_zoo/models/unet_transformer.py:123,133-134: nn.Softmax(dim=1) of a (b, queries, keys) tensor normalises
+//     every key's COLUMN over the queries; transatt_unet.py:35,47 and :101 normalise rows),
+//   * F.adaptive_avg_pool2d on NHWC maps and its gradient (unet_transformer.py:196-198),
+//   * row dot products and fp32 -> run-dtype conversion of the fp32 TN results.
+// All of it is HBM-bound element work: 16-byte accesses, one pass where the mathematics allows it.
+#include "uz_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float tof(T v) { return (float)v; }
+
+// ---- softmax over the ROW axis of (rows, cols): every column is normalised ------------------------------------------
+// workgroup = one strip of 16 * VEC columns of one matrix; 16 threads across the strip (16 bytes each), 16 row groups.
+// Pass 1 keeps a running maximum and a running sum of exponentials per column (one exp per element plus one per
+// maximum update), the 16 row groups are merged through LDS, pass 2 re-reads the strip (L2 / MALL resident for the
+// sizes at hand: 4096 rows x 256 B = 1 MB per strip) and writes exp(x * scale - m) / Z.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cols_fwd_kernel(T* s, int ld, long long sb, int rows, int cols, float scale) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int SW = 16 * VEC;
+  __shared__ float sm[16][SW], sz[16][SW];
+  const int tid = threadIdx.x, cx = tid & 15, rg = tid >> 4;
+  const int c0 = blockIdx.x * SW + cx * VEC;
+  T* base = s + (long long)blockIdx.y * sb;
+  const bool ok = c0 < cols;
+  float m[VEC], z[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; z[e] = 0.f; }
+  if (ok) {
+    for (int r = rg; r < rows; r += 64) {
+      Vec16<T> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 16 * u < rows) v[u] = ld16(base + (long long)(r + 16 * u) * ld + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + 16 * u < rows) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float x = tof(v[u].v[e]) * scale;
+            if (x > m[e]) {
+              z[e] = z[e] * __expf(m[e] - x) + 1.f;
+              m[e] = x;
+            } else {
+              z[e] += __expf(x - m[e]);
+            }
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sm[rg][cx * VEC + e] = m[e]; sz[rg][cx * VEC + e] = z[e]; }
+  __syncthreads();
+  float rz[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) mm = fmaxf(mm, sm[g][cx * VEC + e]);
+    float zz = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float mg = sm[g][cx * VEC + e];
+      zz += mg == -INFINITY ? 0.f : sz[g][cx * VEC + e] * __expf(mg - mm);
+    }
+    m[e] = mm;
+    rz[e] = 1.f / zz;
+  }
+  if (!ok) return;
+  for (int r = rg; r < rows; r += 64) {
+    Vec16<T> v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + 16 * u < rows) v[u] = ld16(base + (long long)(r + 16 * u) * ld + c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + 16 * u < rows) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[u].v[e] = (T)(__expf(tof(v[u].v[e]) * scale - m[e]) * rz[e]);
+        st16(base + (long long)(r + 16 * u) * ld + c0, v[u]);
+      }
+  }
+}
+
+// column dot products dot[b][c] = sum_r a[r][c] * g[r][c] (only when the caller has no cheaper way to them)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cols_dot_kernel(const T* a, const T* g, int ld, long long sb, int rows, int cols,
+                                                               float* dot) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  constexpr int SW = 16 * VEC;
+  __shared__ float sd[16][SW];
+  const int tid = threadIdx.x, cx = tid & 15, rg = tid >> 4;
+  const int c0 = blockIdx.x * SW + cx * VEC;
+  const T* ab = a + (long long)blockIdx.y * sb;
+  const T* gb = g + (long long)blockIdx.y * sb;
+  float d[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) d[e] = 0.f;
+  if (c0 < cols)
+    for (int r = rg; r < rows; r += 16) {
+      const Vec16<T> va = ld16(ab + (long long)r * ld + c0), vg = ld16(gb + (long long)r * ld + c0);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d[e] = fmaf(tof(va.v[e]), tof(vg.v[e]), d[e]);
+    }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sd[rg][cx * VEC + e] = d[e];
+  __syncthreads();
+  if (tid < SW && blockIdx.x * SW + tid < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) t += sd[g2][tid];
+    dot[(long long)blockIdx.y * cols + blockIdx.x * SW + tid] = t;
+  }
+}
+
+// dS = A * (dA - dot[column]) * scale, written over dA
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cols_bwd_kernel(const T* a, T* g, int ld, long long sb, int rows, int cols,
+                                                               float scale, const float* dot, long long chunks) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = cols / VEC;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const long long rr = i / cpr;
+    const int r = (int)(rr % rows), b = (int)(rr / rows);
+    const long long off = (long long)b * sb + (long long)r * ld + cc * VEC;
+    const Vec16<T> va = ld16(a + off);
+    Vec16<T> vg = ld16(g + off);
+    const float* dp = dot + (long long)b * cols + cc * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) vg.v[e] = (T)(tof(va.v[e]) * (tof(vg.v[e]) - dp[e]) * scale);
+    st16(g + off, vg);
+  }
+}
+
+// ---- softmax over the COLUMN axis: one wave per row, the row stays in registers (cols <= 64 * VEC * RPT) ------------
+template <typename T, int RPT, bool BWD>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* a, T* s, int ld, long long sb, int rows, int cols, float scale,
+                                                           long long total_rows) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < total_rows; row += (long long)gridDim.x * 4) {
+    const int b = (int)(row / rows), r = (int)(row % rows);
+    const long long off = (long long)b * sb + (long long)r * ld;
+    Vec16<T> v[RPT], w[RPT];
+    float red = BWD ? 0.f : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int c = (u * 64 + lane) * VEC;
+      if (c < cols) {
+        v[u] = ld16(s + off + c);
+        if constexpr (BWD) {
+          w[u] = ld16(a + off + c);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) red = fmaf(tof(v[u].v[e]), tof(w[u].v[e]), red);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) red = fmaxf(red, tof(v[u].v[e]) * scale);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float t = __shfl_xor(red, o);
+      red = BWD ? red + t : fmaxf(red, t);
+    }
+    if constexpr (BWD) {   // dS = A * (dA - sum(A dA)) * scale
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int c = (u * 64 + lane) * VEC;
+        if (c < cols) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[u].v[e] = (T)(tof(w[u].v[e]) * (tof(v[u].v[e]) - red) * scale);
+          st16(s + off + c, v[u]);
+        }
+      }
+    } else {
+      float ex[RPT][VEC], z = 0.f;
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int c = (u * 64 + lane) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          ex[u][e] = c < cols ? __expf(tof(v[u].v[e]) * scale - red) : 0.f;
+          z += ex[u][e];
+        }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o);
+      const float rz = 1.f / z;
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int c = (u * 64 + lane) * VEC;
+        if (c < cols) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[u].v[e] = (T)(ex[u][e] * rz);
+          st16(s + off + c, v[u]);
+        }
+      }
+    }
+  }
+}
+
+// ---- F.adaptive_avg_pool2d on NHWC: window of output i = [floor(i * In / Out), ceil((i + 1) * In / Out)) --------------
+__device__ __forceinline__ int ap_start(int i, int in, int out) { return (int)(((long long)i * in) / out); }
+__device__ __forceinline__ int ap_end(int i, int in, int out) { return (int)(((long long)(i + 1) * in + out - 1) / out); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const T* x, int ldx, int N, int Hi, int Wi, int C, T* y, int ldy,
+                                                                int Ho, int Wo, long long chunks) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    long long p = i / cpr;
+    const int ow = (int)(p % Wo);
+    p /= Wo;
+    const int oh = (int)(p % Ho), n = (int)(p / Ho);
+    const int h0 = ap_start(oh, Hi, Ho), h1 = ap_end(oh, Hi, Ho), w0 = ap_start(ow, Wi, Wo), w1 = ap_end(ow, Wi, Wo);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) {
+        const Vec16<T> v = ld16(x + (((long long)n * Hi + h) * Wi + w) * ldx + cc * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += tof(v.v[e]);
+      }
+    const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.v[e] = (T)(acc[e] * inv);
+    st16(y + (((long long)n * Ho + oh) * Wo + ow) * ldy + cc * VEC, o);
+  }
+}
+
+// gradient, gathered per INPUT pixel: every output window that contains (h, w) contributes g / area
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const T* g, int ldg, int N, int Hi, int Wi, int C, T* dx, int lddx,
+                                                                int Ho, int Wo, int accumulate, long long chunks) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    long long p = i / cpr;
+    const int w = (int)(p % Wi);
+    p /= Wi;
+    const int h = (int)(p % Hi), n = (int)(p / Hi);
+    int oh_lo = (int)(((long long)h * Ho) / Hi) - 1, oh_hi = (int)(((long long)(h + 1) * Ho + Hi - 1) / Hi);
+    int ow_lo = (int)(((long long)w * Wo) / Wi) - 1, ow_hi = (int)(((long long)(w + 1) * Wo + Wi - 1) / Wi);
+    oh_lo = oh_lo < 0 ? 0 : oh_lo;
+    ow_lo = ow_lo < 0 ? 0 : ow_lo;
+    oh_hi = oh_hi >= Ho ? Ho - 1 : oh_hi;
+    ow_hi = ow_hi >= Wo ? Wo - 1 : ow_hi;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const int h0 = ap_start(oh, Hi, Ho), h1 = ap_end(oh, Hi, Ho);
+      if (h < h0 || h >= h1) continue;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int w0 = ap_start(ow, Wi, Wo), w1 = ap_end(ow, Wi, Wo);
+        if (w < w0 || w >= w1) continue;
+        const float inv = 1.f / (float)((h1 - h0) * (w1 - w0));
+        const Vec16<T> v = ld16(g + (((long long)n * Ho + oh) * Wo + ow) * ldg + cc * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = fmaf(tof(v.v[e]), inv, acc[e]);
+      }
+    }
+    T* dp = dx + (((long long)n * Hi + h) * Wi + w) * lddx + cc * VEC;
+    Vec16<T> o;
+    if (accumulate) {
+      o = ld16(dp);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.v[e] = (T)(tof(o.v[e]) + acc[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.v[e] = (T)acc[e];
+    }
+    st16(dp, o);
+  }
+}
+
+// ---- out[r] = sum_c a[r][c] * b[r][c] (a fp32, b run dtype): one wave per row ----------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* a, int lda, const T* b, int ldb, long long rows, int C, float* out) {
+  const int lane = threadIdx.x & 63;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+    float t = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 va = *reinterpret_cast<const f32x4*>(a + r * lda + c);
+      const T* bp = b + r * ldb + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t = fmaf(va[e], tof(bp[e]), t);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) out[r] = t;
+  }
+}
+
+// ---- dst[r][c] = (T) src[r][c] -----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* src, int lds, T* dst, int ldd, long long rows, int C,
+                                                        int accumulate, long long chunks) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const long long r = i / cpr;
+    float sp[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4) *reinterpret_cast<f32x4*>(&sp[e]) = *reinterpret_cast<const f32x4*>(src + r * lds + cc * VEC + e);
+    T* dp = dst + r * ldd + cc * VEC;
+    Vec16<T> o;
+    if (accumulate) {
+      o = ld16(dp);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.v[e] = (T)(tof(o.v[e]) + sp[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.v[e] = (T)sp[e];
+    }
+    st16(dp, o);
+  }
+}
+
+inline unsigned grid_for_chunks(long long chunks) {
+  long long g = (chunks + 255) / 256;
+  const long long cap = 16LL * UZ_NUM_CU_HW;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+bool softmax_args_ok(int dtype, const void* s, int ld, long long sb, int batch, int rows, int cols, int axis) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  return (dtype == UZ_F32 || dtype == UZ_BF16) && s && batch >= 1 && batch <= 65535 && rows >= 1 && cols >= 1 &&
+         cols % vec == 0 && ld % vec == 0 && ld >= cols && sb % vec == 0 && (axis == 0 || axis == 1) &&
+         ((uintptr_t)s & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int uz_softmax_fwd(int dtype, void* s, int ld, long long sb, int batch, int rows, int cols, int axis, float scale,
+                              void* stream) {
+  UZ_REQUIRE(softmax_args_ok(dtype, s, ld, sb, batch, rows, cols, axis), "uz_softmax_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  if (axis == 0) {
+    const dim3 grid(uz_cdiv(cols, 16 * vec), batch), block(256);
+    if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_fwd_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)s, ld, sb, rows, cols, scale);
+    else hipLaunchKernelGGL(softmax_cols_fwd_kernel<float>, grid, block, 0, st, (float*)s, ld, sb, rows, cols, scale);
+  } else {
+    UZ_REQUIRE(cols <= 64 * vec * 4, "uz_softmax_fwd: rows longer than 64 * 4 sixteen-byte chunks");
+    const long long total = (long long)batch * rows;
+    const dim3 grid(grid_for_chunks(total * 64)), block(256);
+    const int rpt = uz_cdiv(cols, 64 * vec);
+#define UZ_ROWS_FWD(T, R) hipLaunchKernelGGL((softmax_rows_kernel<T, R, false>), grid, block, 0, st, (const T*)nullptr, (T*)s, ld, sb, rows, cols, scale, total)
+    if (dtype == UZ_BF16) {
+      if (rpt == 1) UZ_ROWS_FWD(bf16_t, 1); else if (rpt == 2) UZ_ROWS_FWD(bf16_t, 2); else UZ_ROWS_FWD(bf16_t, 4);
+    } else {
+      if (rpt == 1) UZ_ROWS_FWD(float, 1); else if (rpt == 2) UZ_ROWS_FWD(float, 2); else UZ_ROWS_FWD(float, 4);
+    }
+#undef UZ_ROWS_FWD
+  }
+  UZ_LAUNCH_CHECK("uz_softmax_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_softmax_bwd(int dtype, const void* a, void* g, int ld, long long sb, int batch, int rows, int cols, int axis,
+                              float scale, float* dot, int dot_given, void* stream) {
+  UZ_REQUIRE(softmax_args_ok(dtype, g, ld, sb, batch, rows, cols, axis) && a && ((uintptr_t)a & 15) == 0,
+             "uz_softmax_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  if (axis == 0) {
+    UZ_REQUIRE(dot != nullptr, "uz_softmax_bwd: axis 0 needs the (batch, cols) fp32 buffer `dot`");
+    if (!dot_given) {
+      const dim3 grid(uz_cdiv(cols, 16 * vec), batch), block(256);
+      if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_dot_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, (const bf16_t*)g, ld, sb, rows, cols, dot);
+      else hipLaunchKernelGGL(softmax_cols_dot_kernel<float>, grid, block, 0, st, (const float*)a, (const float*)g, ld, sb, rows, cols, dot);
+      UZ_LAUNCH_CHECK("uz_softmax_bwd(dot)");
+    }
+    const long long chunks = (long long)batch * rows * (cols / vec);
+    const dim3 grid(grid_for_chunks(chunks)), block(256);
+    if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, (bf16_t*)g, ld, sb, rows, cols, scale, dot, chunks);
+    else hipLaunchKernelGGL(softmax_cols_bwd_kernel<float>, grid, block, 0, st, (const float*)a, (float*)g, ld, sb, rows, cols, scale, dot, chunks);
+  } else {
+    UZ_REQUIRE(cols <= 64 * vec * 4, "uz_softmax_bwd: rows longer than 64 * 4 sixteen-byte chunks");
+    const long long total = (long long)batch * rows;
+    const dim3 grid(grid_for_chunks(total * 64)), block(256);
+    const int rpt = uz_cdiv(cols, 64 * vec);
+#define UZ_ROWS_BWD(T, R) hipLaunchKernelGGL((softmax_rows_kernel<T, R, true>), grid, block, 0, st, (const T*)a, (T*)g, ld, sb, rows, cols, scale, total)
+    if (dtype == UZ_BF16) {
+      if (rpt == 1) UZ_ROWS_BWD(bf16_t, 1); else if (rpt == 2) UZ_ROWS_BWD(bf16_t, 2); else UZ_ROWS_BWD(bf16_t, 4);
+    } else {
+      if (rpt == 1) UZ_ROWS_BWD(float, 1); else if (rpt == 2) UZ_ROWS_BWD(float, 2); else UZ_ROWS_BWD(float, 4);
+    }
+#undef UZ_ROWS_BWD
+  }
+  UZ_LAUNCH_CHECK("uz_softmax_bwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_adaptive_avgpool_fwd(int dtype, const void* x, int ldx, int N, int Hi, int Wi, int C, void* y, int ldy, int Ho,
+                                       int Wo, void* stream) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 &&
+                 C % vec == 0 && ldx % vec == 0 && ldy % vec == 0 && ldx >= C && ldy >= C,
+             "uz_adaptive_avgpool_fwd: bad arguments");
+  const long long chunks = (long long)N * Ho * Wo * (C / vec);
+  const dim3 grid(grid_for_chunks(chunks)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UZ_BF16) hipLaunchKernelGGL(adaptive_pool_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, N, Hi, Wi, C, (bf16_t*)y, ldy, Ho, Wo, chunks);
+  else hipLaunchKernelGGL(adaptive_pool_fwd_kernel<float>, grid, block, 0, st, (const float*)x, ldx, N, Hi, Wi, C, (float*)y, ldy, Ho, Wo, chunks);
+  UZ_LAUNCH_CHECK("uz_adaptive_avgpool_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_adaptive_avgpool_bwd(int dtype, const void* g, int ldg, int N, int Hi, int Wi, int C, void* dx, int lddx, int Ho,
+                                       int Wo, int accumulate, void* stream) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && g && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 &&
+                 C % vec == 0 && ldg % vec == 0 && lddx % vec == 0 && ldg >= C && lddx >= C,
+             "uz_adaptive_avgpool_bwd: bad arguments");
+  const long long chunks = (long long)N * Hi * Wi * (C / vec);
+  const dim3 grid(grid_for_chunks(chunks)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UZ_BF16) hipLaunchKernelGGL(adaptive_pool_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)g, ldg, N, Hi, Wi, C, (bf16_t*)dx, lddx, Ho, Wo, accumulate, chunks);
+  else hipLaunchKernelGGL(adaptive_pool_bwd_kernel<float>, grid, block, 0, st, (const float*)g, ldg, N, Hi, Wi, C, (float*)dx, lddx, Ho, Wo, accumulate, chunks);
+  UZ_LAUNCH_CHECK("uz_adaptive_avgpool_bwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_rowdot_f32(int dtype, const float* a, int lda, const void* b, int ldb, long long rows, int C, float* out,
+                             void* stream) {
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && a && b && out && rows > 0 && C > 0 && C % 4 == 0 && lda % 4 == 0 &&
+                 lda >= C && ldb >= C && ((uintptr_t)a & 15) == 0,
+             "uz_rowdot_f32: bad arguments");
+  const dim3 grid(grid_for_chunks(rows * 64)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UZ_BF16) hipLaunchKernelGGL(rowdot_kernel<bf16_t>, grid, block, 0, st, a, lda, (const bf16_t*)b, ldb, rows, C, out);
+  else hipLaunchKernelGGL(rowdot_kernel<float>, grid, block, 0, st, a, lda, (const float*)b, ldb, rows, C, out);
+  UZ_LAUNCH_CHECK("uz_rowdot_f32");
+  return UZ_OK;
+}
+
+extern "C" int uz_cast_rows(int dtype, const float* src, int lds, void* dst, int ldd, long long rows, int C, int accumulate,
+                            void* stream) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && src && dst && rows > 0 && C > 0 && C % vec == 0 && ldd % vec == 0 &&
+                 lds % 4 == 0 && lds >= C && ldd >= C && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0,
+             "uz_cast_rows: bad arguments");
+  const long long chunks = rows * (C / vec);
+  const dim3 grid(grid_for_chunks(chunks)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UZ_BF16) hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, grid, block, 0, st, src, lds, (bf16_t*)dst, ldd, rows, C, accumulate, chunks);
+  else hipLaunchKernelGGL(cast_rows_kernel<float>, grid, block, 0, st, src, lds, (float*)dst, ldd, rows, C, accumulate, chunks);
+  UZ_LAUNCH_CHECK("uz_cast_rows");
+  return UZ_OK;
+}

@@ -10,6 +10,7 @@ momentum and the unbiased variance; eval mode uses the running statistics.
 """
 from __future__ import annotations
 
+import math
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -1179,6 +1180,113 @@ class Engine:
                 ys = run()
             for t, o in zip(ys, outs):
                 self._store_nchw(t, o)
+        return out
+
+    def adaptive_avg_pool(self, x: Act, Ho: int, Wo: int) -> Act:
+        """F.adaptive_avg_pool2d(x, (Ho, Wo)) (unet_transformer.py:196-198); the identity when the map already has that
+        size"""
+        if (x.H, x.W) == (Ho, Wo):
+            return x
+        y = self.new_act(x.N, Ho, Wo, x.C, needs_grad=x.needs_grad)
+        ops.adaptive_avgpool_fwd(x, y)
+        if self.record and x.needs_grad:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                ops.adaptive_avgpool_bwd(g, dx)
+                x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def token_attention(self, xq: Act, xv: Act, wq: nn.Parameter, wk: nn.Parameter, wv: nn.Parameter, out: Act) -> Act:
+        """out_b = softmax_over_queries((X_b wq)(X_b wk)^T / sqrt(c)) (XV_b wv) on the tokens of xq / xv (NHWC rows = the
+        reference's `flatten(2).permute(0, 2, 1)`): MultiHeadSelfAttention.forward (xq is xv) and the attention core of
+        MultiHeadCrossAttention.forward (unet_transformer.py:126-137, :200-213).  `nn.Softmax(dim=1)` on the (b, queries,
+        keys) scores normalises over the QUERY axis, as the reference has it.
+
+        Batched NT products (uz_gemm_nt; the transposed projections V^T = wv^T XV^T, K^T = wk^T X^T come out of the same
+        kernel with the operand roles swapped, so no transposing pass exists), column softmax in place on the score
+        matrix (kept for the backward), TN products (dV = A^T dO, dK = dS^T Q, the weight gradients) on uz_wgrad's
+        one-tap kernel."""
+        B, Nt, c = xq.N, xq.H * xq.W, xq.C
+        assert (xv.N, xv.H * xv.W, xv.C) == (B, Nt, c) and (out.N, out.H * out.W, out.C) == (B, Nt, c)
+        assert tuple(wq.shape) == (c, c) and tuple(wk.shape) == (c, c) and tuple(wv.shape) == (c, c)
+        dt, dev = self.dtype, self.device
+        scale = 1.0 / math.sqrt(c)
+        es = 2 if dt == torch.bfloat16 else 4
+
+        def proj(x: Act, w: nn.Parameter) -> torch.Tensor:            # (B Nt, c) = X w
+            y = torch.empty((B * Nt, c), dtype=dt, device=dev)
+            ops.gemm_nt(dt, 1, B * Nt, c, c, x.ptr(), x.ld, 0, self._pack(w, L.PACK_CONV_DGRAD).data_ptr(), c, 0,
+                        y.data_ptr(), c, 0)
+            return y
+
+        def proj_t(x: Act, w: nn.Parameter) -> torch.Tensor:          # (B, c, Nt) = (X_b w)^T = w^T X_b^T
+            y = torch.empty((B, c, Nt), dtype=dt, device=dev)
+            ops.gemm_nt(dt, B, c, Nt, c, self._pack(w, L.PACK_CONV_DGRAD).data_ptr(), c, 0, x.ptr(), x.ld, Nt * x.ld,
+                        y.data_ptr(), Nt, c * Nt)
+            return y
+
+        Q, K = proj(xq, wq), proj(xq, wk)
+        Vt = proj_t(xv, wv)
+        A = torch.empty((B, Nt, Nt), dtype=dt, device=dev)
+        ops.gemm_nt(dt, B, Nt, Nt, c, Q.data_ptr(), c, Nt * c, K.data_ptr(), c, Nt * c, A.data_ptr(), Nt, Nt * Nt)
+        ops.softmax_fwd(A, 0, scale)
+        ops.gemm_nt(dt, B, Nt, c, Nt, A.data_ptr(), Nt, Nt * Nt, Vt.data_ptr(), Nt, c * Nt, out.ptr(), out.ld, Nt * out.ld)
+        del Vt
+        if not self.record:
+            return out
+
+        def tn_per_image(Lm: torch.Tensor, R: Act) -> torch.Tensor:
+            """out[b] = Lm[b]^T R_b: (B, Nt, c) fp32 from Lm (B, Nt, Nt) and the (B Nt, c) rows of R"""
+            o = torch.empty((B * Nt, c), dtype=torch.float32, device=dev)
+            for b in range(B):
+                ops.wgrad(Act(Lm[b], 0, Nt, 1, 1, Nt), R.rows(b * Nt, 1, 1, Nt), (Nt, c), ntaps=1, out=o[b * Nt:(b + 1) * Nt])
+            return o
+
+        def as_act(t: torch.Tensor) -> Act:
+            return Act(t, 0, c, B, xq.H, xq.W)
+
+        def bwd():
+            g = self._total_grad(out)
+            if g is None:
+                return
+            V = proj(xv, wv)
+            dA = torch.empty((B, Nt, Nt), dtype=dt, device=dev)
+            ops.gemm_nt(dt, B, Nt, Nt, c, g.ptr(), g.ld, Nt * g.ld, V.data_ptr(), c, Nt * c, dA.data_ptr(), Nt, Nt * Nt)
+            dV32 = tn_per_image(A, g)
+            # sum_q A[q][k] dA[q][k] = dV[k] . V[k]: the softmax gradient's column sums without a pass over A and dA
+            dot = ops.rowdot_f32(dV32, V).view(B, Nt)
+            ops.softmax_bwd(A, dA, 0, scale, dot)          # dA now holds dS
+            dV = self.new_act(B, xq.H, xq.W, c)
+            ops.cast_rows(dV32, dV)
+            del dV32, V
+            Kt = proj_t(xq, wk)
+            dQ = self.new_act(B, xq.H, xq.W, c)
+            ops.gemm_nt(dt, B, Nt, c, Nt, dA.data_ptr(), Nt, Nt * Nt, Kt.data_ptr(), Nt, c * Nt, dQ.ptr(), c, Nt * c)
+            del Kt
+            dK32 = tn_per_image(dA, as_act(Q))
+            dK = self.new_act(B, xq.H, xq.W, c)
+            ops.cast_rows(dK32, dK)
+            del dK32, dA
+            self._give_grad(wq, ops.wgrad(xq, dQ, (c, c), ntaps=1, out=self._dst(wq)))
+            self._give_grad(wk, ops.wgrad(xq, dK, (c, c), ntaps=1, out=self._dst(wk)))
+            self._give_grad(wv, ops.wgrad(xv, dV, (c, c), ntaps=1, out=self._dst(wv)))
+            if xq.needs_grad:
+                dx = self.new_act(B, xq.H, xq.W, c)
+                ops.gemm_nt(dt, 1, B * Nt, c, c, dQ.ptr(), c, 0, self._pack(wq, L.PACK_CONV_FWD).data_ptr(), c, 0, dx.ptr(), c, 0)
+                ops.gemm_nt(dt, 1, B * Nt, c, c, dK.ptr(), c, 0, self._pack(wk, L.PACK_CONV_FWD).data_ptr(), c, 0, dx.ptr(), c, 0,
+                            res_ptr=dx.ptr(), ldres=c)
+                xq.add_grad(dx)
+            if xv.needs_grad:
+                dx = self.new_act(B, xq.H, xq.W, c)
+                ops.gemm_nt(dt, 1, B * Nt, c, c, dV.ptr(), c, 0, self._pack(wv, L.PACK_CONV_FWD).data_ptr(), c, 0, dx.ptr(), c, 0)
+                xv.add_grad(dx)
+
+        self.tape.append(bwd)
         return out
 
     def upsample_nearest(self, x: Act, factor: int, out: Act, add: Optional[Act] = None) -> Act:

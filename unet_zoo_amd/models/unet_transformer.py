@@ -8,8 +8,10 @@ projection of Y -- followed by two Conv3x3 + BN + ReLU.
 
 On the HIP kernels: every convolution (3x3, 1x1, with or without BatchNorm), the pools (fused into the producing
 BN/ReLU pass; the stand-alone one of ``Sconv_process`` through the no-ReLU pool kernel), the bilinear resizes
-(align_corners=True) written into their concat slots, the position-encoding adds.  The attention cores themselves are
-batched matrix products + softmax over (attention-grid)^2 tokens: library GEMMs through ``Engine.torch_block``.
+(align_corners=True) written into their concat slots, the position-encoding adds, the adaptive average pools onto the
+attention grid, and the attention cores themselves (``Engine.token_attention``: batched products on the LDS-DMA GEMM,
+column softmax in place on the (attention-grid)^2 x (attention-grid)^2 score matrices, one-tap weight-gradient kernel for
+the products that contract over the queries).
 """
 from __future__ import annotations
 
@@ -76,16 +78,6 @@ class PositionalEncodingPermute2D(nn.Module):
         return eng.add_const(x, self._cache[key])
 
 
-def _attend(Qs, Ks, Vs, wq, wk, wv):
-    """softmax(Q K^T / sqrt(c), dim=1) V on (b, c, h, w) sources (unet_transformer.py:127-137, :208-219)"""
-    b, c, h, w = Qs.shape
-    Q = Qs.flatten(2).permute(0, 2, 1) @ wq
-    K = Ks.flatten(2).permute(0, 2, 1) @ wk
-    V = Vs.flatten(2).permute(0, 2, 1) @ wv
-    A = torch.softmax(torch.bmm(Q, K.permute(0, 2, 1)) / math.sqrt(c), dim=1)
-    return torch.bmm(A, V).permute(0, 2, 1).reshape(b, c, h, w)
-
-
 class MultiHeadSelfAttention(nn.Module):
     def __init__(self, channel):
         super().__init__()
@@ -97,9 +89,8 @@ class MultiHeadSelfAttention(nn.Module):
 
     def emit(self, eng: Engine, x: Act) -> Act:
         xp = self.pe.emit(eng, x)
-        return eng.torch_block(lambda t, wq, wk, wv: _attend(t, t, t, wq, wk, wv), (xp,),
-                               (self.query.weight, self.key.weight, self.value.weight),
-                               eng.new_act(x.N, x.H, x.W, x.C))
+        return eng.token_attention(xp, xp, self.query.weight, self.key.weight, self.value.weight,
+                                   eng.new_act(x.N, x.H, x.W, x.C))
 
 
 class MultiHeadCrossAttention(nn.Module):
@@ -123,11 +114,6 @@ class MultiHeadCrossAttention(nn.Module):
         self.Spe = PositionalEncodingPermute2D(channelS)
         self.Ype = PositionalEncodingPermute2D(channelY)
 
-    def _core(self, Yp, Sp, wq, wk, wv):
-        res = self.common_attn_res_for_QK_V
-        qk = F.adaptive_avg_pool2d(Yp, res)
-        return _attend(qk, qk, F.adaptive_avg_pool2d(Sp, res), wq, wk, wv)
-
     def emit(self, eng: Engine, Y: Act, S: Act) -> Act:
         c = self.common_attn_channels
         Ha, Wa = self.common_attn_res_for_QK_V
@@ -135,8 +121,9 @@ class MultiHeadCrossAttention(nn.Module):
         Sp, _ = eng.conv_bn_relu(eng.max_pool2x2(S_pe), self.Sconv_process[1], self.Sconv_process[2])
         Y_pe = self.Ype.emit(eng, Y)
         Yp, _ = eng.conv_bn_relu(Y_pe, self.Yconv_process[0], self.Yconv_process[1])
-        low = eng.torch_block(self._core, (Yp, Sp), (self.query.weight, self.key.weight, self.value.weight),
-                              eng.new_act(Y.N, Ha, Wa, c))
+        qk = eng.adaptive_avg_pool(Yp, Ha, Wa)
+        low = eng.token_attention(qk, eng.adaptive_avg_pool(Sp, Ha, Wa), self.query.weight, self.key.weight,
+                                  self.value.weight, eng.new_act(Y.N, Ha, Wa, c))
         Ho, Wo = 2 * Y.H, 2 * Y.W
         full, (z_slot, y2_slot) = eng.new_cat(Y.N, Ho, Wo, (c, c))              # cat([Z_attn, Y2_processed], 1)
         z = eng.resize_bilinear(low, eng.new_act(Y.N, Ho, Wo, c), align_corners=True)

@@ -1008,3 +1008,68 @@ def sra_bwd(q: Act, kv: Act, out: Act, lse: torch.Tensor, go: Act, dq: Act, dkv:
         L.check(lib.uz_sra_bwd(byref(d), q.ptr(), kv.ptr(), kv.ptr() + q.C * es, out.ptr(), lse.data_ptr(),
                                go.ptr(), go.ld, dq.ptr(), dq.ld, dkv.ptr(), dkv.ld, ws.data_ptr(), L.stream_ptr()),
                 "uz_sra_bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# Dense token attention (unet_transformer.py:126-137, :190-213; transatt_unet.py:41-49, :91-107): batched NT products on
+# the LDS-DMA GEMM, softmax over either axis, F.adaptive_avg_pool2d -- include/unetzoo_hip.h "Dense token attention".
+def gemm_nt(dtype: torch.dtype, batch: int, M: int, N: int, K: int, x_ptr: int, ldx: int, xb: int, w_ptr: int, ldw: int,
+            wb: int, y_ptr: int, ldy: int, yb: int, *, bias: Optional[torch.Tensor] = None, res_ptr: Optional[int] = None,
+            ldres: int = 0, resb: int = 0) -> None:
+    """y_b[m][n] = sum_k x_b[m][k] w_b[n][k] (+ bias[n]) (+ res_b[m][n]); strides in elements, 0 = shared operand"""
+    d = L.GemmDesc(L.dtype_code(dtype), batch, M, N, K, ldx, ldw, ldy, ldres, xb, wb, yb, resb)
+    es = 2 if dtype == torch.bfloat16 else 4
+    with _Timed(f"gemm_nt_{_tname(dtype)}", 2.0 * batch * M * N * K, es * batch * (M * K + N * K + M * N)):
+        L.check(L.load().uz_gemm_nt(byref(d), x_ptr, w_ptr, _p(bias), res_ptr, y_ptr, L.stream_ptr()), "uz_gemm_nt")
+
+
+def softmax_fwd(s: torch.Tensor, axis: int, scale: float) -> None:
+    """s (batch, rows, cols) <- softmax(scale * s) over axis 0 (of each matrix: columns sum to one) or 1, in place"""
+    assert s.dim() == 3 and s.is_contiguous()
+    B, R, C = s.shape
+    with _Timed(f"softmax_axis{axis}_fwd", 0.0, 3.0 * s.numel() * s.element_size()):
+        L.check(L.load().uz_softmax_fwd(L.dtype_code(s.dtype), s.data_ptr(), C, R * C, B, R, C, axis, scale, L.stream_ptr()),
+                "uz_softmax_fwd")
+
+
+def softmax_bwd(a: torch.Tensor, g: torch.Tensor, axis: int, scale: float, dot: Optional[torch.Tensor] = None) -> None:
+    """g <- a * (g - sum_axis(a * g)) * scale in place; `dot` (batch, cols) fp32 = the sums when the caller has them (axis 0)"""
+    assert a.shape == g.shape and a.is_contiguous() and g.is_contiguous() and a.dtype == g.dtype
+    B, R, C = a.shape
+    given = dot is not None
+    if axis == 0 and dot is None:
+        dot = torch.empty((B, C), dtype=torch.float32, device=a.device)
+    with _Timed(f"softmax_axis{axis}_bwd", 0.0, 3.0 * a.numel() * a.element_size()):
+        L.check(L.load().uz_softmax_bwd(L.dtype_code(a.dtype), a.data_ptr(), g.data_ptr(), C, R * C, B, R, C, axis, scale,
+                                        _p(dot), 1 if given else 0, L.stream_ptr()), "uz_softmax_bwd")
+
+
+def adaptive_avgpool_fwd(x: Act, out: Act) -> None:
+    with _Timed("adaptive_avgpool_fwd", 0.0, x.buf.element_size() * (x.P * x.C + out.P * out.C)):
+        L.check(L.load().uz_adaptive_avgpool_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.N, x.H, x.W, x.C, out.ptr(), out.ld,
+                                                 out.H, out.W, L.stream_ptr()), "uz_adaptive_avgpool_fwd")
+
+
+def adaptive_avgpool_bwd(g: Act, dx: Act, accumulate: bool = False) -> None:
+    with _Timed("adaptive_avgpool_bwd", 0.0, g.buf.element_size() * (g.P * g.C + dx.P * dx.C)):
+        L.check(L.load().uz_adaptive_avgpool_bwd(L.dtype_code(g.dtype), g.ptr(), g.ld, dx.N, dx.H, dx.W, dx.C, dx.ptr(), dx.ld,
+                                                 g.H, g.W, 1 if accumulate else 0, L.stream_ptr()), "uz_adaptive_avgpool_bwd")
+
+
+def rowdot_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """out[r] = sum_c a[r][c] * b[r][c]; a fp32 (rows, C), b run dtype (rows, C)"""
+    assert a.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and a.shape == b.shape
+    assert a.is_contiguous() and b.is_contiguous()
+    out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+    with _Timed("rowdot_f32", 2.0 * a.numel(), a.numel() * (4 + b.element_size())):
+        L.check(L.load().uz_rowdot_f32(L.dtype_code(b.dtype), a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], a.shape[0],
+                                       a.shape[1], out.data_ptr(), L.stream_ptr()), "uz_rowdot_f32")
+    return out
+
+
+def cast_rows(src: torch.Tensor, dst: Act, accumulate: bool = False) -> None:
+    """dst (run dtype) = src (fp32, (P, C) contiguous), or dst += src"""
+    assert src.dtype == torch.float32 and src.is_contiguous() and tuple(src.shape) == (dst.P, dst.C)
+    with _Timed("cast_rows", 0.0, src.numel() * (4 + dst.buf.element_size())):
+        L.check(L.load().uz_cast_rows(L.dtype_code(dst.dtype), src.data_ptr(), dst.C, dst.ptr(), dst.ld, dst.P, dst.C,
+                                      1 if accumulate else 0, L.stream_ptr()), "uz_cast_rows")
