@@ -176,6 +176,14 @@ int uz_wgrad_split(const uz_wgrad_desc* d);
 long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d); /* <0 on error */
 int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace,
              void* stream);
+/* `batch` independent one-tap problems of the shape `d` in one launch pair: problem b reads L + b * lb, R + b * rb
+ * (strides in elements, multiples of 16 bytes) and writes out + b * ob floats -- the per-image products of the token
+ * attention that contract over the rows of both operands (dV_b = A_b^T dO_b, dK_b = dS_b^T Q_b,
+ * unet_transformer.py:133-136; the channel Gram matrix x_b^T x_b of transatt_unet.py:93-101).  The pixel split is
+ * planned for the whole batch. */
+long long uz_wgrad_batched_workspace_bytes(const uz_wgrad_desc* d, int batch);
+int uz_wgrad_batched(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb,
+                     float* out, long long ob, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight re-packing: fp32 master parameters in the reference layout -> kernel layout in run dtype.

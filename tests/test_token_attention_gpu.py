@@ -173,3 +173,95 @@ def test_rowdot_and_cast_rows():
     assert torch.equal(dst.buf, a.to(torch.bfloat16))
     ops.cast_rows(a, dst, accumulate=True)
     assert torch.equal(dst.buf, (a.to(torch.bfloat16).float() + a).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 4, 6), (3, 128, 16, 16)])
+def test_row_attention_matches_autograd(dt, B, C, H, W):
+    """PAM_Module's core (transatt_unet.py:41-49) on q / k / v given as token maps"""
+    g = torch.Generator().manual_seed(C + W)
+    q = torch.randn(B, C // 8, H, W, generator=g).to(dt).double().requires_grad_(True)
+    k = torch.randn(B, C // 8, H, W, generator=g).to(dt).double().requires_grad_(True)
+    v = torch.randn(B, C, H, W, generator=g).to(dt).double().requires_grad_(True)
+    att = torch.softmax(torch.bmm(q.flatten(2).transpose(1, 2), k.flatten(2)), dim=-1)
+    ref = torch.bmm(v.flatten(2), att.transpose(1, 2)).view(B, C, H, W)
+    dy = torch.randn(ref.shape, generator=g).to(dt).double()
+    ref.backward(dy)
+    eng = Engine(dt, torch.device(DEV), True, True)
+    qa, ka, va = (act_from_nchw(t.detach().float().to(DEV), dt) for t in (q, k, v))
+    out = eng.row_attention(qa, ka, va, eng.new_act(B, H, W, C))
+    ftol, gtol = (2e-5, 1e-4) if dt == torch.float32 else (2e-2, 4e-2)
+    assert relerr(out.dense().cpu(), ref.detach()) < ftol
+    out.add_grad(act_from_nchw(dy.float().to(DEV), dt))
+    eng.backward_range(None, len(eng.tape), 0)
+    for a, r, name in ((qa, q, "q"), (ka, k, "k"), (va, v, "v")):
+        e = ((a.grads[0].dense().cpu().double() - r.grad).norm() / r.grad.norm()).item()
+        assert e < gtol, (name, e)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,d,H,W,p", [(2, 64, 4, 6, 0.0), (2, 512, 16, 16, 0.0), (2, 128, 8, 8, 0.25)])
+def test_channel_attention_matches_autograd(dt, B, d, H, W, p):
+    """ScaledDotProductAttention as TransAttUNet calls it (transatt_unet.py:91-107); with dropout the mask is recovered
+    from the engine's own forward (kept elements are those the unmasked product predicts)"""
+    g = torch.Generator().manual_seed(d + W)
+    T = d ** 0.5
+    x = (0.5 * torch.randn(B, d, H, W, generator=g)).to(dt).double().requires_grad_(True)
+    eng = Engine(dt, torch.device(DEV), True, True)
+    xa = act_from_nchw(x.detach().float().to(DEV), dt)
+    torch.manual_seed(5)
+    out = eng.channel_attention(xa, T, p, eng.new_act(B, H, W, d))
+    qf = x.view(B, d, -1)
+    attn = torch.softmax(torch.matmul(qf / T, qf.transpose(1, 2)), dim=-1)
+    if p > 0:
+        torch.manual_seed(5)
+        keep = (torch.rand((B, d, d), device=DEV) >= p).double().cpu() / (1 - p)      # the draw the engine made
+        attn = attn * keep
+    ref = torch.matmul(attn, qf).view(B, d, H, W)
+    dy = torch.randn(ref.shape, generator=g).to(dt).double()
+    ref.backward(dy)
+    ftol, gtol = (2e-5, 1e-4) if dt == torch.float32 else (2e-2, 4e-2)
+    assert relerr(out.dense().cpu(), ref.detach()) < ftol
+    out.add_grad(act_from_nchw(dy.float().to(DEV), dt))
+    eng.backward_range(None, len(eng.tape), 0)
+    e = ((xa.grads[0].dense().cpu().double() - x.grad).norm() / x.grad.norm()).item()
+    assert e < gtol, e
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_learned_row_column_embedding_add(dt):
+    g = torch.Generator().manual_seed(2)
+    B, F_, H, W = 3, 32, 5, 7
+    row_w = nn.Parameter(torch.rand(12, F_, generator=g))
+    col_w = nn.Parameter(torch.rand(12, F_, generator=g))
+    x = torch.randn(B, 2 * F_, H, W, generator=g).to(dt).float().requires_grad_(True)
+    pos = torch.cat([col_w[:W].unsqueeze(0).expand(H, W, -1), row_w[:H].unsqueeze(1).expand(H, W, -1)], dim=-1)
+    ref = x + pos.permute(2, 0, 1).unsqueeze(0)
+    dy = torch.randn(ref.shape, generator=g).to(dt).float()
+    ref.backward(dy)
+    rw, cw = nn.Parameter(row_w.detach().to(DEV)), nn.Parameter(col_w.detach().to(DEV))
+    eng = Engine(dt, torch.device(DEV), True, True)
+    xa = act_from_nchw(x.detach().to(DEV), dt)
+    out = eng.add_row_col_embed(xa, rw, cw)
+    assert relerr(out.dense().cpu(), ref.detach()) < (1e-6 if dt == torch.float32 else 6e-3)
+    out.add_grad(act_from_nchw(dy.to(DEV), dt))
+    eng.backward_range(None, len(eng.tape), 0)
+    assert relerr(eng.param_grads[rw].cpu(), row_w.grad) < 1e-5
+    assert relerr(eng.param_grads[cw].cpu(), col_w.grad) < 1e-5
+    assert relerr(xa.grads[0].dense().cpu(), x.grad) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,P,Ci,Cj,pad", [(3, 256, 256, 512, 0), (2, 1024, 1024, 64, 0), (4, 100, 72, 40, 8), (16, 256, 64, 64, 0),
+                                           (1, 4096, 512, 128, 0)])
+def test_batched_tn_products(dt, B, P, Ci, Cj, pad):
+    """out_b = L_b^T R_b: one launch pair for the batch (bf16: the one-tap LDS-DMA kernel with the problem index on the
+    grid; fp32: problem by problem), ragged pixel counts, row strides longer than the rows"""
+    g = torch.Generator().manual_seed(P + Ci)
+    Lm = torch.randn(B * P, Ci + pad, generator=g).to(dt).to(DEV)
+    Rm = torch.randn(B * P, Cj + pad, generator=g).to(dt).to(DEV)
+    out = ops.wgrad_batched(Act(Lm, 0, Ci, B, 1, P), Act(Rm, 0, Cj, B, 1, P))
+    ref = torch.einsum("bpi,bpj->bij", Lm.view(B, P, -1)[..., :Ci].double(), Rm.view(B, P, -1)[..., :Cj].double())
+    assert relerr(out.cpu(), ref.cpu()) < (2e-5 if dt == torch.float32 else 1e-5)      # fp32 accumulation of exact bf16 products
+    out2 = ops.wgrad_batched(Act(Lm, 0, Ci, B, 1, P), Act(Rm, 0, Cj, B, 1, P))
+    assert torch.equal(out, out2)

@@ -1,1 +1,1 @@
-extern "C" const char* uz_source_hash(void) { return "4351658698f7590e6fbf376fc36b865cc03b36a04f80023a82a6792e8efae26b"; }
+extern "C" const char* uz_source_hash(void) { return "a0917e9e697231b6b543bc2f896cb2b73510725be4ebf07dba0c978ad31eabeb"; }

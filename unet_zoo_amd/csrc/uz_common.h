@@ -140,9 +140,9 @@ struct UzWgrad2Plan {
   int big, one_tap, gather, kw, kr, tiles_i, tiles_j, kg, units, upb, split, nslabs, H, W;
   int wide9;   // nine taps on a 128 (dy) x 64 (x) channel tile
 };
-int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
+int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch = 1);   // batch > 1: uz_wgrad_batched (one-tap only)
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
-                       float* slab, hipStream_t s);
+                       float* slab, hipStream_t s, int batch = 1, long long lb_bytes = 0, long long rb_bytes = 0);
 
 // LDS-DMA pixel-major GEMM (uz_gemm_dma.hip): 1x1 / ConvTranspose fwd + dgrad, dispatched from uz_conv_igemm()
 struct UzGemmPlan {

@@ -230,8 +230,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // element's ntaps values (ntaps*4 contiguous bytes; a wave writes one contiguous span).
 template <int NT, int ZG>
 __global__ __launch_bounds__(64 * ZG) void wgrad_reduce_kernel(const float* __restrict__ slab, int split,
-                                                              long long CiCj, float* __restrict__ out) {
+                                                              long long CiCj, float* __restrict__ out,
+                                                              long long out_b) {
   __shared__ float red[ZG][64][NT + 1];
+  slab += (size_t)blockIdx.y * split * NT * CiCj;   // uz_wgrad_batched: blockIdx.y = problem
+  out += (size_t)blockIdx.y * out_b;
   const int x = threadIdx.x & 63, zg = threadIdx.x >> 6;
   const long long e = (long long)blockIdx.x * 64 + x;
   float acc[NT];
@@ -390,14 +393,56 @@ extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, fl
   const float* slab = static_cast<const float*>(workspace);
   if (d->ntaps == 9) {
     if (nslabs >= 32)
-      hipLaunchKernelGGL((wgrad_reduce_kernel<9, 16>), grid, dim3(1024), 0, s, slab, nslabs, cicj, out);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<9, 16>), grid, dim3(1024), 0, s, slab, nslabs, cicj, out, 0LL);
     else
-      hipLaunchKernelGGL((wgrad_reduce_kernel<9, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<9, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out, 0LL);
   } else if (d->ntaps == 4) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<4, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out, 0LL);
   } else {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<1, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<1, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out, 0LL);
   }
   UZ_LAUNCH_CHECK("uz_wgrad(reduce)");
+  return UZ_OK;
+}
+
+
+// ---- batched one-tap products: out_b[i][j] = sum_p L_b[p][i] R_b[p][j] ------------------------------------------------
+static int batched_plan(const uz_wgrad_desc* d, int batch, UzWgrad2Plan* p2) {
+  UZ_REQUIRE(d && batch >= 1 && batch <= 65535, "uz_wgrad_batched: batch");
+  UZ_REQUIRE(d->ntaps == 1 && d->taps_mode == UZ_TAPS_CONV, "uz_wgrad_batched: one-tap problems only");
+  return uz_wgrad3x3_plan(d, p2, batch) ? 1 : 0;
+}
+
+extern "C" long long uz_wgrad_batched_workspace_bytes(const uz_wgrad_desc* d, int batch) {
+  UzWgrad2Plan p2;
+  const int rc = batched_plan(d, batch, &p2);
+  if (rc < 0) return rc;
+  if (rc == 1) return (long long)batch * p2.nslabs * d->Ci * d->Cj * (long long)sizeof(float);
+  return uz_wgrad_workspace_bytes(d);   // problem by problem through uz_wgrad
+}
+
+extern "C" int uz_wgrad_batched(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb,
+                                float* out, long long ob, void* workspace, void* stream) {
+  UzWgrad2Plan p2;
+  const int rc = batched_plan(d, batch, &p2);
+  if (rc < 0) return rc;
+  UZ_REQUIRE(L && R && out && workspace, "uz_wgrad_batched: null pointer");
+  const int es = d->dtype == UZ_BF16 ? 2 : 4;
+  if (rc == 0) {   // fp32 (parity mode) and shapes outside the LDS-DMA kernel: one uz_wgrad per problem
+    for (int b = 0; b < batch; ++b) {
+      const int r = uz_wgrad(d, static_cast<const char*>(L) + (long long)b * lb * es, static_cast<const char*>(R) + (long long)b * rb * es,
+                             out + (long long)b * ob, workspace, stream);
+      if (r != UZ_OK) return r;
+    }
+    return UZ_OK;
+  }
+  UZ_REQUIRE((((uintptr_t)L | (uintptr_t)R) & 15) == 0 && lb % 8 == 0 && rb % 8 == 0, "uz_wgrad_batched: L / R must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int r2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s, batch, lb * es, rb * es);
+  if (r2 != UZ_OK) return r2;
+  const long long cicj = (long long)d->Ci * d->Cj;
+  const dim3 grid((unsigned)((cicj + 63) / 64), batch);
+  hipLaunchKernelGGL((wgrad_reduce_kernel<1, 4>), grid, dim3(256), 0, s, static_cast<const float*>(workspace), p2.nslabs, cicj, out, (long long)ob);
+  UZ_LAUNCH_CHECK("uz_wgrad_batched(reduce)");
   return UZ_OK;
 }

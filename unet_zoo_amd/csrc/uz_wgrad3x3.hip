@@ -44,6 +44,9 @@ struct Wg2Args {
                 // 2: stride-2 3x3 convolution (UZ_TAPS_CONV_S2): tap t = 3 ty + tx reads (2h + ty - 1, 2w + tx - 1), zero outside
   int Hr, Wr;
   int flags; // tuning switches (env UZ_TUNE): bit 2 = plain workgroup order
+  // uz_wgrad_batched (one-tap, no gather): blockIdx.y = problem index; byte strides of L / R between problems, float
+  // stride of the slabs
+  long long lb, rb, sb;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -130,12 +133,15 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   }
   const int ti0 = (bx / a.tiles_j) * BI, tj0 = (bx % a.tiles_j) * BJ;
   const int ty_blk = (NTY == 1 && NTX == 3) ? by : 0;
-  const int ty_blk_g = (NTX == 1) ? by : 0;   // gather mode: the tap of this workgroup
+  const int ty_blk_g = (NTX == 1 && a.gather != 0) ? by : 0;   // gather mode: the tap of this workgroup
+  const long long pb = (NTX == 1 && a.gather == 0) ? by : 0;   // batched one-tap problems: the problem of this workgroup
   const int u_beg = bz * a.upb;
   const int u_end = (u_beg + a.upb < a.units) ? u_beg + a.upb : a.units;
   const int nu = u_end - u_beg;
-  const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.L), 0, a.lbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.R), 0, a.rbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(static_cast<const char*>(a.L)) + pb * a.lb, 0, a.lbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(static_cast<const char*>(a.R)) + pb * a.rb, 0, a.rbytes, 0x00020000);
 
   const int KW = a.KW, PWR = KW + 2 * HALO;        // R tile row length in pixels
   const int RR = a.KR + ((NTY == 3) ? 2 : 0);      // R tile rows
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
     const int tw = tap0 + tt;
     if (tt >= ntw_me) continue;  // wave-uniform
     const int tap = (NTX == 1) ? ty_blk_g : ((NTY == 3) ? tw : ty_blk * 3 + tw);
-    float* slab = a.slab + ((size_t)bz * (NTX == 1 ? (a.gather == 1 ? 4 : (a.gather == 2 ? 9 : 1)) : 9) + tap) * (size_t)a.Ci * a.Cj;
+    float* slab = a.slab + pb * a.sb + ((size_t)bz * (NTX == 1 ? (a.gather == 1 ? 4 : (a.gather == 2 ? 9 : 1)) : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int cj = tj0 + wj * WTJ + l31;
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
 
 }  // namespace
 
-int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
+int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch) {
   const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
   const bool s2 = d->taps_mode == UZ_TAPS_CONV_S2 && d->ntaps == 9;
   const bool gather = (d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && !(uz_tune_flags() & 0x4000000)) || s2;
@@ -480,7 +486,8 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   p->tiles_j = (d->Cj + (p->wide9 == 2 ? 128 : b) - 1) / (p->wide9 == 2 ? 128 : b);
   p->kg = 1;
   p->units = (int)(nimg * H * W / 64);
-  const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : (gather ? d->ntaps : 1));
+  if (batch > 1 && !(p->one_tap && !gather)) return 0;
+  const long long base = (long long)p->tiles_i * p->tiles_j * ((p->big && !p->one_tap) ? 3 : (gather ? d->ntaps : 1)) * batch;
   // one workgroup per CU (160 KB LDS each): aim for a single full round of <= 256 workgroups
   long long split = base >= UZ_NUM_CU ? 1 : UZ_NUM_CU / base;
   long long max_split = p->units / 8 > 0 ? p->units / 8 : 1;
@@ -513,8 +520,12 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
 }
 
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
-                       float* slab, hipStream_t s) {
+                       float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes) {
   Wg2Args a;
+  a.lb = lb_bytes;
+  a.rb = rb_bytes;
+  a.sb = (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
+  UZ_REQUIRE(batch == 1 || (p.one_tap && !p.gather && batch <= 65535), "uz_wgrad(3x3): only one-tap problems are batched");
   a.L = L;
   a.R = R;
   a.slab = slab;
@@ -544,7 +555,7 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   hipLaunchKernelGGL((wgrad3x3_kernel<__VA_ARGS__, MODE_>), grid, block, 0, s, a)
   if (p.one_tap) {
     UZ_REQUIRE(mode != 1, "uz_wgrad(3x3): one-tap problems have no upsampled form");
-    dim3 grid(p.tiles_i * p.tiles_j, p.gather == 2 ? 9 : (p.gather ? 4 : 1), p.split);
+    dim3 grid(p.tiles_i * p.tiles_j, p.gather == 2 ? 9 : (p.gather ? 4 : batch), p.split);
     if (p.big) {
       if (mode == 0) UZ_WG_LAUNCH(0, 128, 128, 1, 1, 2, 4, 1);
       else if (mode == 2) UZ_WG_LAUNCH(2, 128, 128, 1, 1, 2, 4, 1);

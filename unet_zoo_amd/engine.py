@@ -1201,6 +1201,131 @@ class Engine:
             self.tape.append(bwd)
         return y
 
+    def _tn_images(self, Lt: Act, Rt: Act) -> torch.Tensor:
+        """out_b = L_b^T R_b per image, fp32 (N * Lt.C, Rt.C): the products that contract over the ROWS of both operands
+        (dV = A^T dO, dK = dS^T Q, the channel Gram matrix x^T x) on uz_wgrad's one-tap kernel"""
+        return ops.wgrad_batched(Lt, Rt).view(Lt.N * Lt.C, Rt.C)
+
+    @staticmethod
+    def _matrices_as_act(m: torch.Tensor) -> Act:
+        """a contiguous (B, rows, cols) batch of matrices as the activation (B, 1, rows, cols)"""
+        B, R, C = m.shape
+        return Act(m.view(B * R, C), 0, C, B, 1, R)
+
+    @staticmethod
+    def _transposed(a: Act) -> torch.Tensor:
+        """(B, C, tokens) copy of a token-major activation -- glue for operands of a few MB (q / k / v of a bottleneck)"""
+        return a.buf.view(a.N, a.H * a.W, a.ld)[..., a.off:a.off + a.C].transpose(1, 2).contiguous()
+
+    def row_attention(self, q: Act, k: Act, v: Act, out: Act) -> Act:
+        """out_i = sum_j softmax_j(q_i . k_j) v_j per image: PAM_Module.forward between its 1x1 convolutions and the
+        `gamma * out + x` (transatt_unet.py:41-49).  energy and its gradient are batched NT products, softmax over the
+        key axis in place (kept for the backward), dv = att^T g and dk = dE^T q on the one-tap weight-gradient kernel."""
+        B, Nt, C, dq = q.N, q.H * q.W, v.C, q.C
+        assert (k.N, k.H * k.W, k.C) == (B, Nt, dq) and (v.N, v.H * v.W) == (B, Nt) and (out.N, out.H * out.W, out.C) == (B, Nt, C)
+        dt, dev = self.dtype, self.device
+        vt = self._transposed(v)
+        E = torch.empty((B, Nt, Nt), dtype=dt, device=dev)
+        ops.gemm_nt(dt, B, Nt, Nt, dq, q.ptr(), q.ld, Nt * q.ld, k.ptr(), k.ld, Nt * k.ld, E.data_ptr(), Nt, Nt * Nt)
+        ops.softmax_fwd(E, 1, 1.0)
+        ops.gemm_nt(dt, B, Nt, C, Nt, E.data_ptr(), Nt, Nt * Nt, vt.data_ptr(), Nt, C * Nt, out.ptr(), out.ld, Nt * out.ld)
+        del vt
+        if not self.record:
+            return out
+
+        def bwd():
+            g = self._total_grad(out)
+            if g is None:
+                return
+            dE = torch.empty((B, Nt, Nt), dtype=dt, device=dev)
+            ops.gemm_nt(dt, B, Nt, Nt, C, g.ptr(), g.ld, Nt * g.ld, v.ptr(), v.ld, Nt * v.ld, dE.data_ptr(), Nt, Nt * Nt)
+            if v.needs_grad:
+                dv = self.new_act(B, v.H, v.W, C)
+                ops.cast_rows(self._tn_images(self._matrices_as_act(E), g), dv)
+                v.add_grad(dv)
+            ops.softmax_bwd(E, dE, 1, 1.0)
+            if q.needs_grad:
+                kt = self._transposed(k)
+                dqa = self.new_act(B, q.H, q.W, dq)
+                ops.gemm_nt(dt, B, Nt, dq, Nt, dE.data_ptr(), Nt, Nt * Nt, kt.data_ptr(), Nt, dq * Nt, dqa.ptr(), dq, Nt * dq)
+                q.add_grad(dqa)
+            if k.needs_grad:
+                dka = self.new_act(B, k.H, k.W, dq)
+                ops.cast_rows(self._tn_images(self._matrices_as_act(dE), q), dka)
+                k.add_grad(dka)
+
+        self.tape.append(bwd)
+        return out
+
+    def channel_attention(self, x: Act, temperature: float, p_drop: float, out: Act) -> Act:
+        """out = dropout(softmax((x / T) x^T, dim=-1)) x on the (d, tokens) view of every image:
+        ScaledDotProductAttention.forward as TransAttUNet calls it (transatt_unet.py:91-107, q = k = v = the bottleneck
+        map).  The (d, d) Gram matrix is a TN product (fp32 out of the one-tap weight-gradient kernel), softmax runs on it
+        in fp32, the two products with x are batched NT products; the only transposes are of (d, d) matrices."""
+        B, Nt, d = x.N, x.H * x.W, x.C
+        assert (out.N, out.H * out.W, out.C) == (B, Nt, d)
+        dt, dev = self.dtype, self.device
+        P = self._tn_images(x, x).view(B, d, d)
+        ops.softmax_fwd(P, 1, 1.0 / temperature)
+        drop = p_drop > 0.0 and self.training
+        if drop:       # nn.Dropout in training mode: Bernoulli(1 - p) mask from torch's generator, scaled by 1 / (1 - p)
+            keep = (torch.rand((B, d, d), device=dev) >= p_drop).to(torch.float32).mul_(1.0 / (1.0 - p_drop))
+            Pd = (P * keep).to(dt)
+        else:
+            keep, Pd = None, P.to(dt)
+        ops.gemm_nt(dt, B, Nt, d, d, x.ptr(), x.ld, Nt * x.ld, Pd.data_ptr(), d, d * d, out.ptr(), out.ld, Nt * out.ld)
+        if not (self.record and x.needs_grad):
+            return out
+
+        def bwd():
+            g = self._total_grad(out)
+            if g is None:
+                return
+            dP = self._tn_images(g, x).view(B, d, d)                  # d(loss)/d(Pd)[c1][c2] = sum_n g[n][c1] x[n][c2]
+            if keep is not None:
+                dP.mul_(keep)
+            ops.softmax_bwd(P, dP, 1, 1.0 / temperature)              # now d(loss)/d(x^T x)
+            sym = (dP + dP.transpose(1, 2)).to(dt)                     # x enters the Gram matrix on both sides
+            PdT = Pd.transpose(1, 2).contiguous()
+            dx = self.new_act(B, x.H, x.W, d)
+            ops.gemm_nt(dt, B, Nt, d, d, g.ptr(), g.ld, Nt * g.ld, PdT.data_ptr(), d, d * d, dx.ptr(), d, Nt * d)
+            ops.gemm_nt(dt, B, Nt, d, d, x.ptr(), x.ld, Nt * x.ld, sym.data_ptr(), d, d * d, dx.ptr(), d, Nt * d,
+                        res_ptr=dx.ptr(), ldres=d, resb=Nt * d)
+            x.add_grad(dx)
+
+        self.tape.append(bwd)
+        return out
+
+    def add_row_col_embed(self, x: Act, row_w: nn.Parameter, col_w: nn.Parameter) -> Act:
+        """x + cat([col_embed(j) for every row, row_embed(i) for every column], channel) -- PositionEmbeddingLearned as
+        TransAttUNet adds it to the bottleneck (transatt_unet.py:66-82, :144-145).  The gradient of an embedding row is
+        the sum of the incoming gradient over the batch and over the other map axis (256 terms at 16 x 16, B = 16)."""
+        F_ = col_w.shape[1]
+        assert x.C == 2 * F_ and row_w.shape[1] == F_ and x.H <= row_w.shape[0] and x.W <= col_w.shape[0]
+        H, W = x.H, x.W
+        pos = torch.cat([col_w.detach()[:W].unsqueeze(0).expand(H, W, F_), row_w.detach()[:H].unsqueeze(1).expand(H, W, F_)],
+                        dim=-1).reshape(H * W, 2 * F_)
+        out = self.new_act(x.N, H, W, x.C)
+        xv = x.buf.view(x.N, H * W, x.ld)[..., x.off:x.off + x.C]
+        out.buf.view(x.N, H * W, x.C).copy_(xv.float() + pos)
+        if self.record:
+            def bwd():
+                g = self._total_grad(out)
+                if g is None:
+                    return
+                gv = g.buf.view(x.N, H, W, g.ld)[..., g.off:g.off + x.C].float()
+                d_col = torch.zeros_like(col_w)
+                d_row = torch.zeros_like(row_w)
+                d_col[:W] = gv[..., :F_].sum((0, 1))
+                d_row[:H] = gv[..., F_:].sum((0, 2))
+                self._give_grad(col_w, d_col)
+                self._give_grad(row_w, d_row)
+                if x.needs_grad:
+                    x.add_grad(g)
+
+            self.tape.append(bwd)
+        return out
+
     def token_attention(self, xq: Act, xv: Act, wq: nn.Parameter, wk: nn.Parameter, wv: nn.Parameter, out: Act) -> Act:
         """out_b = softmax_over_queries((X_b wq)(X_b wk)^T / sqrt(c)) (XV_b wv) on the tokens of xq / xv (NHWC rows = the
         reference's `flatten(2).permute(0, 2, 1)`): MultiHeadSelfAttention.forward (xq is xv) and the attention core of
@@ -1241,11 +1366,7 @@ class Engine:
             return out
 
         def tn_per_image(Lm: torch.Tensor, R: Act) -> torch.Tensor:
-            """out[b] = Lm[b]^T R_b: (B, Nt, c) fp32 from Lm (B, Nt, Nt) and the (B Nt, c) rows of R"""
-            o = torch.empty((B * Nt, c), dtype=torch.float32, device=dev)
-            for b in range(B):
-                ops.wgrad(Act(Lm[b], 0, Nt, 1, 1, Nt), R.rows(b * Nt, 1, 1, Nt), (Nt, c), ntaps=1, out=o[b * Nt:(b + 1) * Nt])
-            return o
+            return self._tn_images(self._matrices_as_act(Lm), R)
 
         def as_act(t: torch.Tensor) -> Act:
             return Act(t, 0, c, B, xq.H, xq.W)

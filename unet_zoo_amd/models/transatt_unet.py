@@ -9,8 +9,10 @@ dropout, :84-107) --, four ``Up`` (bilinear x2 with align_corners=True, ``cat([s
 
 Every convolution, BatchNorm, pooling, resize and concat runs on the HIP kernels (the pool is fused into the BN/ReLU
 pass of the producing block, the skip and the upsampled tensor are written straight into their halves of one concat
-buffer).  The two attention cores at the 1/16-resolution bottleneck are batched matrix products + softmax on (h*w) x
-(h*w) and 512 x 512 matrices: library GEMMs through ``Engine.torch_block``.
+buffer).  The two attention cores at the 1/16-resolution bottleneck -- batched matrix products + softmax on (h*w) x (h*w) and
+512 x 512 matrices -- run on the library's batched GEMM, row softmax and one-tap weight-gradient kernels
+(``Engine.row_attention``, ``Engine.channel_attention``); only a bottleneck whose token count is not a multiple of 8
+(inputs such as 48 x 48) falls back to library GEMMs through ``Engine.torch_block``.
 """
 from __future__ import annotations
 
@@ -100,7 +102,11 @@ class PAM_Module(nn.Module):
         q = eng.conv_plain(x, self.query_conv)
         k = eng.conv_plain(x, self.key_conv)
         v = eng.conv_plain(x, self.value_conv)
-        att = eng.torch_block(self._core, (q, k, v), (), eng.new_act(x.N, x.H, x.W, x.C))
+        out = eng.new_act(x.N, x.H, x.W, x.C)
+        if (x.H * x.W) % 8 == 0:
+            att = eng.row_attention(q, k, v, out)
+        else:   # token counts that are not a multiple of 16 bytes (inputs like 48 x 48): library GEMMs
+            att = eng.torch_block(self._core, (q, k, v), (), out)
         return eng.scale_residual(att, self.gamma, x)
 
 
@@ -124,8 +130,7 @@ class PositionEmbeddingLearned(nn.Module):
         if x.H > self.row_embed.num_embeddings or x.W > self.col_embed.num_embeddings:
             raise IndexError(f"position embedding holds {self.row_embed.num_embeddings} rows / columns, the bottleneck "
                              f"map is {x.H}x{x.W} (input larger than 512x512)")
-        return eng.torch_block(self._add, (x,), (self.row_embed.weight, self.col_embed.weight),
-                               eng.new_act(x.N, x.H, x.W, x.C))
+        return eng.add_row_col_embed(x, self.row_embed.weight, self.col_embed.weight)
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -143,7 +148,10 @@ class ScaledDotProductAttention(nn.Module):
         return torch.matmul(attn, q).view(B, d, H, W)
 
     def emit(self, eng: Engine, x: Act) -> Act:
-        return eng.torch_block(self._core, (x,), (), eng.new_act(x.N, x.H, x.W, x.C))
+        out = eng.new_act(x.N, x.H, x.W, x.C)
+        if (x.H * x.W) % 8 == 0:
+            return eng.channel_attention(x, self.temperature, self.dropout.p, out)
+        return eng.torch_block(self._core, (x,), (), out)
 
 
 class TransAttUNet(HipModule):

@@ -78,6 +78,26 @@ class PositionalEncodingPermute2D(nn.Module):
         return eng.add_const(x, self._cache[key])
 
 
+def _attend(Qs, Vs, wq, wk, wv):
+    """softmax(Q K^T / sqrt(c), dim=1) V on (b, c, h, w) sources (unet_transformer.py:127-137, :208-219) with library
+    GEMMs: only for token counts that are not a multiple of 8 (16-byte rows), which the own kernels do not take"""
+    b, c, h, w = Qs.shape
+    t = Qs.flatten(2).permute(0, 2, 1)
+    Q, K, V = t @ wq, t @ wk, Vs.flatten(2).permute(0, 2, 1) @ wv
+    A = torch.softmax(torch.bmm(Q, K.permute(0, 2, 1)) / math.sqrt(c), dim=1)
+    return torch.bmm(A, V).permute(0, 2, 1).reshape(b, c, h, w)
+
+
+def _token_attention(eng: Engine, xq: Act, xv: Act, mod: nn.Module) -> Act:
+    out = eng.new_act(xq.N, xq.H, xq.W, xq.C)
+    ws = (mod.query.weight, mod.key.weight, mod.value.weight)
+    if (xq.H * xq.W) % 8 == 0:
+        return eng.token_attention(xq, xv, *ws, out)
+    if xq is xv:
+        return eng.torch_block(lambda t, *w: _attend(t, t, *w), (xq,), ws, out)
+    return eng.torch_block(_attend, (xq, xv), ws, out)
+
+
 class MultiHeadSelfAttention(nn.Module):
     def __init__(self, channel):
         super().__init__()
@@ -89,8 +109,7 @@ class MultiHeadSelfAttention(nn.Module):
 
     def emit(self, eng: Engine, x: Act) -> Act:
         xp = self.pe.emit(eng, x)
-        return eng.token_attention(xp, xp, self.query.weight, self.key.weight, self.value.weight,
-                                   eng.new_act(x.N, x.H, x.W, x.C))
+        return _token_attention(eng, xp, xp, self)
 
 
 class MultiHeadCrossAttention(nn.Module):
@@ -122,8 +141,7 @@ class MultiHeadCrossAttention(nn.Module):
         Y_pe = self.Ype.emit(eng, Y)
         Yp, _ = eng.conv_bn_relu(Y_pe, self.Yconv_process[0], self.Yconv_process[1])
         qk = eng.adaptive_avg_pool(Yp, Ha, Wa)
-        low = eng.token_attention(qk, eng.adaptive_avg_pool(Sp, Ha, Wa), self.query.weight, self.key.weight,
-                                  self.value.weight, eng.new_act(Y.N, Ha, Wa, c))
+        low = _token_attention(eng, qk, eng.adaptive_avg_pool(Sp, Ha, Wa), self)
         Ho, Wo = 2 * Y.H, 2 * Y.W
         full, (z_slot, y2_slot) = eng.new_cat(Y.N, Ho, Wo, (c, c))              # cat([Z_attn, Y2_processed], 1)
         z = eng.resize_bilinear(low, eng.new_act(Y.N, Ho, Wo, c), align_corners=True)

@@ -1023,6 +1023,23 @@ def gemm_nt(dtype: torch.dtype, batch: int, M: int, N: int, K: int, x_ptr: int, 
         L.check(L.load().uz_gemm_nt(byref(d), x_ptr, w_ptr, _p(bias), res_ptr, y_ptr, L.stream_ptr()), "uz_gemm_nt")
 
 
+def wgrad_batched(Lt: Act, Rt: Act) -> torch.Tensor:
+    """out[b] = L_b^T R_b (fp32, (N, Lt.C, Rt.C)) for the N images of two token maps: one launch pair for the batch"""
+    L.require_cuda(Lt.buf, Rt.buf)
+    lib = L.load()
+    B, P = Lt.N, Lt.H * Lt.W
+    assert (Rt.N, Rt.H * Rt.W) == (B, P) and Lt.dtype == Rt.dtype
+    d = L.WgradDesc(L.dtype_code(Lt.dtype), 1, 1, P, 1, P, Lt.C, Lt.ld, Rt.C, Rt.ld, 1, L.TAPS_CONV, 1)
+    ws_bytes = L.check_count(lib.uz_wgrad_batched_workspace_bytes(byref(d), B), "uz_wgrad_batched_workspace_bytes")
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=Lt.buf.device)
+    out = torch.empty((B, Lt.C, Rt.C), dtype=torch.float32, device=Lt.buf.device)
+    with _Timed(f"wgrad_batched_{_tname(Lt.dtype)}_1tap", 2.0 * B * P * Lt.C * Rt.C,
+                Lt.buf.element_size() * B * P * (Lt.C + Rt.C) + 4.0 * out.numel()):
+        L.check(lib.uz_wgrad_batched(byref(d), B, Lt.ptr(), P * Lt.ld, Rt.ptr(), P * Rt.ld, out.data_ptr(), Lt.C * Rt.C,
+                                     ws.data_ptr(), L.stream_ptr()), "uz_wgrad_batched")
+    return out
+
+
 def softmax_fwd(s: torch.Tensor, axis: int, scale: float) -> None:
     """s (batch, rows, cols) <- softmax(scale * s) over axis 0 (of each matrix: columns sum to one) or 1, in place"""
     assert s.dim() == 3 and s.is_contiguous()
