@@ -629,7 +629,9 @@ int uz_pil_resample_v_f32(const void* src, int Hin, int W, int C, const int* bou
  *   with respect to the left operand; the gradients that contract over the ROWS of both operands (dV = A^T dO,
  *   dK = dS^T Q, dW = X^T dQ) are uz_wgrad with ntaps = 1.
  * uz_softmax_fwd: s_b <- softmax(scale * s_b) in place over axis 0 (every COLUMN sums to one: nn.Softmax(dim=1) of a
- *   (b, rows, cols) tensor, unet_transformer.py:123) or axis 1 (rows; at most 2048 bf16 / 1024 fp32 columns).
+ *   (b, rows, cols) tensor, unet_transformer.py:123; three streaming launches: column statistics per 512-row slice,
+ *   their combination, the elementwise apply -- `workspace` of uz_softmax_workspace_bytes()) or axis 1 (rows; at most
+ *   2048 bf16 / 1024 fp32 columns; no workspace).
  * uz_softmax_bwd: g_b <- a_b * (g_b - dot) * scale in place, a = the softmax output, dot = sum of a * g along the
  *   normalised axis.  Axis 0: `dot` is a (batch, cols) fp32 buffer, computed by a first pass unless dot_given != 0
  *   (attention knows it more cheaply: sum_q A[q][k] dA[q][k] = dV[k] . V[k]); axis 1: computed in registers.
@@ -644,8 +646,9 @@ typedef struct uz_gemm_desc {
 } uz_gemm_desc;
 int uz_gemm_nt(const uz_gemm_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y,
                void* stream);
+long long uz_softmax_workspace_bytes(int batch, int rows, int cols, int axis);   /* axis 0: partial column statistics */
 int uz_softmax_fwd(int dtype, void* s, int ld, long long sb, int batch, int rows, int cols, int axis, float scale,
-                   void* stream);
+                   void* workspace, void* stream);
 int uz_softmax_bwd(int dtype, const void* a, void* g, int ld, long long sb, int batch, int rows, int cols, int axis,
                    float scale, float* dot, int dot_given, void* stream);
 int uz_adaptive_avgpool_fwd(int dtype, const void* x, int ldx, int N, int Hi, int Wi, int C, void* y, int ldy, int Ho,
@@ -656,6 +659,10 @@ int uz_rowdot_f32(int dtype, const float* a, int lda, const void* b, int ldb, lo
                   void* stream);
 int uz_cast_rows(int dtype, const float* src, int lds, void* dst, int ldd, long long rows, int C, int accumulate,
                  void* stream);
+/* out[p][c] = x[p][c] + map[p % HW][c], map fp32 (HW, C): `x + self.pe(x)` (unet_transformer.py:128-129, :181-185), the
+ * learned embeddings of transatt_unet.py:144-145 and swin_unet_v2.py:714-715, broadcast over the batch. */
+int uz_add_map(int dtype, const void* x, int ldx, const float* map, void* out, int ldo, long long P, int HW, int C,
+               void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,1 +1,1 @@
-extern "C" const char* uz_source_hash(void) { return "a0917e9e697231b6b543bc2f896cb2b73510725be4ebf07dba0c978ad31eabeb"; }
+extern "C" const char* uz_source_hash(void) { return "a8ab79dacf54b6908ad53675e8a4bae015c9d3ea84f6e97a882ae1857563506b"; }

@@ -11,76 +11,128 @@
 namespace {
 
 template <typename T> __device__ __forceinline__ float tof(T v) { return (float)v; }
+// exponentials: the fp32 (parity) instantiations use the correctly rounded library function -- v_exp_f32 on a product
+// with log2(e) carries a relative error of |x| * 6e-8, which the score matrices of a 4096-token softmax amplify --,
+// the bf16 ones the hardware instruction (their results are rounded to 8 bits anyway)
+template <typename T> __device__ __forceinline__ float uz_exp(float x) {
+  if constexpr (sizeof(T) == 4) return expf(x);
+  else return __expf(x);
+}
 
 // ---- softmax over the ROW axis of (rows, cols): every column is normalised ------------------------------------------
-// workgroup = one strip of 16 * VEC columns of one matrix; 16 threads across the strip (16 bytes each), 16 row groups.
-// Pass 1 keeps a running maximum and a running sum of exponentials per column (one exp per element plus one per
-// maximum update), the 16 row groups are merged through LDS, pass 2 re-reads the strip (L2 / MALL resident for the
-// sizes at hand: 4096 rows x 256 B = 1 MB per strip) and writes exp(x * scale - m) / Z.
+// Three launches, all of them streaming at full occupancy (a workgroup that walks a whole 4096-row strip twice leaves the
+// CU with 8 waves and runs at 3.5 TB/s; this form reaches what the gradient kernel below reaches):
+//   stats   : workgroup = (strip of 16 * VEC columns, matrix, slice of the rows); 16 threads across the strip, 16 row
+//             groups, running maximum and running sum of exponentials per column, merged through LDS -> one (m, z) pair
+//             per (slice, column)
+//   combine : the slices of a column -> m and 1 / Z
+//   apply   : s <- exp(scale * s - m[col]) / Z[col], elementwise
+constexpr int SM_SLICE = 512;   // rows per stats workgroup
+
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_cols_fwd_kernel(T* s, int ld, long long sb, int rows, int cols, float scale) {
+__global__ __launch_bounds__(256) void softmax_cols_stats_kernel(const T* s, int ld, long long sb, int rows, int cols, float scale,
+                                                                 float* part) {   // part[b][slice][2][cols]
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int SW = 16 * VEC;
   __shared__ float sm[16][SW], sz[16][SW];
   const int tid = threadIdx.x, cx = tid & 15, rg = tid >> 4;
   const int c0 = blockIdx.x * SW + cx * VEC;
-  T* base = s + (long long)blockIdx.y * sb;
-  const bool ok = c0 < cols;
+  const T* base = s + (long long)blockIdx.y * sb;
+  const int r_beg = blockIdx.z * SM_SLICE, r_end = min(rows, r_beg + SM_SLICE);
   float m[VEC], z[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { m[e] = -INFINITY; z[e] = 0.f; }
-  if (ok) {
-    for (int r = rg; r < rows; r += 64) {
+  if (c0 < cols) {
+    for (int r = r_beg + rg; r < r_end; r += 64) {
       Vec16<T> v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (r + 16 * u < rows) v[u] = ld16(base + (long long)(r + 16 * u) * ld + c0);
+        v[u] = (r + 16 * u < r_end) ? ld16(base + (long long)(r + 16 * u) * ld + c0) : zero16<T>();
+      // one rescale of the running sum per group of four rows: 5 exponentials per 4 elements instead of 8
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (r + 16 * u < rows) {
+      for (int e = 0; e < VEC; ++e) {
+        float x[4], mn = m[e];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const float x = tof(v[u].v[e]) * scale;
-            if (x > m[e]) {
-              z[e] = z[e] * __expf(m[e] - x) + 1.f;
-              m[e] = x;
-            } else {
-              z[e] += __expf(x - m[e]);
-            }
-          }
+        for (int u = 0; u < 4; ++u) {
+          x[u] = (r + 16 * u < r_end) ? tof(v[u].v[e]) * scale : -INFINITY;
+          mn = fmaxf(mn, x[u]);
         }
+        float acc = z[e] * uz_exp<T>(m[e] - mn);      // (first group: 0 * exp(-inf) = 0)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += uz_exp<T>(x[u] - mn);   // exp(-inf) = 0 for the rows beyond the slice
+        z[e] = acc;
+        m[e] = mn;
+      }
     }
   }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { sm[rg][cx * VEC + e] = m[e]; sz[rg][cx * VEC + e] = z[e]; }
   __syncthreads();
-  float rz[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
+  if (tid < SW && blockIdx.x * SW + tid < cols) {
     float mm = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) mm = fmaxf(mm, sm[g][cx * VEC + e]);
+    for (int g = 0; g < 16; ++g) mm = fmaxf(mm, sm[g][tid]);
     float zz = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const float mg = sm[g][cx * VEC + e];
-      zz += mg == -INFINITY ? 0.f : sz[g][cx * VEC + e] * __expf(mg - mm);
+      const float mg = sm[g][tid];
+      zz += mg == -INFINITY ? 0.f : sz[g][tid] * uz_exp<T>(mg - mm);
     }
-    m[e] = mm;
-    rz[e] = 1.f / zz;
+    float* pp = part + ((long long)blockIdx.y * gridDim.z + blockIdx.z) * 2 * cols + blockIdx.x * SW + tid;
+    pp[0] = mm;
+    pp[cols] = zz;
   }
-  if (!ok) return;
-  for (int r = rg; r < rows; r += 64) {
+}
+
+__global__ __launch_bounds__(256) void softmax_cols_combine_kernel(const float* part, int nslices, int cols, long long total,
+                                                                   float* mz) {   // mz[b][2][cols] = (m, 1 / Z)
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / cols;
+  const int c = (int)(i % cols);
+  const float* pp = part + b * nslices * 2 * cols + c;
+  float mm = -INFINITY;
+  for (int k = 0; k < nslices; ++k) mm = fmaxf(mm, pp[(long long)k * 2 * cols]);
+  float zz = 0.f;
+  for (int k = 0; k < nslices; ++k) {
+    const float mk = pp[(long long)k * 2 * cols];
+    zz += mk == -INFINITY ? 0.f : pp[(long long)k * 2 * cols + cols] * expf(mk - mm);
+  }
+  mz[b * 2 * cols + c] = mm;
+  mz[b * 2 * cols + cols + c] = 1.f / zz;
+}
+
+// thread = one 16-byte column chunk, SM_ROWS consecutive rows: the column vectors stay in registers and no index needs a
+// division (a grid-stride loop over flat chunk indices spends more VALU time in 64-bit div / mod than in the exponentials)
+constexpr int SM_ROWS = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_cols_apply_kernel(T* s, int ld, long long sb, int rows, int cols, float scale,
+                                                                 const float* mz) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+  if (c0 >= cols) return;
+  const int b = blockIdx.z, r0 = blockIdx.y * SM_ROWS;
+  const float* mp = mz + (long long)b * 2 * cols + c0;
+  float mm[VEC], rz[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; e += 4) {
+    *reinterpret_cast<f32x4*>(&mm[e]) = *reinterpret_cast<const f32x4*>(mp + e);
+    *reinterpret_cast<f32x4*>(&rz[e]) = *reinterpret_cast<const f32x4*>(mp + cols + e);
+  }
+  T* p = s + (long long)b * sb + (long long)r0 * ld + c0;
+  const int nr = min(SM_ROWS, rows - r0);
+  for (int r = 0; r < nr; r += 4) {
     Vec16<T> v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (r + 16 * u < rows) v[u] = ld16(base + (long long)(r + 16 * u) * ld + c0);
+      if (r + u < nr) v[u] = ld16(p + (long long)(r + u) * ld);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (r + 16 * u < rows) {
+      if (r + u < nr) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[u].v[e] = (T)(__expf(tof(v[u].v[e]) * scale - m[e]) * rz[e]);
-        st16(base + (long long)(r + 16 * u) * ld + c0, v[u]);
+        for (int e = 0; e < VEC; ++e) v[u].v[e] = (T)(uz_exp<T>(tof(v[u].v[e]) * scale - mm[e]) * rz[e]);
+        st16(p + (long long)(r + u) * ld, v[u]);
       }
   }
 }
@@ -116,7 +168,8 @@ __global__ __launch_bounds__(256) void softmax_cols_dot_kernel(const T* a, const
   }
 }
 
-// dS = A * (dA - dot[column]) * scale, written over dA
+// dS = A * (dA - dot[column]) * scale, written over dA.  (The apply kernel's thread layout -- one column chunk, 16 rows --
+// measured 287 us against this flat grid-stride loop's 240 us on the 16 x 4096 x 4096 matrices: two input streams.)
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_cols_bwd_kernel(const T* a, T* g, int ld, long long sb, int rows, int cols,
                                                                float scale, const float* dot, long long chunks) {
@@ -184,7 +237,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* a, T* s, int
         const int c = (u * 64 + lane) * VEC;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          ex[u][e] = c < cols ? __expf(tof(v[u].v[e]) * scale - red) : 0.f;
+          ex[u][e] = c < cols ? uz_exp<T>(tof(v[u].v[e]) * scale - red) : 0.f;
           z += ex[u][e];
         }
       }
@@ -328,6 +381,28 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* src, int ld
   }
 }
 
+// ---- out[p][c] = x[p][c] + map[p % HW][c] (map fp32): position encodings / embeddings broadcast over the batch ---------
+template <typename T>
+__global__ __launch_bounds__(256) void add_map_kernel(const T* x, int ldx, const float* map, T* out, int ldo, long long P, int HW, int C,
+                                                      long long chunks) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const long long p = i / cpr;
+    const int q = (int)(p % HW);
+    Vec16<T> v = ld16(x + p * ldx + cc * VEC);
+    const float* mp = map + (long long)q * C + cc * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4) {
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(mp + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v.v[e + k] = (T)(tof(v.v[e + k]) + m4[k]);
+    }
+    st16(out + p * ldo + cc * VEC, v);
+  }
+}
+
 inline unsigned grid_for_chunks(long long chunks) {
   long long g = (chunks + 255) / 256;
   const long long cap = 16LL * UZ_NUM_CU_HW;
@@ -343,15 +418,33 @@ bool softmax_args_ok(int dtype, const void* s, int ld, long long sb, int batch, 
 
 }  // namespace
 
+extern "C" long long uz_softmax_workspace_bytes(int batch, int rows, int cols, int axis) {
+  UZ_REQUIRE(batch >= 1 && rows >= 1 && cols >= 1 && (axis == 0 || axis == 1), "uz_softmax_workspace_bytes: bad arguments");
+  if (axis == 1) return 0;
+  return ((long long)batch * uz_cdiv(rows, SM_SLICE) + batch) * 2 * cols * (long long)sizeof(float);
+}
+
 extern "C" int uz_softmax_fwd(int dtype, void* s, int ld, long long sb, int batch, int rows, int cols, int axis, float scale,
-                              void* stream) {
+                              void* workspace, void* stream) {
   UZ_REQUIRE(softmax_args_ok(dtype, s, ld, sb, batch, rows, cols, axis), "uz_softmax_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int vec = dtype == UZ_BF16 ? 8 : 4;
   if (axis == 0) {
-    const dim3 grid(uz_cdiv(cols, 16 * vec), batch), block(256);
-    if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_fwd_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)s, ld, sb, rows, cols, scale);
-    else hipLaunchKernelGGL(softmax_cols_fwd_kernel<float>, grid, block, 0, st, (float*)s, ld, sb, rows, cols, scale);
+    UZ_REQUIRE(workspace != nullptr, "uz_softmax_fwd: axis 0 needs uz_softmax_workspace_bytes() of workspace");
+    const int nsl = uz_cdiv(rows, SM_SLICE);
+    float* part = static_cast<float*>(workspace);
+    float* mz = part + (long long)batch * nsl * 2 * cols;
+    const dim3 grid(uz_cdiv(cols, 16 * vec), batch, nsl), block(256);
+    if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)s, ld, sb, rows, cols, scale, part);
+    else hipLaunchKernelGGL(softmax_cols_stats_kernel<float>, grid, block, 0, st, (const float*)s, ld, sb, rows, cols, scale, part);
+    UZ_LAUNCH_CHECK("uz_softmax_fwd(stats)");
+    const long long total = (long long)batch * cols;
+    hipLaunchKernelGGL(softmax_cols_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part, nsl, cols, total, mz);
+    UZ_LAUNCH_CHECK("uz_softmax_fwd(combine)");
+    UZ_REQUIRE(uz_cdiv(rows, SM_ROWS) <= 65535, "uz_softmax_fwd: too many rows");
+    const dim3 grid2(uz_cdiv(cols / vec, 256), uz_cdiv(rows, SM_ROWS), batch);
+    if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_apply_kernel<bf16_t>, grid2, block, 0, st, (bf16_t*)s, ld, sb, rows, cols, scale, (const float*)mz);
+    else hipLaunchKernelGGL(softmax_cols_apply_kernel<float>, grid2, block, 0, st, (float*)s, ld, sb, rows, cols, scale, (const float*)mz);
   } else {
     UZ_REQUIRE(cols <= 64 * vec * 4, "uz_softmax_fwd: rows longer than 64 * 4 sixteen-byte chunks");
     const long long total = (long long)batch * rows;
@@ -385,8 +478,8 @@ extern "C" int uz_softmax_bwd(int dtype, const void* a, void* g, int ld, long lo
     }
     const long long chunks = (long long)batch * rows * (cols / vec);
     const dim3 grid(grid_for_chunks(chunks)), block(256);
-    if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, (bf16_t*)g, ld, sb, rows, cols, scale, dot, chunks);
-    else hipLaunchKernelGGL(softmax_cols_bwd_kernel<float>, grid, block, 0, st, (const float*)a, (float*)g, ld, sb, rows, cols, scale, dot, chunks);
+    if (dtype == UZ_BF16) hipLaunchKernelGGL(softmax_cols_bwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, (bf16_t*)g, ld, sb, rows, cols, scale, (const float*)dot, chunks);
+    else hipLaunchKernelGGL(softmax_cols_bwd_kernel<float>, grid, block, 0, st, (const float*)a, (float*)g, ld, sb, rows, cols, scale, (const float*)dot, chunks);
   } else {
     UZ_REQUIRE(cols <= 64 * vec * 4, "uz_softmax_bwd: rows longer than 64 * 4 sixteen-byte chunks");
     const long long total = (long long)batch * rows;
@@ -459,5 +552,20 @@ extern "C" int uz_cast_rows(int dtype, const float* src, int lds, void* dst, int
   if (dtype == UZ_BF16) hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, grid, block, 0, st, src, lds, (bf16_t*)dst, ldd, rows, C, accumulate, chunks);
   else hipLaunchKernelGGL(cast_rows_kernel<float>, grid, block, 0, st, src, lds, (float*)dst, ldd, rows, C, accumulate, chunks);
   UZ_LAUNCH_CHECK("uz_cast_rows");
+  return UZ_OK;
+}
+
+extern "C" int uz_add_map(int dtype, const void* x, int ldx, const float* map, void* out, int ldo, long long P, int HW, int C,
+                          void* stream) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && x && map && out && P > 0 && HW > 0 && P % HW == 0 && C > 0 && C % vec == 0 &&
+                 ldx % vec == 0 && ldo % vec == 0 && ldx >= C && ldo >= C && ((uintptr_t)map & 15) == 0,
+             "uz_add_map: bad arguments");
+  const long long chunks = P * (C / vec);
+  const dim3 grid(grid_for_chunks(chunks)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UZ_BF16) hipLaunchKernelGGL(add_map_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, map, (bf16_t*)out, ldo, P, HW, C, chunks);
+  else hipLaunchKernelGGL(add_map_kernel<float>, grid, block, 0, st, (const float*)x, ldx, map, (float*)out, ldo, P, HW, C, chunks);
+  UZ_LAUNCH_CHECK("uz_add_map");
   return UZ_OK;
 }

@@ -1033,8 +1033,7 @@ class Engine:
         `x + self.pe(x)` of unet_transformer.py:133-134, :181-185.  The gradient passes through unchanged."""
         assert const_map.shape == (x.H * x.W, x.C), (tuple(const_map.shape), (x.H * x.W, x.C))
         out = self.new_act(x.N, x.H, x.W, x.C, x.needs_grad)
-        xv = x.buf.view(x.N, x.H * x.W, x.ld)[..., x.off:x.off + x.C]
-        out.buf.view(x.N, x.H * x.W, x.C).copy_(xv.float() + const_map.to(self.device, torch.float32))
+        ops.add_map(x, const_map.to(self.device, torch.float32).contiguous(), out)
         if self.record and x.needs_grad:
             def bwd():
                 g = self._total_grad(out)
@@ -1049,8 +1048,7 @@ class Engine:
         (swin_unet_v2.py:714-715).  d(p) = sum over the batch of the incoming gradient (N terms per element)."""
         assert tuple(p.shape) == (1, x.H * x.W, x.C), (tuple(p.shape), (1, x.H * x.W, x.C))
         out = out if out is not None else self.new_act(x.N, x.H, x.W, x.C)
-        xv = x.buf.view(x.N, x.H * x.W, x.ld)[..., x.off:x.off + x.C]
-        out.buf.view(x.N, x.H * x.W, out.ld)[..., out.off:out.off + x.C].copy_(xv.float() + p.detach()[0])
+        ops.add_map(x, p.detach()[0], out)
         if self.record:
             def bwd():
                 g = self._total_grad(out)
@@ -1306,8 +1304,7 @@ class Engine:
         pos = torch.cat([col_w.detach()[:W].unsqueeze(0).expand(H, W, F_), row_w.detach()[:H].unsqueeze(1).expand(H, W, F_)],
                         dim=-1).reshape(H * W, 2 * F_)
         out = self.new_act(x.N, H, W, x.C)
-        xv = x.buf.view(x.N, H * W, x.ld)[..., x.off:x.off + x.C]
-        out.buf.view(x.N, H * W, x.C).copy_(xv.float() + pos)
+        ops.add_map(x, pos.contiguous(), out)
         if self.record:
             def bwd():
                 g = self._total_grad(out)

@@ -1044,8 +1044,11 @@ def softmax_fwd(s: torch.Tensor, axis: int, scale: float) -> None:
     """s (batch, rows, cols) <- softmax(scale * s) over axis 0 (of each matrix: columns sum to one) or 1, in place"""
     assert s.dim() == 3 and s.is_contiguous()
     B, R, C = s.shape
+    lib = L.load()
+    ws_bytes = L.check_count(lib.uz_softmax_workspace_bytes(B, R, C, axis), "uz_softmax_workspace_bytes")
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=s.device) if ws_bytes else None
     with _Timed(f"softmax_axis{axis}_fwd", 0.0, 3.0 * s.numel() * s.element_size()):
-        L.check(L.load().uz_softmax_fwd(L.dtype_code(s.dtype), s.data_ptr(), C, R * C, B, R, C, axis, scale, L.stream_ptr()),
+        L.check(lib.uz_softmax_fwd(L.dtype_code(s.dtype), s.data_ptr(), C, R * C, B, R, C, axis, scale, _p(ws), L.stream_ptr()),
                 "uz_softmax_fwd")
 
 
@@ -1090,3 +1093,12 @@ def cast_rows(src: torch.Tensor, dst: Act, accumulate: bool = False) -> None:
     with _Timed("cast_rows", 0.0, src.numel() * (4 + dst.buf.element_size())):
         L.check(L.load().uz_cast_rows(L.dtype_code(dst.dtype), src.data_ptr(), dst.C, dst.ptr(), dst.ld, dst.P, dst.C,
                                       1 if accumulate else 0, L.stream_ptr()), "uz_cast_rows")
+
+
+def add_map(x: Act, map_f32: torch.Tensor, out: Act) -> None:
+    """out = x + map broadcast over the batch; map fp32 (H*W, C)"""
+    assert map_f32.dtype == torch.float32 and map_f32.is_contiguous() and tuple(map_f32.shape) == (x.H * x.W, x.C)
+    assert (out.P, out.C) == (x.P, x.C)
+    with _Timed("add_map", 0.0, 2.0 * x.P * x.C * x.buf.element_size()):
+        L.check(L.load().uz_add_map(L.dtype_code(x.dtype), x.ptr(), x.ld, map_f32.data_ptr(), out.ptr(), out.ld, x.P, x.H * x.W,
+                                    x.C, L.stream_ptr()), "uz_add_map")
