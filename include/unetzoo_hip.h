@@ -664,6 +664,20 @@ int uz_cast_rows(int dtype, const float* src, int lds, void* dst, int ldd, long 
 int uz_add_map(int dtype, const void* x, int ldx, const float* map, void* out, int ldo, long long P, int HW, int C,
                void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Channel-wise cross attention of UCTransNet (Attention_org.forward, unet_zoo/models/uctransnet.py:160-216): the part
+ * between the matrix products.  `scores` fp32 (B, H, C, KV) = Q^T K per (image, head) (uz_wgrad_batched); per plane:
+ * x = scale * scores, InstanceNorm2d (mean / biased variance over the (C, KV) plane, eps, no affine; :176), softmax over KV
+ * (:177).  fwd writes pcat[b][c][h * KV + kv] = P / H and its transpose pcat_t[b][h * KV + kv][c] in the run dtype: the
+ * context product over K = H * KV with V (B, tokens, H * KV) then is `context_layer.mean(dim=3)` of all heads (:195-199) in
+ * one uz_gemm_nt.  bwd takes d(loss)/d(pcat) (fp32, (B, C, H * KV)) and writes d(loss)/d(scores) as ds[b][h][c][kv] and
+ * ds_t[b][h][kv][c] (run dtype), recomputing the statistics and probabilities from `scores`.  KV <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+int uz_chanattn_probs_fwd(int dtype, const float* scores, int B, int H, int C, int KV, float scale, float eps, void* pcat,
+                          void* pcat_t, void* stream);
+int uz_chanattn_probs_bwd(int dtype, const float* scores, const float* dpc, int B, int H, int C, int KV, float scale,
+                          float eps, void* ds, void* ds_t, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,3 +265,38 @@ def test_batched_tn_products(dt, B, P, Ci, Cj, pad):
     assert relerr(out.cpu(), ref.cpu()) < (2e-5 if dt == torch.float32 else 1e-5)      # fp32 accumulation of exact bf16 products
     out2 = ops.wgrad_batched(Act(Lm, 0, Ci, B, 1, P), Act(Rm, 0, Cj, B, 1, P))
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,n,H,C,KV", [(2, 64, 4, 16, 240), (3, 49, 4, 128, 240), (2, 64, 2, 32, 72)])
+def test_channel_cross_attention_matches_autograd(dt, B, n, H, C, KV):
+    """Attention_org.forward between its Linear layers (uctransnet.py:160-199): scores over the tokens, InstanceNorm2d on
+    the (C, KV) planes, softmax over KV, context, mean over the heads"""
+    g = torch.Generator().manual_seed(C + KV)
+    hh = int(math.isqrt(n))
+    Q = torch.randn(B, n, H * C, generator=g).to(dt).double().requires_grad_(True)
+    K = torch.randn(B, n, H * KV, generator=g).to(dt).double().requires_grad_(True)
+    V = torch.randn(B, n, H * KV, generator=g).to(dt).double().requires_grad_(True)
+    Qh = Q.view(B, n, H, C).permute(0, 2, 3, 1)                 # (B, H, C, n)
+    Kh = K.view(B, n, H, KV).permute(0, 2, 1, 3)                # (B, H, n, KV)
+    Vh = V.view(B, n, H, KV).permute(0, 2, 3, 1)                # (B, H, KV, n)
+    scores = torch.matmul(Qh, Kh) / math.sqrt(KV)
+    probs = torch.softmax(F.instance_norm(scores), dim=3)
+    ref = torch.matmul(probs, Vh).permute(0, 3, 2, 1).mean(dim=3)       # (B, n, C)
+    dy = torch.randn(ref.shape, generator=g).to(dt).double()
+    ref.backward(dy)
+
+    def tok(t, c):
+        return Act(t.detach().reshape(B * n, c).to(dt).to(DEV).contiguous(), 0, c, B, hh, n // hh)
+
+    eng = Engine(dt, torch.device(DEV), True, True)
+    Qa, Ka, Va = tok(Q, H * C), tok(K, H * KV), tok(V, H * KV)
+    ctx = eng.channel_cross_attention(Qa, Ka, Va, H)
+    ftol, gtol = (2e-5, 2e-4) if dt == torch.float32 else (2e-2, 5e-2)
+    assert relerr(ctx.buf.view(B, n, C).cpu(), ref.detach()) < ftol
+    ctx.add_grad(tok(dy, C))
+    eng.backward_range(None, len(eng.tape), 0)
+    for a, r, name in ((Qa, Q, "Q"), (Ka, K, "K"), (Va, V, "V")):
+        got = a.grads[0].buf.view(B, n, -1).cpu().double()
+        e = ((got - r.grad).norm() / r.grad.norm()).item()
+        assert e < gtol, (name, e)

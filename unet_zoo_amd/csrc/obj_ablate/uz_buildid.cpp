@@ -1,1 +1,1 @@
-extern "C" const char* uz_source_hash(void) { return "a8ab79dacf54b6908ad53675e8a4bae015c9d3ea84f6e97a882ae1857563506b"; }
+extern "C" const char* uz_source_hash(void) { return "b6e587b5cdd2cb60df16bc4ece022c8925ebbe32c55982d7e29c2a667cc2c6c5"; }

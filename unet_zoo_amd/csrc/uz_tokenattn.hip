@@ -569,3 +569,175 @@ extern "C" int uz_add_map(int dtype, const void* x, int ldx, const float* map, v
   UZ_LAUNCH_CHECK("uz_add_map");
   return UZ_OK;
 }
+
+// ---- channel-wise cross attention of UCTransNet: InstanceNorm2d + softmax on the score planes -----------------------
+// Attention_org.forward (unet_zoo/models/uctransnet.py:160-216): per (image, head) the (C, KV) plane of
+// scores = Q^T K / sqrt(KV) is instance-normalised (nn.InstanceNorm2d(heads): mean and biased variance over the
+// plane, no affine), softmax over KV, and the context layers of the heads are averaged.  One workgroup per (image,
+// head); a plane is at most 128 x 240 fp32 = 123 KB and stays in L2 between the passes, a row lives in registers.
+//   forward : pcat[b][c][h * KV + kv] = softmax_kv((s - mean) * rstd) / H (run dtype: the operand of the context product
+//             over K = H * KV, which also takes the mean over heads) and its transpose pcat_t[b][h * KV + kv][c]
+//   backward: from d(loss)/d(pcat) (fp32, (B, C, H * KV)) to d(loss)/d(scores) * scale as ds[b][h][c][kv] and its
+//             transpose ds_t[b][h][kv][c] (run dtype: operands of dQ = K dS^T and dK = Q dS)
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // 1024 threads; red: 16 floats
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k];
+  return t;
+}
+
+template <typename T, int RPT, bool BWD>
+__global__ __launch_bounds__(1024) void chanattn_probs_kernel(const float* __restrict__ scores, const float* __restrict__ dpc,
+                                                             int H, int C, int KV, float scale, float eps, T* __restrict__ o0,
+                                                             T* __restrict__ o1) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* pl = scores + ((long long)b * H + h) * C * KV;
+  const int n = C * KV;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) t += pl[i];
+  const float mean = block_sum(t, red) * scale / (float)n;
+  t = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float d = pl[i] * scale - mean;
+    t += d * d;
+  }
+  const float rstd = rsqrtf(block_sum(t, red) / (float)n + eps);
+  const float invH = 1.f / (float)H;
+  const int HK = H * KV;
+
+  // one row: normalised scores and probabilities of this lane's RPT elements
+  auto row = [&](int c, float (&sh)[RPT], float (&p)[RPT]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      const int kv = u * 64 + lane;
+      sh[u] = kv < KV ? (pl[(long long)c * KV + kv] * scale - mean) * rstd : -INFINITY;
+      mx = fmaxf(mx, sh[u]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float z = 0.f;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      p[u] = u * 64 + lane < KV ? expf(sh[u] - mx) : 0.f;
+      z += p[u];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o);
+    const float rz = 1.f / z;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) p[u] *= rz;
+  };
+
+  if constexpr (!BWD) {
+    T* pcat = o0 + (long long)b * C * HK + h * KV;
+    T* pcat_t = o1 + ((long long)b * HK + h * KV) * C;
+    for (int c = wave; c < C; c += 16) {
+      float sh[RPT], p[RPT];
+      row(c, sh, p);
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int kv = u * 64 + lane;
+        if (kv < KV) {
+          const T v = (T)(p[u] * invH);
+          pcat[(long long)c * HK + kv] = v;
+          pcat_t[(long long)kv * C + c] = v;
+        }
+      }
+    }
+  } else {
+    // d(loss)/d(P) = dpc / H; softmax: dsh = P * (dP - sum(P dP)); instance norm: ds = rstd * (dsh - mean(dsh) -
+    // sh * mean(dsh * sh)) over the plane
+    const float* dp = dpc + (long long)b * C * HK + h * KV;
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = wave; c < C; c += 16) {
+      float sh[RPT], p[RPT], g[RPT], dot = 0.f;
+      row(c, sh, p);
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int kv = u * 64 + lane;
+        g[u] = kv < KV ? dp[(long long)c * HK + kv] * invH : 0.f;
+        dot += p[u] * g[u];
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        if (u * 64 + lane < KV) {
+          const float dsh = p[u] * (g[u] - dot);
+          a1 += dsh;
+          a2 += dsh * sh[u];
+        }
+      }
+    }
+    const float m1 = block_sum(a1, red) / (float)n;
+    const float m2 = block_sum(a2, red) / (float)n;
+    T* ds = o0 + ((long long)b * H + h) * C * KV;
+    T* ds_t = o1 + ((long long)b * H + h) * KV * C;
+    for (int c = wave; c < C; c += 16) {
+      float sh[RPT], p[RPT], g[RPT], dot = 0.f;
+      row(c, sh, p);
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int kv = u * 64 + lane;
+        g[u] = kv < KV ? dp[(long long)c * HK + kv] * invH : 0.f;
+        dot += p[u] * g[u];
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int kv = u * 64 + lane;
+        if (kv < KV) {
+          const float dsh = p[u] * (g[u] - dot);
+          const T v = (T)(rstd * (dsh - m1 - sh[u] * m2) * scale);
+          ds[(long long)c * KV + kv] = v;
+          ds_t[(long long)kv * C + c] = v;
+        }
+      }
+    }
+  }
+}
+
+template <bool BWD>
+int chanattn_launch(int dtype, const float* scores, const float* dpc, int B, int H, int C, int KV, float scale, float eps,
+                    void* o0, void* o1, hipStream_t st) {
+  const dim3 grid(B * H), block(1024);
+  const int rpt = uz_cdiv(KV, 64);
+#define UZ_CA(T, R) hipLaunchKernelGGL((chanattn_probs_kernel<T, R, BWD>), grid, block, 0, st, scores, dpc, H, C, KV, scale, eps, (T*)o0, (T*)o1)
+  if (dtype == UZ_BF16) {
+    if (rpt <= 4) UZ_CA(bf16_t, 4); else UZ_CA(bf16_t, 16);
+  } else {
+    if (rpt <= 4) UZ_CA(float, 4); else UZ_CA(float, 16);
+  }
+#undef UZ_CA
+  UZ_LAUNCH_CHECK("uz_chanattn_probs");
+  return UZ_OK;
+}
+
+}  // namespace
+
+extern "C" int uz_chanattn_probs_fwd(int dtype, const float* scores, int B, int H, int C, int KV, float scale, float eps,
+                                     void* pcat, void* pcat_t, void* stream) {
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && scores && pcat && pcat_t && B >= 1 && H >= 1 && C >= 1 && KV >= 1 &&
+                 KV <= 1024 && (long long)B * H < (1LL << 31) && (long long)C * KV < (1LL << 31),
+             "uz_chanattn_probs_fwd: bad arguments");
+  return chanattn_launch<false>(dtype, scores, nullptr, B, H, C, KV, scale, eps, pcat, pcat_t, (hipStream_t)stream);
+}
+
+extern "C" int uz_chanattn_probs_bwd(int dtype, const float* scores, const float* dpc, int B, int H, int C, int KV, float scale,
+                                     float eps, void* ds, void* ds_t, void* stream) {
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && scores && dpc && ds && ds_t && B >= 1 && H >= 1 && C >= 1 && KV >= 1 &&
+                 KV <= 1024 && (long long)B * H < (1LL << 31) && (long long)C * KV < (1LL << 31),
+             "uz_chanattn_probs_bwd: bad arguments");
+  return chanattn_launch<true>(dtype, scores, dpc, B, H, C, KV, scale, eps, ds, ds_t, (hipStream_t)stream);
+}

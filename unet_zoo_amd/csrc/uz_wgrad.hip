@@ -439,8 +439,8 @@ extern "C" int uz_wgrad_batched(const uz_wgrad_desc* d, int batch, const void* L
   UZ_REQUIRE((((uintptr_t)L | (uintptr_t)R) & 15) == 0 && lb % 8 == 0 && rb % 8 == 0, "uz_wgrad_batched: L / R must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p2.nslabs == 1) {   // no pixel split: the kernel's slab IS the result (ntaps = 1: same layout)
-    UZ_REQUIRE(ob == (long long)d->Ci * d->Cj, "uz_wgrad_batched: results of an unsplit batch must be dense (ob = Ci * Cj)");
-    return uz_wgrad3x3_launch(d, p2, L, R, out, s, batch, lb * es, rb * es);
+    UZ_REQUIRE(ob >= (long long)d->Ci * d->Cj, "uz_wgrad_batched: results overlap (ob < Ci * Cj)");
+    return uz_wgrad3x3_launch(d, p2, L, R, out, s, batch, lb * es, rb * es, ob);
   }
   const int r2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s, batch, lb * es, rb * es);
   if (r2 != UZ_OK) return r2;

@@ -520,11 +520,11 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch) {
 }
 
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
-                       float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes) {
+                       float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes, long long slab_stride) {
   Wg2Args a;
   a.lb = lb_bytes;
   a.rb = rb_bytes;
-  a.sb = (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
+  a.sb = slab_stride ? slab_stride : (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
   UZ_REQUIRE(batch == 1 || (p.one_tap && !p.gather && batch <= 65535), "uz_wgrad(3x3): only one-tap problems are batched");
   a.L = L;
   a.R = R;

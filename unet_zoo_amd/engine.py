@@ -629,10 +629,11 @@ class Engine:
             self.tape.append(bwd)
         return out
 
-    def add(self, a: Act, b: Act) -> Act:
-        """a + b (the residual sums, resunet.py:56, common_layers.py:199)"""
+    def add(self, a: Act, b: Act, out: Optional[Act] = None) -> Act:
+        """a + b (the residual sums, resunet.py:56, common_layers.py:199); `out`: a concat slot to write into"""
         assert (a.N, a.H, a.W, a.C) == (b.N, b.H, b.W, b.C)
-        out = self.new_act(a.N, a.H, a.W, a.C)
+        out = out if out is not None else self.new_act(a.N, a.H, a.W, a.C)
+        assert (out.N, out.H, out.W, out.C) == (a.N, a.H, a.W, a.C)
         ops.add_acts(a, b, out)
         if self.record:
             def bwd():
@@ -768,6 +769,38 @@ class Engine:
                     dx = self.new_act(x.N, x.H, x.W, x.C)
                     ops.conv_igemm(g, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=1, res=prev)
                     x.add_grad(dx)
+
+            self.tape.append(bwd)
+        return y
+
+    def linear_heads(self, x: Act, lins: Sequence[nn.Linear]) -> Act:
+        """[lin(x) for lin in lins] side by side in one (tokens, len(lins) * out_features) activation: the per-head
+        query / key / value Linear layers of UCTransNet's Attention_org (uctransnet.py:104-116, :140-158).  One activation
+        (not a concat of parts), so the gradients that several consumers leave on it accumulate on the whole tensor --
+        in the consumers' GEMM epilogues -- and the input gradient is one chain of products."""
+        Co, Hn = lins[0].out_features, len(lins)
+        assert all(l.in_features == x.C and l.out_features == Co for l in lins)
+        y = self.new_act(x.N, x.H, x.W, Hn * Co)
+        for h, lin in enumerate(lins):
+            ops.conv_igemm(x, self._pack(lin.weight, L.PACK_CONV_FWD), lin.bias.detach() if lin.bias is not None else None,
+                           y.window(h * Co, Co), ntaps=1)
+        if self.record:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                prev = x.grads.pop() if (x.needs_grad and x.grads and x.parts is None and x.rparts is None) else None
+                for h, lin in enumerate(lins):
+                    gh = g.window(h * Co, Co)
+                    if lin.bias is not None:
+                        self._bias_grad(lin.bias, gh)
+                    self._give_grad(lin.weight, ops.wgrad(gh, x, tuple(lin.weight.shape), ntaps=1, out=self._dst(lin.weight)))
+                    if x.needs_grad:       # dx = sum_h g_h W_h: each product adds the sum so far in its epilogue
+                        dx = self.new_act(x.N, x.H, x.W, x.C)
+                        ops.conv_igemm(gh, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=1, res=prev)
+                        prev = dx
+                if x.needs_grad:
+                    x.add_grad(prev)
 
             self.tape.append(bwd)
         return y
@@ -1322,6 +1355,61 @@ class Engine:
 
             self.tape.append(bwd)
         return out
+
+    def channel_cross_attention(self, Q: Act, K: Act, V: Act, heads: int, eps: float = 1e-5) -> Act:
+        """The channel-wise cross attention of one scale of UCTransNet between its Linear layers
+        (Attention_org.forward, uctransnet.py:160-199): Q (tokens, heads * C), K and V (tokens, heads * KV) hold the heads
+        side by side; per (image, head) scores = Q_h^T K_h / sqrt(KV) (a product over the TOKENS: the one-tap
+        weight-gradient kernel), InstanceNorm2d over the (C, KV) plane, softmax over KV, context = P V_h^T, mean over the
+        heads -- the last two as ONE product over K = heads * KV with P / heads laid out (C, heads * KV).  Returns the
+        (tokens, C) context."""
+        B, n, H = Q.N, Q.H * Q.W, heads
+        C, KV = Q.C // H, K.C // H
+        assert Q.C == H * C and K.C == H * KV and V.C == H * KV and (K.N, K.H * K.W) == (B, n) and (V.N, V.H * V.W) == (B, n)
+        dt, dev = self.dtype, self.device
+        es = 2 if dt == torch.bfloat16 else 4
+        scale = 1.0 / math.sqrt(KV)
+        scores = torch.empty((B, H, C, KV), dtype=torch.float32, device=dev)
+        for h in range(H):
+            ops.wgrad_batched(Q.window(h * C, C), K.window(h * KV, KV), out=scores, out_off=h * C * KV, ob=H * C * KV)
+        pcat, pcat_t = ops.chanattn_probs_fwd(scores, scale, eps, dt)
+        ctx = self.new_act(B, Q.H, Q.W, C)
+        ops.gemm_nt(dt, B, n, C, H * KV, V.ptr(), V.ld, n * V.ld, pcat.data_ptr(), H * KV, C * H * KV, ctx.ptr(), ctx.ld, n * ctx.ld)
+        if not self.record:
+            return ctx
+
+        def bwd():
+            g = self._total_grad(ctx)
+            if g is None:
+                return
+            dpc = ops.wgrad_batched(g, V)                                   # (B, C, H KV): d(loss)/d(P / heads)
+            if V.needs_grad:
+                prevV = V.grads.pop() if V.grads else None
+                dV = self.new_act(B, V.H, V.W, H * KV)
+                ops.gemm_nt(dt, B, n, H * KV, C, g.ptr(), g.ld, n * g.ld, pcat_t.data_ptr(), C, H * KV * C, dV.ptr(), dV.ld, n * dV.ld,
+                            res_ptr=prevV.ptr() if prevV is not None else None, ldres=prevV.ld if prevV is not None else 0,
+                            resb=n * prevV.ld if prevV is not None else 0)
+                V.add_grad(dV)
+            ds, ds_t = ops.chanattn_probs_bwd(scores, dpc, scale, eps, dt)
+            dQ = self.new_act(B, Q.H, Q.W, H * C)
+            dK = self.new_act(B, K.H, K.W, H * KV)
+            # K (and V) serve every scale: a gradient another scale has already left is added in the product's epilogue
+            # instead of by a separate pass
+            prevK = K.grads.pop() if (K.needs_grad and K.grads) else None
+            for h in range(H):
+                ops.gemm_nt(dt, B, n, C, KV, K.ptr() + h * KV * es, K.ld, n * K.ld, ds.data_ptr() + h * C * KV * es, KV, H * C * KV,
+                            dQ.ptr() + h * C * es, dQ.ld, n * dQ.ld)
+                ops.gemm_nt(dt, B, n, KV, C, Q.ptr() + h * C * es, Q.ld, n * Q.ld, ds_t.data_ptr() + h * KV * C * es, C, H * KV * C,
+                            dK.ptr() + h * KV * es, dK.ld, n * dK.ld,
+                            res_ptr=(prevK.ptr() + h * KV * es) if prevK is not None else None,
+                            ldres=prevK.ld if prevK is not None else 0, resb=n * prevK.ld if prevK is not None else 0)
+            if Q.needs_grad:
+                Q.add_grad(dQ)
+            if K.needs_grad:
+                K.add_grad(dK)
+
+        self.tape.append(bwd)
+        return ctx
 
     def token_attention(self, xq: Act, xv: Act, wq: nn.Parameter, wk: nn.Parameter, wv: nn.Parameter, out: Act) -> Act:
         """out_b = softmax_over_queries((X_b wq)(X_b wk)^T / sqrt(c)) (XV_b wv) on the tokens of xq / xv (NHWC rows = the

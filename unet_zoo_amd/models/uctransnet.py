@@ -10,7 +10,11 @@ producer), the patch-embedding convolutions (kernel = stride = patch: space-to-d
 Conv1x1 + BN + ReLU -- evaluated on the TOKEN grid: nearest upsampling replicates every pixel, which leaves the batch
 mean and the biased variance unchanged and commutes with ReLU; only the unbiased-variance factor of the running
 statistics sees the larger count, which ``stat_repeat`` restores --, the global-average / scale-gradient reductions of
-CCA, the 1x1 head.  The Channel Transformer itself works on (image_size / 32)^2 tokens of 16 ... 240 channels: library
+CCA, the 1x1 head, and the Channel Transformer itself ((image_size / 32)^2 tokens of 16 ... 240 channels): LayerNorm,
+Linear, GELU, dropout and the channel-wise cross attention (``Engine.channel_cross_attention``: token-contracting
+products on the one-tap weight-gradient kernel, InstanceNorm + softmax on the score planes, one batched product for the
+context of all heads) as engine operations.  Configurations the own kernels do not take (attention dropout in training,
+widths that are not multiples of 8) run the same mathematics as library
 GEMMs, LayerNorm and softmax through ``Engine.torch_block``, written so that no reduction to a few values over a large
 tensor occurs (instance-norm moments and Linear biases go through matrix products).
 """
@@ -217,6 +221,50 @@ class ChannelTransformer(nn.Module):
         B, _, h, w = maps[0].shape
         return tuple(e.permute(0, 2, 1).reshape(B, -1, h, w) for e in self.encoder.run(embs))
 
+    def _own_kernels(self, eng: Engine, toks: List[Act]) -> bool:
+        """the channel transformer on the library's own kernels: every width a multiple of 8 (16-byte rows), KV <= 1024, no
+        dropout on the attention probabilities / projections in training (the reference default 0.0, uctransnet.py:17);
+        anything else takes the library-GEMM path (Engine.torch_block)"""
+        att = self.encoder.layer[0].channel_attn
+        if eng.training and (att.attn_dropout.p > 0.0 or att.proj_dropout.p > 0.0):
+            return False
+        return all(t.C % 8 == 0 for t in toks) and att.KV_size % 8 == 0 and att.KV_size <= 1024
+
+    def _emit_tokens(self, eng: Engine, toks: List[Act]) -> List[Act]:
+        """Channel_Embeddings' position embedding + dropout, Encoder.forward over Block_ViT (uctransnet.py:50-55, :260-330) as
+        engine operations on (B, h, w, C_i) token maps: LayerNorm, Linear (heads side by side in one activation), the
+        channel-wise cross attention (Engine.channel_cross_attention), GELU, dropout, residual sums.  The four scales of
+        a block live in the channel slots of ONE concat buffer, so `torch.cat(embs, dim=2)` (:263-268) is never executed."""
+        B, h, w = toks[0].N, toks[0].H, toks[0].W
+        cn = [t.C for t in toks]
+        full, slots = eng.new_cat(B, h, w, cn)
+        for i, t in enumerate(toks):
+            emb = getattr(self, f"embeddings_{i + 1}")
+            eng.dropout(eng.add_param_map(t, emb.position_embeddings), emb.dropout.p, out=slots[i])
+        for blk in self.encoder.layer:
+            att = blk.channel_attn
+            H, KV = att.num_attention_heads, att.KV_size
+            emb_all = eng.layer_norm(full, blk.attn_norm)
+            Kall = eng.linear_heads(emb_all, att.key)
+            Vall = eng.linear_heads(emb_all, att.value)
+            nfull, nslots = eng.new_cat(B, h, w, cn)
+            for i, (queries, proj) in enumerate(zip((att.query1, att.query2, att.query3, att.query4),
+                                                    (att.out1, att.out2, att.out3, att.out4))):
+                emb_i = slots[i]
+                cxn = eng.layer_norm(emb_i, getattr(blk, f"attn_norm{i + 1}"))
+                Qi = eng.linear_heads(cxn, queries)
+                ctx = eng.channel_cross_attention(Qi, Kall, Vall, H, eps=att.psi.eps)
+                cx = eng.linear(ctx, proj, residual=emb_i)                          # emb + out_i(context)
+                mlp = getattr(blk, f"ffn{i + 1}")
+                f = eng.layer_norm(cx, getattr(blk, f"ffn_norm{i + 1}"))
+                f = eng.dropout(eng.gelu(eng.linear(f, mlp.fc1)), mlp.dropout.p)
+                if eng.training and mlp.dropout.p > 0.0:
+                    eng.add(eng.dropout(eng.linear(f, mlp.fc2), mlp.dropout.p), cx, out=nslots[i])
+                else:
+                    eng.linear(f, mlp.fc2, out=nslots[i], residual=cx)
+            full, slots = nfull, nslots
+        return [eng.layer_norm(slots[i], getattr(self.encoder, f"encoder_norm{i + 1}")) for i in range(4)]
+
     def emit(self, eng: Engine, ens: List[Act], outs: List[Act]) -> List[Act]:
         toks = []
         for i, en in enumerate(ens):
@@ -225,10 +273,13 @@ class ChannelTransformer(nn.Module):
                 raise ValueError(f"UCTransNet was built for img_size {int(math.sqrt(emb.position_embeddings.shape[1])) * self.patch[i] * 2 ** i}"
                                  f" (square); got a {en.H * 2 ** i}x{en.W * 2 ** i} input")
             toks.append(eng.patch_conv(en, emb.patch_embeddings))
-        pos = [getattr(self, f"embeddings_{i + 1}").position_embeddings for i in range(4)]
-        others = [p for n, p in self.encoder.named_parameters()]
-        enc = [eng.new_act(t.N, t.H, t.W, t.C) for t in toks]
-        eng.torch_block(lambda *a: self._tokens(*a[:8]), toks, pos + others, enc)
+        if self._own_kernels(eng, toks):
+            enc = self._emit_tokens(eng, toks)
+        else:
+            pos = [getattr(self, f"embeddings_{i + 1}").position_embeddings for i in range(4)]
+            others = [p for n, p in self.encoder.named_parameters()]
+            enc = [eng.new_act(t.N, t.H, t.W, t.C) for t in toks]
+            eng.torch_block(lambda *a: self._tokens(*a[:8]), toks, pos + others, enc)
         for i, (e, en, out) in enumerate(zip(enc, ens, outs)):
             rec = getattr(self, f"reconstruct_{i + 1}")
             f = self.patch[i]

@@ -1023,21 +1023,50 @@ def gemm_nt(dtype: torch.dtype, batch: int, M: int, N: int, K: int, x_ptr: int, 
         L.check(L.load().uz_gemm_nt(byref(d), x_ptr, w_ptr, _p(bias), res_ptr, y_ptr, L.stream_ptr()), "uz_gemm_nt")
 
 
-def wgrad_batched(Lt: Act, Rt: Act) -> torch.Tensor:
-    """out[b] = L_b^T R_b (fp32, (N, Lt.C, Rt.C)) for the N images of two token maps: one launch pair for the batch"""
+def wgrad_batched(Lt: Act, Rt: Act, out: Optional[torch.Tensor] = None, out_off: int = 0, ob: Optional[int] = None) -> torch.Tensor:
+    """out[b] = L_b^T R_b (fp32, (N, Lt.C, Rt.C)) for the N images of two token maps: one launch pair for the batch.
+    `out` / `out_off` / `ob` (floats): write result b at out.flat[out_off + b * ob] instead (a head's block of a
+    (B, heads, C, KV) tensor)"""
     L.require_cuda(Lt.buf, Rt.buf)
     lib = L.load()
     B, P = Lt.N, Lt.H * Lt.W
     assert (Rt.N, Rt.H * Rt.W) == (B, P) and Lt.dtype == Rt.dtype
     d = L.WgradDesc(L.dtype_code(Lt.dtype), 1, 1, P, 1, P, Lt.C, Lt.ld, Rt.C, Rt.ld, 1, L.TAPS_CONV, 1)
     ws_bytes = L.check_count(lib.uz_wgrad_batched_workspace_bytes(byref(d), B), "uz_wgrad_batched_workspace_bytes")
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=Lt.buf.device)
-    out = torch.empty((B, Lt.C, Rt.C), dtype=torch.float32, device=Lt.buf.device)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=Lt.buf.device)
+    if out is None:
+        out = torch.empty((B, Lt.C, Rt.C), dtype=torch.float32, device=Lt.buf.device)
+        ob = Lt.C * Rt.C
+    assert out.dtype == torch.float32 and out.is_contiguous() and out_off + (B - 1) * ob + Lt.C * Rt.C <= out.numel()
     with _Timed(f"wgrad_batched_{_tname(Lt.dtype)}_1tap", 2.0 * B * P * Lt.C * Rt.C,
-                Lt.buf.element_size() * B * P * (Lt.C + Rt.C) + 4.0 * out.numel()):
-        L.check(lib.uz_wgrad_batched(byref(d), B, Lt.ptr(), P * Lt.ld, Rt.ptr(), P * Rt.ld, out.data_ptr(), Lt.C * Rt.C,
+                Lt.buf.element_size() * B * P * (Lt.C + Rt.C) + 4.0 * B * Lt.C * Rt.C):
+        L.check(lib.uz_wgrad_batched(byref(d), B, Lt.ptr(), P * Lt.ld, Rt.ptr(), P * Rt.ld, out.data_ptr() + 4 * out_off, ob,
                                      ws.data_ptr(), L.stream_ptr()), "uz_wgrad_batched")
     return out
+
+
+def chanattn_probs_fwd(scores: torch.Tensor, scale: float, eps: float, dtype: torch.dtype):
+    """scores fp32 (B, H, C, KV) -> (pcat (B, C, H*KV), pcat_t (B, H*KV, C)) in `dtype`: softmax_kv(InstanceNorm(scale * s)) / H"""
+    assert scores.dtype == torch.float32 and scores.is_contiguous() and scores.dim() == 4
+    B, H, C, KV = scores.shape
+    pcat = torch.empty((B, C, H * KV), dtype=dtype, device=scores.device)
+    pcat_t = torch.empty((B, H * KV, C), dtype=dtype, device=scores.device)
+    with _Timed("chanattn_probs_fwd", 0.0, 12.0 * scores.numel()):
+        L.check(L.load().uz_chanattn_probs_fwd(L.dtype_code(dtype), scores.data_ptr(), B, H, C, KV, scale, eps, pcat.data_ptr(),
+                                               pcat_t.data_ptr(), L.stream_ptr()), "uz_chanattn_probs_fwd")
+    return pcat, pcat_t
+
+
+def chanattn_probs_bwd(scores: torch.Tensor, dpc: torch.Tensor, scale: float, eps: float, dtype: torch.dtype):
+    """d(loss)/d(pcat) fp32 (B, C, H*KV) -> (ds (B, H, C, KV), ds_t (B, H, KV, C)) in `dtype` = d(loss)/d(scores)"""
+    B, H, C, KV = scores.shape
+    assert dpc.dtype == torch.float32 and dpc.is_contiguous() and tuple(dpc.shape) == (B, C, H * KV)
+    ds = torch.empty((B, H, C, KV), dtype=dtype, device=scores.device)
+    ds_t = torch.empty((B, H, KV, C), dtype=dtype, device=scores.device)
+    with _Timed("chanattn_probs_bwd", 0.0, 24.0 * scores.numel()):
+        L.check(L.load().uz_chanattn_probs_bwd(L.dtype_code(dtype), scores.data_ptr(), dpc.data_ptr(), B, H, C, KV, scale, eps,
+                                               ds.data_ptr(), ds_t.data_ptr(), L.stream_ptr()), "uz_chanattn_probs_bwd")
+    return ds, ds_t
 
 
 def softmax_fwd(s: torch.Tensor, axis: int, scale: float) -> None:
