@@ -1,0 +1,61 @@
+"""TEST INFRASTRUCTURE.  ctypes loader for oracle/libuz_ref.so: the plain-C restatement (`<entry>_ref`, oracle/uz_ref.c) of
+the kernel library's entry points, same signatures, host pointers.  Only tests/ may import this module."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+# entries restated in uz_ref.c (each compiled against the header's own declaration: UZ_SAME_SIGNATURE)
+REF_NAMES = (
+    "uz_pack_weights", "uz_conv_igemm_grid_m", "uz_conv_igemm", "uz_wgrad", "uz_bn_finalize", "uz_bn_eval_scale", "uz_bn_relu_apply",
+    "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply", "uz_outconv_fwd", "uz_gemm_nt", "uz_wgrad_batched_workspace_bytes",
+    "uz_wgrad_batched", "uz_softmax_workspace_bytes", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd",
+    "uz_adaptive_avgpool_bwd", "uz_add_map", "uz_rowdot_f32", "uz_cast_rows", "uz_chanattn_probs_fwd", "uz_chanattn_probs_bwd",
+)
+
+
+def build() -> str:
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return os.path.join(_HERE, "libuz_ref.so")
+
+
+def load():
+    """the library, with the argument types of the product's own bindings (unet_zoo_amd/_lib.py) on every `_ref`"""
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libuz_ref.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "uz_ref.c")):
+            path = build()
+        lib = ctypes.CDLL(path)
+        from unet_zoo_amd import _lib as L
+        prod = L.load()
+        for name in REF_NAMES:
+            fn, pf = getattr(lib, name + "_ref"), getattr(prod, name)
+            fn.argtypes, fn.restype = pf.argtypes, pf.restype
+        _lib = lib
+    return _lib
+
+
+def host(t: torch.Tensor) -> np.ndarray:
+    """a CPU torch tensor as the numpy array whose memory a `_ref` reads / writes (bf16 as uint16 bit patterns)"""
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16).copy()
+    return t.numpy().copy()
+
+
+def tensor(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
+    if dtype == torch.bfloat16:
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+    return torch.from_numpy(a.copy())
+
+
+def ptr(a) -> int:
+    return None if a is None else a.ctypes.data

@@ -1,0 +1,574 @@
+/* TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the arithmetic of libunetzoo_hip.so's entry points, one `<name>_ref` per entry with the SAME
+ * signature, compiled from the same header (include/unetzoo_hip.h; SURVEY.md 8b, last sentence).  Host pointers instead of
+ * device pointers, `stream` and `workspace` ignored, sums in double precision, results rounded once to the tensor's type
+ * (fp32, or bf16 round-to-nearest-even).  Every function cites the reference line whose operator it restates; the CPU
+ * tests (tests/test_c_ref.py) pin each of them against the torch operator the reference calls, the GPU tests
+ * (tests/test_c_ref_gpu.py) hold the kernels against them on the same bytes.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's library
+ * (oracle/libuz_ref.so, built by oracle/Makefile); the product never does.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/unetzoo_hip.h"
+
+/* a `_ref` must have exactly the signature the header declares for the entry it restates */
+#define UZ_SAME_SIGNATURE(name) static __typeof__(name)* const uz_sigcheck_##name __attribute__((unused)) = name##_ref
+
+/* ---- element types ------------------------------------------------------------------------------------------------ */
+static inline float bf16_to_f32(uint16_t v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint16_t f32_to_bf16(float f) { /* round to nearest even; NaN stays NaN */
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline double ld(int dtype, const void* p, long long i) {
+  return dtype == UZ_BF16 ? (double)bf16_to_f32(((const uint16_t*)p)[i]) : (double)((const float*)p)[i];
+}
+/* store v rounded to the tensor type; returns the stored value */
+static inline double st(int dtype, void* p, long long i, double v) {
+  if (dtype == UZ_BF16) {
+    const uint16_t b = f32_to_bf16((float)v);
+    ((uint16_t*)p)[i] = b;
+    return (double)bf16_to_f32(b);
+  }
+  ((float*)p)[i] = (float)v;
+  return (double)(float)v;
+}
+
+/* ---- tap geometry (include/unetzoo_hip.h: UZ_TAPS_*) --------------------------------------------------------------- */
+/* input pixel index (within image n's grid of the operand) read by output pixel (h, w) for tap t, or -1 (zero) */
+static long long tap_pixel(int mode, int ntaps, int dil, int t, int n, int h, int w, int H, int W, int Hin, int Win) {
+  if (mode == UZ_TAPS_CONV) {
+    if (ntaps == 1) return ((long long)n * H + h) * W + w;
+    const int hh = h + (t / 3 - 1) * dil, ww = w + (t % 3 - 1) * dil;
+    if (hh < 0 || hh >= H || ww < 0 || ww >= W) return -1;
+    return ((long long)n * H + hh) * W + ww;
+  }
+  if (mode == UZ_TAPS_CONV_UP2) { /* 3x3 on the nearest x2 upsampling of an (H/2, W/2) tensor, common_layers.py:69-72 */
+    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+    if (hh < 0 || hh >= H || ww < 0 || ww >= W) return -1;
+    return ((long long)n * (H / 2) + (hh >> 1)) * (W / 2) + (ww >> 1);
+  }
+  if (mode == UZ_TAPS_GATHER2X2) { /* ConvTranspose2d k2 s2 input gradient, common_layers.py:104 */
+    const int hh = 2 * h + (t >> 1), ww = 2 * w + (t & 1);
+    if (hh >= Hin || ww >= Win) return -1;
+    return ((long long)n * Hin + hh) * Win + ww;
+  }
+  /* UZ_TAPS_CONV_S2: Conv2d(k3, stride 2, padding 1), common_layers.py:188 */
+  const int hh = 2 * h + t / 3 - 1, ww = 2 * w + t % 3 - 1;
+  if (hh < 0 || hh >= Hin || ww < 0 || ww >= Win) return -1;
+  return ((long long)n * Hin + hh) * Win + ww;
+}
+
+/* ---- uz_pack_weights: fp32 master parameters -> kernel layout -------------------------------------------------------- */
+int uz_pack_weights_ref(int dtype, int mode, const float* w, int Co, int Ci, int T, int Kpad, void* dst, void* stream) {
+  (void)stream;
+  for (int co = 0; co < Co; ++co)
+    for (int ci = 0; ci < Ci; ++ci)
+      for (int t = 0; t < T; ++t) {
+        if (mode == UZ_PACK_CONV_FWD) st(dtype, dst, (long long)co * T * Ci + (long long)t * Ci + ci, w[((long long)co * Ci + ci) * T + t]);
+        else if (mode == UZ_PACK_CONV_DGRAD) st(dtype, dst, (long long)ci * T * Co + (long long)(T - 1 - t) * Co + co, w[((long long)co * Ci + ci) * T + t]);
+        else if (mode == UZ_PACK_CONVT_FWD) st(dtype, dst, ((long long)t * Co + co) * Ci + ci, w[((long long)ci * Co + co) * T + t]);
+        else if (mode == UZ_PACK_CONVT_DGRAD) st(dtype, dst, (long long)ci * T * Co + (long long)t * Co + co, w[((long long)ci * Co + co) * T + t]);
+        else st(dtype, dst, (long long)co * Kpad + (long long)t * Ci + ci, w[((long long)co * Ci + ci) * T + t]);
+      }
+  if (mode == UZ_PACK_IM2COL)
+    for (int co = 0; co < Co; ++co)
+      for (int k = T * Ci; k < Kpad; ++k) st(dtype, dst, (long long)co * Kpad + k, 0.0);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_pack_weights);
+
+/* ---- uz_conv_igemm: nn.Conv2d k3 / k1 (common_layers.py:28,31,47,52,71; u2net.py:10), their input gradients,
+ *      nn.ConvTranspose2d k2 s2 forward (pixel-shuffle store) and input gradient (gather taps) (common_layers.py:104).
+ *      One statistics row (uz_conv_igemm_grid_m_ref() == 1): sum and sum of squares of the STORED values. ------------ */
+int uz_conv_igemm_grid_m_ref(const uz_conv_desc* d) {
+  (void)d;
+  return 1;
+}
+UZ_SAME_SIGNATURE(uz_conv_igemm_grid_m);
+
+int uz_conv_igemm_ref(const uz_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
+                      void* stream) {
+  (void)stream;
+  const int K = d->ntaps * d->Cin;
+  const int Hout = d->Hout ? d->Hout : 2 * d->H, Wout = d->Wout ? d->Wout : 2 * d->W;
+  double* s1 = stats ? (double*)calloc(2 * (size_t)d->Nout, sizeof(double)) : NULL;
+  for (int n = 0; n < d->N; ++n)
+    for (int h = 0; h < d->H; ++h)
+      for (int wq = 0; wq < d->W; ++wq) {
+        const long long p = ((long long)n * d->H + h) * d->W + wq;
+        for (int no = 0; no < d->Nout; ++no) {
+          double acc = 0.0;
+          for (int t = 0; t < d->ntaps; ++t) {
+            const long long q = tap_pixel(d->taps_mode, d->ntaps, d->dil, t, n, h, wq, d->H, d->W, d->Hin, d->Win);
+            if (q < 0) continue;
+            for (int c = 0; c < d->Cin; ++c)
+              acc += ld(d->dtype, x, q * d->ldx + c) * ld(d->dtype, w, (long long)no * K + (long long)t * d->Cin + c);
+          }
+          if (bias) acc += bias[no];
+          long long o;
+          if (d->store_mode == UZ_STORE_PLAIN) {
+            o = p * d->ldy + no;
+          } else { /* n = (2a + b) * Co + co -> pixel (2h + a, 2w + b), channel co */
+            const int ab = no / d->Co, co = no % d->Co;
+            o = (((long long)n * Hout + 2 * h + (ab >> 1)) * Wout + 2 * wq + (ab & 1)) * d->ldy + co;
+          }
+          const double v = st(d->dtype, y, o, acc);
+          if (s1) {
+            s1[no] += v;
+            s1[d->Nout + no] += v * v;
+          }
+        }
+      }
+  if (s1) {
+    for (int i = 0; i < 2 * d->Nout; ++i) stats[i] = (float)s1[i];
+    free(s1);
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_conv_igemm);
+
+/* ---- uz_wgrad: the weight gradients autograd produces for those layers (training_loop.py:119) ---------------------- */
+int uz_wgrad_ref(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream) {
+  (void)workspace;
+  (void)stream;
+  const long long n_out = (long long)d->Ci * d->Cj * d->ntaps;
+  double* acc = (double*)calloc((size_t)n_out, sizeof(double));
+  for (int n = 0; n < d->N; ++n)
+    for (int h = 0; h < d->H; ++h)
+      for (int w = 0; w < d->W; ++w) {
+        const long long p = ((long long)n * d->H + h) * d->W + w;
+        for (int t = 0; t < d->ntaps; ++t) {
+          const long long q = tap_pixel(d->taps_mode, d->ntaps, d->dil, t, n, h, w, d->H, d->W, d->Hr, d->Wr);
+          if (q < 0) continue;
+          for (int i = 0; i < d->Ci; ++i) {
+            const double l = ld(d->dtype, L, p * d->ldl + i);
+            if (l == 0.0) continue;
+            for (int j = 0; j < d->Cj; ++j) acc[((long long)i * d->Cj + j) * d->ntaps + t] += l * ld(d->dtype, R, q * d->ldr + j);
+          }
+        }
+      }
+  for (long long i = 0; i < n_out; ++i) out[i] = (float)acc[i];
+  free(acc);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_wgrad);
+
+/* ---- nn.BatchNorm2d (train) + nn.ReLU + nn.MaxPool2d(2) (common_layers.py:29-33, :90) ------------------------------- */
+int uz_bn_finalize_ref(const float* stats_partial, int grid_m, int C, double count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                       float* mean, float* invstd, void* stream) {
+  (void)stream;
+  for (int c = 0; c < C; ++c) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = 0; g < grid_m; ++g) {
+      s1 += stats_partial[((long long)g * 2 + 0) * C + c];
+      s2 += stats_partial[((long long)g * 2 + 1) * C + c];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const double sc = (gamma ? gamma[c] : 1.0) * is;
+    if (scale) scale[c] = (float)sc;
+    if (shift) shift[c] = (float)((beta ? beta[c] : 0.0) - m * sc);
+    if (mean) mean[c] = (float)m;
+    if (invstd) invstd[c] = (float)is;
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * count / (count - 1.0));
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_bn_finalize);
+
+int uz_bn_eval_scale_ref(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                         float eps, float* scale, float* shift, void* stream) {
+  (void)stream;
+  for (int c = 0; c < C; ++c) {
+    const double sc = (gamma ? gamma[c] : 1.0) / sqrt((double)running_var[c] + (double)eps);
+    scale[c] = (float)sc;
+    shift[c] = (float)((beta ? beta[c] : 0.0) - running_mean[c] * sc);
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_bn_eval_scale);
+
+int uz_bn_relu_apply_ref(int dtype, const void* y, int ldy, const float* scale, const float* shift, int N, int H, int W, int C,
+                         void* act, int lda, void* pooled, int ldp, void* stream) {
+  (void)stream;
+  for (long long p = 0; p < (long long)N * H * W; ++p)
+    for (int c = 0; c < C; ++c) {
+      const double v = (double)(float)((float)ld(dtype, y, p * ldy + c) * scale[c] + shift[c]);   /* one fp32 fma-free evaluation */
+      st(dtype, act, p * lda + c, v > 0.0 ? v : 0.0);
+    }
+  if (pooled) {
+    const int Hp = H / 2, Wp = W / 2;
+    for (int n = 0; n < N; ++n)
+      for (int h = 0; h < Hp; ++h)
+        for (int w = 0; w < Wp; ++w)
+          for (int c = 0; c < C; ++c) {
+            double m = -INFINITY;
+            for (int a = 0; a < 2; ++a)
+              for (int b = 0; b < 2; ++b) {
+                const double v = ld(dtype, act, (((long long)n * H + 2 * h + a) * W + 2 * w + b) * lda + c);
+                if (v > m) m = v;
+              }
+            st(dtype, pooled, (((long long)n * Hp + h) * Wp + w) * ldp + c, m);
+          }
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_bn_relu_apply);
+
+/* gradient arriving at activation pixel (n, h, w), channel c: g0 + g1 + (first maximum of its 2x2 window ? gpool : 0) */
+static double bn_bwd_g(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift, const void* g0, const void* g1,
+                       const void* gpool, int n, int h, int w, int c) {
+  const long long p = ((long long)n * d->H + h) * d->W + w;
+  double g = 0.0;
+  if (g0) g += ld(d->dtype, g0, p * d->ldg0 + c);
+  if (g1) g += ld(d->dtype, g1, p * d->ldg1 + c);
+  if (gpool) {
+    const int ceil_mode = d->pool_ceil & 1, relu = !(d->pool_ceil & 2);
+    const int Hp = ceil_mode ? (d->H + 1) / 2 : d->H / 2, Wp = ceil_mode ? (d->W + 1) / 2 : d->W / 2;
+    const int ph = h / 2, pw = w / 2;
+    if (ph < Hp && pw < Wp) {
+      /* first maximum of the window in raster order, on the activation as it was stored */
+      double best = -INFINITY;
+      int bh = -1, bw = -1;
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+          const int hh = 2 * ph + a, ww = 2 * pw + b;
+          if (hh >= d->H || ww >= d->W) continue;
+          const long long q = ((long long)n * d->H + hh) * d->W + ww;
+          float v = (float)ld(d->dtype, y, q * d->ldy + c) * scale[c] + shift[c];
+          if (relu && v < 0.f) v = 0.f;
+          const double vs = d->dtype == UZ_BF16 ? (double)bf16_to_f32(f32_to_bf16(v)) : (double)v;
+          if (vs > best) {
+            best = vs;
+            bh = hh;
+            bw = ww;
+          }
+        }
+      if (bh == h && bw == w) g += ld(d->dtype, gpool, (((long long)n * Hp + ph) * Wp + pw) * d->ldgp + c);
+    }
+  }
+  return g;
+}
+
+int uz_bn_relu_bwd_reduce_ref(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift, const float* mean,
+                              const float* invstd, const void* g0, const void* g1, const void* gpool, void* workspace, double* sums,
+                              float* dgamma, float* dbeta, void* stream) {
+  (void)workspace;
+  (void)stream;
+  const int relu = !(d->pool_ceil & 2);
+  for (int c = 0; c < d->C; ++c) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int n = 0; n < d->N; ++n)
+      for (int h = 0; h < d->H; ++h)
+        for (int w = 0; w < d->W; ++w) {
+          const long long p = ((long long)n * d->H + h) * d->W + w;
+          const float yv = (float)ld(d->dtype, y, p * d->ldy + c);
+          if (relu && !(yv * scale[c] + shift[c] > 0.f)) continue;
+          const double g = bn_bwd_g(d, y, scale, shift, g0, g1, gpool, n, h, w, c);
+          s0 += g;
+          s1 += g * ((double)yv - mean[c]) * invstd[c];
+        }
+    sums[c] = s0;
+    sums[d->C + c] = s1;
+    if (dbeta) dbeta[c] = (float)s0;
+    if (dgamma) dgamma[c] = (float)s1;
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_bn_relu_bwd_reduce);
+
+int uz_bn_relu_bwd_apply_ref(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, const void* g0, const void* g1, const void* gpool, const double* sums, double count,
+                             void* dy, void* stream) {
+  (void)stream;
+  const int relu = !(d->pool_ceil & 2);
+  for (int n = 0; n < d->N; ++n)
+    for (int h = 0; h < d->H; ++h)
+      for (int w = 0; w < d->W; ++w)
+        for (int c = 0; c < d->C; ++c) {
+          const long long p = ((long long)n * d->H + h) * d->W + w;
+          const float yv = (float)ld(d->dtype, y, p * d->ldy + c);
+          const int on = !relu || (yv * scale[c] + shift[c] > 0.f);
+          const double g = on ? bn_bwd_g(d, y, scale, shift, g0, g1, gpool, n, h, w, c) : 0.0;
+          const double xhat = ((double)yv - mean[c]) * invstd[c];
+          st(d->dtype, dy, p * d->lddy + c, scale[c] * (g - sums[c] / count - xhat * sums[d->C + c] / count));
+        }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_bn_relu_bwd_apply);
+
+/* ---- OutConv (common_layers.py:118-128) ---------------------------------------------------------------------------- */
+int uz_outconv_fwd_ref(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w, const float* b, int Kout,
+                       float* out_nchw, void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < Kout; ++k)
+      for (int q = 0; q < HW; ++q) {
+        double acc = b ? b[k] : 0.0;
+        for (int c = 0; c < C; ++c) acc += ld(dtype, x, ((long long)n * HW + q) * ldx + c) * w[(long long)k * C + c];
+        out_nchw[((long long)n * Kout + k) * HW + q] = (float)acc;
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_outconv_fwd);
+
+/* ---- dense token attention (unet_transformer.py:126-137, :200-213; transatt_unet.py:41-49, :91-107) ------------------ */
+int uz_gemm_nt_ref(const uz_gemm_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y, void* stream) {
+  (void)stream;
+  for (int b = 0; b < d->batch; ++b)
+    for (int m = 0; m < d->M; ++m)
+      for (int n = 0; n < d->N; ++n) {
+        double acc = 0.0;
+        for (int k = 0; k < d->K; ++k)
+          acc += ld(d->dtype, x, b * d->xb + (long long)m * d->ldx + k) * ld(d->dtype, w, b * d->wb + (long long)n * d->ldw + k);
+        if (bias) acc += bias[n];
+        const long long o = b * d->yb + (long long)m * d->ldy + n;
+        if (res) { /* the product is rounded to the tensor type before the residual is added (uz_conv_igemm_res) */
+          const double v = st(d->dtype, y, o, acc);
+          st(d->dtype, y, o, v + ld(d->dtype, res, b * d->resb + (long long)m * d->ldres + n));
+        } else {
+          st(d->dtype, y, o, acc);
+        }
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_gemm_nt);
+
+long long uz_wgrad_batched_workspace_bytes_ref(const uz_wgrad_desc* d, int batch) {
+  (void)d;
+  (void)batch;
+  return 0;
+}
+UZ_SAME_SIGNATURE(uz_wgrad_batched_workspace_bytes);
+
+int uz_wgrad_batched_ref(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb, float* out,
+                         long long ob, void* workspace, void* stream) {
+  const int es = d->dtype == UZ_BF16 ? 2 : 4;
+  for (int b = 0; b < batch; ++b)
+    uz_wgrad_ref(d, (const char*)L + b * lb * es, (const char*)R + b * rb * es, out + b * ob, workspace, stream);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_wgrad_batched);
+
+long long uz_softmax_workspace_bytes_ref(int batch, int rows, int cols, int axis) {
+  (void)batch;
+  (void)rows;
+  (void)cols;
+  (void)axis;
+  return 0;
+}
+UZ_SAME_SIGNATURE(uz_softmax_workspace_bytes);
+
+/* nn.Softmax(dim=1) of a (b, rows, cols) tensor = axis 0 (unet_transformer.py:123); nn.Softmax(dim=-1) = axis 1 */
+int uz_softmax_fwd_ref(int dtype, void* s, int ldm, long long sb, int batch, int rows, int cols, int axis, float scale,
+                       void* workspace, void* stream) {
+  (void)workspace;
+  (void)stream;
+  const int outer = axis == 0 ? cols : rows, inner = axis == 0 ? rows : cols;
+  for (int b = 0; b < batch; ++b)
+    for (int o = 0; o < outer; ++o) {
+#define UZ_AT(i) (b * sb + (axis == 0 ? (long long)(i) * ldm + o : (long long)o * ldm + (i)))
+      double mx = -INFINITY, z = 0.0;
+      for (int i = 0; i < inner; ++i) {
+        const double v = ld(dtype, s, UZ_AT(i)) * scale;
+        if (v > mx) mx = v;
+      }
+      for (int i = 0; i < inner; ++i) z += exp(ld(dtype, s, UZ_AT(i)) * scale - mx);
+      for (int i = 0; i < inner; ++i) st(dtype, s, UZ_AT(i), exp(ld(dtype, s, UZ_AT(i)) * scale - mx) / z);
+    }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_softmax_fwd);
+
+int uz_softmax_bwd_ref(int dtype, const void* a, void* g, int ldm, long long sb, int batch, int rows, int cols, int axis, float scale,
+                       float* dot, int dot_given, void* stream) {
+  (void)stream;
+  const int outer = axis == 0 ? cols : rows, inner = axis == 0 ? rows : cols;
+  for (int b = 0; b < batch; ++b)
+    for (int o = 0; o < outer; ++o) {
+      double dsum = 0.0;
+      if (axis == 0 && dot_given) {
+        dsum = dot[(long long)b * cols + o];
+      } else {
+        for (int i = 0; i < inner; ++i) dsum += ld(dtype, a, UZ_AT(i)) * ld(dtype, g, UZ_AT(i));
+        if (axis == 0 && dot) dot[(long long)b * cols + o] = (float)dsum;
+      }
+      for (int i = 0; i < inner; ++i) st(dtype, g, UZ_AT(i), ld(dtype, a, UZ_AT(i)) * (ld(dtype, g, UZ_AT(i)) - dsum) * scale);
+#undef UZ_AT
+    }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_softmax_bwd);
+
+/* F.adaptive_avg_pool2d (unet_transformer.py:196-198): window of output i = [floor(i In / Out), ceil((i + 1) In / Out)) */
+int uz_adaptive_avgpool_fwd_ref(int dtype, const void* x, int ldx, int N, int Hi, int Wi, int C, void* y, int ldy, int Ho, int Wo,
+                                void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (int oh = 0; oh < Ho; ++oh)
+      for (int ow = 0; ow < Wo; ++ow) {
+        const int h0 = (int)((long long)oh * Hi / Ho), h1 = (int)(((long long)(oh + 1) * Hi + Ho - 1) / Ho);
+        const int w0 = (int)((long long)ow * Wi / Wo), w1 = (int)(((long long)(ow + 1) * Wi + Wo - 1) / Wo);
+        for (int c = 0; c < C; ++c) {
+          double acc = 0.0;
+          for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) acc += ld(dtype, x, (((long long)n * Hi + h) * Wi + w) * ldx + c);
+          st(dtype, y, (((long long)n * Ho + oh) * Wo + ow) * ldy + c, acc / ((h1 - h0) * (w1 - w0)));
+        }
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_adaptive_avgpool_fwd);
+
+int uz_adaptive_avgpool_bwd_ref(int dtype, const void* g, int ldg, int N, int Hi, int Wi, int C, void* dx, int lddx, int Ho, int Wo,
+                                int accumulate, void* stream) {
+  (void)stream;
+  double* acc = (double*)calloc((size_t)N * Hi * Wi * C, sizeof(double));
+  for (int n = 0; n < N; ++n)
+    for (int oh = 0; oh < Ho; ++oh)
+      for (int ow = 0; ow < Wo; ++ow) {
+        const int h0 = (int)((long long)oh * Hi / Ho), h1 = (int)(((long long)(oh + 1) * Hi + Ho - 1) / Ho);
+        const int w0 = (int)((long long)ow * Wi / Wo), w1 = (int)(((long long)(ow + 1) * Wi + Wo - 1) / Wo);
+        for (int c = 0; c < C; ++c) {
+          const double v = ld(dtype, g, (((long long)n * Ho + oh) * Wo + ow) * ldg + c) / ((h1 - h0) * (w1 - w0));
+          for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) acc[(((long long)n * Hi + h) * Wi + w) * C + c] += v;
+        }
+      }
+  for (long long p = 0; p < (long long)N * Hi * Wi; ++p)
+    for (int c = 0; c < C; ++c) st(dtype, dx, p * lddx + c, acc[p * C + c] + (accumulate ? ld(dtype, dx, p * lddx + c) : 0.0));
+  free(acc);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_adaptive_avgpool_bwd);
+
+int uz_add_map_ref(int dtype, const void* x, int ldx, const float* map, void* out, int ldo, long long P, int HW, int C, void* stream) {
+  (void)stream;
+  for (long long p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) st(dtype, out, p * ldo + c, (double)((float)ld(dtype, x, p * ldx + c) + map[(p % HW) * C + c]));
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_add_map);
+
+int uz_rowdot_f32_ref(int dtype, const float* a, int lda, const void* b, int ldb, long long rows, int C, float* out, void* stream) {
+  (void)stream;
+  for (long long r = 0; r < rows; ++r) {
+    double t = 0.0;
+    for (int c = 0; c < C; ++c) t += (double)a[r * lda + c] * ld(dtype, b, r * ldb + c);
+    out[r] = (float)t;
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_rowdot_f32);
+
+int uz_cast_rows_ref(int dtype, const float* src, int lds, void* dst, int ldd, long long rows, int C, int accumulate, void* stream) {
+  (void)stream;
+  for (long long r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c)
+      st(dtype, dst, r * ldd + c, (double)(accumulate ? (float)ld(dtype, dst, r * ldd + c) + src[r * lds + c] : src[r * lds + c]));
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_cast_rows);
+
+/* ---- UCTransNet: softmax(InstanceNorm2d(scores / sqrt(KV))) per (image, head) plane (uctransnet.py:170-178) ---------- */
+static void chan_plane(const float* pl, int C, int KV, float scale, float eps, double* sh, double* P) {
+  const int n = C * KV;
+  double mean = 0.0, var = 0.0;
+  for (int i = 0; i < n; ++i) mean += (double)pl[i] * scale;
+  mean /= n;
+  for (int i = 0; i < n; ++i) {
+    const double dlt = (double)pl[i] * scale - mean;
+    var += dlt * dlt;
+  }
+  const double rstd = 1.0 / sqrt(var / n + (double)eps);
+  for (int c = 0; c < C; ++c) {
+    double mx = -INFINITY, z = 0.0;
+    for (int k = 0; k < KV; ++k) {
+      sh[c * KV + k] = ((double)pl[c * KV + k] * scale - mean) * rstd;
+      if (sh[c * KV + k] > mx) mx = sh[c * KV + k];
+    }
+    for (int k = 0; k < KV; ++k) z += exp(sh[c * KV + k] - mx);
+    for (int k = 0; k < KV; ++k) P[c * KV + k] = exp(sh[c * KV + k] - mx) / z;
+  }
+  sh[n] = rstd; /* one extra slot: the plane's 1 / sigma */
+}
+
+int uz_chanattn_probs_fwd_ref(int dtype, const float* scores, int B, int H, int C, int KV, float scale, float eps, void* pcat,
+                              void* pcat_t, void* stream) {
+  (void)stream;
+  double* sh = (double*)malloc(((size_t)C * KV + 1) * sizeof(double));
+  double* P = (double*)malloc((size_t)C * KV * sizeof(double));
+  const long long HK = (long long)H * KV;
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < H; ++h) {
+      chan_plane(scores + ((long long)b * H + h) * C * KV, C, KV, scale, eps, sh, P);
+      for (int c = 0; c < C; ++c)
+        for (int k = 0; k < KV; ++k) {
+          st(dtype, pcat, ((long long)b * C + c) * HK + (long long)h * KV + k, P[c * KV + k] / H);
+          st(dtype, pcat_t, ((long long)b * HK + (long long)h * KV + k) * C + c, P[c * KV + k] / H);
+        }
+    }
+  free(sh);
+  free(P);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_chanattn_probs_fwd);
+
+int uz_chanattn_probs_bwd_ref(int dtype, const float* scores, const float* dpc, int B, int H, int C, int KV, float scale, float eps,
+                              void* ds, void* ds_t, void* stream) {
+  (void)stream;
+  const int n = C * KV;
+  double* sh = (double*)malloc(((size_t)n + 1) * sizeof(double));
+  double* P = (double*)malloc((size_t)n * sizeof(double));
+  double* dsh = (double*)malloc((size_t)n * sizeof(double));
+  const long long HK = (long long)H * KV;
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < H; ++h) {
+      chan_plane(scores + ((long long)b * H + h) * n, C, KV, scale, eps, sh, P);
+      const double rstd = sh[n];
+      double m1 = 0.0, m2 = 0.0;
+      for (int c = 0; c < C; ++c) {
+        double dot = 0.0;
+        for (int k = 0; k < KV; ++k) dot += P[c * KV + k] * (double)dpc[((long long)b * C + c) * HK + (long long)h * KV + k] / H;
+        for (int k = 0; k < KV; ++k) {
+          dsh[c * KV + k] = P[c * KV + k] * ((double)dpc[((long long)b * C + c) * HK + (long long)h * KV + k] / H - dot);
+          m1 += dsh[c * KV + k];
+          m2 += dsh[c * KV + k] * sh[c * KV + k];
+        }
+      }
+      m1 /= n;
+      m2 /= n;
+      for (int c = 0; c < C; ++c)
+        for (int k = 0; k < KV; ++k) {
+          const double v = rstd * (dsh[c * KV + k] - m1 - sh[c * KV + k] * m2) * scale;
+          st(dtype, ds, (((long long)b * H + h) * C + c) * KV + k, v);
+          st(dtype, ds_t, (((long long)b * H + h) * KV + k) * C + c, v);
+        }
+    }
+  free(sh);
+  free(P);
+  free(dsh);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_chanattn_probs_bwd);
+
+int uz_ref_abi_version(void) { return 1; }

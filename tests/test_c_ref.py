@@ -1,0 +1,271 @@
+"""CPU: the plain-C restatement of the kernel library (oracle/uz_ref.c, one `<entry>_ref` per entry, same signature,
+compiled from the same header) against the torch operators the reference calls -- this pins the restatement; the GPU tests
+(tests/test_c_ref_gpu.py) then hold the kernels against it on the same bytes."""
+import ctypes
+import math
+from ctypes import byref
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import c_ref
+from unet_zoo_amd import _lib as L
+
+DTS = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, dt, g, scale=1.0):
+    return (scale * torch.randn(*shape, generator=g)).to(dt)
+
+
+def nhwc(t):          # (N, C, H, W) -> (N*H*W, C) rows
+    N, C, H, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(N * H * W, C).contiguous()
+
+
+def nchw(rows, N, H, W):
+    return rows.reshape(N, H, W, -1).permute(0, 3, 1, 2)
+
+
+def close(got, ref, dt, what="", f32_tol=1e-6):
+    got, ref = got.double(), ref.double()
+    tol = f32_tol if dt == torch.float32 else 2.0 ** -8          # one rounding to the tensor type
+    err = ((got - ref).abs() / (ref.abs() + 1e-3 * ref.abs().max() + 1e-30)).max().item()
+    assert err <= tol, (what, err)
+
+
+def pack(w, mode, dt, kpad=0):
+    lib = c_ref.load()
+    d0, d1 = w.shape[0], w.shape[1]
+    T = w.numel() // (d0 * d1)
+    co, ci = (d0, d1) if mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD, L.PACK_IM2COL) else (d1, d0)
+    n = {L.PACK_CONV_FWD: co * T * ci, L.PACK_CONV_DGRAD: ci * T * co, L.PACK_CONVT_FWD: T * co * ci, L.PACK_CONVT_DGRAD: ci * T * co}.get(mode, co * kpad)
+    dst = np.zeros(n, dtype=np.uint16 if dt == torch.bfloat16 else np.float32)
+    src = c_ref.host(w.float())
+    assert lib.uz_pack_weights_ref(L.dtype_code(dt), mode, c_ref.ptr(src), co, ci, T, kpad, c_ref.ptr(dst), None) == 0
+    return dst
+
+
+def conv_ref(dt, x_rows, w_packed, bias, N, H, W, Hin, Win, Cin, Nout, ntaps, mode=L.TAPS_CONV, dil=1, store=L.STORE_PLAIN, co=0,
+             out_pixels=None, ldy=None, want_stats=False):
+    lib = c_ref.load()
+    ldy = ldy or (co if store == L.STORE_SHUFFLE2X2 else Nout)
+    P = out_pixels if out_pixels is not None else N * H * W
+    y = np.zeros(P * ldy, dtype=np.uint16 if dt == torch.bfloat16 else np.float32)
+    d = L.ConvDesc(L.dtype_code(dt), N, H, W, Hin, Win, Cin, Cin, Nout, ldy, ntaps, mode, dil, store, co, 0, 0)
+    stats = np.zeros(2 * Nout, dtype=np.float32) if want_stats else None
+    xh = c_ref.host(x_rows)
+    b = c_ref.host(bias.float()) if bias is not None else None
+    assert lib.uz_conv_igemm_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(w_packed), c_ref.ptr(b), c_ref.ptr(y), c_ref.ptr(stats), None) == 0
+    return c_ref.tensor(y, dt).reshape(P, ldy), stats
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("dil", [1, 2])
+def test_conv3x3_and_its_statistics(dt, dil):
+    """nn.Conv2d(k3, padding=dilation) (common_layers.py:28; u2net.py:10) + the sums BatchNorm needs of the stored output"""
+    g = torch.Generator().manual_seed(1)
+    N, Ci, Co, H, W = 2, 8, 16, 7, 9
+    x, w, b = rnd((N, Ci, H, W), dt, g), rnd((Co, Ci, 3, 3), dt, g, 0.3), torch.randn(Co, generator=g)
+    y, stats = conv_ref(dt, nhwc(x), pack(w, L.PACK_CONV_FWD, dt), b, N, H, W, H, W, Ci, Co, 9, dil=dil, want_stats=True)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+    close(nchw(y, N, H, W), ref, dt, "conv")
+    yd = y.double()
+    np.testing.assert_allclose(stats[:Co], yd.sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(stats[Co:], (yd * yd).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv1x1_upsampled_and_strided_convolutions(dt):
+    g = torch.Generator().manual_seed(2)
+    N, Ci, Co = 2, 8, 8
+    x = rnd((N, Ci, 6, 10), dt, g)
+    w1 = rnd((Co, Ci, 1, 1), dt, g)
+    y, _ = conv_ref(dt, nhwc(x), pack(w1, L.PACK_CONV_FWD, dt), None, N, 6, 10, 6, 10, Ci, Co, 1)
+    close(nchw(y, N, 6, 10), F.conv2d(x.double(), w1.double()), dt, "1x1")
+    # nn.Upsample(scale_factor=2) + Conv2d k3 (common_layers.py:69-72): the input lives at half resolution
+    w3 = rnd((Co, Ci, 3, 3), dt, g, 0.3)
+    y, _ = conv_ref(dt, nhwc(x), pack(w3, L.PACK_CONV_FWD, dt), None, N, 12, 20, 6, 10, Ci, Co, 9, mode=L.TAPS_CONV_UP2)
+    close(nchw(y, N, 12, 20), F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w3.double(), padding=1), dt, "up2")
+    # Conv2d(k3, stride 2, padding 1) (common_layers.py:188), odd input size
+    xo = rnd((N, Ci, 7, 9), dt, g)
+    y, _ = conv_ref(dt, nhwc(xo), pack(w3, L.PACK_CONV_FWD, dt), None, N, 4, 5, 7, 9, Ci, Co, 9, mode=L.TAPS_CONV_S2)
+    close(nchw(y, N, 4, 5), F.conv2d(xo.double(), w3.double(), stride=2, padding=1), dt, "stride 2")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_transpose_forward_and_input_gradient(dt):
+    """nn.ConvTranspose2d(k2, s2) (common_layers.py:104): pixel-shuffle store forward, 2x2 gather for the input gradient"""
+    g = torch.Generator().manual_seed(3)
+    N, Ci, Co, H, W = 2, 8, 8, 5, 6
+    x = rnd((N, Ci, H, W), dt, g)
+    w = rnd((Ci, Co, 2, 2), dt, g, 0.5)
+    b = torch.randn(Co, generator=g)
+    y, _ = conv_ref(dt, nhwc(x), pack(w, L.PACK_CONVT_FWD, dt), b.repeat(4), N, H, W, H, W, Ci, 4 * Co, 1, store=L.STORE_SHUFFLE2X2, co=Co,
+                    out_pixels=N * 2 * H * 2 * W)
+    close(nchw(y, N, 2 * H, 2 * W), F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2), dt, "convT fwd")
+    gy = rnd((N, Co, 2 * H, 2 * W), dt, g)
+    xr = x.double().requires_grad_(True)
+    F.conv_transpose2d(xr, w.double(), stride=2).backward(gy.double())
+    dx, _ = conv_ref(dt, nhwc(gy), pack(w, L.PACK_CONVT_DGRAD, dt), None, N, H, W, 2 * H, 2 * W, Co, Ci, 4, mode=L.TAPS_GATHER2X2)
+    close(nchw(dx, N, H, W), xr.grad, dt, "convT dgrad")
+    # and the 3x3 input gradient: the same entry with the flipped-tap packing
+    w3 = rnd((Co, Ci, 3, 3), dt, g, 0.3)
+    x3 = rnd((N, Ci, H, W), dt, g).double().requires_grad_(True)
+    g3 = rnd((N, Co, H, W), dt, g)
+    F.conv2d(x3, w3.double(), padding=1).backward(g3.double())
+    dx3, _ = conv_ref(dt, nhwc(g3), pack(w3, L.PACK_CONV_DGRAD, dt), None, N, H, W, H, W, Co, Ci, 9)
+    close(nchw(dx3, N, H, W), x3.grad, dt, "conv dgrad")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_weight_gradients(dt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(4)
+    N, Ci, Co, H, W = 2, 8, 16, 6, 7
+    x, gy = rnd((N, Ci, H, W), dt, g), rnd((N, Co, H, W), dt, g)
+    for dil in (1, 2):
+        wr = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), wr, padding=dil, dilation=dil).backward(gy.double())
+        out = np.zeros(Co * Ci * 9, dtype=np.float32)
+        d = L.WgradDesc(L.dtype_code(dt), N, H, W, H, W, Co, Co, Ci, Ci, 9, L.TAPS_CONV, dil)
+        Lh, Rh = c_ref.host(nhwc(gy)), c_ref.host(nhwc(x))
+        assert lib.uz_wgrad_ref(byref(d), c_ref.ptr(Lh), c_ref.ptr(Rh), c_ref.ptr(out), None, None) == 0
+        np.testing.assert_allclose(out.reshape(Co, Ci, 3, 3), wr.grad.numpy(), rtol=1e-5, atol=1e-5)
+    # ConvTranspose2d k2 s2: L = x, R = dy on the doubled grid -> (Cin, Cout, 2, 2)
+    gt = rnd((N, Co, 2 * H, 2 * W), dt, g)
+    wt = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(x.double(), wt, stride=2).backward(gt.double())
+    out = np.zeros(Ci * Co * 4, dtype=np.float32)
+    d = L.WgradDesc(L.dtype_code(dt), N, H, W, 2 * H, 2 * W, Ci, Ci, Co, Co, 4, L.TAPS_GATHER2X2, 1)
+    Lh, Rh = c_ref.host(nhwc(x)), c_ref.host(nhwc(gt))
+    assert lib.uz_wgrad_ref(byref(d), c_ref.ptr(Lh), c_ref.ptr(Rh), c_ref.ptr(out), None, None) == 0
+    np.testing.assert_allclose(out.reshape(Ci, Co, 2, 2), wt.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_batchnorm_relu_pool_forward_and_backward(dt):
+    """nn.BatchNorm2d (train) -> nn.ReLU -> nn.MaxPool2d(2) (common_layers.py:29-33, :90) and autograd's backward of it with a
+    gradient on the activation and one on the pooled tensor"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 2, 8, 6, 8
+    y = rnd((N, C, H, W), dt, g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rows = nhwc(y)
+    yd = rows.double()
+    stats = np.concatenate([yd.sum(0).numpy(), (yd * yd).sum(0).numpy()]).astype(np.float32)
+    rm, rv = np.zeros(C, np.float32), np.ones(C, np.float32)
+    scale, shift, mean, invstd = (np.zeros(C, np.float32) for _ in range(4))
+    cnt = float(N * H * W)
+    gm, bt = c_ref.host(gamma), c_ref.host(beta)
+    assert lib.uz_bn_finalize_ref(c_ref.ptr(stats), 1, C, cnt, c_ref.ptr(gm), c_ref.ptr(bt), 1e-5, 0.1, c_ref.ptr(rm), c_ref.ptr(rv),
+                                  c_ref.ptr(scale), c_ref.ptr(shift), c_ref.ptr(mean), c_ref.ptr(invstd), None) == 0
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    yr = y.double().requires_grad_(True)
+    act_ref = F.relu(bn(yr))
+    pool_ref = F.max_pool2d(act_ref, 2)
+    np.testing.assert_allclose(rm, bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv, bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    act, pooled = np.zeros(N * H * W * C, npdt), np.zeros(N * (H // 2) * (W // 2) * C, npdt)
+    yh = c_ref.host(rows)
+    assert lib.uz_bn_relu_apply_ref(L.dtype_code(dt), c_ref.ptr(yh), C, c_ref.ptr(scale), c_ref.ptr(shift), N, H, W, C, c_ref.ptr(act), C,
+                                    c_ref.ptr(pooled), C, None) == 0
+    # scale * y + shift is evaluated in fp32 from fp32 scale / shift vectors, as the kernels do: cancellation costs a few ulp
+    close(nchw(c_ref.tensor(act, dt).reshape(-1, C), N, H, W), act_ref.detach(), dt, "act", f32_tol=2e-5)
+    close(nchw(c_ref.tensor(pooled, dt).reshape(-1, C), N, H // 2, W // 2), pool_ref.detach(), dt, "pooled", f32_tol=2e-5)
+    if dt == torch.bfloat16:
+        return   # the backward comparison needs the masks of the rounded activation; fp32 pins the formulas
+    g0, gp = rnd((N, C, H, W), dt, g), rnd((N, C, H // 2, W // 2), dt, g)
+    (act_ref * g0.double()).sum().backward(retain_graph=True)
+    (pool_ref * gp.double()).sum().backward()
+    d = L.BnBwdDesc(L.dtype_code(dt), N, H, W, C, C, C, 0, C, C, 0)
+    sums = np.zeros(2 * C, np.float64)
+    dgam, dbet = np.zeros(C, np.float32), np.zeros(C, np.float32)
+    g0h, gph = c_ref.host(nhwc(g0)), c_ref.host(nhwc(gp))
+    args = (byref(d), c_ref.ptr(yh), c_ref.ptr(scale), c_ref.ptr(shift), c_ref.ptr(mean), c_ref.ptr(invstd), c_ref.ptr(g0h), None, c_ref.ptr(gph))
+    assert lib.uz_bn_relu_bwd_reduce_ref(*args, None, c_ref.ptr(sums), c_ref.ptr(dgam), c_ref.ptr(dbet), None) == 0
+    np.testing.assert_allclose(dgam, bn.weight.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dbet, bn.bias.grad.numpy(), rtol=1e-4, atol=1e-5)
+    dy = np.zeros(N * H * W * C, np.float32)
+    assert lib.uz_bn_relu_bwd_apply_ref(*args, c_ref.ptr(sums), cnt, c_ref.ptr(dy), None) == 0
+    close(nchw(torch.from_numpy(dy).reshape(-1, C), N, H, W), yr.grad, dt, "dy", f32_tol=2e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_batched_products_softmax_and_adaptive_pool(dt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(6)
+    B, M, N, K = 3, 10, 16, 24
+    x, w, res = rnd((B, M, K), dt, g), rnd((B, N, K), dt, g), rnd((B, M, N), dt, g)
+    bias = torch.randn(N, generator=g)
+    y = np.zeros(B * M * N, np.uint16 if dt == torch.bfloat16 else np.float32)
+    d = L.GemmDesc(L.dtype_code(dt), B, M, N, K, K, K, N, N, M * K, N * K, M * N, M * N)
+    xh, wh, rh, bh = c_ref.host(x), c_ref.host(w), c_ref.host(res), c_ref.host(bias)
+    assert lib.uz_gemm_nt_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(wh), c_ref.ptr(bh), c_ref.ptr(rh), c_ref.ptr(y), None) == 0
+    prod = torch.matmul(x.double(), w.double().transpose(1, 2)) + bias.double()
+    close(c_ref.tensor(y, dt).reshape(B, M, N), prod.to(dt).double() + res.double(), dt, "gemm_nt")
+    for axis in (0, 1):
+        s = rnd((B, 12, 16), dt, g, 2.0)
+        sh = c_ref.host(s)
+        assert lib.uz_softmax_fwd_ref(L.dtype_code(dt), c_ref.ptr(sh), 16, 12 * 16, B, 12, 16, axis, 0.5, None, None) == 0
+        a = c_ref.tensor(sh, dt).reshape(B, 12, 16)
+        close(a, torch.softmax(s.double() * 0.5, dim=1 + axis), dt, "softmax")
+        da = rnd((B, 12, 16), dt, g)
+        dh = c_ref.host(da)
+        dot = np.zeros(B * 16, np.float32)
+        assert lib.uz_softmax_bwd_ref(L.dtype_code(dt), c_ref.ptr(sh), c_ref.ptr(dh), 16, 12 * 16, B, 12, 16, axis, 0.5, c_ref.ptr(dot), 0, None) == 0
+        ad = a.double()
+        close(c_ref.tensor(dh, dt).reshape(B, 12, 16), ad * (da.double() - (ad * da.double()).sum(1 + axis, keepdim=True)) * 0.5, dt, "softmax bwd")
+    xa = rnd((2, 8, 7, 9), dt, g)
+    for (Ho, Wo) in ((3, 4), (14, 18)):
+        xr = xa.double().requires_grad_(True)
+        ref = F.adaptive_avg_pool2d(xr, (Ho, Wo))
+        yo = np.zeros(2 * Ho * Wo * 8, np.uint16 if dt == torch.bfloat16 else np.float32)
+        xh = c_ref.host(nhwc(xa))
+        assert lib.uz_adaptive_avgpool_fwd_ref(L.dtype_code(dt), c_ref.ptr(xh), 8, 2, 7, 9, 8, c_ref.ptr(yo), 8, Ho, Wo, None) == 0
+        close(nchw(c_ref.tensor(yo, dt).reshape(-1, 8), 2, Ho, Wo), ref.detach(), dt, "adaptive pool")
+        gy = rnd(tuple(ref.shape), dt, g)
+        ref.backward(gy.double())
+        dx = np.zeros(2 * 7 * 9 * 8, np.uint16 if dt == torch.bfloat16 else np.float32)
+        gh = c_ref.host(nhwc(gy))
+        assert lib.uz_adaptive_avgpool_bwd_ref(L.dtype_code(dt), c_ref.ptr(gh), 8, 2, 7, 9, 8, c_ref.ptr(dx), 8, Ho, Wo, 0, None) == 0
+        close(nchw(c_ref.tensor(dx, dt).reshape(-1, 8), 2, 7, 9), xr.grad, dt, "adaptive pool bwd")
+
+
+def test_channel_attention_probabilities_and_their_gradient():
+    """softmax(InstanceNorm2d(scores / sqrt(KV))) per (image, head) plane (uctransnet.py:170-178), P / heads laid out
+    (C, heads * KV), against autograd"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(7)
+    B, H, C, KV = 2, 4, 8, 24
+    scores = torch.randn(B, H, C, KV, generator=g)
+    scale = 1.0 / math.sqrt(KV)
+    sr = scores.double().requires_grad_(True)
+    P = torch.softmax(F.instance_norm(sr * scale), dim=3) / H
+    pcat_ref = P.permute(0, 2, 1, 3).reshape(B, C, H * KV)
+    pc, pct = np.zeros(B * C * H * KV, np.float32), np.zeros(B * C * H * KV, np.float32)
+    sh = c_ref.host(scores)
+    assert lib.uz_chanattn_probs_fwd_ref(0, c_ref.ptr(sh), B, H, C, KV, scale, 1e-5, c_ref.ptr(pc), c_ref.ptr(pct), None) == 0
+    np.testing.assert_allclose(pc.reshape(B, C, H * KV), pcat_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pct.reshape(B, H * KV, C), pcat_ref.detach().transpose(1, 2).numpy(), rtol=1e-5, atol=1e-7)
+    dpc = torch.randn(B, C, H * KV, generator=g)
+    pcat_ref.backward(dpc.double())
+    ds, dst = np.zeros(B * H * C * KV, np.float32), np.zeros(B * H * C * KV, np.float32)
+    dh = c_ref.host(dpc)
+    assert lib.uz_chanattn_probs_bwd_ref(0, c_ref.ptr(sh), c_ref.ptr(dh), B, H, C, KV, scale, 1e-5, c_ref.ptr(ds), c_ref.ptr(dst), None) == 0
+    np.testing.assert_allclose(ds.reshape(B, H, C, KV), sr.grad.numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(dst.reshape(B, H, KV, C), sr.grad.transpose(2, 3).numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_every_restated_entry_exists_with_the_products_signature():
+    lib, prod = c_ref.load(), L.load()
+    for name in c_ref.REF_NAMES:
+        assert hasattr(lib, name + "_ref") and hasattr(prod, name)
+    assert lib.uz_ref_abi_version() == prod.uz_abi_version()

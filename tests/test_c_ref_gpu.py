@@ -1,0 +1,179 @@
+"""GPU: the kernels of libunetzoo_hip.so against their plain-C restatement (`<entry>_ref`, oracle/uz_ref.c, pinned on the CPU
+by tests/test_c_ref.py) on the same bytes and the same descriptors.  bf16 results may differ by one rounding of the last
+bit where the kernel's fp32 accumulation order lands on the other side of a tie; fp32 by accumulation order."""
+import math
+from ctypes import byref
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_ref
+from unet_zoo_amd import _lib as L
+from unet_zoo_amd import ops
+from unet_zoo_amd.ops import Act
+
+DEV = "cuda"
+DTS = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, dt, g, scale=1.0):
+    return (scale * torch.randn(*shape, generator=g)).to(dt)
+
+
+def agree(got: torch.Tensor, ref: torch.Tensor, dt, what, f32_tol=1e-4):     # fp32: accumulation order over K <= 1152 terms
+    got, ref = got.detach().cpu().double(), ref.double()
+    den = ref.abs() + 1e-2 * ref.abs().max() + 1e-30
+    err = ((got - ref).abs() / den).max().item()
+    assert err <= (f32_tol if dt == torch.float32 else 2.0 ** -7), (what, err)
+    if dt == torch.bfloat16:      # and nearly all elements are the same bf16 number
+        same = (got == ref).double().mean().item()
+        assert same > 0.97, (what, same)
+
+
+def ref_conv(dt, x_rows, w_packed, bias, desc_args, P_out, ldy, Nout):
+    lib = c_ref.load()
+    y = np.zeros(P_out * ldy, dtype=np.uint16 if dt == torch.bfloat16 else np.float32)
+    d = L.ConvDesc(*desc_args)
+    stats = np.zeros(2 * Nout, dtype=np.float32)
+    xh, wh = c_ref.host(x_rows), c_ref.host(w_packed)
+    bh = c_ref.host(bias) if bias is not None else None
+    assert lib.uz_conv_igemm_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(wh), c_ref.ptr(bh), c_ref.ptr(y), c_ref.ptr(stats), None) == 0
+    return c_ref.tensor(y, dt).reshape(P_out, ldy), stats
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,H,W,Ci,Co,dil", [(2, 32, 32, 64, 64, 1), (1, 16, 32, 128, 128, 1), (2, 16, 16, 64, 64, 2), (1, 9, 11, 32, 40, 1)])
+def test_conv3x3_kernels_against_the_c_restatement(dt, N, H, W, Ci, Co, dil):
+    g = torch.Generator().manual_seed(H + Ci)
+    x = rnd((N * H * W, Ci), dt, g)
+    w = rnd((Co, Ci, 3, 3), torch.float32, g, 0.1)
+    bias = torch.randn(Co, generator=g)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt)
+    xa = Act(x.to(DEV), 0, Ci, N, H, W)
+    ya = ops.new_act(N, H, W, Co, dt, DEV)
+    stats = ops.conv_igemm(xa, wp, bias.to(DEV), ya, ntaps=9, dil=dil, want_stats=True)
+    yr, sr = ref_conv(dt, x, wp.cpu(), bias, (L.dtype_code(dt), N, H, W, H, W, Ci, Ci, Co, Co, 9, L.TAPS_CONV, dil, 0, 0, 0, 0), N * H * W, Co, Co)
+    agree(ya.buf, yr, dt, ops.conv_kernel_name(L.ConvDesc(L.dtype_code(dt), N, H, W, H, W, Ci, Ci, Co, Co, 9, L.TAPS_CONV, dil, 0, 0, 0, 0)))
+    # statistics of the kernel's own stored output (bit-level differences of y are excluded that way)
+    yd = ya.buf.double().cpu()
+    s = stats.double().sum(0).cpu()
+    assert torch.allclose(s[0], yd.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(s[1], (yd * yd).sum(0), rtol=1e-4, atol=1e-2)
+    assert np.allclose(sr[:Co], yr.double().sum(0).numpy(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_pointwise_upsampled_and_transposed_convolutions_against_the_c_restatement(dt):
+    g = torch.Generator().manual_seed(12)
+    N, H, W, Ci, Co = 2, 8, 12, 64, 64
+    x = rnd((N * H * W, Ci), dt, g)
+    xa = Act(x.to(DEV), 0, Ci, N, H, W)
+    dc = L.dtype_code(dt)
+    # 1x1
+    w1 = rnd((Co, Ci, 1, 1), torch.float32, g, 0.2)
+    wp = ops.pack_weights(w1.to(DEV), L.PACK_CONV_FWD, dt)
+    ya = ops.new_act(N, H, W, Co, dt, DEV)
+    ops.conv_igemm(xa, wp, None, ya, ntaps=1)
+    yr, _ = ref_conv(dt, x, wp.cpu(), None, (dc, N, H, W, H, W, Ci, Ci, Co, Co, 1, L.TAPS_CONV, 1, 0, 0, 0, 0), N * H * W, Co, Co)
+    agree(ya.buf, yr, dt, "1x1")
+    # 3x3 on the nearest x2 upsampling (common_layers.py:69-72)
+    w3 = rnd((Co, Ci, 3, 3), torch.float32, g, 0.1)
+    wp3 = ops.pack_weights(w3.to(DEV), L.PACK_CONV_FWD, dt)
+    yu = ops.new_act(N, 2 * H, 2 * W, Co, dt, DEV)
+    ops.conv_igemm(xa, wp3, None, yu, ntaps=9, taps_mode=L.TAPS_CONV_UP2)
+    yr, _ = ref_conv(dt, x, wp3.cpu(), None, (dc, N, 2 * H, 2 * W, H, W, Ci, Ci, Co, Co, 9, L.TAPS_CONV_UP2, 1, 0, 0, 0, 0), N * 4 * H * W, Co, Co)
+    agree(yu.buf, yr, dt, "up2")
+    # ConvTranspose2d k2 s2 forward: pixel-shuffle store (common_layers.py:104)
+    wt = rnd((Ci, Co, 2, 2), torch.float32, g, 0.2)
+    wpt = ops.pack_weights(wt.to(DEV), L.PACK_CONVT_FWD, dt)
+    yt = ops.new_act(N, 2 * H, 2 * W, Co, dt, DEV)
+    ops.conv_igemm(xa, wpt, None, yt, ntaps=1, store_mode=L.STORE_SHUFFLE2X2, nout=4 * Co, co=Co)
+    yr, _ = ref_conv(dt, x, wpt.cpu(), None, (dc, N, H, W, H, W, Ci, Ci, 4 * Co, Co, 1, L.TAPS_CONV, 1, L.STORE_SHUFFLE2X2, Co, 0, 0), N * 4 * H * W, Co, 4 * Co)
+    agree(yt.buf, yr, dt, "convT fwd")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_weight_gradient_kernels_against_the_c_restatement(dt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(13)
+    N, H, W, Ci, Co = 2, 16, 16, 64, 128
+    x, gy = rnd((N * H * W, Ci), dt, g), rnd((N * H * W, Co), dt, g)
+    out = ops.wgrad(Act(gy.to(DEV), 0, Co, N, H, W), Act(x.to(DEV), 0, Ci, N, H, W), (Co, Ci, 3, 3), ntaps=9)
+    ref = np.zeros(Co * Ci * 9, np.float32)
+    d = L.WgradDesc(L.dtype_code(dt), N, H, W, H, W, Co, Co, Ci, Ci, 9, L.TAPS_CONV, 1)
+    Lh, Rh = c_ref.host(gy), c_ref.host(x)
+    assert lib.uz_wgrad_ref(byref(d), c_ref.ptr(Lh), c_ref.ptr(Rh), c_ref.ptr(ref), None, None) == 0
+    r = torch.from_numpy(ref).reshape(Co, Ci, 3, 3).double()
+    err = ((out.cpu().double() - r).abs().max() / r.abs().max()).item()
+    assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_batchnorm_relu_pool_kernels_against_the_c_restatement(dt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(14)
+    N, H, W, C = 2, 16, 24, 64
+    y = rnd((N * H * W, C), dt, g)
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    ya = Act(y.to(DEV), 0, C, N, H, W)
+    act, pooled = ops.new_act(N, H, W, C, dt, DEV), ops.new_act(N, H // 2, W // 2, C, dt, DEV)
+    ops.bn_relu_apply(ya, scale.to(DEV), shift.to(DEV), act, pooled)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    a_r, p_r = np.zeros(N * H * W * C, npdt), np.zeros(N * H * W * C // 4, npdt)
+    yh, sc, sh = c_ref.host(y), c_ref.host(scale), c_ref.host(shift)
+    assert lib.uz_bn_relu_apply_ref(L.dtype_code(dt), c_ref.ptr(yh), C, c_ref.ptr(sc), c_ref.ptr(sh), N, H, W, C, c_ref.ptr(a_r), C,
+                                    c_ref.ptr(p_r), C, None) == 0
+    agree(act.buf, c_ref.tensor(a_r, dt).reshape(-1, C), dt, "bn_relu_apply")
+    agree(pooled.buf, c_ref.tensor(p_r, dt).reshape(-1, C), dt, "pooled")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_attention_building_blocks_against_the_c_restatement(dt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(15)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    B, M, N, K = 3, 200, 136, 72
+    x, w, res = rnd((B, M, K), dt, g), rnd((B, N, K), dt, g), rnd((B, M, N), dt, g)
+    bias = torch.randn(N, generator=g)
+    xd, wd, rd = x.to(DEV), w.to(DEV), res.to(DEV)
+    y = torch.empty(B, M, N, dtype=dt, device=DEV)
+    ops.gemm_nt(dt, B, M, N, K, xd.data_ptr(), K, M * K, wd.data_ptr(), K, N * K, y.data_ptr(), N, M * N, bias=bias.to(DEV),
+                res_ptr=rd.data_ptr(), ldres=N, resb=M * N)
+    yr = np.zeros(B * M * N, npdt)
+    d = L.GemmDesc(dc, B, M, N, K, K, K, N, N, M * K, N * K, M * N, M * N)
+    xh, wh, rh, bh = c_ref.host(x), c_ref.host(w), c_ref.host(res), c_ref.host(bias)
+    assert lib.uz_gemm_nt_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(wh), c_ref.ptr(bh), c_ref.ptr(rh), c_ref.ptr(yr), None) == 0
+    agree(y, c_ref.tensor(yr, dt).reshape(B, M, N), dt, "gemm_nt")
+    for axis, (R, C) in ((0, (640, 136)), (1, (77, 256))):
+        s = rnd((B, R, C), dt, g, 2.0)
+        sd = s.clone().to(DEV)
+        ops.softmax_fwd(sd, axis, 0.3)
+        sh = c_ref.host(s)
+        assert lib.uz_softmax_fwd_ref(dc, c_ref.ptr(sh), C, R * C, B, R, C, axis, 0.3, None, None) == 0
+        agree(sd, c_ref.tensor(sh, dt).reshape(B, R, C), dt, f"softmax axis {axis}", f32_tol=1e-5)
+        da = rnd((B, R, C), dt, g)
+        dd = da.clone().to(DEV)
+        ops.softmax_bwd(sd, dd, axis, 0.3)
+        ah, dh = c_ref.host(sd), c_ref.host(da)
+        dot = np.zeros(B * C, np.float32)
+        assert lib.uz_softmax_bwd_ref(dc, c_ref.ptr(ah), c_ref.ptr(dh), C, R * C, B, R, C, axis, 0.3, c_ref.ptr(dot), 0, None) == 0
+        agree(dd, c_ref.tensor(dh, dt).reshape(B, R, C), dt, f"softmax bwd axis {axis}", f32_tol=1e-4)
+    # UCTransNet's score planes
+    Bc, Hh, Cc, KV = 2, 4, 32, 240
+    scores = torch.randn(Bc, Hh, Cc, KV, generator=g)
+    pc, pct = ops.chanattn_probs_fwd(scores.to(DEV), 1.0 / math.sqrt(KV), 1e-5, dt)
+    pr, ptr_ = np.zeros(Bc * Cc * Hh * KV, npdt), np.zeros(Bc * Cc * Hh * KV, npdt)
+    sh = c_ref.host(scores)
+    assert lib.uz_chanattn_probs_fwd_ref(dc, c_ref.ptr(sh), Bc, Hh, Cc, KV, 1.0 / math.sqrt(KV), 1e-5, c_ref.ptr(pr), c_ref.ptr(ptr_), None) == 0
+    agree(pc, c_ref.tensor(pr, dt).reshape(Bc, Cc, Hh * KV), dt, "chanattn probs", f32_tol=1e-4)
+    agree(pct, c_ref.tensor(ptr_, dt).reshape(Bc, Hh * KV, Cc), dt, "chanattn probs^T", f32_tol=1e-4)
+    dpc = torch.randn(Bc, Cc, Hh * KV, generator=g)
+    ds, dst = ops.chanattn_probs_bwd(scores.to(DEV), dpc.to(DEV), 1.0 / math.sqrt(KV), 1e-5, dt)
+    dr, dtr = np.zeros(Bc * Cc * Hh * KV, npdt), np.zeros(Bc * Cc * Hh * KV, npdt)
+    dh = c_ref.host(dpc)
+    assert lib.uz_chanattn_probs_bwd_ref(dc, c_ref.ptr(sh), c_ref.ptr(dh), Bc, Hh, Cc, KV, 1.0 / math.sqrt(KV), 1e-5, c_ref.ptr(dr), c_ref.ptr(dtr), None) == 0
+    agree(ds, c_ref.tensor(dr, dt).reshape(Bc, Hh, Cc, KV), dt, "chanattn dS", f32_tol=2e-4)
+    agree(dst, c_ref.tensor(dtr, dt).reshape(Bc, Hh, KV, Cc), dt, "chanattn dS^T", f32_tol=2e-4)
