@@ -352,7 +352,8 @@ def swin_unet_v2_forward(sd: State, x: torch.Tensor, training: bool, cfg: dict =
     ds = drop_scales or {}
     # PatchEmbed (:548-556): Conv2d(k=s=patch) -> tokens -> LayerNorm
     t = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
-    t = _layer_norm(t, sd, "patch_embed.norm")
+    if "patch_embed.norm.weight" in sd:                       # patch_norm=True (:555-556)
+        t = _layer_norm(t, sd, "patch_embed.norm")
     if "absolute_pos_embed" in sd:                            # ape=True (:713-715); pos_drop: rate 0 here
         t = t + sd["absolute_pos_embed"]
     skips = []

@@ -442,6 +442,31 @@ def test_swin_options_ape_qk_scale_other_head_width_against_oracle():
         assert (named[n].grad.cpu() - ref_grads[n]).abs().max() <= 2e-2 * ref_grads[n].abs().max() + 1e-8, n
 
 
+def test_swin_without_patch_norm_against_oracle():
+    """patch_norm=False (swin_unet_v2.py:555, :619): the patch embedding feeds the first stage and the first skip without a
+    LayerNorm; fp32 against the oracle, and the state dict holds no `patch_embed.norm.*`"""
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, image_size=64, window_size=4, drop_path_rate=0.0,
+                                  patch_norm=False)
+    m.run_dtype = torch.float32
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert not any(k.startswith("patch_embed.norm") for k in sd)
+    m = m.to(DEV).train()
+    x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=6)
+    cfg = torch_ref.swin_config(sd, 64, window_size=4)
+    ref_logits, ref_loss, ref_grads, _ = torch_ref.train_step_reference("swin_unet_v2", sd, x, mask, cfg=cfg)
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, mask.to(DEV))
+    loss.backward()
+    assert (logits.detach().cpu() - ref_logits).abs().max() <= 1e-3 * ref_logits.abs().max()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    named = dict(m.named_parameters())
+    assert {n for n, p in named.items() if p.grad is not None} == set(ref_grads)
+    for n, g in ref_grads.items():
+        want = g.double().norm().item()
+        assert abs(named[n].grad.double().norm().item() - want) <= 2e-2 * want + 1e-6, n
+
+
 def test_swin_dropout_options_train_and_are_off_in_eval():
     """drop_rate (after the embedding and after the attention projection) and attn_drop_rate (inside the window core):
     masks from torch's generator, reproducible under a seed, identity in eval mode, and the step still trains -- also

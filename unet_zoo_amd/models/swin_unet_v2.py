@@ -280,8 +280,8 @@ class PatchEmbed(nn.Module):
         if (H, W) != self.img_size:
             raise AssertionError(f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]}).")
         t = eng.patch_embed(x, self.proj)
-        if self.norm is None:
-            raise NotImplementedError("patch_norm=False is not implemented")
+        if self.norm is None:          # patch_norm=False (swin_unet_v2.py:555: `if self.norm is not None`)
+            return t if out is None else eng.copy_into(t, out)
         return eng.layer_norm(t, self.norm, out=out)
 
 
@@ -293,8 +293,9 @@ class SwinTransformerSys(HipModule):
                  qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False,
                  patch_norm=True, use_checkpoint=False, final_upsample="expand_first", **kwargs):
         super().__init__()
-        if not patch_norm or final_upsample != "expand_first":
-            raise NotImplementedError("only the reference's default patch_norm / final_upsample are implemented")
+        if final_upsample != "expand_first":
+            raise NotImplementedError("only the reference's default final_upsample='expand_first' is implemented (with any "
+                                      "other value the reference builds no head at all, swin_unet_v2.py:688-692)")
         self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
         self.ape, self.patch_norm = ape, patch_norm
         self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
