@@ -321,7 +321,7 @@ def test_unet_sizes_not_divisible_by_16(H, W):
         np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), st[k + ".running_var"].numpy(), rtol=2e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["unet", "resunet"])
+@pytest.mark.parametrize("name", ["unet", "resunet", "attention_unet"])
 def test_backward_through_eval_mode_batchnorm_matches_the_oracle(name):
     """model.eval() + loss.backward() -- fine-tuning with frozen BatchNorm, which the reference's nn.Modules allow
     (running statistics as constants: dy = scale * g * mask, the conv bias receives a gradient): fp32 run mode against

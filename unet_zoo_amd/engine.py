@@ -443,10 +443,7 @@ class Engine:
         ops.attn_gate_fwd(x, q, vec_q, out)
 
         if self.record:
-            if not self.training:
-                raise NotImplementedError("backward through the eval-mode BatchNorms of an attention gate is not "
-                                          "implemented (its fused backward kernels use the batch-statistics form); "
-                                          "conv / stand-alone BatchNorm layers do support model.eval() + backward()")
+            frozen = not self.training     # model.eval() + backward(): BatchNorms on their running statistics
 
             def bwd():
                 dout = self._sum_grads(out, 1)
@@ -456,7 +453,7 @@ class Engine:
                 dz, a01 = ops.attn_bwd_psi(dout[0], x, q, vec_q, dxd)
                 dg1 = self.new_act(N, H, W, Fi)
                 dx1 = self.new_act(N, H, W, Fi)
-                tot = ops.attn_bwd_branches(g1, x1, q, dz, wpsi, vec_g, vec_x, vec_q, a01, dg1, dx1)
+                tot = ops.attn_bwd_branches(g1, x1, q, dz, wpsi, vec_g, vec_x, vec_q, a01, dg1, dx1, frozen=frozen)
                 totf, a01f = tot.float(), a01.float()
                 self._give_grad(bn_q.weight, a01f[1:2])
                 self._give_grad(bn_q.bias, a01f[0:1])
@@ -465,9 +462,17 @@ class Engine:
                 self._give_grad(bn_x.weight, totf[2 * Fi:3 * Fi])
                 self._give_grad(bn_x.bias, totf[0:Fi].clone())
                 self._give_grad(conv_q.weight, totf[3 * Fi:4 * Fi].reshape(conv_q.weight.shape))
-                for c in (conv_q, conv_g, conv_x):
-                    if c.bias is not None:
-                        self._give_grad(c.bias, None)   # a train-mode BatchNorm follows: analytically zero
+                if frozen:     # no batch statistics behind them: the biases receive the column sums of their outputs' gradients
+                    if conv_q.bias is not None:
+                        self._give_grad(conv_q.bias, totf[4 * Fi:4 * Fi + 1].reshape(conv_q.bias.shape))
+                    if conv_g.bias is not None:
+                        self._bias_grad(conv_g.bias, dg1)
+                    if conv_x.bias is not None:
+                        self._bias_grad(conv_x.bias, dx1)
+                else:
+                    for c in (conv_q, conv_g, conv_x):
+                        if c.bias is not None:
+                            self._give_grad(c.bias, None)   # a train-mode BatchNorm follows: analytically zero
                 self._give_grad(conv_g.weight, ops.wgrad(dg1, g, tuple(conv_g.weight.shape), ntaps=1,
                                                          out=self._dst(conv_g.weight)))
                 self._give_grad(conv_x.weight, ops.wgrad(dx1, x, tuple(conv_x.weight.shape), ntaps=1,

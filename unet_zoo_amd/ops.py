@@ -586,21 +586,30 @@ def attn_bwd_psi(dout: Act, x: Act, q: torch.Tensor, vec_q: torch.Tensor, dxd: A
     return dz, sum_rows(part, G, 2)
 
 
-def attn_bwd_branches(g1: Act, x1: Act, q, dz, wpsi, vec_g, vec_x, vec_q, a01, dg1: Act, dx1: Act) -> torch.Tensor:
-    """reduce + apply passes; returns the float64 totals [4F+1] = (B0, B1, D1, dw_psi, sum dq)"""
+def attn_bwd_branches(g1: Act, x1: Act, q, dz, wpsi, vec_g, vec_x, vec_q, a01, dg1: Act, dx1: Act,
+                      frozen: bool = False) -> torch.Tensor:
+    """reduce + apply passes; returns the float64 totals [4F+1] = (B0, B1, D1, dw_psi, sum dq).
+    frozen: the three BatchNorms run on their running statistics (model.eval() + backward()): the batch-statistics terms
+    of their input gradients vanish -- the kernels receive zeros for the sums they would subtract -- while the sums
+    themselves still are the gradients of gamma / beta and are returned unchanged"""
     lib = L.load()
     F_, P = g1.C, g1.P
     G = attn_grid(g1.dtype, P, F_)
     part = torch.empty((G, 4 * F_ + 1), dtype=torch.float32, device=g1.buf.device)
     code = L.dtype_code(g1.dtype)
+    a01_k = torch.zeros_like(a01) if frozen else a01
     common = (code, g1.ptr(), g1.ld, x1.ptr(), x1.ld, q.data_ptr(), dz.data_ptr(), wpsi.data_ptr(),
-              vec_g.data_ptr(), vec_x.data_ptr(), vec_q.data_ptr(), a01.data_ptr())
+              vec_g.data_ptr(), vec_x.data_ptr(), vec_q.data_ptr(), a01_k.data_ptr())
     es = g1.buf.element_size()
     with _Timed("attn_bwd_reduce", 0.0, es * 2.0 * P * F_):
         L.check(lib.uz_attn_bwd_reduce(*common, P, F_, part.data_ptr(), L.stream_ptr()), "uz_attn_bwd_reduce")
     tot = sum_rows(part, G, 4 * F_ + 1)
+    tot_k = tot
+    if frozen:
+        tot_k = tot.clone()
+        tot_k[:3 * F_].zero_()
     with _Timed("attn_bwd_apply", 0.0, es * 4.0 * P * F_):
-        L.check(lib.uz_attn_bwd_apply(*common, tot.data_ptr(), P, F_, dg1.ptr(), dg1.ld, dx1.ptr(), dx1.ld,
+        L.check(lib.uz_attn_bwd_apply(*common, tot_k.data_ptr(), P, F_, dg1.ptr(), dg1.ld, dx1.ptr(), dx1.ld,
                                       L.stream_ptr()), "uz_attn_bwd_apply")
     return tot
 
