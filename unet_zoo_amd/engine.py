@@ -1361,13 +1361,15 @@ class Engine:
             self.tape.append(bwd)
         return out
 
-    def channel_cross_attention(self, Q: Act, K: Act, V: Act, heads: int, eps: float = 1e-5) -> Act:
+    def channel_cross_attention(self, Q: Act, K: Act, V: Act, heads: int, eps: float = 1e-5,
+                                probs_out: Optional[list] = None) -> Act:
         """The channel-wise cross attention of one scale of UCTransNet between its Linear layers
         (Attention_org.forward, uctransnet.py:160-199): Q (tokens, heads * C), K and V (tokens, heads * KV) hold the heads
         side by side; per (image, head) scores = Q_h^T K_h / sqrt(KV) (a product over the TOKENS: the one-tap
         weight-gradient kernel), InstanceNorm2d over the (C, KV) plane, softmax over KV, context = P V_h^T, mean over the
         heads -- the last two as ONE product over K = heads * KV with P / heads laid out (C, heads * KV).  Returns the
-        (tokens, C) context."""
+        (tokens, C) context; `probs_out` (a list) receives `attention_probs.mean(1)` (B, C, KV), detached fp32: the
+        visualisation output of `vis=True` (uctransnet.py:180-185)."""
         B, n, H = Q.N, Q.H * Q.W, heads
         C, KV = Q.C // H, K.C // H
         assert Q.C == H * C and K.C == H * KV and V.C == H * KV and (K.N, K.H * K.W) == (B, n) and (V.N, V.H * V.W) == (B, n)
@@ -1378,6 +1380,8 @@ class Engine:
         for h in range(H):
             ops.wgrad_batched(Q.window(h * C, C), K.window(h * KV, KV), out=scores, out_off=h * C * KV, ob=H * C * KV)
         pcat, pcat_t = ops.chanattn_probs_fwd(scores, scale, eps, dt)
+        if probs_out is not None:
+            probs_out.append(pcat.view(B, C, H, KV).float().sum(2))      # pcat holds P / heads
         ctx = self.new_act(B, Q.H, Q.W, C)
         ops.gemm_nt(dt, B, n, C, H * KV, V.ptr(), V.ld, n * V.ld, pcat.data_ptr(), H * KV, C * H * KV, ctx.ptr(), ctx.ld, n * ctx.ld)
         if not self.record:

@@ -205,6 +205,8 @@ class ChannelTransformer(nn.Module):
         for i in range(4):
             setattr(self, f"embeddings_{i + 1}", Channel_Embeddings(config, patchSize[i], img_size=img_size // (2 ** i),
                                                                     in_channels=channel_num[i]))
+        self.vis = vis
+        self.attn_weights = []
         self.encoder = Encoder(config, vis, channel_num)
         for i in range(4):
             setattr(self, f"reconstruct_{i + 1}", Reconstruct(channel_num[i], channel_num[i], kernel_size=1,
@@ -243,6 +245,7 @@ class ChannelTransformer(nn.Module):
             eng.dropout(eng.add_param_map(t, emb.position_embeddings), emb.dropout.p, out=slots[i])
         for blk in self.encoder.layer:
             att = blk.channel_attn
+            weights = [] if self.vis else None
             H, KV = att.num_attention_heads, att.KV_size
             emb_all = eng.layer_norm(full, blk.attn_norm)
             Kall = eng.linear_heads(emb_all, att.key)
@@ -253,7 +256,7 @@ class ChannelTransformer(nn.Module):
                 emb_i = slots[i]
                 cxn = eng.layer_norm(emb_i, getattr(blk, f"attn_norm{i + 1}"))
                 Qi = eng.linear_heads(cxn, queries)
-                ctx = eng.channel_cross_attention(Qi, Kall, Vall, H, eps=att.psi.eps)
+                ctx = eng.channel_cross_attention(Qi, Kall, Vall, H, eps=att.psi.eps, probs_out=weights)
                 cx = eng.linear(ctx, proj, residual=emb_i)                          # emb + out_i(context)
                 mlp = getattr(blk, f"ffn{i + 1}")
                 f = eng.layer_norm(cx, getattr(blk, f"ffn_norm{i + 1}"))
@@ -263,6 +266,8 @@ class ChannelTransformer(nn.Module):
                 else:
                     eng.linear(f, mlp.fc2, out=nslots[i], residual=cx)
             full, slots = nfull, nslots
+            if self.vis:
+                self.attn_weights.append(weights)
         return [eng.layer_norm(slots[i], getattr(self.encoder, f"encoder_norm{i + 1}")) for i in range(4)]
 
     def emit(self, eng: Engine, ens: List[Act], outs: List[Act]) -> List[Act]:
@@ -273,9 +278,13 @@ class ChannelTransformer(nn.Module):
                 raise ValueError(f"UCTransNet was built for img_size {int(math.sqrt(emb.position_embeddings.shape[1])) * self.patch[i] * 2 ** i}"
                                  f" (square); got a {en.H * 2 ** i}x{en.W * 2 ** i} input")
             toks.append(eng.patch_conv(en, emb.patch_embeddings))
+        self.attn_weights = []          # vis=True: [layer][scale] -> (B, C_i, KV), as Encoder.forward collects them (:318-322)
         if self._own_kernels(eng, toks):
             enc = self._emit_tokens(eng, toks)
         else:
+            if self.vis:
+                raise NotImplementedError("vis=True needs the own-kernel path of the channel transformer (no attention "
+                                          "dropout in training, widths that are multiples of 8)")
             pos = [getattr(self, f"embeddings_{i + 1}").position_embeddings for i in range(4)]
             others = [p for n, p in self.encoder.named_parameters()]
             enc = [eng.new_act(t.N, t.H, t.W, t.C) for t in toks]
@@ -352,8 +361,6 @@ class UpBlock_attention(nn.Module):
 class UCTransNet(HipModule):
     def __init__(self, config, in_channels=3, num_classes=1, img_size=224, vis=False, **kwargs):
         super().__init__()
-        if vis:
-            raise NotImplementedError("vis=True (returning the attention maps, uctransnet.py:493-494) is not built")
         self.vis, self.n_channels, self.n_classes, self.img_size = vis, in_channels, num_classes, img_size
         c = config.base_channel
         self.inc = ConvBatchNorm(in_channels, c)
@@ -367,6 +374,10 @@ class UCTransNet(HipModule):
         self.up2 = UpBlock_attention(c * 4, c, nb_Conv=2)
         self.up1 = UpBlock_attention(c * 2, c, nb_Conv=2)
         self.outc = nn.Conv2d(c, num_classes, kernel_size=(1, 1), stride=(1, 1))
+
+    def wrap_outputs(self, outs):
+        """`return logits, att_weights` with vis=True (uctransnet.py:493-496); the weights are detached fp32 tensors"""
+        return (outs[0], self.mtc.attn_weights) if self.vis else outs[0]
 
     def emit(self, eng: Engine, x: torch.Tensor):
         N, _, H, W = x.shape
