@@ -1,1 +1,1 @@
-extern "C" const char* uz_source_hash(void) { return "b6e587b5cdd2cb60df16bc4ece022c8925ebbe32c55982d7e29c2a667cc2c6c5"; }
+extern "C" const char* uz_source_hash(void) { return "6c37d7b7ee6a980381867d2fdcc904f51e84ee1a8a13be322f2f04ba414bdb39"; }

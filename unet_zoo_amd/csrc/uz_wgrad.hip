@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// (Round 3 measured the alternative of deferring these reductions to ONE batched launch per backward range: 23 launches
+// of 5-17 us -> one of 442 us.  Worse: a layer's 40-75 MB of slabs are still in the 256 MB Infinity Cache when its own
+// reduction follows the kernel that wrote them; deferred, all 1.2 GB come back from HBM.  The per-layer launch stays.)
 // out[i][j][tap] = sum_z slab[z][tap][i][j]: thread (x, zg) owns element (i,j) = blockIdx.x*64 + x
 // and the splits z = zg, zg+4, ...; reads are contiguous along j, each thread finally writes its
 // element's ntaps values (ntaps*4 contiguous bytes; a wave writes one contiguous span).
