@@ -664,6 +664,12 @@ int uz_cast_rows(int dtype, const float* src, int lds, void* dst, int ldd, long 
 int uz_add_map(int dtype, const void* x, int ldx, const float* map, void* out, int ldo, long long P, int HW, int C,
                void* stream);
 
+/* nn.Dropout(p) in training mode (uctransnet.py:54, :222-223; swin_unet_v2.py:158, :716): out = x * [u >= p] / (1 - p) with
+ * u the caller's uniform draw (P x C fp32, contiguous; torch.rand: the generator stays torch's, a seed reproduces a run).
+ * The backward is the same call on the gradient with the same u. */
+int uz_dropout(int dtype, const void* x, int ldx, const float* u, float p, void* out, int ldo, long long P, int C,
+               void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Channel-wise cross attention of UCTransNet (Attention_org.forward, unet_zoo/models/uctransnet.py:160-216): the part
  * between the matrix products.  `scores` fp32 (B, H, C, KV) = Q^T K per (image, head) (uz_wgrad_batched); per plane:

@@ -300,3 +300,29 @@ def test_channel_cross_attention_matches_autograd(dt, B, n, H, C, KV):
         got = a.grads[0].buf.view(B, n, -1).cpu().double()
         e = ((got - r.grad).norm() / r.grad.norm()).item()
         assert e < gtol, (name, e)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dropout_kernel_uses_torchs_draw(dt):
+    """Engine.dropout: the mask comes from torch.rand under the current seed (reproducible), kept elements are scaled by
+    1 / (1 - p) in fp32, the gradient gets the same mask"""
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W, p = 2, 24, 6, 10, 0.3
+    x = torch.randn(B, C, H, W, generator=g).to(dt).float()
+    eng = Engine(dt, torch.device(DEV), True, True)
+    xa = act_from_nchw(x.to(DEV), dt)
+    torch.manual_seed(77)
+    out = eng.dropout(xa, p)
+    torch.manual_seed(77)
+    u = torch.rand((B * H * W, C), device=DEV)
+    keep = (u >= p).float().cpu().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    scale = (torch.tensor(1.0) / (torch.tensor(1.0) - torch.tensor(p))).item()      # fp32 1 / (1 - p), as nn.Dropout scales
+    ref = (x * keep * scale).to(dt).float()
+    assert torch.equal(out.dense().cpu(), ref)
+    assert 0.6 < keep.mean() < 0.8
+    dy = torch.randn(B, C, H, W, generator=g).to(dt).float()
+    out.add_grad(act_from_nchw(dy.to(DEV), dt))
+    eng.backward_range(None, len(eng.tape), 0)
+    assert torch.equal(xa.grads[0].dense().cpu(), (dy * keep * scale).to(dt).float())
+    ev = Engine(dt, torch.device(DEV), False, False)
+    assert ev.dropout(xa, p) is xa

@@ -741,3 +741,45 @@ extern "C" int uz_chanattn_probs_bwd(int dtype, const float* scores, const float
              "uz_chanattn_probs_bwd: bad arguments");
   return chanattn_launch<true>(dtype, scores, dpc, B, H, C, KV, scale, eps, ds, ds_t, (hipStream_t)stream);
 }
+
+// ---- nn.Dropout in training mode on a token / pixel map: out = x * [u >= p] / (1 - p), u = the caller's uniform draw ----
+// (the Bernoulli draw stays torch's generator -- `torch.rand` -- so that a seed reproduces a run; mask, scale and the
+// copy were four torch passes per dropout, 48 dropouts per UCTransNet step.)  The same kernel applies the mask to the
+// gradient.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* x, int ldx, const float* u, float p, float scale, T* out, int ldo,
+                                                      long long P, int C, long long chunks) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const long long r = i / cpr;
+    Vec16<T> v = ld16(x + r * ldx + cc * VEC);
+    const float* up = u + r * C + cc * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; e += 4) {
+      const f32x4 u4 = *reinterpret_cast<const f32x4*>(up + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v.v[e + k] = (T)(u4[k] >= p ? tof(v.v[e + k]) * scale : 0.f);
+    }
+    st16(out + r * ldo + cc * VEC, v);
+  }
+}
+}  // namespace
+
+extern "C" int uz_dropout(int dtype, const void* x, int ldx, const float* u, float p, void* out, int ldo, long long P, int C,
+                          void* stream) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && x && u && out && P > 0 && C > 0 && C % vec == 0 && ldx % vec == 0 &&
+                 ldo % vec == 0 && ldx >= C && ldo >= C && p >= 0.f && p < 1.f && ((uintptr_t)u & 15) == 0,
+             "uz_dropout: bad arguments");
+  const long long chunks = P * (C / vec);
+  const dim3 grid(grid_for_chunks(chunks)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = 1.f / (1.f - p);
+  if (dtype == UZ_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, ldx, u, p, scale, (bf16_t*)out, ldo, P, C, chunks);
+  else hipLaunchKernelGGL(dropout_kernel<float>, grid, block, 0, st, (const float*)x, ldx, u, p, scale, (float*)out, ldo, P, C, chunks);
+  UZ_LAUNCH_CHECK("uz_dropout");
+  return UZ_OK;
+}

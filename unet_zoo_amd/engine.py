@@ -1108,19 +1108,17 @@ class Engine:
                 return self.copy_into(x, out)
             return x
         out = out if out is not None else self.new_act(x.N, x.H, x.W, x.C)
-        # a 0/1 mask; the scale 1 / (1 - p) is applied in fp32 (in bf16 1.1111 rounds to 1.1094: every kept activation and
-        # its gradient would come out 0.16 % low against nn.Dropout)
-        keep = (torch.rand((x.P, x.C), device=self.device) >= p).to(torch.float32)
-        scale = 1.0 / (1.0 - p)
-        xv = x.buf[:, x.off:x.off + x.C]
-        out.buf[:, out.off:out.off + x.C].copy_((xv.float() * keep).mul_(scale))
+        # the draw is torch's (one launch); mask, fp32 scale 1 / (1 - p) (in bf16 1.1111 rounds to 1.1094: every kept
+        # activation and its gradient would come out 0.16 % low against nn.Dropout) and store are one kernel
+        u = torch.rand((x.P, x.C), device=self.device)
+        ops.dropout(x, u, p, out)
         if self.record and x.needs_grad:
             def bwd():
                 g = self._total_grad(out)
                 if g is None:
                     return
                 dx = self.new_act(x.N, x.H, x.W, x.C)
-                dx.buf.copy_((g.buf[:, g.off:g.off + g.C].float() * keep).mul_(scale))
+                ops.dropout(g, u, p, dx)
                 x.add_grad(dx)
 
             self.tape.append(bwd)

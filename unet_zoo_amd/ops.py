@@ -1140,3 +1140,11 @@ def add_map(x: Act, map_f32: torch.Tensor, out: Act) -> None:
     with _Timed("add_map", 0.0, 2.0 * x.P * x.C * x.buf.element_size()):
         L.check(L.load().uz_add_map(L.dtype_code(x.dtype), x.ptr(), x.ld, map_f32.data_ptr(), out.ptr(), out.ld, x.P, x.H * x.W,
                                     x.C, L.stream_ptr()), "uz_add_map")
+
+
+def dropout(x: Act, u: torch.Tensor, p: float, out: Act) -> None:
+    """out = x * [u >= p] / (1 - p); u fp32 (P, C) uniform draws (the same call masks the gradient)"""
+    assert u.dtype == torch.float32 and u.is_contiguous() and tuple(u.shape) == (x.P, x.C) and (out.P, out.C) == (x.P, x.C)
+    with _Timed("dropout", 0.0, x.P * x.C * (4.0 + 2 * x.buf.element_size())):
+        L.check(L.load().uz_dropout(L.dtype_code(x.dtype), x.ptr(), x.ld, u.data_ptr(), p, out.ptr(), out.ld, x.P, x.C,
+                                    L.stream_ptr()), "uz_dropout")
