@@ -780,32 +780,45 @@ class Engine:
 
     def linear_heads(self, x: Act, lins: Sequence[nn.Linear]) -> Act:
         """[lin(x) for lin in lins] side by side in one (tokens, len(lins) * out_features) activation: the per-head
-        query / key / value Linear layers of UCTransNet's Attention_org (uctransnet.py:104-116, :140-158).  One activation
-        (not a concat of parts), so the gradients that several consumers leave on it accumulate on the whole tensor --
-        in the consumers' GEMM epilogues -- and the input gradient is one chain of products."""
-        Co, Hn = lins[0].out_features, len(lins)
-        assert all(l.in_features == x.C and l.out_features == Co for l in lins)
+        query / key / value Linear layers of UCTransNet's Attention_org (uctransnet.py:104-116, :140-158).  The heads'
+        weights are stacked (one concat of their packed copies), so forward, input gradient and weight gradient are ONE
+        product each instead of one per head -- on 1024 tokens every launch is latency, not work -- and the activation is
+        one tensor (not a concat of parts), so the gradients several consumers leave on it accumulate in their GEMM
+        epilogues."""
+        Co, Ci, Hn = lins[0].out_features, x.C, len(lins)
+        assert all(l.in_features == Ci and l.out_features == Co for l in lins)
+        has_bias = lins[0].bias is not None
+        assert all((l.bias is not None) == has_bias for l in lins)
+        dt, P = self.dtype, x.P
         y = self.new_act(x.N, x.H, x.W, Hn * Co)
-        for h, lin in enumerate(lins):
-            ops.conv_igemm(x, self._pack(lin.weight, L.PACK_CONV_FWD), lin.bias.detach() if lin.bias is not None else None,
-                           y.window(h * Co, Co), ntaps=1)
+        wst = torch.cat([self._pack(l.weight, L.PACK_CONV_FWD) for l in lins], 0)               # (Hn Co, Ci)
+        bias = torch.cat([l.bias.detach() for l in lins]) if has_bias else None
+        ops.gemm_nt(dt, 1, P, Hn * Co, Ci, x.ptr(), x.ld, 0, wst.data_ptr(), Ci, 0, y.ptr(), y.ld, 0, bias=bias)
         if self.record:
             def bwd():
                 g = self._total_grad(y)
                 if g is None:
                     return
-                prev = x.grads.pop() if (x.needs_grad and x.grads and x.parts is None and x.rparts is None) else None
+                if has_bias:
+                    for h, lin in enumerate(lins):
+                        self._bias_grad(lin.bias, g.window(h * Co, Co))
+                # the heads' gradient destinations are consecutive in a flat gradient buffer (parameters of one ModuleList):
+                # then the stacked product writes all of them in place
+                dsts = [self._dst(l.weight) for l in lins]
+                out = None
+                if all(d is not None and d.is_contiguous() for d in dsts) and \
+                        all(dsts[h].data_ptr() == dsts[0].data_ptr() + 4 * h * Co * Ci for h in range(Hn)):
+                    out = torch.as_strided(dsts[0], (Hn * Co, Ci), (Ci, 1))
+                dW = ops.wgrad(g, x, (Hn * Co, Ci), ntaps=1, out=out)
                 for h, lin in enumerate(lins):
-                    gh = g.window(h * Co, Co)
-                    if lin.bias is not None:
-                        self._bias_grad(lin.bias, gh)
-                    self._give_grad(lin.weight, ops.wgrad(gh, x, tuple(lin.weight.shape), ntaps=1, out=self._dst(lin.weight)))
-                    if x.needs_grad:       # dx = sum_h g_h W_h: each product adds the sum so far in its epilogue
-                        dx = self.new_act(x.N, x.H, x.W, x.C)
-                        ops.conv_igemm(gh, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=1, res=prev)
-                        prev = dx
-                if x.needs_grad:
-                    x.add_grad(prev)
+                    self._give_grad(lin.weight, dW[h * Co:(h + 1) * Co])
+                if x.needs_grad:       # dx = sum_h g_h W_h = g [W_0^T ... W_H^T]^T (+ what x has collected so far)
+                    prev = x.grads.pop() if (x.grads and x.parts is None and x.rparts is None) else None
+                    wdg = torch.cat([self._pack(l.weight, L.PACK_CONV_DGRAD) for l in lins], 1)   # (Ci, Hn Co)
+                    dx = self.new_act(x.N, x.H, x.W, Ci)
+                    ops.gemm_nt(dt, 1, P, Ci, Hn * Co, g.ptr(), g.ld, 0, wdg.data_ptr(), Hn * Co, 0, dx.ptr(), dx.ld, 0,
+                                res_ptr=prev.ptr() if prev is not None else None, ldres=prev.ld if prev is not None else 0)
+                    x.add_grad(dx)
 
             self.tape.append(bwd)
         return y
