@@ -670,6 +670,14 @@ int uz_add_map(int dtype, const void* x, int ldx, const float* map, void* out, i
 int uz_dropout(int dtype, const void* x, int ldx, const float* u, float p, void* out, int ldo, long long P, int C,
                void* stream);
 
+/* The gate of UCTransNet's CCA (uctransnet.py:417-427): with s[n][c] = sigmoid(...) > 0 per (image, channel),
+ *   mode 2 (forward):  out = relu(x * s)
+ *   mode 0 (backward): out = g * [x > 0] * x            -- its per-image column sums are d(loss)/d(s)
+ *   mode 1 (backward): out = g * [x > 0] * s + a[n][c]   -- a: the gradient reaching x through the global average behind s
+ * x, g, out: (N * HW, C) activations; s, a: (N, C) fp32. */
+int uz_chanscale_relu(int dtype, int mode, const void* g, int ldg, const void* x, int ldx, const float* s, const float* a,
+                      int N, int HW, int C, void* out, int ldo, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Channel-wise cross attention of UCTransNet (Attention_org.forward, unet_zoo/models/uctransnet.py:160-216): the part
  * between the matrix products.  `scores` fp32 (B, H, C, KV) = Q^T K per (image, head) (uz_wgrad_batched); per plane:

@@ -13,7 +13,12 @@ def short(name):
         if m:
             return "conv3x3_pp<%sx%s,%sx%s,%s>%s" % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(5),
                                                      "_bnred" if m.group(6) == "true" else "")
-    return name.replace("(anonymous namespace)::", "").replace("void ", "")[:64]
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if n.startswith("at::native::"):      # torch glue: keep enough of the functor's name to tell which operation it is
+        import re
+        m = re.search(r"at::native::(\w+)<.*?at::native::(\w+)", n)
+        return ("torch:" + m.group(1) + ":" + m.group(2)) if m else n[:96]
+    return n[:64]
 
 
 def main():

@@ -49,7 +49,7 @@ EXPORTS = (
     "uz_add_relu", "uz_relu_bwd", "uz_pil_resample_h_u8", "uz_pil_resample_v_f32",
     "uz_gemm_nt", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd", "uz_adaptive_avgpool_bwd",
     "uz_rowdot_f32", "uz_cast_rows", "uz_wgrad_batched_workspace_bytes", "uz_wgrad_batched",
-    "uz_softmax_workspace_bytes", "uz_add_map", "uz_dropout", "uz_chanattn_probs_fwd", "uz_chanattn_probs_bwd",
+    "uz_softmax_workspace_bytes", "uz_add_map", "uz_dropout", "uz_chanscale_relu", "uz_chanattn_probs_fwd", "uz_chanattn_probs_bwd",
 )
 
 
@@ -251,6 +251,7 @@ def load():
     lib.uz_chanattn_probs_fwd.argtypes = [ip, vp, ip, ip, ip, ip, c_float, c_float, vp, vp, vp]
     lib.uz_chanattn_probs_bwd.argtypes = [ip, vp, vp, ip, ip, ip, ip, c_float, c_float, vp, vp, vp]
     lib.uz_dropout.argtypes = [ip, vp, ip, vp, c_float, vp, ip, ll, ip, vp]
+    lib.uz_chanscale_relu.argtypes = [ip, ip, vp, ip, vp, ip, vp, vp, ip, ip, ip, vp, ip, vp]
     lib.uz_add_map.argtypes = [ip, vp, ip, vp, vp, ip, ll, ip, ip, vp]
     lib.uz_softmax_bwd.argtypes = [ip, vp, vp, ip, ll, ip, ip, ip, ip, c_float, vp, ip, vp]
     lib.uz_adaptive_avgpool_fwd.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, ip, ip, vp]

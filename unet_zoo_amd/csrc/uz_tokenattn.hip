@@ -783,3 +783,57 @@ extern "C" int uz_dropout(int dtype, const void* x, int ldx, const float* u, flo
   UZ_LAUNCH_CHECK("uz_dropout");
   return UZ_OK;
 }
+
+// ---- CCA gate of UCTransNet (uctransnet.py:417-427): out = relu(x * s[n][c]), s = sigmoid(...) > 0 per (image, channel) --
+// forward: out = relu(x * s).  backward, with m = g * [x > 0] (s > 0, so the ReLU mask is the sign of x):
+//   mode 0: out = m * x          (its per-image column sums are d(loss)/d(s))
+//   mode 1: out = m * s + a[n][c] (a = the gradient that reaches x through the global average behind s)
+namespace {
+template <typename T, int MODE>   // MODE 2: forward
+__global__ __launch_bounds__(256) void chanscale_kernel(const T* g, int ldg, const T* x, int ldx, const float* s, const float* a,
+                                                        T* out, int ldo, int HW, int C, long long chunks) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const int cpr = C / VEC;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    const int cc = (int)(i % cpr);
+    const long long p = i / cpr;
+    const long long n = p / HW;
+    const Vec16<T> xv = ld16(x + p * ldx + cc * VEC);
+    Vec16<T> o;
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.v[e] = (T)fmaxf(tof(xv.v[e]) * s[n * C + cc * VEC + e], 0.f);
+    } else {
+      const Vec16<T> gv = ld16(g + p * ldg + cc * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float xf = tof(xv.v[e]);
+        const float m = xf > 0.f ? tof(gv.v[e]) : 0.f;
+        o.v[e] = (T)(MODE == 0 ? m * xf : m * s[n * C + cc * VEC + e] + a[n * C + cc * VEC + e]);
+      }
+    }
+    st16(out + p * ldo + cc * VEC, o);
+  }
+}
+}  // namespace
+
+extern "C" int uz_chanscale_relu(int dtype, int mode, const void* g, int ldg, const void* x, int ldx, const float* s, const float* a,
+                                 int N, int HW, int C, void* out, int ldo, void* stream) {
+  const int vec = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE((dtype == UZ_F32 || dtype == UZ_BF16) && mode >= 0 && mode <= 2 && x && out && N > 0 && HW > 0 && C > 0 && C % vec == 0 &&
+                 ldx % vec == 0 && ldo % vec == 0 && ldx >= C && ldo >= C && (mode == 0 || s) && (mode != 1 || a) &&
+                 (mode == 2 || (g && ldg % vec == 0 && ldg >= C)),
+             "uz_chanscale_relu: bad arguments");
+  const long long chunks = (long long)N * HW * (C / vec);
+  const dim3 grid(grid_for_chunks(chunks)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define UZ_CS(T, M) hipLaunchKernelGGL((chanscale_kernel<T, M>), grid, block, 0, st, (const T*)g, ldg, (const T*)x, ldx, s, a, (T*)out, ldo, HW, C, chunks)
+  if (dtype == UZ_BF16) {
+    if (mode == 0) UZ_CS(bf16_t, 0); else if (mode == 1) UZ_CS(bf16_t, 1); else UZ_CS(bf16_t, 2);
+  } else {
+    if (mode == 0) UZ_CS(float, 0); else if (mode == 1) UZ_CS(float, 1); else UZ_CS(float, 2);
+  }
+#undef UZ_CS
+  UZ_LAUNCH_CHECK("uz_chanscale_relu");
+  return UZ_OK;
+}

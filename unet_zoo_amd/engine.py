@@ -1549,7 +1549,7 @@ class Engine:
         """CCA.forward (uctransnet.py:417-427): out = relu(x * sigmoid((mlp_x(avgpool(x)) + mlp_g(avgpool(g))) / 2)).
         `g_low` is the decoder tensor BEFORE its nearest x2 upsampling (the global average is the same).  The global
         averages and the gradient of the per-(image, channel) scale are reduced by uz_colsum_batched; the two Linear
-        layers on (N, C) vectors are torch ops; the gating itself is elementwise on the native layout."""
+        layers on (N, C) vectors are torch ops; the gating and its two gradient passes are uz_chanscale_relu."""
         N, C = x.N, x.C
         assert lin_x.in_features == C and lin_x.out_features == C and lin_g.out_features == C and lin_g.in_features == g_low.C
 
@@ -1566,20 +1566,17 @@ class Engine:
         with torch.set_grad_enabled(self.record):
             att = (torch.nn.functional.linear(ax, lin_x.weight, lin_x.bias) + torch.nn.functional.linear(ag, lin_g.weight, lin_g.bias)) / 2.0
             scale = torch.sigmoid(att)                                         # (N, C)
-        xv = x.buf.view(N, x.H * x.W, x.ld)[..., x.off:x.off + C]
-        ov = out.buf.view(N, x.H * x.W, out.ld)[..., out.off:out.off + C]
-        ov.copy_(torch.relu(xv.float() * scale.detach()[:, None, :]))
+        sc = scale.detach().contiguous()
+        ops.chanscale_relu(2, None, x, sc, None, out)
         if self.record:
             def bwd():
                 g = self._total_grad(out)
                 if g is None:
                     return
-                gv = g.buf.view(N, x.H * x.W, g.ld)[..., g.off:g.off + C].float()
-                m = gv * (ov > 0)                                              # gradient behind the ReLU
-                prod = self.new_act(N, x.H, x.W, C)
-                prod.buf.view(N, x.H * x.W, C).copy_(m * xv.float())
-                dscale = torch.empty((N, C), dtype=torch.float32, device=self.device)
                 hw = x.H * x.W
+                prod = self.new_act(N, x.H, x.W, C)
+                ops.chanscale_relu(0, g, x, None, None, prod)                 # g * [x > 0] * x (sigmoid > 0: the ReLU mask is x > 0)
+                dscale = torch.empty((N, C), dtype=torch.float32, device=self.device)
                 ops.colsum_batched([(prod.rows(i * hw, 1, x.H, x.W), dscale[i]) for i in range(N)])
                 params = [lin_x.weight, lin_x.bias, lin_g.weight, lin_g.bias]
                 gr = torch.autograd.grad(scale, [ax, ag] + params, dscale)
@@ -1587,7 +1584,7 @@ class Engine:
                     self._give_grad(p_, gp)
                 if x.needs_grad:
                     dx = self.new_act(N, x.H, x.W, C)
-                    dx.buf.view(N, hw, C).copy_(m * scale.detach()[:, None, :] + gr[0][:, None, :] / float(hw))
+                    ops.chanscale_relu(1, g, x, sc, (gr[0] / float(hw)).contiguous(), dx)
                     x.add_grad(dx)
                 if g_low.needs_grad:
                     dg = self.new_act(g_low.N, g_low.H, g_low.W, g_low.C)

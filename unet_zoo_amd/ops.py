@@ -1148,3 +1148,13 @@ def dropout(x: Act, u: torch.Tensor, p: float, out: Act) -> None:
     with _Timed("dropout", 0.0, x.P * x.C * (4.0 + 2 * x.buf.element_size())):
         L.check(L.load().uz_dropout(L.dtype_code(x.dtype), x.ptr(), x.ld, u.data_ptr(), p, out.ptr(), out.ld, x.P, x.C,
                                     L.stream_ptr()), "uz_dropout")
+
+
+def chanscale_relu(mode: int, g: Optional[Act], x: Act, s: Optional[torch.Tensor], a: Optional[torch.Tensor], out: Act) -> None:
+    """mode 2: out = relu(x * s[n][c]); mode 0: out = g * [x > 0] * x; mode 1: out = g * [x > 0] * s + a[n][c]  (s, a: (N, C) fp32)"""
+    for t in (s, a):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (x.N, x.C))
+    with _Timed("chanscale_relu", 0.0, (2.0 if mode == 2 else 3.0) * x.P * x.C * x.buf.element_size()):
+        L.check(L.load().uz_chanscale_relu(L.dtype_code(x.dtype), mode, g.ptr() if g is not None else None, g.ld if g is not None else 0,
+                                           x.ptr(), x.ld, _p(s), _p(a), x.N, x.H * x.W, x.C, out.ptr(), out.ld, L.stream_ptr()),
+                "uz_chanscale_relu")
