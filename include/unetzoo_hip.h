@@ -184,6 +184,10 @@ int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, v
 long long uz_wgrad_batched_workspace_bytes(const uz_wgrad_desc* d, int batch);
 int uz_wgrad_batched(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb,
                      float* out, long long ob, void* workspace, void* stream);
+/* The same with a second batch level: batch * batch2 problems, problem (b, h) reads L + b * lb + h * lb2, R + b * rb +
+ * h * rb2 and writes out + (b * batch2 + h) * ob (the scores Q_h^T K_h of every (image, head), uctransnet.py:160-168). */
+int uz_wgrad_batched2(const uz_wgrad_desc* d, int batch, int batch2, const void* L, long long lb, long long lb2, const void* R,
+                      long long rb, long long rb2, float* out, long long ob, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight re-packing: fp32 master parameters in the reference layout -> kernel layout in run dtype.
@@ -643,6 +647,10 @@ typedef struct uz_gemm_desc {
   int dtype, batch, M, N, K;
   int ldx, ldw, ldy, ldres;
   long long xb, wb, yb, resb;
+  /* optional second batch level (0 / 1: none): batch * batch2 matrices, matrix (b, h) at + b * xb + h * xb2 ... --
+   * UCTransNet's heads, which sit side by side in the channels of one token map (uctransnet.py:140-158) */
+  int batch2;
+  long long xb2, wb2, yb2, resb2;
 } uz_gemm_desc;
 int uz_gemm_nt(const uz_gemm_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y,
                void* stream);

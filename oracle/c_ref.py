@@ -16,7 +16,7 @@ _lib = None
 REF_NAMES = (
     "uz_pack_weights", "uz_conv_igemm_grid_m", "uz_conv_igemm", "uz_wgrad", "uz_bn_finalize", "uz_bn_eval_scale", "uz_bn_relu_apply",
     "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply", "uz_outconv_fwd", "uz_gemm_nt", "uz_wgrad_batched_workspace_bytes",
-    "uz_wgrad_batched", "uz_softmax_workspace_bytes", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd",
+    "uz_wgrad_batched", "uz_wgrad_batched2", "uz_softmax_workspace_bytes", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd",
     "uz_adaptive_avgpool_bwd", "uz_add_map", "uz_rowdot_f32", "uz_cast_rows", "uz_chanattn_probs_fwd", "uz_chanattn_probs_bwd",
 )
 

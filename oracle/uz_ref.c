@@ -334,21 +334,24 @@ UZ_SAME_SIGNATURE(uz_outconv_fwd);
 /* ---- dense token attention (unet_transformer.py:126-137, :200-213; transatt_unet.py:41-49, :91-107) ------------------ */
 int uz_gemm_nt_ref(const uz_gemm_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y, void* stream) {
   (void)stream;
+  const int nb2 = d->batch2 > 1 ? d->batch2 : 1;
   for (int b = 0; b < d->batch; ++b)
-    for (int m = 0; m < d->M; ++m)
-      for (int n = 0; n < d->N; ++n) {
-        double acc = 0.0;
-        for (int k = 0; k < d->K; ++k)
-          acc += ld(d->dtype, x, b * d->xb + (long long)m * d->ldx + k) * ld(d->dtype, w, b * d->wb + (long long)n * d->ldw + k);
-        if (bias) acc += bias[n];
-        const long long o = b * d->yb + (long long)m * d->ldy + n;
-        if (res) { /* the product is rounded to the tensor type before the residual is added (uz_conv_igemm_res) */
-          const double v = st(d->dtype, y, o, acc);
-          st(d->dtype, y, o, v + ld(d->dtype, res, b * d->resb + (long long)m * d->ldres + n));
-        } else {
-          st(d->dtype, y, o, acc);
+    for (int h = 0; h < nb2; ++h) {
+      const long long xo = b * d->xb + h * d->xb2, wo = b * d->wb + h * d->wb2, yo = b * d->yb + h * d->yb2, ro = b * d->resb + h * d->resb2;
+      for (int m = 0; m < d->M; ++m)
+        for (int n = 0; n < d->N; ++n) {
+          double acc = 0.0;
+          for (int k = 0; k < d->K; ++k) acc += ld(d->dtype, x, xo + (long long)m * d->ldx + k) * ld(d->dtype, w, wo + (long long)n * d->ldw + k);
+          if (bias) acc += bias[n];
+          const long long o = yo + (long long)m * d->ldy + n;
+          if (res) { /* the product is rounded to the tensor type before the residual is added (uz_conv_igemm_res) */
+            const double v = st(d->dtype, y, o, acc);
+            st(d->dtype, y, o, v + ld(d->dtype, res, ro + (long long)m * d->ldres + n));
+          } else {
+            st(d->dtype, y, o, acc);
+          }
         }
-      }
+    }
   return UZ_OK;
 }
 UZ_SAME_SIGNATURE(uz_gemm_nt);
@@ -360,12 +363,20 @@ long long uz_wgrad_batched_workspace_bytes_ref(const uz_wgrad_desc* d, int batch
 }
 UZ_SAME_SIGNATURE(uz_wgrad_batched_workspace_bytes);
 
-int uz_wgrad_batched_ref(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb, float* out,
-                         long long ob, void* workspace, void* stream) {
+int uz_wgrad_batched2_ref(const uz_wgrad_desc* d, int batch, int batch2, const void* L, long long lb, long long lb2, const void* R,
+                          long long rb, long long rb2, float* out, long long ob, void* workspace, void* stream) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   for (int b = 0; b < batch; ++b)
-    uz_wgrad_ref(d, (const char*)L + b * lb * es, (const char*)R + b * rb * es, out + b * ob, workspace, stream);
+    for (int h = 0; h < batch2; ++h)
+      uz_wgrad_ref(d, (const char*)L + (b * lb + h * lb2) * es, (const char*)R + (b * rb + h * rb2) * es,
+                   out + ((long long)b * batch2 + h) * ob, workspace, stream);
   return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_wgrad_batched2);
+
+int uz_wgrad_batched_ref(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb, float* out,
+                         long long ob, void* workspace, void* stream) {
+  return uz_wgrad_batched2_ref(d, batch, 1, L, lb, 0, R, rb, 0, out, ob, workspace, stream);
 }
 UZ_SAME_SIGNATURE(uz_wgrad_batched);
 

@@ -177,3 +177,34 @@ def test_attention_building_blocks_against_the_c_restatement(dt):
     assert lib.uz_chanattn_probs_bwd_ref(dc, c_ref.ptr(sh), c_ref.ptr(dh), Bc, Hh, Cc, KV, 1.0 / math.sqrt(KV), 1e-5, c_ref.ptr(dr), c_ref.ptr(dtr), None) == 0
     agree(ds, c_ref.tensor(dr, dt).reshape(Bc, Hh, Cc, KV), dt, "chanattn dS", f32_tol=2e-4)
     agree(dst, c_ref.tensor(dtr, dt).reshape(Bc, Hh, KV, Cc), dt, "chanattn dS^T", f32_tol=2e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_head_level_batches_against_the_c_restatement(dt):
+    """the second batch level of uz_gemm_nt / uz_wgrad_batched2: UCTransNet's heads side by side in the channels of one
+    token map (uctransnet.py:140-168)"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(21)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    B, n, H, C, KV = 3, 64, 4, 16, 40
+    Q, K = rnd((B * n, H * C), dt, g), rnd((B * n, H * KV), dt, g)
+    scores = ops.wgrad_heads(Act(Q.to(DEV), 0, H * C, B, 8, 8), Act(K.to(DEV), 0, H * KV, B, 8, 8), H)
+    ref = np.zeros(B * H * C * KV, np.float32)
+    d = L.WgradDesc(dc, 1, 1, n, 1, n, C, H * C, KV, H * KV, 1, L.TAPS_CONV, 1)
+    Qh, Kh = c_ref.host(Q), c_ref.host(K)
+    assert lib.uz_wgrad_batched2_ref(byref(d), B, H, c_ref.ptr(Qh), n * H * C, C, c_ref.ptr(Kh), n * H * KV, KV, c_ref.ptr(ref), C * KV,
+                                     None, None) == 0
+    r = torch.from_numpy(ref).reshape(B, H, C, KV).double()
+    assert ((scores.cpu().double() - r).abs().max() / r.abs().max()).item() < 1e-5
+    # dQ_h = K_h dS_h^T: x = K (head h at column h * KV), w = dS (B, H, C, KV), y = dQ (head h at column h * C)
+    ds = rnd((B, H, C, KV), dt, g)
+    dQ = torch.zeros(B * n, H * C, dtype=dt, device=DEV)
+    Kd, dsd = K.to(DEV), ds.to(DEV)
+    ops.gemm_nt(dt, B, n, C, KV, Kd.data_ptr(), H * KV, n * H * KV, dsd.data_ptr(), KV, H * C * KV, dQ.data_ptr(), H * C, n * H * C,
+                batch2=H, xb2=KV, wb2=C * KV, yb2=C)
+    yr = np.zeros(B * n * H * C, npdt)
+    gd = L.GemmDesc(dc, B, n, C, KV, H * KV, KV, H * C, 0, n * H * KV, H * C * KV, n * H * C, 0, H, KV, C * KV, C, 0)
+    dsh = c_ref.host(ds)
+    assert lib.uz_gemm_nt_ref(byref(gd), c_ref.ptr(Kh), c_ref.ptr(dsh), None, None, c_ref.ptr(yr), None) == 0
+    agree(dQ, c_ref.tensor(yr, dt).reshape(B * n, H * C), dt, "gemm_nt heads")

@@ -48,7 +48,7 @@ EXPORTS = (
     "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res",
     "uz_add_relu", "uz_relu_bwd", "uz_pil_resample_h_u8", "uz_pil_resample_v_f32",
     "uz_gemm_nt", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd", "uz_adaptive_avgpool_bwd",
-    "uz_rowdot_f32", "uz_cast_rows", "uz_wgrad_batched_workspace_bytes", "uz_wgrad_batched",
+    "uz_rowdot_f32", "uz_cast_rows", "uz_wgrad_batched_workspace_bytes", "uz_wgrad_batched", "uz_wgrad_batched2",
     "uz_softmax_workspace_bytes", "uz_add_map", "uz_dropout", "uz_chanscale_relu", "uz_chanattn_probs_fwd", "uz_chanattn_probs_bwd",
 )
 
@@ -86,7 +86,8 @@ class SraDesc(Structure):
 
 class GemmDesc(Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "batch", "M", "N", "K", "ldx", "ldw", "ldy", "ldres")] \
-        + [(n, ctypes.c_longlong) for n in ("xb", "wb", "yb", "resb")]
+        + [(n, ctypes.c_longlong) for n in ("xb", "wb", "yb", "resb")] + [("batch2", c_int)] \
+        + [(n, ctypes.c_longlong) for n in ("xb2", "wb2", "yb2", "resb2")]
 
 
 class SumRowsItem(Structure):
@@ -245,6 +246,7 @@ def load():
     lib.uz_pil_resample_v_f32.argtypes = [vp, ip, ip, ip, vp, vp, ip, ip, POINTER(c_float), POINTER(c_float), ip, vp, vp]
     lib.uz_wgrad_batched_workspace_bytes.argtypes = [POINTER(WgradDesc), ip]
     lib.uz_wgrad_batched.argtypes = [POINTER(WgradDesc), ip, vp, ll, vp, ll, vp, ll, vp, vp]
+    lib.uz_wgrad_batched2.argtypes = [POINTER(WgradDesc), ip, ip, vp, ll, ll, vp, ll, ll, vp, ll, vp, vp]
     lib.uz_gemm_nt.argtypes = [POINTER(GemmDesc), vp, vp, vp, vp, vp, vp]
     lib.uz_softmax_workspace_bytes.argtypes = [ip, ip, ip, ip]
     lib.uz_softmax_fwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, c_float, vp, vp]

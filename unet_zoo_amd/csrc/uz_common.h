@@ -143,7 +143,8 @@ struct UzWgrad2Plan {
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch = 1);   // batch > 1: uz_wgrad_batched (one-tap only)
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
                        float* slab, hipStream_t s, int batch = 1, long long lb_bytes = 0, long long rb_bytes = 0,
-                       long long slab_stride = 0);   // floats between the problems' slabs (0: dense)
+                       long long slab_stride = 0,   // floats between the problems' slabs (0: dense)
+                       int batch2 = 1, long long lb2_bytes = 0, long long rb2_bytes = 0);   // batch = ALL problems (outer * inner)
 
 // LDS-DMA pixel-major GEMM (uz_gemm_dma.hip): 1x1 / ConvTranspose fwd + dgrad, dispatched from uz_conv_igemm()
 struct UzGemmPlan {

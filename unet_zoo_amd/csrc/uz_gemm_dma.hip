@@ -36,6 +36,9 @@ struct GArgs {
   // operand); ldw = row stride of w in elements (the convolution paths: K)
   int ldw;
   long long xb, wb, yb, resb;
+  // second batch level (uz_gemm_nt): blockIdx.z = b * nb2 + h; byte strides of the inner index h
+  int nb2;
+  long long xb2, wb2, yb2, resb2;
 };
 
 template <typename T> struct Mma3;
@@ -86,13 +89,14 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * BN;
-  const long long bz = blockIdx.z;
+  const long long bz = (int)blockIdx.z / a.nb2, bh = (int)blockIdx.z - (int)bz * a.nb2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(static_cast<const char*>(a.x)) + bz * a.xb, 0, a.xbytes, 0x00020000);
+      const_cast<char*>(static_cast<const char*>(a.x)) + bz * a.xb + bh * a.xb2, 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(static_cast<const char*>(a.w)) + bz * a.wb, 0, a.wbytes, 0x00020000);
-  T* __restrict__ yg = reinterpret_cast<T*>(static_cast<char*>(a.y) + bz * a.yb);
-  const T* __restrict__ resg = a.res ? reinterpret_cast<const T*>(static_cast<const char*>(a.res) + bz * a.resb) : nullptr;
+      const_cast<char*>(static_cast<const char*>(a.w)) + bz * a.wb + bh * a.wb2, 0, a.wbytes, 0x00020000);
+  T* __restrict__ yg = reinterpret_cast<T*>(static_cast<char*>(a.y) + bz * a.yb + bh * a.yb2);
+  const T* __restrict__ resg =
+      a.res ? reinterpret_cast<const T*>(static_cast<const char*>(a.res) + bz * a.resb + bh * a.resb2) : nullptr;
   const int HW = a.H * a.W;
   const int ncb = (a.Cin + BK - 1) / BK;  // the last slab of a tap may be partial: zero-filled
   const int nsteps = a.ntaps * ncb;
@@ -553,6 +557,8 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x
   a.tiles_m = p.tiles_m;
   a.ldw = a.K;
   a.xb = a.wb = a.yb = a.resb = 0;
+  a.nb2 = 1;
+  a.xb2 = a.wb2 = a.yb2 = a.resb2 = 0;
   return d->dtype == UZ_BF16 ? gemm_launch_t<bf16_t>(p, a, s) : gemm_launch_t<float>(p, a, s);
 }
 
@@ -560,7 +566,11 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x
 static int gemm_nt_plan(const uz_gemm_desc* d, UzGemmPlan* p) {
   const int vec = d->dtype == UZ_BF16 ? 8 : 4, es = d->dtype == UZ_BF16 ? 2 : 4;
   UZ_REQUIRE(d->dtype == UZ_BF16 || d->dtype == UZ_F32, "uz_gemm_nt: dtype");
-  UZ_REQUIRE(d->batch >= 1 && d->batch <= 65535 && d->M >= 1 && d->N >= 1 && d->K >= 1, "uz_gemm_nt: empty problem");
+  UZ_REQUIRE(d->batch >= 1 && d->M >= 1 && d->N >= 1 && d->K >= 1 && d->batch2 >= 0 &&
+                 (long long)d->batch * (d->batch2 > 1 ? d->batch2 : 1) <= 65535,
+             "uz_gemm_nt: empty problem / more than 65535 matrices");
+  UZ_REQUIRE(d->xb2 % vec == 0 && d->wb2 % vec == 0 && d->yb2 % vec == 0 && d->resb2 % vec == 0,
+             "uz_gemm_nt: inner matrix strides must be multiples of 16 bytes");
   UZ_REQUIRE(d->K % vec == 0 && d->N % vec == 0 && d->ldx % vec == 0 && d->ldw % vec == 0 && d->ldy % vec == 0 &&
                  d->ldres % vec == 0,
              "uz_gemm_nt: K, N and the row strides must be multiples of 16 bytes");
@@ -572,7 +582,7 @@ static int gemm_nt_plan(const uz_gemm_desc* d, UzGemmPlan* p) {
   UZ_REQUIRE(xbytes < (1LL << 31) && wbytes < (1LL << 31), "uz_gemm_nt: one matrix must stay below 2 GB");
   p->bn = d->N <= 64 ? 64 : 128;
   p->tiles_n = (d->N + p->bn - 1) / p->bn;
-  const long long per = (long long)p->tiles_n * d->batch;
+  const long long per = (long long)p->tiles_n * d->batch * (d->batch2 > 1 ? d->batch2 : 1);
   p->bm = (p->bn == 128 && (((long long)d->M + 255) / 256) * per * 2 <= UZ_NUM_CU) ? 128 : 256;
   const int nsteps = (d->K + 8 * vec - 1) / (8 * vec);
   p->nst = p->bm == 128 ? 4 : 3;
@@ -631,8 +641,13 @@ extern "C" int uz_gemm_nt(const uz_gemm_desc* d, const void* x, const void* w, c
   a.wb = d->wb * es;
   a.yb = d->yb * es;
   a.resb = d->resb * es;
+  a.nb2 = d->batch2 > 1 ? d->batch2 : 1;
+  a.xb2 = d->xb2 * es;
+  a.wb2 = d->wb2 * es;
+  a.yb2 = d->yb2 * es;
+  a.resb2 = d->resb2 * es;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid(p.grid_m, p.tiles_n, d->batch), block(512);
+  dim3 grid(p.grid_m, p.tiles_n, d->batch * a.nb2), block(512);
   if (d->dtype == UZ_BF16) return gemm_launch_grid<bf16_t>(p, a, grid, s);
   return gemm_launch_grid<float>(p, a, grid, s);
 }

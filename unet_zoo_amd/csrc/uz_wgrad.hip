@@ -424,32 +424,44 @@ extern "C" long long uz_wgrad_batched_workspace_bytes(const uz_wgrad_desc* d, in
   return uz_wgrad_workspace_bytes(d);   // problem by problem through uz_wgrad
 }
 
-extern "C" int uz_wgrad_batched(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb,
-                                float* out, long long ob, void* workspace, void* stream) {
+extern "C" int uz_wgrad_batched2(const uz_wgrad_desc* d, int batch, int batch2, const void* L, long long lb, long long lb2,
+                                 const void* R, long long rb, long long rb2, float* out, long long ob, void* workspace,
+                                 void* stream) {
+  UZ_REQUIRE(batch2 >= 1 && (long long)batch * batch2 <= 65535, "uz_wgrad_batched2: batch2");
+  const int nprob = batch * batch2;
   UzWgrad2Plan p2;
-  const int rc = batched_plan(d, batch, &p2);
+  const int rc = batched_plan(d, nprob, &p2);
   if (rc < 0) return rc;
   UZ_REQUIRE(L && R && out && workspace, "uz_wgrad_batched: null pointer");
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   if (rc == 0) {   // fp32 (parity mode) and shapes outside the LDS-DMA kernel: one uz_wgrad per problem
-    for (int b = 0; b < batch; ++b) {
-      const int r = uz_wgrad(d, static_cast<const char*>(L) + (long long)b * lb * es, static_cast<const char*>(R) + (long long)b * rb * es,
-                             out + (long long)b * ob, workspace, stream);
-      if (r != UZ_OK) return r;
-    }
+    for (int b = 0; b < batch; ++b)
+      for (int h = 0; h < batch2; ++h) {
+        const int r = uz_wgrad(d, static_cast<const char*>(L) + ((long long)b * lb + (long long)h * lb2) * es,
+                               static_cast<const char*>(R) + ((long long)b * rb + (long long)h * rb2) * es,
+                               out + ((long long)b * batch2 + h) * ob, workspace, stream);
+        if (r != UZ_OK) return r;
+      }
     return UZ_OK;
   }
-  UZ_REQUIRE((((uintptr_t)L | (uintptr_t)R) & 15) == 0 && lb % 8 == 0 && rb % 8 == 0, "uz_wgrad_batched: L / R must be 16-byte aligned");
+  UZ_REQUIRE((((uintptr_t)L | (uintptr_t)R) & 15) == 0 && lb % 8 == 0 && rb % 8 == 0 && lb2 % 8 == 0 && rb2 % 8 == 0,
+             "uz_wgrad_batched: L / R must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p2.nslabs == 1) {   // no pixel split: the kernel's slab IS the result (ntaps = 1: same layout)
     UZ_REQUIRE(ob >= (long long)d->Ci * d->Cj, "uz_wgrad_batched: results overlap (ob < Ci * Cj)");
-    return uz_wgrad3x3_launch(d, p2, L, R, out, s, batch, lb * es, rb * es, ob);
+    return uz_wgrad3x3_launch(d, p2, L, R, out, s, nprob, lb * es, rb * es, ob, batch2, lb2 * es, rb2 * es);
   }
-  const int r2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s, batch, lb * es, rb * es);
+  const int r2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s, nprob, lb * es, rb * es, 0, batch2, lb2 * es,
+                                    rb2 * es);
   if (r2 != UZ_OK) return r2;
   const long long cicj = (long long)d->Ci * d->Cj;
-  const dim3 grid((unsigned)((cicj + 63) / 64), batch);
+  const dim3 grid((unsigned)((cicj + 63) / 64), nprob);
   hipLaunchKernelGGL((wgrad_reduce_kernel<1, 4>), grid, dim3(256), 0, s, static_cast<const float*>(workspace), p2.nslabs, cicj, out, (long long)ob);
   UZ_LAUNCH_CHECK("uz_wgrad_batched(reduce)");
   return UZ_OK;
+}
+
+extern "C" int uz_wgrad_batched(const uz_wgrad_desc* d, int batch, const void* L, long long lb, const void* R, long long rb,
+                                float* out, long long ob, void* workspace, void* stream) {
+  return uz_wgrad_batched2(d, batch, 1, L, lb, 0, R, rb, 0, out, ob, workspace, stream);
 }

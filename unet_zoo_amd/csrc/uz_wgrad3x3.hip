@@ -47,6 +47,8 @@ struct Wg2Args {
   // uz_wgrad_batched (one-tap, no gather): blockIdx.y = problem index; byte strides of L / R between problems, float
   // stride of the slabs
   long long lb, rb, sb;
+  int nb2;            // second batch level: problem index = b * nb2 + h, L / R at + b * lb + h * lb2 (slabs: index * sb)
+  long long lb2, rb2;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -138,10 +140,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   const int u_beg = bz * a.upb;
   const int u_end = (u_beg + a.upb < a.units) ? u_beg + a.upb : a.units;
   const int nu = u_end - u_beg;
+  const long long pb1 = (int)pb / a.nb2, pb2 = (int)pb - (int)pb1 * a.nb2;
   const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(static_cast<const char*>(a.L)) + pb * a.lb, 0, a.lbytes, 0x00020000);
+      const_cast<char*>(static_cast<const char*>(a.L)) + pb1 * a.lb + pb2 * a.lb2, 0, a.lbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(static_cast<const char*>(a.R)) + pb * a.rb, 0, a.rbytes, 0x00020000);
+      const_cast<char*>(static_cast<const char*>(a.R)) + pb1 * a.rb + pb2 * a.rb2, 0, a.rbytes, 0x00020000);
 
   const int KW = a.KW, PWR = KW + 2 * HALO;        // R tile row length in pixels
   const int RR = a.KR + ((NTY == 3) ? 2 : 0);      // R tile rows
@@ -520,10 +523,14 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch) {
 }
 
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
-                       float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes, long long slab_stride) {
+                       float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes, long long slab_stride,
+                       int batch2, long long lb2_bytes, long long rb2_bytes) {
   Wg2Args a;
   a.lb = lb_bytes;
   a.rb = rb_bytes;
+  a.nb2 = batch2 > 1 ? batch2 : 1;
+  a.lb2 = lb2_bytes;
+  a.rb2 = rb2_bytes;
   a.sb = slab_stride ? slab_stride : (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
   UZ_REQUIRE(batch == 1 || (p.one_tap && !p.gather && batch <= 65535), "uz_wgrad(3x3): only one-tap problems are batched");
   a.L = L;

@@ -1387,9 +1387,7 @@ class Engine:
         dt, dev = self.dtype, self.device
         es = 2 if dt == torch.bfloat16 else 4
         scale = 1.0 / math.sqrt(KV)
-        scores = torch.empty((B, H, C, KV), dtype=torch.float32, device=dev)
-        for h in range(H):
-            ops.wgrad_batched(Q.window(h * C, C), K.window(h * KV, KV), out=scores, out_off=h * C * KV, ob=H * C * KV)
+        scores = ops.wgrad_heads(Q, K, H)                               # (B, H, C, KV): one launch for all (image, head) pairs
         pcat, pcat_t = ops.chanattn_probs_fwd(scores, scale, eps, dt)
         if probs_out is not None:
             probs_out.append(pcat.view(B, C, H, KV).float().sum(2))      # pcat holds P / heads
@@ -1416,13 +1414,13 @@ class Engine:
             # K (and V) serve every scale: a gradient another scale has already left is added in the product's epilogue
             # instead of by a separate pass
             prevK = K.grads.pop() if (K.needs_grad and K.grads) else None
-            for h in range(H):
-                ops.gemm_nt(dt, B, n, C, KV, K.ptr() + h * KV * es, K.ld, n * K.ld, ds.data_ptr() + h * C * KV * es, KV, H * C * KV,
-                            dQ.ptr() + h * C * es, dQ.ld, n * dQ.ld)
-                ops.gemm_nt(dt, B, n, KV, C, Q.ptr() + h * C * es, Q.ld, n * Q.ld, ds_t.data_ptr() + h * KV * C * es, C, H * KV * C,
-                            dK.ptr() + h * KV * es, dK.ld, n * dK.ld,
-                            res_ptr=(prevK.ptr() + h * KV * es) if prevK is not None else None,
-                            ldres=prevK.ld if prevK is not None else 0, resb=n * prevK.ld if prevK is not None else 0)
+            # dQ_h = K_h dS_h^T and dK_h = Q_h dS_h for every (image, head): one launch each (second batch level = head)
+            ops.gemm_nt(dt, B, n, C, KV, K.ptr(), K.ld, n * K.ld, ds.data_ptr(), KV, H * C * KV, dQ.ptr(), dQ.ld, n * dQ.ld,
+                        batch2=H, xb2=KV, wb2=C * KV, yb2=C)
+            ops.gemm_nt(dt, B, n, KV, C, Q.ptr(), Q.ld, n * Q.ld, ds_t.data_ptr(), C, H * KV * C, dK.ptr(), dK.ld, n * dK.ld,
+                        res_ptr=prevK.ptr() if prevK is not None else None, ldres=prevK.ld if prevK is not None else 0,
+                        resb=n * prevK.ld if prevK is not None else 0,
+                        batch2=H, xb2=C, wb2=KV * C, yb2=KV, resb2=KV)
             if Q.needs_grad:
                 Q.add_grad(dQ)
             if K.needs_grad:

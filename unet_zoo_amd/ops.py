@@ -1024,12 +1024,32 @@ def sra_bwd(q: Act, kv: Act, out: Act, lse: torch.Tensor, go: Act, dq: Act, dkv:
 # the LDS-DMA GEMM, softmax over either axis, F.adaptive_avg_pool2d -- include/unetzoo_hip.h "Dense token attention".
 def gemm_nt(dtype: torch.dtype, batch: int, M: int, N: int, K: int, x_ptr: int, ldx: int, xb: int, w_ptr: int, ldw: int,
             wb: int, y_ptr: int, ldy: int, yb: int, *, bias: Optional[torch.Tensor] = None, res_ptr: Optional[int] = None,
-            ldres: int = 0, resb: int = 0) -> None:
-    """y_b[m][n] = sum_k x_b[m][k] w_b[n][k] (+ bias[n]) (+ res_b[m][n]); strides in elements, 0 = shared operand"""
-    d = L.GemmDesc(L.dtype_code(dtype), batch, M, N, K, ldx, ldw, ldy, ldres, xb, wb, yb, resb)
+            ldres: int = 0, resb: int = 0, batch2: int = 1, xb2: int = 0, wb2: int = 0, yb2: int = 0, resb2: int = 0) -> None:
+    """y_b[m][n] = sum_k x_b[m][k] w_b[n][k] (+ bias[n]) (+ res_b[m][n]); strides in elements, 0 = shared operand.
+    batch2 > 1: a second batch level, matrix (b, h) at + b * xb + h * xb2 ..."""
+    d = L.GemmDesc(L.dtype_code(dtype), batch, M, N, K, ldx, ldw, ldy, ldres, xb, wb, yb, resb, batch2, xb2, wb2, yb2, resb2)
     es = 2 if dtype == torch.bfloat16 else 4
-    with _Timed(f"gemm_nt_{_tname(dtype)}", 2.0 * batch * M * N * K, es * batch * (M * K + N * K + M * N)):
+    nm = batch * max(batch2, 1)
+    with _Timed(f"gemm_nt_{_tname(dtype)}", 2.0 * nm * M * N * K, es * nm * (M * K + N * K + M * N)):
         L.check(L.load().uz_gemm_nt(byref(d), x_ptr, w_ptr, _p(bias), res_ptr, y_ptr, L.stream_ptr()), "uz_gemm_nt")
+
+
+def wgrad_heads(Lt: Act, Rt: Act, heads: int) -> torch.Tensor:
+    """scores[b][h] = L_{b,h}^T R_{b,h} (fp32, (N, heads, Lt.C / heads, Rt.C / heads)): the heads sit side by side in the
+    channels of the two token maps; ONE launch for all (image, head) pairs"""
+    lib = L.load()
+    B, P, H = Lt.N, Lt.H * Lt.W, heads
+    C, KV = Lt.C // H, Rt.C // H
+    assert (Rt.N, Rt.H * Rt.W) == (B, P) and Lt.dtype == Rt.dtype and Lt.C == H * C and Rt.C == H * KV
+    d = L.WgradDesc(L.dtype_code(Lt.dtype), 1, 1, P, 1, P, C, Lt.ld, KV, Rt.ld, 1, L.TAPS_CONV, 1)
+    ws_bytes = L.check_count(lib.uz_wgrad_batched_workspace_bytes(byref(d), B * H), "uz_wgrad_batched_workspace_bytes")
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=Lt.buf.device)
+    out = torch.empty((B, H, C, KV), dtype=torch.float32, device=Lt.buf.device)
+    with _Timed(f"wgrad_batched_{_tname(Lt.dtype)}_1tap", 2.0 * B * H * P * C * KV,
+                Lt.buf.element_size() * B * P * (Lt.C + Rt.C) + 4.0 * out.numel()):
+        L.check(lib.uz_wgrad_batched2(byref(d), B, H, Lt.ptr(), P * Lt.ld, C, Rt.ptr(), P * Rt.ld, KV, out.data_ptr(), C * KV,
+                                      ws.data_ptr(), L.stream_ptr()), "uz_wgrad_batched2")
+    return out
 
 
 def wgrad_batched(Lt: Act, Rt: Act, out: Optional[torch.Tensor] = None, out_off: int = 0, ob: Optional[int] = None) -> torch.Tensor:
