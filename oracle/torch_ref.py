@@ -24,15 +24,27 @@ State = Dict[str, torch.Tensor]
 # product rounds to bf16 here" from "a kernel computes the wrong thing" on networks whose low-sample
 # BatchNorms amplify rounding (u2net: see DESIGN.md).  Only conv_bn_relu/upsample_like honour it.
 _STORE_DTYPE = None
+# Optional jitter in front of every storage rounding: t * (1 + jitter * N(0, 1)).  With jitter of fp32-rounding size
+# (1e-6) the oracle becomes "another correct implementation" -- one whose fp32 sums come out in a different order, so that
+# the few values within 1e-6 of a bf16 tie round the other way -- and oracle-vs-jittered-oracle measures how far two
+# correct bf16-storage implementations of a network end up apart (the yardstick for engine-vs-oracle bounds).
+_STORE_JITTER = 0.0
+_JITTER_GEN = None
 
 
-def set_storage_rounding(dtype) -> None:
-    global _STORE_DTYPE
+def set_storage_rounding(dtype, jitter: float = 0.0, seed: int = 0) -> None:
+    global _STORE_DTYPE, _STORE_JITTER, _JITTER_GEN
     _STORE_DTYPE = dtype
+    _STORE_JITTER = float(jitter) if dtype is not None else 0.0
+    _JITTER_GEN = torch.Generator().manual_seed(seed) if _STORE_JITTER > 0.0 else None
 
 
 def _q(t: torch.Tensor) -> torch.Tensor:
-    return t if _STORE_DTYPE is None else t.to(_STORE_DTYPE).float()
+    if _STORE_DTYPE is None:
+        return t
+    if _STORE_JITTER > 0.0:
+        t = t * (1.0 + _STORE_JITTER * torch.randn(t.shape, generator=_JITTER_GEN))
+    return t.to(_STORE_DTYPE).float()
 
 
 

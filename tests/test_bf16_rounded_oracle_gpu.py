@@ -2,7 +2,11 @@
 (oracle/torch_ref.set_storage_rounding): what remains between the two is summation order and the rounding of values
 that sit exactly between two bf16 numbers -- "the product rounds here" is taken out of the comparison, "a kernel
 computes something else" is not.  Every Conv + BN + ReLU output of the network is compared, then the logits, the loss
-and the gradients (round 1 compared bf16 with the fp32 reference and had to allow 6 % / cosine 0.75)."""
+and the gradients (round 1 compared bf16 with the fp32 reference and had to allow 6 % / cosine 0.75).
+
+Round 3 adds the yardstick for the bounds that still look loose: the oracle against itself with jitter of fp32-rounding
+size (1e-6) in front of every storage rounding (`set_storage_rounding(dtype, jitter=...)`), i.e. against another correct
+bf16-storage implementation whose sums come out in a different order.  The engine must be within twice that distance."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -49,6 +53,13 @@ def _run(name, H, W, seed=5):
     finally:
         Engine.conv_bn_relu, torch_ref.conv_bn_relu = orig, o2
         torch_ref.set_storage_rounding(None)
+    # the yardstick: the same rounded oracle with fp32-rounding-size jitter in front of every storage rounding --
+    # "another correct implementation" (oracle/torch_ref.py) -- against the oracle itself
+    torch_ref.set_storage_rounding(torch.bfloat16, jitter=1e-6, seed=1)
+    try:
+        jl, jloss, jgrads, _ = torch_ref.train_step_reference(name, sd, x, mask)
+    finally:
+        torch_ref.set_storage_rounding(None)
     layers = [(k, ((got[k] - want[k]).norm() / want[k].norm()).item()) for k in want]
     named = dict(m.named_parameters())
     per_param = {}
@@ -61,9 +72,12 @@ def _run(name, H, W, seed=5):
             per_param[n] = F.cosine_similarity(named[n].grad.flatten().cpu(), g.flatten(), dim=0).item()
     a = torch.cat([named[n].grad.flatten().cpu() for n in per_param])
     b = torch.cat([rgrads[n].flatten() for n in per_param])
+    jb = torch.cat([jgrads[n].flatten() for n in per_param])
+    jit = dict(logits_rms=((jl - rl).norm() / rl.norm()).item(), cos=F.cosine_similarity(jb, b, dim=0).item(),
+               worst=min(F.cosine_similarity(jgrads[n].flatten(), rgrads[n].flatten(), dim=0).item() for n in per_param))
     return dict(layers=layers, logits=logits.detach().cpu(), ref=rl, loss=loss.item(), rloss=rloss.item(),
                 cos=F.cosine_similarity(a, b, dim=0).item(), per_param=per_param,
-                gn=a.norm().item(), rgn=b.norm().item())
+                gn=a.norm().item(), rgn=b.norm().item(), jit=jit)
 
 
 # (model, H, W, rms bound of any layer, rms bound of the logits, global gradient cosine, per-parameter cosine)
@@ -75,7 +89,9 @@ CASES = [
     ("unet", 64, 96, 3e-2, 1e-2, 0.995, 0.92),
     # Attention U-Net: BOTH inputs of every decoder convolution (the gated skip psi * x and the upsampled path) carry
     # the decoder's error, which therefore grows ~1.25x per layer instead of shrinking (tools/layer_diff.py)
-    ("attention_unet", 64, 64, 0.15, 0.15, 0.75, 0.3),
+    # Measured: engine vs oracle logits rms 0.083, gradient cosine 0.83, worst parameter 0.76 -- while the oracle against
+    # ITSELF with 1e-6 jitter in front of its storage roundings is 0.14 / 0.70 / 0.60: the network, not a kernel
+    ("attention_unet", 64, 64, 0.15, 0.15, 0.75, 0.5),
     ("nested_unet", 64, 64, 4e-2, 2.5e-2, 0.95, 0.9),
     ("resunet", 64, 64, 3e-2, 1e-2, 0.995, 0.98),
 ]
@@ -85,6 +101,7 @@ CASES = [
 def test_bf16_matches_the_storage_rounded_oracle(name, H, W, layer_rms, logit_rms, cos_all, cos_each):
     r = _run(name, H, W)
     layers = r["layers"]
+    print(name, "oracle vs jittered oracle:", r["jit"])
     print(name, "worst layer", max(e for _, e in layers) if layers else None, "logits rms",
           ((r["logits"] - r["ref"]).norm() / r["ref"].norm()).item(), "loss", r["loss"], r["rloss"], "cos", r["cos"],
           "worst param cos", min(r["per_param"].values()), "norm ratio", r["gn"] / r["rgn"])
@@ -102,3 +119,9 @@ def test_bf16_matches_the_storage_rounded_oracle(name, H, W, layer_rms, logit_rm
     assert abs(r["gn"] / r["rgn"] - 1.0) < 0.1
     worst = min(r["per_param"].items(), key=lambda kv: kv[1])
     assert worst[1] > cos_each, worst
+    # and, self-calibrating: the engine is no further from the oracle than twice what the oracle is from "another correct
+    # implementation" of itself (fp32-rounding-size jitter in front of every bf16 storage rounding)
+    j = r["jit"]
+    assert (got - ref).norm() / ref.norm() <= 2 * j["logits_rms"] + 1e-3, j
+    assert 1 - r["cos"] <= 2 * (1 - j["cos"]) + 2e-3, j
+    assert 1 - worst[1] <= 2 * (1 - j["worst"]) + 2e-2, j
