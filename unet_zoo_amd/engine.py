@@ -807,8 +807,9 @@ class Engine:
                 dsts = [self._dst(l.weight) for l in lins]
                 out = None
                 if all(d is not None and d.is_contiguous() for d in dsts) and \
-                        all(dsts[h].data_ptr() == dsts[0].data_ptr() + 4 * h * Co * Ci for h in range(Hn)):
-                    out = torch.as_strided(dsts[0], (Hn * Co, Ci), (Ci, 1))
+                        all(dsts[h].data_ptr() == dsts[0].data_ptr() + 4 * h * Co * Ci and
+                            dsts[h].untyped_storage().data_ptr() == dsts[0].untyped_storage().data_ptr() for h in range(Hn)):
+                    out = torch.as_strided(dsts[0], (Hn * Co, Ci), (Ci, 1))      # one view over the heads' slots of the flat buffer
                 dW = ops.wgrad(g, x, (Hn * Co, Ci), ntaps=1, out=out)
                 for h, lin in enumerate(lins):
                     self._give_grad(lin.weight, dW[h * Co:(h + 1) * Co])
