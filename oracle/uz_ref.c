@@ -582,4 +582,184 @@ int uz_chanattn_probs_bwd_ref(int dtype, const float* scores, const float* dpc, 
 }
 UZ_SAME_SIGNATURE(uz_chanattn_probs_bwd);
 
+
+/* ---- element passes of the transformer / residual families --------------------------------------------------------- */
+/* nn.GELU() (erf form; missformer.py:196,206) and its derivative */
+int uz_gelu_fwd_ref(int dtype, const void* x, int ldx, void* y, int ldy, long long P, int C, void* stream) {
+  (void)stream;
+  for (long long p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) {
+      const double v = ld(dtype, x, p * ldx + c);
+      st(dtype, y, p * ldy + c, 0.5 * v * (1.0 + erf(v * 0.70710678118654752440)));
+    }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_gelu_fwd);
+
+int uz_gelu_bwd_ref(int dtype, const void* x, int ldx, const void* g, int ldg, void* dx, int lddx, long long P, int C, void* stream) {
+  (void)stream;
+  for (long long p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) {
+      const double v = ld(dtype, x, p * ldx + c);
+      const double d = 0.5 * (1.0 + erf(v * 0.70710678118654752440)) + v * exp(-0.5 * v * v) * 0.39894228040143267794;
+      st(dtype, dx, p * lddx + c, ld(dtype, g, p * ldg + c) * d);
+    }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_gelu_bwd);
+
+/* relu(a + b) and its gradient (multiresunet.py:79-80, 127-129, 133-135) */
+int uz_add_relu_ref(int dtype, const void* a, int lda, const void* b, int ldb, void* out, int ldo, long long P, int C, void* stream) {
+  (void)stream;
+  for (long long p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) {
+      const double v = ld(dtype, a, p * lda + c) + (b ? ld(dtype, b, p * ldb + c) : 0.0);
+      st(dtype, out, p * ldo + c, v > 0.0 ? v : 0.0);
+    }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_add_relu);
+
+int uz_relu_bwd_ref(int dtype, const void* out, int ldo, const void* g, int ldg, void* dx, int lddx, long long P, int C, void* stream) {
+  (void)stream;
+  for (long long p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) st(dtype, dx, p * lddx + c, ld(dtype, out, p * ldo + c) > 0.0 ? ld(dtype, g, p * ldg + c) : 0.0);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_relu_bwd);
+
+/* backward of nn.Upsample(scale_factor=2) (common_layers.py:70): dx[coarse] = sum of its 2 x 2 fine pixels */
+int uz_sum2x2_ref(int dtype, const void* du, int ldu, int N, int H, int W, int C, void* dx, int lddx, void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h)
+      for (int w = 0; w < W; ++w)
+        for (int c = 0; c < C; ++c) {
+          double acc = 0.0;
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) acc += ld(dtype, du, (((long long)n * 2 * H + 2 * h + a) * 2 * W + 2 * w + b) * ldu + c);
+          st(dtype, dx, (((long long)n * H + h) * W + w) * lddx + c, acc);
+        }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_sum2x2);
+
+/* F.interpolate(mode='bilinear', align_corners=...) (u2net.py:19-22; nested_unet.py:32): ATen's source index rule */
+int uz_resize_bilinear_fwd_ref(int dtype, const void* x, int ldx, long long x_img_stride, int N, int Hi, int Wi, int C, void* y,
+                               int ldy, long long y_img_stride, int Ho, int Wo, int align_corners, void* stream) {
+  (void)stream;
+  const double sh = align_corners ? (Ho > 1 ? (double)(Hi - 1) / (Ho - 1) : 0.0) : (double)Hi / Ho;
+  const double sw = align_corners ? (Wo > 1 ? (double)(Wi - 1) / (Wo - 1) : 0.0) : (double)Wi / Wo;
+  for (int n = 0; n < N; ++n)
+    for (int oh = 0; oh < Ho; ++oh)
+      for (int ow = 0; ow < Wo; ++ow) {
+        double fh = align_corners ? oh * sh : (oh + 0.5) * sh - 0.5, fw = align_corners ? ow * sw : (ow + 0.5) * sw - 0.5;
+        if (fh < 0.0) fh = 0.0;
+        if (fw < 0.0) fw = 0.0;
+        const int h0 = (int)fh < Hi - 1 ? (int)fh : Hi - 1, w0 = (int)fw < Wi - 1 ? (int)fw : Wi - 1;
+        const int h1 = h0 < Hi - 1 ? h0 + 1 : h0, w1 = w0 < Wi - 1 ? w0 + 1 : w0;
+        const double lh = fh - h0, lw = fw - w0;
+        for (int c = 0; c < C; ++c) {
+#define UZ_X(hh, ww) ld(dtype, x, n * x_img_stride + ((long long)(hh) * Wi + (ww)) * ldx + c)
+          const double v = (1 - lh) * ((1 - lw) * UZ_X(h0, w0) + lw * UZ_X(h0, w1)) + lh * ((1 - lw) * UZ_X(h1, w0) + lw * UZ_X(h1, w1));
+#undef UZ_X
+          st(dtype, y, n * y_img_stride + ((long long)oh * Wo + ow) * ldy + c, v);
+        }
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_resize_bilinear_fwd);
+
+int uz_bilinear_fwd_ref(int dtype, const void* x, int ldx, long long x_img_stride, int N, int Hi, int Wi, int C, void* y, int ldy,
+                        long long y_img_stride, int Ho, int Wo, void* stream) {
+  return uz_resize_bilinear_fwd_ref(dtype, x, ldx, x_img_stride, N, Hi, Wi, C, y, ldy, y_img_stride, Ho, Wo, 0, stream);
+}
+UZ_SAME_SIGNATURE(uz_bilinear_fwd);
+
+/* dst[n, ho, wo, (ty r + tx) C + c] = src[n, ho r + ty, wo r + tx, c] (missformer.py:17-18, 26-27) and its inverse */
+int uz_space_to_depth_ref(int dtype, const void* src, int lds, void* dst, int ldd, int N, int Ho, int Wo, int C, int r, int inverse,
+                          void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (int ho = 0; ho < Ho; ++ho)
+      for (int wo = 0; wo < Wo; ++wo)
+        for (int ty = 0; ty < r; ++ty)
+          for (int tx = 0; tx < r; ++tx)
+            for (int c = 0; c < C; ++c) {
+              const long long fine = (((long long)n * Ho * r + ho * r + ty) * Wo * r + wo * r + tx);
+              const long long coarse = ((long long)n * Ho + ho) * Wo + wo;
+              const long long col = (long long)(ty * r + tx) * C + c;
+              if (!inverse) st(dtype, dst, coarse * ldd + col, ld(dtype, src, fine * lds + c));
+              else st(dtype, dst, fine * ldd + c, ld(dtype, src, coarse * lds + col));
+            }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_space_to_depth);
+
+/* per-channel sums over the pixels: nn.Linear / PatchEmbed bias gradients (swin_unet_v2.py:120,123,546) */
+int uz_colsum_ref(int dtype, const void* x, int ldm, int P, int C, float* out, void* stream) {
+  (void)stream;
+  for (int c = 0; c < C; ++c) {
+    double t = 0.0;
+    for (long long p = 0; p < P; ++p) t += ld(dtype, x, p * ldm + c);
+    out[c] = (float)t;
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_colsum);
+
+/* DWConv: Conv2d(C, C, 3, 1, 1, groups=C) on NHWC tokens (missformer.py:168-177); w_taps [9][C] */
+int uz_dwconv3x3_ref(int dtype, const void* x, int ldx, const float* w_taps, const float* bias, void* y, int ldy, int N, int H, int W,
+                     int C, int flags, void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h)
+      for (int w = 0; w < W; ++w)
+        for (int c = 0; c < C; ++c) {
+          double acc = bias ? bias[c] : 0.0;
+          for (int t = 0; t < 9; ++t) {
+            const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            acc += ld(dtype, x, (((long long)n * H + hh) * W + ww) * ldx + c) * w_taps[((flags & 2) ? 8 - t : t) * C + c];
+          }
+          if (flags & 1) acc += ld(dtype, x, (((long long)n * H + h) * W + w) * ldx + c);
+          st(dtype, y, (((long long)n * H + h) * W + w) * ldy + c, acc);
+        }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_dwconv3x3);
+
+/* nn.LayerNorm over the channels of a token map (swin_unet_v2.py, missformer.py): plain addressing (mode 0) with the
+ * optional residual / per-image scale / GELU of the engine's fused forms; stats[token] = (mean, rstd).
+ * y = res + image_scale[n] * LN(x); act = 1: y = GELU(LN(x)).  The merge / expand addressings are not restated. */
+int uz_layernorm_fwd_ref(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta, const void* res,
+                         const float* image_scale, void* y, float* stats, void* stream) {
+  (void)stream;
+  if (d->mode != 0) return UZ_ENOTIMPL;
+  const long long P = (long long)d->N * d->Ho * d->Wo;
+  for (long long p = 0; p < P; ++p) {
+    double m = 0.0, v = 0.0;
+    for (int c = 0; c < d->C; ++c) m += ld(d->dtype, x, p * d->ldx + c);
+    m /= d->C;
+    for (int c = 0; c < d->C; ++c) {
+      const double t = ld(d->dtype, x, p * d->ldx + c) - m;
+      v += t * t;
+    }
+    const double rstd = 1.0 / sqrt(v / d->C + (double)d->eps);
+    if (stats) {
+      stats[2 * p] = (float)m;
+      stats[2 * p + 1] = (float)rstd;
+    }
+    const double sc = image_scale ? image_scale[p / ((long long)d->Ho * d->Wo)] : 1.0;
+    for (int c = 0; c < d->C; ++c) {
+      double o = ((ld(d->dtype, x, p * d->ldx + c) - m) * rstd * gamma[c] + beta[c]) * sc;
+      if (d->act == 1) o = 0.5 * o * (1.0 + erf(o * 0.70710678118654752440));
+      if (res) o += ld(d->dtype, res, p * d->ldr + c);
+      st(d->dtype, y, p * d->ldy + c, o);
+    }
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_layernorm_fwd);
+
 int uz_ref_abi_version(void) { return 1; }

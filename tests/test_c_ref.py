@@ -269,3 +269,104 @@ def test_every_restated_entry_exists_with_the_products_signature():
     for name in c_ref.REF_NAMES:
         assert hasattr(lib, name + "_ref") and hasattr(prod, name)
     assert lib.uz_ref_abi_version() == prod.uz_abi_version()
+
+
+# ---- second batch: element passes of the transformer / residual families ---------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+def test_gelu_residual_relu_and_upsample_gradient_restatements(dt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(8)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    P, C = 70, 24
+    x, gy, b = rnd((P, C), dt, g), rnd((P, C), dt, g), rnd((P, C), dt, g)
+    xh, gh, bh = c_ref.host(x), c_ref.host(gy), c_ref.host(b)
+    y = np.zeros(P * C, npdt)
+    assert lib.uz_gelu_fwd_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(y), C, P, C, None) == 0
+    xr = x.double().requires_grad_(True)
+    ref = F.gelu(xr)
+    close(c_ref.tensor(y, dt).reshape(P, C), ref.detach(), dt, "gelu")
+    ref.backward(gy.double())
+    dx = np.zeros(P * C, npdt)
+    assert lib.uz_gelu_bwd_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(gh), C, c_ref.ptr(dx), C, P, C, None) == 0
+    close(c_ref.tensor(dx, dt).reshape(P, C), xr.grad, dt, "gelu bwd")
+    out = np.zeros(P * C, npdt)
+    assert lib.uz_add_relu_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(bh), C, c_ref.ptr(out), C, P, C, None) == 0
+    close(c_ref.tensor(out, dt).reshape(P, C), F.relu(x.double() + b.double()), dt, "add_relu")
+    assert lib.uz_relu_bwd_ref(dc, c_ref.ptr(out), C, c_ref.ptr(gh), C, c_ref.ptr(dx), C, P, C, None) == 0
+    close(c_ref.tensor(dx, dt).reshape(P, C), gy.double() * (c_ref.tensor(out, dt).reshape(P, C).double() > 0), dt, "relu bwd")
+    # nearest x2 upsampling's gradient
+    N, H, W = 2, 5, 6
+    du = rnd((N, C, 2 * H, 2 * W), dt, g)
+    xs = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    F.interpolate(xs, scale_factor=2, mode="nearest").backward(du.double())
+    dxs = np.zeros(N * H * W * C, npdt)
+    duh = c_ref.host(nhwc(du))
+    assert lib.uz_sum2x2_ref(dc, c_ref.ptr(duh), C, N, H, W, C, c_ref.ptr(dxs), C, None) == 0
+    close(nchw(c_ref.tensor(dxs, dt).reshape(-1, C), N, H, W), xs.grad, dt, "sum2x2")
+    cs = np.zeros(C, np.float32)
+    assert lib.uz_colsum_ref(dc, c_ref.ptr(xh), C, P, C, c_ref.ptr(cs), None) == 0
+    np.testing.assert_allclose(cs, x.double().sum(0).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_bilinear_depthwise_space_to_depth_and_layernorm_restatements(dt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(9)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    N, C, Hi, Wi = 2, 8, 5, 7
+    x = rnd((N, C, Hi, Wi), dt, g)
+    xh = c_ref.host(nhwc(x))
+    for (Ho, Wo) in ((10, 14), (8, 9), (3, 4)):
+        for ac in (0, 1):
+            y = np.zeros(N * Ho * Wo * C, npdt)
+            assert lib.uz_resize_bilinear_fwd_ref(dc, c_ref.ptr(xh), C, Hi * Wi * C, N, Hi, Wi, C, c_ref.ptr(y), C, Ho * Wo * C, Ho, Wo, ac, None) == 0
+            ref = F.interpolate(x.double(), size=(Ho, Wo), mode="bilinear", align_corners=bool(ac))
+            close(nchw(c_ref.tensor(y, dt).reshape(-1, C), N, Ho, Wo), ref, dt, f"bilinear {Ho}x{Wo} ac={ac}")
+    # depthwise 3x3 (+ skip) and its input-gradient form (flipped taps)
+    w = torch.randn(C, 1, 3, 3, generator=g)
+    bias = torch.randn(C, generator=g)
+    taps = w.reshape(C, 9).t().contiguous()
+    th, bh = c_ref.host(taps), c_ref.host(bias)
+    y = np.zeros(N * Hi * Wi * C, npdt)
+    assert lib.uz_dwconv3x3_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(th), c_ref.ptr(bh), c_ref.ptr(y), C, N, Hi, Wi, C, 1, None) == 0
+    xr = x.double().requires_grad_(True)
+    ref = F.conv2d(xr, w.double(), bias.double(), padding=1, groups=C)
+    close(nchw(c_ref.tensor(y, dt).reshape(-1, C), N, Hi, Wi), (ref + xr).detach(), dt, "dwconv + skip")
+    gy = rnd((N, C, Hi, Wi), dt, g)
+    ref.backward(gy.double())
+    gh = c_ref.host(nhwc(gy))
+    assert lib.uz_dwconv3x3_ref(dc, c_ref.ptr(gh), C, c_ref.ptr(th), None, c_ref.ptr(y), C, N, Hi, Wi, C, 2, None) == 0
+    close(nchw(c_ref.tensor(y, dt).reshape(-1, C), N, Hi, Wi), xr.grad, dt, "dwconv input gradient")
+    # space to depth: the rows a Conv2d(C, C', r, r) multiplies
+    r = 2
+    xf = rnd((N, C, 4 * r, 3 * r), dt, g)
+    fh = c_ref.host(nhwc(xf))
+    cols = np.zeros(N * 4 * 3 * r * r * C, npdt)
+    assert lib.uz_space_to_depth_ref(dc, c_ref.ptr(fh), C, c_ref.ptr(cols), r * r * C, N, 4, 3, C, r, 0, None) == 0
+    wc = torch.randn(6, C, r, r, generator=g)
+    rows = c_ref.tensor(cols, dt).reshape(N * 12, r * r * C).double()
+    got = rows @ wc.permute(0, 2, 3, 1).reshape(6, -1).double().t()
+    close(nchw(got, N, 4, 3), F.conv2d(xf.double(), wc.double(), stride=r), torch.float32, "space_to_depth rows", f32_tol=1e-9)
+    back = np.zeros(N * 4 * r * 3 * r * C, npdt)
+    assert lib.uz_space_to_depth_ref(dc, c_ref.ptr(cols), r * r * C, c_ref.ptr(back), C, N, 4, 3, C, r, 1, None) == 0
+    assert np.array_equal(back, fh.reshape(-1))
+    # LayerNorm with the engine's fused residual / per-image scale, and the GELU form
+    P = N * Hi * Wi
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    res = rnd((P, C), dt, g)
+    isc = torch.rand(N, generator=g) + 0.5
+    d = L.LnDesc(dc, N, Hi, Wi, C, C, C, C, 0, 0, 0, 1, 1e-5, 0)
+    stats = np.zeros(2 * P, np.float32)
+    yl = np.zeros(P * C, npdt)
+    gm, bt, rh, ih = c_ref.host(gamma), c_ref.host(beta), c_ref.host(res), c_ref.host(isc)
+    assert lib.uz_layernorm_fwd_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), c_ref.ptr(rh), c_ref.ptr(ih), c_ref.ptr(yl), c_ref.ptr(stats), None) == 0
+    xt = nhwc(x).double()
+    ln = F.layer_norm(xt, (C,), gamma.double(), beta.double(), 1e-5)
+    ref = res.double() + ln * isc.double().repeat_interleave(Hi * Wi)[:, None]
+    close(c_ref.tensor(yl, dt).reshape(P, C), ref, dt, "layernorm + res + scale")
+    np.testing.assert_allclose(stats.reshape(P, 2)[:, 0], xt.mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    d2 = L.LnDesc(dc, N, Hi, Wi, C, C, C, 0, 0, 0, 0, 1, 1e-5, 1)
+    assert lib.uz_layernorm_fwd_ref(byref(d2), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), None, None, c_ref.ptr(yl), c_ref.ptr(stats), None) == 0
+    close(c_ref.tensor(yl, dt).reshape(P, C), F.gelu(ln), dt, "gelu(layernorm)")

@@ -208,3 +208,81 @@ def test_head_level_batches_against_the_c_restatement(dt):
     dsh = c_ref.host(ds)
     assert lib.uz_gemm_nt_ref(byref(gd), c_ref.ptr(Kh), c_ref.ptr(dsh), None, None, c_ref.ptr(yr), None) == 0
     agree(dQ, c_ref.tensor(yr, dt).reshape(B * n, H * C), dt, "gemm_nt heads")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_element_kernels_of_the_transformer_families_against_the_c_restatement(dt):
+    """GELU, relu(a + b), nearest-upsampling gradient, bilinear resize (both corner conventions), depthwise 3x3, space to
+    depth, column sums, LayerNorm with residual / per-image scale / GELU"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(31)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    N, H, W, C = 2, 12, 20, 64
+    P = N * H * W
+
+    def act(t, h=H, w=W, c=C):
+        return Act(t.to(DEV), 0, c, N, h, w)
+
+    def new(h=H, w=W, c=C):
+        return ops.new_act(N, h, w, c, dt, DEV)
+
+    x, gy, b = rnd((P, C), dt, g), rnd((P, C), dt, g), rnd((P, C), dt, g)
+    xh, gh, bh = c_ref.host(x), c_ref.host(gy), c_ref.host(b)
+    ref = np.zeros(P * C, npdt)
+    # GELU and its gradient
+    y = new()
+    ops.gelu_fwd(act(x), y)
+    assert lib.uz_gelu_fwd_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(ref), C, P, C, None) == 0
+    agree(y.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, "gelu")
+    ops.gelu_bwd(act(x), act(gy), y)
+    assert lib.uz_gelu_bwd_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(gh), C, c_ref.ptr(ref), C, P, C, None) == 0
+    agree(y.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, "gelu bwd")
+    # relu(a + b)
+    ops.add_relu(act(x), act(b), y)
+    assert lib.uz_add_relu_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(bh), C, c_ref.ptr(ref), C, P, C, None) == 0
+    agree(y.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, "add_relu")
+    # nearest x2 upsampling's gradient
+    du = rnd((N * 4 * H * W, C), dt, g)
+    dx = new()
+    ops.sum2x2(act(du, 2 * H, 2 * W), dx)
+    duh = c_ref.host(du)
+    assert lib.uz_sum2x2_ref(dc, c_ref.ptr(duh), C, N, H, W, C, c_ref.ptr(ref), C, None) == 0
+    agree(dx.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, "sum2x2")
+    # bilinear resize
+    for (Ho, Wo, ac) in ((24, 40, True), (17, 23, False), (6, 10, False)):
+        o = new(Ho, Wo)
+        ops.bilinear_fwd(act(x), o, align_corners=ac)
+        r2 = np.zeros(N * Ho * Wo * C, npdt)
+        assert lib.uz_resize_bilinear_fwd_ref(dc, c_ref.ptr(xh), C, H * W * C, N, H, W, C, c_ref.ptr(r2), C, Ho * Wo * C, Ho, Wo, int(ac), None) == 0
+        agree(o.buf, c_ref.tensor(r2, dt).reshape(-1, C), dt, f"bilinear {Ho}x{Wo} {ac}")
+    # depthwise 3x3 with the skip
+    taps, bias = torch.randn(9, C, generator=g) * 0.3, torch.randn(C, generator=g)
+    ops.dwconv3x3(act(x), taps.to(DEV), bias.to(DEV), y, skip=True)
+    th, bsh = c_ref.host(taps), c_ref.host(bias)
+    assert lib.uz_dwconv3x3_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(th), c_ref.ptr(bsh), c_ref.ptr(ref), C, N, H, W, C, 1, None) == 0
+    agree(y.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, "dwconv3x3")
+    # space to depth
+    cols = new(H // 2, W // 2, 4 * C)
+    ops.space_to_depth(act(x), cols, 2)
+    rc = np.zeros(P * C, npdt)
+    assert lib.uz_space_to_depth_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(rc), 4 * C, N, H // 2, W // 2, C, 2, 0, None) == 0
+    assert torch.equal(cols.buf.cpu(), c_ref.tensor(rc, dt).reshape(-1, 4 * C))
+    # column sums
+    cs = ops.colsum(act(x))
+    rs = np.zeros(C, np.float32)
+    assert lib.uz_colsum_ref(dc, c_ref.ptr(xh), C, P, C, c_ref.ptr(rs), None) == 0
+    assert np.allclose(cs.cpu().numpy(), rs, rtol=1e-5, atol=1e-3)
+    # LayerNorm + residual + per-image scale, and GELU(LayerNorm)
+    gamma, beta, isc = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.rand(N, generator=g) + 0.5
+    gm, bt, ih = c_ref.host(gamma), c_ref.host(beta), c_ref.host(isc)
+    stats = ops.layernorm_fwd(act(x), gamma.to(DEV), beta.to(DEV), y, eps=1e-5, res=act(b), image_scale=isc.to(DEV))
+    d = L.LnDesc(dc, N, H, W, C, C, C, C, 0, 0, 0, 1, 1e-5, 0)
+    rstats = np.zeros(2 * P, np.float32)
+    assert lib.uz_layernorm_fwd_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), c_ref.ptr(bh), c_ref.ptr(ih), c_ref.ptr(ref), c_ref.ptr(rstats), None) == 0
+    agree(y.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, "layernorm")
+    assert np.allclose(stats.cpu().numpy().reshape(-1), rstats, rtol=1e-4, atol=1e-5)
+    ops.layernorm_fwd(act(x), gamma.to(DEV), beta.to(DEV), y, eps=1e-5, gelu=True)
+    d2 = L.LnDesc(dc, N, H, W, C, C, C, 0, 0, 0, 0, 1, 1e-5, 1)
+    assert lib.uz_layernorm_fwd_ref(byref(d2), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), None, None, c_ref.ptr(ref), c_ref.ptr(rstats), None) == 0
+    agree(y.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, "gelu(layernorm)")
