@@ -233,6 +233,10 @@ def main():
                          "torch's clip_grad_norm_ / AdamW (with N > 1: the bucket reducer of RcclDataParallel)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and use the multi-GPU launch strategy even for 1 rank")
+    ap.add_argument("--comm", default="auto", choices=["auto", "overlap", "tail"],
+                    help="N>1 ranks: all-reduce every finished backward phase beside the next one (overlap), the whole "
+                         "gradient buffer once after the backward (tail), or time both before the warm-up and keep the "
+                         "faster (auto; the choice and both timings are reported in the line)")
     ap.add_argument("--phases", type=int, default=5,
                     help="N>1 ranks: number of backward phases (hipGraphs) whose gradient "
                          "all-reduce overlaps the next phase; 1 = one all-reduce after the whole backward")
@@ -316,12 +320,20 @@ def main():
         return loss
 
     gs = None
+    comm_tuning = None
     fb_graph_ms = None
     loss_recheck = None
     dev_before = device_state(dev.index or 0) if rank == 0 else None
     if args.graph == "on":
         gs = GraphedStep(model, "bce_dice" if args.loss == "hip" else torch_criterion, lr=1e-4, weight_decay=1e-5,
-                         max_norm=1.0, phases=args.phases, data_parallel=distributed, cu_reserve=args.cu_reserve)
+                         max_norm=1.0, phases=args.phases, data_parallel=distributed, cu_reserve=args.cu_reserve,
+                         comm="overlap" if args.comm == "auto" else args.comm)
+        comm_tuning = None
+        if distributed and args.comm == "auto":
+            # before the warm-up and the timed steps: both collective schedules on this job's own ranks, keep the faster
+            comm_tuning = gs.autotune_comm(x, mask)
+            comm_tuning = {k: round(v, 3) for k, v in comm_tuning.items()}
+            comm_tuning["chosen"] = gs.comm
         elapsed, fb_s = time_graphed(gs, x, mask, args.steps, args.warmup, distributed, dev)
         fb_graph_ms = fb_s / args.steps * 1e3
         launch_mode = gs.describe()
@@ -473,6 +485,7 @@ def main():
             "roofline": roofline,
             "launch": launch_mode,
             "cu_reserve": L.get_cu_reserve(),
+            "comm_tuning_ms": comm_tuning if args.graph == "on" else None,
             "device": {"before_timed_steps": dev_before, "after_timed_steps": dev_after, "mfma_clock": mfma_clock},
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }

@@ -55,6 +55,15 @@ def main():
     n_phases = len(gs._cuts) - 1
     bad_g = [n for n in ref[2] if not torch.equal(ref[2][n], got[2][n])]
     bad_p = [n for n in ref[3] if not torch.equal(ref[3][n], got[3][n])]
+    # the other collective schedule -- one all-reduce of the whole buffer after the last phase -- on the same graphs,
+    # and the timing pass that chooses between the two
+    m2 = build(name, size, dtype, dev)
+    gs2 = unet_zoo_amd.GraphedStep(m2, "bce_dice", lr=1e-3, weight_decay=1e-5, data_parallel=True, phases=3, comm="tail")
+    tail = run(gs2, m2, x, t)
+    bad_g += [n + " (tail)" for n in ref[2] if not torch.equal(ref[2][n], tail[2][n])]
+    bad_p += [n + " (tail)" for n in ref[3] if not torch.equal(ref[3][n], tail[3][n])]
+    tuning = gs2.autotune_comm(x, t, steps=2)
+    assert set(tuning) == {"overlap", "tail"} and gs2.comm in ("overlap", "tail") and "all-reduce" in gs2.describe()
     torch.save({"loss": (ref[0], got[0]), "loss2": (ref[1], got[1]), "bad_grads": bad_g, "bad_params": bad_p,
                 "n_phases": n_phases, "spans": gs._spans, "n_params": len(ref[2]), "describe": gs.describe(),
                 "backend": dist.get_backend()}, out_path)

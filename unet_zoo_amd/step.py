@@ -112,8 +112,13 @@ class GraphedStep:
     def __init__(self, model: nn.Module, criterion: Union[str, Callable] = "bce_dice", *, lr: float = 1e-4,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-5,
                  max_norm: float = 1.0, phases: int = 5, process_group=None, data_parallel: Optional[bool] = None,
-                 cu_reserve: Optional[int] = None):
-        """cu_reserve: CUs the library's persistent grids leave free (uz_set_cu_reserve; process-wide, applied here,
+                 cu_reserve: Optional[int] = None, comm: str = "overlap"):
+        """comm: when the gradient exchange of a data-parallel step runs -- "overlap": the span of every finished backward
+        phase is all-reduced while the next phase's graph runs; "tail": ONE all-reduce of the whole flat buffer after the
+        last phase.  The same graphs serve both; autotune_comm() times them on the job's own hardware and keeps the faster
+        one (the persistent one-workgroup-per-CU grids and a collective's kernels compete for CUs: which schedule wins
+        depends on the rank count and the fabric).
+        cu_reserve: CUs the library's persistent grids leave free (uz_set_cu_reserve; process-wide, applied here,
         before anything is planned or captured) so that the all-reduce of a finished gradient span can start while the
         next backward phase runs -- convolution / GEMM / weight-gradient kernels otherwise hold every CU with one
         160 KB workgroup until a kernel boundary.  None leaves the library's setting alone (default 0)."""
@@ -138,6 +143,9 @@ class GraphedStep:
             raise RuntimeError("data_parallel=True needs an initialised torch.distributed process group")
         self._nccl = self.distributed and dist.get_backend(process_group) == "nccl"
         self.n_phases = max(1, int(phases)) if self.distributed else 1
+        if comm not in ("overlap", "tail"):
+            raise ValueError(f"comm must be 'overlap' or 'tail', got {comm!r}")
+        self.comm = comm
         self.opt: Optional[FlatClipAdamW] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
         self._cuts: Optional[List[int]] = None
@@ -318,7 +326,13 @@ class GraphedStep:
         else:
             self.loss = g.loss
         self.dice, self.outputs = g.dice, g.outputs
-        if self.distributed:
+        if self.distributed and self.comm == "tail":
+            for gk in g.phases:
+                gk.replay()
+            w = self._all_reduce_avg(self.opt.flat_g[:self._spans[-1][1]])
+            if w is not None:
+                w.wait()
+        elif self.distributed:
             works = []
             for gk, (a0, a1) in zip(g.phases, self._spans):
                 gk.replay()
@@ -330,6 +344,34 @@ class GraphedStep:
             for gk in g.phases:
                 gk.replay()
         return self.loss
+
+    def autotune_comm(self, x: torch.Tensor, target: torch.Tensor, steps: int = 6) -> Dict[str, float]:
+        """Time `steps` whole training steps under each collective schedule ("overlap", "tail") on this job's ranks and
+        keep the faster one; every rank takes the same decision (the slowest rank's time counts).  These are real
+        optimizer steps on (x, target).  Returns {"overlap": ms, "tail": ms}."""
+        if not self.distributed:
+            return {}
+        dev = next(self.model.parameters()).device
+        out: Dict[str, float] = {}
+        for mode in ("overlap", "tail"):
+            self.comm = mode
+            for _ in range(2):
+                self(x, target)
+            torch.cuda.synchronize(dev)
+            if self.world > 1:
+                dist.barrier(group=self.pg)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                self(x, target)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = torch.tensor([e0.elapsed_time(e1) / steps], dtype=torch.float64, device=dev if self._nccl else "cpu")
+            if self.world > 1:
+                dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=self.pg)
+            out[mode] = float(ms.item())
+        self.comm = "tail" if out["tail"] < 0.99 * out["overlap"] else "overlap"      # overlap unless the tail schedule wins by > 1 %
+        return out
 
     def optimizer_step(self) -> None:
         """clip_grad_norm_(max_norm) + AdamW on the flat buffers (training_loop.py:120-121)"""
@@ -359,5 +401,8 @@ class GraphedStep:
         if not self.distributed:
             return f"{crit}hipGraph({'fwd+' if self._fused_loss else ''}bwd) + {opt}"
         mb = [round((a1 - a0) * 4 / 2 ** 20, 1) for a0, a1 in self._spans]
+        if self.comm == "tail":
+            return (f"{crit}{k} hipGraphs ({'fwd + ' if self._fused_loss else ''}backward phases), then ONE RCCL all-reduce of "
+                    f"{round(sum(mb), 1)} MB + {opt}")
         return (f"{crit}{k} hipGraphs ({'fwd + ' if self._fused_loss else ''}backward phases) with async RCCL "
                 f"all-reduce of {mb} MB overlapped with the next phase + {opt}")
