@@ -326,3 +326,43 @@ def test_dropout_kernel_uses_torchs_draw(dt):
     assert torch.equal(xa.grads[0].dense().cpu(), (dy * keep * scale).to(dt).float())
     ev = Engine(dt, torch.device(DEV), False, False)
     assert ev.dropout(xa, p) is xa
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bias", [False, True])
+def test_linear_heads_matches_separate_linears(dt, bias):
+    """Engine.linear_heads: the per-head Linear layers of Attention_org (uctransnet.py:104-116) as one stacked product each for
+    forward, input gradient and weight gradient; an earlier gradient on the input is added in the product's epilogue"""
+    g = torch.Generator().manual_seed(13)
+    B, H_, W_, Ci, Co, Hn = 2, 8, 8, 40, 24, 4
+    lins = [nn.Linear(Ci, Co, bias=bias) for _ in range(Hn)]
+    x = torch.randn(B, Ci, H_, W_, generator=g).to(dt).float()
+    xr = x.double().clone().requires_grad_(True)
+    tok = xr.flatten(2).transpose(1, 2)
+    ref = torch.cat([F.linear(tok, l.weight.to(dt).double(), l.bias.double() if bias else None) for l in lins], -1)   # (B, n, Hn Co)
+    dy = torch.randn(ref.shape, generator=g).to(dt).double()
+    pre = torch.randn(B, Ci, H_, W_, generator=g).to(dt).float()                  # a gradient x has already collected
+    (ref * dy).sum().backward()
+    want_w = [torch.autograd.grad((F.linear(tok.detach(), w_, None) * dy[..., h * Co:(h + 1) * Co]).sum(), w_)[0]
+              for h, w_ in enumerate(l.weight.to(dt).double().requires_grad_(True) for l in lins)]
+    lins_d = [nn.Linear(Ci, Co, bias=bias).to(DEV) for _ in range(Hn)]
+    for a, b_ in zip(lins_d, lins):
+        a.load_state_dict(b_.state_dict())
+    eng = Engine(dt, torch.device(DEV), True, True)
+    xa = act_from_nchw(x.to(DEV), dt)
+    y = eng.linear_heads(xa, lins_d)
+    ftol, gtol = (2e-5, 1e-4) if dt == torch.float32 else (2e-2, 3e-2)
+    got = y.buf.view(B, H_ * W_, Hn * Co).cpu()
+    assert relerr(got, ref.detach()) < ftol
+    xa.add_grad(act_from_nchw(pre.to(DEV), dt))
+    y.add_grad(Act(dy.reshape(B * H_ * W_, Hn * Co).to(dt).to(DEV).contiguous(), 0, Hn * Co, B, H_, W_))
+    eng.backward_range(None, len(eng.tape), 0)
+    assert len(xa.grads) == 1
+    gx = xa.grads[0].dense().cpu().double()
+    assert ((gx - (xr.grad + pre.double())).norm() / (xr.grad + pre.double()).norm()).item() < gtol
+    for h, l in enumerate(lins_d):
+        e = ((eng.param_grads[l.weight].cpu().double() - want_w[h]).norm() / want_w[h].norm()).item()
+        assert e < gtol, (h, e)
+        if bias:
+            wb = dy[..., h * Co:(h + 1) * Co].sum((0, 1))
+            assert ((eng.param_grads[l.bias].cpu().double() - wb).norm() / wb.norm()).item() < gtol
