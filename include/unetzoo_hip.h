@@ -132,7 +132,10 @@ int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const void* w_packed
  * <= 32x32 maps, u2net.py:196-201) split their nine taps across workgroups into fp32 partial tiles in
  * `workspace` and finish with a fixed-order reduce + bias + statistics pass.  workspace_bytes() == 0:
  * identical to uz_conv_igemm (workspace may be NULL).  The statistics rows of THIS entry point are
- * counted by uz_conv_igemm_ws_grid_m(). */
+ * counted by uz_conv_igemm_ws_grid_m().  The same entry serves the split-K form of the direct bf16 3x3 kernel: the
+ * 16 x 16 / 32 x 32 bottleneck maps of a 256 x 256 input have 32 ... 128 tiles of 16 ... 32 channel slabs x nine taps, so
+ * with a workspace the slabs of a tile are dealt to 2 ... 8 workgroups (fp32 partial tiles, the same reduce pass;
+ * uz_conv_igemm_kernel_name(d, 1) then ends in "_splitk").  The split is sized by the hardware's CU count. */
 long long uz_conv_igemm_workspace_bytes(const uz_conv_desc* d);
 int uz_conv_igemm_ws_grid_m(const uz_conv_desc* d);
 int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
@@ -140,7 +143,7 @@ int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void* w_packed,
 /* Input-gradient convolution with the first pass of the BatchNorm backward fused into its epilogue.
  * y = conv(x, w) is the gradient of an activation a = relu(bn(bn_y)) (common_layers.py:28-33: the Conv -> BN -> ReLU
  * whose output feeds only this convolution's forward).  Instead of the statistics of y the kernel writes, per
- * workgroup row of `partial` ([uz_conv_igemm_ws_grid_m()][2][Nout], the layout of uz_bn_relu_bwd_reduce's
+ * workgroup row of `partial` ([uz_conv_igemm_grid_m()][2][Nout], the layout of uz_bn_relu_bwd_reduce's
  * workspace), sum(dz) and sum(dz * xhat) over its pixels with dz = y * [scale * bn_y + shift > 0] (y as stored,
  * i.e. rounded to the tensor dtype) and xhat = (bn_y - mean) * invstd: uz_bn_bwd_finalize() then stands in for
  * uz_bn_relu_bwd_reduce() and the activation gradient is not read a second time.  bf16 problems of the direct 3x3

@@ -55,7 +55,15 @@ CASES = [
     ("pp256w16", 4, 16, 16, 256, 384, 0, False),   # one 16 x 16 map per tile
     ("pp256w16", 3, 12, 14, 128, 136, 0, False),   # ragged 16 x 16 patches, channel tail
     ("pp256w16", 70, 16, 16, 64, 512, 0, False),   # 70 x 4 tiles: the grid is capped at 64 workgroups per N tile
+    # split-K (few tiles, many channel slabs: the slabs of a tile are dealt to several workgroups, fp32 partial tiles + a
+    # fixed-order reduce pass with bias and statistics)
+    ("pp256w16", 16, 16, 16, 1024, 512, 0, False),  # unet's 1024 -> 512 at 16 x 16, B = 16: 64 tiles, 32 slabs -> 4 ranges of 8
+    ("pp256w16", 16, 16, 16, 512, 1024, 0, False),  # 128 tiles: more than a quarter of the CUs -> not split
+    ("pp256", 2, 32, 32, 512, 256, 32, False),      # 16 tiles -> 4 ranges of 4 slabs; input window of a NaN-poisoned buffer
+    ("pp256w16", 2, 12, 14, 544, 136, 0, False),    # ragged patches, channel tail, 17 slabs -> ranges of 5 + 5 + 5 + 2
+    ("pp256", 1, 32, 64, 1024, 128, 0, True),       # upsampled input, 32 slabs -> 8 ranges
 ]
+SPLITK = {(16, 16, 16, 1024, 512): 4, (2, 32, 32, 512, 256): 4, (2, 12, 14, 544, 136): 4, (1, 32, 64, 1024, 128): 8}
 
 
 @pytest.mark.parametrize("cfg,N,H,W,Cin,Cout,win,ups", CASES)
@@ -77,6 +85,11 @@ def test_pp_conv3x3_fwd_bias_stats(cfg, N, H, W, Cin, Cout, win, ups):
     ywide = torch.full((N * H * W, Cout + 16), 7.0, dtype=dt, device=DEV)
     y = Act(ywide, 8, Cout, N, H, W)
     assert kernel_of(N, H, W, Cin, xa.ld, Cout, y.ld, ups) == f"conv3x3_{cfg}_bf16" + ("_up2" if ups else "")
+    d = L.ConvDesc(L.dtype_code(dt), N, H, W, Hi, Wi, Cin, xa.ld, Cout, y.ld, 9, L.TAPS_CONV_UP2 if ups else L.TAPS_CONV, 1,
+                   L.STORE_PLAIN, 0, 0, 0)
+    split = SPLITK.get((N, H, W, Cin, Cout), 1)
+    assert ops.conv_kernel_name(d, with_workspace=True).endswith("_splitk") == (split > 1)
+    assert L.load().uz_conv_igemm_workspace_bytes(byref(d)) == (split * N * H * W * Cout * 4 if split > 1 else 0)
     stats = ops.conv_igemm(xa, wp, b.to(DEV), y, ntaps=9, want_stats=True,
                            taps_mode=L.TAPS_CONV_UP2 if ups else L.TAPS_CONV)
     got = y.dense().cpu()
@@ -93,6 +106,35 @@ def test_pp_conv3x3_fwd_bias_stats(cfg, N, H, W, Cin, Cout, win, ups):
     stats2 = ops.conv_igemm(xa, wp, b.to(DEV), y2, ntaps=9, want_stats=True,
                             taps_mode=L.TAPS_CONV_UP2 if ups else L.TAPS_CONV)
     assert torch.equal(ywide, ywide2) and torch.equal(stats, stats2)
+    if split > 1:
+        # the same descriptor WITHOUT a workspace is the unsplit launch: same sum in another order -- at most one bf16
+        # rounding apart, nearly everywhere the identical number
+        y3 = ops.new_act(N, H, W, Cout, dt, DEV)
+        d3 = L.ConvDesc(L.dtype_code(dt), N, H, W, Hi, Wi, Cin, xa.ld, Cout, y3.ld, 9, L.TAPS_CONV_UP2 if ups else L.TAPS_CONV, 1,
+                        L.STORE_PLAIN, 0, 0, 0)
+        L.check(L.load().uz_conv_igemm(byref(d3), xa.ptr(), wp.data_ptr(), b.to(DEV).data_ptr(), y3.ptr(), None, L.stream_ptr()),
+                "uz_conv_igemm")
+        a3, a1 = y3.dense().cpu(), got
+        assert relerr(a1, a3) < 2.0 ** -7 and (a1 == a3).float().mean() > 0.97
+
+
+def test_pp_split_k_exact_on_small_integers():
+    """the split-K form on integer-valued operands (exact in fp32 whatever the order): equal to the fp32 reference"""
+    g = torch.Generator().manual_seed(24)
+    N, H, W, Cin, Cout = 16, 16, 16, 1024, 512
+    x = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float()
+    w = (torch.randint(-1, 2, (Cout, Cin, 3, 3), generator=g) * (torch.rand(Cout, Cin, 3, 3, generator=g) < 0.02)).float()
+    b = torch.randint(-3, 4, (Cout,), generator=g).float()
+    ref = F.conv2d(x, w, b, padding=1)
+    assert ref.abs().max() < 256
+    xa = act_from_nchw(x.to(DEV), dt)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt)
+    y = ops.new_act(N, H, W, Cout, dt, DEV)
+    d = L.ConvDesc(L.dtype_code(dt), N, H, W, H, W, Cin, xa.ld, Cout, y.ld, 9, L.TAPS_CONV, 1, L.STORE_PLAIN, 0, 0, 0)
+    assert ops.conv_kernel_name(d, with_workspace=True) == "conv3x3_pp256w16_bf16_splitk"
+    stats = ops.conv_igemm(xa, wp, b.to(DEV), y, ntaps=9, want_stats=True)
+    assert torch.equal(y.dense().cpu(), ref)
+    assert torch.equal(stats.double().sum(0)[0].cpu(), ref.double().sum((0, 2, 3)))
 
 
 def test_pp_conv3x3_exact_on_small_integers():
@@ -134,7 +176,10 @@ def test_pp_bn_backward_reduction_in_the_input_gradient_epilogue(N, H, W, C, Cn)
     vec = ops.bn_finalize(stats, N * H * W, gamma, beta, 1e-5, 0.1, torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV))
     g_plain = ops.new_act(N, H, W, Cn, dt, DEV)
     assert kernel_of(N, H, W, C, dyb.ld, Cn, g_plain.ld).startswith("conv3x3_pp")
-    ops.conv_igemm(dyb, wp, None, g_plain, ntaps=9)
+    # the plain launch WITHOUT a workspace: the unsplit kernel, whose summation order the fused epilogue shares (with a
+    # workspace the 16 x 16 case takes the split-K form: same sums, another order)
+    dpl = L.ConvDesc(L.dtype_code(dt), N, H, W, H, W, C, dyb.ld, Cn, g_plain.ld, 9, L.TAPS_CONV, 1, L.STORE_PLAIN, 0, 0, 0)
+    L.check(L.load().uz_conv_igemm(byref(dpl), dyb.ptr(), wp.data_ptr(), None, g_plain.ptr(), None, L.stream_ptr()), "uz_conv_igemm")
     g_fused = ops.new_act(N, H, W, Cn, dt, DEV)
     part = ops.conv_igemm(dyb, wp, None, g_fused, ntaps=9, bnred=(y, vec))
     assert part is not None and part.shape[1:] == (2, Cn)

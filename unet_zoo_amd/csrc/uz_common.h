@@ -111,6 +111,7 @@ static inline const char* uz_ablate_env(const char*) { return nullptr; }
 struct UzDirectPlan {
   int tw, bn, bres, th_n, tw_n, ntiles, tiles_n, grid_m;
   int ppcfg;   // bres == 3: the ping-pong configuration (UZ_PP_*)
+  int ksplit, cps;   // bres == 3: split-K plan of the ping-pong kernel (1: none)
 };
 int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p);
 // operands of the BatchNorm-backward reduction fused into the epilogue (uz_conv_igemm_bnred)
@@ -120,7 +121,8 @@ struct UzBnRed {
   const float *scale, *shift, *mean, *invstd;
 };
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
-                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br = nullptr);
+                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br = nullptr,
+                     float* part = nullptr);   // part: split-K partial tiles (ping-pong plans with ksplit > 1)
 
 // direct 3x3 convolution, ping-pong schedule on 512-pixel x 128-channel tiles (uz_conv3x3_pp.hip); uz_direct_plan()
 // hands the descriptors it takes over with bres = 3
@@ -130,10 +132,11 @@ enum { UZ_PP_512 = 0,      // 16 x 32 pixels x 128 channels
        UZ_PP_256W16 = 3 }; // 16 x 16 pixels x 128 channels
 struct UzPpPlan {
   int cfg, bn, th_n, tw_n, ntiles, tiles_n, grid_m;
+  int ksplit, cps;   // split-K over the channel slabs (only with a workspace): ksplit ranges of cps slabs
 };
 int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p);
 int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const void* w, const float* bias, void* y,
-                 float* stats, hipStream_t s, const UzBnRed* br = nullptr);
+                 float* stats, hipStream_t s, const UzBnRed* br = nullptr, float* part = nullptr);
 
 // 3x3 weight gradient with LDS-DMA pipeline (uz_wgrad3x3.hip), dispatched from uz_wgrad()
 struct UzWgrad2Plan {

@@ -954,6 +954,8 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
       p->ntiles = pp.ntiles;
       p->tiles_n = pp.tiles_n;
       p->grid_m = pp.grid_m;
+      p->ksplit = pp.ksplit;
+      p->cps = pp.cps;
       return 1;
     }
   }
@@ -1035,12 +1037,13 @@ static int direct_launch_t(const UzDirectPlan& p, const DirectArgs& a, hipStream
 }
 
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
-                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br) {
+                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br, float* part) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   if (p.bres == 3) {
-    UzPpPlan pp = {p.ppcfg, p.bn, p.th_n, p.tw_n, p.ntiles, p.tiles_n, p.grid_m};
-    return uz_pp_launch(d, pp, x, w, bias, y, stats, s, br);
+    UzPpPlan pp = {p.ppcfg, p.bn, p.th_n, p.tw_n, p.ntiles, p.tiles_n, p.grid_m, p.ksplit, p.cps};
+    return uz_pp_launch(d, pp, x, w, bias, y, stats, s, br, part);
   }
+  UZ_REQUIRE(part == nullptr, "uz_conv_igemm(direct3x3): split-K is the ping-pong kernel's");
   DirectArgs a;
   a.bn_y = br ? br->y : nullptr;
   a.bn_scale = br ? br->scale : nullptr;

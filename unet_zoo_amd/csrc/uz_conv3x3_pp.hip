@@ -53,6 +53,10 @@ struct PpArgs {
   const float* bn_mean;
   const float* bn_invstd;
   int ld_bny;
+  // split-K (template parameter SPLIT): blockIdx.z owns the channel slabs [z * cps, (z + 1) * cps) and writes its fp32
+  // partial tile to part[z][pixel][channel]; igemm_split_reduce_kernel adds them in fixed order (+ bias, statistics)
+  float* part;
+  int cps;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -175,8 +179,9 @@ template <int V> struct IntC { static constexpr int value = V; };
                       // 16 fragment reads in a tile's first phase only, 128 both groups in lockstep (timing only)
 #endif
 
-template <typename C, bool BNRED>
+template <typename C, bool BNRED, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
+  static_assert(!(BNRED && SPLIT), "the split-K form has no fused epilogue");
   typedef bf16_t T;
   constexpr int ES = 2, VEC = 8;
   constexpr int TH = C::TH, TW = C::TW, PH = C::PH, PHP = C::PHP, PROWS = C::PROWS, APIECES = C::APIECES, A_BYTES = C::A_BYTES;
@@ -269,13 +274,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
 
   // bias table (fp32, the channels of this workgroup): the accumulators' initial value
   float* const sBias = reinterpret_cast<float*>(smem + OFF_BIAS);
-  if (tid < BN) sBias[tid] = (!BNRED && a.bias != nullptr && n0 + tid < a.Nout) ? a.bias[n0 + tid] : 0.f;
+  if (tid < BN) sBias[tid] = (!BNRED && !SPLIT && a.bias != nullptr && n0 + tid < a.Nout) ? a.bias[n0 + tid] : 0.f;
   {   // running BatchNorm sums of this lane (channel chunk lane & 7 of the read-back phase): zero, in the staging strip
     f32x4* sp = reinterpret_cast<f32x4*>(smem + OFF_STG + wave * STG_W + lane * 64);
     sp[0] = sp[1] = sp[2] = sp[3] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   const int ncb = a.Cin / KU;
+  // the slabs of this workgroup: all of them, or (split-K: 16 x 16 bottleneck maps whose tiles fill a quarter of the chip)
+  // the z-th range of cps slabs
+  const int cbeg = SPLIT ? (int)blockIdx.z * a.cps : 0;
+  const int cend = SPLIT ? (cbeg + a.cps < ncb ? cbeg + a.cps : ncb) : ncb;
   // acc[pt][ct]: 16-pixel tile pt = HALVES * (patch row of the wave) + column half, 16-channel tile ct
   f32x4 acc[PT][CT];
   f32x4 fa[UPP][PT], fb[UPP][CT];
@@ -289,11 +298,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   if ((int)blockIdx.x < a.ntiles) {
     decode(blockIdx.x, img, h0, w0);
     compute_avoff(img, h0, w0);
-    issue_a(IntC<0>(), 0, 0); issue_a(IntC<1>(), 0, 0); issue_a(IntC<2>(), 0, 0);
-    issue_a(IntC<3>(), 0, 0); issue_a(IntC<4>(), 0, 0); issue_a(IntC<5>(), 0, 0);
+    issue_a(IntC<0>(), 0, cbeg); issue_a(IntC<1>(), 0, cbeg); issue_a(IntC<2>(), 0, cbeg);
+    issue_a(IntC<3>(), 0, cbeg); issue_a(IntC<4>(), 0, cbeg); issue_a(IntC<5>(), 0, cbeg);
     static_assert(APW <= 6, "prologue issues six halo pieces per wave");
 #pragma unroll
-    for (int u = 0; u < DPH; ++u) issue_b(u, 0, u);
+    for (int u = 0; u < DPH; ++u) issue_b(u, cbeg, u);
   }
   wait_vmcnt<0>();
   __syncthreads();
@@ -342,11 +351,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       sl = sl >= NSLOT ? sl - NSLOT : sl;
       if (!wrap) issue_b(sl, c, pn);
       else if (!last) issue_b(sl, c + 1, pn);
-      else if (has_next) issue_b(sl, 0, pn);
+      else if (has_next) issue_b(sl, cbeg, pn);
       // halo pieces of the next slab (of this tile, or slab 0 of the next tile: avoff then holds that tile's offsets)
       if (!nonext) {
         constexpr int k0 = C::na_before(p), kn = C::na(p);
-        const int cs = last ? 0 : c + 1;
+        const int cs = last ? cbeg : c + 1;
         if constexpr (kn > 0) issue_a(IntC<k0>(), apar ^ 1, cs);
         if constexpr (kn > 1) issue_a(IntC<k0 + 1>(), apar ^ 1, cs);
         if constexpr (kn > 2) issue_a(IntC<k0 + 2>(), apar ^ 1, cs);
@@ -411,6 +420,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     if (UZ_PP_SKEL & 8) {
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) asm volatile("" ::"v"(acc[pt][0]), "v"(acc[pt][1]), "v"(acc[pt][2]), "v"(acc[pt][3]));
+      return;
+    }
+    if constexpr (SPLIT) {
+      // raw fp32 partial tile: a lane holds 4 consecutive channels of pixel (patch row pt / HALVES, column 16 (pt % HALVES)
+      // + lane & 15) per accumulator -> one 16-byte store each; everything has left before the next tile's counted waits
+      int ls = lane;
+      asm volatile("" : "+v"(ls));
+      float* const pz = a.part + (size_t)blockIdx.z * ((size_t)a.N * a.H * a.W) * a.Nout;
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        const int hh = hh0 + ROWS_W * wm + pt / HALVES, ww = ww0 + (pt % HALVES) * 16 + (ls & 15);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int ch = n0 + wn * 64 + 16 * ct + 4 * (ls >> 4);
+          if (hh < a.H && ww < a.W && ch < a.Nout)
+            *reinterpret_cast<f32x4*>(pz + ((size_t)(im * a.H + hh) * a.W + ww) * a.Nout + ch) = acc[pt][ct];
+        }
+      }
+      wait_vmcnt<0>();
       return;
     }
     char* const stg = smem + OFF_STG + wave * STG_W;
@@ -518,8 +546,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     const bool has_next = next < a.ntiles;
     if (has_next) decode(next, nim, nh0, nw0);
 #pragma unroll 1
-    for (int c = 0; c < ncb; ++c) {
-      const bool first = c == 0, last = c == ncb - 1;
+    for (int c = cbeg; c < cend; ++c) {
+      const bool first = c == cbeg, last = c == cend - 1;
       // from the last slab on, the halo requests are those of the next tile's first patch
       if (last && has_next) compute_avoff(nim, nh0, nw0);
       if (first) phase(IntC<0>(), IntC<1>(), c, first, last, has_next);
@@ -545,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   }
 
   // ---- statistics: fixed-order sum over the lanes that own a channel chunk ---------------------------------------------------
-  if (a.stats != nullptr) {
+  if (!SPLIT && a.stats != nullptr) {
     wait_vmcnt<0>();
     __syncthreads();
     // thread `th` left its sums [2][VEC] at strip(th >> 6) + (th & 63) * 64
@@ -613,12 +641,39 @@ int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p) {
   int cap = UZ_NUM_CU / p->tiles_n;
   if (cap < 1) cap = 1;
   p->grid_m = p->ntiles < cap ? p->ntiles : cap;
+  // split-K: the 16 x 16 / 32 x 32 maps of a 256 x 256 input have 32 ... 128 tiles and 16 ... 32 channel slabs of nine taps
+  // each -- a quarter to a half of the chip walks a long K loop.  With a workspace (uz_conv_igemm_ws) the slabs are dealt
+  // to `ksplit` workgroups per tile.  Only where at least FOUR ranges fit (tiles <= a quarter of the CUs): measured on
+  // unet's 16 x 16 layers at B = 16, 1024 -> 512 (64 tiles, 4 ranges) 78.0 -> 47.1 us, but with two ranges the fp32 partial
+  // tiles and the reduce pass cost what the shorter K loop saves (512 -> 1024: 43.8 -> 47.8 us, 1024 -> 1024: 80.6 -> 72.3).
+  // Sized by the hardware's CU count, not by a CU reserve: the summation order, hence the rounding of the result, must
+  // not depend on that setting.
+  p->ksplit = 1;
+  p->cps = d->Cin / KU;
+  {
+    const long long tot = (long long)p->ntiles * p->tiles_n;
+    const int ncb = d->Cin / KU;
+    if ((cfg == UZ_PP_256 || cfg == UZ_PP_256W16) && tot * 4 <= UZ_NUM_CU_HW && ncb >= 16 && d->Nout % 8 == 0 &&
+        !(uz_tune_flags() & 0x40000000)) {
+      long long s = UZ_NUM_CU_HW / tot;
+      if (s > ncb / 4) s = ncb / 4;
+      if (s > 8) s = 8;
+      if (s >= 4) {
+        p->cps = (int)((ncb + s - 1) / s);
+        p->ksplit = (ncb + p->cps - 1) / p->cps;
+      }
+    }
+  }
   return 1;
 }
 
 int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const void* w, const float* bias, void* y,
-                 float* stats, hipStream_t s, const UzBnRed* br) {
+                 float* stats, hipStream_t s, const UzBnRed* br, float* part) {
   PpArgs a;
+  a.part = part;
+  a.cps = p.cps;
+  UZ_REQUIRE(part == nullptr || (br == nullptr && p.ksplit > 1 && (p.cfg == UZ_PP_256 || p.cfg == UZ_PP_256W16)),
+             "uz_conv_igemm(direct3x3 ping-pong): split-K launch without a split plan");
   a.x = x;
   a.w = w;
   a.y = y;
@@ -646,6 +701,13 @@ int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const 
   a.bn_invstd = br ? br->invstd : nullptr;
   a.ld_bny = br ? br->ldy : 0;
   if (br) UZ_REQUIRE(stats != nullptr, "uz_conv_igemm_bnred: partial rows missing");
+  if (part != nullptr) {   // every tile has its own ksplit workgroups (grid_m = ntiles <= 128 here)
+    dim3 gs(p.ntiles, p.tiles_n, p.ksplit);
+    if (p.cfg == UZ_PP_256) hipLaunchKernelGGL((conv3x3_pp_kernel<Cfg256, false, true>), gs, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_pp_kernel<Cfg256w16, false, true>), gs, dim3(512), 0, s, a);
+    UZ_LAUNCH_CHECK("uz_conv_igemm(direct3x3 ping-pong, split-K)");
+    return UZ_OK;
+  }
   dim3 grid(p.grid_m, p.tiles_n), block(512);
 #define UZ_PP_GO(CFG)                                                                          \
   do {                                                                                         \

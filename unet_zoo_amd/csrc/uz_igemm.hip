@@ -357,6 +357,23 @@ struct Plan {
   int rbx, rby, rgx, rgy;  // reduce kernel launch shape
 };
 
+// launch geometry of igemm_split_reduce_kernel for an (M, Nout) result (sized by the hardware's CU count: the number of
+// statistics rows it writes, and with it the order in which uz_bn_finalize adds them, must not follow a CU reserve)
+void reduce_geometry(long long M, int Nout, int vec, Plan* p) {
+  const int CC = Nout / vec;
+  int bx = 1;
+  while (bx < CC && bx < 64) bx <<= 1;
+  p->rbx = bx;
+  p->rby = 256 / bx;
+  p->rgy = (CC + bx - 1) / bx;
+  long long gx = (M + p->rby * 4 - 1) / (p->rby * 4);
+  long long capx = (long long)UZ_NUM_CU_HW * 2 / p->rgy;
+  if (capx < 1) capx = 1;
+  if (gx > capx) gx = capx;
+  if (gx < 1) gx = 1;
+  p->rgx = (int)gx;
+}
+
 int make_plan(const uz_conv_desc* d, Plan* p) {
   UZ_REQUIRE(d != nullptr, "uz_conv_igemm: null descriptor");
   UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "uz_conv_igemm: bad dtype %d", d->dtype);
@@ -418,18 +435,7 @@ int make_plan(const uz_conv_desc* d, Plan* p) {
       p->tiles_m * p->tiles_n <= UZ_NUM_CU / 2 && d->Nout % vec_ == 0 && d->ldy % vec_ == 0 &&
       !(uz_tune_flags() & 8)) {
     p->split = 9;
-    const int CC = d->Nout / vec_;
-    int bx = 1;
-    while (bx < CC && bx < 64) bx <<= 1;
-    p->rbx = bx;
-    p->rby = 256 / bx;
-    p->rgy = (CC + bx - 1) / bx;
-    long long gx = (M + p->rby * 4 - 1) / (p->rby * 4);
-    long long capx = (long long)UZ_NUM_CU * 2 / p->rgy;
-    if (capx < 1) capx = 1;
-    if (gx > capx) gx = capx;
-    if (gx < 1) gx = 1;
-    p->rgx = (int)gx;
+    reduce_geometry(M, d->Nout, vec_, p);
   }
   return UZ_OK;
 }
@@ -485,7 +491,7 @@ extern "C" int uz_conv_igemm_kernel_name(const uz_conv_desc* d, int with_workspa
   if (uz_direct_plan(d, &dp)) {
     const char* up = d->taps_mode == UZ_TAPS_CONV_UP2 ? "_up2" : "";
     static const char* const ppn[4] = {"pp512", "pp512x64", "pp256", "pp256w16"};
-    if (dp.bres == 3) snprintf(name, sizeof(name), "conv3x3_%s_%s%s", ppn[dp.ppcfg & 3], dt, up);
+    if (dp.bres == 3) snprintf(name, sizeof(name), "conv3x3_%s_%s%s%s", ppn[dp.ppcfg & 3], dt, up, (dp.ksplit > 1 && with_workspace) ? "_splitk" : "");
     else if (dp.bres == 2) snprintf(name, sizeof(name), "conv3x3_res64_%s%s", dt, up);
     else snprintf(name, sizeof(name), "conv3x3_direct_%s_bn%d%s%s", dt, dp.bn, dp.bres == 1 ? "_resident" : "", up);
   } else if (uz_gemm_dma_plan(d, &gp)) {
@@ -502,6 +508,11 @@ extern "C" long long uz_conv_igemm_workspace_bytes(const uz_conv_desc* d) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
+  {
+    UzDirectPlan dp;
+    if (uz_direct_plan(d, &dp) && dp.bres == 3 && dp.ksplit > 1)   // split-K ping-pong convolution
+      return (long long)dp.ksplit * d->N * d->H * d->W * d->Nout * (long long)sizeof(float);
+  }
   if (p.split <= 1 || !generic_path(d)) return 0;
   return (long long)p.split * d->N * d->H * d->W * d->Nout * (long long)sizeof(float);
 }
@@ -510,6 +521,14 @@ extern "C" int uz_conv_igemm_ws_grid_m(const uz_conv_desc* d) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
+  {
+    UzDirectPlan dp;
+    if (uz_direct_plan(d, &dp) && dp.bres == 3 && dp.ksplit > 1) {   // the statistics rows come from the reduce pass
+      Plan rp;
+      reduce_geometry((long long)d->N * d->H * d->W, d->Nout, 8, &rp);
+      return rp.rgx;
+    }
+  }
   if (p.split > 1 && generic_path(d)) return p.rgx;
   return uz_conv_igemm_grid_m(d);
 }
@@ -581,8 +600,24 @@ extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void
   UZ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 15) == 0,
              "uz_conv_igemm: x / w / y must be 16-byte aligned");
   UzDirectPlan dp;
-  if (uz_direct_plan(d, &dp))
+  if (uz_direct_plan(d, &dp)) {
+    if (dp.bres == 3 && dp.ksplit > 1 && workspace != nullptr) {
+      // split-K ping-pong convolution: fp32 partial tiles, then the fixed-order reduce + bias + statistics pass
+      hipStream_t s = static_cast<hipStream_t>(stream);
+      const int r1 = uz_direct_launch(d, dp, x, w_packed, nullptr, y, nullptr, s, nullptr, static_cast<float*>(workspace));
+      if (r1 != UZ_OK) return r1;
+      Plan rp;
+      const long long M = (long long)d->N * d->H * d->W;
+      reduce_geometry(M, d->Nout, 8, &rp);
+      const size_t shm = (size_t)256 * 2 * 8 * sizeof(float);
+      hipLaunchKernelGGL((igemm_split_reduce_kernel<bf16_t>), dim3(rp.rgx, rp.rgy), dim3(rp.rbx, rp.rby), shm, s,
+                         static_cast<const float*>(workspace), dp.ksplit, (int)M, d->Nout, bias, static_cast<bf16_t*>(y), d->ldy,
+                         stats_partial);
+      UZ_LAUNCH_CHECK("uz_conv_igemm(split-K reduce)");
+      return UZ_OK;
+    }
     return uz_direct_launch(d, dp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));
+  }
   UzGemmPlan gp;
   if (uz_gemm_dma_plan(d, &gp))
     return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));

@@ -253,7 +253,7 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         if not lib.uz_conv_igemm_bnred_supported(byref(d)) or (bn_y.P, bn_y.C) != (y.P, y.C):
             bnred = None
         else:
-            gm = L.check_count(lib.uz_conv_igemm_ws_grid_m(byref(d)), "uz_conv_igemm_ws_grid_m")
+            gm = L.check_count(lib.uz_conv_igemm_grid_m(byref(d)), "uz_conv_igemm_grid_m")     # the unsplit launch's rows
             part = torch.empty((gm, 2, d.Nout), dtype=torch.float32, device=x.buf.device)
             with _Timed(kname + "_bnred", 2.0 * M * d.Nout * K, es * (x.P * x.C + 2 * M * d.Nout + d.Nout * K)):
                 L.check(lib.uz_conv_igemm_bnred(byref(d), x.ptr(), w_packed.data_ptr(), y.ptr(), bn_y.ptr(), bn_y.ld,
