@@ -48,6 +48,33 @@ PEAK = {"mfma_bf16_tflops": 2500.0, "mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}
 
 _LOSS_IMPL = "hip"
 
+# Kernel family (the library's own names: uz_conv_igemm_kernel_name / uz_wgrad_kernel_name) -> substrings of the kernel
+# symbols rocprofv3 reports for it.  The PMC table (tools/pmc_traffic.py) is keyed by symbol; a family matches every symbol
+# that contains one of its substrings (all epilogue variants of a ping-pong configuration share the `PpCfg<...>` prefix).
+# tests/test_bench_contract.py checks that every entry resolves in the newest committed profiles/r*_pmc_traffic.json.
+PMC_KEYS = {
+    "conv3x3_pp512_bf16": ("PpCfg<16, 32, 4, 2, 1>",),
+    "conv3x3_pp512x64_bf16": ("PpCfg<16, 32, 8, 1, 3>",),
+    "conv3x3_pp256_bf16": ("PpCfg<8, 32, 4, 2, 3>",),
+    "conv3x3_pp256w16_bf16": ("PpCfg<16, 16, 4, 2, 3>",),
+    "wgrad9_bf16_128x64_rowwalk": ("wgrad9_kernel<128,",),
+    "wgrad9_bf16_64x64_rowwalk": ("wgrad9_kernel<64,",),
+    "wgrad3x3_bf16_128x128_3tap": ("wgrad3x3_kernel<128, 128, 1, 3,",),
+    "wgrad3x3_bf16_128x128_gather4": ("wgrad3x3_kernel<128, 128, 1, 1,",),
+}
+
+
+def newest_pmc_file(root: str = None):
+    """profiles/rNN_pmc_traffic.json with the highest round number, or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(root or ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return files[-1] if files else None
+
+
+def pmc_rows(family: str, pmc_kernels: dict) -> list:
+    keys = PMC_KEYS.get(family, ())
+    return [v for k, v in pmc_kernels.items() if any(c in k for c in keys)]
+
 
 def torch_criterion(out, mask):
     """nn.BCEWithLogitsLoss as the reference applies it (scripts/train.py:135; dict outputs: training_loop.py:60-64)"""
@@ -211,6 +238,33 @@ def time_graphed(gs, x, mask, steps, warmup, distributed, dev):
     return elapsed, time.perf_counter() - t1
 
 
+def second_headline(dev, steps: int, warmup: int, cpu_steps: int, with_cpu: bool, loss_impl: str):
+    """The north star's second model on the same GPU, same process, after the headline measurement: swin_unet_v2
+    (image_size 256, window 8) B = 16, whole train step from hipGraphs, with its own CPU baseline (oracle, same batch)."""
+    name, B, hw = "swin_unet_v2", 16, 256
+    torch.manual_seed(0)
+    m, kw = make_model(name, hw)
+    m.run_dtype = torch.bfloat16
+    m = m.to(dev).train()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, hw, hw, generator=g).to(dev)
+    mask = (torch.rand(B, 1, hw, hw, generator=g) > 0.5).float().to(dev)
+    gs = GraphedStep(m, "bce_dice" if loss_impl == "hip" else torch_criterion, lr=1e-4, weight_decay=1e-5, max_norm=1.0)
+    elapsed, fb_s = time_graphed(gs, x, mask, steps, warmup, False, dev)
+    out = {"metric": f"images/sec (fwd+bwd) {name} B={B} 3x{hw}x{hw} (window {kw['window_size']}), 1 MI355X",
+           "value": round(B * steps / elapsed, 2), "unit": "images/sec", "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "dtype": "bf16", "data": "synthetic",
+           "fwd_bwd_ms": round(fb_s / steps * 1e3, 3), "loss": round(float(gs.loss.item()), 5), "launch": gs.describe(),
+           "config": {"workload": f"{name} train step (zero_grad+fwd+BCE+bwd+clip+AdamW), B={B} 3x{hw}x{hw}, "
+                                  f"stochastic depth as in the reference's training mode, random-init weights"}}
+    del gs, m
+    torch.cuda.empty_cache()
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(B, hw, cpu_steps, name)
+        out["vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
@@ -227,7 +281,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=None,
                     help="batch of the CPU baseline (default: the configuration's own batch, capped at 16 -- unet B=16: "
                          "~6 s per step on the 16 host threads of a one-GPU box)")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU steps after one warm-up (median)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up (median; BASELINE.md section 4: >= 3)")
     ap.add_argument("--graph", default="on", choices=["on", "off"],
                     help="on: unet_zoo_amd.GraphedStep (hipGraph replays); off: eager launches through autograd + "
                          "torch's clip_grad_norm_ / AdamW (with N > 1: the bucket reducer of RcclDataParallel)")
@@ -248,6 +302,9 @@ def main():
                          "torch = F.binary_cross_entropy_with_logits, evaluated eagerly between the graphs")
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="eager steps with per-launch HIP events, run after the timed region")
+    ap.add_argument("--second-steps", type=int, default=20,
+                    help="N=1 default workload only: after the headline, time this many steps of swin_unet_v2 B=16 256x256 "
+                         "(the north star's second model) in the same process -> `second_headline`; 0 = skip")
     ap.add_argument("--fp32-steps", type=int, default=10,
                     help="N=1, bf16 runs: also time this many steps of the SAME model in the fp32 run mode (the "
                          "mode that meets the 1e-3 parity bound) and report fp32_images_per_s; 0 = skip")
@@ -428,27 +485,18 @@ def main():
         # prescribes for gfx950) -- counters cannot be read from inside this process
         traffic = None
         try:
-            pmc_file = next(n for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
-                            if os.path.exists(os.path.join(ROOT, "profiles", n)))
-            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+            pmc_path = newest_pmc_file()
+            with open(pmc_path) as f:
                 pmc = json.load(f)["kernels"]
-            # (the family names are the library's own, uz_conv_igemm_kernel_name(); the PMC table is keyed by kernel symbol;
-            # both epilogue variants of a ping-pong configuration belong to the kernel)
-            keys = {"conv3x3_pp512_bf16": ("PpCfg<16, 32, 4, 2, 1>, false>", "PpCfg<16, 32, 4, 2, 1>, true>"),
-                    "conv3x3_pp512x64_bf16": ("PpCfg<16, 32, 8, 1, 3>, false>", "PpCfg<16, 32, 8, 1, 3>, true>"),
-                    "conv3x3_pp256_bf16": ("PpCfg<8, 32, 4, 2, 3>, false>", "PpCfg<8, 32, 4, 2, 3>, true>"),
-                    "conv3x3_direct_bf16_bn128": ("21conv3x3_direct_kernelIDF16bLi32ELi128ELb0ELb0EEEvNS_10DirectArgsE",
-                                                  "21conv3x3_direct_kernelIDF16bLi32ELi128ELb0EEEvNS_10DirectArgsE"),
-                    "wgrad3x3_bf16_128x128_3tap": ("wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1, 0>",
-                                                   "wgrad3x3_kernel<128, 128, 1, 3, 2, 4, 1>")}.get(dom_name, ())
-            rows = [pmc[k] for k in pmc if any(c in k for c in keys)]
+            # (both epilogue variants of a ping-pong configuration belong to the kernel: their symbols share the prefix)
+            rows = pmc_rows(dom_name, pmc)
             if rows and args.model == "unet" and args.size == 256 and args.batch == 16:
                 n = sum(r["launches"] for r in rows)
                 traffic = {"hbm_read_mb_per_launch": round(sum(r["hbm_read_mb_per_launch_corrected"] * r["launches"] for r in rows) / n, 2),
                            "hbm_write_mb_per_launch": round(sum(r["hbm_write_mb_per_launch"] * r["launches"] for r in rows) / n, 2),
                            "algorithmic_mb_per_launch": round(dom["bytes"] / dom["launches"] / 2 ** 20, 2),
-                           "source": f"profiles/{pmc_file}"}
-        except (OSError, KeyError, ValueError, StopIteration):
+                           "source": "profiles/" + os.path.basename(pmc_path)}
+        except (OSError, KeyError, ValueError, TypeError):
             pass
         if dom is not None:
             flops_per_launch = dom["flops"] / dom["launches"]
@@ -489,8 +537,29 @@ def main():
             "device": {"before_timed_steps": dev_before, "after_timed_steps": dev_after, "mfma_clock": mfma_clock},
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }
+        # the north star's block-level line: unet level 1 DoubleConv forward (im2col + both convolutions + BatchNorm
+        # finalize / apply + ReLU + pool) as the eager profile steps timed it, against SURVEY 8d's floor
+        # s * P * (Cin + 3 * Cout) + weights (409 MB at B = 16 256 x 256 bf16) and 8 TB/s
+        sc = ops.profile_scopes().get("doubleconv_l1")
+        if sc and args.model == "unet" and args.profile_steps > 0:
+            P_, es_ = args.batch * args.size * args.size, (2 if run_dtype == torch.bfloat16 else 4)
+            alg = es_ * P_ * (3 + 3 * 64) + 4 * (9 * 3 * 64 + 64 + 9 * 64 * 64 + 64)
+            us = sc["ms"] / nprof * 1e3
+            line["doubleconv_l1"] = {
+                "block": "unet down_convolution_1: DoubleConv(3->64->64, train BN, ReLU) + MaxPool, forward",
+                "algorithmic_mb": round(alg / 1e6, 1), "us": round(us, 1), "launches": sc["launches"] // nprof,
+                "achieved_gbs": round(alg / us / 1e3, 1), "peak_gbs": PEAK["hbm_gbs"],
+                "frac": round(alg / us / 1e3 / PEAK["hbm_gbs"], 4),
+                "kernels_us": {k: round(v / nprof * 1e3, 1) for k, v in sorted(sc["kernels"].items())}}
         if fp32 is not None:
             line.update(fp32)
+        if (world == 1 and not distributed and args.second_steps > 0 and args.graph == "on" and args.dtype == "bf16"
+                and (args.model, args.size, args.batch) == ("unet", 256, 16)):
+            try:
+                line["second_headline"] = second_headline(dev, args.second_steps, args.warmup, args.cpu_steps,
+                                                          not args.no_cpu_baseline, args.loss)
+            except Exception as e:      # noqa: BLE001  (the headline line must not be lost over the second one)
+                line["second_headline"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             cpu_b = args.cpu_batch if args.cpu_batch else min(args.batch, 16)
             cb = cpu_baseline(cpu_b, args.size, args.cpu_steps, args.model)

@@ -179,6 +179,9 @@ int uz_wgrad_split(const uz_wgrad_desc* d);
 long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d); /* <0 on error */
 int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace,
              void* stream);
+/* The kernel family the library's plan launches for this descriptor, written to buf (labels of per-kernel measurements;
+ * e.g. "wgrad9_bf16_128x64_rowwalk": nine taps per workgroup, uz_wgrad9.hip).  Returns the length, <0 on error. */
+int uz_wgrad_kernel_name(const uz_wgrad_desc* d, char* buf, int cap);
 /* `batch` independent one-tap problems of the shape `d` in one launch pair: problem b reads L + b * lb, R + b * rb
  * (strides in elements, multiples of 16 bytes) and writes out + b * ob floats -- the per-image products of the token
  * attention that contract over the rows of both operands (dV_b = A_b^T dO_b, dK_b = dS_b^T Q_b,

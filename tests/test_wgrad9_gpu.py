@@ -1,0 +1,157 @@
+"""GPU: the row-walk nine-tap weight-gradient kernel (unet_zoo_amd/csrc/uz_wgrad9.hip) through the C ABI, asserted BY NAME
+through uz_wgrad_kernel_name(), against autograd's weight gradient of F.conv2d (what loss.backward() computes for
+unet_zoo/models/common_layers.py:28,31) on bf16-rounded operands: 2e-2 of the tensor's max on random data, EXACT on small
+integers (every product and every partial sum is then representable, so any wrong / missing / doubled pixel shows).
+Covers each strip width (W = 16, 32, 64, several strips per row), both channel tiles, channel tails, operands that are
+windows of wider NaN-poisoned buffers, the nearest-x2-upsampled x operand, segment starts inside a workgroup's range,
+image borders and bitwise repeatability."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from unet_zoo_amd import _lib as L
+from unet_zoo_amd import ops
+from unet_zoo_amd.ops import Act, act_from_nchw
+
+DEV = "cuda"
+dt = torch.bfloat16
+
+
+def relerr(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+def ref_wgrad(x, dy, up=False):
+    w = torch.zeros(dy.shape[1], x.shape[1], 3, 3, requires_grad=True)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    F.conv2d(xin, w, None, padding=1).backward(dy)
+    return w.grad
+
+
+def kname(dya, xa, mode=L.TAPS_CONV):
+    d = L.WgradDesc(L.dtype_code(dt), dya.N, dya.H, dya.W, xa.H, xa.W, dya.C, dya.ld, xa.C, xa.ld, 9, mode, 1)
+    return ops.wgrad_kernel_name(d)
+
+
+SHAPES = [
+    # N, H, W, Cin, Cout
+    (2, 16, 64, 64, 64),      # 64 x 64 tile, one strip, one row per step
+    (1, 8, 128, 128, 128),    # 128 x 64 tile, two strips per row: real halo columns between the strips
+    (1, 6, 256, 32, 64),      # four strips; x channels < 64 (tail of the x tile)
+    (2, 16, 32, 128, 128),    # W = 32: two rows per step, two x tiles
+    (2, 16, 16, 256, 128),    # W = 16: four rows per step, four images' worth of segment starts
+    (3, 16, 16, 64, 320),     # three dy tiles of 128 (the last one a 64-channel tail), odd image count
+    (1, 64, 64, 72, 40),      # channel tails on both operands (multiples of 8 only)
+    (5, 8, 64, 64, 64),       # segments (8 steps) shorter than a workgroup's range: starts in mid-range
+    (1, 128, 64, 192, 64),    # x tiles 3 x dy tile 1, long walk
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", SHAPES)
+def test_rowwalk_against_autograd(N, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(H * 1000 + W + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dt).float()
+    dy = torch.randn(N, Cout, H, W, generator=g).to(dt).float()
+    ref = ref_wgrad(x, dy)
+    dya, xa = act_from_nchw(dy.to(DEV), dt), act_from_nchw(x.to(DEV), dt)
+    assert kname(dya, xa).startswith("wgrad9_bf16_" + ("128x64" if Cout > 64 else "64x64"))
+    got = ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9)
+    assert relerr(got.cpu(), ref) < 2e-2
+    again = ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9)
+    assert torch.equal(got, again), "two launches on the same bytes differ"
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (1, 8, 128, 128, 128), (2, 16, 32, 128, 128),
+                                            (2, 16, 16, 128, 128), (1, 32, 128, 40, 72)])
+def test_rowwalk_exact_on_integers(N, H, W, Cin, Cout):
+    """operands in {-2..2}: |sum| < 2^24, so fp32 accumulation in any order is exact and the result must EQUAL autograd's"""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float()
+    dy = torch.randint(-2, 3, (N, Cout, H, W), generator=g).float()
+    ref = ref_wgrad(x, dy)
+    dya, xa = act_from_nchw(dy.to(DEV), dt), act_from_nchw(x.to(DEV), dt)
+    assert kname(dya, xa).startswith("wgrad9_")
+    got = ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9).cpu()
+    bad = (got != ref).nonzero()
+    assert bad.numel() == 0, f"{bad.shape[0]} elements differ, first (co, ci, ty, tx) = {bad[0].tolist()}: {got[tuple(bad[0])]} vs {ref[tuple(bad[0])]}"
+
+
+def test_rowwalk_border_taps_see_zero_padding():
+    """an all-ones problem counts the pixels every tap sees: H*W for the centre, (H-1)*W / H*(W-1) / (H-1)*(W-1) for the
+    edge and corner taps -- the zero padding of rows -1, H and columns -1, W, per image and per strip"""
+    N, H, W, C = 3, 16, 128, 64
+    x = torch.ones(N, C, H, W)
+    dy = torch.ones(N, C, H, W)
+    got = ops.wgrad(act_from_nchw(dy.to(DEV), dt), act_from_nchw(x.to(DEV), dt), (C, C, 3, 3), ntaps=9).cpu()
+    rows = torch.tensor([H - 1, H, H - 1]).float()
+    cols = torch.tensor([W - 1, W, W - 1]).float()
+    want = (N * rows[:, None] * cols[None, :]).expand(C, C, 3, 3)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (1, 16, 32, 96, 192)])
+def test_rowwalk_channel_windows_of_poisoned_buffers(N, H, W, Cin, Cout):
+    """both operands are channel windows of wider buffers whose other channels are NaN (concat slots)"""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dt).float()
+    dy = torch.randn(N, Cout, H, W, generator=g).to(dt).float()
+    ref = ref_wgrad(x, dy)
+    P = N * H * W
+    xw = torch.full((P, Cin + 96), float("nan"), dtype=dt, device=DEV)
+    xw[:, 64:64 + Cin] = act_from_nchw(x.to(DEV), dt).buf
+    dw_ = torch.full((P, Cout + 40), float("nan"), dtype=dt, device=DEV)
+    dw_[:, 8:8 + Cout] = act_from_nchw(dy.to(DEV), dt).buf
+    dya, xa = Act(dw_, 8, Cout, N, H, W), Act(xw, 64, Cin, N, H, W)
+    assert kname(dya, xa).startswith("wgrad9_")
+    got = ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9)
+    assert torch.isfinite(got).all()
+    assert relerr(got.cpu(), ref) < 2e-2
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (1, 32, 32, 128, 128), (1, 16, 128, 64, 192)])
+def test_rowwalk_upsampled_x(N, H, W, Cin, Cout):
+    """UpConvBlock (attention_unet.py:16-29): x lives at (H/2, W/2) and is read through nearest x2 upsampling"""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randint(-2, 3, (N, Cin, H // 2, W // 2), generator=g).float()
+    dy = torch.randint(-2, 3, (N, Cout, H, W), generator=g).float()
+    ref = ref_wgrad(x, dy, up=True)
+    dya, xa = act_from_nchw(dy.to(DEV), dt), act_from_nchw(x.to(DEV), dt)
+    assert kname(dya, xa, L.TAPS_CONV_UP2).startswith("wgrad9_")
+    got = ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9, taps_mode=L.TAPS_CONV_UP2).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_plan_keeps_the_round3_kernels_where_they_measured_faster():
+    """uz_wgrad9_plan's exceptions (dy twice as wide as x on a small map; 64 dy channels against >= 128 x channels) still
+    run on uz_wgrad3x3.hip and still agree with autograd"""
+    for (N, H, W, Cin, Cout) in [(1, 8, 128, 64, 128), (1, 16, 64, 128, 64)]:
+        g = torch.Generator().manual_seed(5)
+        x = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float()
+        dy = torch.randint(-2, 3, (N, Cout, H, W), generator=g).float()
+        dya, xa = act_from_nchw(dy.to(DEV), dt), act_from_nchw(x.to(DEV), dt)
+        assert kname(dya, xa).startswith("wgrad3x3_bf16_")
+        assert torch.equal(ops.wgrad(dya, xa, (Cout, Cin, 3, 3), ntaps=9).cpu(), ref_wgrad(x, dy))
+
+
+def test_rowwalk_full_size_layer_properties():
+    """unet's 64 -> 64 layer at BASELINE configs[1] size (B = 16, 256 x 256): linearity in dy (a size-independent property:
+    dW(dy1 + dy2) = dW(dy1) + dW(dy2), exact on integers) and agreement with autograd on a corner block of channels"""
+    N, H, W, C = 16, 256, 256, 64
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randint(-1, 2, (N * H * W, C), generator=g, device=DEV).to(dt)
+    d1 = torch.randint(-1, 2, (N * H * W, C), generator=g, device=DEV).to(dt)
+    d2 = torch.randint(-1, 2, (N * H * W, C), generator=g, device=DEV).to(dt)
+    xa = Act(x, 0, C, N, H, W)
+    w1 = ops.wgrad(Act(d1, 0, C, N, H, W), xa, (C, C, 3, 3), ntaps=9)
+    w2 = ops.wgrad(Act(d2, 0, C, N, H, W), xa, (C, C, 3, 3), ntaps=9)
+    w12 = ops.wgrad(Act((d1.float() + d2.float()).to(dt), 0, C, N, H, W), xa, (C, C, 3, 3), ntaps=9)
+    assert torch.equal(w12, w1 + w2)
+    # 8 x 8 channels of the first two images against torch on the GPU (fp32 conv2d of integers is exact)
+    xs = x.view(N, H, W, C)[:2, :, :, :8].permute(0, 3, 1, 2).float()
+    ds = d1.view(N, H, W, C)[:2, :, :, :8].permute(0, 3, 1, 2).float()
+    sub = ops.wgrad(act_from_nchw(ds, dt), act_from_nchw(xs, dt), (8, 8, 3, 3), ntaps=9)
+    wz = torch.zeros(8, 8, 3, 3, device=DEV, requires_grad=True)
+    F.conv2d(xs, wz, None, padding=1).backward(ds)
+    assert torch.equal(sub, wz.grad)

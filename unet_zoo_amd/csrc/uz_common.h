@@ -142,7 +142,12 @@ int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const 
 struct UzWgrad2Plan {
   int big, one_tap, gather, kw, kr, tiles_i, tiles_j, kg, units, upb, split, nslabs, H, W;
   int wide9;   // nine taps on a 128 (dy) x 64 (x) channel tile
+  int v9, bi;  // v9 = 1: the row-walk nine-tap kernel of uz_wgrad9.hip on bi x 64 channel tiles takes the descriptor
 };
+// row-walk nine-tap weight gradient (uz_wgrad9.hip); uz_wgrad3x3_plan() tries it first
+int uz_wgrad9_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
+int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, hipStream_t s);
+const char* uz_wgrad9_name(const UzWgrad2Plan& p);
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch = 1);   // batch > 1: uz_wgrad_batched (one-tap only)
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
                        float* slab, hipStream_t s, int batch = 1, long long lb_bytes = 0, long long rb_bytes = 0,

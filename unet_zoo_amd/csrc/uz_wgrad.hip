@@ -345,6 +345,27 @@ extern "C" int uz_wgrad_split(const uz_wgrad_desc* d) {
   return p.split;
 }
 
+extern "C" int uz_wgrad_kernel_name(const uz_wgrad_desc* d, char* buf, int cap) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(buf != nullptr && cap > 0, "uz_wgrad_kernel_name: no buffer");
+  UzWgrad2Plan p2;
+  const char* dt = d->dtype == UZ_BF16 ? "bf16" : "fp32";
+  int n;
+  if (!uz_wgrad3x3_plan(d, &p2)) {
+    n = snprintf(buf, cap, "wgrad_%s_%dx%d", dt, p.b, p.b);
+  } else if (p2.v9) {
+    n = snprintf(buf, cap, "%s", uz_wgrad9_name(p2));
+  } else {
+    const char* tile = p2.wide9 == 1 ? "128x64" : (p2.wide9 == 2 ? "64x128" : (p2.big ? "128x128" : "64x64"));
+    if (p2.gather) n = snprintf(buf, cap, "wgrad3x3_bf16_%s_gather%d", tile, d->ntaps);
+    else if (p2.one_tap) n = snprintf(buf, cap, "wgrad3x3_bf16_%s_1tap", tile);
+    else n = snprintf(buf, cap, "wgrad3x3_bf16_%s_%s", tile, (p2.big && !p2.wide9) ? "3tap" : "9tap");
+  }
+  return n < cap ? n : cap - 1;
+}
+
 extern "C" long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d) {
   Plan p;
   const int rc = make_plan(d, &p);

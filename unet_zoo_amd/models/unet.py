@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import ops
 from ..engine import Engine
 from ..graph import HipModule
 from .blocks import DoubleConv, DownSample, OutConv, UpSample_UNet
@@ -43,12 +44,17 @@ class UNet(HipModule):
         widths = (64, 128, 256, 512)
 
         cats = []
-        cur = eng.input_im2col(x)
+        with ops.profile_scope("doubleconv_l1"):   # (label of bench.py's block-level figure; no effect outside a profile)
+            cur = eng.input_im2col(x)
         for lvl, (down, c) in enumerate(zip(downs, widths)):
             h, w = H >> lvl, W >> lvl
             full, (up_slot, skip_slot) = eng.new_cat(N, h, w, (c, c))  # cat([up, skip], 1)
             cats.append((full, up_slot))
-            _, cur = down.emit(eng, cur, skip_slot, im2col=(lvl == 0))
+            if lvl == 0:
+                with ops.profile_scope("doubleconv_l1"):
+                    _, cur = down.emit(eng, cur, skip_slot, im2col=True)
+            else:
+                _, cur = down.emit(eng, cur, skip_slot, im2col=False)
         cur, _ = self.bottle_neck.emit(eng, cur)
         for lvl in (3, 2, 1, 0):
             full, up_slot = cats[lvl]

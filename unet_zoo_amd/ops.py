@@ -111,6 +111,30 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 # kernel, grouped by kernel family, with the algorithmic flops / bytes of exactly those launches.
 _prof_on = False
 _prof_log: list = []
+_prof_scope = None          # label of the model block being emitted (profile_scope), None outside
+_prof_scopes: dict = {}     # {label: {"ms", "launches"}} of the last profile_end()
+
+
+class profile_scope:
+    """with profile_scope("doubleconv_l1"): ... -- the timed launches inside also count towards that label
+    (profile_scopes() after profile_end()); bench.py's block-level figure for the north-star DoubleConv"""
+
+    def __init__(self, label: str):
+        self.label = label
+
+    def __enter__(self):
+        global _prof_scope
+        self.prev, _prof_scope = _prof_scope, self.label
+        return self
+
+    def __exit__(self, *exc):
+        global _prof_scope
+        _prof_scope = self.prev
+        return False
+
+
+def profile_scopes() -> dict:
+    return dict(_prof_scopes)
 
 
 def profile_begin() -> None:
@@ -125,12 +149,19 @@ def profile_end() -> dict:
     _prof_on = False
     torch.cuda.synchronize()
     out: dict = {}
-    for name, e0, e1, fl, by in _prof_log:
+    _prof_scopes.clear()
+    for name, e0, e1, fl, by, scope in _prof_log:
         d = out.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-        d["ms"] += e0.elapsed_time(e1)
+        ms = e0.elapsed_time(e1)
+        d["ms"] += ms
         d["launches"] += 1
         d["flops"] += fl
         d["bytes"] += by
+        if scope is not None:
+            sd = _prof_scopes.setdefault(scope, {"ms": 0.0, "launches": 0, "kernels": {}})
+            sd["ms"] += ms
+            sd["launches"] += 1
+            sd["kernels"][name] = sd["kernels"].get(name, 0.0) + ms
     _prof_log.clear()
     return out
 
@@ -158,7 +189,7 @@ class _Timed:
             n = L.load().uz_profile_disarm()
             if n == 0:          # nothing was launched through the library inside this scope: plain bracket
                 self.e1.record()
-            _prof_log.append((self.name, self.e0, self.e1, self.flops, self.bytes))
+            _prof_log.append((self.name, self.e0, self.e1, self.flops, self.bytes, _prof_scope))
         return False
 
 
@@ -198,8 +229,9 @@ def im2col3x3_nchw(x: torch.Tensor, kpad: int, dtype: torch.dtype) -> Act:
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
     N, C, H, W = x.shape
     out = new_act(N, H, W, kpad, dtype, x.device, needs_grad=False)
-    L.check(L.load().uz_im2col3x3_nchw(L.dtype_code(dtype), x.data_ptr(), N, C, H, W, kpad,
-                                       out.buf.data_ptr(), L.stream_ptr()), "uz_im2col3x3_nchw")
+    with _Timed("im2col3x3_nchw", 0.0, 4.0 * x.numel() + out.buf.element_size() * out.buf.numel()):
+        L.check(L.load().uz_im2col3x3_nchw(L.dtype_code(dtype), x.data_ptr(), N, C, H, W, kpad,
+                                           out.buf.data_ptr(), L.stream_ptr()), "uz_im2col3x3_nchw")
     return out
 
 
@@ -277,6 +309,15 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     return stats
 
 
+def wgrad_kernel_name(d) -> str:
+    """uz_wgrad_kernel_name(): the kernel family the library's plan picks for a WgradDesc (labels of bench.py's per-kernel
+    timing; tests use it to assert which kernel they exercise)"""
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    L.check_count(L.load().uz_wgrad_kernel_name(byref(d), buf, 96), "uz_wgrad_kernel_name")
+    return buf.value.decode()
+
+
 def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
           taps_mode: int = L.TAPS_CONV, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i, j, tap] = sum_p L[p, i] * R[pix(p, tap), j]  (fp32, reference parameter layout)."""
@@ -289,27 +330,7 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     if out is None:
         out = torch.empty(out_shape, dtype=torch.float32, device=Lt.buf.device)
     assert out.numel() == Lt.C * Rt.C * ntaps and out.is_contiguous() and out.dtype == torch.float32
-    tile = 128 if (Lt.C > 64 and Rt.C > 64) else 64
-    kname = f"wgrad_{_tname(Lt.dtype)}_{tile}x{tile}"
-    W_ = Lt.W
-    gather = (taps_mode == L.TAPS_GATHER2X2 and ntaps == 4) or (taps_mode == L.TAPS_CONV_S2 and ntaps == 9)
-    if (Lt.dtype == torch.bfloat16 and (taps_mode in (L.TAPS_CONV, L.TAPS_CONV_UP2) or gather)
-            and ((ntaps == 9 and dil == 1) or ntaps == 1 or gather)
-            and Lt.C % 8 == 0 and Rt.C % 8 == 0
-            and (ntaps == 1 or ((W_ in (16, 32) or (W_ >= 64 and W_ % 64 == 0)) and Lt.H % (64 // min(W_, 64)) == 0))):
-        # mirrors uz_wgrad3x3_plan() (one-tap problems walk the tokens as a flat list: any map shape)
-        big = Lt.C % 128 == 0 and Rt.C % 128 == 0
-        if (ntaps == 1 or gather) and not big:   # mirrors uz_wgrad3x3_plan(): fewer operand re-reads with the larger tile
-            t64 = Lt.C * ((Rt.C + 63) // 64) + Rt.C * ((Lt.C + 63) // 64)
-            t128 = Lt.C * ((Rt.C + 127) // 128) + Rt.C * ((Lt.C + 127) // 128)
-            big = t128 < t64
-        kname = "wgrad3x3_bf16_" + ("128x128" if big else "64x64") + (("_gather%d" % ntaps) if gather else "_1tap" if ntaps == 1 else ("_3tap" if big else "_9tap"))
-        if ntaps == 9 and not gather:   # the nine-tap 128 x 64 / 64 x 128 tiles of uz_wgrad3x3_plan()
-            P_ = Lt.N * Lt.H * Lt.W
-            if Lt.C % 128 == 0 and Rt.C % 64 == 0 and ((Rt.C == 64 and P_ >= (1 << 19)) or (Rt.C >= 1024 and Lt.C >= 512)):
-                kname = "wgrad3x3_bf16_128x64_9tap"
-            elif Lt.C == 64 and Rt.C % 128 == 0:
-                kname = "wgrad3x3_bf16_64x128_9tap"
+    kname = wgrad_kernel_name(d)   # the family the library's own plan launches for this descriptor
     with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
         L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
@@ -323,10 +344,11 @@ def bn_finalize(stats: torch.Tensor, count: int, gamma, beta, eps: float, moment
     C = stats.shape[2]
     dev = stats.device
     vec = torch.empty((4, C), dtype=torch.float32, device=dev)  # scale, shift, mean, invstd
-    L.check(lib.uz_bn_finalize(stats.data_ptr(), stats.shape[0], C, float(count), gamma.data_ptr(),
-                               beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
-                               vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
-                               vec[3].data_ptr(), L.stream_ptr()), "uz_bn_finalize")
+    with _Timed("bn_finalize", 0.0, 4.0 * stats.numel()):
+        L.check(lib.uz_bn_finalize(stats.data_ptr(), stats.shape[0], C, float(count), gamma.data_ptr(),
+                                   beta.data_ptr(), eps, momentum, _p(running_mean), _p(running_var),
+                                   vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                   vec[3].data_ptr(), L.stream_ptr()), "uz_bn_finalize")
     return vec
 
 
