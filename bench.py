@@ -61,6 +61,7 @@ PMC_KEYS = {
     "wgrad9_bf16_64x64_rowwalk": ("wgrad9_kernel<64,",),
     "wgrad3x3_bf16_128x128_3tap": ("wgrad3x3_kernel<128, 128, 1, 3,",),
     "wgrad3x3_bf16_128x128_gather4": ("wgrad3x3_kernel<128, 128, 1, 1,",),
+    "wgrad_g4_bf16_128x64_4tap": ("wgrad_g4_kernel<128,",),
 }
 
 

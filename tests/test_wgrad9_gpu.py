@@ -155,3 +155,51 @@ def test_rowwalk_full_size_layer_properties():
     wz = torch.zeros(8, 8, 3, 3, device=DEV, requires_grad=True)
     F.conv2d(xs, wz, None, padding=1).backward(ds)
     assert torch.equal(sub, wz.grad)
+
+
+# ---- 2 x 2 gather (ConvTranspose2d k2 s2) weight gradient, four taps per workgroup: unet_zoo_amd/csrc/uz_wgrad_g4.hip ----
+def ref_convt_wgrad(x, dy):
+    """autograd's weight gradient of F.conv_transpose2d(x, w, stride=2) (common_layers.py:104), cropped / zero-padded to
+    dy's size as UpSample_UNet pads odd skips (common_layers.py:110-113)"""
+    w = torch.zeros(x.shape[1], dy.shape[1], 2, 2, requires_grad=True)
+    y = F.conv_transpose2d(x, w, None, stride=2)
+    y = F.pad(y, [0, dy.shape[3] - y.shape[3], 0, dy.shape[2] - y.shape[2]])
+    y.backward(dy)
+    return w.grad
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,odd", [
+    (2, 16, 16, 256, 128, 0),    # W = 16: four coarse rows per step; 2 x 2 tiles
+    (1, 8, 32, 128, 64, 0),      # W = 32
+    (2, 4, 64, 64, 96, 0),       # 64-wide x tile (four waves), g tail tile of 32 channels
+    (1, 6, 128, 128, 64, 0),     # two strips per coarse row
+    (1, 8, 64, 72, 40, 1),       # channel tails on both operands; fine grid (2H + 1) x (2W + 1)
+    (3, 16, 16, 1024, 512, 0),   # unet's up_convolution_1 shape: 64 tiles
+])
+def test_gather4_exact_on_integers(N, H, W, Cin, Cout, odd):
+    g = torch.Generator().manual_seed(17)
+    x = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float()
+    dy = torch.randint(-2, 3, (N, Cout, 2 * H + odd, 2 * W + odd), generator=g).float()
+    ref = ref_convt_wgrad(x, dy)
+    xa, dya = act_from_nchw(x.to(DEV), dt), act_from_nchw(dy.to(DEV), dt)
+    d = L.WgradDesc(L.dtype_code(dt), xa.N, xa.H, xa.W, dya.H, dya.W, xa.C, xa.ld, dya.C, dya.ld, 4, L.TAPS_GATHER2X2, 1)
+    assert ops.wgrad_kernel_name(d).startswith("wgrad_g4_bf16_" + ("128" if Cin > 64 else "64")), ops.wgrad_kernel_name(d)
+    got = ops.wgrad(xa, dya, (Cin, Cout, 2, 2), ntaps=4, taps_mode=L.TAPS_GATHER2X2)
+    assert torch.equal(got.cpu(), ref)
+    assert torch.equal(got, ops.wgrad(xa, dya, (Cin, Cout, 2, 2), ntaps=4, taps_mode=L.TAPS_GATHER2X2))
+
+
+def test_gather4_channel_windows_of_poisoned_buffers():
+    """g is the up-slot of a concat buffer (cat([up, skip], 1)), x a window of a wider buffer; the neighbours are NaN"""
+    N, H, W, Cin, Cout = 2, 16, 32, 128, 64
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dt).float()
+    dy = torch.randn(N, Cout, 2 * H, 2 * W, generator=g).to(dt).float()
+    ref = ref_convt_wgrad(x, dy)
+    xw = torch.full((N * H * W, Cin + 64), float("nan"), dtype=dt, device=DEV)
+    xw[:, 32:32 + Cin] = act_from_nchw(x.to(DEV), dt).buf
+    gw = torch.full((N * 4 * H * W, 2 * Cout), float("nan"), dtype=dt, device=DEV)
+    gw[:, :Cout] = act_from_nchw(dy.to(DEV), dt).buf
+    got = ops.wgrad(Act(xw, 32, Cin, N, H, W), Act(gw, 0, Cout, N, 2 * H, 2 * W), (Cin, Cout, 2, 2), ntaps=4,
+                    taps_mode=L.TAPS_GATHER2X2)
+    assert torch.isfinite(got).all() and relerr(got.cpu(), ref) < 2e-2

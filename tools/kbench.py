@@ -28,8 +28,35 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3  # us
 
+CONVT = [("up1", 16, 1024, 512), ("up2", 32, 512, 256), ("up3", 64, 256, 128), ("up4", 128, 128, 64)]
+
+
+def convt_wgrad():
+    """the four ConvTranspose2d(k2 s2) weight gradients of unet (B = 16): x on the coarse grid, g in the up-slot of the
+    decoder's concat buffer (ld = 2 Cout)"""
+    tunes = ["0"]
+    for a in sys.argv:
+        if a.startswith("--tune="):
+            tunes = a.split("=")[1].split(",")
+    for name, hc, cin, cout in CONVT:
+        x = ops.new_act(B, hc, hc, cin, dt, DEV); x.buf.normal_()
+        full = ops.new_act(B, 2 * hc, 2 * hc, 2 * cout, dt, DEV); full.buf.normal_()
+        g = full.window(0, cout)
+        mb = (x.buf.numel() + g.P * cout) * 2 / 1e6
+        line = f"{name:4s} {hc:3d}->{2 * hc:3d} {cin:4d}->{cout:4d} {mb:6.1f} MB |"
+        for rep in range(2):
+            for t in tunes:
+                os.environ["UZ_TUNE"] = t
+                us = timeit(lambda: ops.wgrad(x, g, (cin, cout, 2, 2), ntaps=4, taps_mode=L.TAPS_GATHER2X2))
+                if rep == 1:
+                    line += f" [{t}] {us:7.1f}us {mb / us * 1e3 / 1e3:5.2f}TB/s |"
+        print(line, flush=True)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "convt":
+        return convt_wgrad()
     tunes = ["0"]
     for a in sys.argv:
         if a.startswith("--tune="):

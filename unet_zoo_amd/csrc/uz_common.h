@@ -148,6 +148,9 @@ struct UzWgrad2Plan {
 int uz_wgrad9_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
 int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, hipStream_t s);
 const char* uz_wgrad9_name(const UzWgrad2Plan& p);
+// 2 x 2 gather (ConvTranspose2d k2 s2 / PatchExpand) weight gradient, four taps per workgroup (uz_wgrad_g4.hip): v9 = 2
+int uz_wgrad_g4_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
+int uz_wgrad_g4_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, hipStream_t s);
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch = 1);   // batch > 1: uz_wgrad_batched (one-tap only)
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
                        float* slab, hipStream_t s, int batch = 1, long long lb_bytes = 0, long long rb_bytes = 0,

@@ -355,6 +355,8 @@ extern "C" int uz_wgrad_kernel_name(const uz_wgrad_desc* d, char* buf, int cap) 
   int n;
   if (!uz_wgrad3x3_plan(d, &p2)) {
     n = snprintf(buf, cap, "wgrad_%s_%dx%d", dt, p.b, p.b);
+  } else if (p2.v9 == 2) {
+    n = snprintf(buf, cap, "wgrad_g4_bf16_%dx64_4tap", p2.bi);
   } else if (p2.v9) {
     n = snprintf(buf, cap, "%s", uz_wgrad9_name(p2));
   } else {

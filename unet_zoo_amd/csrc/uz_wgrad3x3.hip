@@ -426,6 +426,7 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch) {
   p->v9 = 0;
   p->bi = 0;
   if (batch == 1 && uz_wgrad9_plan(d, p)) return 1;   // nine taps per workgroup, row walk (uz_wgrad9.hip)
+  if (batch == 1 && uz_wgrad_g4_plan(d, p)) return 1;   // 2 x 2 gather, four taps per workgroup (uz_wgrad_g4.hip)
   const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
   const bool s2 = d->taps_mode == UZ_TAPS_CONV_S2 && d->ntaps == 9;
   const bool gather = (d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && !(uz_tune_flags() & 0x4000000)) || s2;
@@ -529,8 +530,8 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
                        float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes, long long slab_stride,
                        int batch2, long long lb2_bytes, long long rb2_bytes) {
   if (p.v9) {
-    UZ_REQUIRE(batch == 1, "uz_wgrad(3x3): the row-walk kernel takes one problem");
-    return uz_wgrad9_launch(d, p, L, R, slab, s);
+    UZ_REQUIRE(batch == 1, "uz_wgrad(3x3): the row-walk / four-tap kernels take one problem");
+    return p.v9 == 2 ? uz_wgrad_g4_launch(d, p, L, R, slab, s) : uz_wgrad9_launch(d, p, L, R, slab, s);
   }
   Wg2Args a;
   a.lb = lb_bytes;
