@@ -141,7 +141,7 @@ def test_bf16_unet_on_the_kernels_the_benchmark_times():
     print(sorted(fams))
     assert "conv3x3_pp512x64_bf16" in fams, fams
     assert "conv3x3_pp512_bf16" in fams or "conv3x3_pp256_bf16" in fams, fams
-    assert "wgrad9_bf16_64x64_rowwalk" in fams and "wgrad9_bf16_128x64_rowwalk" in fams, fams
+    assert "wgrad9_bf16_64x64_rowwalk" in fams, fams
     layers = r["layers"]
     assert layers[0][1] < 1e-4, layers[0]
     for k, e in layers:

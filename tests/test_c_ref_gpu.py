@@ -110,6 +110,42 @@ def test_weight_gradient_kernels_against_the_c_restatement(dt):
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("N,H,W,Cx,Cdy,mode", [
+    (2, 8, 64, 64, 64, "conv"),        # row-walk kernel, 64 x 64 tile (uz_wgrad9.hip)
+    (1, 8, 128, 128, 128, "conv"),     # row-walk kernel, 128 x 64 tile, two strips per row
+    (2, 16, 16, 72, 136, "conv"),      # W = 16, channel tails
+    (1, 16, 32, 64, 64, "up2"),        # x through nearest x2 upsampling (x lives at 8 x 16)
+    (2, 8, 16, 128, 64, "convt"),      # ConvTranspose2d k2 s2: four taps per workgroup (uz_wgrad_g4.hip)
+    (1, 4, 64, 64, 40, "convt"),
+])
+def test_round4_weight_gradient_kernels_against_the_c_restatement(N, H, W, Cx, Cdy, mode):
+    """the row-walk nine-tap kernel and the four-tap 2 x 2 gather kernel (bf16) against uz_wgrad_ref on the same bytes"""
+    dt = torch.bfloat16
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(23)
+    if mode == "convt":     # L = x on the coarse grid, R = the output gradient on the fine grid
+        Lt, Rt = rnd((N * H * W, Cx), dt, g), rnd((N * 4 * H * W, Cdy), dt, g)
+        La, Ra = Act(Lt.to(DEV), 0, Cx, N, H, W), Act(Rt.to(DEV), 0, Cdy, N, 2 * H, 2 * W)
+        shape, nt, tm = (Cx, Cdy, 2, 2), 4, L.TAPS_GATHER2X2
+        d = L.WgradDesc(L.dtype_code(dt), N, H, W, 2 * H, 2 * W, Cx, Cx, Cdy, Cdy, 4, tm, 1)
+    else:
+        hx, wx = (H // 2, W // 2) if mode == "up2" else (H, W)
+        Lt, Rt = rnd((N * H * W, Cdy), dt, g), rnd((N * hx * wx, Cx), dt, g)
+        La, Ra = Act(Lt.to(DEV), 0, Cdy, N, H, W), Act(Rt.to(DEV), 0, Cx, N, hx, wx)
+        tm = L.TAPS_CONV_UP2 if mode == "up2" else L.TAPS_CONV
+        shape, nt = (Cdy, Cx, 3, 3), 9
+        d = L.WgradDesc(L.dtype_code(dt), N, H, W, hx, wx, Cdy, Cdy, Cx, Cx, 9, tm, 1)
+    name = ops.wgrad_kernel_name(d)
+    assert name.startswith("wgrad_g4_") if mode == "convt" else name.startswith("wgrad9_"), name
+    out = ops.wgrad(La, Ra, shape, ntaps=nt, taps_mode=tm)
+    ref = np.zeros(out.numel(), np.float32)
+    Lh, Rh = c_ref.host(Lt), c_ref.host(Rt)
+    assert lib.uz_wgrad_ref(byref(d), c_ref.ptr(Lh), c_ref.ptr(Rh), c_ref.ptr(ref), None, None) == 0
+    r = torch.from_numpy(ref).reshape(shape).double()
+    err = ((out.cpu().double() - r).abs().max() / r.abs().max()).item()
+    assert err < 1e-5, (name, err)
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_batchnorm_relu_pool_kernels_against_the_c_restatement(dt):
     lib = c_ref.load()

@@ -72,11 +72,13 @@ __device__ __forceinline__ void tr_pair(bf16x4& lo, bf16x4& hi, unsigned lds_add
 }
 __device__ __forceinline__ void pin(bf16x4& v) { asm volatile("" : "+v"(v)); }
 
-template <int BI, int KW, int NW_ = 4> struct W9 {
+template <int BI, int KW, int NW_ = 4, int KG_ = 1> struct W9 {
   static_assert((BI == 128 || BI == 64) && (KW == 64 || KW == 32 || KW == 16), "tile configuration");
-  static constexpr int NW = NW_;                     // waves: NW / 2 (dy) x 2 (x)
-  static constexpr int TI = BI / (16 * NW);          // 32-channel dy tiles per wave
-  static_assert(TI >= 1 && (NW == 4 || NW == 8), "wave grid");
+  static constexpr int NW = NW_;                     // waves: KG pixel groups x NW / (2 KG) (dy) x 2 (x)
+  static constexpr int KG = KG_;                     // pixel groups: group k owns the sub-steps 4 k / KG .. of every step
+  static constexpr int TI = BI * KG / (16 * NW);     // 32-channel dy tiles per wave
+  static constexpr int NU = 12 / KG;                 // units (sub-step, tap row) per wave and step
+  static_assert(TI >= 1 && (NW == 4 || NW == 8) && (KG == 1 || KG == 2) && TI * 16 * NW == BI * KG, "wave grid");
   static constexpr int G = 64 / KW;                  // image rows per step
   static constexpr int RBL = BI * 2;                 // bytes per dy pixel row in LDS
   static constexpr int CPRL = RBL / 16;              // 16-byte chunks per dy pixel
@@ -87,12 +89,17 @@ template <int BI, int KW, int NW_ = 4> struct W9 {
   static constexpr int QR = (KW + 1) / 8;            // the piece that holds the right halo column
   static constexpr int ROWB = RPX * 128;
   static constexpr int LSTAGE = 64 * RBL;
-  static constexpr int NSL = BI == 128 ? (KW == 64 ? 4 : 5) : (KW == 16 ? 5 : 6);   // dy stages = steps in the ring
+#ifndef UZ_W9_DEEP
+#define UZ_W9_DEEP 0   // 1: a seventh dy stage on the 64-wide tile -- measured same-box against six: no difference (the ring is not the limit)
+#endif
+  static constexpr int NSL = BI == 128 ? (KW == 64 ? 4 : 5) : (KW == 16 ? 5 : (UZ_W9_DEEP ? 7 : 6));   // dy stages = steps in the ring
   static constexpr int NSR = NSL * G + 4;            // x row slots: G per step + 2 shared + 2 for one segment start
   static constexpr int KL = NLP / NW;                // dy pieces per wave and step
   static constexpr int MR = (RPIECES + NW - 1) / NW; // x pieces per wave and row (piece q = wave + 4 m; the last m: some waves)
   static constexpr int PMIN = KL + G * (RPIECES / NW);   // pieces EVERY wave requests per steady step
-  static constexpr int L_OFF = 0, R_OFF = NSL * LSTAGE, SMEM = R_OFF + NSR * ROWB;
+  static constexpr int L_OFF = 0, R_OFF = NSL * LSTAGE, RING = R_OFF + NSR * ROWB;
+  static constexpr int XCH = KG == 2 ? (NW / 2) * 9 * 16 * 256 : 0;   // the pixel groups' accumulators meet in LDS after the loop
+  static constexpr int SMEM = RING > XCH ? RING : XCH;
   static_assert(NLP % NW == 0, "dy pieces split evenly over the waves");
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static_assert((NSL - 2) * PMIN <= 63, "vmcnt range");
@@ -107,9 +114,15 @@ template <int BI, int KW, int NW_ = 4> struct W9 {
 // alone (everything else switched off) ran at 54 cycles each and the empty loop took as long as the MFMAs should
 // (profiles/r04_wgrad9_skeleton.txt).  Now: ~240 instructions beside 72 MFMAs (3.3 per MFMA gap), bookkeeping per step
 // and row instead of per piece, fragment addresses per step instead of per read.
-template <int BI, int KW, int MODE, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
-  typedef W9<BI, KW, NWV> C;
+// LD = 1: four LOADER waves (4 .. 7) beside four compute waves (one of each per SIMD).  The loaders do nothing but the
+// ring: bookkeeping, LDS-DMA requests, the vmcnt wait that publishes a step; the compute waves' instruction stream is then
+// fragment reads, permutes and MFMAs only (~3.7 instructions per MFMA gap, which one wave per SIMD hides, cf.
+// MI355X_MICROARCH.md "one wave per SIMD ... <= 5 ... hidden per gap").  Both kinds meet at the one s_barrier per step.
+template <int BI, int KW, int MODE, int NWV = 4, int KGV = 1, int LD = 0>
+__global__ __launch_bounds__(64 * (NWV + 4 * LD), 1) void wgrad9_kernel(const Wg9Args a) {
+  typedef W9<BI, KW, NWV, KGV> C;
+  static_assert(LD == 0 || (NWV == 4 && KGV == 1), "loader waves go with four compute waves");
+  constexpr int KG = C::KG, NU = C::NU;
   constexpr int NW = C::NW, TI = C::TI, G = C::G, RBL = C::RBL, CPRL = C::CPRL, RPPL = C::RPPL, NLP = C::NLP;
   constexpr int RPIECES = C::RPIECES, QR = C::QR, ROWB = C::ROWB, LSTAGE = C::LSTAGE, NSL = C::NSL, NSR = C::NSR;
   constexpr int KL = C::KL, MR = C::MR, PMIN = C::PMIN, L_OFF = C::L_OFF, R_OFF = C::R_OFF;
@@ -119,8 +132,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
   __shared__ __attribute__((aligned(1024))) char smem[C::SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave >> 1, wj = wave & 1;   // wave tile: dy channels 32 TI wi .., x channels 32 wj ..
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = LD != 0 && wave_id >= 4;
+  const int wave = LD != 0 ? (wave_id & 3) : wave_id;   // index among the waves of its kind (DMA piece tables / wave tile)
+  // wave tile: dy channels 32 TI wi .., x channels 32 wj ..; pixel group kgrp (KG = 2: the 64 x 64 tile on eight waves --
+  // waves w and w + 4, which share a SIMD, own the same channel tile and the two halves of every step's pixels; with four
+  // waves, one per SIMD, the ~200 scalar / vector / LDS instructions of a step beside 36 MFMAs left the matrix pipe idle a
+  // third of the time)
+  const int kgrp = KG == 2 ? wave / (NW / 2) : 0, wloc = KG == 2 ? wave % (NW / 2) : wave;
+  const int wi = wloc >> 1, wj = wloc & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
   // work item = (channel tile, pixel split z); the tiles of one z share an XCD when the split is a multiple of 8
@@ -245,6 +265,22 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
     i_ls = (i_ls + 1 == NSL) ? 0 : i_ls + 1;
   };
 
+  if (LD != 0 && loader) {
+    // ---- a loader wave: request NSL - 1 steps ahead, publish a step when it has landed, one barrier per step ------------
+#pragma unroll
+    for (int b = 0; b < NSL - 1; ++b) issue_batch();
+    wait_vmcnt<(NSL - 2) * PMIN>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int s = 0; s < nu; ++s) {
+      wait_vmcnt<(NSL - 3) * PMIN>();   // step s + 1 has landed
+      __builtin_amdgcn_s_barrier();     // ... for every wave; step s - 1 is read by nobody any more
+      issue_batch();                    // step s + NSL - 1 into its slots
+    }
+    wait_vmcnt<0>();
+    return;
+  }
+
   f32x16 acc[TI][9];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -258,20 +294,25 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
   const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
   const int lk = 8 * (g >> 1) + q4;           // pixel of this lane inside a 16-pixel sub-step
   const int lcol = 16 * (g & 1) + 4 * p4;     // channel inside a 32-channel tile
+  // a pixel group's sub-steps start 64 / KG pixels into the step: KW = 64: half a row further (coff), KW <= 32: roff rows down
+  constexpr int SPG = 4 / KG;                                // sub-steps per pixel group
+  constexpr int RW = (KG == 2 ? (G >= 4 ? G / 2 : 1) : G) + 2;   // x rows a wave reads per step
+  const int roff = (KG == 2 && G >= 2) ? kgrp * (G / 2) : 0;
+  const int coff = (KG == 2 && G == 1) ? kgrp * 32 : 0;
   unsigned aoff[TI];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
-    aoff[i] = (unsigned)(lk * RBL + (((wi * TI + i) ^ (CPRL == 16 ? q4 : (q4 >> 1))) << 6) + lcol * 2);
-  const unsigned boffV = (unsigned)(lk * 128 + ((wj ^ ((q4 >> 1) & 1)) << 6) + lcol * 2);             // pixels lk + {0..3, 4..7}
-  const unsigned boffW = (unsigned)((lk + 2) * 128 + ((wj ^ (((q4 + 2) >> 1) & 1)) << 6) + lcol * 2);   // the same two pixels on
-  unsigned va[TI], vv[G + 2], vw[G + 2];   // this step's dy stage and x rows 0 .. G + 1, as this lane reads them
+    aoff[i] = (unsigned)(kgrp * (SPG * 16 * RBL) + lk * RBL + (((wi * TI + i) ^ (CPRL == 16 ? q4 : (q4 >> 1))) << 6) + lcol * 2);
+  const unsigned boffV = (unsigned)((coff + lk) * 128 + ((wj ^ ((q4 >> 1) & 1)) << 6) + lcol * 2);             // pixels lk + {0..3, 4..7}
+  const unsigned boffW = (unsigned)((coff + lk + 2) * 128 + ((wj ^ (((q4 + 2) >> 1) & 1)) << 6) + lcol * 2);   // the same two pixels on
+  unsigned va[TI], vv[RW], vw[RW];   // this step's dy stage and the x rows this wave reads, as this lane reads them
   auto step_addr = [&](int vb, int ls) __attribute__((always_inline)) {
     const unsigned lb = smem_u + L_OFF + ls * LSTAGE;
 #pragma unroll
     for (int i = 0; i < TI; ++i) va[i] = lb + aoff[i];
 #pragma unroll
-    for (int j = 0; j < G + 2; ++j) {
-      int slot = vb + j;
+    for (int j = 0; j < RW; ++j) {
+      int slot = vb + roff + j;
       if (slot >= NSR) slot -= NSR;
       const unsigned rb = smem_u + R_OFF + slot * ROWB;
       vv[j] = rb + boffV;
@@ -333,9 +374,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
   } while (0)
 
   // ---- prologue: the first NSL - 1 steps -------------------------------------------------------------------------------
+  if constexpr (LD == 0) {
 #pragma unroll
-  for (int b = 0; b < NSL - 1; ++b) issue_batch();
-  wait_vmcnt<(NSL - 2) * PMIN>();   // the first step has landed (what may stay in flight: the steady pieces of the younger steps)
+    for (int b = 0; b < NSL - 1; ++b) issue_batch();
+    wait_vmcnt<(NSL - 2) * PMIN>();   // the first step has landed (what may stay in flight: the steady pieces of the younger steps)
+  }
   __builtin_amdgcn_s_barrier();
 
   const bool mm = !(UZ_W9_FLAGS(a) & 64);   // measurement only: no MFMAs
@@ -346,31 +389,42 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
   fetch(IntC<1>{});
 #pragma unroll 1
   for (int s = 0; s < nu; ++s) {
-    UZ_W9_UNIT(0);
-    UZ_W9_UNIT(1);
-    UZ_W9_UNIT(2);
-    UZ_W9_UNIT(3);
-    UZ_W9_UNIT(4);
-    UZ_W9_UNIT(5);
+    if constexpr (NU == 12) {
+      UZ_W9_UNIT(0);
+      UZ_W9_UNIT(1);
+      UZ_W9_UNIT(2);
+      UZ_W9_UNIT(3);
+      UZ_W9_UNIT(4);
+      UZ_W9_UNIT(5);
+    } else {
+      UZ_W9_UNIT(0);
+      UZ_W9_UNIT(1);
+      UZ_W9_UNIT(2);
+    }
     // mid-step: step s + 1 has landed for every wave, step s - 1 is read by nobody any more -> request step s + NSL - 1
-    wait_vmcnt<(NSL - 3) * PMIN>();
+    if constexpr (LD == 0) wait_vmcnt<(NSL - 3) * PMIN>();
     __builtin_amdgcn_s_barrier();
     // the two waves of a SIMD (w, w + 4) request at different times: while one does its bookkeeping and DMA issue (~100
     // instructions that issue no MFMA) the other one's MFMAs keep the matrix pipe busy
-    if (NW == 4 || wave < 4 || stagger_off) issue_batch();
-    UZ_W9_UNIT(6);
-    UZ_W9_UNIT(7);
-    UZ_W9_UNIT(8);
-    if (NW == 8 && wave >= 4 && !stagger_off) issue_batch();
-    UZ_W9_UNIT(9);
-    // where the next step lives (the last read of this step's addresses was unit 9's request of unit 11)
+    if (LD == 0 && (NW == 4 || wave < 4 || stagger_off)) issue_batch();
+    if constexpr (NU == 12) {
+      UZ_W9_UNIT(6);
+      UZ_W9_UNIT(7);
+      UZ_W9_UNIT(8);
+      if (LD == 0 && NW == 8 && wave >= 4 && !stagger_off) issue_batch();
+      UZ_W9_UNIT(9);
+    } else {
+      if (LD == 0 && NW == 8 && wave >= 4 && !stagger_off) issue_batch();
+      UZ_W9_UNIT(3);
+    }
+    // where the next step lives (the last read of this step's addresses was the request of unit NU - 1)
     if (++m_hb == a.hsteps) m_hb = 0;
     m_vb += G + (m_hb == 0 ? 2 : 0);
     if (m_vb >= NSR) m_vb -= NSR;
     m_ls = (m_ls + 1 == NSL) ? 0 : m_ls + 1;
     step_addr(m_vb, m_ls);
-    // units 10 and 11 request units 0 and 1 of the next step (the MFMAs stay outside the branches: inside, hipcc keeps a
-    // second copy of the accumulator registers)
+    // the last two units request units 0 and 1 of the next step (the MFMAs stay outside the branches: inside, hipcc keeps
+    // a second copy of the accumulator registers)
     const bool more = s + 1 < nu;
     if (more) {
       fetch(IntC<0>{});
@@ -378,7 +432,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
     } else {
       wait_lgkm<4>();
     }
-    if (mm) compute(IntC<10>{});
+    if (mm) compute(IntC<NU - 2>{});
     __builtin_amdgcn_sched_barrier(0);
     if (more) {
       fetch(IntC<1>{});
@@ -386,14 +440,41 @@ __global__ __launch_bounds__(64 * NWV, 1) void wgrad9_kernel(const Wg9Args a) {
     } else {
       wait_lgkm<0>();
     }
-    if (mm) compute(IntC<11>{});
+    if (mm) compute(IntC<NU - 1>{});
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef UZ_W9_UNIT
 #undef UZ_W9_NREADS
 #undef UZ_W9_XROW
-  wait_vmcnt<0>();   // (the requests for steps past the end: zero fills nobody reads)
+  if constexpr (LD == 0) wait_vmcnt<0>();   // (the requests for steps past the end: zero fills nobody reads)
 
+  if constexpr (KG == 2) {
+    // the second pixel group hands its accumulators to its partner (same channel tile, same lane roles) through LDS:
+    // [wave tile][tap][4 rows][lane][4 floats] -- a lane's 16 bytes, 1 KB per wave-instruction, no bank conflicts
+    static_assert(TI == 1, "one accumulator tile per wave");
+    __builtin_amdgcn_s_barrier();   // every wave has left the ring
+    float* xch = reinterpret_cast<float*>(smem) + (size_t)wloc * (9 * 16 * 64) + lane * 4;
+    if (kgrp == 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          *reinterpret_cast<f32x4*>(xch + (t * 4 + r4) * 256) =
+              f32x4{acc[0][t][4 * r4], acc[0][t][4 * r4 + 1], acc[0][t][4 * r4 + 2], acc[0][t][4 * r4 + 3]};
+    }
+    __syncthreads();
+    if (kgrp == 1) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(xch + (t * 4 + r4) * 256);
+        acc[0][t][4 * r4] += o.x;
+        acc[0][t][4 * r4 + 1] += o.y;
+        acc[0][t][4 * r4 + 2] += o.z;
+        acc[0][t][4 * r4 + 3] += o.w;
+      }
+  }
   // ---- partial slab [split][tap][Ci][Cj] -------------------------------------------------------------------------------
   if (UZ_W9_FLAGS(a) & 128) return;   // measurement only: no slab
   const int cj = tj0 + wj * 32 + l31;
@@ -437,17 +518,11 @@ int uz_wgrad9_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p) {
   if (!(W == 16 || W == 32 || (W >= 64 && W % 64 == 0))) return 0;
   const int kw = W < 64 ? W : 64, g = 64 / kw;
   if (H % g != 0) return 0;
-  const int bi = (d->Ci > 64 && !(f & 0x10000000)) ? 128 : 64;
-  if (!(f & 0x40000000)) {
-    // where the round-3 kernels stay (same box, B = 16 unet layers, profiles/r04_kbench_wgrad_rowwalk_vs_r03.txt): dy twice
-    // as wide as x on a map of < 2^19 pixels (64 -> 128 @ 128 x 128 ... 512 -> 1024 @ 16 x 16: one or two channel tiles,
-    // 16 steps per workgroup -- the 295 KB accumulator export and the ring's fill are a third of the launch; 5-10 %
-    // behind the nine-tap 128 x 64 tile of uz_wgrad3x3.hip), and 64 dy channels against >= 128 x channels (128 -> 64 @
-    // 256 x 256: the 64 x 128 tile reads x once, 64 x 64 tiles read dy twice)
-    const long long P = (long long)d->N * d->H * d->W;
-    if (d->Ci >= 2 * d->Cj && d->Ci % 128 == 0 && d->Cj % 64 == 0 && P < (1LL << 19)) return 0;
-    if (d->Ci == 64 && d->Cj % 128 == 0) return 0;
-  }
+  // 64 x 64 tiles on four compute + four loader waves everywhere; the 128 x 64 tile on eight do-everything waves (this
+  // round's first form) stays behind an ablation switch.  Same box, B = 16 unet layers, uz_wgrad = kernel + reduction
+  // (profiles/r04_kbench_wgrad_rowwalk_vs_r03.txt): 64 x 64 + loaders 1300 us over the fourteen layers, 128 x 64 (with the
+  // round-3 kernels where those won) 1369, round 3 1462 -- and half the slab bytes (37.7 MB per launch).
+  const int bi = (d->Ci > 64 && (f & 0x10000000)) ? 128 : 64;
   const int nsl = bi == 128 ? (kw == 64 ? W9Nsl<128, 64>::value : (kw == 32 ? W9Nsl<128, 32>::value : W9Nsl<128, 16>::value))
                             : (kw == 64 ? W9Nsl<64, 64>::value : (kw == 32 ? W9Nsl<64, 32>::value : W9Nsl<64, 16>::value));
   const int hsteps = H / g;
@@ -513,10 +588,16 @@ int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* 
   a.flags = uz_tune_flags();
   const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
   const dim3 grid((unsigned)(a.ntiles * p.split));
-#define UZ_W9_LAUNCH1(BI_, KW_, NW_)                                                                       \
+#define UZ_W9_LAUNCH2(BI_, KW_, NW_, KG_)                                                                  \
   do {                                                                                                     \
-    if (up) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 1, NW_>), grid, dim3(64 * NW_), 0, s, a);          \
-    else hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 0, NW_>), grid, dim3(64 * NW_), 0, s, a);             \
+    if (up) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 1, NW_, KG_>), grid, dim3(64 * NW_), 0, s, a);     \
+    else hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 0, NW_, KG_>), grid, dim3(64 * NW_), 0, s, a);        \
+  } while (0)
+#define UZ_W9_LAUNCH1(BI_, KW_, NW_) UZ_W9_LAUNCH2(BI_, KW_, NW_, 1)
+#define UZ_W9_LAUNCHL(BI_, KW_)                                                                            \
+  do {                                                                                                     \
+    if (up) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 1, 4, 1, 1>), grid, dim3(512), 0, s, a);           \
+    else hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 0, 4, 1, 1>), grid, dim3(512), 0, s, a);              \
   } while (0)
   const bool w4 = (a.flags & 0x20000000) != 0;   // ablation build: the 128-wide tile on four waves of 64 x 32
   if (p.bi == 128) {
@@ -524,11 +605,15 @@ int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* 
     else if (p.kw == 32) { if (w4) UZ_W9_LAUNCH1(128, 32, 4); else UZ_W9_LAUNCH1(128, 32, 8); }
     else { if (w4) UZ_W9_LAUNCH1(128, 16, 4); else UZ_W9_LAUNCH1(128, 16, 8); }
   } else {
-    if (p.kw == 64) UZ_W9_LAUNCH1(64, 64, 4);
-    else if (p.kw == 32) UZ_W9_LAUNCH1(64, 32, 4);
-    else UZ_W9_LAUNCH1(64, 16, 4);
+    // ablation build: 0x20000000 four waves that do everything, 0x2000000 eight waves in two pixel groups
+    const int form = (a.flags & 0x20000000) ? 1 : ((a.flags & 0x2000000) ? 2 : 0);
+    if (p.kw == 64) { if (form == 1) UZ_W9_LAUNCH1(64, 64, 4); else if (form == 2) UZ_W9_LAUNCH2(64, 64, 8, 2); else UZ_W9_LAUNCHL(64, 64); }
+    else if (p.kw == 32) { if (form == 1) UZ_W9_LAUNCH1(64, 32, 4); else if (form == 2) UZ_W9_LAUNCH2(64, 32, 8, 2); else UZ_W9_LAUNCHL(64, 32); }
+    else { if (form == 1) UZ_W9_LAUNCH1(64, 16, 4); else if (form == 2) UZ_W9_LAUNCH2(64, 16, 8, 2); else UZ_W9_LAUNCHL(64, 16); }
   }
 #undef UZ_W9_LAUNCH1
+#undef UZ_W9_LAUNCH2
+#undef UZ_W9_LAUNCHL
   UZ_LAUNCH_CHECK("uz_wgrad(row walk)");
   return UZ_OK;
 }
