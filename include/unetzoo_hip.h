@@ -15,8 +15,8 @@
  *            UZ_BF16 = bf16 storage + bf16 MFMA with fp32 accumulate (throughput mode);
  *   - return 0 on success, otherwise a negative UZ_E* code or a positive hipError_t;
  *     uz_last_error_string() describes the last failure on the calling thread.
- * All functions are re-entrant; there is no process-global mutable state except the
- * thread-local error string.
+ * All functions are re-entrant.  Process-global mutable state: the thread-local error string and ONE process-wide
+ * setting, uz_set_cu_reserve() (an atomic the plans read when they size their grids; set it before planning or capturing).
  */
 #ifndef UNETZOO_HIP_H
 #define UNETZOO_HIP_H
@@ -182,6 +182,10 @@ int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, v
 /* The kernel family the library's plan launches for this descriptor, written to buf (labels of per-kernel measurements;
  * e.g. "wgrad9_bf16_128x64_rowwalk": nine taps per workgroup, uz_wgrad9.hip).  Returns the length, <0 on error. */
 int uz_wgrad_kernel_name(const uz_wgrad_desc* d, char* buf, int cap);
+/* uz_wgrad in two calls, for per-kernel measurements (bench.py brackets each with its own event pair): phase 1 = the main
+ * kernel (partial slabs into the workspace), phase 2 = the fixed-order slab reduction into `out`.  uz_wgrad == 1 then 2. */
+int uz_wgrad_phase(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream,
+                   int phase);
 /* `batch` independent one-tap problems of the shape `d` in one launch pair: problem b reads L + b * lb, R + b * rb
  * (strides in elements, multiples of 16 bytes) and writes out + b * ob floats -- the per-image products of the token
  * attention that contract over the rows of both operands (dV_b = A_b^T dO_b, dK_b = dS_b^T Q_b,

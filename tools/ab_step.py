@@ -17,7 +17,10 @@ VARIANTS = [("fused conv + convT", dict(fuse_bn_reduce=True, fuse_bn_reduce_conv
 
 def build(attrs, model_name, B, S):
     for k, v in attrs.items():
-        setattr(Engine, k, v)
+        if k == "UZ_TUNE":       # plan switches of the ablation build (UNET_ZOO_AMD_LIB=.../libunetzoo_hip_ablate.so): the
+            os.environ["UZ_TUNE"] = str(v)     # plans are taken at capture time, so a captured step keeps its variant
+        else:
+            setattr(Engine, k, v)
     torch.manual_seed(0)
     kw = dict(image_size=S) if model_name in ("swin_unet_v2", "uctransnet") else {}
     model = unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1, **kw).cuda()
@@ -38,7 +41,11 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--tunes", default=None, help="comma list of UZ_TUNE values instead of the Engine variants (ablation build)")
     a = ap.parse_args()
+    global VARIANTS
+    if a.tunes:
+        VARIANTS = [(f"UZ_TUNE={t}", {"UZ_TUNE": int(t)}) for t in a.tunes.split(",")]
     built = [(name, build(attrs, a.model, a.batch, a.size)) for name, attrs in VARIANTS]
     best = {name: 1e9 for name, _ in VARIANTS}
     for r in range(a.rounds):

@@ -2,7 +2,7 @@
 # bench.py lines of the other model configurations (one JSON line each) -> gpurun_out/bench_TAG_<model>.json
 # usage (on the GPU box): bash tools/bench_models.sh TAG
 TAG=${1:-r02}
-run() { name=$1; shift; python bench.py --no-cpu-baseline --fp32-steps 0 "$@" > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.err; python3 - gpurun_out/bench_${TAG}_$name.json $name <<'PY'
+run() { name=$1; shift; python bench.py --no-cpu-baseline --fp32-steps 0 --second-steps 0 "$@" > gpurun_out/bench_${TAG}_$name.json 2> gpurun_out/bench_${TAG}_$name.err; python3 - gpurun_out/bench_${TAG}_$name.json $name <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

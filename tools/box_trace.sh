@@ -5,9 +5,9 @@ TAG=${1:-$(date +%H%M%S)}
 MODEL=${2:-unet}      # bench.py --model
 EXTRA=${3:-}          # further bench.py arguments, e.g. "--size 224 --batch 32"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 bench.py --model $MODEL $EXTRA --no-cpu-baseline --fp32-steps 0 --profile-steps 0 > gpurun_out/box_${TAG}_bench.json 2>/dev/null
+python3 bench.py --model $MODEL $EXTRA --no-cpu-baseline --fp32-steps 0 --second-steps 0 --profile-steps 0 > gpurun_out/box_${TAG}_bench.json 2>/dev/null
 OUT=gpurun_out/prof_box_$TAG; rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace -d "$OUT" -o x -- python3 bench.py --model $MODEL $EXTRA --steps 20 --warmup 3 --profile-steps 0 --no-cpu-baseline --fp32-steps 0 > "$OUT/bench.json" 2> "$OUT/err.log"
+rocprofv3 --kernel-trace -d "$OUT" -o x -- python3 bench.py --model $MODEL $EXTRA --steps 20 --warmup 3 --profile-steps 0 --no-cpu-baseline --fp32-steps 0 --second-steps 0 > "$OUT/bench.json" 2> "$OUT/err.log"
 DB=$(ls "$OUT"/*.db "$OUT"/*/*.db 2>/dev/null | head -1)
 python3 tools/prof_steady.py "$DB" 5 30 > gpurun_out/box_${TAG}_steady.txt
 rm -rf "$OUT"

@@ -8,7 +8,7 @@ STEPS=20; WARM=3
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python3 bench.py --steps $STEPS --warmup $WARM --profile-steps 0 --no-cpu-baseline --fp32-steps 0 $*"
+CMD="python3 bench.py --steps $STEPS --warmup $WARM --profile-steps 0 --no-cpu-baseline --fp32-steps 0 --second-steps 0 $*"
 rocprofv3 --kernel-trace --stats -d "$OUT" -o x -- $CMD > gpurun_out/${TAG}_bench.json 2> "$OUT/err.log"
 DB=$(ls "$OUT"/*.db "$OUT"/*/*.db 2>/dev/null | head -1)
 python3 tools/prof_csv.py "$DB" "rocprofv3 --kernel-trace --stats -- $CMD" > gpurun_out/${TAG}_kernel_stats.csv

@@ -377,8 +377,9 @@ extern "C" long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d) {
   return nslabs * d->ntaps * d->Ci * d->Cj * (long long)sizeof(float);
 }
 
-extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out,
-                        void* workspace, void* stream) {
+// phase 0: both launches; 1: the main kernel (partial slabs into the workspace); 2: the fixed-order slab reduction
+static int wgrad_phases(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream,
+                        int phase) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
@@ -407,13 +408,14 @@ extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, fl
   UzWgrad2Plan p2;
   int nslabs = p.split;
   int rc2;
-  if (uz_wgrad3x3_plan(d, &p2)) {
-    nslabs = p2.nslabs;
-    rc2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s);
-  } else {
-    rc2 = d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
+  const bool lds_dma = uz_wgrad3x3_plan(d, &p2) != 0;
+  if (lds_dma) nslabs = p2.nslabs;
+  if (phase != 2) {
+    if (lds_dma) rc2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s);
+    else rc2 = d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
+    if (rc2 != UZ_OK) return rc2;
   }
-  if (rc2 != UZ_OK) return rc2;
+  if (phase == 1) return UZ_OK;
   const long long cicj = (long long)d->Ci * d->Cj;
   const dim3 grid((unsigned)((cicj + 63) / 64));
   const float* slab = static_cast<const float*>(workspace);
@@ -429,6 +431,16 @@ extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, fl
   }
   UZ_LAUNCH_CHECK("uz_wgrad(reduce)");
   return UZ_OK;
+}
+
+extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream) {
+  return wgrad_phases(d, L, R, out, workspace, stream, 0);
+}
+
+extern "C" int uz_wgrad_phase(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace,
+                              void* stream, int phase) {
+  UZ_REQUIRE(phase == 1 || phase == 2, "uz_wgrad_phase: phase %d (1: main kernel, 2: slab reduction)", phase);
+  return wgrad_phases(d, L, R, out, workspace, stream, phase);
 }
 
 

@@ -330,11 +330,19 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     if out is None:
         out = torch.empty(out_shape, dtype=torch.float32, device=Lt.buf.device)
     assert out.numel() == Lt.C * Rt.C * ntaps and out.is_contiguous() and out.dtype == torch.float32
+    if not _prof_on:
+        L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(), L.stream_ptr()), "uz_wgrad")
+        return out
+    # measured (bench.py's eager profile steps): the main kernel and the slab reduction in brackets of their own, so that
+    # a family's average launch time is ONE kernel's, as a kernel trace reports it
     kname = wgrad_kernel_name(d)   # the family the library's own plan launches for this descriptor
     with _Timed(kname, 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
                 Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
-        L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(),
-                             L.stream_ptr()), "uz_wgrad")
+        L.check(lib.uz_wgrad_phase(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(), L.stream_ptr(), 1),
+                "uz_wgrad_phase")
+    with _Timed("wgrad_reduce", 0.0, float(ws_bytes) + 4.0 * out.numel()):
+        L.check(lib.uz_wgrad_phase(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(), L.stream_ptr(), 2),
+                "uz_wgrad_phase")
     return out
 
 
