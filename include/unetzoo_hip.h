@@ -200,6 +200,25 @@ int uz_wgrad_batched2(const uz_wgrad_desc* d, int batch, int batch2, const void*
                       long long rb, long long rb2, float* out, long long ob, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The network's first convolution as direct kernels (bf16 run mode; uz_conv_first.hip): nn.Conv2d(C <= 3, Cout in {32, 64},
+ * k3, p1) on the fp32 NCHW input image (reference: the first layer of every UNet-family model, common_layers.py:28 reached
+ * from unet.py:15; attention_unet.py:11; u2net.py:30) -- no im2col buffer.
+ *   fwd:   y[p][co] (bf16 NHWC, pixel stride ldy) = bias[co] + sum_{c,ty,tx} w[co][c][ty][tx] x[n][c][h+ty-1][w+tx-1], x and w
+ *          rounded to bf16 (what the im2col path stored), fp32 accumulation, one rounding; stats (nullable):
+ *          uz_conv3x3_first_rows(N, H, W) partial rows [row][2][Cout] of sum / sum of squares of the STORED values
+ *          (uz_bn_finalize reads them).
+ *   wgrad: dw[co][c][ty][tx] (fp32, the parameter's own layout) = sum_p dy[p][co] x[n][c][h+ty-1][w+tx-1]; workspace of
+ *          uz_conv3x3_first_wgrad_workspace_bytes() for the workgroups' partial slabs (fixed-order reduction).
+ * ------------------------------------------------------------------------------------------- */
+int uz_conv3x3_first_supported(int dtype, int C, int Cout);
+int uz_conv3x3_first_rows(int N, int H, int W);
+int uz_conv3x3_first_fwd(int dtype, const float* x, int N, int C, int H, int W, const float* w, const float* bias, int Cout,
+                         void* y, int ldy, float* stats, void* stream);
+long long uz_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W, int Cout);
+int uz_conv3x3_first_wgrad(int dtype, const float* x, int N, int C, int H, int W, const void* dy, int lddy, int Cout, float* dw,
+                           void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Weight re-packing: fp32 master parameters in the reference layout -> kernel layout in run dtype.
  *   UZ_PACK_CONV_FWD : w[Co][Ci][T] (OIHW)     -> dst[Co][t*Ci + ci]
  *   UZ_PACK_CONV_DGRAD: w[Co][Ci][T]           -> dst[Ci][(T-1-t)*Co + co]   (flipped taps)

@@ -143,7 +143,26 @@ def _window_core_torch(qkv, tau, w1, b1, w2, b2, rel_index, heads: int, ws: int,
     return o.permute(0, 3, 1, 2)
 
 
+class ImageInput:
+    """The network input for its first convolution: the fp32 NCHW image and -- only if somebody asks -- its im2col'd 3x3
+    patches (an Act of [P][Kpad] in the run dtype: rounds 1-3's form of the first layer, still the fp32 run mode's)."""
+
+    __slots__ = ("nchw", "kpad", "dtype", "_patches", "N", "H", "W")
+
+    def __init__(self, nchw: torch.Tensor, kpad: int, dtype: torch.dtype):
+        self.nchw, self.kpad, self.dtype, self._patches = nchw, kpad, dtype, None
+        self.N, _, self.H, self.W = nchw.shape
+
+    def patches(self) -> Act:
+        if self._patches is None:
+            self._patches = ops.im2col3x3_nchw(self.nchw, self.kpad, self.dtype)
+        return self._patches
+
+
 class Engine:
+    # the first convolution of the bf16 run mode as direct kernels on the fp32 NCHW image (uz_conv_first.hip) instead of
+    # im2col + GEMM + one-tap weight gradient (class-level: tools/ab_step.py times both ways in one process)
+    direct_first_conv = True
     # the BatchNorm-backward reduction of a sole-reader activation rides in the epilogue of the 3x3 input-gradient
     # convolution / of the ConvTranspose input-gradient GEMM that produces its gradient (class-level so that
     # tools/ab_step.py can time both ways in one process; no environment switch)
@@ -282,13 +301,14 @@ class Engine:
         return gs
 
     # ------------------------------------------------------------------ blocks
-    def input_im2col(self, x: torch.Tensor) -> Act:
-        """Network input (N,C,H,W) fp32 -> 3x3 patches [P][Kpad] for the first convolution."""
+    def input_im2col(self, x: torch.Tensor) -> "ImageInput":
+        """Network input (N,C,H,W) fp32 for the first convolution: the image itself (the direct first-convolution kernels of
+        the bf16 run mode read it as it is) and, on demand, its 3x3 patches [P][Kpad] (`ImageInput.patches()`: fp32 run
+        mode, channel counts the direct kernels do not take, consumers other than Conv -> BN -> ReLU)."""
         L.require_cuda(x)
         if x.dim() != 4:
             raise ValueError(f"expected a (N, C, H, W) input, got shape {tuple(x.shape)}")
-        C = x.shape[1]
-        return ops.im2col3x3_nchw(x.contiguous().float(), _round_up(9 * C, self.bk), self.dtype)
+        return ImageInput(x.contiguous().float(), _round_up(9 * x.shape[1], self.bk), self.dtype)
 
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
                      pool: bool = False, im2col: bool = False, upsample: bool = False,
@@ -314,7 +334,16 @@ class Engine:
         tmode = L.TAPS_CONV_UP2 if upsample else L.TAPS_CONV
         Cout = conv.out_channels
         dil = conv.dilation[0]
-        if im2col:
+        image = None       # the fp32 NCHW input when the direct first-convolution kernels take this layer
+        if im2col and isinstance(x, ImageInput):
+            if (self.direct_first_conv and conv.kernel_size == (3, 3) and dil == 1 and conv.padding == (1, 1)
+                    and conv.stride == (1, 1) and ops.conv_first_supported(self.dtype, x.nchw.shape[1], Cout)):
+                image = x.nchw
+            else:
+                x = x.patches()
+        if image is not None:
+            wp, ntaps = None, 1
+        elif im2col:
             wp = self._pack(conv.weight, L.PACK_IM2COL, x.C)
             ntaps = 1
         else:
@@ -324,8 +353,11 @@ class Engine:
             assert ntaps == 9 or not upsample
         y = self.new_act(N, H, W, Cout)
         bias = conv.bias.detach() if conv.bias is not None else None
-        stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, taps_mode=tmode,
-                               want_stats=self.training)
+        if image is not None:
+            stats = ops.conv_first_fwd(image, conv.weight.detach(), bias, y, self.training)
+        else:
+            stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, taps_mode=tmode,
+                                   want_stats=self.training)
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
             vec = ops.bn_finalize(stats if stat_repeat == 1 else stats * float(stat_repeat), y.P * stat_repeat,
@@ -383,7 +415,9 @@ class Engine:
                         # d(bias) = sum_p dy == 0 analytically under train-mode BN (the batch mean
                         # removes any per-channel constant); the reference's value is rounding noise.
                         self._give_grad(conv.bias, None)
-                if im2col:
+                if image is not None:
+                    self._give_grad(conv.weight, ops.conv_first_wgrad(image, dy, out=self._dst(conv.weight)))
+                elif im2col:
                     dwp = ops.wgrad(dy, x, (Cout, x.C), ntaps=1)
                     cin = conv.in_channels
                     dw = dwp[:, :9 * cin].reshape(Cout, 9, cin).permute(0, 2, 1).reshape(conv.weight.shape)
@@ -547,6 +581,8 @@ class Engine:
         Cout = conv.out_channels
         k = conv.kernel_size[0]
         assert conv.kernel_size in ((3, 3), (1, 1)) and conv.dilation == (1, 1)
+        if im2col and isinstance(x, ImageInput):
+            x = x.patches()
         if im2col:
             wp, ntaps = self._pack(conv.weight, L.PACK_IM2COL, x.C), 1
         else:

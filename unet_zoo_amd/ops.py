@@ -235,6 +235,47 @@ def im2col3x3_nchw(x: torch.Tensor, kpad: int, dtype: torch.dtype) -> Act:
     return out
 
 
+def conv_first_supported(dtype: torch.dtype, C: int, Cout: int) -> bool:
+    """the direct first-convolution kernels (uz_conv_first.hip) take this layer: bf16 run mode, C <= 3, Cout in {32, 64}"""
+    return bool(L.load().uz_conv3x3_first_supported(L.dtype_code(dtype), C, Cout))
+
+
+def conv_first_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], y: Act, want_stats: bool):
+    """y = Conv2d(k3, p1)(x) for the fp32 NCHW network input x (no im2col buffer); returns the BatchNorm partial rows
+    (rows, 2, Cout) of the stored values when want_stats"""
+    L.require_cuda(x, w, y.buf)
+    assert x.dtype == torch.float32 and x.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    N, C, H, W = x.shape
+    Cout = w.shape[0]
+    assert (y.N, y.H, y.W, y.C) == (N, H, W, Cout) and tuple(w.shape) == (Cout, C, 3, 3)
+    lib = L.load()
+    stats = None
+    if want_stats:
+        rows = L.check_count(lib.uz_conv3x3_first_rows(N, H, W), "uz_conv3x3_first_rows")
+        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
+    with _Timed("conv3x3_first_bf16", 2.0 * N * H * W * 9 * C * Cout, 4.0 * x.numel() + 2.0 * y.P * Cout):
+        L.check(lib.uz_conv3x3_first_fwd(L.dtype_code(y.dtype), x.data_ptr(), N, C, H, W, w.data_ptr(), _p(bias), Cout,
+                                         y.ptr(), y.ld, _p(stats), L.stream_ptr()), "uz_conv3x3_first_fwd")
+    return stats
+
+
+def conv_first_wgrad(x: torch.Tensor, dy: Act, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d(loss)/d(weight) (Cout, C, 3, 3) fp32 of the first convolution from the fp32 NCHW input and the output gradient"""
+    L.require_cuda(x, dy.buf)
+    N, C, H, W = x.shape
+    Cout = dy.C
+    lib = L.load()
+    ws_bytes = L.check_count(lib.uz_conv3x3_first_wgrad_workspace_bytes(N, H, W, Cout), "uz_conv3x3_first_wgrad_workspace_bytes")
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((Cout, C, 3, 3), dtype=torch.float32, device=x.device)
+    assert out.numel() == Cout * C * 9 and out.is_contiguous() and out.dtype == torch.float32
+    with _Timed("wgrad_first_bf16", 2.0 * N * H * W * 9 * C * Cout, 4.0 * x.numel() + 2.0 * dy.P * Cout):
+        L.check(lib.uz_conv3x3_first_wgrad(L.dtype_code(dy.dtype), x.data_ptr(), N, C, H, W, dy.ptr(), dy.ld, Cout,
+                                           out.data_ptr(), ws.data_ptr(), L.stream_ptr()), "uz_conv3x3_first_wgrad")
+    return out
+
+
 def conv_kernel_name(d, with_workspace: bool = False) -> str:
     """uz_conv_igemm_kernel_name(): the kernel family the library's plan picks for a ConvDesc (labels of the per-kernel
     timing of bench.py; tests use it to assert which generation they exercise)"""
