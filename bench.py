@@ -291,6 +291,9 @@ def main():
                     help="N>1 ranks: all-reduce every finished backward phase beside the next one (overlap), the whole "
                          "gradient buffer once after the backward (tail), or time both before the warm-up and keep the "
                          "faster (auto; the choice and both timings are reported in the line)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N>1 ranks: fp32 all-reduce of the gradients (default, the reference's semantics) or the bf16 exchange "
+                         "of GraphedStep(comm_dtype=torch.bfloat16): half the bytes on the links, two bf16 roundings")
     ap.add_argument("--phases", type=int, default=5,
                     help="N>1 ranks: number of backward phases (hipGraphs) whose gradient "
                          "all-reduce overlaps the next phase; 1 = one all-reduce after the whole backward")
@@ -384,7 +387,8 @@ def main():
     if args.graph == "on":
         gs = GraphedStep(model, "bce_dice" if args.loss == "hip" else torch_criterion, lr=1e-4, weight_decay=1e-5,
                          max_norm=1.0, phases=args.phases, data_parallel=distributed, cu_reserve=args.cu_reserve,
-                         comm="overlap" if args.comm == "auto" else args.comm)
+                         comm="overlap" if args.comm == "auto" else args.comm,
+                         comm_dtype=torch.bfloat16 if args.comm_dtype == "bf16" else None)
         comm_tuning = None
         if distributed and args.comm == "auto":
             # before the warm-up and the timed steps: both collective schedules on this job's own ranks, keep the faster
@@ -534,6 +538,7 @@ def main():
             "launch": launch_mode,
             "cu_reserve": L.get_cu_reserve(),
             "comm_tuning_ms": comm_tuning if args.graph == "on" else None,
+            "comm_dtype": args.comm_dtype if distributed else None,
             "device": {"before_timed_steps": dev_before, "after_timed_steps": dev_after, "mfma_clock": mfma_clock},
             "kernel_ms_per_step": {k: round(v["ms"] / nprof, 3) for k, v in sorted(prof.items())},
         }

@@ -62,10 +62,28 @@ def main():
     tail = run(gs2, m2, x, t)
     bad_g += [n + " (tail)" for n in ref[2] if not torch.equal(ref[2][n], tail[2][n])]
     bad_p += [n + " (tail)" for n in ref[3] if not torch.equal(ref[3][n], tail[3][n])]
+    # the bf16 gradient exchange (comm_dtype = torch.bfloat16: all-to-all of bf16 shards, fp32 sum on arrival, all-gather) over
+    # RCCL, both schedules: with one rank the result is the local round trip through bf16, bit for bit
+    bad_bf16 = []
+    for mode in ("overlap", "tail"):
+        m3 = build(name, size, dtype, dev)
+        gs3 = unet_zoo_amd.GraphedStep(m3, "bce_dice", lr=1e-3, weight_decay=1e-5, data_parallel=True, phases=3, comm=mode,
+                                       comm_dtype=torch.bfloat16)
+        float(gs3.forward_backward(x, t))
+        torch.cuda.synchronize()
+        names3 = {id(p): n for n, p in m3.named_parameters()}
+        for p in gs3.opt.params:
+            n = names3[id(p)]
+            if not torch.equal(p.grad, ref[2][n].to(torch.bfloat16).float()):
+                bad_bf16.append(f"{n} ({mode})")
+        gs3.optimizer_step()
+        float(gs3(x, t))            # a second step through the same buffers and streams
+        torch.cuda.synchronize()
+        assert "bf16" in gs3.describe()
     tuning = gs2.autotune_comm(x, t, steps=2)
     assert set(tuning) == {"overlap", "tail"} and gs2.comm in ("overlap", "tail") and "all-reduce" in gs2.describe()
     torch.save({"loss": (ref[0], got[0]), "loss2": (ref[1], got[1]), "bad_grads": bad_g, "bad_params": bad_p,
-                "n_phases": n_phases, "spans": gs._spans, "n_params": len(ref[2]), "describe": gs.describe(),
+                "bad_bf16": bad_bf16, "n_phases": n_phases, "spans": gs._spans, "n_params": len(ref[2]), "describe": gs.describe(),
                 "backend": dist.get_backend()}, out_path)
     dist.destroy_process_group()
 

@@ -24,6 +24,7 @@ def shard(rank, batch, size):
 
 def main():
     out_path, model_name, size, batch, dtype = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    comm_dtype = torch.bfloat16 if (len(sys.argv) > 6 and sys.argv[6] == "bf16") else None
     rank, local_rank, world = launch.rank_info()
     own_gpu = torch.cuda.device_count() >= world
     dev = torch.device("cuda", local_rank if own_gpu else 0)
@@ -42,7 +43,7 @@ def main():
             for p in model.parameters():
                 p.add_(0.5)
     x, m = shard(rank, batch, size)
-    gs = unet_zoo_amd.GraphedStep(model, "bce_dice", lr=1e-3, weight_decay=1e-5, phases=3)
+    gs = unet_zoo_amd.GraphedStep(model, "bce_dice", lr=1e-3, weight_decay=1e-5, phases=3, comm_dtype=comm_dtype)
     assert gs.distributed and gs.world == world
     loss = gs.forward_backward(x.to(dev), m.to(dev))
     torch.cuda.synchronize()

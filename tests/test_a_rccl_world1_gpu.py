@@ -34,3 +34,5 @@ def test_rccl_branch_of_graphed_step_at_world_1(tmp_path, model_name, size, batc
     assert got["loss"][0] == got["loss"][1] and got["loss2"][0] == got["loss2"][1]
     assert not got["bad_grads"], got["bad_grads"][:5]
     assert not got["bad_params"], got["bad_params"][:5]
+    # comm_dtype = bf16: one rank's exchange is the local bf16 round trip of the fp32 gradients, bit for bit
+    assert not got["bad_bf16"], got["bad_bf16"][:5]

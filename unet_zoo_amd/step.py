@@ -112,12 +112,19 @@ class GraphedStep:
     def __init__(self, model: nn.Module, criterion: Union[str, Callable] = "bce_dice", *, lr: float = 1e-4,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-5,
                  max_norm: float = 1.0, phases: int = 5, process_group=None, data_parallel: Optional[bool] = None,
-                 cu_reserve: Optional[int] = None, comm: str = "overlap"):
+                 cu_reserve: Optional[int] = None, comm: str = "overlap", comm_dtype: Optional[torch.dtype] = None):
         """comm: when the gradient exchange of a data-parallel step runs -- "overlap": the span of every finished backward
         phase is all-reduced while the next phase's graph runs; "tail": ONE all-reduce of the whole flat buffer after the
         last phase.  The same graphs serve both; autotune_comm() times them on the job's own hardware and keeps the faster
         one (the persistent one-workgroup-per-CU grids and a collective's kernels compete for CUs: which schedule wins
         depends on the rank count and the fabric).
+        comm_dtype: None / torch.float32 -- gradients are all-reduced in fp32 (the reference's DataParallel sums fp32 replicas'
+        gradients, multi_gpu.py:28-31); torch.bfloat16 -- an OPTION that halves the bytes on the links: every rank rounds its
+        span to bf16, a reduce-scatter by all-to-all, the shards are summed in fp32 ON ARRIVAL (fixed rank order) and averaged,
+        rounded once to bf16 and all-gathered: every rank ends with the same bf16-representable mean; 2 (N-1)/N of the bf16
+        span crosses each rank's links instead of 2 (N-1)/N of the fp32 one, and the direct all-to-all / all-gather pair uses
+        all of a GPU's xGMI links at once.  Not the default: it changes the gradients by two bf16
+        roundings.
         cu_reserve: CUs the library's persistent grids leave free (uz_set_cu_reserve; process-wide, applied here,
         before anything is planned or captured) so that the all-reduce of a finished gradient span can start while the
         next backward phase runs -- convolution / GEMM / weight-gradient kernels otherwise hold every CU with one
@@ -146,6 +153,11 @@ class GraphedStep:
         if comm not in ("overlap", "tail"):
             raise ValueError(f"comm must be 'overlap' or 'tail', got {comm!r}")
         self.comm = comm
+        if comm_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError(f"comm_dtype must be None, torch.float32 or torch.bfloat16, got {comm_dtype!r}")
+        self.comm_dtype = torch.bfloat16 if comm_dtype == torch.bfloat16 else torch.float32
+        self._comm_stream: Optional[torch.cuda.Stream] = None
+        self._comm_bufs: Dict[tuple, tuple] = {}
         self.opt: Optional[FlatClipAdamW] = None
         self._g_opt: Optional[torch.cuda.CUDAGraph] = None
         self._cuts: Optional[List[int]] = None
@@ -285,7 +297,54 @@ class GraphedStep:
             dist.broadcast(h, src=0, group=self.pg)
             t.copy_(h)
 
+    class _EventWait:
+        """what the bf16 exchange hands back in place of a collective's work handle"""
+
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def _exchange_bf16(self, buf: torch.Tensor):
+        """buf (a span of the flat fp32 gradient buffer) <- bf16(mean over ranks of bf16(buf)): all-to-all of bf16 shards,
+        fp32 sum on arrival in rank order, one rounding, all-gather -- on a side stream, so that the next backward phase
+        keeps running; returns an object whose wait() orders the caller's stream behind it"""
+        n, W = buf.numel(), self.world
+        shard = (n + W - 1) // W
+        key = (buf.data_ptr(), n)
+        if key not in self._comm_bufs:
+            dev = buf.device
+            self._comm_bufs[key] = (torch.zeros(W * shard, dtype=torch.bfloat16, device=dev),
+                                    torch.empty(W * shard, dtype=torch.bfloat16, device=dev),
+                                    torch.empty(shard, dtype=torch.bfloat16, device=dev))
+        send, recv, mine = self._comm_bufs[key]
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=buf.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        cs = self._comm_stream
+        with torch.cuda.stream(cs):
+            cs.wait_event(ready)
+            send[:n].copy_(buf)                                   # fp32 -> bf16 (round to nearest even); the tail stays zero
+            dist.all_to_all_single(recv, send, group=self.pg)     # shard r of every rank's span arrives at rank r
+            mine.copy_(recv.view(W, shard).float().sum(0).mul_(1.0 / W))   # fp32 accumulate on arrival, fixed order, one rounding
+            dist.all_gather_into_tensor(send, mine, group=self.pg)
+            buf.copy_(send[:n])
+            done = torch.cuda.Event()
+            done.record(cs)
+        return GraphedStep._EventWait(done)
+
     def _all_reduce_avg(self, buf: torch.Tensor):
+        if self.comm_dtype == torch.bfloat16:
+            if self._nccl:
+                return self._exchange_bf16(buf)
+            # other backends (gloo rehearsals): the same arithmetic staged through the host -- every rank's span rounded to
+            # bf16, summed in fp32, averaged, rounded once
+            h = buf.detach().to(torch.bfloat16).float().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            buf.copy_(h.mul_(1.0 / self.world).to(torch.bfloat16).float().to(buf.device))
+            return None
         if self._nccl:
             return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
         # other backends (gloo: CPU rehearsals and the single-GPU two-rank test): staged through the host
@@ -401,6 +460,8 @@ class GraphedStep:
         if not self.distributed:
             return f"{crit}hipGraph({'fwd+' if self._fused_loss else ''}bwd) + {opt}"
         mb = [round((a1 - a0) * 4 / 2 ** 20, 1) for a0, a1 in self._spans]
+        if self.comm_dtype == torch.bfloat16:
+            opt = "gradient exchange in bf16 (all-to-all, fp32 sum on arrival, all-gather) + " + opt
         if self.comm == "tail":
             return (f"{crit}{k} hipGraphs ({'fwd + ' if self._fused_loss else ''}backward phases), then ONE RCCL all-reduce of "
                     f"{round(sum(mb), 1)} MB + {opt}")
