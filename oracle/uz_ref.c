@@ -762,4 +762,82 @@ int uz_layernorm_fwd_ref(const uz_ln_desc* d, const void* x, const float* gamma,
 }
 UZ_SAME_SIGNATURE(uz_layernorm_fwd);
 
+/* ---- uz_conv3x3_first_*: the network's first convolution on the fp32 NCHW input (common_layers.py:28 from unet.py:15) -- */
+int uz_conv3x3_first_supported_ref(int dtype, int C, int Cout) {
+  return dtype == UZ_BF16 && C >= 1 && C <= 3 && (Cout == 32 || Cout == 64);
+}
+UZ_SAME_SIGNATURE(uz_conv3x3_first_supported);
+
+int uz_conv3x3_first_rows_ref(int N, int H, int W) { /* the restatement keeps its sums in one row */
+  (void)N, (void)H, (void)W;
+  return 1;
+}
+UZ_SAME_SIGNATURE(uz_conv3x3_first_rows);
+
+static inline double rb(double v) { return (double)bf16_to_f32(f32_to_bf16((float)v)); } /* what the im2col path stored */
+
+int uz_conv3x3_first_fwd_ref(int dtype, const float* x, int N, int C, int H, int W, const float* w, const float* bias, int Cout,
+                             void* y, int ldy, float* stats, void* stream) {
+  (void)stream;
+  if (!uz_conv3x3_first_supported_ref(dtype, C, Cout)) return UZ_ENOTIMPL;
+  double* s1 = stats ? (double*)calloc(2 * (size_t)Cout, sizeof(double)) : NULL;
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h)
+      for (int wq = 0; wq < W; ++wq)
+        for (int co = 0; co < Cout; ++co) {
+          double acc = 0.0;
+          for (int c = 0; c < C; ++c)
+            for (int ty = 0; ty < 3; ++ty)
+              for (int tx = 0; tx < 3; ++tx) {
+                const int hh = h + ty - 1, ww = wq + tx - 1;
+                if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                acc += rb(x[(((long long)n * C + c) * H + hh) * W + ww]) * rb(w[((co * C + c) * 3 + ty) * 3 + tx]);
+              }
+          if (bias) acc += bias[co];
+          const double v = st(dtype, y, (((long long)n * H + h) * W + wq) * ldy + co, acc);
+          if (s1) {
+            s1[co] += v;
+            s1[Cout + co] += v * v;
+          }
+        }
+  if (s1) {
+    for (int i = 0; i < 2 * Cout; ++i) stats[i] = (float)s1[i];
+    free(s1);
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_conv3x3_first_fwd);
+
+long long uz_conv3x3_first_wgrad_workspace_bytes_ref(int N, int H, int W, int Cout) {
+  (void)N, (void)H, (void)W, (void)Cout;
+  return 0;
+}
+UZ_SAME_SIGNATURE(uz_conv3x3_first_wgrad_workspace_bytes);
+
+int uz_conv3x3_first_wgrad_ref(int dtype, const float* x, int N, int C, int H, int W, const void* dy, int lddy, int Cout, float* dw,
+                               void* workspace, void* stream) {
+  (void)workspace, (void)stream;
+  if (!uz_conv3x3_first_supported_ref(dtype, C, Cout)) return UZ_ENOTIMPL;
+  for (int co = 0; co < Cout; ++co)
+    for (int c = 0; c < C; ++c)
+      for (int ty = 0; ty < 3; ++ty)
+        for (int tx = 0; tx < 3; ++tx) {
+          double acc = 0.0;
+          for (int n = 0; n < N; ++n)
+            for (int h = 0; h < H; ++h) {
+              const int hh = h + ty - 1;
+              if (hh < 0 || hh >= H) continue;
+              for (int wq = 0; wq < W; ++wq) {
+                const int ww = wq + tx - 1;
+                if (ww < 0 || ww >= W) continue;
+                acc += ld(dtype, dy, (((long long)n * H + h) * W + wq) * lddy + co) *
+                       rb(x[(((long long)n * C + c) * H + hh) * W + ww]);
+              }
+            }
+          dw[((co * C + c) * 3 + ty) * 3 + tx] = (float)acc;
+        }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_conv3x3_first_wgrad);
+
 int uz_ref_abi_version(void) { return 1; }

@@ -370,3 +370,33 @@ def test_bilinear_depthwise_space_to_depth_and_layernorm_restatements(dt):
     d2 = L.LnDesc(dc, N, Hi, Wi, C, C, C, 0, 0, 0, 0, 1, 1e-5, 1)
     assert lib.uz_layernorm_fwd_ref(byref(d2), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), None, None, c_ref.ptr(yl), c_ref.ptr(stats), None) == 0
     close(c_ref.tensor(yl, dt).reshape(P, C), F.gelu(ln), dt, "gelu(layernorm)")
+
+
+# ---- the network's first convolution on the fp32 NCHW image (uz_conv3x3_first_*) -------------------------------------------
+@pytest.mark.parametrize("N,C,H,W,Cout", [(2, 3, 9, 11, 32), (1, 1, 6, 5, 64)])
+def test_first_convolution_restatement(N, C, H, W, Cout):
+    lib = c_ref.load()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    x, w, b = torch.randn(N, C, H, W, generator=g), torch.randn(Cout, C, 3, 3, generator=g) * 0.3, torch.randn(Cout, generator=g)
+    xb, wb = x.to(dt).double(), w.to(dt).double()              # the operands the layer sees in the bf16 run mode
+    assert lib.uz_conv3x3_first_supported_ref(L.dtype_code(dt), C, Cout) == 1 and lib.uz_conv3x3_first_supported_ref(0, C, Cout) == 0
+    rows = lib.uz_conv3x3_first_rows_ref(N, H, W)
+    y, stats = np.zeros(N * H * W * Cout, np.uint16), np.zeros(rows * 2 * Cout, np.float32)
+    xh, wh, bh = c_ref.host(x), c_ref.host(w), c_ref.host(b)
+    assert lib.uz_conv3x3_first_fwd_ref(L.dtype_code(dt), c_ref.ptr(xh), N, C, H, W, c_ref.ptr(wh), c_ref.ptr(bh), Cout, c_ref.ptr(y),
+                                        Cout, c_ref.ptr(stats), None) == 0
+    ref = F.conv2d(xb, wb, b.double(), padding=1)
+    got = nchw(c_ref.tensor(y, dt).reshape(-1, Cout), N, H, W)
+    assert torch.equal(got, ref.to(dt))                          # double sums, one rounding: the correctly rounded result
+    st = stats.reshape(rows, 2, Cout).sum(0)
+    np.testing.assert_allclose(st[0], got.double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(st[1], (got.double() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-4)
+    gy = rnd((N, Cout, H, W), dt, g)
+    wr = torch.zeros(Cout, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xb, wr, padding=1).backward(gy.double())
+    dw = np.zeros(Cout * C * 9, np.float32)
+    gh = c_ref.host(nhwc(gy))
+    assert lib.uz_conv3x3_first_wgrad_workspace_bytes_ref(N, H, W, Cout) == 0
+    assert lib.uz_conv3x3_first_wgrad_ref(L.dtype_code(dt), c_ref.ptr(xh), N, C, H, W, c_ref.ptr(gh), Cout, Cout, c_ref.ptr(dw), None, None) == 0
+    np.testing.assert_allclose(dw.reshape(Cout, C, 3, 3), wr.grad.numpy(), rtol=1e-5, atol=1e-5)

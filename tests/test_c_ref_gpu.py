@@ -146,6 +146,31 @@ def test_round4_weight_gradient_kernels_against_the_c_restatement(N, H, W, Cx, C
     assert err < 1e-5, (name, err)
 
 
+@pytest.mark.parametrize("N,C,H,W,Cout", [(2, 3, 16, 64, 64), (1, 2, 21, 50, 32)])
+def test_first_convolution_kernels_against_the_c_restatement(N, C, H, W, Cout):
+    """uz_conv3x3_first_fwd / _wgrad (uz_conv_first.hip) against their restatements on the same bytes"""
+    dt = torch.bfloat16
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(29)
+    x, w, b = torch.randn(N, C, H, W, generator=g), torch.randn(Cout, C, 3, 3, generator=g) * 0.3, torch.randn(Cout, generator=g)
+    y = ops.new_act(N, H, W, Cout, dt, DEV)
+    stats = ops.conv_first_fwd(x.to(DEV), w.to(DEV), b.to(DEV), y, True)
+    yr, sr = np.zeros(N * H * W * Cout, np.uint16), np.zeros(2 * Cout, np.float32)
+    xh, wh, bh = c_ref.host(x), c_ref.host(w), c_ref.host(b)
+    assert lib.uz_conv3x3_first_fwd_ref(L.dtype_code(dt), c_ref.ptr(xh), N, C, H, W, c_ref.ptr(wh), c_ref.ptr(bh), Cout, c_ref.ptr(yr),
+                                        Cout, c_ref.ptr(sr), None) == 0
+    agree(y.buf, c_ref.tensor(yr, dt).reshape(-1, Cout), dt, "first conv")
+    s = stats.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(s.reshape(-1), sr.astype(np.float64), rtol=2e-3, atol=0.5)   # sums of the stored (once-rounded) values
+    gy = rnd((N * H * W, Cout), dt, g)
+    dw = ops.conv_first_wgrad(x.to(DEV), Act(gy.to(DEV), 0, Cout, N, H, W))
+    dr = np.zeros(Cout * C * 9, np.float32)
+    gh = c_ref.host(gy)
+    assert lib.uz_conv3x3_first_wgrad_ref(L.dtype_code(dt), c_ref.ptr(xh), N, C, H, W, c_ref.ptr(gh), Cout, Cout, c_ref.ptr(dr), None, None) == 0
+    r = torch.from_numpy(dr).reshape(Cout, C, 3, 3).double()
+    assert ((dw.cpu().double() - r).abs().max() / r.abs().max()).item() < 1e-5
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_batchnorm_relu_pool_kernels_against_the_c_restatement(dt):
     lib = c_ref.load()
