@@ -996,6 +996,12 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma_kernel(const AttnArgs a)
 // (A first version with one wave per (window, head) needed 128 running-sum registers per lane, spilled and
 // was slower than the VALU kernel; see the block decomposition inside the kernel.)
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): every global load in flight (the
+// next window's prefetch) and every global store (the window's results, acknowledged ~1 us after issue) -- four such drains
+// per window were more than half of the attention kernels' wave time (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.55).  The kernels
+// below exchange data between waves through LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ bf16x8 pack8(const float* f) {
   bf16x8 v;
 #pragma unroll
@@ -1023,9 +1029,13 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   __shared__ __attribute__((aligned(16))) bf16_t sKT[AD * VTS], sGT[AD * VTS], sQT[AD * VTS];
   __shared__ __attribute__((aligned(16))) bf16_t sPW[2 * AN * VTS];   // P, W [key][query]; later the dk / dv hand-over
   __shared__ float sRedQ[2][64 * 17];   // dq hand-over of the kt = 1 waves, [lane][16] (+1 pad)
-  __shared__ float sRk[AN];             // 1 / |k_j|
-  __shared__ int sCnt[AN];
-  __shared__ float sTab[2][AN * ANS];   // 1/clip(tau) (negated where the clip is active) and bias of this head
+  __shared__ __attribute__((aligned(16))) float sRk[AN];   // 1 / |k_j|
+  __shared__ __attribute__((aligned(16))) int sCnt[AN];
+  // 1 / clip(tau) (negated where the clip is active) and the bias of this head in LANE ORDER: a lane's 16 score elements are
+  // the same (query, key) pairs in every window, [table][g4][thread] holds its four values of key group g4 as one 16-byte
+  // read that is conflict-free across the wave (the [query][key] table it replaces cost 32 ds_read_b32 per window, each
+  // waited for where it was used)
+  __shared__ float4 sTabL[2][4][256];
   static_assert(2 * 2 * 64 * 17 * sizeof(float) <= sizeof(bf16_t) * 2 * AN * VTS, "dk / dv hand-over must fit in sPW");
   bf16_t* sP = sPW;
   bf16_t* sW = sPW + AN * VTS;
@@ -1039,20 +1049,39 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   const bf16_t* __restrict__ out = static_cast<const bf16_t*>(a.out);
   const bf16_t* __restrict__ dout = static_cast<const bf16_t*>(a.dout);
   bf16_t* __restrict__ dqkv = static_cast<bf16_t*>(a.dqkv);
-  for (int e = tid; e < AN * AN; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    const bool in = r < N && c < N;
-    const float tv = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
-    const float inv = 1.f / fmaxf(tv, 0.01f);
-    sTab[0][r * ANS + c] = tv >= 0.01f ? inv : -inv;
-    sTab[1][r * ANS + c] = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;   // padding: exp() = 0, no test
-  }
+  const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
   // running sums over this workgroup's windows of dS (-> d bias) and dS * c (-> d tau) for
-  // (query 32 qt + l31, key 32 kt + row(r))
+  // (query 32 qt + l31, key 32 kt + 4 lh + (r & 3) + 8 (r >> 2))
   float accb[16], acct[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) accb[r] = acct[r] = 0.f;
-  const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
+  // the two tables: coalesced rows from global memory into a [query][key] staging tile (the P / W area), then each lane
+  // gathers its own 16 entries into the lane-order table
+  float* stage = reinterpret_cast<float*>(sPW);   // [AN][ANS] floats
+  static_assert(AN * ANS * sizeof(float) <= sizeof(bf16_t) * 2 * AN * VTS, "the staging tile must fit in sPW");
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    for (int e = tid; e < AN * AN; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const bool in = r < N && c < N;
+      float v;
+      if (t == 0) {
+        const float tv = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
+        const float inv = 1.f / fmaxf(tv, 0.01f);
+        v = tv >= 0.01f ? inv : -inv;
+      } else {
+        v = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;   // padding: exp() = 0, no test
+      }
+      stage[r * ANS + c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float* sp = stage + iq * ANS + 32 * kt + 8 * g4 + 4 * lh;
+      sTabL[t][g4][tid] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+    }
+    __syncthreads();
+  }
 
   // A window's q, dO, O, k, v fragments are fetched one window ahead: the loads are issued right after the
   // score products have consumed the current ones and land during the element pass.
@@ -1093,7 +1122,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
 
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
-    __syncthreads();   // previous window: every reader of the tiles / hand-over areas is done (and sTab has landed)
+    lds_barrier();   // previous window: every reader of the tiles / hand-over areas is done (and sTab has landed)
     const WinTok tq = ntq, tkk = ntk;
     bf16x8 qf[2], gf[2], kf[2], vf[2];
     float rq = 0.f, Di = 0.f;
@@ -1139,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
           for (int e = 0; e < 8; ++e) sKT[(16 * ks + 8 * lh + e) * VTS + jk] = kf[ks][e];
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---------------- element pass: column = query iq, rows = keys of tile kt
     f32x16 dq, dk, dv;
@@ -1156,23 +1185,37 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       float w1[16];
       bf16_t* pcol = sP + (32 * kt + 4 * lh) * VTS + iq;
       bf16_t* wcol = sW + (32 * kt + 4 * lh) * VTS + iq;
+      // per key group of four: 1 / |k|, the two table entries (and, under the shifted-window mask, the region ids) in one
+      // 16-byte read each -- own data of the lane, so the 16 elements are independent chains
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jr = (r & 3) + 8 * (r >> 2);            // key row inside the tile, less 4 * lh
-        const int j = 32 * kt + jr + 4 * lh;
-        const float u = ut[r] * a.scale;
-        const float rden = fminf(rq * sRk[j], 1e6f);      // 1 / max(|scale q||k|, 1e-6)
-        const float tis = sTab[0][iq * ANS + j], ti = fabsf(tis);
-        const float c = u * rden;
-        float sv = fmaf(c, ti, sTab[1][iq * ANS + j]);
-        if (masked && sCnt[j] != tq.cnt) sv -= 100.f;
-        const float p = __expf(sv - lse);
-        const float ds = p * (dt[r] - Di);
-        accb[r] += ds;
-        acct[r] = fmaf(ds, c, acct[r]);
-        w1[r] = ds * ti * rden;
-        pcol[jr * VTS] = (bf16_t)p;
-        wcol[jr * VTS] = (bf16_t)w1[r];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 v = *reinterpret_cast<const float4*>(&sRk[32 * kt + 8 * g4 + 4 * lh]);
+        const float4 t = sTabL[0][g4][tid], b = sTabL[1][g4][tid];
+        const float rk4[4] = {v.x, v.y, v.z, v.w}, ti4[4] = {t.x, t.y, t.z, t.w}, bi4[4] = {b.x, b.y, b.z, b.w};
+        float pen4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (masked) {
+          const int4 c4 = *reinterpret_cast<const int4*>(&sCnt[32 * kt + 8 * g4 + 4 * lh]);
+          pen4[0] = c4.x != tq.cnt ? -100.f : 0.f;
+          pen4[1] = c4.y != tq.cnt ? -100.f : 0.f;
+          pen4[2] = c4.z != tq.cnt ? -100.f : 0.f;
+          pen4[3] = c4.w != tq.cnt ? -100.f : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g4 + e, jr = e + 8 * g4;        // jr: key row inside the tile, less 4 * lh
+          const float u = ut[r] * a.scale;
+          const float rden = fminf(rq * rk4[e], 1e6f);      // 1 / max(|scale q||k|, 1e-6)
+          const float ti = fabsf(ti4[e]);
+          const float c = u * rden;
+          const float sv = fmaf(c, ti, bi4[e]) + pen4[e];
+          const float p = __expf(sv - lse);
+          const float ds = p * (dt[r] - Di);
+          accb[r] += ds;
+          acct[r] = fmaf(ds, c, acct[r]);
+          w1[r] = ds * ti * rden;
+          pcol[jr * VTS] = (bf16_t)p;
+          wcol[jr * VTS] = (bf16_t)w1[r];
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = dk[r] = dv[r] = 0.f;
@@ -1191,20 +1234,20 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         for (int r = 0; r < 16; ++r) red[r] = dq[r];
       }
     }
-    __syncthreads();   // dq partials visible; every wave is done with P / W
+    lds_barrier();   // dq partials visible; every wave is done with P / W
     if (kt == 0 && iq < N) {
       // dq_i = scale * (A_i - (q_i . A_i) / |q_i|^2 q_i), A_i = sum_j W_ij k_j
       const float* r1 = &sRedQ[qt][lane * 17];
-      const bf16_t* qrow = qkv + (size_t)tq.tok * a.ldq + h * AD + 4 * lh;
       bf16_t* drow = dqkv + (size_t)tq.tok * a.lddq + h * AD + 4 * lh;
       float qv[16], dot = 0.f, q2 = 0.f;
+      // q_i from the transposed LDS tile, not from global memory again: a load here waits behind the next window's prefetch
+      // and in front of this window's stores (vmcnt is in order), a full memory round trip per window and epilogue
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(qrow + 8 * q4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * q4 + e;
-          qv[r] = (float)t4[e];
+          qv[r] = (float)sQT[(4 * lh + 8 * q4 + e) * VTS + iq];
           dq[r] += r1[r];
           dot = fmaf(qv[r], dq[r], dot);
           q2 = fmaf(qv[r], qv[r], q2);
@@ -1230,21 +1273,19 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         red2[r] = dv[r];
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (qt == 0 && jk < N) {
       // dk_j = B_j - (k_j . B_j) / |k_j|^2 k_j, B_j = scale * sum_i W_ij q_i
       const float* k1 = sRedK + (kt * 2 + 0) * 64 * 17 + lane * 17;
       const float* v1 = sRedK + (kt * 2 + 1) * 64 * 17 + lane * 17;
-      const bf16_t* krow = qkv + (size_t)tkk.tok * a.ldq + a.C + h * AD + 4 * lh;
       bf16_t* drow = dqkv + (size_t)tkk.tok * a.lddq + a.C + h * AD + 4 * lh;
       float kv[16], dot = 0.f, k2 = 0.f;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(krow + 8 * q4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * q4 + e;
-          kv[r] = (float)t4[e];
+          kv[r] = (float)sKT[(4 * lh + 8 * q4 + e) * VTS + jk];
           dk[r] = a.scale * (dk[r] + k1[r]);
           dot = fmaf(kv[r], dk[r], dot);
           k2 = fmaf(kv[r], kv[r], k2);
@@ -1266,16 +1307,22 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       }
     }
   }
+  // The sums leave through the staging tile as whole rows (a lane's own 16 elements are 4-byte pieces of 32 different rows:
+  // written directly they were 2048 partial-sector writes per wave and table)
   float* part = a.partial + ((size_t)blockIdx.x * 2 * a.heads + h) * N * N;   // [row][2][heads][N][N]
   const size_t tau_off = (size_t)a.heads * N * N;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (iq < N && j < N) {
-      const float tis = sTab[0][iq * ANS + j];
-      part[iq * N + j] = accb[r];
-      part[tau_off + iq * N + j] = tis > 0.f ? -acct[r] * tis * tis : 0.f;   // d/dtau of c / clip(tau, 0.01)
+  for (int t = 0; t < 2; ++t) {
+    __syncthreads();   // the last window's readers of sPW (t = 0) / the row stores of t = 0 are done
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float tis = reinterpret_cast<const float*>(&sTabL[0][r >> 2][tid])[r & 3];
+      stage[iq * ANS + j] = t == 0 ? accb[r] : (tis > 0.f ? -acct[r] * tis * tis : 0.f);   // d/dtau of c / clip(tau, 0.01)
     }
+    __syncthreads();
+    for (int r = w; r < N; r += 4)
+      if (lane < N) part[(t ? tau_off : 0) + r * N + lane] = stage[r * ANS + lane];
   }
 }
 
@@ -1334,7 +1381,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
   if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
 
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
-    __syncthreads();   // previous window's readers are done (and sTab has landed)
+    lds_barrier();   // previous window's readers are done (and sTab has landed)
     const WinTok tq = ntq, tkk = ntk;
     bf16x8 qf[2], kf[2];
     float rq;
@@ -1365,7 +1412,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
           for (int e = 0; e < 8; ++e) sVT[(16 * ks + 8 * lh + e) * VTS + jk] = nv[ks][e];
       }
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 ut;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ut[r] = 0.f;
@@ -1384,7 +1431,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (lh == 0) sM[kt][iq] = mx;
-    __syncthreads();
+    lds_barrier();
     const float m = fmaxf(sM[0][iq], sM[1][iq]);
     float ls = 0.f;
 #pragma unroll
@@ -1405,7 +1452,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
       for (int r = 0; r < 16; ++r) red[r] = o[r];
       if (lh == 0) sL[qt][l31] = ls;
     }
-    __syncthreads();
+    lds_barrier();
     if (kt == 0 && iq < N) {
       const float* r1 = &sRedO[qt][lane * 17];
       const float l = ls + sL[qt][l31];
