@@ -610,6 +610,7 @@ struct AttnArgs {
   int B, H, W, C, heads, ws, shift, Nt;
   int ldq, ldo, lddo, lddq;
   float scale;
+  int flags;          // ablation build only (UZ_KFLAGS)
 };
 
 constexpr int AD = 32;       // head dimension (embed_dim 96 / 3 heads, doubled together: always 32)
@@ -1059,28 +1060,33 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   // gathers its own 16 entries into the lane-order table
   float* stage = reinterpret_cast<float*>(sPW);   // [AN][ANS] floats
   static_assert(AN * ANS * sizeof(float) <= sizeof(bf16_t) * 2 * AN * VTS, "the staging tile must fit in sPW");
+  {
+    // all 32 loads of a thread in flight at once (as a loop of load -> divide -> store they were 16 serialized memory round
+    // trips, 8 us of a kernel that spends 4 us per window)
+    float tv[16], bv[16];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    for (int e = tid; e < AN * AN; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      const bool in = r < N && c < N;
-      float v;
-      if (t == 0) {
-        const float tv = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
-        const float inv = 1.f / fmaxf(tv, 0.01f);
-        v = tv >= 0.01f ? inv : -inv;
-      } else {
-        v = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;   // padding: exp() = 0, no test
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+      const bool in = r < N && c < N && !(UZ_KFLAGS(a) & 0x10000);
+      tv[i] = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
+      bv[i] = in ? a.bias[((size_t)h * N + r) * N + c] : ((r < N && c < N) ? 0.f : -1e30f);   // padding: exp() = 0, no test
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+        const float inv = 1.f / fmaxf(tv[i], 0.01f);
+        stage[r * ANS + c] = t == 0 ? (tv[i] >= 0.01f ? inv : -inv) : bv[i];
       }
-      stage[r * ANS + c] = v;
-    }
-    __syncthreads();
+      __syncthreads();
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const float* sp = stage + iq * ANS + 32 * kt + 8 * g4 + 4 * lh;
-      sTabL[t][g4][tid] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float* sp = stage + iq * ANS + 32 * kt + 8 * g4 + 4 * lh;
+        sTabL[t][g4][tid] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // A window's q, dO, O, k, v fragments are fetched one window ahead: the loads are issued right after the
@@ -1122,6 +1128,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
 
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
+    if (UZ_KFLAGS(a) & 0x40000) break;
     lds_barrier();   // previous window: every reader of the tiles / hand-over areas is done (and sTab has landed)
     const WinTok tq = ntq, tkk = ntk;
     bf16x8 qf[2], gf[2], kf[2], vf[2];
@@ -1322,7 +1329,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
     }
     __syncthreads();
     for (int r = w; r < N; r += 4)
-      if (lane < N) part[(t ? tau_off : 0) + r * N + lane] = stage[r * ANS + lane];
+      if (lane < N && !(UZ_KFLAGS(a) & 0x20000)) part[(t ? tau_off : 0) + r * N + lane] = stage[r * ANS + lane];
   }
 }
 
@@ -2251,7 +2258,7 @@ extern "C" int uz_winattn_fwd(const uz_winattn_desc* d, const void* qkv, const f
   AttnArgs a{};
   a.qkv = qkv; a.out = out; a.lse = lse; a.tau = tau; a.bias = bias;
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
-  a.ldq = d->ldq; a.ldo = d->ldo; a.scale = d->scale;
+  a.ldq = d->ldq; a.ldo = d->ldo; a.scale = d->scale; a.flags = uz_tune_flags();
   const dim3 grid(attn_grid_x(d, ATTN_SLOTS_FWD), d->heads), block(256);
   if (d->dtype == UZ_BF16 && !(uz_tune_flags() & 0x1000)) {
     // matrix-core path: one wave per (window, head), four per workgroup
@@ -2287,7 +2294,7 @@ extern "C" int uz_winattn_bwd(const uz_winattn_desc* d, const void* qkv, const f
   a.qkv = qkv; a.out = const_cast<void*>(out); a.lse = const_cast<float*>(lse); a.tau = tau; a.bias = bias;
   a.dout = dout; a.dqkv = dqkv; a.partial = partial;
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.heads = d->heads; a.ws = d->ws; a.shift = d->shift; a.Nt = d->Nt;
-  a.ldq = d->ldq; a.ldo = d->ldo; a.lddo = lddo; a.lddq = lddq; a.scale = d->scale;
+  a.ldq = d->ldq; a.ldo = d->ldo; a.lddo = lddo; a.lddq = lddq; a.scale = d->scale; a.flags = uz_tune_flags();
   const dim3 grid(attn_grid_x(d, attn_bwd_mfma(d) ? ATTN_SLOTS_BWD_MFMA : ATTN_SLOTS_BWD), d->heads), block(256);
   if (attn_bwd_mfma(d)) {
     hipLaunchKernelGGL(winattn_bwd_mfma_kernel, grid, block, 0, (hipStream_t)stream, a);
