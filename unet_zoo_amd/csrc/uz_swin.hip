@@ -635,6 +635,7 @@ __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x);
 // 32-wide fp32 vector helpers written on float pairs so that they compile to v_pk_fma_f32 / v_pk_mul_f32
 // (two fp32 operations per lane and instruction): the attention kernels are VALU-bound
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ float dot32(const float* a, const float* b) {
   f32x2 acc = {0.f, 0.f};
 #pragma unroll
@@ -1053,9 +1054,9 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
   // running sums over this workgroup's windows of dS (-> d bias) and dS * c (-> d tau) for
   // (query 32 qt + l31, key 32 kt + 4 lh + (r & 3) + 8 (r >> 2))
-  float accb[16], acct[16];
+  f32x2 accb2[8], acct2[8];   // element pairs (r, r + 1)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) accb[r] = acct[r] = 0.f;
+  for (int r = 0; r < 8; ++r) accb2[r] = acct2[r] = (f32x2){0.f, 0.f};
   // the two tables: coalesced rows from global memory into a [query][key] staging tile (the P / W area), then each lane
   // gathers its own 16 entries into the lane-order table
   float* stage = reinterpret_cast<float*>(sPW);   // [AN][ANS] floats
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       for (int i = 0; i < 16; ++i) {
         const int e = tid + 256 * i, r = e >> 6, c = e & 63;
         const float inv = 1.f / fmaxf(tv[i], 0.01f);
-        stage[r * ANS + c] = t == 0 ? (tv[i] >= 0.01f ? inv : -inv) : bv[i];
+        stage[r * ANS + c] = t == 0 ? (tv[i] >= 0.01f ? inv : -inv) : bv[i];   // negated where the clip is active
       }
       __syncthreads();
 #pragma unroll
@@ -1142,12 +1143,16 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         gf[ks] = ng[ks];
         kf[ks] = nk[ks];
         vf[ks] = nv[ks];
+        // |q|^2, |k|^2 and dO . O on bf16 pairs (v_dot2c_f32_bf16: fp32 products and sums), 12 instructions instead of ~130
+        const bf16x2* qp = reinterpret_cast<const bf16x2*>(&qf[ks]);
+        const bf16x2* kp = reinterpret_cast<const bf16x2*>(&kf[ks]);
+        const bf16x2* gp = reinterpret_cast<const bf16x2*>(&gf[ks]);
+        const bf16x2* op = reinterpret_cast<const bf16x2*>(&no[ks]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float qv = (float)qf[ks][e], kv = (float)kf[ks][e];
-          q2 = fmaf(qv, qv, q2);
-          k2 = fmaf(kv, kv, k2);
-          Di = fmaf((float)gf[ks][e], (float)no[ks][e], Di);
+        for (int e = 0; e < 4; ++e) {
+          q2 = __builtin_amdgcn_fdot2_f32_bf16(qp[e], qp[e], q2, false);
+          k2 = __builtin_amdgcn_fdot2_f32_bf16(kp[e], kp[e], k2, false);
+          Di = __builtin_amdgcn_fdot2_f32_bf16(gp[e], op[e], Di, false);
         }
       }
       q2 += __shfl_xor(q2, 32);
@@ -1193,35 +1198,48 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       bf16_t* pcol = sP + (32 * kt + 4 * lh) * VTS + iq;
       bf16_t* wcol = sW + (32 * kt + 4 * lh) * VTS + iq;
       // per key group of four: 1 / |k|, the two table entries (and, under the shifted-window mask, the region ids) in one
-      // 16-byte read each -- own data of the lane, so the 16 elements are independent chains
+      // 16-byte read each -- own data of the lane, so the 16 elements are independent chains; the arithmetic runs on float
+      // pairs (v_pk_mul / v_pk_fma / v_pk_add_f32: two elements per instruction)
+      const f32x2 sc2 = {a.scale, a.scale}, rq2 = {rq, rq}, nlse2 = {-lse, -lse}, nDi2 = {-Di, -Di};
+      const f32x2 l2e2 = {1.44269504088896341f, 1.44269504088896341f};
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const float4 v = *reinterpret_cast<const float4*>(&sRk[32 * kt + 8 * g4 + 4 * lh]);
         const float4 t = sTabL[0][g4][tid], b = sTabL[1][g4][tid];
-        const float rk4[4] = {v.x, v.y, v.z, v.w}, ti4[4] = {t.x, t.y, t.z, t.w}, bi4[4] = {b.x, b.y, b.z, b.w};
-        float pen4[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
         if (masked) {
           const int4 c4 = *reinterpret_cast<const int4*>(&sCnt[32 * kt + 8 * g4 + 4 * lh]);
-          pen4[0] = c4.x != tq.cnt ? -100.f : 0.f;
-          pen4[1] = c4.y != tq.cnt ? -100.f : 0.f;
-          pen4[2] = c4.z != tq.cnt ? -100.f : 0.f;
-          pen4[3] = c4.w != tq.cnt ? -100.f : 0.f;
+          pn.x = c4.x != tq.cnt ? -100.f : 0.f;
+          pn.y = c4.y != tq.cnt ? -100.f : 0.f;
+          pn.z = c4.z != tq.cnt ? -100.f : 0.f;
+          pn.w = c4.w != tq.cnt ? -100.f : 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g4 + e, jr = e + 8 * g4;        // jr: key row inside the tile, less 4 * lh
-          const float u = ut[r] * a.scale;
-          const float rden = fminf(rq * rk4[e], 1e6f);      // 1 / max(|scale q||k|, 1e-6)
-          const float ti = fabsf(ti4[e]);
-          const float c = u * rden;
-          const float sv = fmaf(c, ti, bi4[e]) + pen4[e];
-          const float p = __expf(sv - lse);
-          const float ds = p * (dt[r] - Di);
-          accb[r] += ds;
-          acct[r] = fmaf(ds, c, acct[r]);
-          w1[r] = ds * ti * rden;
-          pcol[jr * VTS] = (bf16_t)p;
-          wcol[jr * VTS] = (bf16_t)w1[r];
+        for (int hp = 0; hp < 2; ++hp) {
+          const int r = 4 * g4 + 2 * hp, jr = 2 * hp + 8 * g4;   // jr: key row inside the tile, less 4 * lh
+          const f32x2 rk2 = hp ? (f32x2){v.z, v.w} : (f32x2){v.x, v.y};
+          const f32x2 ti2 = hp ? (f32x2){fabsf(t.z), fabsf(t.w)} : (f32x2){fabsf(t.x), fabsf(t.y)};
+          const f32x2 bi2 = hp ? (f32x2){b.z, b.w} : (f32x2){b.x, b.y};
+          const f32x2 pn2 = hp ? (f32x2){pn.z, pn.w} : (f32x2){pn.x, pn.y};
+          const f32x2 ut2 = {ut[r], ut[r + 1]}, dt2 = {dt[r], dt[r + 1]};
+          f32x2 rden = rq2 * rk2;                                  // 1 / max(|scale q||k|, 1e-6)
+          rden.x = fminf(rden.x, 1e6f);
+          rden.y = fminf(rden.y, 1e6f);
+          const f32x2 c = (ut2 * sc2) * rden;
+          f32x2 sv = __builtin_elementwise_fma(c, ti2, bi2);
+          if (masked) sv += pn2;
+          const f32x2 ea = (sv + nlse2) * l2e2;
+          const f32x2 pp = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+          const f32x2 ds = pp * (dt2 + nDi2);
+          accb2[r >> 1] += ds;
+          acct2[r >> 1] = __builtin_elementwise_fma(ds, c, acct2[r >> 1]);
+          const f32x2 ww = (ds * ti2) * rden;
+          w1[r] = ww.x;
+          w1[r + 1] = ww.y;
+          pcol[jr * VTS] = (bf16_t)pp.x;
+          pcol[(jr + 1) * VTS] = (bf16_t)pp.y;
+          wcol[jr * VTS] = (bf16_t)ww.x;
+          wcol[(jr + 1) * VTS] = (bf16_t)ww.y;
         }
       }
 #pragma unroll
@@ -1325,7 +1343,8 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
     for (int r = 0; r < 16; ++r) {
       const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float tis = reinterpret_cast<const float*>(&sTabL[0][r >> 2][tid])[r & 3];
-      stage[iq * ANS + j] = t == 0 ? accb[r] : (tis > 0.f ? -acct[r] * tis * tis : 0.f);   // d/dtau of c / clip(tau, 0.01)
+      // d/dtau of c / clip(tau, 0.01): -sum(dS c) / tau^2 where the clip is not active, else 0
+      stage[iq * ANS + j] = t == 0 ? accb2[r >> 1][r & 1] : (tis > 0.f ? -acct2[r >> 1][r & 1] * tis * tis : 0.f);
     }
     __syncthreads();
     for (int r = w; r < N; r += 4)
