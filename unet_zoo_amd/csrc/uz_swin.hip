@@ -1361,9 +1361,11 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
   __shared__ __attribute__((aligned(16))) bf16_t sVT[AD * VTS];
   __shared__ float sRedO[2][64 * 17];   // P V hand-over of the kt = 1 waves, [lane][16] (+1 pad)
   __shared__ float sM[2][AN], sL[2][AN];
-  __shared__ float sRk[AN];
-  __shared__ int sCnt[AN];
-  __shared__ float sTab[2][AN * ANS];   // 1 / clip(tau) and bias of this head (padding: bias = -1e30)
+  __shared__ __attribute__((aligned(16))) float sRk[AN];
+  __shared__ __attribute__((aligned(16))) int sCnt[AN];
+  // 1 / clip(tau) and bias of this head (padding: bias = -1e30) in lane order, as in winattn_bwd_mfma_kernel: [table][key group
+  // of four][thread] -> the lane's own four values in one conflict-free 16-byte read
+  __shared__ float4 sTabL[2][4][256];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5, h = blockIdx.y;
   const int qt = w >> 1, kt = w & 1;
   const int N = a.ws * a.ws;
@@ -1371,13 +1373,41 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
   const bool masked = a.shift > 0;
   const bf16_t* __restrict__ qkv = static_cast<const bf16_t*>(a.qkv);
   bf16_t* __restrict__ out = static_cast<bf16_t*>(a.out);
-  for (int e = tid; e < AN * AN; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    const bool in = r < N && c < N;
-    sTab[0][r * ANS + c] = in ? 1.f / fmaxf(a.tau[((size_t)h * a.Nt + r) * a.Nt + c], 0.01f) : 1.f;
-    sTab[1][r * ANS + c] = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;
-  }
   const int iq = 32 * qt + l31, jk = 32 * kt + l31;   // this lane's query (column role) / key (column role)
+  {
+    // coalesced rows from global memory (all 32 loads of a thread in flight at once) into a [query][key] staging tile -- the
+    // P V hand-over area, not yet in use --, then each lane gathers its own 16 entries
+    float* stage = &sRedO[0][0];   // 32 query rows at a time
+    static_assert(32 * ANS <= 2 * 64 * 17, "half the staging tile must fit in sRedO");
+    float tv[16], bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+      const bool in = r < N && c < N;
+      tv[i] = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
+      bv[i] = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i = 8 * half; i < 8 * half + 8; ++i) {   // rows 32 half .. 32 half + 31
+          const int e = tid + 256 * i, r = (e >> 6) - 32 * half, c = e & 63;
+          stage[r * ANS + c] = t == 0 ? 1.f / fmaxf(tv[i], 0.01f) : bv[i];
+        }
+        __syncthreads();
+        if (qt == half) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float* sp = stage + l31 * ANS + 32 * kt + 8 * g4 + 4 * lh;
+            sTabL[t][g4][tid] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
 
   WinTok ntq = {0, -1}, ntk = {0, -1};
   bf16x8 nq[2], nk[2], nv[2];
@@ -1417,11 +1447,12 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
       for (int ks = 0; ks < 2; ++ks) {
         qf[ks] = nq[ks];
         kf[ks] = nk[ks];
+        const bf16x2* qp = reinterpret_cast<const bf16x2*>(&qf[ks]);
+        const bf16x2* kp = reinterpret_cast<const bf16x2*>(&kf[ks]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float qv = (float)qf[ks][e], kv = (float)kf[ks][e];
-          q2 = fmaf(qv, qv, q2);
-          k2 = fmaf(kv, kv, k2);
+        for (int e = 0; e < 4; ++e) {   // v_dot2c_f32_bf16
+          q2 = __builtin_amdgcn_fdot2_f32_bf16(qp[e], qp[e], q2, false);
+          k2 = __builtin_amdgcn_fdot2_f32_bf16(kp[e], kp[e], k2, false);
         }
       }
       q2 += __shfl_xor(q2, 32);
@@ -1447,13 +1478,26 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
     if (win + (int)gridDim.x < nWin) fetch(win + gridDim.x);
     float sv[16], mx = -3.0e38f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float rden = fminf(rq * sRk[j], 1e6f);      // 1 / max(|scale q||k|, 1e-6)
-      float v = fmaf(ut[r] * a.scale * rden, sTab[0][iq * ANS + j], sTab[1][iq * ANS + j]);
-      if (masked && sCnt[j] != tq.cnt) v -= 100.f;
-      sv[r] = v;
-      mx = fmaxf(mx, v);
+    for (int g4 = 0; g4 < 4; ++g4) {   // key group of four: one 16-byte read per operand, 16 independent element chains
+      const float4 kq = *reinterpret_cast<const float4*>(&sRk[32 * kt + 8 * g4 + 4 * lh]);
+      const float4 t = sTabL[0][g4][tid], b = sTabL[1][g4][tid];
+      const float rk4[4] = {kq.x, kq.y, kq.z, kq.w}, ti4[4] = {t.x, t.y, t.z, t.w}, bi4[4] = {b.x, b.y, b.z, b.w};
+      float pen4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (masked) {
+        const int4 c4 = *reinterpret_cast<const int4*>(&sCnt[32 * kt + 8 * g4 + 4 * lh]);
+        pen4[0] = c4.x != tq.cnt ? -100.f : 0.f;
+        pen4[1] = c4.y != tq.cnt ? -100.f : 0.f;
+        pen4[2] = c4.z != tq.cnt ? -100.f : 0.f;
+        pen4[3] = c4.w != tq.cnt ? -100.f : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e;
+        const float rden = fminf(rq * rk4[e], 1e6f);      // 1 / max(|scale q||k|, 1e-6)
+        const float v = fmaf(ut[r] * a.scale * rden, ti4[e], bi4[e]) + pen4[e];
+        sv[r] = v;
+        mx = fmaxf(mx, v);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     if (lh == 0) sM[kt][iq] = mx;
