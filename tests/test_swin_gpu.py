@@ -496,3 +496,18 @@ def test_swin_dropout_options_train_and_are_off_in_eval():
     gs = unet_zoo_amd.GraphedStep(m, "bce_dice", lr=1e-3)
     losses = [gs(x, mask).item() for _ in range(10)]
     assert all(np.isfinite(losses)) and min(losses[5:]) < losses[0]
+
+
+@pytest.mark.parametrize("rows,n,n0", [(16, 196608, 98304), (147, 24576, 24576), (64, 16384, 16380), (33, 20000, 20000)])
+def test_row_sums_of_few_rows_of_many_columns(rows, n, n0):
+    """uz_sum_rows_f32 on the window-attention d(bias) / d(tau) partial shapes (the 16-byte-per-thread kernel of uz_attn.hip)
+    against a double-precision torch sum; the split into two destinations falls inside a thread's four columns once"""
+    g = torch.Generator().manual_seed(rows)
+    part = torch.randn(rows, n, generator=g).to(DEV)
+    out0 = torch.empty(n0, device=DEV)
+    out1 = torch.empty(n - n0, device=DEV) if n0 < n else None
+    ops.sum_rows_f32(part, rows, out0, out1)
+    ref = part.double().sum(0).float()
+    assert torch.equal(out0, ref[:n0])
+    if out1 is not None:
+        assert torch.equal(out1, ref[n0:])
