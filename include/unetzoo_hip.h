@@ -186,6 +186,21 @@ int uz_wgrad_kernel_name(const uz_wgrad_desc* d, char* buf, int cap);
  * kernel (partial slabs into the workspace), phase 2 = the fixed-order slab reduction into `out`.  uz_wgrad == 1 then 2. */
 int uz_wgrad_phase(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream,
                    int phase);
+/* n independent problems, each exactly uz_wgrad(&items[i].desc, L, R, out, ...), issued together: the one-tap (nn.Linear)
+ * problems of the bf16 run mode share launches -- one per tile shape and 24 problems, plus one reduction per 64 -- with the
+ * pixel split planned for the whole set; every other problem runs through uz_wgrad.  The weight gradients of a model's
+ * Linear layers (swin_unet_v2.py:205-240, missformer.py:148-214) are not needed before the optimizer step, so the host
+ * defers them to the end of the backward pass.  Deterministic for a given set of items: each problem's pixel split -- and so
+ * the order of its fp32 additions -- is a function of the set, not of timing.  A problem that is not split writes straight
+ * into `out`.  Workspace: uz_wgrad_multi_workspace_bytes(), 256-byte aligned. */
+typedef struct {
+  uz_wgrad_desc desc;
+  const void* L;
+  const void* R;
+  float* out;
+} uz_wgrad_item;
+long long uz_wgrad_multi_workspace_bytes(const uz_wgrad_item* items, int n); /* <0 on error */
+int uz_wgrad_multi(const uz_wgrad_item* items, int n, void* workspace, void* stream);
 /* `batch` independent one-tap problems of the shape `d` in one launch pair: problem b reads L + b * lb, R + b * rb
  * (strides in elements, multiples of 16 bytes) and writes out + b * ob floats -- the per-image products of the token
  * attention that contract over the rows of both operands (dV_b = A_b^T dO_b, dK_b = dS_b^T Q_b,

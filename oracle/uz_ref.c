@@ -840,4 +840,20 @@ int uz_conv3x3_first_wgrad_ref(int dtype, const float* x, int N, int C, int H, i
 }
 UZ_SAME_SIGNATURE(uz_conv3x3_first_wgrad);
 
+/* ---- uz_wgrad_multi: the same weight gradients, issued together (the host defers the nn.Linear ones, swin_unet_v2.py:205-240) -- */
+long long uz_wgrad_multi_workspace_bytes_ref(const uz_wgrad_item* items, int n) {
+  (void)items, (void)n;
+  return 0;
+}
+UZ_SAME_SIGNATURE(uz_wgrad_multi_workspace_bytes);
+
+int uz_wgrad_multi_ref(const uz_wgrad_item* items, int n, void* workspace, void* stream) {
+  for (int i = 0; i < n; ++i) {
+    const int rc = uz_wgrad_ref(&items[i].desc, items[i].L, items[i].R, items[i].out, workspace, stream);
+    if (rc != UZ_OK) return rc;
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_wgrad_multi);
+
 int uz_ref_abi_version(void) { return 1; }

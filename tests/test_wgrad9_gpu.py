@@ -203,3 +203,76 @@ def test_gather4_channel_windows_of_poisoned_buffers():
     got = ops.wgrad(Act(xw, 32, Cin, N, H, W), Act(gw, 0, Cout, N, 2 * H, 2 * W), (Cin, Cout, 2, 2), ntaps=4,
                     taps_mode=L.TAPS_GATHER2X2)
     assert torch.isfinite(got).all() and relerr(got.cpu(), ref) < 2e-2
+
+
+# ---- uz_wgrad_multi: several problems issued together ------------------------------------------------------------------
+def _multi_entries(g, shapes):
+    ents = []
+    for (N, H, W, Co, Ci) in shapes:
+        dy = ops.Act(torch.randint(-2, 3, (N * H * W, Co), generator=g).to(torch.bfloat16).to(DEV), 0, Co, N, H, W)
+        x = ops.Act(torch.randint(-2, 3, (N * H * W, Ci), generator=g).to(torch.bfloat16).to(DEV), 0, Ci, N, H, W)
+        ents.append((dy, x, torch.full((Co, Ci), float("nan"), device=DEV), 1, L.TAPS_CONV, 1))
+    return ents
+
+
+def test_wgrad_multi_linear_layers_exact_on_integers():
+    """the nn.Linear weight gradients of a swin-like backward range in one uz_wgrad_multi call: 128 x 128 and 64 x 64 tile
+    groups, token counts that are no multiple of 64, more problems than one launch carries; integer operands, so every
+    summation order gives the same fp32 result as the double-precision product"""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2, 56, 56, 288, 96), (2, 56, 56, 96, 96), (2, 56, 56, 384, 96), (2, 56, 56, 96, 384), (2, 28, 28, 576, 192),
+              (2, 28, 28, 192, 768), (2, 14, 14, 1152, 384), (2, 7, 7, 768, 3072), (1, 7, 7, 40, 24), (3, 5, 9, 64, 64)]
+    shapes = shapes + [(1, 14, 14, 32 + 8 * i, 48) for i in range(30)]      # > 24 problems of the 64 x 64 tile shape
+    ents = _multi_entries(g, shapes)
+    ops.wgrad_multi(ents)
+    for (dy, x, out, *_), sh in zip(ents, shapes):
+        ref = dy.buf.double().t() @ x.buf.double()
+        assert torch.equal(out.double(), ref), sh
+
+
+def test_wgrad_multi_mixes_shared_launches_with_single_problems():
+    """a nine-tap convolution problem and an fp32 problem in the same call run through uz_wgrad; results as uz_wgrad's"""
+    g = torch.Generator().manual_seed(6)
+    ents = _multi_entries(g, [(2, 32, 32, 128, 64), (1, 16, 16, 256, 256)])
+    N, H, W, C = 2, 32, 32, 64
+    dy = ops.Act(torch.randn(N * H * W, C, generator=g).to(torch.bfloat16).to(DEV), 0, C, N, H, W)
+    x = ops.Act(torch.randn(N * H * W, C, generator=g).to(torch.bfloat16).to(DEV), 0, C, N, H, W)
+    o9 = torch.empty(C, C, 3, 3, device=DEV)
+    ents.append((dy, x, o9, 9, L.TAPS_CONV, 1))
+    dyf = ops.Act(torch.randn(200, 24, generator=g).to(DEV), 0, 24, 1, 10, 20)
+    xf = ops.Act(torch.randn(200, 16, generator=g).to(DEV), 0, 16, 1, 10, 20)
+    of = torch.empty(24, 16, device=DEV)
+    ents.append((dyf, xf, of, 1, L.TAPS_CONV, 1))
+    ops.wgrad_multi(ents)
+    assert torch.equal(o9, ops.wgrad(dy, x, (C, C, 3, 3), ntaps=9))
+    assert torch.equal(of, ops.wgrad(dyf, xf, (24, 16), ntaps=1))
+    for dyb, xb, out, *_ in ents[:2]:
+        assert torch.equal(out.double(), dyb.buf.double().t() @ xb.buf.double())
+
+
+def test_swin_step_with_and_without_deferred_linear_weight_gradients():
+    """the engine's deferred nn.Linear weight gradients (Engine.defer_linear_wgrads) against the one-by-one launches on a
+    swin_unet_v2 backward: same gradients up to the summation order of the pixel split"""
+    import unet_zoo_amd
+    from unet_zoo_amd.engine import Engine
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    grads, fams = [], []
+    for defer in (True, False):
+        Engine.defer_linear_wgrads = defer
+        try:
+            torch.manual_seed(0)
+            m = unet_zoo_amd.create_model("swin_unet_v2", image_size=64, in_channels=3, num_classes=1, window_size=4,
+                                          drop_path_rate=0.0)
+            m.run_dtype = torch.bfloat16
+            m = m.to(DEV).train()
+            ops.profile_begin()
+            m(x).float().mean().backward()
+            fams.append(set(ops.profile_end()))
+            grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            Engine.defer_linear_wgrads = True
+    assert "wgrad_multi" in fams[0] and "wgrad_multi" not in fams[1]
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 50
+    for n in grads[0]:
+        a, b = grads[0][n].double(), grads[1][n].double()
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max().item() + 1e-9, n

@@ -46,7 +46,7 @@ EXPORTS = (
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
     "uz_gelu_fwd", "uz_gelu_bwd", "uz_dwconv3x3", "uz_dwconv3x3_wgrad_rows", "uz_dwconv3x3_wgrad",
     "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
-    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res",
+    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res", "uz_wgrad_multi_workspace_bytes", "uz_wgrad_multi",
     "uz_add_relu", "uz_relu_bwd", "uz_pil_resample_h_u8", "uz_pil_resample_v_f32",
     "uz_gemm_nt", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd", "uz_adaptive_avgpool_bwd",
     "uz_rowdot_f32", "uz_cast_rows", "uz_wgrad_batched_workspace_bytes", "uz_wgrad_batched", "uz_wgrad_batched2",
@@ -89,6 +89,10 @@ class GemmDesc(Structure):
     _fields_ = [(n, c_int) for n in ("dtype", "batch", "M", "N", "K", "ldx", "ldw", "ldy", "ldres")] \
         + [(n, ctypes.c_longlong) for n in ("xb", "wb", "yb", "resb")] + [("batch2", c_int)] \
         + [(n, ctypes.c_longlong) for n in ("xb2", "wb2", "yb2", "resb2")]
+
+
+class WgradItem(Structure):
+    _fields_ = [("desc", WgradDesc), ("L", c_void_p), ("R", c_void_p), ("out", c_void_p)]
 
 
 class SumRowsItem(Structure):
@@ -235,6 +239,9 @@ def load():
     lib.uz_fuse1x1_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip]
     lib.uz_fuse1x1_bwd.argtypes = [vp, ip, ip, ip, ip, vp, vp, POINTER(c_void_p), ip, vp, vp, vp, vp, vp]
     lib.uz_sum_rows_f32_batched.argtypes = [POINTER(SumRowsItem), ip, vp]
+    lib.uz_wgrad_multi_workspace_bytes.argtypes = [POINTER(WgradItem), ip]
+    lib.uz_wgrad_multi_workspace_bytes.restype = ctypes.c_longlong
+    lib.uz_wgrad_multi.argtypes = [POINTER(WgradItem), ip, vp, vp]
     lib.uz_colsum_batched_workspace_bytes.argtypes = [ip, POINTER(ColsumItem), ip]
     lib.uz_colsum_batched.argtypes = [ip, POINTER(ColsumItem), ip, vp, vp]
     lib.uz_bce_dice_workspace_bytes.argtypes = [ll]

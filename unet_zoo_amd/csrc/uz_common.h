@@ -157,6 +157,17 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
                        long long slab_stride = 0,   // floats between the problems' slabs (0: dense)
                        int batch2 = 1, long long lb2_bytes = 0, long long rb2_bytes = 0);   // batch = ALL problems (outer * inner)
 
+// several one-tap problems in one launch (uz_wgrad_multi): plans from uz_wgrad3x3_plan() with one_tap && !gather && !v9, all
+// of one tile shape (big); at most uz_wgrad3x3_multi_max() per launch
+struct UzWgradMultiItem {
+  const uz_wgrad_desc* d;
+  UzWgrad2Plan p;
+  const void *L, *R;
+  float* slab;
+};
+int uz_wgrad3x3_multi_max();
+int uz_wgrad3x3_multi_launch(const UzWgradMultiItem* items, int n, hipStream_t s);
+
 // LDS-DMA pixel-major GEMM (uz_gemm_dma.hip): 1x1 / ConvTranspose fwd + dgrad, dispatched from uz_conv_igemm()
 struct UzGemmPlan {
   int bn, bm, nst, tiles_m, tiles_n, grid_m;

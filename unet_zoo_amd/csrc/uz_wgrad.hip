@@ -444,6 +444,202 @@ extern "C" int uz_wgrad_phase(const uz_wgrad_desc* d, const void* L, const void*
 }
 
 
+// ---- several independent problems in one launch pair (uz_wgrad_multi) ---------------------------------------------------
+// The nn.Linear weight gradients of a backward range are not on the critical path (nothing reads them before the
+// optimizer): issued one by one each was a ~12 us launch on 3 ... 30 tiles plus a ~4 us reduction, ~100 launches per
+// swin_unet_v2 step.  Deferred and issued together they fill the chip with ~64-step workgroups.
+constexpr int UZ_RED_MULTI = 64;
+struct RedItem {
+  const float* slab;
+  float* out;
+  long long cicj;
+  int split, first;
+};
+struct RedMulti {
+  int n, total;
+  RedItem it[UZ_RED_MULTI];
+};
+static_assert(sizeof(RedMulti) <= 4096, "kernel arguments");
+// the slab sums of wgrad_reduce_kernel<1, 4>, problem by lookup: same order of additions per element.  V = 4: four
+// consecutive elements per thread (16-byte loads; Ci * Cj is a multiple of 64 for every problem of the shared launches).
+template <int V>
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedMulti m) {
+  constexpr int ZG = 4;
+  __shared__ float red[ZG][64][V];
+  int lo = 0, hi = m.n;   // the problem of this workgroup: binary search, first[] is increasing
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= m.it[mid].first) lo = mid;
+    else hi = mid;
+  }
+  const RedItem& q = m.it[lo];
+  const int x = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const long long e = ((long long)((int)blockIdx.x - q.first) * 64 + x) * V;
+  float acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = 0.f;
+  auto ld = [&](int z, float* f) {
+    const float* p = q.slab + (size_t)z * q.cicj + e;
+    if constexpr (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      f[0] = t.x, f[1] = t.y, f[2] = t.z, f[3] = t.w;
+    } else {
+      f[0] = p[0];
+    }
+  };
+  if (e < q.cicj) {
+    int z = zg;
+    for (; z + ZG < q.split; z += 2 * ZG) {
+      float a0[V], a1[V];
+      ld(z, a0);
+      ld(z + ZG, a1);
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = (acc[v] + a0[v]) + a1[v];
+    }
+    if (z < q.split) {
+      float a0[V];
+      ld(z, a0);
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] += a0[v];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) red[zg][x][v] = acc[v];
+  __syncthreads();
+  if (zg == 0 && e < q.cicj) {
+    float r[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      r[v] = 0.f;
+#pragma unroll
+      for (int k = 0; k < ZG; ++k) r[v] += red[k][x][v];
+    }
+    if constexpr (V == 4) *reinterpret_cast<float4*>(q.out + e) = make_float4(r[0], r[1], r[2], r[3]);
+    else q.out[e] = r[0];
+  }
+}
+
+namespace {
+struct MultiPlan {
+  int n = 0;
+  bool* together = nullptr;       // problem i goes into the shared launches
+  UzWgrad2Plan* p2 = nullptr;
+  long long* ws_off = nullptr;    // byte offset of problem i's slabs in the workspace
+  long long ws_total = 0;
+  ~MultiPlan() {
+    delete[] together;
+    delete[] p2;
+    delete[] ws_off;
+  }
+};
+}  // namespace
+
+static int multi_plan(const uz_wgrad_item* items, int n, MultiPlan* mp) {
+  UZ_REQUIRE(items && n >= 1 && n <= 4096, "uz_wgrad_multi: items / n");
+  mp->n = n;
+  mp->together = new bool[n];
+  mp->p2 = new UzWgrad2Plan[n];
+  mp->ws_off = new long long[n];
+  long long steps = 0;
+  for (int i = 0; i < n; ++i) {
+    const uz_wgrad_desc* d = &items[i].desc;
+    const long long wb = uz_wgrad_workspace_bytes(d);   // validates the descriptor
+    if (wb < 0) return (int)wb;
+    UzWgrad2Plan& p = mp->p2[i];
+    mp->together[i] = uz_wgrad3x3_plan(d, &p) != 0 && p.one_tap && !p.gather && !p.v9 && d->ntaps == 1;
+    if (mp->together[i]) steps += (long long)p.units * p.tiles_i * p.tiles_j;
+  }
+  // K-steps (64 pixels each) per workgroup: long enough to carry the pipeline fill and the 64 KB slab store, short
+  // enough that the whole set is several rounds of workgroups
+  long long T = steps / (4LL * UZ_NUM_CU);
+  T = T < 8 ? 8 : (T > 64 ? 64 : T);
+  long long off = 0;
+  for (int i = 0; i < n; ++i) {
+    const uz_wgrad_desc* d = &items[i].desc;
+    mp->ws_off[i] = off;
+    long long bytes;
+    if (mp->together[i]) {
+      UzWgrad2Plan& p = mp->p2[i];
+      long long upb = p.units < T ? p.units : T;
+      const long long split = (p.units + upb - 1) / upb;
+      upb = (p.units + split - 1) / split;
+      p.upb = (int)upb;
+      p.split = (int)((p.units + upb - 1) / upb);
+      p.nslabs = p.split;
+      bytes = (long long)p.nslabs * d->Ci * d->Cj * (long long)sizeof(float);
+    } else {
+      bytes = uz_wgrad_workspace_bytes(d);
+    }
+    off += (bytes + 255) & ~255LL;
+  }
+  mp->ws_total = off;
+  return UZ_OK;
+}
+
+extern "C" long long uz_wgrad_multi_workspace_bytes(const uz_wgrad_item* items, int n) {
+  MultiPlan mp;
+  const int rc = multi_plan(items, n, &mp);
+  return rc != UZ_OK ? rc : mp.ws_total;
+}
+
+extern "C" int uz_wgrad_multi(const uz_wgrad_item* items, int n, void* workspace, void* stream) {
+  MultiPlan mp;
+  const int rc = multi_plan(items, n, &mp);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, "uz_wgrad_multi: workspace must be 256-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  for (int i = 0; i < n; ++i) {
+    UZ_REQUIRE(items[i].L && items[i].R && items[i].out, "uz_wgrad_multi: null pointer in item %d", i);
+    UZ_REQUIRE((((uintptr_t)items[i].L | (uintptr_t)items[i].R) & 15) == 0, "uz_wgrad_multi: L / R must be 16-byte aligned");
+    if (!mp.together[i]) {
+      const int r = uz_wgrad(&items[i].desc, items[i].L, items[i].R, items[i].out, ws + mp.ws_off[i], stream);
+      if (r != UZ_OK) return r;
+    }
+  }
+  const int cap = uz_wgrad3x3_multi_max();
+  for (int big = 0; big < 2; ++big) {
+    UzWgradMultiItem grp[64];
+    int g = 0;
+    for (int i = 0; i <= n; ++i) {
+      const bool take = i < n && mp.together[i] && mp.p2[i].big == big;
+      // a problem that is not split writes its one "slab" where the result belongs
+      if (take)
+        grp[g++] = UzWgradMultiItem{&items[i].desc, mp.p2[i], items[i].L, items[i].R,
+                                    mp.p2[i].nslabs == 1 ? items[i].out : reinterpret_cast<float*>(ws + mp.ws_off[i])};
+      if (g == cap || (i == n && g > 0)) {
+        const int r = uz_wgrad3x3_multi_launch(grp, g, s);
+        if (r != UZ_OK) return r;
+        g = 0;
+      }
+    }
+  }
+  bool vec4 = true;   // 16-byte stores need aligned destinations (a gradient may be a view into a flat buffer)
+  for (int i = 0; i < n; ++i)
+    if (mp.together[i] && mp.p2[i].nslabs > 1 && (((uintptr_t)items[i].out & 15) != 0 || ((long long)items[i].desc.Ci * items[i].desc.Cj) % 4 != 0))
+      vec4 = false;
+  const int epb = vec4 ? 256 : 64;   // elements per workgroup
+  RedMulti rm;
+  rm.n = 0;
+  int blocks = 0;
+  for (int i = 0; i <= n; ++i) {
+    if (i < n && mp.together[i] && mp.p2[i].nslabs > 1) {
+      const long long cicj = (long long)items[i].desc.Ci * items[i].desc.Cj;
+      rm.it[rm.n++] = RedItem{reinterpret_cast<const float*>(ws + mp.ws_off[i]), items[i].out, cicj, mp.p2[i].nslabs, blocks};
+      blocks += (int)((cicj + epb - 1) / epb);
+    }
+    if (rm.n == UZ_RED_MULTI || (i == n && rm.n > 0)) {
+      rm.total = blocks;
+      if (vec4) hipLaunchKernelGGL(wgrad_reduce_multi_kernel<4>, dim3(blocks), dim3(256), 0, s, rm);
+      else hipLaunchKernelGGL(wgrad_reduce_multi_kernel<1>, dim3(blocks), dim3(256), 0, s, rm);
+      UZ_LAUNCH_CHECK("uz_wgrad_multi(reduce)");
+      rm.n = 0;
+      blocks = 0;
+    }
+  }
+  return UZ_OK;
+}
+
 // ---- batched one-tap products: out_b[i][j] = sum_p L_b[p][i] R_b[p][j] ------------------------------------------------
 static int batched_plan(const uz_wgrad_desc* d, int batch, UzWgrad2Plan* p2) {
   UZ_REQUIRE(d && batch >= 1 && batch <= 65535, "uz_wgrad_batched: batch");

@@ -86,7 +86,8 @@ __device__ __forceinline__ void pin(bf16x4& v) { asm volatile("" : "+v"(v)); }
 // 2x2 / stride-2 3x3 gathers (Wg2Args::gather 1 / 2).  Compile-time: the pieces are issued from ten places of the
 // unrolled double-step, each would carry the three-way branch.
 template <int BI, int BJ, int NTY, int NTX, int WI, int WJ, int TG, int MODE>
-__global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
+__device__ __forceinline__ void wgrad3x3_body(const Wg2Args& a, const int blk_x, const int blk_y, const int blk_z, const int grd_x,
+                                              const int grd_z) {
   static_assert(WI * WJ * TG == 8, "8 waves");
   static_assert((NTX == 3) || (NTX == 1 && NTY == 1), "1 tap or 3/9 taps");
   constexpr int HALO = (NTX == 3) ? 1 : 0;
@@ -121,16 +122,16 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   // work item = (channel tile, kernel row ty, pixel split z).  The three kernel rows of one
   // (tile, z) read the same dy tile and overlapping x rows: give them workgroup ids that differ by
   // multiples of 8 so that they share an XCD (one L2) and run at about the same time (speed only).
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  int bx = blk_x, by = blk_y, bz = blk_z;
   if (NTY == 1 && NTX == 3) {
-    const int U = gridDim.x * gridDim.z;           // (tile, z) pairs
+    const int U = grd_x * grd_z;           // (tile, z) pairs
     if ((U & 7) == 0 && !(UZ_KFLAGS(a) & 4)) {
-      const int id = blockIdx.x + gridDim.x * (blockIdx.y + 3 * blockIdx.z);
+      const int id = blk_x + grd_x * (blk_y + 3 * blk_z);
       const int xcd = id & 7, j = id >> 3;
       by = j % 3;
       const int u = (j / 3) * 8 + xcd;
-      bx = u % (int)gridDim.x;
-      bz = u / (int)gridDim.x;
+      bx = u % grd_x;
+      bz = u / grd_x;
     }
   }
   const int ti0 = (bx / a.tiles_j) * BI, tj0 = (bx % a.tiles_j) * BJ;
@@ -420,6 +421,38 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
   }
 }
 
+template <int BI, int BJ, int NTY, int NTX, int WI, int WJ, int TG, int MODE>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_kernel(const Wg2Args a) {
+  wgrad3x3_body<BI, BJ, NTY, NTX, WI, WJ, TG, MODE>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z);
+}
+
+// Several one-tap problems (the nn.Linear weight gradients of a backward range, uz_wgrad_multi) in one launch: workgroup
+// w belongs to problem i with first[i] <= w < first[i + 1] and is its (tile, split) pair number w - first[i], tile fastest.
+// The problems' arguments travel in the kernel-argument segment (<= 4 KB: UZ_WG_MULTI problems per launch).
+constexpr int UZ_WG_MULTI = 24;
+struct WgMulti {
+  int n;
+  int first[UZ_WG_MULTI + 1];
+  int tiles[UZ_WG_MULTI];
+  Wg2Args p[UZ_WG_MULTI];
+};
+static_assert(sizeof(WgMulti) <= 4096, "kernel arguments");
+template <int BI, int BJ, int WI, int WJ, int TG>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_multi_kernel(const WgMulti m) {
+  int i = 0;
+  while (i + 1 < m.n && (int)blockIdx.x >= m.first[i + 1]) ++i;
+  const int tiles = m.tiles[i], n = m.first[i + 1] - m.first[i];
+  int local = blockIdx.x - m.first[i];
+  // The tiles of one pixel range read the same dy / x pixels: put them on one XCD (workgroup ids 8 apart share an L2) and
+  // next to each other in time.  The problem's ids of one residue mod 8 form a column; columns are filled one after the
+  // other with (pixel range, tile) pairs, tile fastest -- a permutation of the problem's own workgroups.
+  {
+    const int c = local & 7, j = local >> 3, q = n >> 3, rem = n & 7;
+    local = c * q + (c < rem ? c : rem) + j;
+  }
+  wgrad3x3_body<BI, BJ, 1, 1, WI, WJ, TG, 0>(m.p[i], local % tiles, 0, local / tiles, tiles, 1);
+}
+
 }  // namespace
 
 int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch) {
@@ -526,21 +559,11 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch) {
   return 1;
 }
 
-int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
-                       float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes, long long slab_stride,
-                       int batch2, long long lb2_bytes, long long rb2_bytes) {
-  if (p.v9) {
-    UZ_REQUIRE(batch == 1, "uz_wgrad(3x3): the row-walk / four-tap kernels take one problem");
-    return p.v9 == 2 ? uz_wgrad_g4_launch(d, p, L, R, slab, s) : uz_wgrad9_launch(d, p, L, R, slab, s);
-  }
-  Wg2Args a;
-  a.lb = lb_bytes;
-  a.rb = rb_bytes;
-  a.nb2 = batch2 > 1 ? batch2 : 1;
-  a.lb2 = lb2_bytes;
-  a.rb2 = rb2_bytes;
-  a.sb = slab_stride ? slab_stride : (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
-  UZ_REQUIRE(batch == 1 || (p.one_tap && !p.gather && batch <= 65535), "uz_wgrad(3x3): only one-tap problems are batched");
+static void wg2_fill(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, Wg2Args* ap) {
+  Wg2Args& a = *ap;
+  a.lb = a.rb = a.lb2 = a.rb2 = 0;
+  a.nb2 = 1;
+  a.sb = (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
   a.L = L;
   a.R = R;
   a.slab = slab;
@@ -564,6 +587,48 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.units = p.units;
   a.upb = p.upb;
   a.tiles_j = p.tiles_j;
+}
+
+// One launch for up to UZ_WG_MULTI one-tap problems of one tile shape (uz_wgrad_multi): see wgrad3x3_multi_kernel
+int uz_wgrad3x3_multi_max() { return UZ_WG_MULTI; }
+int uz_wgrad3x3_multi_launch(const UzWgradMultiItem* items, int n, hipStream_t s) {
+  UZ_REQUIRE(n >= 1 && n <= UZ_WG_MULTI, "uz_wgrad_multi: %d problems in one launch", n);
+  WgMulti m;
+  m.n = n;
+  int wg = 0;
+  const int big = items[0].p.big;
+  for (int i = 0; i < n; ++i) {
+    const UzWgradMultiItem& it = items[i];
+    UZ_REQUIRE(it.p.one_tap && !it.p.gather && !it.p.v9 && it.p.big == big && it.p.kg == 1,
+               "uz_wgrad_multi: one-tap problems of one tile shape only");
+    wg2_fill(it.d, it.p, it.L, it.R, it.slab, &m.p[i]);
+    m.first[i] = wg;
+    m.tiles[i] = it.p.tiles_i * it.p.tiles_j;
+    wg += m.tiles[i] * it.p.split;
+  }
+  m.first[n] = wg;
+  if (big) hipLaunchKernelGGL((wgrad3x3_multi_kernel<128, 128, 2, 4, 1>), dim3(wg), dim3(512), 0, s, m);
+  else hipLaunchKernelGGL((wgrad3x3_multi_kernel<64, 64, 2, 2, 2>), dim3(wg), dim3(512), 0, s, m);
+  UZ_LAUNCH_CHECK("uz_wgrad_multi");
+  return UZ_OK;
+}
+
+int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
+                       float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes, long long slab_stride,
+                       int batch2, long long lb2_bytes, long long rb2_bytes) {
+  if (p.v9) {
+    UZ_REQUIRE(batch == 1, "uz_wgrad(3x3): the row-walk / four-tap kernels take one problem");
+    return p.v9 == 2 ? uz_wgrad_g4_launch(d, p, L, R, slab, s) : uz_wgrad9_launch(d, p, L, R, slab, s);
+  }
+  Wg2Args a;
+  wg2_fill(d, p, L, R, slab, &a);
+  a.lb = lb_bytes;
+  a.rb = rb_bytes;
+  a.nb2 = batch2 > 1 ? batch2 : 1;
+  a.lb2 = lb2_bytes;
+  a.rb2 = rb2_bytes;
+  a.sb = slab_stride ? slab_stride : (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
+  UZ_REQUIRE(batch == 1 || (p.one_tap && !p.gather && batch <= 65535), "uz_wgrad(3x3): only one-tap problems are batched");
   dim3 block(512);
   const int mode = a.r_up ? 1 : (p.gather == 1 ? 2 : (p.gather == 2 ? 3 : 0));
 #define UZ_WG_LAUNCH(MODE_, ...) \

@@ -163,6 +163,9 @@ class Engine:
     # the first convolution of the bf16 run mode as direct kernels on the fp32 NCHW image (uz_conv_first.hip) instead of
     # im2col + GEMM + one-tap weight gradient (class-level: tools/ab_step.py times both ways in one process)
     direct_first_conv = True
+    # nn.Linear weight gradients of a backward range: nothing reads them before the optimizer, so they are issued together
+    # when the range ends (uz_wgrad_multi) instead of as ~100 small launches between the GEMMs of a swin_unet_v2 step
+    defer_linear_wgrads = True
     # the BatchNorm-backward reduction of a sole-reader activation rides in the epilogue of the 3x3 input-gradient
     # convolution / of the ConvTranspose input-gradient GEMM that produces its gradient (class-level so that
     # tools/ab_step.py can time both ways in one process; no environment switch)
@@ -192,6 +195,7 @@ class Engine:
         self.grad_log: List[Tuple[int, nn.Parameter]] = []
         self._pending_colsums: List[Tuple[int, nn.Parameter, Act]] = []   # bias gradients of the running backward range
         self._pending_rowsums: List[Tuple[int, Callable[[], None]]] = []
+        self._pending_wgrads: List[Tuple[int, nn.Parameter, Act, Act]] = []
         self._rowsum_items: list = []
         self._cpb: Dict[nn.Module, dict] = {}     # position_biases(): WindowAttention module -> batched entry
         self._bn_counters: List[torch.Tensor] = []  # num_batches_tracked of the train-mode BatchNorms seen
@@ -253,6 +257,13 @@ class Engine:
         range in two launches (uz_colsum_batched) when backward_range() ends; g stays alive until then."""
         self._pending_colsums.append((self._cur_entry, p, g))
 
+    def _linear_wgrad(self, p: nn.Parameter, g: Act, x: Act) -> None:
+        """d(loss)/d(weight) of y = W x from the output gradient g and the input x, now or with the rest of the range"""
+        if self.defer_linear_wgrads and self.dtype == torch.bfloat16:
+            self._pending_wgrads.append((self._cur_entry, p, g, x))
+        else:
+            self._give_grad(p, ops.wgrad(g, x, tuple(p.shape), ntaps=1, out=self._dst(p)))
+
     def _after_rowsums(self, fn: Callable[[], None]) -> None:
         """run fn (the _give_grad calls of parameter gradients left as per-workgroup partial rows) once the batched row
         sums of this backward range have been enqueued; ops take `defer=self._rowsum_items`"""
@@ -266,6 +277,16 @@ class Engine:
             for entry, fn in after:
                 self._cur_entry = entry
                 fn()
+        wpend, self._pending_wgrads = self._pending_wgrads, []
+        if wpend:
+            wouts = []
+            for _, p, _, _ in wpend:
+                dst = self._dst(p)
+                wouts.append(dst if dst is not None else torch.empty(tuple(p.shape), dtype=torch.float32, device=self.device))
+            ops.wgrad_multi([(g, x, o, 1, L.TAPS_CONV, 1) for (_, _, g, x), o in zip(wpend, wouts)])
+            for (entry, p, _, _), o in zip(wpend, wouts):
+                self._cur_entry = entry
+                self._give_grad(p, o)
         pend, self._pending_colsums = self._pending_colsums, []
         if not pend:
             return
@@ -803,8 +824,7 @@ class Engine:
                     residual.add_grad(g)
                 if lin.bias is not None:
                     self._bias_grad(lin.bias, g)
-                self._give_grad(lin.weight, ops.wgrad(g, x, tuple(lin.weight.shape), ntaps=1,
-                                                      out=self._dst(lin.weight)))
+                self._linear_wgrad(lin.weight, g, x)
                 if x.needs_grad:
                     prev = x.grads.pop() if (x.grads and x.parts is None and x.rparts is None) else None
                     dx = self.new_act(x.N, x.H, x.W, x.C)

@@ -387,6 +387,27 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     return out
 
 
+def wgrad_multi(entries: Sequence) -> None:
+    """uz_wgrad for every (L, R, out, ntaps, taps_mode, dil) entry, issued together (uz_wgrad_multi): the one-tap problems
+    -- nn.Linear weight gradients -- share a few launches; out tensors are fp32, reference parameter layout"""
+    if not entries:
+        return
+    lib = L.load()
+    arr = (L.WgradItem * len(entries))()
+    flops = nbytes = 0.0
+    for i, (Lt, Rt, out, ntaps, taps_mode, dil) in enumerate(entries):
+        L.require_cuda(Lt.buf, Rt.buf, out)
+        assert out.numel() == Lt.C * Rt.C * ntaps and out.is_contiguous() and out.dtype == torch.float32
+        d = L.WgradDesc(L.dtype_code(Lt.dtype), Lt.N, Lt.H, Lt.W, Rt.H, Rt.W, Lt.C, Lt.ld, Rt.C, Rt.ld, ntaps, taps_mode, dil)
+        arr[i] = L.WgradItem(d, Lt.ptr(), Rt.ptr(), out.data_ptr())
+        flops += 2.0 * Lt.P * Lt.C * Rt.C * ntaps
+        nbytes += Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()
+    ws_bytes = L.check_count(lib.uz_wgrad_multi_workspace_bytes(arr, len(entries)), "uz_wgrad_multi_workspace_bytes")
+    ws = torch.empty(max(ws_bytes, 256) // 4, dtype=torch.float32, device=entries[0][0].buf.device)
+    with _Timed("wgrad_multi", flops, nbytes + 2.0 * ws_bytes):
+        L.check(lib.uz_wgrad_multi(arr, len(entries), ws.data_ptr(), L.stream_ptr()), "uz_wgrad_multi")
+
+
 def bn_finalize(stats: torch.Tensor, count: int, gamma, beta, eps: float, momentum: float,
                 running_mean, running_var):
     lib = L.load()
