@@ -444,9 +444,12 @@ class Engine:
                     dw = dwp[:, :9 * cin].reshape(Cout, 9, cin).permute(0, 2, 1).reshape(conv.weight.shape)
                     self._give_grad(conv.weight, dw.contiguous())
                 else:
-                    self._give_grad(conv.weight, ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=ntaps,
-                                                           dil=dil, taps_mode=tmode,
-                                                           out=self._dst(conv.weight)))
+                    if ntaps == 1 and tmode == L.TAPS_CONV:
+                        self._linear_wgrad(conv.weight, dy, x)      # a 1x1 convolution is a Linear layer on the pixel list
+                    else:
+                        self._give_grad(conv.weight, ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=ntaps,
+                                                               dil=dil, taps_mode=tmode,
+                                                               out=self._dst(conv.weight)))
                     if x.needs_grad and upsample:
                         # gradient of the (virtual) upsampled tensor, then 2x2 sums
                         du = self.new_act(N, H, W, x.C)
@@ -624,8 +627,11 @@ class Engine:
                     dw = dwp[:, :9 * cin].reshape(Cout, 9, cin).permute(0, 2, 1).reshape(conv.weight.shape)
                     self._give_grad(conv.weight, dw.contiguous())
                     return
-                self._give_grad(conv.weight, ops.wgrad(g, x, tuple(conv.weight.shape), ntaps=ntaps,
-                                                       out=self._dst(conv.weight)))
+                if ntaps == 1:
+                    self._linear_wgrad(conv.weight, g, x)
+                else:
+                    self._give_grad(conv.weight, ops.wgrad(g, x, tuple(conv.weight.shape), ntaps=ntaps,
+                                                           out=self._dst(conv.weight)))
                 if x.needs_grad:
                     dx = self.new_act(x.N, x.H, x.W, x.C)
                     ops.conv_igemm(g, self._pack(conv.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=ntaps)
