@@ -231,6 +231,49 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // out[i][j][tap] = sum_z slab[z][tap][i][j]: thread (x, zg) owns element (i,j) = blockIdx.x*64 + x
 // and the splits z = zg, zg+4, ...; reads are contiguous along j, each thread finally writes its
 // element's ntaps values (ntaps*4 contiguous bytes; a wave writes one contiguous span).
+// The same sums with the nine taps as part of the row: slab z is ONE contiguous row of NT * Ci * Cj floats, a thread owns
+// four consecutive columns (16-byte loads, 1 KB per wave and row) and the splits z = zg, zg + ZG, ...  For the small
+// layers (64 x 64 channels: 256 slabs of 147 KB, written a moment ago and still in the Infinity Cache) the kernel above
+// ran 64 workgroups -- a quarter of the chip -- at 256-byte pieces; this one runs NT * Ci * Cj / 256 = 144.
+template <int NT, int ZG>
+__global__ __launch_bounds__(64 * ZG) void wgrad_reduce_flat_kernel(const float* __restrict__ slab, int split, long long CiCj,
+                                                                   float* __restrict__ out) {
+  __shared__ float4 red[ZG][64];
+  const long long row = (long long)NT * CiCj;
+  const int x = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const long long col = ((long long)blockIdx.x * 64 + x) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < row) {
+    int z = zg;
+    for (; z + ZG < split; z += 2 * ZG) {   // two splits' loads in flight per pass
+      const float4 a0 = *reinterpret_cast<const float4*>(slab + (size_t)z * row + col);
+      const float4 a1 = *reinterpret_cast<const float4*>(slab + (size_t)(z + ZG) * row + col);
+      acc.x = (acc.x + a0.x) + a1.x;
+      acc.y = (acc.y + a0.y) + a1.y;
+      acc.z = (acc.z + a0.z) + a1.z;
+      acc.w = (acc.w + a0.w) + a1.w;
+    }
+    if (z < split) {
+      const float4 a0 = *reinterpret_cast<const float4*>(slab + (size_t)z * row + col);
+      acc.x += a0.x, acc.y += a0.y, acc.z += a0.z, acc.w += a0.w;
+    }
+  }
+  red[zg][x] = acc;
+  __syncthreads();
+  if (zg == 0 && col < row) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < ZG; ++k) {
+      const float4 r = red[k][x];
+      v[0] += r.x, v[1] += r.y, v[2] += r.z, v[3] += r.w;
+    }
+    const int t = (int)(col / CiCj);   // Ci * Cj is a multiple of 4: the four columns are one tap's
+    const long long e = col - (long long)t * CiCj;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[(e + i) * NT + t] = v[i];
+  }
+}
+
 template <int NT, int ZG>
 __global__ __launch_bounds__(64 * ZG) void wgrad_reduce_kernel(const float* __restrict__ slab, int split,
                                                               long long CiCj, float* __restrict__ out,
@@ -420,7 +463,10 @@ static int wgrad_phases(const uz_wgrad_desc* d, const void* L, const void* R, fl
   const dim3 grid((unsigned)((cicj + 63) / 64));
   const float* slab = static_cast<const float*>(workspace);
   if (d->ntaps == 9) {
-    if (nslabs >= 32)
+    if (nslabs >= 32 && cicj % 4 == 0 && (cicj <= 64 * 128 || uz_ablate_env("UZ_RED_FLAT_ALL")) && !(uz_tune_flags() & 0x40000000))
+      hipLaunchKernelGGL((wgrad_reduce_flat_kernel<9, 16>), dim3((unsigned)((9 * cicj / 4 + 63) / 64)), dim3(1024), 0, s, slab,
+                         nslabs, cicj, out);
+    else if (nslabs >= 32)
       hipLaunchKernelGGL((wgrad_reduce_kernel<9, 16>), grid, dim3(1024), 0, s, slab, nslabs, cicj, out, 0LL);
     else
       hipLaunchKernelGGL((wgrad_reduce_kernel<9, 4>), grid, dim3(256), 0, s, slab, nslabs, cicj, out, 0LL);
