@@ -21,7 +21,7 @@ REF_NAMES = (
     "uz_gelu_fwd", "uz_gelu_bwd", "uz_add_relu", "uz_relu_bwd", "uz_sum2x2", "uz_resize_bilinear_fwd", "uz_bilinear_fwd",
     "uz_space_to_depth", "uz_colsum", "uz_dwconv3x3", "uz_layernorm_fwd", "uz_conv3x3_first_supported", "uz_conv3x3_first_rows",
     "uz_conv3x3_first_fwd", "uz_conv3x3_first_wgrad_workspace_bytes", "uz_conv3x3_first_wgrad", "uz_wgrad_multi_workspace_bytes",
-    "uz_wgrad_multi",
+    "uz_wgrad_multi", "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
 )
 
 

@@ -856,4 +856,183 @@ int uz_wgrad_multi_ref(const uz_wgrad_item* items, int n, void* workspace, void*
 }
 UZ_SAME_SIGNATURE(uz_wgrad_multi);
 
+/* ---- uz_winattn_*: WindowAttention core with roll / window_partition / window_reverse as index arithmetic
+ * (swin_unet_v2.py:127-159 with :30-56, :214-238, :246-262) ----------------------------------------------------------- */
+typedef struct {
+  long long tok; /* row of the token tensor */
+  int cnt;       /* region id of the shifted-window mask (:214-236) */
+} wa_tok;
+static wa_tok wa_token(const uz_winattn_desc* d, int win, int i) {
+  const int nwx = d->W / d->ws, nwy = d->H / d->ws, nW = nwx * nwy;
+  const int b = win / nW, wi = win % nW, wy = wi / nwx, wx = wi % nwx;
+  const int hs = wy * d->ws + i / d->ws, wsx = wx * d->ws + i % d->ws; /* coordinates in the rolled image */
+  const int h = (hs + d->shift) % d->H, w = (wsx + d->shift) % d->W;
+  wa_tok t;
+  t.tok = ((long long)b * d->H + h) * d->W + w;
+  const int hid = hs < d->H - d->ws ? 0 : (hs < d->H - d->shift ? 1 : 2);
+  const int wid = wsx < d->W - d->ws ? 0 : (wsx < d->W - d->shift ? 1 : 2);
+  t.cnt = d->shift > 0 ? hid * 3 + wid : 0;
+  return t;
+}
+/* scores of one (window, head): c = cosine, S = c / clip(tau) + bias (+ mask); P = softmax(S); returns nothing, fills arrays */
+static void wa_scores(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias, int win, int h, const wa_tok* tk,
+                      double* c, double* P, double* lse, int* clamped) {
+  const int N = d->ws * d->ws;
+  for (int i = 0; i < N; ++i) {
+    double nq = 0.0, mx = -1e300;
+    for (int e = 0; e < 32; ++e) {
+      const double q = d->scale * ld(d->dtype, qkv, tk[i].tok * d->ldq + h * 32 + e);
+      nq += q * q;
+    }
+    nq = sqrt(nq);
+    for (int j = 0; j < N; ++j) {
+      double u = 0.0, nk = 0.0;
+      for (int e = 0; e < 32; ++e) {
+        const double q = d->scale * ld(d->dtype, qkv, tk[i].tok * d->ldq + h * 32 + e);
+        const double k = ld(d->dtype, qkv, tk[j].tok * d->ldq + d->C + h * 32 + e);
+        u += q * k;
+        nk += k * k;
+      }
+      nk = sqrt(nk);
+      const double den = nq * nk > 1e-6 ? nq * nk : 1e-6;
+      clamped[i * N + j] = !(nq * nk > 1e-6);
+      c[i * N + j] = u / den;
+      const double tv = tau[((long long)h * d->Nt + i) * d->Nt + j];
+      double sv = c[i * N + j] / (tv > 0.01 ? tv : 0.01) + bias[((long long)h * N + i) * N + j];
+      if (tk[i].cnt != tk[j].cnt) sv -= 100.0;
+      P[i * N + j] = sv;
+      if (sv > mx) mx = sv;
+    }
+    double sum = 0.0;
+    for (int j = 0; j < N; ++j) sum += exp(P[i * N + j] - mx);
+    lse[i] = mx + log(sum);
+    for (int j = 0; j < N; ++j) P[i * N + j] = exp(P[i * N + j] - lse[i]);
+  }
+  (void)win;
+}
+
+int uz_winattn_fwd_ref(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias, void* out, float* lse,
+                       void* stream) {
+  (void)stream;
+  const int N = d->ws * d->ws, nWin = d->B * (d->H / d->ws) * (d->W / d->ws);
+  if (d->C != 32 * d->heads || N > 64) return UZ_ENOTIMPL;
+  double *c = malloc(sizeof(double) * N * N), *P = malloc(sizeof(double) * N * N), *l = malloc(sizeof(double) * N);
+  int* cl = malloc(sizeof(int) * N * N);
+  wa_tok* tk = malloc(sizeof(wa_tok) * N);
+  for (int win = 0; win < nWin; ++win) {
+    for (int i = 0; i < N; ++i) tk[i] = wa_token(d, win, i);
+    for (int h = 0; h < d->heads; ++h) {
+      wa_scores(d, qkv, tau, bias, win, h, tk, c, P, l, cl);
+      for (int i = 0; i < N; ++i) {
+        lse[((long long)win * d->heads + h) * N + i] = (float)l[i];
+        for (int e = 0; e < 32; ++e) {
+          double o = 0.0;
+          for (int j = 0; j < N; ++j) o += P[i * N + j] * ld(d->dtype, qkv, tk[j].tok * d->ldq + 2 * d->C + h * 32 + e);
+          st(d->dtype, out, tk[i].tok * d->ldo + h * 32 + e, o);
+        }
+      }
+    }
+  }
+  free(c), free(P), free(l), free(cl), free(tk);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_winattn_fwd);
+
+int uz_winattn_bwd_rows_ref(const uz_winattn_desc* d) { /* the restatement keeps its sums in one row */
+  (void)d;
+  return 1;
+}
+UZ_SAME_SIGNATURE(uz_winattn_bwd_rows);
+
+/* gradients of the above by the chain rule, scores recomputed (the forward's out / lse are not read); partial[0][2][heads][N][N] */
+int uz_winattn_bwd_ref(const uz_winattn_desc* d, const void* qkv, const float* tau, const float* bias, const void* out,
+                       const float* lse_in, const void* dout, int lddo, void* dqkv, int lddq, float* partial, void* stream) {
+  (void)out, (void)lse_in, (void)stream;
+  const int N = d->ws * d->ws, nWin = d->B * (d->H / d->ws) * (d->W / d->ws);
+  if (d->C != 32 * d->heads || N > 64) return UZ_ENOTIMPL;
+  double *c = malloc(sizeof(double) * N * N), *P = malloc(sizeof(double) * N * N), *l = malloc(sizeof(double) * N);
+  double *dc = malloc(sizeof(double) * N * N), *acc = calloc((size_t)2 * d->heads * N * N, sizeof(double));
+  int* cl = malloc(sizeof(int) * N * N);
+  wa_tok* tk = malloc(sizeof(wa_tok) * N);
+  for (int win = 0; win < nWin; ++win) {
+    for (int i = 0; i < N; ++i) tk[i] = wa_token(d, win, i);
+    for (int h = 0; h < d->heads; ++h) {
+      wa_scores(d, qkv, tau, bias, win, h, tk, c, P, l, cl);
+      double* ab = acc + (size_t)h * N * N;
+      double* at = acc + ((size_t)d->heads + h) * N * N;
+      for (int i = 0; i < N; ++i) {
+        double D = 0.0;
+        for (int j = 0; j < N; ++j) {
+          double dp = 0.0;
+          for (int e = 0; e < 32; ++e)
+            dp += ld(d->dtype, dout, tk[i].tok * lddo + h * 32 + e) * ld(d->dtype, qkv, tk[j].tok * d->ldq + 2 * d->C + h * 32 + e);
+          dc[i * N + j] = dp;
+          D += P[i * N + j] * dp;
+        }
+        for (int j = 0; j < N; ++j) {
+          const double ds = P[i * N + j] * (dc[i * N + j] - D);
+          const double tv = tau[((long long)h * d->Nt + i) * d->Nt + j], t = tv > 0.01 ? tv : 0.01;
+          ab[i * N + j] += ds;
+          if (tv >= 0.01) at[i * N + j] += -ds * c[i * N + j] / (t * t);
+          dc[i * N + j] = ds / t;
+        }
+      }
+      for (int j = 0; j < N; ++j) /* dv_j = sum_i P_ij dO_i */
+        for (int e = 0; e < 32; ++e) {
+          double v = 0.0;
+          for (int i = 0; i < N; ++i) v += P[i * N + j] * ld(d->dtype, dout, tk[i].tok * lddo + h * 32 + e);
+          st(d->dtype, dqkv, tk[j].tok * lddq + 2 * d->C + h * 32 + e, v);
+        }
+      for (int i = 0; i < N; ++i) { /* dq_i = scale sum_j dc_ij d c_ij / d(scale q_i) */
+        double nq2 = 0.0, g[32];
+        for (int e = 0; e < 32; ++e) {
+          const double q = d->scale * ld(d->dtype, qkv, tk[i].tok * d->ldq + h * 32 + e);
+          nq2 += q * q;
+          g[e] = 0.0;
+        }
+        for (int j = 0; j < N; ++j) {
+          double nk2 = 0.0;
+          for (int e = 0; e < 32; ++e) {
+            const double k = ld(d->dtype, qkv, tk[j].tok * d->ldq + d->C + h * 32 + e);
+            nk2 += k * k;
+          }
+          const double den = cl[i * N + j] ? 1e-6 : sqrt(nq2 * nk2);
+          for (int e = 0; e < 32; ++e) {
+            const double q = d->scale * ld(d->dtype, qkv, tk[i].tok * d->ldq + h * 32 + e);
+            const double k = ld(d->dtype, qkv, tk[j].tok * d->ldq + d->C + h * 32 + e);
+            g[e] += dc[i * N + j] * (k / den - (cl[i * N + j] ? 0.0 : c[i * N + j] * q / nq2));
+          }
+        }
+        for (int e = 0; e < 32; ++e) st(d->dtype, dqkv, tk[i].tok * lddq + h * 32 + e, d->scale * g[e]);
+      }
+      for (int j = 0; j < N; ++j) { /* dk_j = sum_i dc_ij d c_ij / d k_j */
+        double nk2 = 0.0, g[32];
+        for (int e = 0; e < 32; ++e) {
+          const double k = ld(d->dtype, qkv, tk[j].tok * d->ldq + d->C + h * 32 + e);
+          nk2 += k * k;
+          g[e] = 0.0;
+        }
+        for (int i = 0; i < N; ++i) {
+          double nq2 = 0.0;
+          for (int e = 0; e < 32; ++e) {
+            const double q = d->scale * ld(d->dtype, qkv, tk[i].tok * d->ldq + h * 32 + e);
+            nq2 += q * q;
+          }
+          const double den = cl[i * N + j] ? 1e-6 : sqrt(nq2 * nk2);
+          for (int e = 0; e < 32; ++e) {
+            const double q = d->scale * ld(d->dtype, qkv, tk[i].tok * d->ldq + h * 32 + e);
+            const double k = ld(d->dtype, qkv, tk[j].tok * d->ldq + d->C + h * 32 + e);
+            g[e] += dc[i * N + j] * (q / den - (cl[i * N + j] ? 0.0 : c[i * N + j] * k / nk2));
+          }
+        }
+        for (int e = 0; e < 32; ++e) st(d->dtype, dqkv, tk[j].tok * lddq + d->C + h * 32 + e, g[e]);
+      }
+    }
+  }
+  for (size_t i = 0; i < (size_t)2 * d->heads * N * N; ++i) partial[i] = (float)acc[i];
+  free(c), free(P), free(l), free(dc), free(acc), free(cl), free(tk);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_winattn_bwd);
+
 int uz_ref_abi_version(void) { return 1; }

@@ -400,3 +400,71 @@ def test_first_convolution_restatement(N, C, H, W, Cout):
     assert lib.uz_conv3x3_first_wgrad_workspace_bytes_ref(N, H, W, Cout) == 0
     assert lib.uz_conv3x3_first_wgrad_ref(L.dtype_code(dt), c_ref.ptr(xh), N, C, H, W, c_ref.ptr(gh), Cout, Cout, c_ref.ptr(dw), None, None) == 0
     np.testing.assert_allclose(dw.reshape(Cout, C, 3, 3), wr.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---- window attention (uz_winattn_*): pinned against the formula of swin_unet_v2.py:134-152 written with torch + autograd ------
+def _window_attention_torch(qkv, tau, bias, B, H, W, heads, ws, shift, scale):
+    """qkv (P, 3C) double -> out (P, C); roll / window_partition / mask / window_reverse as the reference does them
+    (swin_unet_v2.py:30-56, :214-238, :246-262), the core as :134-152"""
+    C = qkv.shape[1] // 3
+    N = ws * ws
+    x = qkv.reshape(B, H, W, 3 * C)
+    if shift > 0:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = x.reshape(B, H // ws, ws, W // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, N, 3, heads, 32)
+    q, k, v = xw[:, :, 0].transpose(1, 2), xw[:, :, 1].transpose(1, 2), xw[:, :, 2].transpose(1, 2)   # (nWin, heads, N, 32)
+    q = q * scale
+    attn = (q @ k.transpose(-2, -1)) / torch.clamp(q.norm(dim=-1, keepdim=True) * k.norm(dim=-1, keepdim=True).transpose(-2, -1), min=1e-6)
+    attn = attn / torch.clamp(tau[:, :N, :N], min=0.01).unsqueeze(0) + bias.unsqueeze(0)
+    if shift > 0:
+        img = torch.zeros(1, H, W, 1, dtype=torch.float64)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.reshape(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, N)
+        mask = mw.unsqueeze(1) - mw.unsqueeze(2)
+        mask = torch.where(mask != 0, torch.full_like(mask, -100.0), torch.zeros_like(mask))
+        nW = mask.shape[0]
+        attn = (attn.reshape(B, nW, heads, N, N) + mask.reshape(1, nW, 1, N, N)).reshape(-1, heads, N, N)
+    p = torch.softmax(attn, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(-1, N, C)                                                      # (nWin, N, C)
+    o = o.reshape(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    if shift > 0:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o.reshape(-1, C), torch.logsumexp(attn, dim=-1)
+
+
+@pytest.mark.parametrize("shift,Nt", [(0, 16), (2, 20)])
+def test_window_attention_restatement(shift, Nt):
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(41 + shift)
+    B, H, W, heads, ws = 2, 8, 8, 2, 4
+    C, N, P = 32 * heads, ws * ws, B * H * W
+    scale = 32 ** -0.5
+    qkv = torch.randn(P, 3 * C, generator=g)
+    qkv[5, :C] = 0.0                                   # a zero query row: the 1e-6 clamp of the norm product is active
+    tau = torch.rand(heads, Nt, Nt, generator=g) * 0.5 + 0.005      # some entries under the 0.01 clip
+    bias = torch.randn(heads, N, N, generator=g) * 0.3
+    dout = torch.randn(P, C, generator=g)
+    qd = qkv.double().requires_grad_(True)
+    td, bd = tau.double().requires_grad_(True), bias.double().requires_grad_(True)
+    o_ref, lse_ref = _window_attention_torch(qd, td, bd, B, H, W, heads, ws, shift, scale)
+    (o_ref * dout.double()).sum().backward()
+    d = L.WinAttnDesc(0, B, H, W, C, heads, ws, shift, Nt, 3 * C, C, scale)
+    nwin = B * (H // ws) * (W // ws)
+    out, lse = np.zeros(P * C, np.float32), np.zeros(nwin * heads * N, np.float32)
+    qh, th, bh = c_ref.host(qkv), c_ref.host(tau), c_ref.host(bias)
+    assert lib.uz_winattn_fwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(th), c_ref.ptr(bh), c_ref.ptr(out), c_ref.ptr(lse), None) == 0
+    np.testing.assert_allclose(out.reshape(P, C), o_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lse.reshape(nwin, heads, N), lse_ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert lib.uz_winattn_bwd_rows_ref(byref(d)) == 1
+    dq, part = np.zeros(P * 3 * C, np.float32), np.zeros(2 * heads * N * N, np.float32)
+    dh = c_ref.host(dout)
+    assert lib.uz_winattn_bwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(th), c_ref.ptr(bh), c_ref.ptr(out), c_ref.ptr(lse), c_ref.ptr(dh), C,
+                                  c_ref.ptr(dq), 3 * C, c_ref.ptr(part), None) == 0
+    np.testing.assert_allclose(dq.reshape(P, 3 * C), qd.grad.numpy(), rtol=2e-4, atol=2e-5)
+    part = part.reshape(2, heads, N, N)
+    np.testing.assert_allclose(part[0], bd.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(part[1], td.grad[:, :N, :N].numpy(), rtol=2e-4, atol=2e-4)

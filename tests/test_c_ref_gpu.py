@@ -172,6 +172,49 @@ def test_first_convolution_kernels_against_the_c_restatement(N, C, H, W, Cout):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("ws,shift,Nt", [(8, 4, 64), (4, 0, 16), (7, 3, 49)])
+def test_window_attention_kernels_against_the_c_restatement(dt, ws, shift, Nt):
+    """uz_winattn_fwd / uz_winattn_bwd (fp32: the VALU kernels; bf16: the matrix-core kernels of round 4) against the
+    restatement pinned to torch autograd on the CPU (tests/test_c_ref.py): outputs, row log-sum-exp, dqkv, d(bias), d(tau);
+    a zero query row (the 1e-6 clamp of the norm product), tau entries under the 0.01 clip, the shifted-window mask"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(100 * ws + shift)
+    B, heads = 2, 3
+    H = W = 2 * ws
+    C, N, P = 32 * heads, ws * ws, B * H * W
+    qkv = rnd((P, 3 * C), dt, g)
+    qkv[5, :C] = 0
+    tau = torch.rand(heads, Nt, Nt, generator=g) * 0.5 + 0.005
+    bias = torch.randn(heads, N, N, generator=g) * 0.3
+    dout = rnd((P, C), dt, g)
+    qa, da = Act(qkv.to(DEV), 0, 3 * C, B, H, W), Act(dout.to(DEV), 0, C, B, H, W)
+    out, dq = ops.new_act(B, H, W, C, dt, DEV), ops.new_act(B, H, W, 3 * C, dt, DEV)
+    lse = ops.winattn_fwd(qa, tau.to(DEV), bias.to(DEV), out, heads, ws, shift)
+    dbias, dtau = ops.winattn_bwd(qa, tau.to(DEV), bias.to(DEV), out, lse, da, dq, heads, ws, shift)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    d = L.WinAttnDesc(L.dtype_code(dt), B, H, W, C, heads, ws, shift, Nt, 3 * C, C, 32 ** -0.5)
+    nwin = B * (H // ws) * (W // ws)
+    o_r, l_r = np.zeros(P * C, npdt), np.zeros(nwin * heads * N, np.float32)
+    qh, th, bh, dh = c_ref.host(qkv), c_ref.host(tau), c_ref.host(bias), c_ref.host(dout)
+    assert lib.uz_winattn_fwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(th), c_ref.ptr(bh), c_ref.ptr(o_r), c_ref.ptr(l_r), None) == 0
+    dq_r, part = np.zeros(P * 3 * C, npdt), np.zeros(2 * heads * N * N, np.float32)
+    assert lib.uz_winattn_bwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(th), c_ref.ptr(bh), c_ref.ptr(o_r), c_ref.ptr(l_r), c_ref.ptr(dh), C,
+                                  c_ref.ptr(dq_r), 3 * C, c_ref.ptr(part), None) == 0
+    tol = 1e-4 if dt == torch.float32 else 3e-2      # bf16: P and W enter the second products rounded to bf16
+
+    def near(got, ref, what):
+        got, ref = got.detach().cpu().double(), ref.double()
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        assert err <= tol, (what, err)
+    near(out.buf, c_ref.tensor(o_r, dt).reshape(P, C), "out")
+    near(lse.reshape(-1), torch.from_numpy(l_r), "lse") if dt == torch.float32 else None
+    near(dq.buf, c_ref.tensor(dq_r, dt).reshape(P, 3 * C), "dqkv")
+    part = torch.from_numpy(part).reshape(2, heads, N, N)
+    near(dbias, part[0], "dbias")
+    near(dtau, part[1], "dtau")
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_batchnorm_relu_pool_kernels_against_the_c_restatement(dt):
     lib = c_ref.load()
     g = torch.Generator().manual_seed(14)
