@@ -250,18 +250,21 @@ def test_wgrad_multi_mixes_shared_launches_with_single_problems():
         assert torch.equal(out.double(), dyb.buf.double().t() @ xb.buf.double())
 
 
-def test_swin_step_with_and_without_deferred_linear_weight_gradients():
+@pytest.mark.parametrize("B,img,ws", [(2, 64, 4), (1, 224, 7)])
+def test_swin_step_with_and_without_deferred_linear_weight_gradients(B, img, ws):
     """the engine's deferred nn.Linear weight gradients (Engine.defer_linear_wgrads) against the one-by-one launches on a
-    swin_unet_v2 backward: same gradients up to the summation order of the pixel split"""
+    swin_unet_v2 backward: same gradients up to the summation order of the pixel split.  At 224 x 224 / window 7 the
+    PatchExpand weight gradients (token maps 7 / 14 / 28 wide) take the space-to-depth + Linear route in the deferred run
+    and the 2 x 2 gather kernel in the other."""
     import unet_zoo_amd
     from unet_zoo_amd.engine import Engine
-    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    x = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(1)).to(DEV)
     grads, fams = [], []
     for defer in (True, False):
         Engine.defer_linear_wgrads = defer
         try:
             torch.manual_seed(0)
-            m = unet_zoo_amd.create_model("swin_unet_v2", image_size=64, in_channels=3, num_classes=1, window_size=4,
+            m = unet_zoo_amd.create_model("swin_unet_v2", image_size=img, in_channels=3, num_classes=1, window_size=ws,
                                           drop_path_rate=0.0)
             m.run_dtype = torch.bfloat16
             m = m.to(DEV).train()

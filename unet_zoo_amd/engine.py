@@ -899,8 +899,17 @@ class Engine:
                 g = self._total_grad(y)
                 if g is None:
                     return
-                dwt = ops.wgrad(x, g, (x.C, Co, 2, 2), ntaps=4, taps_mode=L.TAPS_GATHER2X2)   # [cin][co][tap]
-                self._give_grad(lin.weight, dwt.view(x.C, Co, 4).permute(2, 1, 0).reshape(4 * Co, x.C).contiguous())
+                d = L.WgradDesc(L.dtype_code(self.dtype), x.N, x.H, x.W, g.H, g.W, x.C, x.ld, Co, g.ld, 4, L.TAPS_GATHER2X2, 1)
+                if self.dtype == torch.bfloat16 and self.defer_linear_wgrads and ops.wgrad_kernel_name(d).startswith("wgrad_bf16_"):
+                    # token maps the four-tap gather kernel does not take (7 / 14 / 28 wide at 224 x 224) fell to the first
+                    # generation kernel on 8 ... 72 workgroups: dy back in the Linear's own (p1 p2 c) column order, then it
+                    # is one more Linear weight gradient of the deferred set, already in the parameter's layout
+                    gs = self.new_act(x.N, x.H, x.W, 4 * Co, needs_grad=False)
+                    ops.space_to_depth(g, gs, 2)
+                    self._linear_wgrad(lin.weight, gs, x)
+                else:
+                    dwt = ops.wgrad(x, g, (x.C, Co, 2, 2), ntaps=4, taps_mode=L.TAPS_GATHER2X2)   # [cin][co][tap]
+                    self._give_grad(lin.weight, dwt.view(x.C, Co, 4).permute(2, 1, 0).reshape(4 * Co, x.C).contiguous())
                 if x.needs_grad:
                     dx = self.new_act(x.N, x.H, x.W, x.C)
                     ops.conv_igemm(g, self._pack(lin.weight, L.PACK_CONV_DGRAD), None, dx, ntaps=4,
