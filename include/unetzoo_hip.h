@@ -128,6 +128,11 @@ int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w_packed, co
  * gather modes) with UZ_STORE_PLAIN; others: UZ_ENOTIMPL. */
 int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                       const void* res, int ldres, void* y, void* stream);
+/* The same with the workspace of uz_conv_igemm_workspace_bytes() (may be NULL): products with few tiles and a long K loop
+ * (Linear layers on the 8 x 8 / 16 x 16 token maps) then run split over K -- fp32 partial tiles, a fixed-order reduce pass
+ * that adds bias and residual -- as uz_conv_igemm_ws does for the form without a residual. */
+int uz_conv_igemm_res_ws(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                         const void* res, int ldres, void* y, void* workspace, void* stream);
 /* Same with a scratch buffer: small-M 3x3 problems on the generic kernel (u2net's dilated layers at
  * <= 32x32 maps, u2net.py:196-201) split their nine taps across workgroups into fp32 partial tiles in
  * `workspace` and finish with a fixed-order reduce + bias + statistics pass.  workspace_bytes() == 0:

@@ -22,8 +22,8 @@ def build(attrs, model_name, B, S):
         else:
             setattr(Engine, k, v)
     torch.manual_seed(0)
-    kw = dict(image_size=S) if model_name in ("swin_unet_v2", "uctransnet") else {}
-    model = unet_zoo_amd.create_model(model_name, in_channels=3, num_classes=1, **kw).cuda()
+    import bench   # the benchmark's own create_model call (swin: image_size and a window that divides the token maps)
+    model = bench.make_model(model_name, S)[0].cuda()
     model.run_dtype = torch.bfloat16
     step = unet_zoo_amd.GraphedStep(model, "bce_dice", lr=1e-4, weight_decay=1e-2, max_norm=1.0)
     x = torch.randn(B, 3, S, S, device="cuda")

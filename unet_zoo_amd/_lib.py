@@ -46,7 +46,7 @@ EXPORTS = (
     "uz_clip_adamw_workspace_bytes", "uz_clip_adamw",
     "uz_gelu_fwd", "uz_gelu_bwd", "uz_dwconv3x3", "uz_dwconv3x3_wgrad_rows", "uz_dwconv3x3_wgrad",
     "uz_space_to_depth", "uz_im2col_nchw", "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
-    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res", "uz_wgrad_multi_workspace_bytes", "uz_wgrad_multi",
+    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_colsum_batched_workspace_bytes", "uz_colsum_batched", "uz_sum_rows_f32_batched", "uz_conv_igemm_res", "uz_wgrad_multi_workspace_bytes", "uz_wgrad_multi", "uz_conv_igemm_res_ws",
     "uz_add_relu", "uz_relu_bwd", "uz_pil_resample_h_u8", "uz_pil_resample_v_f32",
     "uz_gemm_nt", "uz_softmax_fwd", "uz_softmax_bwd", "uz_adaptive_avgpool_fwd", "uz_adaptive_avgpool_bwd",
     "uz_rowdot_f32", "uz_cast_rows", "uz_wgrad_batched_workspace_bytes", "uz_wgrad_batched", "uz_wgrad_batched2",
@@ -153,6 +153,7 @@ def load():
     lib.uz_conv_igemm_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     lib.uz_conv_igemm_res.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, ip, vp, vp]
+    lib.uz_conv_igemm_res_ws.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, ip, vp, vp, vp]
     lib.uz_conv_igemm_workspace_bytes.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm_ws_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm_ws.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]

@@ -171,8 +171,11 @@ int uz_wgrad3x3_multi_launch(const UzWgradMultiItem* items, int n, hipStream_t s
 // LDS-DMA pixel-major GEMM (uz_gemm_dma.hip): 1x1 / ConvTranspose fwd + dgrad, dispatched from uz_conv_igemm()
 struct UzGemmPlan {
   int bn, bm, nst, tiles_m, tiles_n, grid_m;
+  int ksplit, cps;   // split-K over the 128-byte K slabs (only with a workspace): ksplit ranges of cps slabs
 };
 int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p);
+long long uz_gemm_dma_workspace_bytes(const uz_conv_desc* d);   // fp32 partial tiles of a split-K plan, else 0
+// part: the split-K workspace (ksplit x M x Nout floats) -- the caller then runs the reduce pass; without it the unsplit plan
 int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
                        const float* bias, void* y, float* stats, hipStream_t s, const void* res = nullptr,
-                       int ldres = 0, const UzBnRed* br = nullptr);
+                       int ldres = 0, const UzBnRed* br = nullptr, float* part = nullptr);

@@ -39,6 +39,11 @@ struct GArgs {
   // second batch level (uz_gemm_nt): blockIdx.z = b * nb2 + h; byte strides of the inner index h
   int nb2;
   long long xb2, wb2, yb2, resb2;
+  // split-K (one-tap problems with few tiles and a long K loop: the 8 x 8 / 16 x 16 token maps of swin_unet_v2, the
+  // spatial-reduction products of MISSFormer): blockIdx.z owns K slabs [z * cps, (z + 1) * cps) and leaves its fp32
+  // accumulators in part[z][M][Nout]; igemm_split_reduce_kernel adds them in a fixed order, then bias / residual / rounding
+  float* part;
+  int ksplit, cps;
 };
 
 template <typename T> struct Mma3;
@@ -89,7 +94,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * BN;
-  const long long bz = (int)blockIdx.z / a.nb2, bh = (int)blockIdx.z - (int)bz * a.nb2;
+  const int kz = a.ksplit > 1 ? (int)blockIdx.z : 0;
+  const long long bz = a.ksplit > 1 ? 0 : (int)blockIdx.z / a.nb2, bh = a.ksplit > 1 ? 0 : (int)blockIdx.z - (int)bz * a.nb2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(static_cast<const char*>(a.x)) + bz * a.xb + bh * a.xb2, 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
@@ -99,7 +105,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
       a.res ? reinterpret_cast<const T*>(static_cast<const char*>(a.res) + bz * a.resb + bh * a.resb2) : nullptr;
   const int HW = a.H * a.W;
   const int ncb = (a.Cin + BK - 1) / BK;  // the last slab of a tap may be partial: zero-filled
-  const int nsteps = a.ntaps * ncb;
+  const int s_beg = a.ksplit > 1 ? kz * a.cps : 0;                 // first K slab of this workgroup
+  const int nsteps = a.ksplit > 1 ? ((a.ntaps * ncb - s_beg < a.cps) ? a.ntaps * ncb - s_beg : a.cps) : a.ntaps * ncb;   // and how many
 
   unsigned b_row_off[NBP];
   int b_coff[NBP];   // byte offset of this lane's logical chunk inside a 128-byte slab
@@ -150,7 +157,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
 
   // stage loads of tile `m0t` (pixel offsets recomputed per call: a few VALU ops, no per-tile register arrays,
   // so the NEXT tile's first stages can be issued from the current tile's epilogue)
-  auto issue = [&](int m0t, int stage, int s) {
+  auto issue = [&](int m0t, int stage, int sl) {
+      const int s = s_beg + sl;
       const int tap = s / ncb, cb = s - tap * ncb;
       const int dpix = (a.mode == UZ_TAPS_GATHER2X2) ? (tap >> 1) * a.Win + (tap & 1) : 0;
       const int s2y = (tap * 11) >> 5, s2x = tap - 3 * s2y;   // UZ_TAPS_CONV_S2: tap = 3 ty + tx
@@ -259,6 +267,23 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
     const int ab = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 / a.Co : 0;
     const int co0 = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 - ab * a.Co : n0;
     pre = 0;
+    if (a.ksplit > 1) {   // fp32 accumulators of this K range: accumulator column = pixel, register quad = 4 consecutive channels
+      float* part = a.part + (size_t)kz * a.M * a.Nout;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * WTN + j * 32 + 8 * q + 4 * lh;
+            if (m < a.M && n < a.Nout)   // Nout is a multiple of 8 here: a quad is inside or outside as a whole
+              *reinterpret_cast<float4*>(part + (size_t)m * a.Nout + n) =
+                  make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          }
+      }
+      continue;
+    }
     if constexpr (sizeof(T) == 2) {
       constexpr int RSC = RSCB;
       static_assert(BM * RSC <= NST * STAGE, "C staging must fit the ring");
@@ -484,7 +509,31 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
   int cap = (p->nst == 2 ? 2 : 1) * UZ_NUM_CU / p->tiles_n;
   if (cap < 1) cap = 1;
   p->grid_m = p->tiles_m < cap ? p->tiles_m : cap;
+  // split-K: few tiles walking a long K loop (a step costs a third of a memory round trip whatever the tile, see the
+  // kernel): M = 1024 x N = 768 x K = 2304 ran 48 workgroups for 20.7 us.  Only with a workspace, a plain store and
+  // neither statistics nor a fused reduction (the launch checks those); >= 4 slabs per range.
+  p->ksplit = 1;
+  p->cps = nsteps;
+  const long long tiles = (long long)p->tiles_m * p->tiles_n;
+  // (the reduce pass is a launch of its own, ~8 us: 48 tiles x 36 slabs -- swin's 8 x 8 maps -- came out even, 20.7 us either way)
+  if (conv1 && d->dtype == UZ_BF16 && d->store_mode == UZ_STORE_PLAIN && p->nst > 2 &&
+      ((tiles <= 32 && nsteps >= 16) || (tiles <= 64 && nsteps >= 48)) && !(uz_tune_flags() & 0x80)) {
+    long long ks = UZ_NUM_CU / tiles;
+    if (ks > nsteps / 4) ks = nsteps / 4;
+    if (ks > 8) ks = 8;
+    if (ks >= 2) {
+      p->cps = (int)((nsteps + ks - 1) / ks);
+      p->ksplit = (nsteps + p->cps - 1) / p->cps;
+      p->grid_m = p->tiles_m;   // one tile per workgroup
+    }
+  }
   return 1;
+}
+
+long long uz_gemm_dma_workspace_bytes(const uz_conv_desc* d) {
+  UzGemmPlan p;
+  if (!uz_gemm_dma_plan(d, &p) || p.ksplit <= 1) return 0;
+  return (long long)p.ksplit * d->N * d->H * d->W * d->Nout * (long long)sizeof(float);
 }
 
 template <typename T>
@@ -515,11 +564,26 @@ static int gemm_launch_t(const UzGemmPlan& p, const GArgs& a, hipStream_t s) {
   return gemm_launch_grid<T>(p, a, dim3(p.grid_m, p.tiles_n), s);
 }
 
-int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x, const void* w,
+int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p_in, const void* x, const void* w,
                        const float* bias, void* y, float* stats, hipStream_t s, const void* res, int ldres,
-                       const UzBnRed* br) {
+                       const UzBnRed* br, float* part) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
+  UzGemmPlan p = p_in;
+  if (p.ksplit > 1 && part == nullptr) {   // no workspace: the unsplit plan
+    UzGemmPlan q = p;
+    int cap = UZ_NUM_CU / p.tiles_n;
+    if (cap < 1) cap = 1;
+    q.grid_m = p.tiles_m < cap ? p.tiles_m : cap;
+    q.ksplit = 1;
+    p = q;
+  }
   GArgs a;
+  a.part = p.ksplit > 1 ? part : nullptr;
+  a.ksplit = p.ksplit;
+  a.cps = p.cps;
+  if (p.ksplit > 1)
+    UZ_REQUIRE(stats == nullptr && br == nullptr && d->dtype == UZ_BF16 && d->store_mode == UZ_STORE_PLAIN,
+               "uz_conv_igemm(split-K GEMM): plain bf16 products without statistics only");
   a.bn_y = br ? br->y : nullptr;
   a.bn_scale = br ? br->scale : nullptr;
   a.bn_shift = br ? br->shift : nullptr;
@@ -559,6 +623,7 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p, const void* x
   a.xb = a.wb = a.yb = a.resb = 0;
   a.nb2 = 1;
   a.xb2 = a.wb2 = a.yb2 = a.resb2 = 0;
+  if (p.ksplit > 1) return gemm_launch_grid<bf16_t>(p, a, dim3(p.grid_m, p.tiles_n, p.ksplit), s);
   return d->dtype == UZ_BF16 ? gemm_launch_t<bf16_t>(p, a, s) : gemm_launch_t<float>(p, a, s);
 }
 
@@ -590,6 +655,8 @@ static int gemm_nt_plan(const uz_gemm_desc* d, UzGemmPlan* p) {
     if (p->bn == 128) p->bm = 128;
     p->nst = 2;
   }
+  p->ksplit = 1;
+  p->cps = nsteps;
   p->tiles_m = (d->M + p->bm - 1) / p->bm;
   long long cap = (p->nst == 2 ? 2 : 1) * (long long)UZ_NUM_CU / per;
   if (cap < 1) cap = 1;
@@ -609,6 +676,9 @@ extern "C" int uz_gemm_nt(const uz_gemm_desc* d, const void* x, const void* w, c
   a.bn_y = nullptr;
   a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr;
   a.ld_bny = 0;
+  a.part = nullptr;
+  a.ksplit = 1;
+  a.cps = 0;
   a.x = x;
   a.w = w;
   a.y = y;

@@ -282,11 +282,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 
 // y[m][n] = T(sum_z part[z][m][n] + bias[n]); statistics of the stored value as per-workgroup rows.
 // block (bx chunk lanes, by pixel lanes); grid (gx pixel groups, gy chunk groups)
+// res (nullable): a tensor of y's shape added AFTER the rounding of the sum, as a separate add of the stored result would
+// (the residual form of the LDS-DMA GEMM, uz_conv_igemm_res)
 template <typename T>
 __global__ __launch_bounds__(256) void igemm_split_reduce_kernel(const float* __restrict__ part, int split, int M,
                                                                  int Nout, const float* __restrict__ bias,
                                                                  T* __restrict__ y, int ldy,
-                                                                 float* __restrict__ stats) {
+                                                                 float* __restrict__ stats,
+                                                                 const T* __restrict__ res, int ldres) {
   constexpr int VEC = ElemTraits<T>::VEC;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [by][bx][2*VEC]
   const int CC = Nout / VEC;
@@ -317,8 +320,14 @@ __global__ __launch_bounds__(256) void igemm_split_reduce_kernel(const float* __
     }
     Vec16<T> o;
 #pragma unroll
+    for (int i = 0; i < VEC; ++i) o.v[i] = (T)v[i];
+    if (res != nullptr) {
+      const Vec16<T> r = ld16(res + (size_t)m * ldres + c0);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.v[i] = (T)((float)o.v[i] + (float)r.v[i]);
+    }
+#pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      o.v[i] = (T)v[i];
       const float f = (float)o.v[i];
       s1[i] += f;
       s2[i] += f * f;
@@ -452,8 +461,9 @@ int launch(const uz_conv_desc* d, const Plan& p, const IgemmArgs& a, hipStream_t
   if (a.part != nullptr) {
     constexpr int VEC = ElemTraits<T>::VEC;
     const size_t shm = (size_t)256 * 2 * VEC * sizeof(float);
-    hipLaunchKernelGGL((igemm_split_reduce_kernel<T>), dim3(p.rgx, p.rgy), dim3(p.rbx, p.rby), shm, s, a.part,
-                       p.split, a.M, a.Nout, a.bias, static_cast<T*>(a.y), a.ldy, a.stats);
+    hipLaunchKernelGGL((igemm_split_reduce_kernel<T>), dim3(p.rgx, p.rgy), dim3(p.rbx, p.rby), shm, s,
+                       static_cast<const float*>(a.part), p.split, a.M, a.Nout, a.bias, static_cast<T*>(a.y), a.ldy, a.stats,
+                       static_cast<const T*>(nullptr), 0);
     UZ_LAUNCH_CHECK("uz_conv_igemm(split reduce)");
   }
   return UZ_OK;
@@ -513,6 +523,11 @@ extern "C" long long uz_conv_igemm_workspace_bytes(const uz_conv_desc* d) {
     if (uz_direct_plan(d, &dp) && dp.bres == 3 && dp.ksplit > 1)   // split-K ping-pong convolution
       return (long long)dp.ksplit * d->N * d->H * d->W * d->Nout * (long long)sizeof(float);
   }
+  {
+    UzDirectPlan dp;
+    const long long gb = uz_direct_plan(d, &dp) ? 0 : uz_gemm_dma_workspace_bytes(d);   // split-K LDS-DMA GEMM
+    if (gb > 0) return gb;
+  }
   if (p.split <= 1 || !generic_path(d)) return 0;
   return (long long)p.split * d->N * d->H * d->W * d->Nout * (long long)sizeof(float);
 }
@@ -538,8 +553,29 @@ extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w
   return uz_conv_igemm_ws(d, x, w_packed, bias, y, stats_partial, nullptr, stream);
 }
 
+// split-K LDS-DMA GEMM: fp32 partial tiles of the K ranges, then the fixed-order reduce + bias (+ residual) pass
+static int gemm_split_k(const uz_conv_desc* d, const UzGemmPlan& gp, const void* x, const void* w_packed, const float* bias,
+                        const void* res, int ldres, void* y, void* workspace, hipStream_t s) {
+  const int r1 = uz_gemm_dma_launch(d, gp, x, w_packed, nullptr, y, nullptr, s, nullptr, 0, nullptr, static_cast<float*>(workspace));
+  if (r1 != UZ_OK) return r1;
+  Plan rp;
+  const long long M = (long long)d->N * d->H * d->W;
+  reduce_geometry(M, d->Nout, 8, &rp);
+  const size_t shm = (size_t)256 * 2 * 8 * sizeof(float);
+  hipLaunchKernelGGL((igemm_split_reduce_kernel<bf16_t>), dim3(rp.rgx, rp.rgy), dim3(rp.rbx, rp.rby), shm, s,
+                     static_cast<const float*>(workspace), gp.ksplit, (int)M, d->Nout, bias, static_cast<bf16_t*>(y), d->ldy,
+                     static_cast<float*>(nullptr), static_cast<const bf16_t*>(res), ldres);
+  UZ_LAUNCH_CHECK("uz_conv_igemm(split-K GEMM reduce)");
+  return UZ_OK;
+}
+
 extern "C" int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                                  const void* res, int ldres, void* y, void* stream) {
+  return uz_conv_igemm_res_ws(d, x, w_packed, bias, res, ldres, y, nullptr, stream);
+}
+
+extern "C" int uz_conv_igemm_res_ws(const uz_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                    const void* res, int ldres, void* y, void* workspace, void* stream) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
@@ -554,6 +590,8 @@ extern "C" int uz_conv_igemm_res(const uz_conv_desc* d, const void* x, const voi
     uz_set_error("uz_conv_igemm_res: only problems of the LDS-DMA GEMM with a plain store take a residual");
     return UZ_ENOTIMPL;
   }
+  if (gp.ksplit > 1 && workspace != nullptr)
+    return gemm_split_k(d, gp, x, w_packed, bias, res, ldres, y, workspace, static_cast<hipStream_t>(stream));
   return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, nullptr, static_cast<hipStream_t>(stream), res, ldres);
 }
 
@@ -612,15 +650,18 @@ extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void
       const size_t shm = (size_t)256 * 2 * 8 * sizeof(float);
       hipLaunchKernelGGL((igemm_split_reduce_kernel<bf16_t>), dim3(rp.rgx, rp.rgy), dim3(rp.rbx, rp.rby), shm, s,
                          static_cast<const float*>(workspace), dp.ksplit, (int)M, d->Nout, bias, static_cast<bf16_t*>(y), d->ldy,
-                         stats_partial);
+                         stats_partial, static_cast<const bf16_t*>(nullptr), 0);
       UZ_LAUNCH_CHECK("uz_conv_igemm(split-K reduce)");
       return UZ_OK;
     }
     return uz_direct_launch(d, dp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));
   }
   UzGemmPlan gp;
-  if (uz_gemm_dma_plan(d, &gp))
+  if (uz_gemm_dma_plan(d, &gp)) {
+    if (gp.ksplit > 1 && workspace != nullptr && stats_partial == nullptr)
+      return gemm_split_k(d, gp, x, w_packed, bias, nullptr, 0, y, workspace, static_cast<hipStream_t>(stream));
     return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));
+  }
   IgemmArgs a;
   a.x = x;
   a.w = w_packed;

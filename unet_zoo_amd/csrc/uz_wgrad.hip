@@ -463,7 +463,7 @@ static int wgrad_phases(const uz_wgrad_desc* d, const void* L, const void* R, fl
   const dim3 grid((unsigned)((cicj + 63) / 64));
   const float* slab = static_cast<const float*>(workspace);
   if (d->ntaps == 9) {
-    if (nslabs >= 32 && cicj % 4 == 0 && (cicj <= 64 * 128 || uz_ablate_env("UZ_RED_FLAT_ALL")) && !(uz_tune_flags() & 0x40000000))
+    if (nslabs >= 32 && cicj % 4 == 0 && (cicj <= 64 * 128 || uz_ablate_env("UZ_RED_FLAT_ALL")) && !(uz_tune_flags() & 0x100))
       hipLaunchKernelGGL((wgrad_reduce_flat_kernel<9, 16>), dim3((unsigned)((9 * cicj / 4 + 63) / 64)), dim3(1024), 0, s, slab,
                          nslabs, cicj, out);
     else if (nslabs >= 32)

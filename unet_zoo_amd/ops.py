@@ -338,8 +338,8 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
         assert (res.P, res.C) == (y.P, y.C) and res.dtype == y.dtype and not want_stats
         if kname.startswith("gemm_dma") and store_mode == L.STORE_PLAIN:
             with _Timed(kname, 2.0 * M * d.Nout * K, es * (x.P * x.C + 2 * M * d.Nout + d.Nout * K)):
-                L.check(lib.uz_conv_igemm_res(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), res.ptr(), res.ld, y.ptr(),
-                                              L.stream_ptr()), "uz_conv_igemm_res")
+                L.check(lib.uz_conv_igemm_res_ws(byref(d), x.ptr(), w_packed.data_ptr(), _p(bias), res.ptr(), res.ld, y.ptr(),
+                                                 _p(ws), L.stream_ptr()), "uz_conv_igemm_res_ws")
             return None
     with _Timed(kname, 2.0 * M * d.Nout * K,
                         es * (x.P * x.C + M * d.Nout + d.Nout * K)):
