@@ -279,3 +279,22 @@ def test_swin_step_with_and_without_deferred_linear_weight_gradients(B, img, ws)
     for n in grads[0]:
         a, b = grads[0][n].double(), grads[1][n].double()
         assert (a - b).abs().max() <= 1e-4 * b.abs().max().item() + 1e-9, n
+
+
+# ---- dilated 3x3 weight gradients (u2net's RSU4F) on the LDS-DMA kernel ---------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cx,Cdy,dil", [(8, 32, 32, 256, 512, 2), (8, 16, 16, 512, 256, 4), (2, 16, 16, 256, 256, 8),
+                                              (2, 32, 32, 64, 40, 2), (1, 32, 64, 128, 128, 4)])
+def test_dilated_weight_gradient_on_the_gather_kernel(N, H, W, Cx, Cdy, dil):
+    """Conv2d(k3, padding=d, dilation=d) weight gradient (REBNCONV dirate 2 / 4 / 8, u2net.py:10-13) as nine displaced
+    one-tap problems: the kernel family by name, exact on integers against autograd, dilation beyond the map's half width"""
+    g = torch.Generator().manual_seed(dil * 7 + H)
+    x = torch.randint(-2, 3, (N, Cx, H, W), generator=g).float()
+    dy = torch.randint(-2, 3, (N, Cdy, H, W), generator=g).float()
+    w = torch.zeros(Cdy, Cx, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, padding=dil, dilation=dil).backward(dy)
+    La, Ra = act_from_nchw(dy.to(DEV), torch.bfloat16), act_from_nchw(x.to(DEV), torch.bfloat16)
+    d = L.WgradDesc(L.dtype_code(torch.bfloat16), N, H, W, H, W, Cdy, Cdy, Cx, Cx, 9, L.TAPS_CONV, dil)
+    assert ops.wgrad_kernel_name(d).endswith("_dilated9"), ops.wgrad_kernel_name(d)
+    out = ops.wgrad(La, Ra, (Cdy, Cx, 3, 3), ntaps=9, dil=dil)
+    assert torch.equal(out.cpu(), w.grad)
+    assert torch.equal(ops.wgrad(La, Ra, (Cdy, Cx, 3, 3), ntaps=9, dil=dil), out)

@@ -404,7 +404,8 @@ extern "C" int uz_wgrad_kernel_name(const uz_wgrad_desc* d, char* buf, int cap) 
     n = snprintf(buf, cap, "%s", uz_wgrad9_name(p2));
   } else {
     const char* tile = p2.wide9 == 1 ? "128x64" : (p2.wide9 == 2 ? "64x128" : (p2.big ? "128x128" : "64x64"));
-    if (p2.gather) n = snprintf(buf, cap, "wgrad3x3_bf16_%s_gather%d", tile, d->ntaps);
+    if (p2.gather == 3) n = snprintf(buf, cap, "wgrad3x3_bf16_%s_dilated9", tile);
+    else if (p2.gather) n = snprintf(buf, cap, "wgrad3x3_bf16_%s_gather%d", tile, d->ntaps);
     else if (p2.one_tap) n = snprintf(buf, cap, "wgrad3x3_bf16_%s_1tap", tile);
     else n = snprintf(buf, cap, "wgrad3x3_bf16_%s_%s", tile, (p2.big && !p2.wide9) ? "3tap" : "9tap");
   }

@@ -43,6 +43,7 @@ struct Wg2Args {
                 // of 2H (+1) x 2W (+1) pixels and tap t = blockIdx.y reads pixel (2h + (t >> 1), 2w + (t & 1));
                 // 2: stride-2 3x3 convolution (UZ_TAPS_CONV_S2): tap t = 3 ty + tx reads (2h + ty - 1, 2w + tx - 1), zero outside
   int Hr, Wr;
+  int dil;   // gather == 3: dilated 3x3 (REBNCONV dirate 2 / 4 / 8, u2net.py:10-13): tap t reads (h + (ty-1) dil, w + (tx-1) dil), zero outside
   int flags; // tuning switches (env UZ_TUNE): bit 2 = plain workgroup order
   // uz_wgrad_batched (one-tap, no gather): blockIdx.y = problem index; byte strides of L / R between problems, float
   // stride of the slabs
@@ -221,6 +222,11 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg2Args& a, const int blk_x,
         const int rh = 2 * (h_ + p_rrel[i_]) + gy - 1, rw = 2 * (w0_ + p_crel[i_]) + gx - 1;                        \
         r_in_ = (unsigned)rh < (unsigned)a.Hr && (unsigned)rw < (unsigned)a.Wr;                                     \
         rp_ = (unsigned)((img_ * a.Hr + rh) * a.Wr + rw);                                                           \
+      } else if constexpr (MODE == 4) {                                                                             \
+        const int gy = (ty_blk_g * 11) >> 5, gx = ty_blk_g - 3 * gy;                                                \
+        const int rh = h_ + p_rrel[i_] + (gy - 1) * a.dil, rw = w0_ + p_crel[i_] + (gx - 1) * a.dil;                \
+        r_in_ = (unsigned)rh < (unsigned)a.H && (unsigned)rw < (unsigned)a.W;                                       \
+        rp_ = (unsigned)((img_ * a.H + rh) * a.W + rw);                                                             \
       }                                                                                                             \
       const unsigned off_ = (ok_ && r_in_) ? rp_ * (unsigned)(a.ldr * 2) + p_coff[i_] : OOB;                        \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rr, (lds_ptr_t)(sbase_ + q_ * 1024), 16, off_, 0, 0, 0);            \
@@ -408,7 +414,7 @@ __device__ __forceinline__ void wgrad3x3_body(const Wg2Args& a, const int blk_x,
     const int tw = tap0 + tt;
     if (tt >= ntw_me) continue;  // wave-uniform
     const int tap = (NTX == 1) ? ty_blk_g : ((NTY == 3) ? tw : ty_blk * 3 + tw);
-    float* slab = a.slab + pb * a.sb + ((size_t)bz * (NTX == 1 ? (a.gather == 1 ? 4 : (a.gather == 2 ? 9 : 1)) : 9) + tap) * (size_t)a.Ci * a.Cj;
+    float* slab = a.slab + pb * a.sb + ((size_t)bz * (NTX == 1 ? (a.gather == 1 ? 4 : (a.gather >= 2 ? 9 : 1)) : 9) + tap) * (size_t)a.Ci * a.Cj;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int cj = tj0 + wj * WTJ + l31;
@@ -462,11 +468,15 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch) {
   if (batch == 1 && uz_wgrad_g4_plan(d, p)) return 1;   // 2 x 2 gather, four taps per workgroup (uz_wgrad_g4.hip)
   const bool up = d->taps_mode == UZ_TAPS_CONV_UP2;
   const bool s2 = d->taps_mode == UZ_TAPS_CONV_S2 && d->ntaps == 9;
-  const bool gather = (d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && !(uz_tune_flags() & 0x4000000)) || s2;
+  // dilated 3x3 (u2net's RSU4F, dirate 2 / 4 / 8 on 32 x 32 and 16 x 16 maps): nine one-tap problems whose x pixel is
+  // displaced by (ty - 1, tx - 1) * dil -- the addressing of the stride-2 gather without the stride.  (They ran on the
+  // first-generation kernel: 6 x 64.7 + 9 x 35.7 us per u2net step.)
+  const bool dil9 = d->taps_mode == UZ_TAPS_CONV && d->ntaps == 9 && d->dil > 1 && !(uz_tune_flags() & 0x200);
+  const bool gather = (d->taps_mode == UZ_TAPS_GATHER2X2 && d->ntaps == 4 && !(uz_tune_flags() & 0x4000000)) || s2 || dil9;
   if (d->dtype != UZ_BF16 || !(d->taps_mode == UZ_TAPS_CONV || up || gather)) return 0;
   if (!((d->ntaps == 9 && d->dil == 1) || (d->ntaps == 1 && !up) || gather)) return 0;
   p->one_tap = d->ntaps == 1 || gather;   // gather: four (nine) one-tap problems, blockIdx.y = tap
-  p->gather = s2 ? 2 : (gather ? 1 : 0);
+  p->gather = dil9 ? 3 : (s2 ? 2 : (gather ? 1 : 0));
   if (d->Ci % 8 != 0 || d->Cj % 8 != 0) return 0;
   int W = d->W, H = d->H;
   long long nimg = d->N;
@@ -571,6 +581,7 @@ static void wg2_fill(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* 
   a.rbytes = (unsigned)(((long long)d->N * d->Hr * d->Wr - 1) * d->ldr * 2 + (long long)d->Cj * 2);
   a.r_up = d->taps_mode == UZ_TAPS_CONV_UP2 ? 1 : 0;
   a.gather = p.gather;
+  a.dil = d->dil;
   a.Hr = d->Hr;
   a.Wr = d->Wr;
   a.flags = uz_tune_flags();
@@ -630,20 +641,22 @@ int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void
   a.sb = slab_stride ? slab_stride : (long long)p.nslabs * d->ntaps * d->Ci * d->Cj;
   UZ_REQUIRE(batch == 1 || (p.one_tap && !p.gather && batch <= 65535), "uz_wgrad(3x3): only one-tap problems are batched");
   dim3 block(512);
-  const int mode = a.r_up ? 1 : (p.gather == 1 ? 2 : (p.gather == 2 ? 3 : 0));
+  const int mode = a.r_up ? 1 : (p.gather == 1 ? 2 : (p.gather == 2 ? 3 : (p.gather == 3 ? 4 : 0)));
 #define UZ_WG_LAUNCH(MODE_, ...) \
   hipLaunchKernelGGL((wgrad3x3_kernel<__VA_ARGS__, MODE_>), grid, block, 0, s, a)
   if (p.one_tap) {
     UZ_REQUIRE(mode != 1, "uz_wgrad(3x3): one-tap problems have no upsampled form");
-    dim3 grid(p.tiles_i * p.tiles_j, p.gather == 2 ? 9 : (p.gather ? 4 : batch), p.split);
+    dim3 grid(p.tiles_i * p.tiles_j, p.gather >= 2 ? 9 : (p.gather ? 4 : batch), p.split);
     if (p.big) {
       if (mode == 0) UZ_WG_LAUNCH(0, 128, 128, 1, 1, 2, 4, 1);
       else if (mode == 2) UZ_WG_LAUNCH(2, 128, 128, 1, 1, 2, 4, 1);
-      else UZ_WG_LAUNCH(3, 128, 128, 1, 1, 2, 4, 1);
+      else if (mode == 3) UZ_WG_LAUNCH(3, 128, 128, 1, 1, 2, 4, 1);
+      else UZ_WG_LAUNCH(4, 128, 128, 1, 1, 2, 4, 1);
     } else {   // 4 waves idle: memory-bound
       if (mode == 0) UZ_WG_LAUNCH(0, 64, 64, 1, 1, 2, 2, 2);
       else if (mode == 2) UZ_WG_LAUNCH(2, 64, 64, 1, 1, 2, 2, 2);
-      else UZ_WG_LAUNCH(3, 64, 64, 1, 1, 2, 2, 2);
+      else if (mode == 3) UZ_WG_LAUNCH(3, 64, 64, 1, 1, 2, 2, 2);
+      else UZ_WG_LAUNCH(4, 64, 64, 1, 1, 2, 2, 2);
     }
   } else if (p.big) {
     UZ_REQUIRE(mode <= 1, "uz_wgrad(3x3): gathers are one-tap problems");
