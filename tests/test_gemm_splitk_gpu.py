@@ -55,3 +55,24 @@ def test_split_k_gemm_random_operands_against_fp32():
     ref = x.float() @ w.float().t() + b
     err = ((y.buf.cpu().float() - ref).abs().max() / ref.abs().max()).item()
     assert err < 1e-2, err
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil", [(8, 16, 16, 512, 512, 2), (8, 32, 32, 512, 256, 4), (2, 16, 16, 256, 512, 8)])
+def test_split_k_dilated_convolution_with_statistics(N, H, W, Cin, Cout, dil):
+    """the dilated nine-tap form (REBNCONV dirate 2 / 4 / 8 of RSU4F, u2net.py:10-13: K = 9 Cin) split over K, BatchNorm
+    partial sums from the reduce pass: exact on integers against F.conv2d, sums of the stored values"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(dil)
+    x = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float()
+    w = torch.randint(-1, 2, (Cout, Cin, 3, 3), generator=g).float()
+    ref = F.conv2d(x, w, None, padding=dil, dilation=dil).to(dt)
+    xa = ops.act_from_nchw(x.to(DEV), dt)
+    y = ops.new_act(N, H, W, Cout, dt, DEV)
+    d = L.ConvDesc(L.dtype_code(dt), N, H, W, H, W, Cin, Cin, Cout, Cout, 9, L.TAPS_CONV, dil, L.STORE_PLAIN, 0, 0, 0)
+    assert L.load().uz_conv_igemm_workspace_bytes(byref(d)) > 0
+    stats = ops.conv_igemm(xa, ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dt), None, y, ntaps=9, dil=dil, want_stats=True)
+    got = y.buf.view(N, H, W, Cout).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(got, ref)
+    s = stats.double().sum(0).cpu()
+    assert torch.allclose(s[0], ref.double().sum((0, 2, 3)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(s[1], (ref.double() ** 2).sum((0, 2, 3)), rtol=1e-6, atol=1e-2)

@@ -516,8 +516,10 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
   p->cps = nsteps;
   const long long tiles = (long long)p->tiles_m * p->tiles_n;
   // (the reduce pass is a launch of its own, ~8 us: 48 tiles x 36 slabs -- swin's 8 x 8 maps -- came out even, 20.7 us either way)
-  if (conv1 && d->dtype == UZ_BF16 && d->store_mode == UZ_STORE_PLAIN && p->nst > 2 &&
-      ((tiles <= 32 && nsteps >= 16) || (tiles <= 64 && nsteps >= 48)) && !(uz_tune_flags() & 0x80)) {
+  // The dilated nine-tap form (K = 9 Cin: 72 slabs for u2net's 512-channel RSU4F on 16 x 16 / 32 x 32 maps) splits too.
+  if ((conv1 || conv9) && d->dtype == UZ_BF16 && d->store_mode == UZ_STORE_PLAIN && p->nst > 2 &&
+      ((tiles <= 32 && nsteps >= 16) || (tiles <= 64 && nsteps >= 48) || (tiles <= 128 && nsteps >= 64)) &&
+      !(uz_tune_flags() & 0x80)) {
     long long ks = UZ_NUM_CU / tiles;
     if (ks > nsteps / 4) ks = nsteps / 4;
     if (ks > 8) ks = 8;
@@ -583,7 +585,7 @@ int uz_gemm_dma_launch(const uz_conv_desc* d, const UzGemmPlan& p_in, const void
   a.cps = p.cps;
   if (p.ksplit > 1)
     UZ_REQUIRE(stats == nullptr && br == nullptr && d->dtype == UZ_BF16 && d->store_mode == UZ_STORE_PLAIN,
-               "uz_conv_igemm(split-K GEMM): plain bf16 products without statistics only");
+               "uz_conv_igemm(split-K GEMM): plain bf16 products; statistics come from the reduce pass");
   a.bn_y = br ? br->y : nullptr;
   a.bn_scale = br ? br->scale : nullptr;
   a.bn_shift = br ? br->shift : nullptr;

@@ -544,6 +544,14 @@ extern "C" int uz_conv_igemm_ws_grid_m(const uz_conv_desc* d) {
       return rp.rgx;
     }
   }
+  {
+    UzDirectPlan dp;
+    if (!uz_direct_plan(d, &dp) && uz_gemm_dma_workspace_bytes(d) > 0) {   // split-K LDS-DMA GEMM: rows of its reduce pass
+      Plan rp;
+      reduce_geometry((long long)d->N * d->H * d->W, d->Nout, 8, &rp);
+      return rp.rgx;
+    }
+  }
   if (p.split > 1 && generic_path(d)) return p.rgx;
   return uz_conv_igemm_grid_m(d);
 }
@@ -555,7 +563,7 @@ extern "C" int uz_conv_igemm(const uz_conv_desc* d, const void* x, const void* w
 
 // split-K LDS-DMA GEMM: fp32 partial tiles of the K ranges, then the fixed-order reduce + bias (+ residual) pass
 static int gemm_split_k(const uz_conv_desc* d, const UzGemmPlan& gp, const void* x, const void* w_packed, const float* bias,
-                        const void* res, int ldres, void* y, void* workspace, hipStream_t s) {
+                        const void* res, int ldres, void* y, void* workspace, hipStream_t s, float* stats = nullptr) {
   const int r1 = uz_gemm_dma_launch(d, gp, x, w_packed, nullptr, y, nullptr, s, nullptr, 0, nullptr, static_cast<float*>(workspace));
   if (r1 != UZ_OK) return r1;
   Plan rp;
@@ -564,7 +572,7 @@ static int gemm_split_k(const uz_conv_desc* d, const UzGemmPlan& gp, const void*
   const size_t shm = (size_t)256 * 2 * 8 * sizeof(float);
   hipLaunchKernelGGL((igemm_split_reduce_kernel<bf16_t>), dim3(rp.rgx, rp.rgy), dim3(rp.rbx, rp.rby), shm, s,
                      static_cast<const float*>(workspace), gp.ksplit, (int)M, d->Nout, bias, static_cast<bf16_t*>(y), d->ldy,
-                     static_cast<float*>(nullptr), static_cast<const bf16_t*>(res), ldres);
+                     stats, static_cast<const bf16_t*>(res), ldres);
   UZ_LAUNCH_CHECK("uz_conv_igemm(split-K GEMM reduce)");
   return UZ_OK;
 }
@@ -658,8 +666,8 @@ extern "C" int uz_conv_igemm_ws(const uz_conv_desc* d, const void* x, const void
   }
   UzGemmPlan gp;
   if (uz_gemm_dma_plan(d, &gp)) {
-    if (gp.ksplit > 1 && workspace != nullptr && stats_partial == nullptr)
-      return gemm_split_k(d, gp, x, w_packed, bias, nullptr, 0, y, workspace, static_cast<hipStream_t>(stream));
+    if (gp.ksplit > 1 && workspace != nullptr)   // (statistics rows: uz_conv_igemm_ws_grid_m, written by the reduce pass)
+      return gemm_split_k(d, gp, x, w_packed, bias, nullptr, 0, y, workspace, static_cast<hipStream_t>(stream), stats_partial);
     return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream));
   }
   IgemmArgs a;
