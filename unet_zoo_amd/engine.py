@@ -531,10 +531,8 @@ class Engine:
                     for c in (conv_q, conv_g, conv_x):
                         if c.bias is not None:
                             self._give_grad(c.bias, None)   # a train-mode BatchNorm follows: analytically zero
-                self._give_grad(conv_g.weight, ops.wgrad(dg1, g, tuple(conv_g.weight.shape), ntaps=1,
-                                                         out=self._dst(conv_g.weight)))
-                self._give_grad(conv_x.weight, ops.wgrad(dx1, x, tuple(conv_x.weight.shape), ntaps=1,
-                                                         out=self._dst(conv_x.weight)))
+                self._linear_wgrad(conv_g.weight, dg1, g)      # 1x1 convolutions: with the deferred set (uz_wgrad_multi)
+                self._linear_wgrad(conv_x.weight, dx1, x)
                 if g.needs_grad:
                     dg = self.new_act(N, H, W, g.C)
                     ops.conv_igemm(dg1, self._pack(conv_g.weight, L.PACK_CONV_DGRAD), None, dg, ntaps=1)
