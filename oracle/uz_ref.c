@@ -735,14 +735,31 @@ UZ_SAME_SIGNATURE(uz_dwconv3x3);
 int uz_layernorm_fwd_ref(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta, const void* res,
                          const float* image_scale, void* y, float* stats, void* stream) {
   (void)stream;
-  if (d->mode != 0) return UZ_ENOTIMPL;
+  if (d->mode < 0 || d->mode > 2) return UZ_ENOTIMPL;
   const long long P = (long long)d->N * d->Ho * d->Wo;
+  double* row = malloc(sizeof(double) * d->C);
   for (long long p = 0; p < P; ++p) {
+    /* the input row of output token p under the addressing mode (PatchMerging :315-332, PatchExpand :352-362, :375-387) */
+    const int img = (int)(p / ((long long)d->Ho * d->Wo)), rem = (int)(p % ((long long)d->Ho * d->Wo));
+    const int i = rem / d->Wo, j = rem % d->Wo;
+    for (int c = 0; c < d->C; ++c) {
+      long long off;
+      if (d->mode == UZ_LN_PLAIN) {
+        off = p * d->ldx + c;
+      } else if (d->mode == UZ_LN_MERGE) { /* input grid (2Ho, 2Wo), C/4 channels; segment s of (i, j) is token (2i + (s&1), 2j + (s>>1)) */
+        const int cq = d->C / 4, sgm = c / cq;
+        off = (((long long)img * 2 * d->Ho + 2 * i + (sgm & 1)) * (2 * d->Wo) + 2 * j + (sgm >> 1)) * d->ldx + (c - sgm * cq);
+      } else { /* input grid (Ho/r, Wo/r), r*r*C channels; token (h r + p1, w r + p2) reads channels (p1 r + p2) C + c */
+        const int r = d->r, h = i / r, p1 = i % r, w = j / r, p2 = j % r;
+        off = (((long long)img * (d->Ho / r) + h) * (d->Wo / r) + w) * d->ldx + (long long)(p1 * r + p2) * d->C + c;
+      }
+      row[c] = ld(d->dtype, x, off);
+    }
     double m = 0.0, v = 0.0;
-    for (int c = 0; c < d->C; ++c) m += ld(d->dtype, x, p * d->ldx + c);
+    for (int c = 0; c < d->C; ++c) m += row[c];
     m /= d->C;
     for (int c = 0; c < d->C; ++c) {
-      const double t = ld(d->dtype, x, p * d->ldx + c) - m;
+      const double t = row[c] - m;
       v += t * t;
     }
     const double rstd = 1.0 / sqrt(v / d->C + (double)d->eps);
@@ -752,12 +769,13 @@ int uz_layernorm_fwd_ref(const uz_ln_desc* d, const void* x, const float* gamma,
     }
     const double sc = image_scale ? image_scale[p / ((long long)d->Ho * d->Wo)] : 1.0;
     for (int c = 0; c < d->C; ++c) {
-      double o = ((ld(d->dtype, x, p * d->ldx + c) - m) * rstd * gamma[c] + beta[c]) * sc;
+      double o = ((row[c] - m) * rstd * gamma[c] + beta[c]) * sc;
       if (d->act == 1) o = 0.5 * o * (1.0 + erf(o * 0.70710678118654752440));
       if (res) o += ld(d->dtype, res, p * d->ldr + c);
       st(d->dtype, y, p * d->ldy + c, o);
     }
   }
+  free(row);
   return UZ_OK;
 }
 UZ_SAME_SIGNATURE(uz_layernorm_fwd);

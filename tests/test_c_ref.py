@@ -468,3 +468,42 @@ def test_window_attention_restatement(shift, Nt):
     part = part.reshape(2, heads, N, N)
     np.testing.assert_allclose(part[0], bd.grad.numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(part[1], td.grad[:, :N, :N].numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_layernorm_restatement_merge_and_expand_addressing(dt):
+    """uz_layernorm_fwd_ref under UZ_LN_MERGE (PatchMerging's strided gather + cat, swin_unet_v2.py:320-326) and UZ_LN_EXPAND
+    (PatchExpand / FinalPatchExpand_X4's rearrange, :358, :382) against torch on the materialised tensors"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(51)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    N = 2
+    # merge: input (N, 2Ho, 2Wo, Cq) -> LayerNorm over 4 Cq channels of the gathered token
+    Ho, Wo, Cq = 3, 5, 8
+    x = rnd((N, 2 * Ho, 2 * Wo, Cq), dt, g)
+    C = 4 * Cq
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xd = x.double()
+    cat = torch.cat([xd[:, 0::2, 0::2], xd[:, 1::2, 0::2], xd[:, 0::2, 1::2], xd[:, 1::2, 1::2]], -1).reshape(-1, C)
+    ref = F.layer_norm(cat, (C,), gamma.double(), beta.double(), 1e-5)
+    P = N * Ho * Wo
+    y, stats = np.zeros(P * C, npdt), np.zeros(2 * P, np.float32)
+    xh, gm, bt = c_ref.host(x.reshape(-1, Cq)), c_ref.host(gamma), c_ref.host(beta)
+    d = L.LnDesc(dc, N, Ho, Wo, C, Cq, C, 0, 0, 0, L.LN_MERGE, 1, 1e-5, 0)
+    assert lib.uz_layernorm_fwd_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), None, None, c_ref.ptr(y), c_ref.ptr(stats), None) == 0
+    close(c_ref.tensor(y, dt).reshape(P, C), ref, dt, "layernorm(merge)")
+    np.testing.assert_allclose(stats.reshape(P, 2)[:, 0], cat.mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    # expand: input (N, h, w, r r C) -> output grid (h r, w r), LayerNorm over C
+    for r in (2, 4):
+        h, w, C = 2, 3, 16
+        x = rnd((N, h, w, r * r * C), dt, g)
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        t = x.double().reshape(N, h, w, r, r, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)      # b (h p1) (w p2) c
+        ref = F.layer_norm(t, (C,), gamma.double(), beta.double(), 1e-5)
+        P = N * h * r * w * r
+        y, stats = np.zeros(P * C, npdt), np.zeros(2 * P, np.float32)
+        xh, gm, bt = c_ref.host(x.reshape(-1, r * r * C)), c_ref.host(gamma), c_ref.host(beta)
+        d = L.LnDesc(dc, N, h * r, w * r, C, r * r * C, C, 0, 0, 0, L.LN_EXPAND, r, 1e-5, 0)
+        assert lib.uz_layernorm_fwd_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), None, None, c_ref.ptr(y), c_ref.ptr(stats), None) == 0
+        close(c_ref.tensor(y, dt).reshape(P, C), ref, dt, f"layernorm(expand {r})")

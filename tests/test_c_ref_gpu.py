@@ -215,6 +215,36 @@ def test_window_attention_kernels_against_the_c_restatement(dt, ws, shift, Nt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("mode,r,N,Ho,Wo,C", [("merge", 1, 2, 14, 14, 384), ("merge", 1, 1, 7, 9, 192), ("expand", 2, 2, 16, 16, 96),
+                                              ("expand", 4, 1, 32, 24, 96)])
+def test_layernorm_addressing_modes_against_the_c_restatement(dt, mode, r, N, Ho, Wo, C):
+    """uz_layernorm_fwd with PatchMerging's gather (UZ_LN_MERGE) and PatchExpand's rearrange (UZ_LN_EXPAND, r = 2 / 4) as
+    addressing modes, against the restatement pinned to torch on the CPU (swin_unet_v2.py:320-326, :358, :382)"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(Ho + C + r)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    if mode == "merge":
+        xin = rnd((N * 2 * Ho * 2 * Wo, C // 4), dt, g)
+        xa = Act(xin.to(DEV), 0, C // 4, N, 2 * Ho, 2 * Wo)
+        m, ldx = L.LN_MERGE, C // 4
+    else:
+        xin = rnd((N * (Ho // r) * (Wo // r), r * r * C), dt, g)
+        xa = Act(xin.to(DEV), 0, r * r * C, N, Ho // r, Wo // r)
+        m, ldx = L.LN_EXPAND, r * r * C
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    y = ops.new_act(N, Ho, Wo, C, dt, DEV)
+    stats = ops.layernorm_fwd(xa, gamma.to(DEV), beta.to(DEV), y, mode=m, r=r, eps=1e-5)
+    P = N * Ho * Wo
+    ref, rstats = np.zeros(P * C, npdt), np.zeros(2 * P, np.float32)
+    xh, gm, bt = c_ref.host(xin), c_ref.host(gamma), c_ref.host(beta)
+    d = L.LnDesc(dc, N, Ho, Wo, C, ldx, C, 0, 0, 0, m, r, 1e-5, 0)
+    assert lib.uz_layernorm_fwd_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), None, None, c_ref.ptr(ref), c_ref.ptr(rstats), None) == 0
+    agree(y.buf, c_ref.tensor(ref, dt).reshape(P, C), dt, f"layernorm({mode} {r})")
+    assert np.allclose(stats.cpu().numpy().reshape(-1), rstats, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_batchnorm_relu_pool_kernels_against_the_c_restatement(dt):
     lib = c_ref.load()
     g = torch.Generator().manual_seed(14)
