@@ -22,6 +22,7 @@ REF_NAMES = (
     "uz_space_to_depth", "uz_colsum", "uz_dwconv3x3", "uz_layernorm_fwd", "uz_conv3x3_first_supported", "uz_conv3x3_first_rows",
     "uz_conv3x3_first_fwd", "uz_conv3x3_first_wgrad_workspace_bytes", "uz_conv3x3_first_wgrad", "uz_wgrad_multi_workspace_bytes",
     "uz_wgrad_multi", "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
+    "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd",
 )
 
 

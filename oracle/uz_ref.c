@@ -1053,4 +1053,46 @@ int uz_winattn_bwd_ref(const uz_winattn_desc* d, const void* qkv, const float* t
 }
 UZ_SAME_SIGNATURE(uz_winattn_bwd);
 
+/* ---- additive attention gate, forward (AttentionBlock.forward, attention_unet.py:34-40) without its two 1x1 convolutions ---- */
+int uz_attn_grid_ref(int dtype, int P, int channels) { /* the restatement keeps its sums in one row */
+  (void)dtype, (void)P, (void)channels;
+  return 1;
+}
+UZ_SAME_SIGNATURE(uz_attn_grid);
+
+/* q[p] = b_psi + sum_c relu(bn_g(g1raw) + bn_x(x1raw))[p, c] w_psi[c]; partial[0] = (sum q, sum q^2): the statistics of bn_q */
+int uz_attn_psi_fwd_ref(int dtype, const void* g1raw, int ldg, const void* x1raw, int ldx, const float* vec_g, const float* vec_x,
+                        const float* wpsi, const float* bpsi, int P, int F, float* q, float* partial, void* stream) {
+  (void)stream;
+  double s1 = 0.0, s2 = 0.0;
+  for (long long p = 0; p < P; ++p) {
+    double acc = bpsi ? (double)bpsi[0] : 0.0;
+    for (int c = 0; c < F; ++c) {
+      const double a = ld(dtype, g1raw, p * ldg + c) * vec_g[c] + vec_g[F + c] + ld(dtype, x1raw, p * ldx + c) * vec_x[c] + vec_x[F + c];
+      if (a > 0.0) acc += a * wpsi[c];
+    }
+    q[p] = (float)acc;
+    s1 += (double)q[p];
+    s2 += (double)q[p] * (double)q[p];
+  }
+  if (partial) {
+    partial[0] = (float)s1;
+    partial[1] = (float)s2;
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_attn_psi_fwd);
+
+/* out = x * sigmoid(bn_q(q)) */
+int uz_attn_gate_fwd_ref(int dtype, const void* x, int ldx, const float* q, const float* vec_q, int P, int C, void* out, int ldo,
+                         void* stream) {
+  (void)stream;
+  for (long long p = 0; p < P; ++p) {
+    const double z = (double)q[p] * vec_q[0] + vec_q[1], sg = 1.0 / (1.0 + exp(-z));
+    for (int c = 0; c < C; ++c) st(dtype, out, p * ldo + c, ld(dtype, x, p * ldx + c) * sg);
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_attn_gate_fwd);
+
 int uz_ref_abi_version(void) { return 1; }

@@ -507,3 +507,32 @@ def test_layernorm_restatement_merge_and_expand_addressing(dt):
         d = L.LnDesc(dc, N, h * r, w * r, C, r * r * C, C, 0, 0, 0, L.LN_EXPAND, r, 1e-5, 0)
         assert lib.uz_layernorm_fwd_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(gm), c_ref.ptr(bt), None, None, c_ref.ptr(y), c_ref.ptr(stats), None) == 0
         close(c_ref.tensor(y, dt).reshape(P, C), ref, dt, f"layernorm(expand {r})")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_attention_gate_forward_restatement(dt):
+    """uz_attn_psi_fwd_ref / uz_attn_gate_fwd_ref against AttentionBlock.forward written with torch (attention_unet.py:34-40:
+    psi = sigmoid(bn(conv1x1(relu(bn(W_g g) + bn(W_x x))))), out = x * psi), the BatchNorms as (scale, shift) rows"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(61)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    P, Fi, C = 150, 24, 40
+    g1, x1, x = rnd((P, Fi), dt, g), rnd((P, Fi), dt, g), rnd((P, C), dt, g)
+    vg, vx = torch.randn(4, Fi, generator=g), torch.randn(4, Fi, generator=g)
+    wpsi, bpsi = torch.randn(Fi, generator=g), torch.randn(1, generator=g)
+    vq = torch.tensor([[0.7], [-0.2], [0.0], [1.0]])
+    a = F.relu(g1.double() * vg[0].double() + vg[1].double() + x1.double() * vx[0].double() + vx[1].double())
+    q_ref = a @ wpsi.double() + bpsi.double()
+    q, part = np.zeros(P, np.float32), np.zeros(2, np.float32)
+    gh, xh1, vgh, vxh, wh, bh = c_ref.host(g1), c_ref.host(x1), c_ref.host(vg), c_ref.host(vx), c_ref.host(wpsi), c_ref.host(bpsi)
+    assert lib.uz_attn_grid_ref(dc, P, Fi) == 1
+    assert lib.uz_attn_psi_fwd_ref(dc, c_ref.ptr(gh), Fi, c_ref.ptr(xh1), Fi, c_ref.ptr(vgh), c_ref.ptr(vxh), c_ref.ptr(wh), c_ref.ptr(bh), P, Fi,
+                                   c_ref.ptr(q), c_ref.ptr(part), None) == 0
+    np.testing.assert_allclose(q, q_ref.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(part, [q_ref.sum().item(), (q_ref ** 2).sum().item()], rtol=1e-5)
+    out = np.zeros(P * C, npdt)
+    xh, vqh = c_ref.host(x), c_ref.host(vq)
+    assert lib.uz_attn_gate_fwd_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(q), c_ref.ptr(vqh), P, C, c_ref.ptr(out), C, None) == 0
+    ref = x.double() * torch.sigmoid(torch.from_numpy(q).double() * 0.7 - 0.2)[:, None]
+    close(c_ref.tensor(out, dt).reshape(P, C), ref, dt, "attention gate")

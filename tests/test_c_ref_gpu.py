@@ -245,6 +245,37 @@ def test_layernorm_addressing_modes_against_the_c_restatement(dt, mode, r, N, Ho
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_attention_gate_forward_kernels_against_the_c_restatement(dt):
+    """uz_attn_psi_fwd / uz_attn_gate_fwd (AttentionBlock.forward without its 1x1 convolutions, attention_unet.py:34-40)
+    against their restatements: q, the statistics rows of bn_q, the gated output"""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(71)
+    dc = L.dtype_code(dt)
+    npdt = np.uint16 if dt == torch.bfloat16 else np.float32
+    N, H, W, Fi, C = 2, 24, 40, 32, 64
+    P = N * H * W
+    g1, x1, x = rnd((P, Fi), dt, g), rnd((P, Fi), dt, g), rnd((P, C), dt, g)
+    vg, vx = torch.randn(4, Fi, generator=g), torch.randn(4, Fi, generator=g)
+    wpsi, bpsi = torch.randn(Fi, generator=g), torch.randn(1, generator=g)
+    vq = torch.tensor([[0.7], [-0.2], [0.0], [1.0]])
+    ga, xa1, xa = Act(g1.to(DEV), 0, Fi, N, H, W), Act(x1.to(DEV), 0, Fi, N, H, W), Act(x.to(DEV), 0, C, N, H, W)
+    q, part = ops.attn_psi_fwd(ga, xa1, vg.to(DEV), vx.to(DEV), wpsi.to(DEV), bpsi.to(DEV))
+    out = ops.new_act(N, H, W, C, dt, DEV)
+    ops.attn_gate_fwd(xa, q, vq.to(DEV), out)
+    qr, pr = np.zeros(P, np.float32), np.zeros(2, np.float32)
+    gh, xh1, vgh, vxh, wh, bh = c_ref.host(g1), c_ref.host(x1), c_ref.host(vg), c_ref.host(vx), c_ref.host(wpsi), c_ref.host(bpsi)
+    assert lib.uz_attn_psi_fwd_ref(dc, c_ref.ptr(gh), Fi, c_ref.ptr(xh1), Fi, c_ref.ptr(vgh), c_ref.ptr(vxh), c_ref.ptr(wh), c_ref.ptr(bh), P, Fi,
+                                   c_ref.ptr(qr), c_ref.ptr(pr), None) == 0
+    assert np.allclose(q.cpu().numpy(), qr, rtol=1e-4, atol=1e-4)
+    assert np.allclose(part.double().sum(0).reshape(-1).cpu().numpy(), pr, rtol=1e-4)
+    orf = np.zeros(P * C, npdt)
+    xh, vqh = c_ref.host(x), c_ref.host(vq)
+    qk = q.cpu().numpy().copy()      # the kernel's own q, so that the gate is compared on the same input
+    assert lib.uz_attn_gate_fwd_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(qk), c_ref.ptr(vqh), P, C, c_ref.ptr(orf), C, None) == 0
+    agree(out.buf, c_ref.tensor(orf, dt).reshape(P, C), dt, "attention gate")
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_batchnorm_relu_pool_kernels_against_the_c_restatement(dt):
     lib = c_ref.load()
     g = torch.Generator().manual_seed(14)
