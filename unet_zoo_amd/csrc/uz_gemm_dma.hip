@@ -76,8 +76,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // workgroups, and a third of a round trip per step.  NST = 2 serves K <= 128 (at most two slabs, both requested
 // up front, the host guarantees it): 64 KB of LDS, so TWO workgroups share a CU and one's epilogue overlaps the
 // other's loads -- the full-resolution Linear layers of swin_unet_v2 (K = 96) are one short tile per workgroup.
-template <typename T, int BN, int BM, int NST, bool BNRED = false>
+// SPLITK is a template argument, not a run-time branch: with `if (a.ksplit > 1)` in the shared epilogue every bf16
+// instantiation kept its fp32 accumulators and their store addresses live beside the staging epilogue (+35..45 VGPRs;
+// <128, 256, 3, BNRED> went from 253 registers to 256 + 105 spilled, round 4).  tests/test_kernel_resources.py guards it.
+template <typename T, int BN, int BM, int NST, bool BNRED = false, bool SPLITK = false>
 __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const GArgs a) {
+  static_assert(!(SPLITK && BNRED), "the split-K form stores fp32 partial tiles only");
   constexpr int VEC = ElemTraits<T>::VEC;
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = 8 * VEC;
@@ -94,8 +98,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.y * BN;
-  const int kz = a.ksplit > 1 ? (int)blockIdx.z : 0;
-  const long long bz = a.ksplit > 1 ? 0 : (int)blockIdx.z / a.nb2, bh = a.ksplit > 1 ? 0 : (int)blockIdx.z - (int)bz * a.nb2;
+  const int kz = SPLITK ? (int)blockIdx.z : 0;
+  const long long bz = SPLITK ? 0 : (int)blockIdx.z / a.nb2, bh = SPLITK ? 0 : (int)blockIdx.z - (int)bz * a.nb2;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(static_cast<const char*>(a.x)) + bz * a.xb + bh * a.xb2, 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
       a.res ? reinterpret_cast<const T*>(static_cast<const char*>(a.res) + bz * a.resb + bh * a.resb2) : nullptr;
   const int HW = a.H * a.W;
   const int ncb = (a.Cin + BK - 1) / BK;  // the last slab of a tap may be partial: zero-filled
-  const int s_beg = a.ksplit > 1 ? kz * a.cps : 0;                 // first K slab of this workgroup
-  const int nsteps = a.ksplit > 1 ? ((a.ntaps * ncb - s_beg < a.cps) ? a.ntaps * ncb - s_beg : a.cps) : a.ntaps * ncb;   // and how many
+  const int s_beg = SPLITK ? kz * a.cps : 0;                 // first K slab of this workgroup
+  const int nsteps = SPLITK ? ((a.ntaps * ncb - s_beg < a.cps) ? a.ntaps * ncb - s_beg : a.cps) : a.ntaps * ncb;   // and how many
 
   unsigned b_row_off[NBP];
   int b_coff[NBP];   // byte offset of this lane's logical chunk inside a 128-byte slab
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
     const int ab = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 / a.Co : 0;
     const int co0 = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 - ab * a.Co : n0;
     pre = 0;
-    if (a.ksplit > 1) {   // fp32 accumulators of this K range: accumulator column = pixel, register quad = 4 consecutive channels
+    if constexpr (SPLITK) {   // fp32 accumulators of this K range: accumulator column = pixel, register quad = 4 consecutive channels
       float* part = a.part + (size_t)kz * a.M * a.Nout;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -283,8 +287,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
           }
       }
       continue;
-    }
-    if constexpr (sizeof(T) == 2) {
+    } else if constexpr (sizeof(T) == 2) {
       constexpr int RSC = RSCB;
       static_assert(BM * RSC <= NST * STAGE, "C staging must fit the ring");
       __builtin_amdgcn_s_barrier();   // every wave has finished reading this tile's A / B stages
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
     }
   }
 
+  if constexpr (SPLITK) return;
   if constexpr (sizeof(T) == 2) {
     if (a.stats != nullptr) {
       constexpr int CPR = BN * ES / 16;
@@ -542,6 +546,13 @@ template <typename T>
 static int gemm_launch_grid(const UzGemmPlan& p, const GArgs& a, dim3 grid, hipStream_t s) {
   dim3 block(512);
   if constexpr (sizeof(T) == 2) {
+    if (a.ksplit > 1) {   // the plan splits three-/four-stage shapes only
+      if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3, false, true>), grid, block, 0, s, a);
+      else if (p.bm == 128) hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 128, 4, false, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gemm_dma_kernel<T, 128, 256, 3, false, true>), grid, block, 0, s, a);
+      UZ_LAUNCH_CHECK("uz_conv_igemm(gemm_dma, split-K)");
+      return UZ_OK;
+    }
     if (a.bn_y != nullptr) {
       if (p.bn == 64 && p.nst == 2) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 2, true>), grid, block, 0, s, a);
       else if (p.bn == 64) hipLaunchKernelGGL((gemm_dma_kernel<T, 64, 256, 3, true>), grid, block, 0, s, a);
