@@ -160,6 +160,17 @@ int uz_conv_igemm_bnred(const uz_conv_desc* d, const void* x, const void* w_pack
                         int ld_bny, const float* scale, const float* shift, const float* mean, const float* invstd,
                         float* partial, void* stream);
 
+/* Convolution that reads its input THROUGH the BatchNorm + ReLU in front of it (round 5): x holds the raw output of the
+ * preceding convolution, the kernel computes y = conv(a, w) + bias with a = relu(x * in_scale[c] + in_shift[c]) formed
+ * inside LDS on the halo patch (fp32 fma, rounded to the tensor dtype exactly as uz_bn_relu_apply would store it; zero
+ * padding stays zero), so the normalised activation of a DoubleConv's first half (common_layers.py:28-33: Conv -> BN ->
+ * ReLU -> Conv) is never written to or read from HBM.  Statistics rows as uz_conv_igemm (uz_conv_igemm_grid_m() rows).
+ * bf16 3x3 problems of the direct ping-pong kernel whose LDS image leaves room for the channel table
+ * (uz_conv_igemm_xf_supported() == 1); others: UZ_ENOTIMPL -- the caller then materialises the activation. */
+int uz_conv_igemm_xf_supported(const uz_conv_desc* d);
+int uz_conv_igemm_xf(const uz_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                     const void* w_packed, const float* bias, void* y, float* stats_partial, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient (reduction over pixels), fp32 output in the reference's parameter layout.
  *   out[i, j, tap] (+)= sum_p L[p, i] * R[pix(p, tap), j]

@@ -37,7 +37,7 @@ EXPORTS = (
     "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
     "uz_conv_igemm_workspace_bytes", "uz_conv_igemm_ws_grid_m", "uz_conv_igemm_ws",
-    "uz_conv_igemm_bnred_supported", "uz_conv_igemm_bnred", "uz_conv_igemm_kernel_name", "uz_bn_bwd_finalize", "uz_profile_arm", "uz_profile_disarm",
+    "uz_conv_igemm_bnred_supported", "uz_conv_igemm_bnred", "uz_conv_igemm_xf_supported", "uz_conv_igemm_xf", "uz_conv_igemm_kernel_name", "uz_bn_bwd_finalize", "uz_profile_arm", "uz_profile_disarm",
     "uz_patchify", "uz_layernorm_fwd", "uz_layernorm_bwd_rows", "uz_layernorm_bwd", "uz_layernorm_act_bwd",
     "uz_ln_head_fwd", "uz_ln_head_bwd_workspace_bytes", "uz_ln_head_bwd", "uz_sum_rows_f32_ld",
     "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
@@ -158,6 +158,8 @@ def load():
     lib.uz_conv_igemm_ws_grid_m.argtypes = [POINTER(ConvDesc)]
     lib.uz_conv_igemm_ws.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]
     lib.uz_conv_igemm_bnred_supported.argtypes = [POINTER(ConvDesc)]
+    lib.uz_conv_igemm_xf_supported.argtypes = [POINTER(ConvDesc)]
+    lib.uz_conv_igemm_xf.argtypes = [POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.uz_conv_igemm_kernel_name.argtypes = [POINTER(ConvDesc), c_int, c_char_p, c_int]
     lib.uz_profile_arm.argtypes = [vp, vp]
     lib.uz_profile_disarm.argtypes = []

@@ -120,9 +120,14 @@ struct UzBnRed {
   int ldy;
   const float *scale, *shift, *mean, *invstd;
 };
+// per-input-channel (scale, shift) of the BatchNorm + ReLU applied to x on its way into LDS (uz_conv_igemm_xf, uz_wgrad_xf)
+struct UzXf {
+  const float *scale, *shift;
+};
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
                      const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br = nullptr,
-                     float* part = nullptr);   // part: split-K partial tiles (ping-pong plans with ksplit > 1)
+                     float* part = nullptr,   // part: split-K partial tiles (ping-pong plans with ksplit > 1)
+                     const UzXf* xf = nullptr);
 
 // direct 3x3 convolution, ping-pong schedule on 512-pixel x 128-channel tiles (uz_conv3x3_pp.hip); uz_direct_plan()
 // hands the descriptors it takes over with bres = 3
@@ -136,7 +141,8 @@ struct UzPpPlan {
 };
 int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p);
 int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const void* w, const float* bias, void* y,
-                 float* stats, hipStream_t s, const UzBnRed* br = nullptr, float* part = nullptr);
+                 float* stats, hipStream_t s, const UzBnRed* br = nullptr, float* part = nullptr, const UzXf* xf = nullptr);
+int uz_pp_xf_channels(const UzPpPlan& p);   // input channels the XF form of this plan's configuration takes (0: none)
 
 // 3x3 weight gradient with LDS-DMA pipeline (uz_wgrad3x3.hip), dispatched from uz_wgrad()
 struct UzWgrad2Plan {

@@ -1037,12 +1037,14 @@ static int direct_launch_t(const UzDirectPlan& p, const DirectArgs& a, hipStream
 }
 
 int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x, const void* w,
-                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br, float* part) {
+                     const float* bias, void* y, float* stats, hipStream_t s, const UzBnRed* br, float* part,
+                     const UzXf* xf) {
   const int es = d->dtype == UZ_BF16 ? 2 : 4;
   if (p.bres == 3) {
     UzPpPlan pp = {p.ppcfg, p.bn, p.th_n, p.tw_n, p.ntiles, p.tiles_n, p.grid_m, p.ksplit, p.cps};
-    return uz_pp_launch(d, pp, x, w, bias, y, stats, s, br, part);
+    return uz_pp_launch(d, pp, x, w, bias, y, stats, s, br, part, xf);
   }
+  UZ_REQUIRE(xf == nullptr, "uz_conv_igemm_xf: the input transform is the ping-pong kernel's");
   UZ_REQUIRE(part == nullptr, "uz_conv_igemm(direct3x3): split-K is the ping-pong kernel's");
   DirectArgs a;
   a.bn_y = br ? br->y : nullptr;

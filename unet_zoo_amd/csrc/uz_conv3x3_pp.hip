@@ -57,6 +57,11 @@ struct PpArgs {
   // partial tile to part[z][pixel][channel]; igemm_split_reduce_kernel adds them in fixed order (+ bias, statistics)
   float* part;
   int cps;
+  // XF (template parameter): x holds the RAW output of the preceding convolution; its BatchNorm + ReLU
+  // a = relu(fma(x, xf_scale[c], xf_shift[c])) (rounded to bf16 as uz_bn_relu_apply would store it) is applied to the halo
+  // patch inside LDS, so the normalised activation never exists in HBM (DoubleConv's middle tensor, common_layers.py:28-33)
+  const float* xf_scale;
+  const float* xf_shift;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -99,6 +104,21 @@ struct PpCfg {
   static constexpr int SMEM_BYTES = OFF_BIAS + BN * 4;
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
   static_assert(UPP * (PT + CT) * 4 + PT * CT * 4 <= 200, "register budget: fragments + accumulators");
+  // XF instantiations: what is left of the 160 KB holds the (scale, shift) table of the input channels, 64 bytes per
+  // 8-channel chunk [scale x 8 | shift x 8] -- one base address and four ds_read_b128 per transformed piece
+  static constexpr int OFF_XF = SMEM_BYTES;
+  static constexpr int XF_CHUNKS = (160 * 1024 - SMEM_BYTES) / 64;
+  static constexpr int XF_CH = XF_CHUNKS * 8;                  // input channels the table can hold
+  // a halo piece requested in phase q is transformed in place at the end of read phase q + XD by the wave that requested it
+  // (its own vmcnt wait orders the LDS-DMA in front of its own reads; the phase's barrier publishes the result)
+  static constexpr int XD = 1;
+  // vmcnt(N) before that transform: everything up to phase p - XD has landed, the requests of the XD youngest phases may fly
+  static constexpr int wait_xf(int p, int grp) {
+    int n = 0;
+    for (int k = p - XD + 1; k <= p; ++k) n += nb(grp) + na(k);
+    return n;
+  }
+  static constexpr bool xf_here(int p) { return p - XD >= 0 && na(p - XD) > 0; }
 
   // halo pieces a wave requests in phase p (for the next slab): none in a slab's last phase when a slab has few phases
   // (they must have landed when that phase ends)
@@ -179,9 +199,17 @@ template <int V> struct IntC { static constexpr int value = V; };
                       // 16 fragment reads in a tile's first phase only, 128 both groups in lockstep (timing only)
 #endif
 
-template <typename C, bool BNRED, bool SPLIT = false>
+template <int OFF> __device__ __forceinline__ void lds_read16u(u32x4& dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_write16u(unsigned lds_addr, const u32x4& v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
+}
+
+template <typename C, bool BNRED, bool SPLIT = false, bool XF = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   static_assert(!(BNRED && SPLIT), "the split-K form has no fused epilogue");
+  static_assert(!(BNRED && XF), "the fused BatchNorm-backward sums belong to input gradients, the input transform to forwards");
   typedef bf16_t T;
   constexpr int ES = 2, VEC = 8;
   constexpr int TH = C::TH, TW = C::TW, PH = C::PH, PHP = C::PHP, PROWS = C::PROWS, APIECES = C::APIECES, A_BYTES = C::A_BYTES;
@@ -189,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   constexpr int NSLOT = C::NSLOT, DPH = C::DPH, UPP = C::UPP, ROWS_W = C::ROWS_W, HALVES = C::HALVES, PT = C::PT, CT = C::CT;
   constexpr int OFF_B = C::OFF_B, OFF_STG = C::OFF_STG, OFF_SCR = C::OFF_SCR, OFF_BIAS = C::OFF_BIAS, NSTORE = C::NSTORE;
   constexpr int SLOT_BYTES = UPP * B_UNIT;
-  __shared__ __attribute__((aligned(1024))) char smem[C::SMEM_BYTES];
+  __shared__ __attribute__((aligned(1024))) char smem[C::SMEM_BYTES + (XF ? C::XF_CHUNKS * 64 : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,6 +313,54 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   // the z-th range of cps slabs
   const int cbeg = SPLIT ? (int)blockIdx.z * a.cps : 0;
   const int cend = SPLIT ? (cbeg + a.cps < ncb ? cbeg + a.cps : ncb) : ncb;
+  if constexpr (XF) {   // (scale, shift) of this workgroup's input channels [32 cbeg, 32 cend): chunk q = [scale x 8 | shift x 8]
+    float* const sXf = reinterpret_cast<float*>(smem + C::OFF_XF);
+    for (int i = tid; i < (cend - cbeg) * KU; i += 512) {
+      const int ch = cbeg * KU + i;
+      sXf[(i >> 3) * 16 + (i & 7)] = a.xf_scale[ch];
+      sXf[(i >> 3) * 16 + 8 + (i & 7)] = a.xf_shift[ch];
+    }
+  }
+  // XF: halo piece wave + 8 k of slab cs, landed in patch buffer buf, becomes relu(fma(x, scale, shift)) in place.  A lane
+  // transforms the 16 bytes it requested (8 channels of one patch pixel): logical chunk unswz(lane & 3, patch column) of the
+  // slab; a lane whose request was out of range (zero padding, rows beyond the patch) keeps its zeros.  All LDS accesses
+  // from inline asm: beside LDS-DMA in flight hipcc would put s_waitcnt vmcnt(0) in front of its own.
+  auto xf_piece = [&](auto kc, int buf, int cs) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (XF && k < APW) {
+      const int piece = wave + 8 * k;
+      if (piece < APIECES) {   // wave-uniform (the rest are the dummies that keep the request counts equal)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int r = piece * 16 + (ln >> 2);
+        const int pj = r / PHP;
+        const unsigned paddr = smem_u + (unsigned)(buf * A_BYTES + piece * 1024) + (unsigned)(ln << 4);
+        const unsigned taddr = smem_u + (unsigned)C::OFF_XF + (unsigned)((((cs - cbeg) << 2) + unswz(ln & 3, pj)) << 6);
+        u32x4 v, s0, s1, h0, h1;
+        lds_read16u<0>(v, paddr);
+        lds_read16u<0>(s0, taddr);
+        lds_read16u<16>(s1, taddr);
+        lds_read16u<32>(h0, taddr);
+        lds_read16u<48>(h1, taddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v), "+v"(s0), "+v"(s1), "+v"(h0), "+v"(h1)::"memory");
+        const bool inside = avoff[k] != OOB;
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sc0 = __builtin_bit_cast(float, i < 2 ? s0[2 * i] : s1[2 * i - 4]);
+          const float sc1 = __builtin_bit_cast(float, i < 2 ? s0[2 * i + 1] : s1[2 * i - 3]);
+          const float sh0 = __builtin_bit_cast(float, i < 2 ? h0[2 * i] : h1[2 * i - 4]);
+          const float sh1 = __builtin_bit_cast(float, i < 2 ? h0[2 * i + 1] : h1[2 * i - 3]);
+          const float x0 = __builtin_bit_cast(float, v[i] << 16), x1 = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+          const float y0 = fmaxf(fmaf(x0, sc0, sh0), 0.f), y1 = fmaxf(fmaf(x1, sc1, sh1), 0.f);
+          const bf16_t b0 = (bf16_t)y0, b1 = (bf16_t)y1;   // round to nearest even, as the stand-alone pass stores it
+          const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+          o[i] = inside ? u : 0u;
+        }
+        lds_write16u(paddr, o);
+      }
+    }
+  };
   // acc[pt][ct]: 16-pixel tile pt = HALVES * (patch row of the wave) + column half, 16-channel tile ct
   f32x4 acc[PT][CT];
   f32x4 fa[UPP][PT], fb[UPP][CT];
@@ -306,6 +382,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   }
   wait_vmcnt<0>();
   __syncthreads();
+  if constexpr (XF) {   // the first patch (the table is visible since the barrier above)
+    if ((int)blockIdx.x < a.ntiles) {
+      xf_piece(IntC<0>(), 0, cbeg); xf_piece(IntC<1>(), 0, cbeg); xf_piece(IntC<2>(), 0, cbeg);
+      xf_piece(IntC<3>(), 0, cbeg); xf_piece(IntC<4>(), 0, cbeg); xf_piece(IntC<5>(), 0, cbeg);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
   // ---- one phase ---------------------------------------------------------------------------------------------------------
   // c: slab of this tile, first: c == 0 (the previous tile's stores are among the young requests), last: c == ncb - 1,
@@ -363,19 +447,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       }
     }
     {
+      // XF: the halo pieces this wave requested XD phases ago are transformed below: they must have landed (and with them
+      // everything older, the previous tile's stores included)
+      constexpr bool TX = XF && C::xf_here(p);
       auto waits = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
-        constexpr int NW = C::wait_normal(p, g), NN = C::wait_nonext(p, g);
+        constexpr int NW0 = C::wait_normal(p, g), NN = C::wait_nonext(p, g), NX = C::wait_xf(p, g);
+        constexpr int NW = (TX && NX < NW0) ? NX : NW0;
         if (nonext) {
           if (p <= DPH - 2 && first) wait_vmcnt<NN + NSTORE>();
           else wait_vmcnt<NN>();
         } else {
-          if (p <= DPH - 2 && first) wait_vmcnt<NW + NSTORE>();
+          if (p <= DPH - 2 && first && !(TX && NX < NW0 + NSTORE)) wait_vmcnt<NW0 + NSTORE>();
           else wait_vmcnt<NW>();
         }
       };
       if (C::nb(0) == C::nb(1) || grp == 0) waits(IntC<0>());
       else waits(IntC<1>());
+      if constexpr (TX) {
+        if (!nonext) {
+          constexpr int q = p - C::XD, k0 = C::na_before(q), kn = C::na(q);
+          const int cs = last ? cbeg : c + 1;
+          if constexpr (kn > 0) xf_piece(IntC<k0>(), apar ^ 1, cs);
+          if constexpr (kn > 1) xf_piece(IntC<k0 + 1>(), apar ^ 1, cs);
+          if constexpr (kn > 2) xf_piece(IntC<k0 + 2>(), apar ^ 1, cs);
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -667,11 +764,24 @@ int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p) {
   return 1;
 }
 
+// input channels whose (scale, shift) table fits beside a configuration's LDS image (uz_conv_igemm_xf); 0: no XF form
+int uz_pp_xf_channels(const UzPpPlan& p) {
+  switch (p.cfg) {
+    case UZ_PP_512X64: return Cfg512x64::XF_CH;
+    default: return 0;
+  }
+}
+
 int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const void* w, const float* bias, void* y,
-                 float* stats, hipStream_t s, const UzBnRed* br, float* part) {
+                 float* stats, hipStream_t s, const UzBnRed* br, float* part, const UzXf* xf) {
   PpArgs a;
   a.part = part;
   a.cps = p.cps;
+  a.xf_scale = xf ? xf->scale : nullptr;
+  a.xf_shift = xf ? xf->shift : nullptr;
+  if (xf)
+    UZ_REQUIRE(br == nullptr && part == nullptr && xf->scale && xf->shift && d->Cin <= uz_pp_xf_channels(p),
+               "uz_conv_igemm_xf(direct3x3 ping-pong): configuration %d takes no input transform for %d channels", p.cfg, d->Cin);
   UZ_REQUIRE(part == nullptr || (br == nullptr && p.ksplit > 1 && (p.cfg == UZ_PP_256 || p.cfg == UZ_PP_256W16)),
              "uz_conv_igemm(direct3x3 ping-pong): split-K launch without a split plan");
   a.x = x;
@@ -709,6 +819,11 @@ int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const 
     return UZ_OK;
   }
   dim3 grid(p.grid_m, p.tiles_n), block(512);
+  if (xf) {
+    hipLaunchKernelGGL((conv3x3_pp_kernel<Cfg512x64, false, false, true>), grid, block, 0, s, a);
+    UZ_LAUNCH_CHECK("uz_conv_igemm_xf(direct3x3 ping-pong)");
+    return UZ_OK;
+  }
 #define UZ_PP_GO(CFG)                                                                          \
   do {                                                                                         \
     if (br) hipLaunchKernelGGL((conv3x3_pp_kernel<CFG, true>), grid, block, 0, s, a);          \

@@ -603,6 +603,34 @@ extern "C" int uz_conv_igemm_res_ws(const uz_conv_desc* d, const void* x, const 
   return uz_gemm_dma_launch(d, gp, x, w_packed, bias, y, nullptr, static_cast<hipStream_t>(stream), res, ldres);
 }
 
+// ---- convolution reading its input through the BatchNorm + ReLU in front of it (include/unetzoo_hip.h) -----------------
+extern "C" int uz_conv_igemm_xf_supported(const uz_conv_desc* d) {
+  UzDirectPlan dp;
+  if (d == nullptr || d->dtype != UZ_BF16) return 0;
+  if (!uz_direct_plan(d, &dp) || dp.bres != 3 || dp.ksplit > 1) return 0;
+  UzPpPlan pp = {dp.ppcfg, dp.bn, dp.th_n, dp.tw_n, dp.ntiles, dp.tiles_n, dp.grid_m, dp.ksplit, dp.cps};
+  return d->Cin <= uz_pp_xf_channels(pp) ? 1 : 0;
+}
+
+extern "C" int uz_conv_igemm_xf(const uz_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                                const void* w_packed, const float* bias, void* y, float* stats_partial, void* stream) {
+  Plan p;
+  const int rc = make_plan(d, &p);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(x && w_packed && y && in_scale && in_shift, "uz_conv_igemm_xf: null pointer");
+  UZ_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)y & 15) == 0,
+             "uz_conv_igemm_xf: x / w / y must be 16-byte aligned");
+  if (!uz_conv_igemm_xf_supported(d)) {
+    uz_set_error("uz_conv_igemm_xf: only bf16 3x3 problems of the ping-pong configurations whose LDS image leaves room for "
+                 "the channel table (ask uz_conv_igemm_xf_supported)");
+    return UZ_ENOTIMPL;
+  }
+  UzDirectPlan dp;
+  UZ_REQUIRE(uz_direct_plan(d, &dp), "uz_conv_igemm_xf: no plan");
+  const UzXf xf = {in_scale, in_shift};
+  return uz_direct_launch(d, dp, x, w_packed, bias, y, stats_partial, static_cast<hipStream_t>(stream), nullptr, nullptr, &xf);
+}
+
 extern "C" int uz_conv_igemm_bnred_supported(const uz_conv_desc* d) {
   UzDirectPlan dp;
   UzGemmPlan gp;

@@ -290,12 +290,15 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
                ntaps: int, dil: int = 1, taps_mode: int = L.TAPS_CONV,
                store_mode: int = L.STORE_PLAIN, nout: Optional[int] = None, co: int = 0,
                want_stats: bool = False, res: Optional[Act] = None,
-               bnred: Optional[tuple] = None) -> Optional[torch.Tensor]:
+               bnred: Optional[tuple] = None, xform: Optional[tuple] = None) -> Optional[torch.Tensor]:
     """y = conv(x, w) + bias [+ res] on the matrix cores; returns the BN partial-sum rows if asked.  res: a tensor
     of y's shape added in the GEMM epilogue (uz_conv_igemm_res), or by a separate add where that kernel does not apply.
     bnred = (bn_y, vec): y is the gradient of relu(bn(bn_y)); the kernel's epilogue accumulates the two sums of that
     BatchNorm's backward (uz_conv_igemm_bnred) and their partial rows are returned -- or None when the problem is not
-    one of the kernels that can (the caller then runs the stand-alone reduction)."""
+    one of the kernels that can (the caller then runs the stand-alone reduction).
+    xform = (scale, shift): x is the RAW output of the preceding convolution and the kernel reads it through that layer's
+    BatchNorm + ReLU, relu(x * scale + shift) per input channel (uz_conv_igemm_xf); the caller has asked
+    conv_xform_supported() first."""
     L.require_cuda(x.buf, w_packed, y.buf)
     lib = L.load()
     if taps_mode == L.TAPS_CONV:
@@ -320,6 +323,12 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.buf.device) if wsb > 0 else None
     M, K, es = N * H * W, ntaps * x.C, x.buf.element_size()
     kname = conv_kernel_name(d, ws is not None)   # the family the library's own plan launches for this descriptor
+    if xform is not None:
+        assert bnred is None and res is None
+        with _Timed(kname + "_xf", 2.0 * M * d.Nout * K, es * (x.P * x.C + M * d.Nout + d.Nout * K)):
+            L.check(lib.uz_conv_igemm_xf(byref(d), x.ptr(), xform[0].data_ptr(), xform[1].data_ptr(), w_packed.data_ptr(),
+                                         _p(bias), y.ptr(), _p(stats), L.stream_ptr()), "uz_conv_igemm_xf")
+        return stats
     if bnred is not None:
         assert bias is None and res is None and not want_stats
         bn_y, vec4 = bnred
@@ -348,6 +357,14 @@ def conv_igemm(x: Act, w_packed: torch.Tensor, bias: Optional[torch.Tensor], y: 
     if res is not None:
         add_acts(y, res, y)
     return stats
+
+
+def conv_xform_supported(x: Act, nout: int, ldy: int, *, upsample: bool = False) -> bool:
+    """whether uz_conv_igemm_xf takes the 3x3 convolution of x (channels, pixel grid, run dtype) to nout channels"""
+    H, W = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
+    d = L.ConvDesc(L.dtype_code(x.dtype), x.N, H, W, x.H, x.W, x.C, x.ld, nout, ldy, 9,
+                   L.TAPS_CONV_UP2 if upsample else L.TAPS_CONV, 1, L.STORE_PLAIN, 0, 0, 0)
+    return bool(L.load().uz_conv_igemm_xf_supported(byref(d)))
 
 
 def wgrad_kernel_name(d) -> str:
