@@ -74,15 +74,29 @@ constexpr int KU = 32;                  // K per unit
 constexpr int STG_ROW = 144;            // staging row: 64 channels + 16 bytes
 constexpr int STG_W = 32 * STG_ROW;     // a wave's staging strip: 32 pixels (also parks its 64 x 64 B of running sums)
 
-template <int TH_, int TW_, int WM_, int WN_, int UPP_>
+// XM (the XF instantiations): another deal of the halo pieces to the waves, see piece() below
+template <int TH_, int TW_, int WM_, int WN_, int UPP_, bool XM_ = false>
 struct PpCfg {
   static constexpr int TH = TH_, TW = TW_, WM = WM_, WN = WN_, UPP = UPP_;
+  static constexpr bool XM = XM_;
   static_assert(WM * WN == 8 && (TW == 32 || TW == 16) && TH % WM == 0 && 9 % UPP == 0, "tile configuration");
   static constexpr int PH = TH + 2, PW = TW + 2, PHP = PH | 1;
   static constexpr int PROWS = PW * PHP;
   static constexpr int APIECES = (PROWS * RB + 1023) / 1024;   // 1 KB pieces (16 rows) of a patch
   static constexpr int A_BYTES = APIECES * 1024;
-  static constexpr int APW = (APIECES + 7) / 8;                // pieces per wave and slab (beyond APIECES: dummies)
+  static constexpr int APW = XM ? 8 : (APIECES + 7) / 8;       // pieces per wave and slab (beyond APIECES: dummies)
+  // Halo piece k of wave w.  Plain: w + 8 k.  XM (input transform, three phases per slab): the arithmetic of a piece
+  // requested in phase q rides in the MFMA gaps of the requesting wave's compute phase q + 1 -- but group 1's LAST compute
+  // phase runs beside group 0's first reads of the next slab, so group 1 must own no piece of the second batch.  Group 1
+  // (waves 4-7): pieces 0 .. 15, all in the first batch (k < 4; k >= 4 dummies); group 0: 16 .. 27 in the first batch
+  // (k < 3, k = 3 a dummy), 28 ... in the second (k = 4 .. 7).  Four requests per wave in each of the first two phases:
+  // two dummies per wave and slab more than the plain deal, and no transform left in any read phase.
+  static constexpr int piece(int w, int k) {
+    if (!XM) return w + 8 * k;
+    if (w >= 4) return k < 4 ? (w - 4) + 4 * k : APIECES + 64;
+    return k < 3 ? 16 + w + 4 * k : (k == 3 ? APIECES + 64 : 28 + w + 4 * (k - 4));
+  }
+  static_assert(!XM || (9 / UPP_ == 3 && APIECES > 28 && APIECES <= 44), "the XM deal is made for three phases and 29 .. 44 pieces");
   static constexpr int BN = 64 * WN;
   static constexpr int B_UNIT = BN * RB;                       // weight tile of a unit
   static constexpr int BPU = B_UNIT / 1024;                    // pieces per unit (8 or 4)
@@ -123,6 +137,7 @@ struct PpCfg {
   // halo pieces a wave requests in phase p (for the next slab): none in a slab's last phase when a slab has few phases
   // (they must have landed when that phase ends)
   static constexpr int na(int p) {
+    if (XM) return p < 2 ? 4 : 0;
     if (NPH == 9) return p < APW ? 1 : 0;
     const int first = (APW + NPH - 2) / (NPH - 1);
     int left = APW;
@@ -199,6 +214,9 @@ template <int V> struct IntC { static constexpr int value = V; };
                       // 16 fragment reads in a tile's first phase only, 128 both groups in lockstep (timing only)
 #endif
 
+// (a function, not __builtin_bit_cast(float, vec[i]) in place: with a vector element as its direct operand hipcc 7.2 reads
+// element 0 whatever the subscript -- found when every channel was scaled by its chunk's first scale)
+__device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
 template <int OFF> __device__ __forceinline__ void lds_read16u(u32x4& dst, unsigned lds_addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
 }
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int k = 0; k < APW; ++k) {
-      const int r = (wave + 8 * k) * 16 + (ln >> 2);
+      const int r = C::piece(wave, k) * 16 + (ln >> 2);
       const int pj = r / PHP, pi = r - pj * PHP;
       const int hh = hh0 - 1 + pi, ww = ww0 - 1 + pj;
       const bool ok = r < PROWS && pi < PH && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   auto issue_a = [&](auto kc, int buf, int cslab) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k < APW) {
-      const int piece = wave + 8 * k;
+      const int piece = C::piece(wave, k);
       char* dst = piece < APIECES ? smem + buf * A_BYTES + piece * 1024 : smem + OFF_SCR;
       dma16(xr, dst, avoff[k], (unsigned)(cslab * KU * ES));
     }
@@ -321,43 +339,62 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       sXf[(i >> 3) * 16 + 8 + (i & 7)] = a.xf_shift[ch];
     }
   }
-  // XF: halo piece wave + 8 k of slab cs, landed in patch buffer buf, becomes relu(fma(x, scale, shift)) in place.  A lane
-  // transforms the 16 bytes it requested (8 channels of one patch pixel): logical chunk unswz(lane & 3, patch column) of the
-  // slab; a lane whose request was out of range (zero padding, rows beyond the patch) keeps its zeros.  All LDS accesses
-  // from inline asm: beside LDS-DMA in flight hipcc would put s_waitcnt vmcnt(0) in front of its own.
-  auto xf_piece = [&](auto kc, int buf, int cs) __attribute__((always_inline)) {
+  // XF: halo piece wave + 8 k of slab cs, landed in patch buffer buf, becomes relu(fma(x, scale, shift)) in place, by the wave
+  // that requested it (its own vmcnt wait orders the LDS-DMA in front of its own reads).  Of its piece's row (lane >> 2) a
+  // lane takes LOGICAL chunk lane & 3 -- physical chunk swz(lane & 3, patch column) -- so its 8 + 8 table values are the
+  // same for every piece of a slab and live in registers (xt).  A row whose request was out of range (zero padding, rows
+  // beyond the patch) keeps its zeros.  All LDS accesses from inline asm: beside LDS-DMA in flight hipcc would put
+  // s_waitcnt vmcnt(0) in front of its own.
+  u32x4 xd[4] = {}, xt[4] = {};   // staged raw bytes of up to four pieces; [scale 0..3 | 4..7 | shift 0..3 | 4..7]
+  unsigned xad[4] = {};           // where they go back to
+  auto xf_addr = [&](auto kc, int buf) __attribute__((always_inline)) -> unsigned {
+    constexpr int k = decltype(kc)::value;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int piece = C::piece(wave, k);
+    const int r = piece * 16 + (ln >> 2);
+    const int pj = r / PHP;
+    return smem_u + (unsigned)(buf * A_BYTES + piece * 1024) + (unsigned)((ln >> 2) << 6) + (unsigned)(swz(ln & 3, pj) << 4);
+  };
+  auto xf_table = [&](int cs) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const unsigned taddr = smem_u + (unsigned)C::OFF_XF + (unsigned)((((cs - cbeg) << 2) + (ln & 3)) << 6);
+    lds_read16u<0>(xt[0], taddr);
+    lds_read16u<16>(xt[1], taddr);
+    lds_read16u<32>(xt[2], taddr);
+    lds_read16u<48>(xt[3], taddr);
+  };
+  auto xf_math = [&](const u32x4& v) __attribute__((always_inline)) -> u32x4 {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float sc0 = u2f(xt[i >> 1][2 * (i & 1)]), sc1 = u2f(xt[i >> 1][2 * (i & 1) + 1]);
+      const float sh0 = u2f(xt[2 + (i >> 1)][2 * (i & 1)]), sh1 = u2f(xt[2 + (i >> 1)][2 * (i & 1) + 1]);
+      const float x0 = u2f(v[i] << 16), x1 = u2f(v[i] & 0xffff0000u);
+      // fma in fp32, round to nearest even (v_cvt_pk_bf16_f32), then the ReLU on the packed pair: a negative bf16 is a
+      // negative int16, so max(., 0) as integers is max(., +0.0) -- the bits uz_bn_relu_apply stores (a NaN stays a NaN)
+      const bf16x2 b = __builtin_convertvector(f32x2{fmaf(x0, sc0, sh0), fmaf(x1, sc1, sh1)}, bf16x2);
+      o[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b), s16x2{0, 0}));
+    }
+    return o;
+  };
+  // whether piece wave + 8 k exists (the rest are the dummies that keep the request counts equal): wave-uniform
+  auto xf_real = [&](int k) { return C::piece(wave, k) < APIECES; };
+  // one piece at once (prologue; group 1 in a slab's last read phase): read, wait, transform, write
+  auto xf_now = [&](auto kc, int buf) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
     if constexpr (XF && k < APW) {
-      const int piece = wave + 8 * k;
-      if (piece < APIECES) {   // wave-uniform (the rest are the dummies that keep the request counts equal)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int r = piece * 16 + (ln >> 2);
-        const int pj = r / PHP;
-        const unsigned paddr = smem_u + (unsigned)(buf * A_BYTES + piece * 1024) + (unsigned)(ln << 4);
-        const unsigned taddr = smem_u + (unsigned)C::OFF_XF + (unsigned)((((cs - cbeg) << 2) + unswz(ln & 3, pj)) << 6);
-        u32x4 v, s0, s1, h0, h1;
-        lds_read16u<0>(v, paddr);
-        lds_read16u<0>(s0, taddr);
-        lds_read16u<16>(s1, taddr);
-        lds_read16u<32>(h0, taddr);
-        lds_read16u<48>(h1, taddr);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v), "+v"(s0), "+v"(s1), "+v"(h0), "+v"(h1)::"memory");
-        const bool inside = avoff[k] != OOB;
-        u32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float sc0 = __builtin_bit_cast(float, i < 2 ? s0[2 * i] : s1[2 * i - 4]);
-          const float sc1 = __builtin_bit_cast(float, i < 2 ? s0[2 * i + 1] : s1[2 * i - 3]);
-          const float sh0 = __builtin_bit_cast(float, i < 2 ? h0[2 * i] : h1[2 * i - 4]);
-          const float sh1 = __builtin_bit_cast(float, i < 2 ? h0[2 * i + 1] : h1[2 * i - 3]);
-          const float x0 = __builtin_bit_cast(float, v[i] << 16), x1 = __builtin_bit_cast(float, v[i] & 0xffff0000u);
-          const float y0 = fmaxf(fmaf(x0, sc0, sh0), 0.f), y1 = fmaxf(fmaf(x1, sc1, sh1), 0.f);
-          const bf16_t b0 = (bf16_t)y0, b1 = (bf16_t)y1;   // round to nearest even, as the stand-alone pass stores it
-          const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
-          o[i] = inside ? u : 0u;
-        }
-        lds_write16u(paddr, o);
+      if (xf_real(k)) {
+        const unsigned ad = xf_addr(kc, buf);
+        u32x4 v;
+        lds_read16u<0>(v, ad);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v), "+v"(xt[0]), "+v"(xt[1]), "+v"(xt[2]), "+v"(xt[3])::"memory");
+        const u32x4 o = xf_math(v);
+        if (avoff[k] != OOB) lds_write16u(ad, o);   // rows outside the image keep the zeros the LDS-DMA put there
       }
     }
   };
@@ -376,7 +413,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     compute_avoff(img, h0, w0);
     issue_a(IntC<0>(), 0, cbeg); issue_a(IntC<1>(), 0, cbeg); issue_a(IntC<2>(), 0, cbeg);
     issue_a(IntC<3>(), 0, cbeg); issue_a(IntC<4>(), 0, cbeg); issue_a(IntC<5>(), 0, cbeg);
-    static_assert(APW <= 6, "prologue issues six halo pieces per wave");
+    issue_a(IntC<6>(), 0, cbeg); issue_a(IntC<7>(), 0, cbeg);
+    static_assert(APW <= 8, "prologue issues eight halo pieces per wave");
 #pragma unroll
     for (int u = 0; u < DPH; ++u) issue_b(u, cbeg, u);
   }
@@ -384,8 +422,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
   __syncthreads();
   if constexpr (XF) {   // the first patch (the table is visible since the barrier above)
     if ((int)blockIdx.x < a.ntiles) {
-      xf_piece(IntC<0>(), 0, cbeg); xf_piece(IntC<1>(), 0, cbeg); xf_piece(IntC<2>(), 0, cbeg);
-      xf_piece(IntC<3>(), 0, cbeg); xf_piece(IntC<4>(), 0, cbeg); xf_piece(IntC<5>(), 0, cbeg);
+      xf_table(cbeg);
+      xf_now(IntC<0>(), 0); xf_now(IntC<1>(), 0); xf_now(IntC<2>(), 0);
+      xf_now(IntC<3>(), 0); xf_now(IntC<4>(), 0); xf_now(IntC<5>(), 0);
+      xf_now(IntC<6>(), 0); xf_now(IntC<7>(), 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -443,7 +483,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
         if constexpr (kn > 0) issue_a(IntC<k0>(), apar ^ 1, cs);
         if constexpr (kn > 1) issue_a(IntC<k0 + 1>(), apar ^ 1, cs);
         if constexpr (kn > 2) issue_a(IntC<k0 + 2>(), apar ^ 1, cs);
-        static_assert(kn <= 3, "at most three halo pieces per wave and phase");
+        if constexpr (kn > 3) issue_a(IntC<k0 + 3>(), apar ^ 1, cs);
+        static_assert(kn <= 4, "at most four halo pieces per wave and phase");
       }
     }
     {
@@ -465,12 +506,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       if (C::nb(0) == C::nb(1) || grp == 0) waits(IntC<0>());
       else waits(IntC<1>());
       if constexpr (TX) {
+        // The pieces requested XD phases ago have landed: STAGE them (one ds_read each).  The arithmetic rides in the gaps
+        // of this wave's own MFMAs below and the result is written back when they are done -- before the barrier that ends
+        // the compute phase, which for group 1 must not be the slab's last (PpCfg::piece).
         if (!nonext) {
           constexpr int q = p - C::XD, k0 = C::na_before(q), kn = C::na(q);
-          const int cs = last ? cbeg : c + 1;
-          if constexpr (kn > 0) xf_piece(IntC<k0>(), apar ^ 1, cs);
-          if constexpr (kn > 1) xf_piece(IntC<k0 + 1>(), apar ^ 1, cs);
-          if constexpr (kn > 2) xf_piece(IntC<k0 + 2>(), apar ^ 1, cs);
+          if constexpr (q == 0 || C::na(q > 0 ? q - 1 : 0) == 0) xf_table(last ? cbeg : c + 1);   // the slab's first pieces: its table
+          auto stage = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < kn) {
+              xad[i] = xf_addr(IntC<k0 + i>(), apar ^ 1);
+              if (xf_real(k0 + i)) lds_read16u<0>(xd[i], xad[i]);
+            }
+          };
+          stage(IntC<0>()); stage(IntC<1>()); stage(IntC<2>()); stage(IntC<3>());
+          // The wait belongs HERE, in the block of the reads, naming their destinations: to hipcc an asm load's register
+          // is written when the statement ends, and with the wait further down it copied the staged registers across
+          // the join of this branch BEFORE the data had arrived (one tile in a few hundred came out untransformed).
+          // The fragment reads are waited for with them -- they are due at the barrier below anyway.
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]), "+v"(xd[3]), "+v"(xt[0]), "+v"(xt[1]), "+v"(xt[2]), "+v"(xt[3])::"memory");
         }
       }
     }
@@ -484,20 +539,77 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) pin16(fb[k][ct]);
     }
+    constexpr bool TXC = XF && C::xf_here(p);
+    u32x4 xo[4];
+    if constexpr (TXC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xd[i]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xt[i]));
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (!(UZ_PP_SKEL & 2)) {
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (!TXC) {
 #pragma unroll
-      for (int k = 0; k < UPP; ++k)
+        for (int k = 0; k < UPP; ++k)
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
+          for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[k][ct]);
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[k][pt]);
-            acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, (INIT && k == 0) ? cinit[ct] : acc[pt][ct], 0, 0, 0);
+            for (int ct = 0; ct < CT; ++ct) {
+              const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[k][ct]);
+              const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[k][pt]);
+              acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, (INIT && k == 0) ? cinit[ct] : acc[pt][ct], 0, 0, 0);
+            }
+      } else {
+        // The staged pieces' arithmetic, two vector instructions behind every MFMA (an MFMA holds the SIMD's vector issue
+        // for 8 of its 16 cycles: two per gap are nearly free, MI355X_MICROARCH.md) -- placed by hand, one micro-step
+        // (unpack | fma | round + relu of one dword = two channels) per gap with a scheduling barrier behind it: left to
+        // sched_group_barrier the scheduler put most of it behind the last MFMA.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        constexpr int q = p - C::XD, kn = C::na(q);
+        constexpr int NMF = UPP * PT * CT;
+        static_assert(3 * 4 * kn <= NMF, "one micro-step per MFMA gap");
+        float t0[16], t1[16];
+#pragma unroll
+        for (int g = 0; g < NMF; ++g) {
+          const int k = g / (PT * CT), pt = (g / CT) % PT, ct = g % CT;
+          const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[k][ct]);
+          const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[k][pt]);
+          acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, (INIT && k == 0) ? cinit[ct] : acc[pt][ct], 0, 0, 0);
+          if (g < 3 * 4 * kn) {
+            const int u = g / 3, st = g % 3, pc = u >> 2, i = u & 3;
+            if (st == 0) {
+              t0[u] = u2f(xd[pc][i] << 16);
+              t1[u] = u2f(xd[pc][i] & 0xffff0000u);
+            } else if (st == 1) {
+              t0[u] = fmaf(t0[u], u2f(xt[i >> 1][2 * (i & 1)]), u2f(xt[2 + (i >> 1)][2 * (i & 1)]));
+              t1[u] = fmaf(t1[u], u2f(xt[i >> 1][2 * (i & 1) + 1]), u2f(xt[2 + (i >> 1)][2 * (i & 1) + 1]));
+            } else {
+              const bf16x2 bb = __builtin_convertvector(f32x2{t0[u], t1[u]}, bf16x2);
+              xo[pc][i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, bb), s16x2{0, 0}));
+            }
           }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // (used HERE: otherwise the arithmetic sinks into the conditional block of the write-back, behind the MFMAs)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < kn) asm volatile("" : "+v"(xo[i]));
+      }
       __builtin_amdgcn_s_setprio(0);
+      if constexpr (TXC) {
+        constexpr int q = p - C::XD, k0 = C::na_before(q), kn = C::na(q);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!nonext) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < kn && xf_real(k0 + i) && avoff[k0 + i] != OOB) lds_write16u(xad[i], xo[i]);   // (per lane: zero padding stays)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
     } else if (INIT) {
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
@@ -690,6 +802,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
 }
 
 typedef PpCfg<16, 32, 8, 1, 3> Cfg512x64;
+typedef PpCfg<16, 32, 8, 1, 3, true> Cfg512x64X;   // the XF instantiation's deal of the halo pieces
 typedef PpCfg<8, 32, 4, 2, 3> Cfg256;
 typedef PpCfg<16, 16, 4, 2, 3> Cfg256w16;
 
@@ -767,7 +880,7 @@ int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p) {
 // input channels whose (scale, shift) table fits beside a configuration's LDS image (uz_conv_igemm_xf); 0: no XF form
 int uz_pp_xf_channels(const UzPpPlan& p) {
   switch (p.cfg) {
-    case UZ_PP_512X64: return Cfg512x64::XF_CH;
+    case UZ_PP_512X64: return Cfg512x64X::XF_CH;
     default: return 0;
   }
 }
@@ -820,7 +933,7 @@ int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const 
   }
   dim3 grid(p.grid_m, p.tiles_n), block(512);
   if (xf) {
-    hipLaunchKernelGGL((conv3x3_pp_kernel<Cfg512x64, false, false, true>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<Cfg512x64X, false, false, true>), grid, block, 0, s, a);
     UZ_LAUNCH_CHECK("uz_conv_igemm_xf(direct3x3 ping-pong)");
     return UZ_OK;
   }
