@@ -209,6 +209,10 @@ template <int OFF> __device__ __forceinline__ void lds_read16(f32x4& dst, unsign
 __device__ __forceinline__ void pin16(f32x4& v) { asm volatile("" : "+v"(v)); }
 template <int V> struct IntC { static constexpr int value = V; };
 
+#ifndef UZ_XF_SKEL
+#define UZ_XF_SKEL 0   // measurement builds of the XF form: 1 no arithmetic (the staged bytes go back as they are), 2 no staging
+                      // reads and no write-back either (the deal of the pieces and the table only)
+#endif
 #ifndef UZ_PP_SKEL
 #define UZ_PP_SKEL 0   // measurement builds: 1 no fragment reads, 2 no MFMAs, 4 no DMA after the prologue, 8 no epilogue,
                       // 16 fragment reads in a tile's first phase only, 128 both groups in lockstep (timing only)
@@ -217,8 +221,18 @@ template <int V> struct IntC { static constexpr int value = V; };
 // (a function, not __builtin_bit_cast(float, vec[i]) in place: with a vector element as its direct operand hipcc 7.2 reads
 // element 0 whatever the subscript -- found when every channel was scaled by its chunk's first scale)
 __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+// one v_fma_f32, opaque to the SLP vectoriser: left alone it pairs neighbouring fmas into v_pk_fma_f32, which beside MFMAs
+// costs more issue cycles than the two scalar instructions it replaces (MI355X_MICROARCH.md, "price of one filler")
+__device__ __forceinline__ float fma1(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 template <int OFF> __device__ __forceinline__ void lds_read16u(u32x4& dst, unsigned lds_addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void lds_write4u(unsigned lds_addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(lds_addr), "v"(v), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void lds_write16u(unsigned lds_addr, const u32x4& v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
@@ -351,7 +365,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
     constexpr int k = decltype(kc)::value;
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const int piece = C::piece(wave, k);
+    const int pc_ = C::piece(wave, k);
+    const int piece = pc_ < APIECES ? pc_ : 0;   // (a dummy: any address inside the patch, its bytes are never written back)
     const int r = piece * 16 + (ln >> 2);
     const int pj = r / PHP;
     return smem_u + (unsigned)(buf * A_BYTES + piece * 1024) + (unsigned)((ln >> 2) << 6) + (unsigned)(swz(ln & 3, pj) << 4);
@@ -467,6 +482,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       read_unit(IntC<0>()); read_unit(IntC<1>()); read_unit(IntC<2>());
     }
     const bool nonext = last && !has_next;
+    if constexpr (XF && C::xf_here(p)) {
+      // The pieces this wave requested XD phases ago are STAGED here (one ds_read each), between the fragment reads and
+      // this phase's requests, so that they return while those are issued; their arithmetic rides in the gaps of this
+      // wave's own MFMAs below.  They must have landed: nothing of this phase is in flight yet, so that is vmcnt(0) --
+      // which asks of the weight pieces of phase p + 1 only what the end of this read phase asks anyway (and of the
+      // previous tile's stores that they are done, one and a half phases after they were issued).
+      // NO branch around the reads (not even for a dummy piece or the last slab of the last tile, which stage bytes nobody
+      // writes back): to hipcc an asm load's register is written when the statement ends, and at the join of a branch it
+      // COPIED the staged registers before the data had arrived -- one tile in a few hundred came out untransformed.
+      constexpr int q = p - C::XD, k0 = C::na_before(q), kn = C::na(q);
+      wait_vmcnt<0>();
+      if constexpr (q == 0 || C::na(q > 0 ? q - 1 : 0) == 0) xf_table(nonext ? cbeg : (last ? cbeg : c + 1));   // the slab's first pieces: its table
+      auto stage = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < kn) {
+          const unsigned ad = xf_addr(IntC<k0 + i>(), apar ^ 1);
+          if (!(UZ_XF_SKEL & 2)) lds_read16u<0>(xd[i], ad);
+          // where the result goes: back in place -- or, for a lane whose row is zero padding (it keeps the zeros the
+          // LDS-DMA put there), a dummy piece, the slab after the last: into the 1 KB that swallows the dummy pieces.
+          // An address instead of a branch: the write-back sits in the MFMA stream, where an exec-masked block cost more
+          // than the arithmetic.
+          xad[i] = (!nonext && xf_real(k0 + i) && avoff[k0 + i] != OOB) ? ad : smem_u + (unsigned)OFF_SCR + (unsigned)(lane << 4);
+        }
+      };
+      stage(IntC<0>()); stage(IntC<1>()); stage(IntC<2>()); stage(IntC<3>());
+    }
     if (!(UZ_PP_SKEL & 4)) {
       // weight pieces of phase p + DPH
       constexpr int pn = (p + DPH) % NPH;
@@ -505,29 +546,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
       };
       if (C::nb(0) == C::nb(1) || grp == 0) waits(IntC<0>());
       else waits(IntC<1>());
-      if constexpr (TX) {
-        // The pieces requested XD phases ago have landed: STAGE them (one ds_read each).  The arithmetic rides in the gaps
-        // of this wave's own MFMAs below and the result is written back when they are done -- before the barrier that ends
-        // the compute phase, which for group 1 must not be the slab's last (PpCfg::piece).
-        if (!nonext) {
-          constexpr int q = p - C::XD, k0 = C::na_before(q), kn = C::na(q);
-          if constexpr (q == 0 || C::na(q > 0 ? q - 1 : 0) == 0) xf_table(last ? cbeg : c + 1);   // the slab's first pieces: its table
-          auto stage = [&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            if constexpr (i < kn) {
-              xad[i] = xf_addr(IntC<k0 + i>(), apar ^ 1);
-              if (xf_real(k0 + i)) lds_read16u<0>(xd[i], xad[i]);
-            }
-          };
-          stage(IntC<0>()); stage(IntC<1>()); stage(IntC<2>()); stage(IntC<3>());
-          // The wait belongs HERE, in the block of the reads, naming their destinations: to hipcc an asm load's register
-          // is written when the statement ends, and with the wait further down it copied the staged registers across
-          // the join of this branch BEFORE the data had arrived (one tile in a few hundred came out untransformed).
-          // The fragment reads are waited for with them -- they are due at the barrier below anyway.
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]), "+v"(xd[3]), "+v"(xt[0]), "+v"(xt[1]), "+v"(xt[2]), "+v"(xt[3])::"memory");
-        }
-      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -569,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         typedef short s16x2 __attribute__((ext_vector_type(2)));
-        constexpr int q = p - C::XD, kn = C::na(q);
+        constexpr int q = p - C::XD, k0 = C::na_before(q), kn = C::na(q);
         constexpr int NMF = UPP * PT * CT;
         static_assert(3 * 4 * kn <= NMF, "one micro-step per MFMA gap");
         float t0[16], t1[16];
@@ -579,37 +597,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
           const bf16x8 wv = *reinterpret_cast<const bf16x8*>(&fb[k][ct]);
           const bf16x8 xv = *reinterpret_cast<const bf16x8*>(&fa[k][pt]);
           acc[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xv, (INIT && k == 0) ? cinit[ct] : acc[pt][ct], 0, 0, 0);
-          if (g < 3 * 4 * kn) {
+          if ((UZ_XF_SKEL & 1) && g < kn) xo[g] = xd[g];
+          if (!(UZ_XF_SKEL & 3) && g < 3 * 4 * kn) {
             const int u = g / 3, st = g % 3, pc = u >> 2, i = u & 3;
             if (st == 0) {
               t0[u] = u2f(xd[pc][i] << 16);
               t1[u] = u2f(xd[pc][i] & 0xffff0000u);
             } else if (st == 1) {
-              t0[u] = fmaf(t0[u], u2f(xt[i >> 1][2 * (i & 1)]), u2f(xt[2 + (i >> 1)][2 * (i & 1)]));
-              t1[u] = fmaf(t1[u], u2f(xt[i >> 1][2 * (i & 1) + 1]), u2f(xt[2 + (i >> 1)][2 * (i & 1) + 1]));
+              t0[u] = fma1(t0[u], u2f(xt[i >> 1][2 * (i & 1)]), u2f(xt[2 + (i >> 1)][2 * (i & 1)]));
+              t1[u] = fma1(t1[u], u2f(xt[i >> 1][2 * (i & 1) + 1]), u2f(xt[2 + (i >> 1)][2 * (i & 1) + 1]));
             } else {
               const bf16x2 bb = __builtin_convertvector(f32x2{t0[u], t1[u]}, bf16x2);
               xo[pc][i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, bb), s16x2{0, 0}));
             }
           }
+          // a finished piece goes back at once (one 16-byte write: as four dword writes, bank-conflicted four ways, the launch
+          // took 115 us instead of 111), overlapping the MFMAs that remain
+          if (!(UZ_XF_SKEL & 2) && g >= 12 && g % 12 == 0 && g / 12 - 1 < kn) lds_write16u(xad[g / 12 - 1], xo[g / 12 - 1]);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // (used HERE: otherwise the arithmetic sinks into the conditional block of the write-back, behind the MFMAs)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i < kn) asm volatile("" : "+v"(xo[i]));
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if constexpr (TXC) {
-        constexpr int q = p - C::XD, k0 = C::na_before(q), kn = C::na(q);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!nonext) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (i < kn && xf_real(k0 + i) && avoff[k0 + i] != OOB) lds_write16u(xad[i], xo[i]);   // (per lane: zero padding stays)
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (12 * kn >= NMF) {
+          if (!(UZ_XF_SKEL & 2)) lds_write16u(xad[kn - 1], xo[kn - 1]);
         }
       }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (TXC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else if (INIT) {
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
