@@ -198,6 +198,15 @@ int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, v
 /* The kernel family the library's plan launches for this descriptor, written to buf (labels of per-kernel measurements;
  * e.g. "wgrad9_bf16_128x64_rowwalk": nine taps per workgroup, uz_wgrad9.hip).  Returns the length, <0 on error. */
 int uz_wgrad_kernel_name(const uz_wgrad_desc* d, char* buf, int cap);
+/* The weight gradient of a convolution whose input was read through the BatchNorm + ReLU in front of it (uz_conv_igemm_xf):
+ * R holds the RAW output of the preceding convolution; the kernel's loader waves form relu(R * r_scale[c] + r_shift[c]),
+ * rounded to the tensor dtype as uz_bn_relu_apply would store it, inside the LDS ring (zero padding stays zero), so the
+ * normalised activation of a DoubleConv's first half (common_layers.py:28-33) is not needed in the backward either.
+ * Nine-tap bf16 problems of the row-walk kernel (uz_wgrad_xf_supported() == 1); others: UZ_ENOTIMPL.  phase: 0 = uz_wgrad's
+ * two launches, 1 / 2 = as uz_wgrad_phase.  Workspace: uz_wgrad_workspace_bytes(). */
+int uz_wgrad_xf_supported(const uz_wgrad_desc* d);
+int uz_wgrad_xf(const uz_wgrad_desc* d, const void* L, const void* R, const float* r_scale, const float* r_shift,
+                float* out, void* workspace, void* stream, int phase);
 /* uz_wgrad in two calls, for per-kernel measurements (bench.py brackets each with its own event pair): phase 1 = the main
  * kernel (partial slabs into the workspace), phase 2 = the fixed-order slab reduction into `out`.  uz_wgrad == 1 then 2. */
 int uz_wgrad_phase(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream,

@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("UNET_ZOO_AMD_LIB") or os.path.join(os.path.dirname(os
 # every symbol include/unetzoo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "uz_abi_version", "uz_last_error_string", "uz_build_ablate", "uz_source_hash", "uz_set_cu_reserve", "uz_get_cu_reserve", "uz_clock_probe", "uz_conv_igemm_grid_m", "uz_conv_igemm",
-    "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_wgrad_kernel_name", "uz_wgrad_phase", "uz_conv3x3_first_supported", "uz_conv3x3_first_rows", "uz_conv3x3_first_fwd",
+    "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_wgrad_kernel_name", "uz_wgrad_phase", "uz_wgrad_xf_supported", "uz_wgrad_xf", "uz_conv3x3_first_supported", "uz_conv3x3_first_rows", "uz_conv3x3_first_fwd",
     "uz_conv3x3_first_wgrad_workspace_bytes", "uz_conv3x3_first_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
     "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_outconv_bwd_rows", "uz_outconv_bwd_bnred",
@@ -191,6 +191,8 @@ def load():
     lib.uz_wgrad.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp]
     lib.uz_wgrad_kernel_name.argtypes = [POINTER(WgradDesc), c_char_p, c_int]
     lib.uz_wgrad_phase.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp, c_int]
+    lib.uz_wgrad_xf_supported.argtypes = [POINTER(WgradDesc)]
+    lib.uz_wgrad_xf.argtypes = [POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp, c_int]
     lib.uz_conv3x3_first_supported.argtypes = [ip, ip, ip]
     lib.uz_conv3x3_first_rows.argtypes = [ip, ip, ip]
     lib.uz_conv3x3_first_fwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, ip, vp, vp]

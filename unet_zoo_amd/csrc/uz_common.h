@@ -152,7 +152,8 @@ struct UzWgrad2Plan {
 };
 // row-walk nine-tap weight gradient (uz_wgrad9.hip); uz_wgrad3x3_plan() tries it first
 int uz_wgrad9_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
-int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, hipStream_t s);
+int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, hipStream_t s,
+                     const UzXf* xf = nullptr);   // xf: R is read through a BatchNorm + ReLU (uz_wgrad_xf)
 const char* uz_wgrad9_name(const UzWgrad2Plan& p);
 // 2 x 2 gather (ConvTranspose2d k2 s2 / PatchExpand) weight gradient, four taps per workgroup (uz_wgrad_g4.hip): v9 = 2
 int uz_wgrad_g4_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p);
@@ -161,7 +162,8 @@ int uz_wgrad3x3_plan(const uz_wgrad_desc* d, UzWgrad2Plan* p, int batch = 1);   
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
                        float* slab, hipStream_t s, int batch = 1, long long lb_bytes = 0, long long rb_bytes = 0,
                        long long slab_stride = 0,   // floats between the problems' slabs (0: dense)
-                       int batch2 = 1, long long lb2_bytes = 0, long long rb2_bytes = 0);   // batch = ALL problems (outer * inner)
+                       int batch2 = 1, long long lb2_bytes = 0, long long rb2_bytes = 0,   // batch = ALL problems (outer * inner)
+                       const UzXf* xf = nullptr);   // row-walk plans only (uz_wgrad_xf)
 
 // several one-tap problems in one launch (uz_wgrad_multi): plans from uz_wgrad3x3_plan() with one_tap && !gather && !v9, all
 // of one tile shape (big); at most uz_wgrad3x3_multi_max() per launch

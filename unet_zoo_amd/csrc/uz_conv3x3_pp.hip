@@ -613,11 +613,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const PpArgs a) {
           }
           // a finished piece goes back at once (one 16-byte write: as four dword writes, bank-conflicted four ways, the launch
           // took 115 us instead of 111), overlapping the MFMAs that remain
-          if (!(UZ_XF_SKEL & 2) && g >= 12 && g % 12 == 0 && g / 12 - 1 < kn) lds_write16u(xad[g / 12 - 1], xo[g / 12 - 1]);
+          if (!(UZ_XF_SKEL & 2) && !(UZ_XF_SKEL & 4) && g >= 12 && g % 12 == 0 && g / 12 - 1 < kn) lds_write16u(xad[g / 12 - 1], xo[g / 12 - 1]);
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (12 * kn >= NMF) {
-          if (!(UZ_XF_SKEL & 2)) lds_write16u(xad[kn - 1], xo[kn - 1]);
+          if (!(UZ_XF_SKEL & 2) && !(UZ_XF_SKEL & 4)) lds_write16u(xad[kn - 1], xo[kn - 1]);
+        }
+        if (UZ_XF_SKEL & 4) {   // (measurement: every write-back behind the last MFMA)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < kn) lds_write16u(xad[i], xo[i]);
         }
       }
       __builtin_amdgcn_s_setprio(0);

@@ -423,7 +423,7 @@ extern "C" long long uz_wgrad_workspace_bytes(const uz_wgrad_desc* d) {
 
 // phase 0: both launches; 1: the main kernel (partial slabs into the workspace); 2: the fixed-order slab reduction
 static int wgrad_phases(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream,
-                        int phase) {
+                        int phase, const UzXf* xf = nullptr) {
   Plan p;
   const int rc = make_plan(d, &p);
   if (rc != UZ_OK) return rc;
@@ -455,7 +455,8 @@ static int wgrad_phases(const uz_wgrad_desc* d, const void* L, const void* R, fl
   const bool lds_dma = uz_wgrad3x3_plan(d, &p2) != 0;
   if (lds_dma) nslabs = p2.nslabs;
   if (phase != 2) {
-    if (lds_dma) rc2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s);
+    UZ_REQUIRE(xf == nullptr || (lds_dma && p2.v9 == 1 && p2.bi == 64), "uz_wgrad_xf: not a problem of the row-walk kernel (ask uz_wgrad_xf_supported)");
+    if (lds_dma) rc2 = uz_wgrad3x3_launch(d, p2, L, R, static_cast<float*>(workspace), s, 1, 0, 0, 0, 1, 0, 0, xf);
     else rc2 = d->dtype == UZ_BF16 ? launch<bf16_t>(p, a, s) : launch<float>(p, a, s);
     if (rc2 != UZ_OK) return rc2;
   }
@@ -482,6 +483,25 @@ static int wgrad_phases(const uz_wgrad_desc* d, const void* L, const void* R, fl
 
 extern "C" int uz_wgrad(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace, void* stream) {
   return wgrad_phases(d, L, R, out, workspace, stream, 0);
+}
+
+// ---- weight gradient whose R operand is read through the BatchNorm + ReLU in front of the layer (include/unetzoo_hip.h) ---
+extern "C" int uz_wgrad_xf_supported(const uz_wgrad_desc* d) {
+  UzWgrad2Plan p2;
+  if (d == nullptr || d->dtype != UZ_BF16 || d->ntaps != 9) return 0;
+  return (uz_wgrad3x3_plan(d, &p2) && p2.v9 == 1 && p2.bi == 64) ? 1 : 0;
+}
+
+extern "C" int uz_wgrad_xf(const uz_wgrad_desc* d, const void* L, const void* R, const float* r_scale, const float* r_shift,
+                           float* out, void* workspace, void* stream, int phase) {
+  UZ_REQUIRE(r_scale && r_shift, "uz_wgrad_xf: null pointer");
+  UZ_REQUIRE(phase >= 0 && phase <= 2, "uz_wgrad_xf: phase %d (0: both launches, 1: main kernel, 2: slab reduction)", phase);
+  if (!uz_wgrad_xf_supported(d)) {
+    uz_set_error("uz_wgrad_xf: only nine-tap bf16 problems of the row-walk kernel (ask uz_wgrad_xf_supported)");
+    return UZ_ENOTIMPL;
+  }
+  const UzXf xf = {r_scale, r_shift};
+  return wgrad_phases(d, L, R, out, workspace, stream, phase, &xf);
 }
 
 extern "C" int uz_wgrad_phase(const uz_wgrad_desc* d, const void* L, const void* R, float* out, void* workspace,

@@ -626,11 +626,13 @@ int uz_wgrad3x3_multi_launch(const UzWgradMultiItem* items, int n, hipStream_t s
 
 int uz_wgrad3x3_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R,
                        float* slab, hipStream_t s, int batch, long long lb_bytes, long long rb_bytes, long long slab_stride,
-                       int batch2, long long lb2_bytes, long long rb2_bytes) {
+                       int batch2, long long lb2_bytes, long long rb2_bytes, const UzXf* xf) {
   if (p.v9) {
     UZ_REQUIRE(batch == 1, "uz_wgrad(3x3): the row-walk / four-tap kernels take one problem");
-    return p.v9 == 2 ? uz_wgrad_g4_launch(d, p, L, R, slab, s) : uz_wgrad9_launch(d, p, L, R, slab, s);
+    UZ_REQUIRE(xf == nullptr || p.v9 == 1, "uz_wgrad_xf: the row-walk kernel only");
+    return p.v9 == 2 ? uz_wgrad_g4_launch(d, p, L, R, slab, s) : uz_wgrad9_launch(d, p, L, R, slab, s, xf);
   }
+  UZ_REQUIRE(xf == nullptr, "uz_wgrad_xf: the row-walk kernel only");
   Wg2Args a;
   wg2_fill(d, p, L, R, slab, &a);
   a.lb = lb_bytes;

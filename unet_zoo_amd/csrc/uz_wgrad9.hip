@@ -46,6 +46,11 @@ struct Wg9Args {
   int units, upb;        // steps in the whole tensor, steps per pixel split
   int tiles_j, ntiles, split;
   int flags;
+  // XF (template parameter): R holds the RAW output of the convolution in front of this layer; the loader waves turn every
+  // x row into relu(fma(R, xf_scale[c], xf_shift[c])) (rounded to bf16 as uz_bn_relu_apply stores it) inside the LDS ring
+  // before they publish it -- the weight gradient of a DoubleConv's second convolution without the normalised tensor
+  const float* xf_scale;
+  const float* xf_shift;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -71,6 +76,14 @@ __device__ __forceinline__ void tr_pair(bf16x4& lo, bf16x4& hi, unsigned lds_add
                : "v"(lds_addr), "i"(OFF0), "i"(OFF0 + OFF));
 }
 __device__ __forceinline__ void pin(bf16x4& v) { asm volatile("" : "+v"(v)); }
+// (a function: with a vector element as the direct operand of __builtin_bit_cast hipcc 7.2 reads element 0, uz_conv3x3_pp.hip)
+__device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ void lds_rd16(u32x4& dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr));
+}
+__device__ __forceinline__ void lds_wr16(unsigned lds_addr, const u32x4& v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr), "v"(v) : "memory");
+}
 
 template <int BI, int KW, int NW_ = 4, int KG_ = 1> struct W9 {
   static_assert((BI == 128 || BI == 64) && (KW == 64 || KW == 32 || KW == 16), "tile configuration");
@@ -118,10 +131,11 @@ template <int BI, int KW, int NW_ = 4, int KG_ = 1> struct W9 {
 // ring: bookkeeping, LDS-DMA requests, the vmcnt wait that publishes a step; the compute waves' instruction stream is then
 // fragment reads, permutes and MFMAs only (~3.7 instructions per MFMA gap, which one wave per SIMD hides, cf.
 // MI355X_MICROARCH.md "one wave per SIMD ... <= 5 ... hidden per gap").  Both kinds meet at the one s_barrier per step.
-template <int BI, int KW, int MODE, int NWV = 4, int KGV = 1, int LD = 0>
+template <int BI, int KW, int MODE, int NWV = 4, int KGV = 1, int LD = 0, bool XF = false>
 __global__ __launch_bounds__(64 * (NWV + 4 * LD), 1) void wgrad9_kernel(const Wg9Args a) {
   typedef W9<BI, KW, NWV, KGV> C;
   static_assert(LD == 0 || (NWV == 4 && KGV == 1), "loader waves go with four compute waves");
+  static_assert(!XF || LD == 1, "the input transform is the loader waves' work");
   constexpr int KG = C::KG, NU = C::NU;
   constexpr int NW = C::NW, TI = C::TI, G = C::G, RBL = C::RBL, CPRL = C::CPRL, RPPL = C::RPPL, NLP = C::NLP;
   constexpr int RPIECES = C::RPIECES, QR = C::QR, ROWB = C::ROWB, LSTAGE = C::LSTAGE, NSL = C::NSL, NSR = C::NSR;
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(64 * (NWV + 4 * LD), 1) void wgrad9_kernel(const Wg
   // out-of-range base they wrap and fetch bytes that only reach accumulator rows / columns nobody stores.
   unsigned ltab[KL];          // dy piece wave + 4 k
   unsigned xtab[MR], xtabe[MR];   // x piece q = wave + 4 m of a row; xtabe: its halo lane out of range (strip at the image edge)
+  int xflag[MR];                  // XF: bit 0 this lane's bytes exist at all (channel tail, slot padding), bit 1 a halo column
 #pragma unroll
   for (int k = 0; k < KL; ++k) {
     const int i = wave + NW * k;
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(64 * (NWV + 4 * LD), 1) void wgrad9_kernel(const Wg
     const bool ok = tj0 + lchunk * 8 < a.Cj && t <= KW + 1;
     xtab[m] = ok ? (unsigned)(scol * a.ldr * 2 + tj0 * 2 + lchunk * 16) : ROW_OOB;
     xtabe[m] = (ok && (t == 0 || t == KW + 1)) ? LANE_OOB : xtab[m];
+    xflag[m] = (ok ? 1 : 0) | ((t == 0 || t == KW + 1) ? 2 : 0);
   }
 
   // ---- the issue stream: position of the next step to request ---------------------------------------------------------
@@ -267,13 +283,90 @@ __global__ __launch_bounds__(64 * (NWV + 4 * LD), 1) void wgrad9_kernel(const Wg
 
   if (LD != 0 && loader) {
     // ---- a loader wave: request NSL - 1 steps ahead, publish a step when it has landed, one barrier per step ------------
+    // XF: between "landed" and "published" the wave turns the NEW x rows of that step, piece by piece as it requested them
+    // (its own vmcnt wait orders the LDS-DMA in front of its own reads), into relu(fma(x, scale, shift)) in place.  A
+    // lane's 16 bytes are one 8-channel chunk of one pixel, and which chunk depends on the lane alone (the swizzle key of
+    // slot pixel 8 q + (lane >> 3) is bit 4 of the lane): its 8 + 8 table values are kernel constants in registers.
+    // Lanes whose request was out of range (zero padding above / below / beside the image, channel tails) keep their zeros.
+    float xsc[8], xsh[8];
+    int x_strip = c_strip, x_hb = c_hb, x_t = 0, x_vb = 0;   // the transform stream: the same walk as the requests
+    if constexpr (XF) {
+      const int sw = (lane >> 4) & 1, pc = lane & 7;
+      const int lchunk = (((pc >> 2) ^ sw) << 2) + (pc & 3);
+      const int ch = tj0 + lchunk * 8 < a.Cj ? tj0 + lchunk * 8 : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xsc[e] = a.xf_scale[ch + e];
+        xsh[e] = a.xf_shift[ch + e];
+      }
+      // (used here: the wait for these loads then sits in front of the first LDS-DMA request, not among them)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(xsc[e]), "v"(xsh[e]));
+    }
+    auto xf_step = [&]() __attribute__((always_inline)) {
+      if constexpr (XF) {
+        const bool valid = x_t < nu;
+        const bool start = x_hb == 0 || x_t == 0;
+        const int h = x_hb * G, w0 = x_strip * KW;
+        const bool at_l = w0 == 0, at_r = w0 + KW == a.W;
+        // rows J = 2 .. G + 1 (and 0, 1 at a segment start), pieces m of this wave: at most (G + 2) MR
+#pragma unroll
+        for (int jj = 0; jj < G + 2; ++jj) {
+          const int J = jj < G ? jj + 2 : jj - G;   // the G new rows, then the two more of a segment start
+          if (jj >= G && !start) continue;
+          const bool rv = valid && (unsigned)(h - 1 + J) < (unsigned)a.H;
+          int slot = x_vb + J;
+          if (slot >= NSR) slot -= NSR;
+          const unsigned base = smem_u + (unsigned)(R_OFF + slot * ROWB + wave * 1024) + (unsigned)(lane << 4);
+          u32x4 v[MR];
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+            if (NW * m + NW <= RPIECES || wave + NW * m < RPIECES) lds_rd16(v[m], base + m * (NW * 1024));
+          if constexpr (MR == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0])::"memory");
+          else if constexpr (MR == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
+          static_assert(MR <= 3, "x pieces per wave and row");
+#pragma unroll
+          for (int m = 0; m < MR; ++m) {
+            const int q = wave + NW * m;
+            if (NW * m + NW <= RPIECES || q < RPIECES) {
+              const bool edge = (q == 0 && at_l) || (q == QR && at_r);
+              // (not a comparison of the offsets: the left halo column of an inner strip is a NEGATIVE offset from the strip's
+              // first pixel, a huge unsigned that is perfectly in range once the row base is added)
+              const bool ok = rv && (xflag[m] & 1) && !(edge && (xflag[m] & 2));
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+              typedef short s16x2 __attribute__((ext_vector_type(2)));
+              u32x4 o;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float x0 = u2f(v[m][i] << 16), x1 = u2f(v[m][i] & 0xffff0000u);
+                const bf16x2 b = __builtin_convertvector(f32x2{fmaf(x0, xsc[2 * i], xsh[2 * i]), fmaf(x1, xsc[2 * i + 1], xsh[2 * i + 1])}, bf16x2);
+                o[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b), s16x2{0, 0}));
+              }
+              if (ok) lds_wr16(base + m * (NW * 1024), o);
+            }
+          }
+        }
+        if (++x_hb == a.hsteps) {
+          x_hb = 0;
+          if (++x_strip == a.nstrips) x_strip = 0;
+        }
+        x_vb += G + (x_hb == 0 ? 2 : 0);
+        if (x_vb >= NSR) x_vb -= NSR;
+        ++x_t;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    };
 #pragma unroll
     for (int b = 0; b < NSL - 1; ++b) issue_batch();
     wait_vmcnt<(NSL - 2) * PMIN>();
+    xf_step();                          // step 0
     __builtin_amdgcn_s_barrier();
 #pragma unroll 1
     for (int s = 0; s < nu; ++s) {
       wait_vmcnt<(NSL - 3) * PMIN>();   // step s + 1 has landed
+      xf_step();                        // ... and is what the convolution in front of this layer fed its successor
       __builtin_amdgcn_s_barrier();     // ... for every wave; step s - 1 is read by nobody any more
       issue_batch();                    // step s + NSL - 1 into its slots
     }
@@ -563,8 +656,13 @@ const char* uz_wgrad9_name(const UzWgrad2Plan& p) {
   return p.bi == 128 ? "wgrad9_bf16_128x64_rowwalk" : "wgrad9_bf16_64x64_rowwalk";
 }
 
-int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, hipStream_t s) {
+int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* L, const void* R, float* slab, hipStream_t s,
+                     const UzXf* xf) {
   Wg9Args a;
+  a.xf_scale = xf ? xf->scale : nullptr;
+  a.xf_shift = xf ? xf->shift : nullptr;
+  if (xf) UZ_REQUIRE(p.bi == 64 && xf->scale && xf->shift && !(uz_tune_flags() & 0x22000000),
+                     "uz_wgrad_xf: the input transform is the loader-wave form's (64 x 64 tiles)");
   a.L = L;
   a.R = R;
   a.slab = slab;
@@ -596,7 +694,9 @@ int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* 
 #define UZ_W9_LAUNCH1(BI_, KW_, NW_) UZ_W9_LAUNCH2(BI_, KW_, NW_, 1)
 #define UZ_W9_LAUNCHL(BI_, KW_)                                                                            \
   do {                                                                                                     \
-    if (up) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 1, 4, 1, 1>), grid, dim3(512), 0, s, a);           \
+    if (xf && up) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 1, 4, 1, 1, true>), grid, dim3(512), 0, s, a);     \
+    else if (xf) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 0, 4, 1, 1, true>), grid, dim3(512), 0, s, a);      \
+    else if (up) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 1, 4, 1, 1>), grid, dim3(512), 0, s, a);      \
     else hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 0, 4, 1, 1>), grid, dim3(512), 0, s, a);              \
   } while (0)
   const bool w4 = (a.flags & 0x20000000) != 0;   // ablation build: the 128-wide tile on four waves of 64 x 32

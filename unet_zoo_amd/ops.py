@@ -376,9 +376,17 @@ def wgrad_kernel_name(d) -> str:
     return buf.value.decode()
 
 
+def wgrad_xform_supported(Lt: Act, Rt: Act, ntaps: int, *, taps_mode: int = L.TAPS_CONV, dil: int = 1) -> bool:
+    """whether uz_wgrad_xf takes this weight-gradient problem (R read through a BatchNorm + ReLU)"""
+    d = L.WgradDesc(L.dtype_code(Lt.dtype), Lt.N, Lt.H, Lt.W, Rt.H, Rt.W, Lt.C, Lt.ld, Rt.C, Rt.ld, ntaps, taps_mode, dil)
+    return bool(L.load().uz_wgrad_xf_supported(byref(d)))
+
+
 def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
-          taps_mode: int = L.TAPS_CONV, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[i, j, tap] = sum_p L[p, i] * R[pix(p, tap), j]  (fp32, reference parameter layout)."""
+          taps_mode: int = L.TAPS_CONV, out: Optional[torch.Tensor] = None, xform: Optional[tuple] = None) -> torch.Tensor:
+    """out[i, j, tap] = sum_p L[p, i] * R[pix(p, tap), j]  (fp32, reference parameter layout).
+    xform = (scale, shift): R is the RAW output of the convolution in front of this layer and is read through that
+    layer's BatchNorm + ReLU (uz_wgrad_xf; ask wgrad_xform_supported first)."""
     L.require_cuda(Lt.buf, Rt.buf)
     lib = L.load()
     d = L.WgradDesc(L.dtype_code(Lt.dtype), Lt.N, Lt.H, Lt.W, Rt.H, Rt.W, Lt.C, Lt.ld, Rt.C, Rt.ld,
@@ -388,6 +396,19 @@ def wgrad(Lt: Act, Rt: Act, out_shape, *, ntaps: int, dil: int = 1,
     if out is None:
         out = torch.empty(out_shape, dtype=torch.float32, device=Lt.buf.device)
     assert out.numel() == Lt.C * Rt.C * ntaps and out.is_contiguous() and out.dtype == torch.float32
+    if xform is not None:
+        def run(phase):
+            L.check(lib.uz_wgrad_xf(byref(d), Lt.ptr(), Rt.ptr(), xform[0].data_ptr(), xform[1].data_ptr(), out.data_ptr(),
+                                    ws.data_ptr(), L.stream_ptr(), phase), "uz_wgrad_xf")
+        if not _prof_on:
+            run(0)
+            return out
+        with _Timed(wgrad_kernel_name(d) + "_xf", 2.0 * Lt.P * Lt.C * Rt.C * ntaps,
+                    Lt.buf.element_size() * (Lt.P * Lt.C + Rt.P * Rt.C) + 4.0 * out.numel()):
+            run(1)
+        with _Timed("wgrad_reduce", 0.0, float(ws_bytes) + 4.0 * out.numel()):
+            run(2)
+        return out
     if not _prof_on:
         L.check(lib.uz_wgrad(byref(d), Lt.ptr(), Rt.ptr(), out.data_ptr(), ws.data_ptr(), L.stream_ptr()), "uz_wgrad")
         return out
