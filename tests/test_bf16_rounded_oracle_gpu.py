@@ -139,6 +139,8 @@ def test_bf16_unet_on_the_kernels_the_benchmark_times():
     finally:
         fams = set(ops.profile_end())
     print(sorted(fams))
+    # (the 64 -> 64 convolution reads its input through the BatchNorm + ReLU in front of it since round 5: "_xf")
+    assert "conv3x3_pp512x64_bf16_xf" in fams and "wgrad9_bf16_64x64_rowwalk_xf" in fams, fams
     assert "conv3x3_pp512x64_bf16" in fams, fams
     assert "conv3x3_pp512_bf16" in fams or "conv3x3_pp256_bf16" in fams, fams
     assert "wgrad9_bf16_64x64_rowwalk" in fams, fams

@@ -10,7 +10,8 @@ import torch
 import unet_zoo_amd
 from unet_zoo_amd.engine import Engine
 
-VARIANTS = [("fused conv + convT", dict(fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+VARIANTS = [("fold BN apply (xf)", dict(fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+            ("fused conv + convT", dict(fold_bn_apply=False, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
             ("fused conv only", dict(fuse_bn_reduce=True, fuse_bn_reduce_convt=False)),
             ("two-pass everywhere", dict(fuse_bn_reduce=False, fuse_bn_reduce_convt=False))]
 

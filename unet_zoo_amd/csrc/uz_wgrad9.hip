@@ -27,6 +27,9 @@
 // The in-kernel measurement switches (no DMA / no MFMAs / no slab / no fragment reads: profiles/r04_wgrad9_skeleton.txt)
 // exist only with -DUZ_W9_SKEL: each costs a scalar branch per unit of the main loop, which the plain ablation build
 // (make ABLATE=1, used for same-box A/B of the PLANS) must not carry either.
+#ifndef UZ_W9X_SKEL
+#define UZ_W9X_SKEL 0   // measurement builds of the XF form: 1 no arithmetic, 2 no LDS reads / writes either (the walk only)
+#endif
 #ifdef UZ_W9_SKEL
 #define UZ_W9_FLAGS(a) ((a).flags)
 #else
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(64 * (NWV + 4 * LD), 1) void wgrad9_kernel(const Wg
           u32x4 v[MR];
 #pragma unroll
           for (int m = 0; m < MR; ++m)
-            if (NW * m + NW <= RPIECES || wave + NW * m < RPIECES) lds_rd16(v[m], base + m * (NW * 1024));
+            if (!(UZ_W9X_SKEL & 2) && (NW * m + NW <= RPIECES || wave + NW * m < RPIECES)) lds_rd16(v[m], base + m * (NW * 1024));
           if constexpr (MR == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0])::"memory");
           else if constexpr (MR == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
           else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
@@ -337,14 +340,14 @@ __global__ __launch_bounds__(64 * (NWV + 4 * LD), 1) void wgrad9_kernel(const Wg
               typedef float f32x2 __attribute__((ext_vector_type(2)));
               typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
               typedef short s16x2 __attribute__((ext_vector_type(2)));
-              u32x4 o;
+              u32x4 o = v[m];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
+              for (int i = 0; i < 4 && !(UZ_W9X_SKEL & 3); ++i) {
                 const float x0 = u2f(v[m][i] << 16), x1 = u2f(v[m][i] & 0xffff0000u);
                 const bf16x2 b = __builtin_convertvector(f32x2{fmaf(x0, xsc[2 * i], xsh[2 * i]), fmaf(x1, xsc[2 * i + 1], xsh[2 * i + 1])}, bf16x2);
                 o[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, b), s16x2{0, 0}));
               }
-              if (ok) lds_wr16(base + m * (NW * 1024), o);
+              if (ok && !(UZ_W9X_SKEL & 2)) lds_wr16(base + m * (NW * 1024), o);
             }
           }
         }

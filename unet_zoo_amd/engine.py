@@ -171,6 +171,10 @@ class Engine:
     # tools/ab_step.py can time both ways in one process; no environment switch)
     fuse_bn_reduce = True
     fuse_bn_reduce_convt = True
+    # the BatchNorm + ReLU between the two convolutions of a DoubleConv is not a pass of its own: the second convolution and
+    # its weight gradient read the first one's raw output through it (uz_conv_igemm_xf / uz_wgrad_xf), where both kernels
+    # take the shape; the normalised middle tensor then never exists (class-level: tools/ab_step.py times both ways)
+    fold_bn_apply = True
 
     def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
                  grad_sink: Optional[Callable[[nn.Parameter, torch.Tensor], None]] = None,
@@ -334,7 +338,8 @@ class Engine:
     def conv_bn_relu(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, *, out: Optional[Act] = None,
                      pool: bool = False, im2col: bool = False, upsample: bool = False,
                      residual: Optional[Act] = None, pool_ceil: bool = False, relu: bool = True,
-                     stat_repeat: int = 1, sole_reader: bool = False) -> Tuple[Act, Optional[Act]]:
+                     stat_repeat: int = 1, sole_reader: bool = False,
+                     defer_apply: Optional[nn.Conv2d] = None) -> Tuple[Act, Optional[Act]]:
         """[nearest x2 upsample ->] Conv3x3(+bias) -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)].
 
         Reference: DoubleConv / ConvBlock / REBNCONV halves (common_layers.py:28-33, 47-56;
@@ -348,12 +353,19 @@ class Engine:
         sample count of the running variance's unbiased factor is k times larger.  sole_reader: the caller states
         that nothing but this convolution reads x (the middle tensor of a DoubleConv): if x is itself the output of a
         Conv -> BN -> ReLU, the first pass of ITS BatchNorm backward then rides in the epilogue of this layer's
-        input-gradient convolution (uz_conv_igemm_bnred) instead of re-reading the gradient.  Returns (act, pooled)."""
+        input-gradient convolution (uz_conv_igemm_bnred) instead of re-reading the gradient.  defer_apply = the 3x3
+        convolution that is the ONLY reader of this layer's output (DoubleConv's second): if that convolution and its
+        weight gradient can read the raw output through BatchNorm + ReLU (Engine.fold_bn_apply), the apply pass is not run
+        and the returned activation is LAZY (Act.lazy = (scale, shift) over the raw buffer); the caller hands it to
+        conv_bn_relu(..., sole_reader=True) and to nothing else.  Returns (act, pooled)."""
         N, H, W = x.N, x.H, x.W
         if upsample:
             H, W = 2 * H, 2 * W
         tmode = L.TAPS_CONV_UP2 if upsample else L.TAPS_CONV
         Cout = conv.out_channels
+        xf = getattr(x, "lazy", None)      # x is the raw output of a convolution, to be read through its BatchNorm + ReLU
+        assert xf is None or (sole_reader and not im2col and conv.kernel_size == (3, 3) and conv.dilation == (1, 1)), \
+            "a lazy activation goes to the 3x3 convolution it was deferred for"
         dil = conv.dilation[0]
         image = None       # the fp32 NCHW input when the direct first-convolution kernels take this layer
         if im2col and isinstance(x, ImageInput):
@@ -378,7 +390,7 @@ class Engine:
             stats = ops.conv_first_fwd(image, conv.weight.detach(), bias, y, self.training)
         else:
             stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, taps_mode=tmode,
-                                   want_stats=self.training)
+                                   want_stats=self.training, xform=xf)
         if self.training:
             mom = bn.momentum if bn.momentum is not None else 0.1
             vec = ops.bn_finalize(stats if stat_repeat == 1 else stats * float(stat_repeat), y.P * stat_repeat,
@@ -387,13 +399,26 @@ class Engine:
                 self._bn_counters.append(bn.num_batches_tracked)   # bumped together in finish_forward()
         else:
             vec = self._bn_vectors(bn, None, y.P)      # running statistics: (scale, shift, mean, invstd)
-        act = out if out is not None else self.new_act(N, H, W, Cout)
-        if pool and pool_ceil:
-            pooled = self.new_act(N, (H + 1) // 2, (W + 1) // 2, Cout)
+        lazy = False
+        if (defer_apply is not None and self.fold_bn_apply and out is None and not pool and residual is None and relu
+                and stat_repeat == 1 and self.dtype == torch.bfloat16 and defer_apply.kernel_size == (3, 3)
+                and defer_apply.dilation == (1, 1) and defer_apply.stride == (1, 1) and defer_apply.in_channels == Cout):
+            # both kernels of the reader must take the map (the weight gradient's L operand has the reader's channels)
+            c2 = defer_apply.out_channels
+            lazy = (ops.conv_xform_supported(y, c2, c2)
+                    and ops.wgrad_xform_shapes_supported(N, H, W, c2, c2, Cout, y.ld, self.dtype))
+        if lazy:
+            act = ops.Act(y.buf, y.off, y.C, N, H, W, True)
+            act.lazy = (vec[0], vec[1])
+            pooled = None
         else:
-            pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
-        assert relu or residual is None
-        ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu)
+            act = out if out is not None else self.new_act(N, H, W, Cout)
+            if pool and pool_ceil:
+                pooled = self.new_act(N, (H + 1) // 2, (W + 1) // 2, Cout)
+            else:
+                pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
+            assert relu or residual is None
+            ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu)
         if self.record and self.training and relu and pooled is None and residual is None and stat_repeat == 1:
             act.bn_src = (y, vec)      # what a sole reader's input-gradient kernel needs (see sole_reader)
 
@@ -449,7 +474,7 @@ class Engine:
                     else:
                         self._give_grad(conv.weight, ops.wgrad(dy, x, tuple(conv.weight.shape), ntaps=ntaps,
                                                                dil=dil, taps_mode=tmode,
-                                                               out=self._dst(conv.weight)))
+                                                               out=self._dst(conv.weight), xform=xf))
                     if x.needs_grad and upsample:
                         # gradient of the (virtual) upsampled tensor, then 2x2 sums
                         du = self.new_act(N, H, W, x.C)

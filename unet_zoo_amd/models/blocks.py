@@ -32,7 +32,8 @@ class DoubleConv(nn.Module):
     def emit(self, eng: Engine, x: Act, *, out: Optional[Act] = None, pool: bool = False,
              im2col: bool = False) -> Tuple[Act, Optional[Act]]:
         s = self.conv_op
-        mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col)
+        # the middle tensor has one reader: where the kernels can, it is never written down (Engine.fold_bn_apply)
+        mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col, defer_apply=s[3])
         return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True)
 
 

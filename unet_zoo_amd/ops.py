@@ -19,7 +19,7 @@ class Act:
     """NHWC activation: element (pixel p, channel c) at ``buf[p, off + c]``; ``buf`` is (P, ld)."""
 
     __slots__ = ("buf", "off", "C", "N", "H", "W", "grads", "parts", "rparts", "needs_grad", "colsums", "bn_src",
-                 "bn_partials")
+                 "bn_partials", "lazy")
 
     def __init__(self, buf: torch.Tensor, off: int, C: int, N: int, H: int, W: int,
                  needs_grad: bool = True):
@@ -33,6 +33,10 @@ class Act:
         # optional (partials [G, 2, Ctot], channel offset): per-channel sums of this tensor that its
         # producing kernel delivered for free (used for ConvTranspose2d bias gradients)
         self.colsums = None
+        # (scale, shift): the buffer holds the RAW output of a convolution and stands for relu(buf * scale + shift), which
+        # nobody has written down (Engine.conv_bn_relu(defer_apply=True)); only the kernels that read through that map
+        # (conv_igemm / wgrad with xform=...) may take it
+        self.lazy = None
 
     @property
     def ld(self) -> int:
@@ -88,6 +92,8 @@ class Act:
     def dense(self) -> torch.Tensor:
         """(N, C, H, W) fp32 copy — test/debug helper, not used on the hot path."""
         v = self.buf[:, self.off:self.off + self.C].float()
+        if self.lazy is not None:   # the tensor this view stands for, as uz_bn_relu_apply would have stored it
+            v = torch.relu(torch.addcmul(self.lazy[1], v, self.lazy[0])).to(self.buf.dtype).float()
         return v.reshape(self.N, self.H, self.W, self.C).permute(0, 3, 1, 2).contiguous()
 
 
@@ -379,6 +385,12 @@ def wgrad_kernel_name(d) -> str:
 def wgrad_xform_supported(Lt: Act, Rt: Act, ntaps: int, *, taps_mode: int = L.TAPS_CONV, dil: int = 1) -> bool:
     """whether uz_wgrad_xf takes this weight-gradient problem (R read through a BatchNorm + ReLU)"""
     d = L.WgradDesc(L.dtype_code(Lt.dtype), Lt.N, Lt.H, Lt.W, Rt.H, Rt.W, Lt.C, Lt.ld, Rt.C, Rt.ld, ntaps, taps_mode, dil)
+    return bool(L.load().uz_wgrad_xf_supported(byref(d)))
+
+
+def wgrad_xform_shapes_supported(N: int, H: int, W: int, Ci: int, ldl: int, Cj: int, ldr: int, dtype: torch.dtype) -> bool:
+    """the same question before the output gradient exists: a (N, H, W, Ci) gradient against a (N, H, W, Cj) raw input"""
+    d = L.WgradDesc(L.dtype_code(dtype), N, H, W, H, W, Ci, ldl, Cj, ldr, 9, L.TAPS_CONV, 1)
     return bool(L.load().uz_wgrad_xf_supported(byref(d)))
 
 
