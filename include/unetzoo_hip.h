@@ -265,9 +265,12 @@ int uz_conv3x3_first_wgrad(int dtype, const float* x, int N, int C, int H, int W
  *   UZ_PACK_CONVT_FWD : w[Ci][Co][4]           -> dst[t*Co + co][ci]
  *   UZ_PACK_CONVT_DGRAD: w[Ci][Co][4]          -> dst[ci][t*Co + co]
  *   UZ_PACK_IM2COL    : w[Co][Ci][T], K=T*Ci   -> dst[Co][Kpad], k = t*Ci + ci, zero padded
+ *   UZ_PACK_VEC_REPEAT: v[Co] (Ci = 1)         -> dst[t*Co + c] = v[c], t < T, dst stays FP32 whatever `dtype` (the bias of
+ *                       nn.ConvTranspose2d k2 s2 for each of the four sub-pixels of the pixel-shuffle store,
+ *                       common_layers.py:104; batched form only: a model's four repeats ride in the weights' launch)
  * ------------------------------------------------------------------------------------------- */
 enum { UZ_PACK_CONV_FWD = 0, UZ_PACK_CONV_DGRAD = 1, UZ_PACK_CONVT_FWD = 2, UZ_PACK_CONVT_DGRAD = 3,
-       UZ_PACK_IM2COL = 4 };
+       UZ_PACK_IM2COL = 4, UZ_PACK_VEC_REPEAT = 5 };
 int uz_pack_weights(int dtype, int mode, const float* w, int Co, int Ci, int T, int Kpad, void* dst,
                     void* stream);
 /* The same for a whole model in one launch: `items_device` is a device array of n_items entries

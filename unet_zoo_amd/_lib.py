@@ -15,7 +15,7 @@ import torch
 UZ_F32, UZ_BF16 = 0, 1
 TAPS_CONV, TAPS_GATHER2X2, TAPS_CONV_UP2, TAPS_CONV_S2 = 0, 1, 2, 3
 STORE_PLAIN, STORE_SHUFFLE2X2 = 0, 1
-PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD, PACK_IM2COL = range(5)
+PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD, PACK_IM2COL, PACK_VEC_REPEAT = range(6)
 
 LIB_NAME = "libunetzoo_hip.so"
 # UNET_ZOO_AMD_LIB: another build of the same ABI (tools/kbench.py points it at the ablation build); the product

@@ -794,6 +794,12 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const uz_pack
   const long long count = ((int)blockIdx.y + 1 < n ? items[blockIdx.y + 1].begin : total) - it.begin;
   T* __restrict__ dst = static_cast<T*>(it.dst);
   const float* __restrict__ src = it.src;
+  if (it.mode == UZ_PACK_VEC_REPEAT) {   // fp32 in, fp32 out: v[Co] T times over
+    float* __restrict__ df = static_cast<float*>(it.dst);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += (long long)gridDim.x * blockDim.x)
+      df[idx] = src[idx % it.Co];
+    return;
+  }
   const bool same = it.mode == UZ_PACK_CONV_FWD || it.mode == UZ_PACK_CONVT_DGRAD;
   const bool transposed = it.mode == UZ_PACK_CONV_DGRAD || it.mode == UZ_PACK_CONVT_FWD;
   if (it.T == 1 && same && count == (long long)it.Co * it.Ci && (count & 3) == 0 &&

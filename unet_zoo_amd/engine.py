@@ -52,7 +52,10 @@ class PackCache:
         key = (id(p), mode, kpad, dtype)
         e = self.entries.get(key)
         if e is None:
-            dst = ops.pack_weights(p.detach(), mode, dtype, kpad)   # packed now, batched from the next step on
+            if mode == L.PACK_VEC_REPEAT:     # an fp32 vector kpad times over (ConvTranspose2d's bias per sub-pixel)
+                dst = p.detach().float().repeat(kpad).contiguous()
+            else:
+                dst = ops.pack_weights(p.detach(), mode, dtype, kpad)   # packed now, batched from the next step on
             self.entries[key] = (p, mode, kpad, dtype, dst)
             self._table = None
             return dst
@@ -99,6 +102,10 @@ class PackCache:
         arr = (L.PackItem * max(len(generic), 1))()
         begin = 0
         for i, (p, mode, kpad, dst) in enumerate(generic):
+            if mode == L.PACK_VEC_REPEAT:
+                arr[i] = L.PackItem(p.data_ptr(), dst.data_ptr(), begin, mode, p.numel(), 1, kpad, 0, 0)
+                begin += dst.numel()
+                continue
             d0, d1 = p.shape[0], p.shape[1]
             T = p.numel() // (d0 * d1)
             co, ci = (d0, d1) if mode in (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD, L.PACK_IM2COL) else (d1, d0)
@@ -799,15 +806,16 @@ class Engine:
             v[:, 2 * x.H:, :, :] = 0
             v[:, :, 2 * x.W:, :] = 0
         wp = self._pack(m.weight, L.PACK_CONVT_FWD)
-        bias4 = m.bias.detach().repeat(4) if m.bias is not None else None
+        # (the bias of every sub-pixel: refreshed with the weights by the batched pack launch, not by a launch of its own)
+        bias4 = self._cache.get(m.bias, L.PACK_VEC_REPEAT, 4, self.dtype) if m.bias is not None else None
         ops.conv_igemm(x, wp, bias4, out, ntaps=1, store_mode=L.STORE_SHUFFLE2X2, nout=4 * Co, co=Co)
 
         if self.record:
             def bwd():
                 g = self._sum_grads(out, 1)[0]
                 if m.bias is not None:
-                    cs = g.channel_sums()
-                    self._give_grad(m.bias, cs if cs is not None else ops.colsum(g))
+                    cs = g.channel_sums(out=self._dst(m.bias))
+                    self._give_grad(m.bias, cs if cs is not None else ops.colsum(g, out=self._dst(m.bias)))
                 self._give_grad(m.weight, ops.wgrad(x, g, tuple(m.weight.shape), ntaps=4,
                                                     taps_mode=L.TAPS_GATHER2X2, out=self._dst(m.weight)))
                 if x.needs_grad:

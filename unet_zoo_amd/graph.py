@@ -146,6 +146,12 @@ class PhasedStep:
 
     def loss(self, target: torch.Tensor) -> torch.Tensor:
         """loss_fn on the outputs of the last emit(); leaves d(loss)/d(output) for backward(..., heads=True)"""
+        direct = getattr(self.loss_fn, "direct", None)
+        if direct is not None:   # a criterion that hands over its own gradients (the fused BCE + Dice kernel): no autograd node
+            loss, gouts = direct(self.model.wrap_outputs(tuple(o.detach() for o in self._outs)), target)
+            assert len(gouts) == len(self._outs)
+            self._gouts = tuple(gouts)
+            return loss.detach()
         leaves = tuple(o.detach().requires_grad_(True) for o in self._outs)
         with torch.enable_grad():
             loss = self.loss_fn(self.model.wrap_outputs(leaves), target)

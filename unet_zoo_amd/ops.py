@@ -63,15 +63,18 @@ class Act:
         """rows [r0, r0 + N*H*W) as an (N, H, W, C) tensor of their own (token-concats along dim -2)"""
         return Act(self.buf[r0:r0 + N * H * W], self.off, self.C, N, H, W, self.needs_grad)
 
-    def channel_sums(self) -> Optional[torch.Tensor]:
-        """sum over pixels per channel (fp32) if the producer recorded partial sums, else None"""
+    def channel_sums(self, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """sum over pixels per channel (fp32) if the producer recorded partial sums, else None; out: written in place
+        (a parameter's .grad: no copy launch afterwards)"""
         if self.colsums is None:
             return None
         part, o = self.colsums
         # own kernel rather than part[:, 0, o:o+C].sum(0): no library reduction on the (capturable) hot path --
         # torch's multi-block reductions reset their semaphores with a memset node, which a replayed hipGraph
         # executes correctly only once on this stack (DESIGN.md section 5a)
-        out = torch.empty(self.C, dtype=torch.float32, device=part.device)
+        if out is None:
+            out = torch.empty(self.C, dtype=torch.float32, device=part.device)
+        assert out.numel() == self.C and out.dtype == torch.float32 and out.is_contiguous()
         L.check(L.load().uz_sum_rows_f32_ld(part.data_ptr() + 4 * o, part.shape[1] * part.shape[2], part.shape[0],
                                             self.C, out.data_ptr(), self.C, None, L.stream_ptr()), "uz_sum_rows_f32_ld")
         return out

@@ -38,7 +38,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .graph import HipModule, PhasedStep
-from .loss import loss_and_dice
+from .loss import loss_and_dice, loss_and_dice_direct
 from .optim import FlatClipAdamW
 
 # hipGraph capture checks only THIS thread's calls: the process-group watchdog thread polls its events concurrently
@@ -256,6 +256,12 @@ class GraphedStep:
                 l, d = loss_and_dice(out, tt)
                 dice_box.append(d)
                 return l
+
+            def fused_direct(out, tt):   # the same numbers and d(loss)/d(outputs) without autograd's three extra launches
+                l, d, gouts = loss_and_dice_direct(out, tt)
+                dice_box.append(d)
+                return l, gouts
+            fused.direct = fused_direct
             ps.loss_fn = fused
         else:
             # forward graph; the criterion runs eagerly on its static outputs; the backward graphs read static
