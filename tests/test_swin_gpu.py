@@ -411,12 +411,11 @@ def test_continuous_position_bias_batched_launch():
         assert relerr(one[k], t) < 1e-5
 
 
-def test_swin_options_ape_qk_scale_other_head_width_against_oracle():
-    """constructor options the reference accepts beyond its defaults (swin_unet_v2.py:596-700): ape=True, qk_scale,
-    head_dim 16 (num_heads doubled) -- the window core then runs through the library-GEMM path -- fp32 against the
-    oracle, gradients of the absolute position embedding and tau included"""
+def test_swin_options_ape_qk_scale_against_oracle():
+    """constructor options the reference accepts beyond its defaults (swin_unet_v2.py:596-700): ape=True, qk_scale -- fp32
+    against the oracle, gradients of the absolute position embedding and tau included"""
     torch.manual_seed(0)
-    kw = dict(image_size=64, window_size=4, drop_path_rate=0.0, ape=True, qk_scale=0.2, num_heads=[6, 12, 24, 48])
+    kw = dict(image_size=64, window_size=4, drop_path_rate=0.0, ape=True, qk_scale=0.2)
     m = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, **kw)
     m.run_dtype = torch.float32
     with torch.no_grad():
@@ -425,7 +424,7 @@ def test_swin_options_ape_qk_scale_other_head_width_against_oracle():
     assert "absolute_pos_embed" in sd and tuple(sd["absolute_pos_embed"].shape) == (1, 256, 96)
     m = m.to(DEV).train()
     x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=4)
-    cfg = torch_ref.swin_config(sd, 64, window_size=4, num_heads=(6, 12, 24, 48))
+    cfg = torch_ref.swin_config(sd, 64, window_size=4)
     cfg["qk_scale"] = 0.2
     ref_logits, ref_loss, ref_grads, _ = torch_ref.train_step_reference("swin_unet_v2", sd, x, mask, cfg=cfg)
     logits = m(x.to(DEV))
@@ -467,11 +466,29 @@ def test_swin_without_patch_norm_against_oracle():
         assert abs(named[n].grad.double().norm().item() - want) <= 2e-2 * want + 1e-6, n
 
 
+def test_swin_refuses_what_no_kernel_takes():
+    """head widths other than 32 and dropout on the attention probabilities have no window-attention kernel; rounds 2-4 ran
+    them through torch GEMMs and autograd (a second backend) -- now they are refused, in training, with a message that says
+    what IS supported; eval mode (dropout off) still runs"""
+    x, _ = torch_ref.synthetic_batch(2, 3, 64, 64, seed=4)
+    torch.manual_seed(0)
+    m = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, image_size=64, window_size=4,
+                                  num_heads=[6, 12, 24, 48]).to(DEV)
+    with pytest.raises(NotImplementedError, match="head_dim 32"):
+        m(x.to(DEV))
+    m = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, image_size=64, window_size=4,
+                                  attn_drop_rate=0.1).to(DEV).train()
+    with pytest.raises(NotImplementedError, match="attention dropout"):
+        m(x.to(DEV))
+    m.eval()
+    with torch.no_grad():
+        assert torch.isfinite(m(x.to(DEV))).all()
+
+
 def test_swin_dropout_options_train_and_are_off_in_eval():
-    """drop_rate (after the embedding and after the attention projection) and attn_drop_rate (inside the window core):
-    masks from torch's generator, reproducible under a seed, identity in eval mode, and the step still trains -- also
-    replayed from hipGraphs"""
-    kw = dict(image_size=64, window_size=4, drop_rate=0.1, attn_drop_rate=0.1, ape=True)
+    """drop_rate (after the embedding and after the attention projection): masks from torch's generator, reproducible under
+    a seed, identity in eval mode, and the step still trains -- also replayed from hipGraphs"""
+    kw = dict(image_size=64, window_size=4, drop_rate=0.1, ape=True)
     torch.manual_seed(0)
     m = unet_zoo_amd.create_model("swin_unet_v2", in_channels=3, num_classes=1, **kw).to(DEV)
     x, mask = torch_ref.synthetic_batch(2, 3, 64, 64, seed=4)

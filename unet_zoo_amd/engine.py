@@ -114,42 +114,6 @@ class PackCache:
         self._table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._total, self._n, self._table_dtype = begin, len(generic), dtype
 
-def _window_core_torch(qkv, tau, w1, b1, w2, b2, rel_index, heads: int, ws: int, shift: int, scale: float, p_drop: float):
-    """WindowAttention.forward between its qkv and proj Linears, with the caller's roll / window_partition /
-    window_reverse / mask (swin_unet_v2.py:127-159, :246-262), on the (N, 3C, H, W) qkv map"""
-    import torch.nn.functional as F
-    N, C3, H, W = qkv.shape
-    C, d, n = C3 // 3, C3 // 3 // heads, ws * ws
-    t = qkv.permute(0, 2, 3, 1)
-    if shift > 0:
-        t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
-    t = t.reshape(N, H // ws, ws, W // ws, ws, C3).permute(0, 1, 3, 2, 4, 5).reshape(-1, n, 3, heads, d).permute(2, 0, 3, 1, 4)
-    q, k, v = t[0] * scale, t[1], t[2]
-    attn = (q @ k.transpose(-2, -1)) / torch.clamp(q.norm(dim=-1, keepdim=True) * k.norm(dim=-1, keepdim=True).transpose(-2, -1), min=1e-6)
-    attn = attn / torch.clip(tau[:, :n, :n].unsqueeze(0), min=0.01)
-    idx = rel_index[:n, :n].to(qkv.device)
-    bias = F.linear(F.relu(F.linear(idx, w1, b1)), w2, b2)                      # (n, n, heads)
-    attn = attn + bias.permute(2, 0, 1).unsqueeze(0)
-    if shift > 0:
-        img = torch.zeros(1, H, W, 1, device=qkv.device)
-        cnt = 0
-        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
-            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
-                img[:, hs, wsl, :] = cnt
-                cnt += 1
-        mw = img.view(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, n)
-        am = mw.unsqueeze(1) - mw.unsqueeze(2)
-        am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)           # (nW, n, n)
-        nW = am.shape[0]
-        attn = (attn.view(-1, nW, heads, n, n) + am.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
-    attn = F.dropout(attn.softmax(dim=-1), p_drop, p_drop > 0.0)
-    o = (attn @ v).transpose(1, 2).reshape(-1, n, C)
-    o = o.view(N, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, C)
-    if shift > 0:
-        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
-    return o.permute(0, 3, 1, 2)
-
-
 class ImageInput:
     """The network input for its first convolution: the fp32 NCHW image and -- only if somebody asks -- its im2col'd 3x3
     patches (an Act of [P][Kpad] in the run dtype: rounds 1-3's form of the first layer, still the fp32 run mode's)."""
@@ -1262,75 +1226,54 @@ class Engine:
         return pooled
 
     # ------------------------------------------------------------------ library-GEMM glue (bottleneck attention)
-    @staticmethod
-    def _dense_nchw(a: Act) -> torch.Tensor:
-        """(N, C, H, W) fp32 copy of an activation"""
-        return a.buf.view(a.N, a.H, a.W, a.ld)[..., a.off:a.off + a.C].permute(0, 3, 1, 2).float()
+    # ------------------------------------------------------------------ token grids the attention kernels take
+    # The dense attention kernels address score matrices with 16-byte rows: H * W tokens per image must be a multiple of
+    # 8.  Other maps (a 9 x 9 bottleneck of a 72 x 72 input) run on a grid WIDENED to the next multiple of 8 columns:
+    # zero tokens there, masked out of every softmax (they must not count as keys / queries), cropped from the result.
+    # (Rounds 2-4 sent such shapes through torch.bmm / autograd -- a second backend; this replaces it.)
+    MASKED_SCORE = -30000.0   # a score no real one comes near; finite, so that a slice of nothing but masked entries
+                              # still has a maximum to subtract (exp(-inf - (-inf)) is a NaN)
 
     @staticmethod
-    def _store_nchw(t: torch.Tensor, a: Act) -> None:
-        a.buf.view(a.N, a.H, a.W, a.ld)[..., a.off:a.off + a.C].copy_(t.permute(0, 2, 3, 1))
+    def padded_width(H: int, W: int) -> int:
+        return W if (H * W) % 8 == 0 else (W + 7) // 8 * 8
 
-    def torch_block(self, fn: Callable[..., torch.Tensor], inputs: Sequence[Act], params: Sequence[nn.Parameter],
-                    out):
-        """out = fn(*inputs_as_NCHW_fp32, *params) evaluated with PyTorch ops, differentiated by autograd; `out` is one
-        activation or a sequence of them (fn then returns a tuple).
-
-        For the handful of batched matrix products + softmax of the hybrids' BOTTLENECK attention (16x16 / 32x32
-        maps or a few dozen tokens: < 0.1 % of a step's arithmetic; position / channel attention of
-        transatt_unet.py:29-107, the MultiHeadDense attention of unet_transformer.py:127-228, the channel
-        transformer of uctransnet.py:86-330): plain library GEMMs (rocBLAS through torch.bmm) are what such small dense
-        products are for; every convolution, normalisation and resampling around them stays on the HIP kernels.  `fn`
-        must not contain a reduction to a few values over a large tensor (those use a memset node that hipGraph
-        replay mishandles): scalar-parameter gradients go through scale_residual() instead."""
-        outs = list(out) if isinstance(out, (list, tuple)) else [out]
-        xs = [self._dense_nchw(a) for a in inputs]
-
-        def run():
-            y = fn(*xs, *params)
-            ys = list(y) if isinstance(y, (list, tuple)) else [y]
-            assert len(ys) == len(outs)
-            for t, o in zip(ys, outs):
-                assert tuple(t.shape) == (o.N, o.C, o.H, o.W), (tuple(t.shape), (o.N, o.C, o.H, o.W))
-            return ys
-
-        if self.record:
-            xs = [x.requires_grad_(a.needs_grad) for x, a in zip(xs, inputs)]
-            with torch.enable_grad():
-                ys = run()
-            for t, o in zip(ys, outs):
-                self._store_nchw(t.detach(), o)
-
+    def pad_w(self, x: Act, Wp: int) -> Act:
+        """x on a token grid of Wp >= x.W columns, the added columns zero"""
+        if Wp == x.W:
+            return x
+        xp = self.new_act(x.N, x.H, Wp, x.C, needs_grad=x.needs_grad)
+        xp.buf.zero_()
+        xp.buf.view(x.N, x.H, Wp, x.C)[:, :, :x.W].copy_(x.buf.view(x.N, x.H, x.W, x.ld)[..., x.off:x.off + x.C])
+        if self.record and x.needs_grad:
             def bwd():
-                gs = [self._total_grad(o) for o in outs]
-                if all(g is None for g in gs):
+                g = self._total_grad(xp)
+                if g is None:
                     return
-                live = [(t, self._dense_nchw(g)) for t, g in zip(ys, gs) if g is not None]
-                wrt = [x for x in xs if x.requires_grad] + [p for p in params if p.requires_grad]
-                grads = torch.autograd.grad([t for t, _ in live], wrt, [g for _, g in live], allow_unused=True)
-                k = 0
-                for x, a in zip(xs, inputs):
-                    if not x.requires_grad:
-                        continue
-                    gx = grads[k]
-                    k += 1
-                    if gx is not None:
-                        da = self.new_act(a.N, a.H, a.W, a.C)
-                        self._store_nchw(gx, da)
-                        a.add_grad(da)
-                for p_ in params:
-                    if p_.requires_grad:
-                        gp = grads[k]
-                        k += 1
-                        self._give_grad(p_, gp if gp is not None else torch.zeros_like(p_))
-
+                dx = self.new_act(x.N, x.H, x.W, x.C)
+                dx.buf.view(x.N, x.H, x.W, x.C).copy_(g.buf.view(x.N, x.H, Wp, g.ld)[:, :, :x.W, g.off:g.off + x.C])
+                x.add_grad(dx)
             self.tape.append(bwd)
-        else:
-            with torch.no_grad():
-                ys = run()
-            for t, o in zip(ys, outs):
-                self._store_nchw(t, o)
-        return out
+        return xp
+
+    def crop_w(self, xp: Act, W: int, out: Optional[Act] = None) -> Act:
+        """the first W columns of xp's token grid (into `out` if given)"""
+        if W == xp.W and out is None:
+            return xp
+        y = out if out is not None else self.new_act(xp.N, xp.H, W, xp.C, needs_grad=xp.needs_grad)
+        y.buf.view(y.N, y.H, W, y.ld)[..., y.off:y.off + y.C].copy_(
+            xp.buf.view(xp.N, xp.H, xp.W, xp.ld)[:, :, :W, xp.off:xp.off + xp.C])
+        if self.record and xp.needs_grad:
+            def bwd():
+                g = self._total_grad(y)
+                if g is None:
+                    return
+                dp = self.new_act(xp.N, xp.H, xp.W, xp.C)
+                dp.buf.zero_()
+                dp.buf.view(xp.N, xp.H, xp.W, xp.C)[:, :, :W].copy_(g.buf.view(y.N, y.H, W, g.ld)[..., g.off:g.off + y.C])
+                xp.add_grad(dp)
+            self.tape.append(bwd)
+        return y
 
     def adaptive_avg_pool(self, x: Act, Ho: int, Wo: int) -> Act:
         """F.adaptive_avg_pool2d(x, (Ho, Wo)) (unet_transformer.py:196-198); the identity when the map already has that
@@ -1367,7 +1310,7 @@ class Engine:
         """(B, C, tokens) copy of a token-major activation -- glue for operands of a few MB (q / k / v of a bottleneck)"""
         return a.buf.view(a.N, a.H * a.W, a.ld)[..., a.off:a.off + a.C].transpose(1, 2).contiguous()
 
-    def row_attention(self, q: Act, k: Act, v: Act, out: Act) -> Act:
+    def row_attention(self, q: Act, k: Act, v: Act, out: Act, valid_w: Optional[int] = None) -> Act:
         """out_i = sum_j softmax_j(q_i . k_j) v_j per image: PAM_Module.forward between its 1x1 convolutions and the
         `gamma * out + x` (transatt_unet.py:41-49).  energy and its gradient are batched NT products, softmax over the
         key axis in place (kept for the backward), dv = att^T g and dk = dE^T q on the one-tap weight-gradient kernel."""
@@ -1377,6 +1320,8 @@ class Engine:
         vt = self._transposed(v)
         E = torch.empty((B, Nt, Nt), dtype=dt, device=dev)
         ops.gemm_nt(dt, B, Nt, Nt, dq, q.ptr(), q.ld, Nt * q.ld, k.ptr(), k.ld, Nt * k.ld, E.data_ptr(), Nt, Nt * Nt)
+        if valid_w is not None and valid_w < k.W:    # widened grid (pad_w): the added KEYS leave every query's softmax
+            E.view(B, Nt, k.H, k.W)[..., valid_w:] = self.MASKED_SCORE
         ops.softmax_fwd(E, 1, 1.0)
         ops.gemm_nt(dt, B, Nt, C, Nt, E.data_ptr(), Nt, Nt * Nt, vt.data_ptr(), Nt, C * Nt, out.ptr(), out.ld, Nt * out.ld)
         del vt
@@ -1532,7 +1477,8 @@ class Engine:
         self.tape.append(bwd)
         return ctx
 
-    def token_attention(self, xq: Act, xv: Act, wq: nn.Parameter, wk: nn.Parameter, wv: nn.Parameter, out: Act) -> Act:
+    def token_attention(self, xq: Act, xv: Act, wq: nn.Parameter, wk: nn.Parameter, wv: nn.Parameter, out: Act,
+                        valid_w: Optional[int] = None) -> Act:
         """out_b = softmax_over_queries((X_b wq)(X_b wk)^T / sqrt(c)) (XV_b wv) on the tokens of xq / xv (NHWC rows = the
         reference's `flatten(2).permute(0, 2, 1)`): MultiHeadSelfAttention.forward (xq is xv) and the attention core of
         MultiHeadCrossAttention.forward (unet_transformer.py:126-137, :200-213).  `nn.Softmax(dim=1)` on the (b, queries,
@@ -1565,6 +1511,8 @@ class Engine:
         Vt = proj_t(xv, wv)
         A = torch.empty((B, Nt, Nt), dtype=dt, device=dev)
         ops.gemm_nt(dt, B, Nt, Nt, c, Q.data_ptr(), c, Nt * c, K.data_ptr(), c, Nt * c, A.data_ptr(), Nt, Nt * Nt)
+        if valid_w is not None and valid_w < xq.W:   # widened grid: the added QUERIES leave every key's softmax (over queries)
+            A.view(B, xq.H, xq.W, Nt)[:, :, valid_w:, :] = self.MASKED_SCORE
         ops.softmax_fwd(A, 0, scale)
         ops.gemm_nt(dt, B, Nt, c, Nt, A.data_ptr(), Nt, Nt * Nt, Vt.data_ptr(), Nt, c * Nt, out.ptr(), out.ld, Nt * out.ld)
         del Vt
@@ -1789,13 +1737,12 @@ class Engine:
         qkv = self.linear(x, attn.qkv)
         p_attn = attn.attn_drop.p if self.training else 0.0
         if p_attn > 0.0 or x.C // heads != 32:
-            # options the fused kernels do not take (attention dropout acts inside the softmax-times-V product; head
-            # widths other than 32): the window core through library GEMMs, roll / partition / mask spelled out
-            o = self.torch_block(lambda t, tau_, w1, b1, w2, b2: _window_core_torch(
-                t, tau_, w1, b1, w2, b2, attn.log_relative_position_index, heads, ws, shift, attn.scale, p_attn),
-                (qkv,), (attn.tau, attn.cpb.fc1.weight, attn.cpb.fc1.bias, attn.cpb.fc2.weight, attn.cpb.fc2.bias),
-                self.new_act(x.N, x.H, x.W, x.C))
-            return self.dropout(self.linear(o, attn.proj), attn.proj_drop.p)
+            # (rounds 2-4 ran these through torch GEMMs and autograd; the product has ONE backend, and it has no window
+            # core for them: dropout on the attention probabilities inside the softmax-times-V product, head widths
+            # other than 32)
+            raise NotImplementedError(
+                f"swin_unet_v2 on the HIP engine: the window-attention kernels take head_dim 32 (got {x.C // heads}) and no "
+                f"attention dropout in training (attn_drop_rate={attn.attn_drop.p}); drop_rate / drop_path_rate are supported")
         cpb = attn.cpb
         pre = self._cpb.get(attn)                      # evaluated by position_biases() at the start of the forward
         if pre is not None and pre["N"] == N:

@@ -12,7 +12,7 @@ pass of the producing block, the skip and the upsampled tensor are written strai
 buffer).  The two attention cores at the 1/16-resolution bottleneck -- batched matrix products + softmax on (h*w) x (h*w) and
 512 x 512 matrices -- run on the library's batched GEMM, row softmax and one-tap weight-gradient kernels
 (``Engine.row_attention``, ``Engine.channel_attention``); only a bottleneck whose token count is not a multiple of 8
-(inputs such as 48 x 48) falls back to library GEMMs through ``Engine.torch_block``.
+(inputs such as 48 x 48) runs on a token grid widened by masked zero tokens (``Engine.pad_w``).
 """
 from __future__ import annotations
 
@@ -90,23 +90,17 @@ class PAM_Module(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
         self.softmax = nn.Softmax(dim=-1)
 
-    @staticmethod
-    def _core(q, k, v):
-        """energy[i, j] = q_i . k_j; out_i = sum_j softmax_j(energy)[i, j] v_j  (transatt_unet.py:41-49)"""
-        B, C, H, W = v.shape
-        qt = q.flatten(2).transpose(1, 2)                       # (B, N, C/8)
-        att = torch.softmax(torch.bmm(qt, k.flatten(2)), dim=-1)   # (B, N, N)
-        return torch.bmm(v.flatten(2), att.transpose(1, 2)).view(B, C, H, W)
-
     def emit(self, eng: Engine, x: Act) -> Act:
         q = eng.conv_plain(x, self.query_conv)
         k = eng.conv_plain(x, self.key_conv)
         v = eng.conv_plain(x, self.value_conv)
-        out = eng.new_act(x.N, x.H, x.W, x.C)
-        if (x.H * x.W) % 8 == 0:
-            att = eng.row_attention(q, k, v, out)
-        else:   # token counts that are not a multiple of 16 bytes (inputs like 48 x 48): library GEMMs
-            att = eng.torch_block(self._core, (q, k, v), (), out)
+        Wp = eng.padded_width(x.H, x.W)
+        if Wp == x.W:
+            att = eng.row_attention(q, k, v, eng.new_act(x.N, x.H, x.W, x.C))
+        else:   # token counts that are not a multiple of 16 bytes (inputs like 48 x 48): a widened grid, the added keys masked
+            attp = eng.row_attention(eng.pad_w(q, Wp), eng.pad_w(k, Wp), eng.pad_w(v, Wp), eng.new_act(x.N, x.H, Wp, x.C),
+                                     valid_w=x.W)
+            att = eng.crop_w(attp, x.W)
         return eng.scale_residual(att, self.gamma, x)
 
 
@@ -139,19 +133,13 @@ class ScaledDotProductAttention(nn.Module):
         self.temperature = temperature ** 0.5
         self.dropout = nn.Dropout(attn_dropout)
 
-    def _core(self, x):
-        """channel attention: softmax((x / T) x^T) over channels, dropout, times x (transatt_unet.py:91-107)"""
-        B, d, H, W = x.shape
-        q = x.view(B, d, -1)
-        attn = torch.matmul(q / self.temperature, q.transpose(1, 2))
-        attn = F.dropout(F.softmax(attn, dim=-1), self.dropout.p, self.training)
-        return torch.matmul(attn, q).view(B, d, H, W)
-
     def emit(self, eng: Engine, x: Act) -> Act:
-        out = eng.new_act(x.N, x.H, x.W, x.C)
-        if (x.H * x.W) % 8 == 0:
-            return eng.channel_attention(x, self.temperature, self.dropout.p, out)
-        return eng.torch_block(self._core, (x,), (), out)
+        Wp = eng.padded_width(x.H, x.W)
+        if Wp == x.W:
+            return eng.channel_attention(x, self.temperature, self.dropout.p, eng.new_act(x.N, x.H, x.W, x.C))
+        # zero tokens add nothing to the channel Gram matrix and receive attn @ 0 = 0: no mask needed
+        outp = eng.channel_attention(eng.pad_w(x, Wp), self.temperature, self.dropout.p, eng.new_act(x.N, x.H, Wp, x.C))
+        return eng.crop_w(outp, x.W)
 
 
 class TransAttUNet(HipModule):

@@ -13,10 +13,8 @@ statistics sees the larger count, which ``stat_repeat`` restores --, the global-
 CCA, the 1x1 head, and the Channel Transformer itself ((image_size / 32)^2 tokens of 16 ... 240 channels): LayerNorm,
 Linear, GELU, dropout and the channel-wise cross attention (``Engine.channel_cross_attention``: token-contracting
 products on the one-tap weight-gradient kernel, InstanceNorm + softmax on the score planes, one batched product for the
-context of all heads) as engine operations.  Configurations the own kernels do not take (attention dropout in training,
-widths that are not multiples of 8) run the same mathematics as library
-GEMMs, LayerNorm and softmax through ``Engine.torch_block``, written so that no reduction to a few values over a large
-tensor occurs (instance-norm moments and Linear biases go through matrix products).
+context of all heads) as engine operations.  Configurations those kernels do not take (attention dropout in training,
+widths that are not multiples of 8) are refused with NotImplementedError: the product has one backend.
 """
 from __future__ import annotations
 
@@ -63,28 +61,6 @@ def get_uctransnet_config():
     return config
 
 
-def _linear(x, lin: nn.Linear):
-    """x W^T + b with the bias inside the matrix product: its gradient comes out of the GEMM, not out of a
-    column-sum reduction (see Engine.torch_block)"""
-    if lin.bias is None:
-        return x @ lin.weight.t()
-    ones = x.new_ones(x.shape[:-1] + (1,))
-    return torch.cat([x, ones], -1) @ torch.cat([lin.weight.t(), lin.bias[None, :]], 0)
-
-
-def _instance_norm_rows(s, eps=1e-5):
-    """nn.InstanceNorm2d(heads) on (B, heads, C, KV) scores (uctransnet.py:118, :176): per (image, head) mean and
-    biased variance over the (C, KV) plane, the two moments taken by matrix products with a ones vector"""
-    B, Hh, C, KV = s.shape
-    flat = s.reshape(B * Hh, C * KV)
-    ones = flat.new_ones(C * KV, 1)
-    n = float(C * KV)
-    mean = (flat @ ones) / n
-    cen = flat - mean
-    var = ((cen * cen) @ ones) / n
-    return (cen * torch.rsqrt(var + eps)).reshape(B, Hh, C, KV)
-
-
 class Channel_Embeddings(nn.Module):
     def __init__(self, config, patchsize, img_size, in_channels):
         super().__init__()
@@ -128,19 +104,6 @@ class Attention_org(nn.Module):
         self.attn_dropout = nn.Dropout(config.transformer["attention_dropout_rate"])
         self.proj_dropout = nn.Dropout(config.transformer["attention_dropout_rate"])
 
-    def run(self, embs, emb_all):
-        """uctransnet.py:126-226 for four scales; softmax over the KV channels of instance-normalised scores"""
-        K = torch.stack([_linear(emb_all, k) for k in self.key], dim=1)                    # (B, h, n, KV)
-        Vt = torch.stack([_linear(emb_all, v) for v in self.value], dim=1).transpose(-1, -2)  # (B, h, KV, n)
-        outs = []
-        for emb, queries, out in zip(embs, (self.query1, self.query2, self.query3, self.query4),
-                                     (self.out1, self.out2, self.out3, self.out4)):
-            Q = torch.stack([_linear(emb, q) for q in queries], dim=1).transpose(-1, -2)    # (B, h, C, n)
-            scores = torch.matmul(Q, K) / math.sqrt(self.KV_size)                           # (B, h, C, KV)
-            probs = F.dropout(torch.softmax(_instance_norm_rows(scores), dim=3), self.attn_dropout.p, self.training)
-            ctx = torch.matmul(probs, Vt).permute(0, 3, 2, 1).mean(dim=3)                   # (B, n, C)
-            outs.append(F.dropout(_linear(ctx, out), self.proj_dropout.p, self.training))
-        return outs
 
 
 class Mlp(nn.Module):
@@ -155,9 +118,6 @@ class Mlp(nn.Module):
         nn.init.normal_(self.fc1.bias, std=1e-6)
         nn.init.normal_(self.fc2.bias, std=1e-6)
 
-    def run(self, x):
-        x = F.dropout(F.gelu(_linear(x, self.fc1)), self.dropout.p, self.training)
-        return F.dropout(_linear(x, self.fc2), self.dropout.p, self.training)
 
 
 class Block_ViT(nn.Module):
@@ -173,13 +133,6 @@ class Block_ViT(nn.Module):
         for i, c in enumerate(channel_num):
             setattr(self, f"ffn{i + 1}", Mlp(config, c, c * r))
 
-    def run(self, embs):
-        """uctransnet.py:260-301"""
-        emb_all = self.attn_norm(torch.cat(embs, dim=2))
-        cx = [getattr(self, f"attn_norm{i + 1}")(e) for i, e in enumerate(embs)]
-        cx = self.channel_attn.run(cx, emb_all)
-        cx = [o + c for o, c in zip(embs, cx)]
-        return [getattr(self, f"ffn{i + 1}").run(getattr(self, f"ffn_norm{i + 1}")(c)) + c for i, c in enumerate(cx)]
 
 
 class Encoder(nn.Module):
@@ -192,10 +145,6 @@ class Encoder(nn.Module):
         for _ in range(config.transformer["num_layers"]):
             self.layer.append(copy.deepcopy(Block_ViT(config, vis, channel_num)))
 
-    def run(self, embs):
-        for blk in self.layer:
-            embs = blk.run(embs)
-        return [getattr(self, f"encoder_norm{i + 1}")(e) for i, e in enumerate(embs)]
 
 
 class ChannelTransformer(nn.Module):
@@ -212,21 +161,10 @@ class ChannelTransformer(nn.Module):
             setattr(self, f"reconstruct_{i + 1}", Reconstruct(channel_num[i], channel_num[i], kernel_size=1,
                                                               scale_factor=(patchSize[i], patchSize[i])))
 
-    def _tokens(self, *args):
-        """position embeddings + dropout, the encoder; (B, C, h, w) maps in and out (uctransnet.py:50-55, :304-330)"""
-        maps, pos = args[:4], args[4:8]
-        embs = []
-        for i, (m, p) in enumerate(zip(maps, pos)):
-            emb = getattr(self, f"embeddings_{i + 1}")
-            t = m.flatten(2).transpose(-1, -2) + p
-            embs.append(F.dropout(t, emb.dropout.p, self.training))
-        B, _, h, w = maps[0].shape
-        return tuple(e.permute(0, 2, 1).reshape(B, -1, h, w) for e in self.encoder.run(embs))
-
     def _own_kernels(self, eng: Engine, toks: List[Act]) -> bool:
         """the channel transformer on the library's own kernels: every width a multiple of 8 (16-byte rows), KV <= 1024, no
         dropout on the attention probabilities / projections in training (the reference default 0.0, uctransnet.py:17);
-        anything else takes the library-GEMM path (Engine.torch_block)"""
+        anything else is refused (emit)"""
         att = self.encoder.layer[0].channel_attn
         if eng.training and (att.attn_dropout.p > 0.0 or att.proj_dropout.p > 0.0):
             return False
@@ -281,14 +219,10 @@ class ChannelTransformer(nn.Module):
         self.attn_weights = []          # vis=True: [layer][scale] -> (B, C_i, KV), as Encoder.forward collects them (:318-322)
         if self._own_kernels(eng, toks):
             enc = self._emit_tokens(eng, toks)
-        else:
-            if self.vis:
-                raise NotImplementedError("vis=True needs the own-kernel path of the channel transformer (no attention "
-                                          "dropout in training, widths that are multiples of 8)")
-            pos = [getattr(self, f"embeddings_{i + 1}").position_embeddings for i in range(4)]
-            others = [p for n, p in self.encoder.named_parameters()]
-            enc = [eng.new_act(t.N, t.H, t.W, t.C) for t in toks]
-            eng.torch_block(lambda *a: self._tokens(*a[:8]), toks, pos + others, enc)
+        else:   # (rounds 2-4 ran these through torch GEMMs and autograd: the product has one backend)
+            raise NotImplementedError("uctransnet on the HIP engine: the channel transformer's kernels take widths that are "
+                                      "multiples of 8, KV_size <= 1024 and no dropout on the attention probabilities / "
+                                      "projections in training (the reference's default 0.0, uctransnet.py:17)")
         for i, (e, en, out) in enumerate(zip(enc, ens, outs)):
             rec = getattr(self, f"reconstruct_{i + 1}")
             f = self.patch[i]

@@ -78,24 +78,17 @@ class PositionalEncodingPermute2D(nn.Module):
         return eng.add_const(x, self._cache[key])
 
 
-def _attend(Qs, Vs, wq, wk, wv):
-    """softmax(Q K^T / sqrt(c), dim=1) V on (b, c, h, w) sources (unet_transformer.py:127-137, :208-219) with library
-    GEMMs: only for token counts that are not a multiple of 8 (16-byte rows), which the own kernels do not take"""
-    b, c, h, w = Qs.shape
-    t = Qs.flatten(2).permute(0, 2, 1)
-    Q, K, V = t @ wq, t @ wk, Vs.flatten(2).permute(0, 2, 1) @ wv
-    A = torch.softmax(torch.bmm(Q, K.permute(0, 2, 1)) / math.sqrt(c), dim=1)
-    return torch.bmm(A, V).permute(0, 2, 1).reshape(b, c, h, w)
-
-
 def _token_attention(eng: Engine, xq: Act, xv: Act, mod: nn.Module) -> Act:
-    out = eng.new_act(xq.N, xq.H, xq.W, xq.C)
+    """softmax(Q K^T / sqrt(c), dim=1) V (unet_transformer.py:127-137, :208-219) on Engine.token_attention; token maps
+    whose H * W is not a multiple of 8 run on a grid widened by zero tokens that are masked out of the softmax"""
     ws = (mod.query.weight, mod.key.weight, mod.value.weight)
-    if (xq.H * xq.W) % 8 == 0:
-        return eng.token_attention(xq, xv, *ws, out)
-    if xq is xv:
-        return eng.torch_block(lambda t, *w: _attend(t, t, *w), (xq,), ws, out)
-    return eng.torch_block(_attend, (xq, xv), ws, out)
+    Wp = eng.padded_width(xq.H, xq.W)
+    if Wp == xq.W:
+        return eng.token_attention(xq, xv, *ws, eng.new_act(xq.N, xq.H, xq.W, xq.C))
+    xqp = eng.pad_w(xq, Wp)
+    xvp = xqp if xq is xv else eng.pad_w(xv, Wp)
+    op = eng.token_attention(xqp, xvp, *ws, eng.new_act(xq.N, xq.H, Wp, xq.C), valid_w=xq.W)
+    return eng.crop_w(op, xq.W)
 
 
 class MultiHeadSelfAttention(nn.Module):
