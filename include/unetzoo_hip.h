@@ -619,7 +619,8 @@ int uz_im2col_nchw(int dtype, const float* x_nchw, int N, int C, int H, int W, i
 /* softmax(q k^T * scale) v per (image, head), head_dim 64 (missformer.py:21-39, :113-128).
  * q / out: (B*N, ld) token tensors, head h in columns [64h, 64h+64).  Key j of image b is row
  * ((j / kps) * B + b) * kps + j % kps of k / v (kps = NK: one [B][NK] block; the bridge attends to four
- * blocks of kps rows, missformer.py:81-100).  lse: B*heads*N floats kept for the backward. */
+ * blocks of kps rows, missformer.py:81-100).  lse: B*heads*N floats kept for the backward: log2 of the sum of
+ * exp(scaled scores), i.e. logsumexp / ln 2. */
 typedef struct uz_sra_desc {
   int dtype, B, N, NK, heads, head_dim, kps;
   int ldq, ldk, ldv, ldo;

@@ -23,6 +23,11 @@ REF_NAMES = (
     "uz_conv3x3_first_fwd", "uz_conv3x3_first_wgrad_workspace_bytes", "uz_conv3x3_first_wgrad", "uz_wgrad_multi_workspace_bytes",
     "uz_wgrad_multi", "uz_winattn_fwd", "uz_winattn_bwd_rows", "uz_winattn_bwd",
     "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd",
+    # round 5
+    "uz_conv_igemm_xf", "uz_wgrad_xf", "uz_bn_relu_add_apply", "uz_pool_grad_combine", "uz_resize_bilinear_bwd", "uz_bilinear_bwd",
+    "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_dropout", "uz_chanscale_relu", "uz_patchify", "uz_im2col3x3_nchw",
+    "uz_sum_rows_f32_ld", "uz_sum_rows_f32", "uz_resample2", "uz_attn_bwd_psi", "uz_attn_bwd_reduce", "uz_attn_bwd_apply",
+    "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
 )
 
 

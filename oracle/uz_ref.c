@@ -1095,4 +1095,459 @@ int uz_attn_gate_fwd_ref(int dtype, const void* x, int ldx, const float* q, cons
 }
 UZ_SAME_SIGNATURE(uz_attn_gate_fwd);
 
+
+/* ======================================================================================================================
+ * Round 5: the input-transform forms, the attention gate's backward, the resize backward, spatial-reduction attention
+ * and the element / bookkeeping passes that had no restatement yet.
+ * ==================================================================================================================== */
+
+/* a[p][c] = relu(x * scale + shift) rounded to the tensor type: ONE fp32 fma and one rounding, as uz_bn_relu_apply stores it
+ * (common_layers.py:29-30: BatchNorm2d folded into scale / shift, then ReLU) */
+static void xf_apply(int dtype, const void* x, int ldx, long long P, int C, const float* scale, const float* shift, void* a) {
+  for (long long p = 0; p < P; ++p)
+    for (int c = 0; c < C; ++c) {
+      const float z = fmaf((float)ld(dtype, x, p * ldx + c), scale[c], shift[c]);
+      st(dtype, a, p * C + c, z > 0.f ? (double)z : 0.0);
+    }
+}
+
+/* the second convolution of a DoubleConv reading the first one's RAW output through its BatchNorm + ReLU
+ * (common_layers.py:28-33): exactly uz_bn_relu_apply followed by uz_conv_igemm, the middle tensor private to the call */
+int uz_conv_igemm_xf_ref(const uz_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, const void* w_packed,
+                         const float* bias, void* y, float* stats_partial, void* stream) {
+  const long long Pin = (long long)d->N * d->Hin * d->Win;
+  const size_t es = d->dtype == UZ_BF16 ? 2 : 4;
+  void* a = malloc((size_t)Pin * d->Cin * es);
+  if (!a) return UZ_EINVAL;
+  xf_apply(d->dtype, x, d->ldx, Pin, d->Cin, in_scale, in_shift, a);
+  uz_conv_desc d2 = *d;
+  d2.ldx = d->Cin;
+  const int rc = uz_conv_igemm_ref(&d2, a, w_packed, bias, y, stats_partial, stream);
+  free(a);
+  return rc;
+}
+UZ_SAME_SIGNATURE(uz_conv_igemm_xf);
+
+/* ... and that convolution's weight gradient (autograd, training_loop.py:119) with R = the raw output */
+int uz_wgrad_xf_ref(const uz_wgrad_desc* d, const void* L, const void* R, const float* r_scale, const float* r_shift, float* out,
+                    void* workspace, void* stream, int phase) {
+  (void)phase;
+  const long long Pr = (long long)d->N * d->Hr * d->Wr;
+  const size_t es = d->dtype == UZ_BF16 ? 2 : 4;
+  void* a = malloc((size_t)Pr * d->Cj * es);
+  if (!a) return UZ_EINVAL;
+  xf_apply(d->dtype, R, d->ldr, Pr, d->Cj, r_scale, r_shift, a);
+  uz_wgrad_desc d2 = *d;
+  d2.ldr = d->Cj;
+  const int rc = uz_wgrad_ref(&d2, L, a, out, workspace, stream);
+  free(a);
+  return rc;
+}
+UZ_SAME_SIGNATURE(uz_wgrad_xf);
+
+/* act = relu(scale y + shift) + res, pooled = MaxPool2d(2, 2[, ceil_mode]) of the STORED act (u2net.py:74, :30, :221-229);
+ * bit 1 of pool_ceil: BatchNorm without the ReLU (resunet's skip branch) */
+int uz_bn_relu_add_apply_ref(int dtype, const void* y, int ldy, const float* scale, const float* shift, int N, int H, int W, int C,
+                             const void* res, int ldr, void* act, int lda, void* pooled, int ldp, int pool_ceil, void* stream) {
+  (void)stream;
+  const int relu = !(pool_ceil & 2), ceil_mode = pool_ceil & 1;
+  for (long long p = 0; p < (long long)N * H * W; ++p)
+    for (int c = 0; c < C; ++c) {
+      float v = fmaf((float)ld(dtype, y, p * ldy + c), scale[c], shift[c]);
+      if (relu && !(v > 0.f)) v = 0.f;
+      if (res) v += (float)ld(dtype, res, p * ldr + c);
+      st(dtype, act, p * lda + c, (double)v);
+    }
+  if (pooled) {
+    const int Hp = ceil_mode ? (H + 1) / 2 : H / 2, Wp = ceil_mode ? (W + 1) / 2 : W / 2;
+    for (int n = 0; n < N; ++n)
+      for (int h = 0; h < Hp; ++h)
+        for (int w = 0; w < Wp; ++w)
+          for (int c = 0; c < C; ++c) {
+            double m = -INFINITY;
+            for (int a = 0; a < 2; ++a)
+              for (int b = 0; b < 2; ++b) {
+                if (2 * h + a >= H || 2 * w + b >= W) continue;
+                const double v = ld(dtype, act, (((long long)n * H + 2 * h + a) * W + 2 * w + b) * lda + c);
+                if (v > m) m = v;
+              }
+            st(dtype, pooled, (((long long)n * Hp + h) * Wp + w) * ldp + c, m);
+          }
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_bn_relu_add_apply);
+
+/* out = g0 + g1 + unpool(gp): the pooled gradient goes to the FIRST maximum of its 2x2 window of act in raster order, the
+ * element ATen's max_pool2d records (common_layers.py:90 under autograd) */
+int uz_pool_grad_combine_ref(int dtype, int N, int H, int W, int C, const void* act, int lda, const void* g0, int ldg0, const void* g1,
+                             int ldg1, const void* gp, int ldgp, void* out, int ldo, int pool_ceil, void* stream) {
+  (void)stream;
+  const int Hp = (pool_ceil & 1) ? (H + 1) / 2 : H / 2, Wp = (pool_ceil & 1) ? (W + 1) / 2 : W / 2;
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h)
+      for (int w = 0; w < W; ++w)
+        for (int c = 0; c < C; ++c) {
+          const long long p = ((long long)n * H + h) * W + w;
+          double g = 0.0;
+          if (g0) g += ld(dtype, g0, p * ldg0 + c);
+          if (g1) g += ld(dtype, g1, p * ldg1 + c);
+          const int ph = h / 2, pw = w / 2;
+          if (gp && ph < Hp && pw < Wp) {
+            double best = -INFINITY;
+            int bh = -1, bw = -1;
+            for (int a = 0; a < 2; ++a)
+              for (int b = 0; b < 2; ++b) {
+                const int hh = 2 * ph + a, ww = 2 * pw + b;
+                if (hh >= H || ww >= W) continue;
+                const double v = ld(dtype, act, (((long long)n * H + hh) * W + ww) * lda + c);
+                if (v > best) best = v, bh = hh, bw = ww;
+              }
+            if (bh == h && bw == w) g += ld(dtype, gp, (((long long)n * Hp + ph) * Wp + pw) * ldgp + c);
+          }
+          st(dtype, out, p * ldo + c, g);
+        }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_pool_grad_combine);
+
+/* backward of F.interpolate(mode='bilinear') (u2net.py:19-22, nested_unet.py:32): every output pixel hands its gradient to its
+ * four sources with the forward's weights; sums in double, one rounding */
+int uz_resize_bilinear_bwd_ref(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi, int C, void* dx,
+                               int lddx, long long dx_img_stride, int Ho, int Wo, int align_corners, void* stream) {
+  (void)stream;
+  const double sh = align_corners ? (Ho > 1 ? (double)(Hi - 1) / (Ho - 1) : 0.0) : (double)Hi / Ho;
+  const double sw = align_corners ? (Wo > 1 ? (double)(Wi - 1) / (Wo - 1) : 0.0) : (double)Wi / Wo;
+  double* acc = (double*)calloc((size_t)Hi * Wi * C, sizeof(double));
+  if (!acc) return UZ_EINVAL;
+  for (int n = 0; n < N; ++n) {
+    memset(acc, 0, (size_t)Hi * Wi * C * sizeof(double));
+    for (int oh = 0; oh < Ho; ++oh)
+      for (int ow = 0; ow < Wo; ++ow) {
+        double fh = align_corners ? oh * sh : (oh + 0.5) * sh - 0.5, fw = align_corners ? ow * sw : (ow + 0.5) * sw - 0.5;
+        if (fh < 0.0) fh = 0.0;
+        if (fw < 0.0) fw = 0.0;
+        const int h0 = (int)fh < Hi - 1 ? (int)fh : Hi - 1, w0 = (int)fw < Wi - 1 ? (int)fw : Wi - 1;
+        const int h1 = h0 < Hi - 1 ? h0 + 1 : h0, w1 = w0 < Wi - 1 ? w0 + 1 : w0;
+        const double lh = fh - h0, lw = fw - w0;
+        for (int c = 0; c < C; ++c) {
+          const double gv = ld(dtype, g, n * g_img_stride + ((long long)oh * Wo + ow) * ldg + c);
+          acc[((size_t)h0 * Wi + w0) * C + c] += (1 - lh) * (1 - lw) * gv;
+          acc[((size_t)h0 * Wi + w1) * C + c] += (1 - lh) * lw * gv;
+          acc[((size_t)h1 * Wi + w0) * C + c] += lh * (1 - lw) * gv;
+          acc[((size_t)h1 * Wi + w1) * C + c] += lh * lw * gv;
+        }
+      }
+    for (long long q = 0; q < (long long)Hi * Wi; ++q)
+      for (int c = 0; c < C; ++c) st(dtype, dx, n * dx_img_stride + q * lddx + c, acc[(size_t)q * C + c]);
+  }
+  free(acc);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_resize_bilinear_bwd);
+
+int uz_bilinear_bwd_ref(int dtype, const void* g, int ldg, long long g_img_stride, int N, int Hi, int Wi, int C, void* dx, int lddx,
+                        long long dx_img_stride, int Ho, int Wo, void* stream) {
+  return uz_resize_bilinear_bwd_ref(dtype, g, ldg, g_img_stride, N, Hi, Wi, C, dx, lddx, dx_img_stride, Ho, Wo, 0, stream);
+}
+UZ_SAME_SIGNATURE(uz_bilinear_bwd);
+
+/* nn.BCEWithLogitsLoss (mean) + its gradient + dice_coefficient of the thresholded prediction (scripts/train.py:135,
+ * utils/metrics.py:7-24: sigmoid > 0.5 i.e. logit > 0, epsilon 1e-7, 1.0 for an empty union) */
+long long uz_bce_dice_workspace_bytes_ref(long long n) {
+  (void)n;
+  return 64;
+}
+UZ_SAME_SIGNATURE(uz_bce_dice_workspace_bytes);
+
+int uz_bce_dice_ref(const float* logits, const float* target, long long n, float* dlogits, float* out2, void* workspace, void* stream) {
+  (void)workspace, (void)stream;
+  double loss = 0.0, inter = 0.0, sp = 0.0, stt = 0.0;
+  for (long long i = 0; i < n; ++i) {
+    const double x = logits[i], t = target[i];
+    loss += (x > 0.0 ? x : 0.0) - x * t + log1p(exp(-fabs(x)));
+    const double sg = 1.0 / (1.0 + exp(-x));
+    if (dlogits) dlogits[i] = (float)((sg - t) / (double)n);
+    const double pr = x > 0.0 ? 1.0 : 0.0;
+    inter += pr * t;
+    sp += pr;
+    stt += t;
+  }
+  out2[0] = (float)(loss / (double)n);
+  out2[1] = (sp + stt == 0.0) ? 1.0f : (float)((2.0 * inter + 1e-7) / (sp + stt + 1e-7));
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_bce_dice);
+
+/* nn.Dropout(p) in training mode on the caller's uniform draw (uctransnet.py:54; swin_unet_v2.py:158) */
+int uz_dropout_ref(int dtype, const void* x, int ldx, const float* u, float p, void* out, int ldo, long long P, int C, void* stream) {
+  (void)stream;
+  const float inv = 1.0f / (1.0f - p);
+  for (long long r = 0; r < P; ++r)
+    for (int c = 0; c < C; ++c) st(dtype, out, r * ldo + c, u[r * C + c] >= p ? (double)((float)ld(dtype, x, r * ldx + c) * inv) : 0.0);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_dropout);
+
+/* the gate of UCTransNet's CCA (uctransnet.py:417-427) and its two gradient forms */
+int uz_chanscale_relu_ref(int dtype, int mode, const void* g, int ldg, const void* x, int ldx, const float* s, const float* a, int N,
+                          int HW, int C, void* out, int ldo, void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (long long q = 0; q < HW; ++q)
+      for (int c = 0; c < C; ++c) {
+        const long long p = (long long)n * HW + q;
+        const double xv = ld(dtype, x, p * ldx + c), sv = s[(long long)n * C + c];
+        double v;
+        if (mode == 2) v = xv * sv > 0.0 ? (double)((float)xv * (float)sv) : 0.0;
+        else {
+          const double gv = xv > 0.0 ? ld(dtype, g, p * ldg + c) : 0.0;
+          v = mode == 0 ? gv * xv : gv * sv + (a ? (double)a[(long long)n * C + c] : 0.0);
+        }
+        st(dtype, out, p * ldo + c, v);
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_chanscale_relu);
+
+/* PatchEmbed's Conv2d(kernel = stride = patch) input as GEMM rows (swin_unet_v2.py:548-556) */
+int uz_patchify_ref(int dtype, const float* x_nchw, int N, int C, int H, int W, int patch, int Kpad, void* out, void* stream) {
+  (void)stream;
+  const int Hp = H / patch, Wp = W / patch;
+  for (int n = 0; n < N; ++n)
+    for (int i = 0; i < Hp; ++i)
+      for (int j = 0; j < Wp; ++j) {
+        const long long row = ((long long)n * Hp + i) * Wp + j;
+        for (int k = 0; k < Kpad; ++k) {
+          double v = 0.0;
+          if (k < patch * patch * C) {
+            const int c = k % C, kw = (k / C) % patch, kh = k / C / patch;
+            v = x_nchw[(((long long)n * C + c) * H + i * patch + kh) * W + j * patch + kw];
+          }
+          st(dtype, out, row * Kpad + k, v);
+        }
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_patchify);
+
+/* im2col of the NCHW fp32 network input for its first 3x3 convolution (unet.py:31): dst[p][t C + c], zero padded */
+int uz_im2col3x3_nchw_ref(int dtype, const float* x_nchw, int N, int C, int H, int W, int Kpad, void* dst, void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h)
+      for (int w = 0; w < W; ++w) {
+        const long long p = ((long long)n * H + h) * W + w;
+        for (int k = 0; k < Kpad; ++k) {
+          double v = 0.0;
+          if (k < 9 * C) {
+            const int t = k / C, c = k % C, hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = x_nchw[(((long long)n * C + c) * H + hh) * W + ww];
+          }
+          st(dtype, dst, p * Kpad + k, v);
+        }
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_im2col3x3_nchw);
+
+/* fixed-order row sums written where they are wanted (weight | bias gradient halves of a partial row) */
+int uz_sum_rows_f32_ld_ref(const float* partial, int ldp, int rows, int n, float* out0, int n0, float* out1, void* stream) {
+  (void)stream;
+  for (int e = 0; e < n; ++e) {
+    double t = 0.0;
+    for (int r = 0; r < rows; ++r) t += (double)partial[(long long)r * ldp + e];
+    if (e < n0) out0[e] = (float)t;
+    else out1[e - n0] = (float)t;
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_sum_rows_f32_ld);
+
+int uz_sum_rows_f32_ref(const float* partial, int rows, int n, float* out0, int n0, float* out1, void* stream) {
+  return uz_sum_rows_f32_ld_ref(partial, n, rows, n, out0, n0, out1, stream);
+}
+UZ_SAME_SIGNATURE(uz_sum_rows_f32);
+
+/* pixel-grid moves: copy into a concat slot / every second pixel (what a stride-2 convolution reads, common_layers.py:188) /
+ * that selection's gradient */
+int uz_resample2_ref(int dtype, const void* src, int lds, int N, int Hs, int Ws, int C, void* dst, int ldd, int Hd, int Wd, int mode,
+                     void* stream) {
+  (void)stream;
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < Hd; ++h)
+      for (int w = 0; w < Wd; ++w)
+        for (int c = 0; c < C; ++c) {
+          double v = 0.0;
+          if (mode == 0) v = ld(dtype, src, (((long long)n * Hs + h) * Ws + w) * lds + c);
+          else if (mode == 1) v = ld(dtype, src, (((long long)n * Hs + 2 * h) * Ws + 2 * w) * lds + c);
+          else if (!(h & 1) && !(w & 1)) v = ld(dtype, src, (((long long)n * Hs + h / 2) * Ws + w / 2) * lds + c);
+          st(dtype, dst, (((long long)n * Hd + h) * Wd + w) * ldd + c, v);
+        }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_resample2);
+
+/* ---- attention gate backward (attention_unet.py:34-40 under autograd; uz_attn.hip) -------------------------------------- */
+/* dx_direct = dOut psi;  dZ[p] = (sum_c dOut x) psi (1 - psi);  partial[0] = (sum dZ, sum dZ qhat) */
+int uz_attn_bwd_psi_ref(int dtype, const void* dout, int ldd, const void* x, int ldx, const float* q, const float* vec_q, int P, int C,
+                        void* dx_direct, int lddx, float* dz, float* partial, void* stream) {
+  (void)stream;
+  double a0 = 0.0, a1 = 0.0;
+  for (long long p = 0; p < P; ++p) {
+    const double z = (double)q[p] * vec_q[0] + vec_q[1], psi = 1.0 / (1.0 + exp(-z));
+    double dot = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const double d = ld(dtype, dout, p * ldd + c);
+      dot += d * ld(dtype, x, p * ldx + c);
+      st(dtype, dx_direct, p * lddx + c, d * psi);
+    }
+    dz[p] = (float)(dot * psi * (1.0 - psi));
+    a0 += (double)dz[p];
+    a1 += (double)dz[p] * ((double)q[p] - vec_q[2]) * vec_q[3];
+  }
+  partial[0] = (float)a0;
+  partial[1] = (float)a1;
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_attn_bwd_psi);
+
+/* dq = s_q (dZ - a0/P - qhat a1/P) (BatchNorm backward of the 1-channel psi map);  dPre = dq w_psi [G1 + X1 > 0];
+ * partial[0] = [B0 | B1 | D1 | W | sum dq]: sums of dPre, dPre ghat, dPre xhat, dq relu(G1 + X1) per channel */
+static double gate_dq(const float* q, const float* dz, const float* vec_q, const double* a01, int P, long long p) {
+  const double k0 = a01[0] / P, k1 = a01[1] / P;
+  return (double)vec_q[0] * ((double)dz[p] - k0 - ((double)q[p] - vec_q[2]) * vec_q[3] * k1);
+}
+
+int uz_attn_bwd_reduce_ref(int dtype, const void* g1raw, int ldg, const void* x1raw, int ldx, const float* q, const float* dz,
+                           const float* wpsi, const float* vec_g, const float* vec_x, const float* vec_q, const double* a01, int P,
+                           int F, float* partial, void* stream) {
+  (void)stream;
+  double* acc = (double*)calloc((size_t)4 * F + 1, sizeof(double));
+  if (!acc) return UZ_EINVAL;
+  for (long long p = 0; p < P; ++p) {
+    const double dq = gate_dq(q, dz, vec_q, a01, P, p);
+    for (int c = 0; c < F; ++c) {
+      const double gv = ld(dtype, g1raw, p * ldg + c), xv = ld(dtype, x1raw, p * ldx + c);
+      const double s = gv * vec_g[c] + vec_g[F + c] + xv * vec_x[c] + vec_x[F + c];
+      const double dpre = s > 0.0 ? dq * wpsi[c] : 0.0;
+      acc[c] += dpre;
+      acc[F + c] += dpre * (gv - vec_g[2 * F + c]) * vec_g[3 * F + c];
+      acc[2 * F + c] += dpre * (xv - vec_x[2 * F + c]) * vec_x[3 * F + c];
+      acc[3 * F + c] += dq * (s > 0.0 ? s : 0.0);
+    }
+    acc[4 * F] += dq;
+  }
+  for (int e = 0; e < 4 * F + 1; ++e) partial[e] = (float)acc[e];
+  free(acc);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_attn_bwd_reduce);
+
+/* dg1raw = s_g (dPre - B0/P - ghat B1/P),  dx1raw = s_x (dPre - B0/P - xhat D1/P): the two BatchNorm backwards */
+int uz_attn_bwd_apply_ref(int dtype, const void* g1raw, int ldg, const void* x1raw, int ldx, const float* q, const float* dz,
+                          const float* wpsi, const float* vec_g, const float* vec_x, const float* vec_q, const double* a01,
+                          const double* totals, int P, int F, void* dg1raw, int lddg, void* dx1raw, int lddx, void* stream) {
+  (void)stream;
+  for (long long p = 0; p < P; ++p) {
+    const double dq = gate_dq(q, dz, vec_q, a01, P, p);
+    for (int c = 0; c < F; ++c) {
+      const double gv = ld(dtype, g1raw, p * ldg + c), xv = ld(dtype, x1raw, p * ldx + c);
+      const double s = gv * vec_g[c] + vec_g[F + c] + xv * vec_x[c] + vec_x[F + c];
+      const double dpre = s > 0.0 ? dq * wpsi[c] : 0.0;
+      const double gh = (gv - vec_g[2 * F + c]) * vec_g[3 * F + c], xh = (xv - vec_x[2 * F + c]) * vec_x[3 * F + c];
+      st(dtype, dg1raw, p * lddg + c, vec_g[c] * (dpre - totals[c] / P - gh * totals[F + c] / P));
+      st(dtype, dx1raw, p * lddx + c, vec_x[c] * (dpre - totals[c] / P - xh * totals[2 * F + c] / P));
+    }
+  }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_attn_bwd_apply);
+
+/* ---- spatial-reduction attention (EfficientSelfAtten, missformer.py:21-39, :113-128): softmax(q k^T scale) v per (image, head),
+ * key j of image b at row ((j / kps) B + b) kps + j % kps ----------------------------------------------------------------- */
+static long long sra_krow(const uz_sra_desc* d, int b, int j) { return ((long long)(j / d->kps) * d->B + b) * d->kps + j % d->kps; }
+
+int uz_sra_fwd_ref(const uz_sra_desc* d, const void* q, const void* k, const void* v, void* out, float* lse, void* stream) {
+  (void)stream;
+  const int D = d->head_dim;
+  double* s = (double*)malloc((size_t)d->NK * sizeof(double));
+  if (!s) return UZ_EINVAL;
+  for (int b = 0; b < d->B; ++b)
+    for (int h = 0; h < d->heads; ++h)
+      for (int i = 0; i < d->N; ++i) {
+        const long long qr = (long long)b * d->N + i;
+        double m = -INFINITY;
+        for (int j = 0; j < d->NK; ++j) {
+          double acc = 0.0;
+          for (int e = 0; e < D; ++e) acc += ld(d->dtype, q, qr * d->ldq + h * D + e) * ld(d->dtype, k, sra_krow(d, b, j) * d->ldk + h * D + e);
+          s[j] = acc * d->scale;
+          if (s[j] > m) m = s[j];
+        }
+        double z = 0.0;
+        for (int j = 0; j < d->NK; ++j) z += exp(s[j] - m);
+        if (lse) lse[((long long)b * d->heads + h) * d->N + i] = (float)((m + log(z)) * 1.4426950408889634);   /* log2 units, as the kernels keep it */
+        for (int e = 0; e < D; ++e) {
+          double acc = 0.0;
+          for (int j = 0; j < d->NK; ++j) acc += exp(s[j] - m) / z * ld(d->dtype, v, sra_krow(d, b, j) * d->ldv + h * D + e);
+          st(d->dtype, out, qr * d->ldo + h * D + e, acc);
+        }
+      }
+  free(s);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_sra_fwd);
+
+long long uz_sra_bwd_workspace_bytes_ref(const uz_sra_desc* d) {
+  (void)d;
+  return 64;
+}
+UZ_SAME_SIGNATURE(uz_sra_bwd_workspace_bytes);
+
+/* dq = scale (P o (dP - delta)) K, dK = scale (P o (dP - delta))^T Q, dV = P^T dO, delta_i = dO_i . O_i (softmax backward with P
+ * recomputed from the kept log-sum-exp); dkv rows laid out like the kv tensor: [dK | dV] */
+int uz_sra_bwd_ref(const uz_sra_desc* d, const void* q, const void* k, const void* v, const void* o, const float* lse, const void* go,
+                   int ldgo, void* dq, int lddq, void* dkv, int lddkv, void* workspace, void* stream) {
+  (void)workspace, (void)stream;
+  const int D = d->head_dim, HD = d->heads * D;
+  const long long nkv = (long long)d->B * d->NK;
+  double* dK = (double*)calloc((size_t)nkv * HD * 2, sizeof(double));
+  if (!dK) return UZ_EINVAL;
+  double* dV = dK + (size_t)nkv * HD;
+  double* dqa = (double*)malloc((size_t)D * sizeof(double));
+  for (int b = 0; b < d->B; ++b)
+    for (int h = 0; h < d->heads; ++h)
+      for (int i = 0; i < d->N; ++i) {
+        const long long qr = (long long)b * d->N + i;
+        const double l = lse[((long long)b * d->heads + h) * d->N + i] * 0.6931471805599453;
+        double delta = 0.0;
+        for (int e = 0; e < D; ++e) delta += ld(d->dtype, go, qr * ldgo + h * D + e) * ld(d->dtype, o, qr * d->ldo + h * D + e);
+        for (int e = 0; e < D; ++e) dqa[e] = 0.0;
+        for (int j = 0; j < d->NK; ++j) {
+          const long long kr = sra_krow(d, b, j);
+          double sc = 0.0, dp = 0.0;
+          for (int e = 0; e < D; ++e) {
+            sc += ld(d->dtype, q, qr * d->ldq + h * D + e) * ld(d->dtype, k, kr * d->ldk + h * D + e);
+            dp += ld(d->dtype, go, qr * ldgo + h * D + e) * ld(d->dtype, v, kr * d->ldv + h * D + e);
+          }
+          const double pr = exp(sc * d->scale - l), ds = pr * (dp - delta) * d->scale;
+          for (int e = 0; e < D; ++e) {
+            dqa[e] += ds * ld(d->dtype, k, kr * d->ldk + h * D + e);
+            dK[(size_t)kr * HD + h * D + e] += ds * ld(d->dtype, q, qr * d->ldq + h * D + e);
+            dV[(size_t)kr * HD + h * D + e] += pr * ld(d->dtype, go, qr * ldgo + h * D + e);
+          }
+        }
+        for (int e = 0; e < D; ++e) st(d->dtype, dq, qr * lddq + h * D + e, dqa[e]);
+      }
+  for (long long r = 0; r < nkv; ++r)
+    for (int c = 0; c < HD; ++c) {
+      st(d->dtype, dkv, r * lddkv + c, dK[(size_t)r * HD + c]);
+      st(d->dtype, dkv, r * lddkv + HD + c, dV[(size_t)r * HD + c]);
+    }
+  free(dqa);
+  free(dK);
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_sra_bwd);
+
 int uz_ref_abi_version(void) { return 1; }

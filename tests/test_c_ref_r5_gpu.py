@@ -1,0 +1,325 @@
+"""GPU: the kernels of libunetzoo_hip.so against the round-5 restatements of oracle/uz_ref.c (pinned on the CPU by
+tests/test_c_ref_r5.py) on the same bytes and the same descriptors, called through the C ABI with device pointers.
+Element passes must agree to the bit or to one rounding of the tensor type; reductions to accumulation order."""
+from ctypes import byref
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_ref
+from unet_zoo_amd import _lib as L
+from unet_zoo_amd import ops
+from unet_zoo_amd.ops import Act
+from test_c_ref_gpu import DTS, agree, rnd
+
+DEV = "cuda"
+
+
+def npdt(dt):
+    return np.uint16 if dt == torch.bfloat16 else np.float32
+
+
+def dev(t):
+    return t.to(DEV).contiguous()
+
+
+def ok(rc, what=""):
+    assert rc == 0, (what, rc, L.last_error() if hasattr(L, "last_error") else "")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(8, 64, 128, 64, 64), (5, 120, 125, 32, 64)])     # >= 128 tiles of 16 x 32 pixels: the plan the XF form has
+def test_convolution_and_weight_gradient_through_batchnorm_relu_against_the_c_restatement(N, H, W, Cin, Cout):
+    """uz_conv_igemm_xf / uz_wgrad_xf (bf16 only: the fp32 run mode has no such kernel) against their restatements"""
+    dt = torch.bfloat16
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(81)
+    x = rnd((N * H * W, Cin), dt, g)
+    w = rnd((Cout, Cin, 3, 3), torch.float32, g, 0.1)
+    bias = torch.randn(Cout, generator=g)
+    scale = (torch.rand(Cin, generator=g) + 0.5) * torch.where(torch.rand(Cin, generator=g) < 0.2, -1.0, 1.0)
+    shift = torch.rand(Cin, generator=g) * 0.8 + 0.3
+    d = L.ConvDesc(L.dtype_code(dt), N, H, W, H, W, Cin, Cin, Cout, Cout, 9, L.TAPS_CONV, 1, L.STORE_PLAIN, 0, 0, 0)
+    if not lib.uz_conv_igemm_xf_supported(byref(d)):
+        pytest.fail("no input-transform plan for this shape")
+    xa = Act(dev(x), 0, Cin, N, H, W)
+    wp = ops.pack_weights(dev(w), L.PACK_CONV_FWD, dt)
+    ya = ops.new_act(N, H, W, Cout, dt, DEV)
+    st = ops.conv_igemm(xa, wp, dev(bias), ya, ntaps=9, want_stats=True, xform=(dev(scale), dev(shift)))
+    yr, sr = np.zeros(N * H * W * Cout, np.uint16), np.zeros(2 * Cout, np.float32)
+    xh, wh, sch, shh, bh = c_ref.host(x), c_ref.host(wp), c_ref.host(scale), c_ref.host(shift), c_ref.host(bias)
+    assert ref.uz_conv_igemm_xf_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(sch), c_ref.ptr(shh), c_ref.ptr(wh), c_ref.ptr(bh), c_ref.ptr(yr),
+                                    c_ref.ptr(sr), None) == 0
+    agree(ya.buf, c_ref.tensor(yr, dt).reshape(-1, Cout), dt, "conv_xf")
+    yd = ya.buf.double().cpu()
+    assert torch.allclose(st.double().sum(0).cpu()[0], yd.sum(0), rtol=1e-4, atol=1e-2)
+
+    gy = rnd((N * H * W, Cout), dt, g)
+    ga = Act(dev(gy), 0, Cout, N, H, W)
+    if W % 32:          # the row-walk weight gradient (and with it its XF form) takes whole 32-pixel strips only
+        assert not ops.wgrad_xform_supported(ga, xa, 9)
+        return
+    assert ops.wgrad_xform_supported(ga, xa, 9)
+    dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
+    ops.wgrad(ga, xa, (Cout, Cin, 3, 3), ntaps=9, out=dw, xform=(dev(scale), dev(shift)))
+    out = np.zeros(Cout * Cin * 9, np.float32)
+    dd = L.WgradDesc(L.dtype_code(dt), N, H, W, H, W, Cout, Cout, Cin, Cin, 9, L.TAPS_CONV, 1)
+    gh = c_ref.host(gy)
+    assert ref.uz_wgrad_xf_ref(byref(dd), c_ref.ptr(gh), c_ref.ptr(xh), c_ref.ptr(sch), c_ref.ptr(shh), c_ref.ptr(out), None, None, 0) == 0
+    want = torch.from_numpy(out).reshape(Cout, Cin, 3, 3).double()
+    err = ((dw.double().cpu() - want).abs().max() / want.abs().max()).item()
+    assert err < 1e-4, err          # same bf16 operands, fp32 accumulation order only
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("ceil_mode", [0, 1])
+def test_residual_apply_pool_and_pool_gradient_kernels_against_the_c_restatement(dt, ceil_mode):
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(82 + ceil_mode)
+    dc = L.dtype_code(dt)
+    N, H, W, C = 2, 23, 37, 64
+    P = N * H * W
+    Hp, Wp = ((H + 1) // 2, (W + 1) // 2) if ceil_mode else (H // 2, W // 2)
+    y, res = rnd((P, C), dt, g), rnd((P, C), dt, g)
+    scale, shift = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    yd, rd, sd, hd = dev(y), dev(res), dev(scale), dev(shift)
+    act, pooled = torch.zeros(P, C, dtype=dt, device=DEV), torch.zeros(N * Hp * Wp, C, dtype=dt, device=DEV)
+    ok(lib.uz_bn_relu_add_apply(dc, yd.data_ptr(), C, sd.data_ptr(), hd.data_ptr(), N, H, W, C, rd.data_ptr(), C, act.data_ptr(), C,
+                                pooled.data_ptr(), C, ceil_mode, None))
+    ar, pr = np.zeros(P * C, npdt(dt)), np.zeros(N * Hp * Wp * C, npdt(dt))
+    yh, rh, sch, shh = c_ref.host(y), c_ref.host(res), c_ref.host(scale), c_ref.host(shift)
+    assert ref.uz_bn_relu_add_apply_ref(dc, c_ref.ptr(yh), C, c_ref.ptr(sch), c_ref.ptr(shh), N, H, W, C, c_ref.ptr(rh), C, c_ref.ptr(ar), C,
+                                        c_ref.ptr(pr), C, ceil_mode, None) == 0
+    torch.cuda.synchronize()
+    agree(act, c_ref.tensor(ar, dt).reshape(P, C), dt, "bn_relu_add_apply")
+    agree(pooled, c_ref.tensor(pr, dt).reshape(-1, C), dt, "pooled")
+
+    # the gradient router on the kernel's own stored act (ties of the relu's zeros included)
+    g0, g1, gp = rnd((P, C), dt, g), rnd((P, C), dt, g), rnd((N * Hp * Wp, C), dt, g)
+    out = torch.zeros(P, C, dtype=dt, device=DEV)
+    g0d, g1d, gpd = dev(g0), dev(g1), dev(gp)
+    ok(lib.uz_pool_grad_combine(dc, N, H, W, C, act.data_ptr(), C, g0d.data_ptr(), C, g1d.data_ptr(), C, gpd.data_ptr(), C, out.data_ptr(), C,
+                                ceil_mode, None))
+    ah = c_ref.host(act)
+    orf = np.zeros(P * C, npdt(dt))
+    g0h, g1h, gph = c_ref.host(g0), c_ref.host(g1), c_ref.host(gp)
+    assert ref.uz_pool_grad_combine_ref(dc, N, H, W, C, c_ref.ptr(ah), C, c_ref.ptr(g0h), C, c_ref.ptr(g1h), C, c_ref.ptr(gph), C, c_ref.ptr(orf), C,
+                                        ceil_mode, None) == 0
+    agree(out, c_ref.tensor(orf, dt).reshape(P, C), dt, "pool_grad_combine")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("align", [0, 1])
+def test_bilinear_resize_backward_kernels_against_the_c_restatement(dt, align):
+    """both kernels behind uz_resize_bilinear_bwd: the 16-byte vector form (NHWC, C a multiple of the vector) and the wave
+    form (one-channel NCHW planes), enlarging and reducing"""
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(83)
+    dc = L.dtype_code(dt)
+    for (N, C, Hi, Wi, Ho, Wo) in [(2, 64, 9, 13, 18, 26), (2, 32, 20, 24, 7, 9), (3, 1, 11, 7, 44, 28), (2, 1, 40, 36, 10, 9)]:
+        gy = rnd((N * Ho * Wo, C), dt, g)
+        gd = dev(gy)
+        dx = torch.zeros(N * Hi * Wi, C, dtype=dt, device=DEV)
+        ok(lib.uz_resize_bilinear_bwd(dc, gd.data_ptr(), C, Ho * Wo * C, N, Hi, Wi, C, dx.data_ptr(), C, Hi * Wi * C, Ho, Wo, align, None))
+        gh = c_ref.host(gy)
+        dr = np.zeros(N * Hi * Wi * C, npdt(dt))
+        assert ref.uz_resize_bilinear_bwd_ref(dc, c_ref.ptr(gh), C, Ho * Wo * C, N, Hi, Wi, C, c_ref.ptr(dr), C, Hi * Wi * C, Ho, Wo, align, None) == 0
+        agree(dx, c_ref.tensor(dr, dt).reshape(-1, C), dt, f"resize bwd {C}ch {Hi}x{Wi}<-{Ho}x{Wo}")     # fp32: the kernel forms the weights in fp32
+        if not align:
+            dx2 = torch.zeros_like(dx)
+            ok(lib.uz_bilinear_bwd(dc, gd.data_ptr(), C, Ho * Wo * C, N, Hi, Wi, C, dx2.data_ptr(), C, Hi * Wi * C, Ho, Wo, None))
+            assert torch.equal(dx, dx2)
+
+
+def test_loss_kernel_against_the_c_restatement():
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(84)
+    for n in (16 * 256 * 256, 12345):
+        x, t = torch.randn(n, generator=g) * 3, (torch.rand(n, generator=g) > 0.6).float()
+        xd, td = dev(x), dev(t)
+        dl, out2 = torch.zeros(n, device=DEV), torch.zeros(2, device=DEV)
+        ws = torch.zeros(lib.uz_bce_dice_workspace_bytes(n) // 4 + 1, device=DEV)
+        ok(lib.uz_bce_dice(xd.data_ptr(), td.data_ptr(), n, dl.data_ptr(), out2.data_ptr(), ws.data_ptr(), None))
+        xh, th = c_ref.host(x), c_ref.host(t)
+        dr, o2 = np.zeros(n, np.float32), np.zeros(2, np.float32)
+        assert ref.uz_bce_dice_ref(c_ref.ptr(xh), c_ref.ptr(th), n, c_ref.ptr(dr), c_ref.ptr(o2), None, None) == 0
+        assert np.allclose(out2.cpu().numpy(), o2, rtol=2e-6)
+        assert np.allclose(dl.cpu().numpy(), dr, rtol=1e-5, atol=3e-7 / n)     # (sigmoid - t) / n: fp32 sigmoid next to t = 1
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_dropout_gate_and_row_sum_kernels_against_the_c_restatement(dt):
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(85)
+    dc = L.dtype_code(dt)
+    P, C, p = 777, 96, 0.1
+    x, u = rnd((P, C), dt, g), torch.rand(P, C, generator=g)
+    xd, ud = dev(x), dev(u)
+    out = torch.zeros(P, C, dtype=dt, device=DEV)
+    ok(lib.uz_dropout(dc, xd.data_ptr(), C, ud.data_ptr(), p, out.data_ptr(), C, P, C, None))
+    xh, uh = c_ref.host(x), c_ref.host(u)
+    orf = np.zeros(P * C, npdt(dt))
+    assert ref.uz_dropout_ref(dc, c_ref.ptr(xh), C, c_ref.ptr(uh), p, c_ref.ptr(orf), C, P, C, None) == 0
+    agree(out, c_ref.tensor(orf, dt).reshape(P, C), dt, "dropout")
+
+    N, HW = 3, 259
+    xg, gg = rnd((N * HW, C), dt, g), rnd((N * HW, C), dt, g)
+    s, a = torch.rand(N, C, generator=g) + 0.1, torch.randn(N, C, generator=g)
+    xgd, ggd, sd, ad = dev(xg), dev(gg), dev(s), dev(a)
+    xgh, ggh, sh, ah = c_ref.host(xg), c_ref.host(gg), c_ref.host(s), c_ref.host(a)
+    for mode in (2, 0, 1):
+        o = torch.zeros(N * HW, C, dtype=dt, device=DEV)
+        ok(lib.uz_chanscale_relu(dc, mode, ggd.data_ptr() if mode != 2 else None, C, xgd.data_ptr(), C, sd.data_ptr(),
+                                 ad.data_ptr() if mode == 1 else None, N, HW, C, o.data_ptr(), C, None))
+        orf = np.zeros(N * HW * C, npdt(dt))
+        assert ref.uz_chanscale_relu_ref(dc, mode, c_ref.ptr(ggh) if mode != 2 else None, C, c_ref.ptr(xgh), C, c_ref.ptr(sh),
+                                         c_ref.ptr(ah) if mode == 1 else None, N, HW, C, c_ref.ptr(orf), C, None) == 0
+        agree(o, c_ref.tensor(orf, dt).reshape(-1, C), dt, f"chanscale_relu mode {mode}")
+
+    if dt == torch.float32:
+        rows, n, n0, ld = 300, 200, 128, 333
+        part = torch.randn(rows, ld, generator=g)
+        pd = dev(part)
+        o0, o1 = torch.zeros(n0, device=DEV), torch.zeros(n - n0, device=DEV)
+        ok(lib.uz_sum_rows_f32_ld(pd.data_ptr(), ld, rows, n, o0.data_ptr(), n0, o1.data_ptr(), None))
+        ph = c_ref.host(part)
+        r0, r1 = np.zeros(n0, np.float32), np.zeros(n - n0, np.float32)
+        assert ref.uz_sum_rows_f32_ld_ref(c_ref.ptr(ph), ld, rows, n, c_ref.ptr(r0), n0, c_ref.ptr(r1), None) == 0
+        assert np.array_equal(o0.cpu().numpy(), r0) and np.array_equal(o1.cpu().numpy(), r1)      # double accumulation: exact
+        dense = part[:, :n].contiguous()
+        dd = dev(dense)
+        o2 = torch.zeros(n, device=DEV)
+        ok(lib.uz_sum_rows_f32(dd.data_ptr(), rows, n, o2.data_ptr(), n, None, None))
+        assert np.array_equal(o2.cpu().numpy(), np.concatenate([r0, r1]))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_input_gather_and_pixel_grid_kernels_against_the_c_restatement(dt):
+    """pure data movement: bit for bit"""
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(86)
+    dc = L.dtype_code(dt)
+    N, C, H, W, patch, Kpad = 2, 3, 64, 96, 4, 64
+    x = torch.randn(N, C, H, W, generator=g)
+    xd = dev(x)
+    xh = c_ref.host(x)
+    rows = N * (H // patch) * (W // patch)
+    out = torch.full((rows, Kpad), 7.0, dtype=dt, device=DEV)
+    ok(lib.uz_patchify(dc, xd.data_ptr(), N, C, H, W, patch, Kpad, out.data_ptr(), None))
+    orf = np.zeros(rows * Kpad, npdt(dt))
+    assert ref.uz_patchify_ref(dc, c_ref.ptr(xh), N, C, H, W, patch, Kpad, c_ref.ptr(orf), None) == 0
+    assert torch.equal(out.cpu(), c_ref.tensor(orf, dt).reshape(rows, Kpad))
+
+    Hc, Wc, Kp3 = 21, 50, 32
+    xs = torch.randn(N, C, Hc, Wc, generator=g)
+    xsd, xsh = dev(xs), c_ref.host(xs)
+    col = torch.full((N * Hc * Wc, Kp3), 7.0, dtype=dt, device=DEV)
+    ok(lib.uz_im2col3x3_nchw(dc, xsd.data_ptr(), N, C, Hc, Wc, Kp3, col.data_ptr(), None))
+    crf = np.zeros(N * Hc * Wc * Kp3, npdt(dt))
+    assert ref.uz_im2col3x3_nchw_ref(dc, c_ref.ptr(xsh), N, C, Hc, Wc, Kp3, c_ref.ptr(crf), None) == 0
+    assert torch.equal(col.cpu(), c_ref.tensor(crf, dt).reshape(-1, Kp3))
+
+    Hs, Ws, Cc = 17, 29, 32
+    Hd, Wd = (Hs + 1) // 2, (Ws + 1) // 2
+    src = rnd((N * Hs * Ws, Cc), dt, g)
+    sd, sh = dev(src), c_ref.host(src)
+    for mode, (ha, wa, hb, wb) in ((0, (Hs, Ws, Hs, Ws)), (1, (Hs, Ws, Hd, Wd)), (2, (Hd, Wd, Hs, Ws))):
+        s_rows, d_rows = N * ha * wa, N * hb * wb
+        o = torch.full((d_rows, Cc), 7.0, dtype=dt, device=DEV)
+        ok(lib.uz_resample2(dc, sd.data_ptr(), Cc, N, ha, wa, Cc, o.data_ptr(), Cc, hb, wb, mode, None))
+        r = np.zeros(d_rows * Cc, npdt(dt))
+        assert ref.uz_resample2_ref(dc, c_ref.ptr(sh), Cc, N, ha, wa, Cc, c_ref.ptr(r), Cc, hb, wb, mode, None) == 0
+        assert torch.equal(o.cpu(), c_ref.tensor(r, dt).reshape(d_rows, Cc)), mode
+        assert s_rows <= src.shape[0]
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_attention_gate_backward_kernels_against_the_c_restatement(dt):
+    """uz_attn_bwd_psi -> uz_attn_bwd_reduce -> uz_attn_bwd_apply (attention_unet.py:34-40 under autograd), each stage on the
+    inputs the kernel chain itself produced"""
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(87)
+    dc = L.dtype_code(dt)
+    N, H, W, Fi, C = 2, 24, 40, 32, 64
+    P = N * H * W
+    g1, x1, x, dout = rnd((P, Fi), dt, g), rnd((P, Fi), dt, g), rnd((P, C), dt, g), rnd((P, C), dt, g)
+    q = torch.randn(P, generator=g)
+    wpsi = torch.randn(Fi, generator=g) * 0.5
+
+    def rows(v):
+        m, var = v.double().mean(0), v.double().var(0, unbiased=False)
+        inv = 1 / torch.sqrt(var + 1e-5)
+        gam = torch.rand(v.shape[1], generator=g).double() + 0.5
+        return torch.stack([gam * inv, 0.1 - m * gam * inv, m, inv]).float()
+    vg, vx, vq = rows(g1), rows(x1), rows(q[:, None])
+    doa, xa = Act(dev(dout), 0, C, N, H, W), Act(dev(x), 0, C, N, H, W)
+    dxd = ops.new_act(N, H, W, C, dt, DEV)
+    dz, a01 = ops.attn_bwd_psi(doa, xa, dev(q), dev(vq), dxd)
+    h = c_ref.host
+    doh, xh, qh, vqh = h(dout), h(x), h(q), h(vq)
+    dxr, dzr, pr = np.zeros(P * C, npdt(dt)), np.zeros(P, np.float32), np.zeros(2, np.float32)
+    assert ref.uz_attn_bwd_psi_ref(dc, c_ref.ptr(doh), C, c_ref.ptr(xh), C, c_ref.ptr(qh), c_ref.ptr(vqh), P, C, c_ref.ptr(dxr), C, c_ref.ptr(dzr),
+                                   c_ref.ptr(pr), None) == 0
+    agree(dxd.buf, c_ref.tensor(dxr, dt).reshape(P, C), dt, "dx direct")
+    assert np.allclose(dz.cpu().numpy(), dzr, rtol=1e-4, atol=1e-5)
+    assert np.allclose(a01.cpu().numpy(), pr, rtol=1e-3, atol=1e-3)
+
+    ga, x1a = Act(dev(g1), 0, Fi, N, H, W), Act(dev(x1), 0, Fi, N, H, W)
+    dg, dx1 = ops.new_act(N, H, W, Fi, dt, DEV), ops.new_act(N, H, W, Fi, dt, DEV)
+    tot = ops.attn_bwd_branches(ga, x1a, dev(q), dz, dev(wpsi), dev(vg), dev(vx), dev(vq), a01, dg, dx1)
+    dzk, a01k = dz.cpu().numpy().copy(), a01.cpu().numpy().astype(np.float64).copy()
+    g1h, x1h, wh, vgh, vxh = h(g1), h(x1), h(wpsi), h(vg), h(vx)
+    red = np.zeros(4 * Fi + 1, np.float32)
+    assert ref.uz_attn_bwd_reduce_ref(dc, c_ref.ptr(g1h), Fi, c_ref.ptr(x1h), Fi, c_ref.ptr(qh), c_ref.ptr(dzk), c_ref.ptr(wh), c_ref.ptr(vgh),
+                                      c_ref.ptr(vxh), c_ref.ptr(vqh), c_ref.ptr(a01k), P, Fi, c_ref.ptr(red), None) == 0
+    tk = tot.cpu().numpy()
+    assert np.allclose(tk, red, rtol=2e-3, atol=2e-3 * np.abs(red).max()), np.abs(tk - red).max()
+    totk = tk.astype(np.float64).copy()
+    dgr, dxr1 = np.zeros(P * Fi, npdt(dt)), np.zeros(P * Fi, npdt(dt))
+    assert ref.uz_attn_bwd_apply_ref(dc, c_ref.ptr(g1h), Fi, c_ref.ptr(x1h), Fi, c_ref.ptr(qh), c_ref.ptr(dzk), c_ref.ptr(wh), c_ref.ptr(vgh),
+                                     c_ref.ptr(vxh), c_ref.ptr(vqh), c_ref.ptr(a01k), c_ref.ptr(totk), P, Fi, c_ref.ptr(dgr), Fi,
+                                     c_ref.ptr(dxr1), Fi, None) == 0
+    agree(dg.buf, c_ref.tensor(dgr, dt).reshape(P, Fi), dt, "d g1raw")
+    agree(dx1.buf, c_ref.tensor(dxr1, dt).reshape(P, Fi), dt, "d x1raw")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,Nq,heads,kps,blocks", [(2, 200, 2, 49, 1), (2, 96, 1, 25, 4)])
+def test_spatial_reduction_attention_kernels_against_the_c_restatement(dt, B, Nq, heads, kps, blocks):
+    ref = c_ref.load()
+    g = torch.Generator().manual_seed(88)
+    dc = L.dtype_code(dt)
+    D = 64
+    NK, HD = kps * blocks, heads * D
+    scale = D ** -0.5
+    q, kv, go = rnd((B * Nq, HD), dt, g), rnd((B * NK, 2 * HD), dt, g), rnd((B * Nq, HD), dt, g)
+    qa, kva, goa = Act(dev(q), 0, HD, B, 1, Nq), Act(dev(kv), 0, 2 * HD, B, 1, NK), Act(dev(go), 0, HD, B, 1, Nq)
+    out = ops.new_act(B, 1, Nq, HD, dt, DEV)
+    lse = ops.sra_fwd(qa, kva, out, B, heads, kps, scale)
+    d = L.SraDesc(dc, B, Nq, NK, heads, D, kps, HD, 2 * HD, 2 * HD, HD, scale)
+    h = c_ref.host
+    qh, kvh = h(q), h(kv)
+    orf, lr = np.zeros(B * Nq * HD, npdt(dt)), np.zeros(B * heads * Nq, np.float32)
+    vptr = kvh.ctypes.data + HD * kvh.itemsize
+    assert ref.uz_sra_fwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(kvh), vptr, c_ref.ptr(orf), c_ref.ptr(lr), None) == 0
+    want = c_ref.tensor(orf, dt).reshape(-1, HD)
+    if dt == torch.float32:
+        agree(out.buf, want, dt, "sra forward")
+    else:       # the MFMA kernel rounds the probabilities to bf16 for P V (every flash kernel does); the restatement keeps them
+        err = ((out.buf.double().cpu() - want.double()).abs().max() / want.double().abs().max()).item()      # in double
+        assert err < 1e-2, err
+    assert np.allclose(lse.cpu().numpy(), lr, rtol=1e-3, atol=1e-3)          # log2 units of the scaled scores, both
+
+    dq, dkv = ops.new_act(B, 1, Nq, HD, dt, DEV), ops.new_act(B, 1, NK, 2 * HD, dt, DEV)
+    ops.sra_bwd(qa, kva, out, lse, goa, dq, dkv, B, heads, kps, scale)
+    oh, goh = h(out.buf), h(go)
+    lk = lse.cpu().numpy().copy()
+    dqr, dkvr = np.zeros(B * Nq * HD, npdt(dt)), np.zeros(B * NK * 2 * HD, npdt(dt))
+    assert ref.uz_sra_bwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(kvh), vptr, c_ref.ptr(oh), c_ref.ptr(lk), c_ref.ptr(goh), HD, c_ref.ptr(dqr), HD,
+                              c_ref.ptr(dkvr), 2 * HD, None, None) == 0
+    for got, want, what in ((dq.buf, dqr, "dq"), (dkv.buf, dkvr, "dkv")):
+        want = c_ref.tensor(want, dt).reshape(got.shape).double()
+        err = ((got.double().cpu() - want).abs().max() / want.abs().max()).item()
+        assert err < (1e-4 if dt == torch.float32 else 2e-2), (what, err)
