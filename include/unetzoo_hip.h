@@ -328,6 +328,16 @@ int uz_bn_relu_apply(int dtype, const void* y, int ldy, const float* scale, cons
 int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const float* scale, const float* shift,
                          int N, int H, int W, int C, const void* res, int ldr, void* act, int lda,
                          void* pooled, int ldp, int pool_ceil, void* stream);
+/* uz_bn_finalize + uz_bn_relu_add_apply in ONE launch (training forward of Conv -> BatchNorm -> ReLU, common_layers.py:28-33):
+ * the first workgroups of the element pass sum the `rows` partial rows (same order as uz_bn_finalize: the same bits), write
+ * vec = [scale | shift | mean | invstd] (4 C floats) and the running statistics, and release a flag the other workgroups wait
+ * for before they read scale / shift.  *flag must be 0 at launch (one int per call, the caller clears its flag arena once per
+ * step) and is left at the number of finalizing workgroups.  Where the grid is smaller than the finalize (a few pixels, many
+ * channels) the two launches are issued instead and the flag is not touched. */
+int uz_bn_relu_add_apply_fin(int dtype, const void* y, int ldy, const float* stats_partial, int rows, double count,
+                             const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                             float* running_var, float* vec, int* flag, int N, int H, int W, int C, const void* res, int ldr,
+                             void* act, int lda, void* pooled, int ldp, int pool_ceil, void* stream);
 /* pool_ceil = 1: pooled is (N, ceil(H/2), ceil(W/2), C), border windows clipped (ceil_mode=True, u2net.py:30);
  * pool_ceil = 0: pooled is (N, H/2, W/2, C), an odd last row / column is not pooled (MaxPool2d default). */
 
@@ -362,6 +372,17 @@ int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const float* sca
                          const float* shift, const float* mean, const float* invstd, const void* g0,
                          const void* g1, const void* gpool, const double* sums, double count,
                          void* dy, void* stream);
+/* Pass 1 alone: the partial rows [rows][2][C] into `workspace`, rows = uz_bn_relu_bwd_workspace_bytes() / (8 C); and
+ * uz_bn_bwd_finalize + uz_bn_relu_bwd_apply in ONE launch over such rows (from uz_bn_relu_bwd_reduce_rows, uz_conv_igemm_bnred
+ * or uz_outconv_bwd_bnred): the flag protocol of uz_bn_relu_add_apply_fin; sums / dgamma / dbeta are written as by
+ * uz_bn_bwd_finalize (same order of additions). */
+int uz_bn_relu_bwd_reduce_rows(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const void* g0, const void* g1, const void* gpool,
+                               void* workspace, void* stream);
+int uz_bn_relu_bwd_apply_fin(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const void* g0, const void* g1, const void* gpool,
+                             const float* partial, int rows, double* sums, float* dgamma, float* dbeta, int* flag,
+                             double count, void* dy, void* stream);
 /* The finalize half of uz_bn_relu_bwd_reduce() alone: sums[2][C] (double), dbeta = sums[0], dgamma = sums[1] from
  * `rows` partial rows [rows][2][C] written by uz_conv_igemm_bnred(). */
 int uz_bn_bwd_finalize(const float* partial, int rows, int C, double* sums, float* dgamma, float* dbeta, void* stream);

@@ -10,7 +10,8 @@ import torch
 import unet_zoo_amd
 from unet_zoo_amd.engine import Engine
 
-VARIANTS = [("fold BN apply (xf)", dict(fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+VARIANTS = [("finalize in consumer", dict(fuse_bn_finalize=True, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+            ("fold BN apply (xf)", dict(fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
             ("fused conv + convT", dict(fold_bn_apply=False, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
             ("fused conv only", dict(fuse_bn_reduce=True, fuse_bn_reduce_convt=False)),
             ("two-pass everywhere", dict(fuse_bn_reduce=False, fuse_bn_reduce_convt=False))]

@@ -32,7 +32,7 @@ EXPORTS = (
     "uz_colsum",
     "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd", "uz_attn_bwd_psi", "uz_attn_bwd_reduce",
     "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum_rows_f32", "uz_sum2x2",
-    "uz_bn_relu_add_apply", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_resize_bilinear_fwd", "uz_resize_bilinear_bwd", "uz_resample2",
+    "uz_bn_relu_add_apply", "uz_bn_relu_add_apply_fin", "uz_bn_relu_bwd_reduce_rows", "uz_bn_relu_bwd_apply_fin", "uz_bilinear_fwd", "uz_bilinear_bwd", "uz_resize_bilinear_fwd", "uz_resize_bilinear_bwd", "uz_resample2",
     "uz_pool_grad_combine",
     "uz_sideconv3x3_fwd", "uz_sideconv3x3_bwd_workspace_bytes", "uz_sideconv3x3_bwd",
     "uz_fuse1x1_fwd", "uz_fuse1x1_bwd_workspace_bytes", "uz_fuse1x1_bwd",
@@ -231,6 +231,11 @@ def load():
     lib.uz_sum2x2.argtypes = [ip, vp, ip, ip, ip, ip, ip, vp, ip, vp]
     ll = ctypes.c_longlong
     lib.uz_bn_relu_add_apply.argtypes = [ip, vp, ip, vp, vp, ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, ip, vp]
+    lib.uz_bn_relu_add_apply_fin.argtypes = [ip, vp, ip, vp, ip, ctypes.c_double, vp, vp, c_float, c_float, vp, vp, vp, vp,
+                                             ip, ip, ip, ip, vp, ip, vp, ip, vp, ip, ip, vp]
+    lib.uz_bn_relu_bwd_reduce_rows.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.uz_bn_relu_bwd_apply_fin.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, ip, vp, vp, vp, vp,
+                                             ctypes.c_double, vp, vp]
     lib.uz_bilinear_fwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, vp]
     lib.uz_bilinear_bwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, vp]
     lib.uz_resize_bilinear_fwd.argtypes = [ip, vp, ip, ll, ip, ip, ip, ip, vp, ip, ll, ip, ip, ip, vp]

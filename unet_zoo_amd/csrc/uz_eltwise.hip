@@ -76,6 +76,141 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// A finalize INSIDE its consumer's launch (uz_bn_relu_add_apply_fin, uz_bn_relu_bwd_apply_fin; round 5).  The finalize
+// kernels above are 5 us launches between two large kernels, 36 of them per unet step and 448 per u2net step, and they
+// cannot be batched: each sits on the dependency chain between the kernel that produced the partial rows and the element
+// pass that needs the result.  Here the first `nfin` workgroups of the element pass do the finalize's work -- the same row
+// groups and the same pairing tree as bn_finalize_kernel<EW> / bn_bwd_finalize_kernel<EW>, 256 threads standing in for its
+// 1024, so the same bits -- publish the vectors and add 1 to a flag with release order; every workgroup then waits for
+// flag == nfin with acquire order before it reads them.  Workgroups are dispatched in index order, so the finalizing
+// ones are resident before any waiting one: the wait cannot starve them.  The flag must be zero at launch (the caller's
+// per-step memset of its flag arena) and is left at nfin.
+// ------------------------------------------------------------------------------------------
+constexpr int FIN_SH_DOUBLES = 2 * 128 * 9;   // EW = 8: [2][128][9]; EW = 32: [2][32][33] is smaller
+
+template <int EW>
+__device__ __forceinline__ void fin_row_sums(const float* __restrict__ part, int rows, int C, int blk, int tid, double* sh) {
+  constexpr int NG = 1024 / EW, LD = EW + 1, GS = 256 / EW;
+  // thread tid stands for the finalize kernel's threads tid + 256 k, k = 0..3: the same channel (256 is a multiple of EW), row
+  // groups tid / EW + k GS.  The loads of the four are issued together (one after the other they were 8 memory round trips on
+  // the critical path of the whole launch); each keeps its own order of additions.
+  const int cl = tid % EW, g0 = tid / EW, c = blk * EW + cl;
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C) {
+    for (int r0 = g0; r0 < rows; r0 += NG) {
+      float x1[4], x2[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k * GS;
+        const int rc = r < rows ? r : 0;
+        x1[k] = part[((size_t)rc * 2 + 0) * C + c];
+        x2[k] = part[((size_t)rc * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r0 + k * GS < rows) {
+          a1[k] += (double)x1[k];
+          a2[k] += (double)x2[k];
+        }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sh[(0 * NG + g0 + k * GS) * LD + cl] = a1[k];
+    sh[(1 * NG + g0 + k * GS) * LD + cl] = a2[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = NG / 2; st > 0; st >>= 1) {
+    for (int v = tid; v < st * EW; v += 256) {
+      const int vl = v % EW, g = v / EW;
+      sh[(0 * NG + g) * LD + vl] += sh[(0 * NG + g + st) * LD + vl];
+      sh[(1 * NG + g) * LD + vl] += sh[(1 * NG + g + st) * LD + vl];
+    }
+    __syncthreads();
+  }
+}
+
+struct BnFin {
+  const float* part;   // [rows][2][C] as the producing kernel left them
+  int rows, ew;        // ew: 8 or 32, the choice uz_bn_finalize / uz_bn_bwd_finalize make for this shape
+  double count;
+  const float *gamma, *beta;
+  float eps, momentum;
+  float *running_mean, *running_var;   // may be null
+  float* vec;          // forward: [4][C] = scale, shift, mean, invstd (out)
+  double* sums;        // backward: [2][C] (out)
+  float *dgamma, *dbeta;   // backward (out, may be null)
+  int* flag;
+};
+
+// The hand-over uses no cache-wide fence.  (Measured: an acquire LOAD in the poll loop -- a cache invalidate per poll -- ran
+// the unet step at 10.3 ms instead of 6.3; relaxed polls + one agent-scope release / acquire fence per workgroup still cost
+// ~17 us per launch: 2048 workgroups each invalidating their XCD's L2 under the streaming loads of the others.)  Instead the
+// few words handed over are themselves written and read at agent scope -- relaxed atomic stores / loads, i.e. sc1 accesses
+// that are coherent across the XCDs' L2s -- and ordered by waiting for the stores' completion before the flag add.
+#ifndef UZ_FIN_SLEEP
+#define UZ_FIN_SLEEP 4
+#endif
+template <typename V> __device__ __forceinline__ void fin_store(V* p, V v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename V> __device__ __forceinline__ V fin_load(const V* p) {
+  return __hip_atomic_load(const_cast<V*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fin_publish(int* flag, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the coherence point
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fin_wait(int* flag, int nfin, int tid) {
+  if (tid == 0)
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfin) __builtin_amdgcn_s_sleep(UZ_FIN_SLEEP);
+  __syncthreads();
+}
+
+// forward: what bn_finalize_kernel<EW> block `blk` does
+template <int EW>
+__device__ __forceinline__ void fin_forward(const BnFin& f, int C, int blk, int tid, double* sh) {
+  constexpr int NG = 1024 / EW, LD = EW + 1;
+  fin_row_sums<EW>(f.part, f.rows, C, blk, tid, sh);
+  const int c = blk * EW + tid;
+  if (tid < EW && c < C) {
+    const double t1 = sh[(0 * NG) * LD + tid], t2 = sh[(1 * NG) * LD + tid];
+    const double m = t1 / f.count;
+    double var = t2 / f.count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double istd = 1.0 / sqrt(var + (double)f.eps);
+    fin_store(f.vec + c, (float)((double)f.gamma[c] * istd));          // scale, shift: read by the waiting workgroups
+    fin_store(f.vec + C + c, (float)((double)f.beta[c] - m * (double)f.gamma[c] * istd));
+    f.vec[2 * C + c] = (float)m;                                       // mean, invstd: for the backward's launches
+    f.vec[3 * C + c] = (float)istd;
+    if (f.running_mean != nullptr) {
+      const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+      f.running_mean[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_mean[c] + (double)f.momentum * m);
+      f.running_var[c] = (float)((1.0 - (double)f.momentum) * (double)f.running_var[c] + (double)f.momentum * unbiased);
+    }
+  }
+}
+
+// backward: what bn_bwd_finalize_kernel<EW> block `blk` does
+template <int EW>
+__device__ __forceinline__ void fin_backward(const BnFin& f, int C, int blk, int tid, double* sh) {
+  constexpr int NG = 1024 / EW, LD = EW + 1;
+  fin_row_sums<EW>(f.part, f.rows, C, blk, tid, sh);
+  const int c = blk * EW + tid;
+  if (tid < EW && c < C) {
+    const double t1 = sh[(0 * NG) * LD + tid], t2 = sh[(1 * NG) * LD + tid];
+    fin_store(f.sums + c, t1);
+    fin_store(f.sums + C + c, t2);
+    if (f.dgamma != nullptr) {
+      f.dbeta[c] = (float)t1;
+      f.dgamma[c] = (float)t2;
+    }
+  }
+}
+
 __global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* beta, const float* rm,
                                      const float* rv, float eps, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,11 +227,28 @@ __global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* bet
 // x VEC channels; consecutive threads walk the channel chunks of one pixel/window first, so each
 // wave-instruction reads whole contiguous pixel rows.
 // ------------------------------------------------------------------------------------------
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
-    const T* __restrict__ y, int ldy, const float* __restrict__ scale, const float* __restrict__ shift,
+    const T* __restrict__ y, int ldy, const float* scale, const float* shift,
     int N, int H, int W, int C, T* __restrict__ act, int lda, T* __restrict__ pooled, int ldp,
-    const T* __restrict__ res, int ldr, int pool_ceil) {
+    const T* __restrict__ res, int ldr, int pool_ceil, const BnFin fin) {
+  const float* fin_tab = nullptr;
+  if constexpr (FIN) {   // scale = fin.vec, shift = fin.vec + C: written by the first workgroups of THIS launch
+    __shared__ double fin_sh[FIN_SH_DOUBLES];
+    const int nfin = (C + fin.ew - 1) / fin.ew;
+    if ((int)blockIdx.x < nfin) {
+      if (fin.ew == 8) fin_forward<8>(fin, C, blockIdx.x, threadIdx.x, fin_sh);
+      else fin_forward<32>(fin, C, blockIdx.x, threadIdx.x, fin_sh);
+      fin_publish(fin.flag, threadIdx.x);
+    }
+    fin_wait(fin.flag, nfin, threadIdx.x);
+    // scale | shift (2 C floats, written a moment ago by other workgroups of this launch) by coherent loads into LDS once;
+    // the loop below reads them there (coherent loads in the loop: 133 us instead of 43 at 64 channels x 1 M pixels)
+    float* tab = reinterpret_cast<float*>(fin_sh);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) tab[i] = fin_load(fin.vec + i);
+    __syncthreads();
+    fin_tab = tab;
+  }
   // res != nullptr: act = relu(bn(y)) + res (the RSU residual, u2net.py:74), pooled = maxpool(act).
   // Windows are enumerated on the ceil grid so that every pixel is visited once; a window clipped by an odd
   // border is pooled only in ceil mode (MaxPool2d(2, 2, ceil_mode=True), u2net.py:30) and dropped in floor mode.
@@ -113,10 +265,18 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
     const long long u = idx / CC;
     const int c0 = cc * VEC;
     float sc[VEC], sh[VEC];
+    if constexpr (FIN) {
 #pragma unroll
-    for (int i = 0; i < VEC; i += 4) {
-      *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(scale + c0 + i);
-      *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(shift + c0 + i);
+      for (int i = 0; i < VEC; i += 4) {
+        *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(fin_tab + c0 + i);
+        *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(fin_tab + C + c0 + i);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VEC; i += 4) {
+        *reinterpret_cast<float4*>(sc + i) = *reinterpret_cast<const float4*>(scale + c0 + i);
+        *reinterpret_cast<float4*>(sh + i) = *reinterpret_cast<const float4*>(shift + c0 + i);
+      }
     }
     if constexpr (!POOL) {
       float v[VEC];
@@ -184,11 +344,34 @@ struct BnBwdArgs {
   float* dbeta;
   double inv_count;
   int N, H, W, C, ldy, ldg0, ldg1, ldgp, lddy, pool_ceil;
+  BnFin fin;           // FIN launches of pass 2: the totals are formed by the first workgroups of the launch itself
 };
 
-template <typename T, bool POOL, int PASS>
+template <typename T, bool POOL, int PASS, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
   constexpr int VEC = ElemTraits<T>::VEC;
+  const double* fin_tab = nullptr;
+  if constexpr (FIN) {
+    static_assert(PASS == 2, "the fused finalize belongs to the apply pass");
+    __shared__ double fin_sh[FIN_SH_DOUBLES];
+    const int nfin = (a.C + a.fin.ew - 1) / a.fin.ew;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x, tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (wg < nfin) {
+      if (a.fin.ew == 8) fin_backward<8>(a.fin, a.C, wg, tid, fin_sh);
+      else fin_backward<32>(a.fin, a.C, wg, tid, fin_sh);
+      fin_publish(a.fin.flag, tid);
+    }
+    fin_wait(a.fin.flag, nfin, tid);
+    // the totals of this workgroup's channel slice by coherent loads into LDS once (every thread loading its own 16 doubles
+    // that way was 67 M loads past the caches per launch)
+    const int cw = blockDim.x * VEC, cb = blockIdx.y * cw;
+    for (int i = tid; i < 2 * cw; i += 256) {
+      const int which = i / cw, j = i - which * cw;
+      fin_sh[i] = cb + j < a.C ? fin_load(a.sums + (size_t)which * a.C + cb + j) : 0.0;
+    }
+    __syncthreads();
+    fin_tab = fin_sh;
+  }
   // a 2x2 pooling window, or (no pool) four pixels one grid stride apart: either way a thread has its 8-12
   // sixteen-byte loads of an iteration in flight together (one pixel per iteration ran the reduce pass at 3.2 TB/s)
   constexpr int NPIX = 4;
@@ -215,8 +398,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
     mu[i] = a.mean[c0 + i];
     is[i] = a.invstd[c0 + i];
     if (PASS == 2) {
-      k0[i] = (float)(a.sums[c0 + i] * a.inv_count);
-      k1[i] = (float)(a.sums[a.C + c0 + i] * a.inv_count);
+      if constexpr (FIN) {
+        k0[i] = (float)(fin_tab[threadIdx.x * VEC + i] * a.inv_count);
+        k1[i] = (float)(fin_tab[blockDim.x * VEC + threadIdx.x * VEC + i] * a.inv_count);
+      } else {
+        k0[i] = (float)(a.sums[c0 + i] * a.inv_count);
+        k1[i] = (float)(a.sums[a.C + c0 + i] * a.inv_count);
+      }
     }
   }
   float S0[VEC], S1[VEC];
@@ -995,11 +1183,11 @@ static int bn_relu_apply_t(const void* y, int ldy, const float* scale, const flo
   if (pooled != nullptr) {
     const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)pooled, ldp, (const T*)res, ldr, pool_ceil);
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)pooled, ldp, (const T*)res, ldr, pool_ceil, BnFin{});
   } else {
     const long long total = (long long)N * H * W * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 2);
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 2, BnFin{});
   }
   UZ_LAUNCH_CHECK("uz_bn_relu_apply");
   return UZ_OK;
@@ -1033,6 +1221,60 @@ extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const flo
                           : bn_relu_apply_t<float>(y, ldy, scale, shift, N, H, W, C, act, lda, pooled, ldp, res, ldr, pool_ceil, s);
 }
 
+static inline int fin_ew(int rows, int C) { return (rows >= 128 && C <= 512) ? 8 : 32; }   // as uz_bn_finalize chooses
+
+template <typename T>
+static int bn_relu_apply_fin_t(const void* y, int ldy, const BnFin& fin, int N, int H, int W, int C, void* act, int lda,
+                               void* pooled, int ldp, const void* res, int ldr, int pool_ceil, hipStream_t s, bool* done) {
+  constexpr int VEC = ElemTraits<T>::VEC;
+  const bool pool = pooled != nullptr;
+  const long long total = (pool ? (long long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long long)N * H * W) * (C / VEC);
+  const int grid = grid_for(total, 256);
+  *done = grid >= (C + fin.ew - 1) / fin.ew && 2 * C <= 2 * FIN_SH_DOUBLES;   // the table of the waiting workgroups: 2 C floats
+  if (!*done) return UZ_OK;
+  if (pool)
+    hipLaunchKernelGGL((bn_relu_apply_kernel<T, true, true>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, fin.vec, fin.vec + C, N,
+                       H, W, C, (T*)act, lda, (T*)pooled, ldp, (const T*)res, ldr, pool_ceil, fin);
+  else
+    hipLaunchKernelGGL((bn_relu_apply_kernel<T, false, true>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, fin.vec, fin.vec + C,
+                       N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 2, fin);
+  UZ_LAUNCH_CHECK("uz_bn_relu_add_apply_fin");
+  return UZ_OK;
+}
+
+extern "C" int uz_bn_relu_add_apply_fin(int dtype, const void* y, int ldy, const float* stats_partial, int rows, double count,
+                                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                        float* running_var, float* vec, int* flag, int N, int H, int W, int C, const void* res,
+                                        int ldr, void* act, int lda, void* pooled, int ldp, int pool_ceil, void* stream) {
+  UZ_REQUIRE(dtype == UZ_F32 || dtype == UZ_BF16, "uz_bn_relu_add_apply_fin: bad dtype");
+  const int vecw = dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(y && act && stats_partial && gamma && beta && vec && flag, "uz_bn_relu_add_apply_fin: null pointer");
+  UZ_REQUIRE(rows > 0 && count > 0, "uz_bn_relu_add_apply_fin: bad statistics shape");
+  UZ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "uz_bn_relu_add_apply_fin: running stats");
+  UZ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % vecw == 0, "uz_bn_relu_add_apply_fin: C=%d must be a multiple of %d", C, vecw);
+  UZ_REQUIRE(ldy % vecw == 0 && lda % vecw == 0 && ldy >= C && lda >= C, "uz_bn_relu_add_apply_fin: bad ld");
+  if (res != nullptr) UZ_REQUIRE(ldr % vecw == 0 && ldr >= C, "uz_bn_relu_add_apply_fin: bad ldr");
+  if (pooled != nullptr) {
+    UZ_REQUIRE(pool_ceil || (H >= 2 && W >= 2), "uz_bn_relu_add_apply_fin: floor-mode pool of a %dx%d map is empty", H, W);
+    UZ_REQUIRE(ldp % vecw == 0 && ldp >= C, "uz_bn_relu_add_apply_fin: bad ldp");
+  }
+  BnFin fin{};
+  fin.part = stats_partial; fin.rows = rows; fin.ew = fin_ew(rows, C); fin.count = count;
+  fin.gamma = gamma; fin.beta = beta; fin.eps = eps; fin.momentum = momentum;
+  fin.running_mean = running_mean; fin.running_var = running_var; fin.vec = vec; fin.flag = flag;
+  hipStream_t s = (hipStream_t)stream;
+  bool done = false;
+  const int rc = dtype == UZ_BF16
+      ? bn_relu_apply_fin_t<bf16_t>(y, ldy, fin, N, H, W, C, act, lda, pooled, ldp, res, ldr, pool_ceil, s, &done)
+      : bn_relu_apply_fin_t<float>(y, ldy, fin, N, H, W, C, act, lda, pooled, ldp, res, ldr, pool_ceil, s, &done);
+  if (rc != UZ_OK || done) return rc;
+  // a grid smaller than the finalize (a map of a few pixels with many channels): the two launches
+  const int rc2 = uz_bn_finalize(stats_partial, rows, C, count, gamma, beta, eps, momentum, running_mean, running_var, vec,
+                                 vec + C, vec + 2 * C, vec + 3 * C, stream);
+  if (rc2 != UZ_OK) return rc2;
+  return uz_bn_relu_add_apply(dtype, y, ldy, vec, vec + C, N, H, W, C, res, ldr, act, lda, pooled, ldp, pool_ceil, stream);
+}
+
 static int bnbwd_check(const uz_bnbwd_desc* d, const void* g0, const void* g1, const void* gp) {
   UZ_REQUIRE(d != nullptr, "uz_bn_relu_bwd: null descriptor");
   UZ_REQUIRE(d->dtype == UZ_F32 || d->dtype == UZ_BF16, "uz_bn_relu_bwd: bad dtype");
@@ -1055,16 +1297,20 @@ static void bnbwd_shape(const uz_bnbwd_desc* d, bool pool, dim3* grid, dim3* blo
   reduce_shape(d->C / vec, units, grid, block, pass == 2 ? 8 : (f == 2 ? 8 : f == 4 ? 6 : 4));
 }
 
-template <typename T, int PASS>
+template <typename T, int PASS, bool FIN = false>
 static int bnbwd_launch(const uz_bnbwd_desc* d, const BnBwdArgs& a, bool pool, hipStream_t s) {
   constexpr int VEC = ElemTraits<T>::VEC;
   dim3 grid, block;
   bnbwd_shape(d, pool, &grid, &block, PASS);
   const size_t shm = PASS == 1 ? (size_t)256 * 2 * VEC * sizeof(float) : 0;
+  if constexpr (FIN) {
+    UZ_REQUIRE((long long)grid.x * grid.y >= (a.C + a.fin.ew - 1) / a.fin.ew && block.x * block.y == 256,
+               "uz_bn_relu_bwd_apply_fin: the grid is smaller than the finalize (ask uz_bn_relu_bwd_apply_fin_supported)");
+  }
   if (pool) {
-    hipLaunchKernelGGL((bn_relu_bwd_kernel<T, true, PASS>), grid, block, shm, s, a);
+    hipLaunchKernelGGL((bn_relu_bwd_kernel<T, true, PASS, FIN>), grid, block, shm, s, a);
   } else {
-    hipLaunchKernelGGL((bn_relu_bwd_kernel<T, false, PASS>), grid, block, shm, s, a);
+    hipLaunchKernelGGL((bn_relu_bwd_kernel<T, false, PASS, FIN>), grid, block, shm, s, a);
   }
   UZ_LAUNCH_CHECK("uz_bn_relu_bwd");
   return UZ_OK;
@@ -1098,6 +1344,7 @@ static BnBwdArgs bnbwd_args(const uz_bnbwd_desc* d, const void* y, const float* 
   a.ldgp = d->ldgp;
   a.pool_ceil = d->pool_ceil;
   a.lddy = d->lddy;
+  a.fin = BnFin{};
   return a;
 }
 
@@ -1164,6 +1411,49 @@ extern "C" int uz_bn_relu_bwd_apply(const uz_bnbwd_desc* d, const void* y, const
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 2>(d, a, gpool != nullptr, s)
                              : bnbwd_launch<float, 2>(d, a, gpool != nullptr, s);
+}
+
+// the first pass alone: partial rows [rows][2][C] into the workspace, rows = uz_bn_relu_bwd_workspace_bytes / (8 C)
+extern "C" int uz_bn_relu_bwd_reduce_rows(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift,
+                                          const float* mean, const float* invstd, const void* g0, const void* g1,
+                                          const void* gpool, void* workspace, void* stream) {
+  const int rc = bnbwd_check(d, g0, g1, gpool);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(y && scale && shift && mean && invstd && workspace, "uz_bn_relu_bwd_reduce_rows: null pointer");
+  BnBwdArgs a = bnbwd_args(d, y, scale, shift, mean, invstd, g0, g1, gpool);
+  a.partials = static_cast<float*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 1>(d, a, gpool != nullptr, s) : bnbwd_launch<float, 1>(d, a, gpool != nullptr, s);
+}
+
+extern "C" int uz_bn_relu_bwd_apply_fin(const uz_bnbwd_desc* d, const void* y, const float* scale, const float* shift,
+                                        const float* mean, const float* invstd, const void* g0, const void* g1,
+                                        const void* gpool, const float* partial, int rows, double* sums, float* dgamma,
+                                        float* dbeta, int* flag, double count, void* dy, void* stream) {
+  const int rc = bnbwd_check(d, g0, g1, gpool);
+  if (rc != UZ_OK) return rc;
+  UZ_REQUIRE(y && scale && shift && mean && invstd && sums && dy && partial && flag, "uz_bn_relu_bwd_apply_fin: null pointer");
+  UZ_REQUIRE(count > 0 && rows > 0, "uz_bn_relu_bwd_apply_fin: count / rows");
+  UZ_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "uz_bn_relu_bwd_apply_fin: dgamma/dbeta");
+  const int vec = d->dtype == UZ_BF16 ? 8 : 4;
+  UZ_REQUIRE(d->lddy % vec == 0 && d->lddy >= d->C, "uz_bn_relu_bwd_apply_fin: bad lddy");
+  BnBwdArgs a = bnbwd_args(d, y, scale, shift, mean, invstd, g0, g1, gpool);
+  a.sums = sums;
+  a.dy = dy;
+  a.inv_count = 1.0 / count;
+  a.fin.part = partial; a.fin.rows = rows; a.fin.ew = fin_ew(rows, d->C);
+  a.fin.sums = sums; a.fin.dgamma = dgamma; a.fin.dbeta = dbeta; a.fin.flag = flag;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid, block;
+  bnbwd_shape(d, gpool != nullptr, &grid, &block, 2);
+  if ((long long)grid.x * grid.y < (d->C + a.fin.ew - 1) / a.fin.ew) {   // grid smaller than the finalize: the two launches
+    bnbwd_finalize(partial, rows, d->C, sums, dgamma, dbeta, s);
+    UZ_LAUNCH_CHECK("uz_bn_relu_bwd_apply_fin(finalize)");
+    a.fin = BnFin{};
+    return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 2>(d, a, gpool != nullptr, s) : bnbwd_launch<float, 2>(d, a, gpool != nullptr, s);
+  }
+  return d->dtype == UZ_BF16 ? bnbwd_launch<bf16_t, 2, true>(d, a, gpool != nullptr, s)
+                             : bnbwd_launch<float, 2, true>(d, a, gpool != nullptr, s);
 }
 
 extern "C" int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,

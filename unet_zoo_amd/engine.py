@@ -146,6 +146,14 @@ class Engine:
     # its weight gradient read the first one's raw output through it (uz_conv_igemm_xf / uz_wgrad_xf), where both kernels
     # take the shape; the normalised middle tensor then never exists (class-level: tools/ab_step.py times both ways)
     fold_bn_apply = True
+    # the BatchNorm finalize launches (forward: statistics -> scale / shift; backward: partial rows -> totals) riding in the
+    # launch of the element pass that consumes them (uz_bn_relu_add_apply_fin, uz_bn_relu_bwd_apply_fin; 36 launches of
+    # ~5 us per unet step, 448 per u2net step).  OFF: measured slower (round 5, tools/ab_step.py, same box: unet 6.654 vs
+    # 6.586 ms, u2net 16.05 vs 15.84 ms) -- the finalize stays on the critical path of its consumer either way, and the
+    # hand-over inside one launch (coherent stores, flag add, poll, coherent table loads: four extra memory round trips)
+    # costs more than the ~2 us of launch gap it removes.  Kept as a tested switch (tests/test_bn_fin_gpu.py).
+    fuse_bn_finalize = False
+    FIN_FLAGS = 4096
 
     def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
                  grad_sink: Optional[Callable[[nn.Parameter, torch.Tensor], None]] = None,
@@ -175,6 +183,21 @@ class Engine:
         self._cpb: Dict[nn.Module, dict] = {}     # position_biases(): WindowAttention module -> batched entry
         self._bn_counters: List[torch.Tensor] = []  # num_batches_tracked of the train-mode BatchNorms seen
         self._cur_entry = -1
+        # one int32 per fused finalize of this forward + backward, zero when its launch starts: cleared by ONE fill kernel
+        # per step (created with the first request; a kernel, not a memset node -- DESIGN 5a)
+        self._fin_flags: Optional[torch.Tensor] = None
+        self._fin_used = 0
+
+    def _fin_flag(self) -> Optional[torch.Tensor]:
+        """the next zeroed flag of this step's arena, or None when the finalize launches are to stay launches of their own"""
+        if not self.fuse_bn_finalize:
+            return None
+        if self._fin_flags is None:
+            self._fin_flags = torch.zeros(self.FIN_FLAGS, dtype=torch.int32, device=self.device)
+        if self._fin_used >= self.FIN_FLAGS:
+            return None
+        self._fin_used += 1
+        return self._fin_flags[self._fin_used - 1:self._fin_used]
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, N, H, W, C, needs_grad=True) -> Act:
@@ -362,14 +385,6 @@ class Engine:
         else:
             stats = ops.conv_igemm(x, wp, bias, y, ntaps=ntaps, dil=dil, taps_mode=tmode,
                                    want_stats=self.training, xform=xf)
-        if self.training:
-            mom = bn.momentum if bn.momentum is not None else 0.1
-            vec = ops.bn_finalize(stats if stat_repeat == 1 else stats * float(stat_repeat), y.P * stat_repeat,
-                                  bn.weight.detach(), bn.bias.detach(), bn.eps, mom, bn.running_mean, bn.running_var)
-            if bn.num_batches_tracked is not None:
-                self._bn_counters.append(bn.num_batches_tracked)   # bumped together in finish_forward()
-        else:
-            vec = self._bn_vectors(bn, None, y.P)      # running statistics: (scale, shift, mean, invstd)
         lazy = False
         if (defer_apply is not None and self.fold_bn_apply and out is None and not pool and residual is None and relu
                 and stat_repeat == 1 and self.dtype == torch.bfloat16 and defer_apply.kernel_size == (3, 3)
@@ -378,6 +393,18 @@ class Engine:
             c2 = defer_apply.out_channels
             lazy = (ops.conv_xform_supported(y, c2, c2)
                     and ops.wgrad_xform_shapes_supported(N, H, W, c2, c2, Cout, y.ld, self.dtype))
+        # the finalize inside the apply pass's launch: training statistics, an apply pass to ride in
+        fin = self._fin_flag() if (self.training and not lazy and stat_repeat == 1) else None
+        vec = None
+        if self.training:
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            if fin is None:
+                vec = ops.bn_finalize(stats if stat_repeat == 1 else stats * float(stat_repeat), y.P * stat_repeat,
+                                      bn.weight.detach(), bn.bias.detach(), bn.eps, mom, bn.running_mean, bn.running_var)
+            if bn.num_batches_tracked is not None:
+                self._bn_counters.append(bn.num_batches_tracked)   # bumped together in finish_forward()
+        else:
+            vec = self._bn_vectors(bn, None, y.P)      # running statistics: (scale, shift, mean, invstd)
         if lazy:
             act = ops.Act(y.buf, y.off, y.C, N, H, W, True)
             act.lazy = (vec[0], vec[1])
@@ -389,7 +416,11 @@ class Engine:
             else:
                 pooled = self.new_act(N, H // 2, W // 2, Cout) if pool else None
             assert relu or residual is None
-            ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu)
+            if fin is not None:
+                vec = ops.bn_relu_apply_fin(y, stats, y.P, bn.weight.detach(), bn.bias.detach(), bn.eps, mom, bn.running_mean,
+                                            bn.running_var, fin, act, pooled, residual, pool_ceil, relu=relu)
+            else:
+                ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu)
         if self.record and self.training and relu and pooled is None and residual is None and stat_repeat == 1:
             act.bn_src = (y, vec)      # what a sole reader's input-gradient kernel needs (see sole_reader)
 
@@ -422,7 +453,7 @@ class Engine:
                 # g0 came from a sole reader's input-gradient kernel with the reduction already done in its epilogue
                 parts = getattr(g0, "bn_partials", None) if (g1 is None and gp is None and residual is None) else None
                 ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil, relu=relu,
-                                partials=parts, frozen=frozen)
+                                partials=parts, frozen=frozen, fin_flag=None if frozen else self._fin_flag())
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:

@@ -538,10 +538,33 @@ def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
                 "uz_bn_relu_add_apply")
 
 
+def bn_relu_apply_fin(y: Act, stats: torch.Tensor, count: int, gamma, beta, eps: float, momentum: float, running_mean,
+                      running_var, flag: torch.Tensor, act: Act, pooled: Optional[Act] = None, res: Optional[Act] = None,
+                      pool_ceil: bool = False, relu: bool = True) -> torch.Tensor:
+    """bn_finalize + bn_relu_apply in one launch (uz_bn_relu_add_apply_fin): returns vec = (scale, shift, mean, invstd).
+    flag: one zeroed int32 element of the caller's per-step flag arena."""
+    if pooled is not None:
+        want = ((y.H + 1) // 2, (y.W + 1) // 2) if pool_ceil else (y.H // 2, y.W // 2)
+        assert (pooled.H, pooled.W) == want, (pooled.H, pooled.W, want)
+    C = stats.shape[2]
+    assert C == y.C and flag.dtype == torch.int32 and flag.numel() == 1
+    vec = torch.empty((4, C), dtype=torch.float32, device=stats.device)
+    es = y.buf.element_size()
+    with _Timed("bn_relu_apply", 0.0, es * y.P * y.C * ((2.25 if pooled is not None else 2.0) + (res is not None)) + 4.0 * stats.numel()):
+        L.check(L.load().uz_bn_relu_add_apply_fin(
+            L.dtype_code(y.dtype), y.ptr(), y.ld, stats.data_ptr(), stats.shape[0], float(count), gamma.data_ptr(), beta.data_ptr(),
+            eps, momentum, _p(running_mean), _p(running_var), vec.data_ptr(), flag.data_ptr(), y.N, y.H, y.W, y.C,
+            res.ptr() if res is not None else None, res.ld if res is not None else 0, act.ptr(), act.ld,
+            pooled.ptr() if pooled is not None else None, pooled.ld if pooled is not None else 0,
+            int(pool_ceil) | (0 if relu else 2), L.stream_ptr()), "uz_bn_relu_add_apply_fin")
+    return vec
+
+
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
                 dbeta: torch.Tensor, pool_ceil: bool = False, relu: bool = True,
-                partials: Optional[torch.Tensor] = None, frozen: bool = False) -> None:
+                partials: Optional[torch.Tensor] = None, frozen: bool = False,
+                fin_flag: Optional[torch.Tensor] = None) -> None:
     """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch; relu=False: the
     forward was a plain BatchNorm.  partials: the rows of the first pass as left by the convolution that produced g0
     (conv_igemm(bnred=...)): only their fixed-order sum is launched instead of the reduction pass.
@@ -559,6 +582,24 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
     s = L.stream_ptr()
     nsrc = (g0 is not None) + (g1 is not None) + 0.25 * (gpool is not None)
     es = y.buf.element_size()
+    if fin_flag is not None and not frozen:
+        # the finalize rides in the apply pass's launch (uz_bn_relu_bwd_apply_fin): fin_flag is one zeroed int32 of the
+        # caller's per-step flag arena
+        if partials is not None:
+            assert relu and g1 is None and gpool is None and partials.shape[1:] == (2, y.C) and partials.is_contiguous()
+            rows, pptr = partials.shape[0], partials.data_ptr()
+        else:
+            wsb = L.check_count(lib.uz_bn_relu_bwd_workspace_bytes(byref(d), int(gpool is not None)),
+                                "uz_bn_relu_bwd_workspace_bytes")
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=y.buf.device)
+            rows, pptr = wsb // (8 * y.C), ws.data_ptr()
+            with _Timed("bn_relu_bwd_reduce", 0.0, es * y.P * y.C * (1 + nsrc)):
+                L.check(lib.uz_bn_relu_bwd_reduce_rows(byref(d), *args, pptr, s), "uz_bn_relu_bwd_reduce_rows")
+        with _Timed("bn_relu_bwd_apply", 0.0, es * y.P * y.C * (2 + nsrc)):
+            L.check(lib.uz_bn_relu_bwd_apply_fin(byref(d), *args, pptr, rows, sums.data_ptr(), dgamma.data_ptr(),
+                                                 dbeta.data_ptr(), fin_flag.data_ptr(), float(y.P), dy.ptr(), s),
+                    "uz_bn_relu_bwd_apply_fin")
+        return
     if partials is not None:
         assert relu and g1 is None and gpool is None and partials.shape[1:] == (2, y.C) and partials.is_contiguous()
         L.check(lib.uz_bn_bwd_finalize(partials.data_ptr(), partials.shape[0], y.C, sums.data_ptr(),
