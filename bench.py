@@ -211,6 +211,69 @@ def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet", thre
             "sample": f"{model_name} train step on CPU fp32, B={batch} 3x{hw}x{hw}, 1 warm-up + {steps} timed steps, median"}
 
 
+def torch_rocm_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
+    """The SAME training step through stock PyTorch-ROCm on the same GPU (MIOpen / rocBLAS kernels, eager launches): the
+    oracle's restatement of the reference graph (torch.nn.functional calls with the reference's own parameters) moved to
+    the device -- (a) as the reference runs it (fp32, NCHW; scripts/train.py has neither autocast nor channels_last) and
+    (b) as a user would tune it without leaving PyTorch (bf16 autocast, channels_last).  A reported yardstick beside
+    `cpu_baseline` (--torch-baseline; checker code, never the measured product path).  Images/s, median step."""
+    from oracle import torch_ref
+    out = {}
+    dev = torch.device("cuda")
+    for key, amp, cl in (("as_reference_fp32_nchw", False, False), ("bf16_autocast_channels_last", True, True)):
+        torch.manual_seed(0)
+        m, kw = make_model(model_name, hw)
+        sd = m.state_dict()
+        with torch.device(dev):      # the oracle's factory calls (attention masks, index tables) on the device
+            fkw = {"cfg": torch_ref.swin_config(sd, hw, window_size=kw["window_size"])} if model_name == "swin_unet_v2" else {}
+        st = torch_ref.clone_state(sd, requires_grad=False)
+        for k in list(st):
+            v = st[k].detach().to(dev)
+            if cl and v.dim() == 4:
+                v = v.contiguous(memory_format=torch.channels_last)
+            if v.is_floating_point() and not torch_ref._is_buffer(k):
+                v.requires_grad_(True)
+            st[k] = v
+        params = [v for v in st.values() if v.requires_grad]
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-5, fused=True)
+        x, mask = torch_ref.synthetic_batch(batch, 3, hw, hw, seed=1234)
+        x, mask = x.to(dev), mask.to(dev)
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        times = []
+        t_start = time.perf_counter()
+        for i in range(steps + 3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            with torch.device(dev), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                outp = torch_ref.FORWARDS[model_name](st, x, True, **fkw)
+            loss = torch_ref.model_loss(_as_float(outp), mask)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 1.0)
+            opt.step()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 240 and i >= 3:    # MIOpen's first-use search can take minutes: bounded
+                break
+        timed = sorted(times[3:]) if len(times) > 3 else sorted(times[-1:])
+        med = timed[len(timed) // 2]
+        out[key] = {"images_per_s": round(batch / med, 1), "ms_per_step": round(med * 1e3, 3), "timed_steps": len(timed),
+                    "first_step_s": round(times[0], 1)}
+    out["what"] = (f"{model_name} train step (zero_grad+fwd+BCE+bwd+clip+fused AdamW) B={batch} 3x{hw}x{hw} through stock "
+                   f"torch {torch.__version__} ops on this GPU, eager; 3 warm-up steps, median of the rest")
+    return out
+
+
+def _as_float(o):
+    """logits of an autocast forward as fp32 for the loss (dict / tuple outputs kept)"""
+    if isinstance(o, dict):
+        return {k: v.float() for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(v.float() for v in o)
+    return o.float()
+
+
 def time_graphed(gs, x, mask, steps, warmup, distributed, dev):
     """W untimed + exactly K timed whole steps between barrier + synchronize; returns (max-over-ranks seconds,
     seconds of K forward+backward(+all-reduce) replays alone)"""
@@ -278,6 +341,9 @@ def main():
                          "--size 256 (window 8) or configs[3] with --size 224 --batch 32 (window 7)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-baseline", action="store_true",
+                    help="also time the same step through stock PyTorch-ROCm ops on this GPU (oracle graph on the device; "
+                         "MIOpen's first-use search makes this take minutes) -> \"torch_rocm_baseline\" in the line")
     ap.add_argument("--cpu-batch", type=int, default=None,
                     help="batch of the CPU baseline (default: the configuration's own batch, capped at 16 -- unet B=16: "
                          "~6 s per step on the 16 host threads of a one-GPU box)")
@@ -544,11 +610,12 @@ def main():
         }
         # the north star's block-level line: unet level 1 DoubleConv forward (im2col + both convolutions + BatchNorm
         # finalize / apply + ReLU + pool) as the eager profile steps timed it, against SURVEY 8d's floor
-        # s * P * (Cin + 3 * Cout) + weights (409 MB at B = 16 256 x 256 bf16) and 8 TB/s
+        # 4 * P * Cin + s * P * 3 * Cout + weights (415 MB at B = 16 256 x 256 bf16) and 8 TB/s
         sc = ops.profile_scopes().get("doubleconv_l1")
         if sc and args.model == "unet" and args.profile_steps > 0:
             P_, es_ = args.batch * args.size * args.size, (2 if run_dtype == torch.bfloat16 else 4)
-            alg = es_ * P_ * (3 + 3 * 64) + 4 * (9 * 3 * 64 + 64 + 9 * 64 * 64 + 64)
+            # the network input is fp32 NCHW (4 bytes per element), the activations are in the run dtype
+            alg = 4 * P_ * 3 + es_ * P_ * (3 * 64) + 4 * (9 * 3 * 64 + 64 + 9 * 64 * 64 + 64)
             us = sc["ms"] / nprof * 1e3
             line["doubleconv_l1"] = {
                 "block": "unet down_convolution_1: DoubleConv(3->64->64, train BN, ReLU) + MaxPool, forward",
@@ -571,6 +638,8 @@ def main():
             # (8 threads, to compare with the survey's anchors: a quarter of the batch keeps the default run short)
             cb["value_8_threads"] = cpu_baseline(max(cpu_b // 4, 1), args.size, 1, args.model, threads=8)["value"]
             line["cpu_baseline"] = cb
+        if world == 1 and args.torch_baseline:
+            line["torch_rocm_baseline"] = torch_rocm_baseline(args.batch, args.size, 10, args.model)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

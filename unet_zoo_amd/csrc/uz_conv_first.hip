@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const CfArgs a) {
           *reinterpret_cast<bf16x4*>(stg + px * STG + (32 * t + 8 * g4 + 4 * b) * 2) = o;
         }
       }
-      // full NHWC rows: CPP lanes x 16 bytes = the CT * 64 bytes of one pixel (CT = 2: a 128-byte line)
+      // full NHWC rows: CPP lanes x 16 bytes = the CT * 64 bytes of one pixel (CT = 2: a 128-byte line).  The strip is this
+      // wave's own: lanes hand data to other lanes of the SAME wave, whose LDS operations complete in program order -- no
+      // s_barrier needed; the wave barriers keep the compiler from moving accesses across the hand-over.
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < 32 / PPI; ++j) {
         const int p = j * PPI + lane / CPP;
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const CfArgs a) {
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();   // the strip is rewritten by the next row
     }
   }
   if (a.stats == nullptr) return;
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const CfArgs a) {
     red[lane * 16 + e] = st1[e];
     red[lane * 16 + 8 + e] = st2[e];
   }
+  __builtin_amdgcn_wave_barrier();   // same-wave hand-over, as above
 #pragma unroll
   for (int idx = lane; idx < CPP * 16; idx += 64) {   // (chunk c2, value v2 of its 16 sums)
     const int c2 = idx / 16, v2 = idx % 16;

@@ -1002,6 +1002,11 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma_kernel(const AttnArgs a)
 // next window's prefetch) and every global store (the window's results, acknowledged ~1 us after issue) -- four such drains
 // per window were more than half of the attention kernels' wave time (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.55).  The kernels
 // below exchange data between waves through LDS only.
+// Contract of every call site (round-4 review): (1) nothing a wave wrote to GLOBAL memory is read by another wave of the
+// workgroup afterwards -- results leave through each wave's own stores, the prefetch loads land in registers of the wave that
+// issued them -- so no vmcnt wait is owed; (2) every call sits in workgroup-uniform control flow (the window loop's trip count
+// and the pass structure depend on blockIdx and kernel arguments only), as s_barrier requires; `asm volatile` with a memory
+// clobber is not moved across other memory accesses or into a branch by the compiler.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ bf16x8 pack8(const float* f) {

@@ -451,7 +451,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_multi_kernel(const WgMulti m)
   int local = blockIdx.x - m.first[i];
   // The tiles of one pixel range read the same dy / x pixels: put them on one XCD (workgroup ids 8 apart share an L2) and
   // next to each other in time.  The problem's ids of one residue mod 8 form a column; columns are filled one after the
-  // other with (pixel range, tile) pairs, tile fastest -- a permutation of the problem's own workgroups.
+  // other with (pixel range, tile) pairs, tile fastest -- a permutation of the problem's own workgroups.  (The hardware's
+  // XCD is blockIdx.x mod 8 = (first[i] + local) mod 8: first[i] need not be a multiple of 8 -- it rotates WHICH XCD a
+  // column lands on, not the fact that equal `local & 7` means equal XCD.)
   {
     const int c = local & 7, j = local >> 3, q = n >> 3, rem = n & 7;
     local = c * q + (c < rem ? c : rem) + j;

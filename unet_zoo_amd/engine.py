@@ -366,6 +366,9 @@ class Engine:
             if (self.direct_first_conv and conv.kernel_size == (3, 3) and dil == 1 and conv.padding == (1, 1)
                     and conv.stride == (1, 1) and ops.conv_first_supported(self.dtype, x.nchw.shape[1], Cout)):
                 image = x.nchw
+                # the backward's weight gradient reads the caller's OWN tensor (contiguous fp32 input: no copy was made): an
+                # in-place change of the input between forward and backward is caught there instead of giving a wrong dW
+                image_version = image._version
             else:
                 x = x.patches()
         if image is not None:
@@ -464,6 +467,9 @@ class Engine:
                         # removes any per-channel constant); the reference's value is rounding noise.
                         self._give_grad(conv.bias, None)
                 if image is not None:
+                    if image._version != image_version:
+                        raise RuntimeError("the network input was modified in place between forward and backward: the first "
+                                           "convolution's weight gradient reads it (pass a copy, or finish backward first)")
                     self._give_grad(conv.weight, ops.conv_first_wgrad(image, dy, out=self._dst(conv.weight)))
                 elif im2col:
                     dwp = ops.wgrad(dy, x, (Cout, x.C), ntaps=1)
