@@ -323,3 +323,33 @@ def test_spatial_reduction_attention_kernels_against_the_c_restatement(dt, B, Nq
         want = c_ref.tensor(want, dt).reshape(got.shape).double()
         err = ((got.double().cpu() - want).abs().max() / want.abs().max()).item()
         assert err < (1e-4 if dt == torch.float32 else 2e-2), (what, err)
+
+
+def test_batched_row_sums_equal_the_single_launches_bit_for_bit():
+    """uz_sum_rows_f32_batched: every buffer summed with the arithmetic uz_sum_rows_f32 uses for it alone -- the column form
+    (LayerNorm dgamma | dbeta rows) and both wide forms (window attention's d(bias) | d(tau) rows: 16 and 4 row groups) --
+    so a parameter gradient does not depend on which launch formed it; also against the C restatement (double sums)"""
+    ref = c_ref.load()
+    g = torch.Generator().manual_seed(89)
+    shapes = [(147, 24576, 12288), (64, 49152, 24576), (32, 98304, 49152), (16, 196608, 98304),   # swin_unet_v2's four levels
+              (512, 192, 96), (300, 200, 128), (40, 16384, 16384), (256, 20000, 20000), (257, 16384, 8192)]
+    items, singles = [], []
+    for rows, n, n0 in shapes:
+        part = dev(torch.randn(rows, n, generator=g))
+        o0, o1 = torch.zeros(n0, device=DEV), (torch.zeros(n - n0, device=DEV) if n0 < n else None)
+        s0, s1 = torch.zeros(n0, device=DEV), (torch.zeros(n - n0, device=DEV) if n0 < n else None)
+        ops.sum_rows_f32(part, rows, s0, s1)
+        items.append((part, rows, o0, o1))
+        singles.append((s0, s1))
+    ops.sum_rows_f32_batched(items)
+    torch.cuda.synchronize()
+    for (part, rows, o0, o1), (s0, s1), (_, n, n0) in zip(items, singles, shapes):
+        assert torch.equal(o0, s0), (rows, n)
+        if o1 is not None:
+            assert torch.equal(o1, s1), (rows, n)
+        ph = c_ref.host(part)
+        r0, r1 = np.zeros(n0, np.float32), np.zeros(max(n - n0, 1), np.float32)
+        assert ref.uz_sum_rows_f32_ref(c_ref.ptr(ph), rows, n, c_ref.ptr(r0), n0, c_ref.ptr(r1) if n0 < n else None, None) == 0
+        assert np.array_equal(o0.cpu().numpy(), r0)
+        if o1 is not None:
+            assert np.array_equal(o1.cpu().numpy(), r1[:n - n0])

@@ -9,10 +9,11 @@ import collections
 def short(name):
     if "conv3x3_pp_kernel" in name:
         import re
-        m = re.search(r"PpCfg<(\d+), (\d+), (\d+), (\d+), (\d+)>, (true|false)", name)
+        m = re.search(r"PpCfg<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (?:true|false))?>, (true|false), (true|false), (true|false)", name)
         if m:
-            return "conv3x3_pp<%sx%s,%sx%s,%s>%s" % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(5),
-                                                     "_bnred" if m.group(6) == "true" else "")
+            return "conv3x3_pp<%sx%s,%sx%s,%s>%s%s%s" % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(5),
+                                                         "_bnred" if m.group(6) == "true" else "",
+                                                         "_splitk" if m.group(7) == "true" else "", "_xf" if m.group(8) == "true" else "")
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
     if n.startswith("at::native::"):      # torch glue: keep enough of the functor's name to tell which operation it is
         import re
@@ -52,4 +53,5 @@ def main():
         print(f"#   {us:8.1f} us/step  {f}")
 
 
-main()
+if __name__ == "__main__":
+    main()

@@ -308,46 +308,7 @@ __global__ __launch_bounds__(1024) void sum_rows_f32_kernel(const float* __restr
 template <int RG>
 __global__ __launch_bounds__(256) void sum_rows_f32_wide_kernel(const float* __restrict__ partial, int ld, int rows, int n,
                                                                 float* __restrict__ out0, int n0, float* __restrict__ out1) {
-  constexpr int CQ = 256 / RG;   // column quads per workgroup
-  __shared__ double sh[RG][CQ][4 + 1];
-  const int cq = threadIdx.x % CQ, g = threadIdx.x / CQ;
-  const int e = (blockIdx.x * CQ + cq) * 4;
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
-  if (e < n) {
-    int r = g;
-    for (; r + 3 * RG < rows; r += 4 * RG) {   // four independent loads in flight
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(r + u * RG) * ld + e);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        s[0] += (double)v[u].x;
-        s[1] += (double)v[u].y;
-        s[2] += (double)v[u].z;
-        s[3] += (double)v[u].w;
-      }
-    }
-    for (; r < rows; r += RG) {
-      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)r * ld + e);
-      s[0] += (double)v.x;
-      s[1] += (double)v.y;
-      s[2] += (double)v.z;
-      s[3] += (double)v.w;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sh[g][cq][i] = s[i];
-  __syncthreads();
-  if (g == 0 && e < n) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double t = 0.0;
-      for (int r = 0; r < RG; ++r) t += sh[r][cq][i];
-      const int idx = e + i;
-      if (idx < n0) out0[idx] = (float)t;
-      else out1[idx - n0] = (float)t;
-    }
-  }
+  uz_sum_rows_wide_body<RG>(partial, ld, rows, n, out0, n0, out1, blockIdx.x);
 }
 
 // dx[lo pixel][c] = sum of the 2x2 fine pixels (backward of nearest-neighbour x2 upsampling)
@@ -523,8 +484,8 @@ extern "C" int uz_sum_rows_f32_ld(const float* partial, int ld, int rows, int n,
                                   void* stream) {
   UZ_REQUIRE(partial && out0 && rows > 0 && n > 0 && ld >= n && n0 >= 0 && n0 <= n && (out1 || n0 == n),
              "uz_sum_rows_f32: bad args");
-  if (rows <= 256 && n >= 16384 && n % 4 == 0 && ld % 4 == 0 && ((uintptr_t)partial & 15) == 0) {
-    if (rows >= 64)
+  if (const int rg = uz_sum_rows_wide_rg(partial, ld, rows, n)) {
+    if (rg == 16)
       hipLaunchKernelGGL(sum_rows_f32_wide_kernel<16>, dim3(uz_cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, partial, ld, rows,
                          n, out0, n0, out1);
     else

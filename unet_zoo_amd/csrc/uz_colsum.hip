@@ -175,6 +175,14 @@ __global__ __launch_bounds__(1024) void sum_rows_batched_kernel(const SrBatch b)
     else it.out1[e - it.n0] = (float)t;
   }
 }
+// the wide form of uz_sum_rows_f32 (few rows, many columns: window attention's d(bias) | d(tau) rows) for many buffers
+template <int RG>
+__global__ __launch_bounds__(256) void sum_rows_wide_batched_kernel(const SrBatch b) {
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
+  const SrItem& it = b.it[i];
+  uz_sum_rows_wide_body<RG>(it.partial, it.n, it.rows, it.n, it.out0, it.n0, it.out1, (int)blockIdx.x - it.blk0);
+}
 }  // namespace
 
 extern "C" int uz_sum_rows_f32_batched(const uz_sum_rows_item* items, int n, void* stream) {
@@ -184,23 +192,41 @@ extern "C" int uz_sum_rows_f32_batched(const uz_sum_rows_item* items, int n, voi
                    items[i].n0 <= items[i].n && (items[i].out1 || items[i].n0 == items[i].n),
                "uz_sum_rows_f32_batched: bad item %d", i);
   hipStream_t s = (hipStream_t)stream;
-  for (int first = 0; first < n; first += SRB_MAX) {
+  // three classes, each the arithmetic uz_sum_rows_f32 would use for the buffer on its own: 0 = 32 row groups x 32 columns,
+  // 16 / 4 = the wide form with that many row groups; one launch per class and SRB_MAX buffers
+  for (int cls : {0, 16, 4}) {
     SrBatch b;
-    b.n = n - first < SRB_MAX ? n - first : SRB_MAX;
+    b.n = 0;
     int blk = 0;
-    for (int i = 0; i < b.n; ++i) {
-      const uz_sum_rows_item& src = items[first + i];
-      b.it[i].partial = src.partial;
-      b.it[i].out0 = src.out0;
-      b.it[i].out1 = src.out1;
-      b.it[i].rows = src.rows;
-      b.it[i].n = src.n;
-      b.it[i].n0 = src.n0;
-      b.it[i].blk0 = blk;
-      blk += (src.n + 31) / 32;
+    auto flush = [&]() -> int {
+      if (b.n == 0) return UZ_OK;
+      if (cls == 0) hipLaunchKernelGGL(sum_rows_batched_kernel, dim3(blk), dim3(1024), 0, s, b);
+      else if (cls == 16) hipLaunchKernelGGL(sum_rows_wide_batched_kernel<16>, dim3(blk), dim3(256), 0, s, b);
+      else hipLaunchKernelGGL(sum_rows_wide_batched_kernel<4>, dim3(blk), dim3(256), 0, s, b);
+      UZ_LAUNCH_CHECK("uz_sum_rows_f32_batched");
+      b.n = 0;
+      blk = 0;
+      return UZ_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+      const uz_sum_rows_item& src = items[i];
+      if (uz_sum_rows_wide_rg(src.partial, src.n, src.rows, src.n) != cls) continue;
+      SrItem& d = b.it[b.n++];
+      d.partial = src.partial;
+      d.out0 = src.out0;
+      d.out1 = src.out1;
+      d.rows = src.rows;
+      d.n = src.n;
+      d.n0 = src.n0;
+      d.blk0 = blk;
+      blk += cls == 0 ? (src.n + 31) / 32 : uz_cdiv(src.n, cls == 16 ? 64 : 256);
+      if (b.n == SRB_MAX) {
+        const int rc = flush();
+        if (rc != UZ_OK) return rc;
+      }
     }
-    hipLaunchKernelGGL(sum_rows_batched_kernel, dim3(blk), dim3(1024), 0, s, b);
-    UZ_LAUNCH_CHECK("uz_sum_rows_f32_batched");
+    const int rc = flush();
+    if (rc != UZ_OK) return rc;
   }
   return UZ_OK;
 }

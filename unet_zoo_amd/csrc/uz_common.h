@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 #include "../../include/unetzoo_hip.h"
 
@@ -83,6 +84,59 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
 }
 
 static inline int uz_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Row sums of few rows of many columns (uz_sum_rows_f32's wide form, uz_attn.hip; the same body serves the batched launch of
+// uz_colsum.hip, so one buffer's sums do not depend on which launch formed them): workgroup `block` of 256 threads owns
+// 256 / RG column quads, thread (cq, g) every RG-th row of its quad; the RG partial sums meet in LDS, fixed order.
+template <int RG>
+__device__ __forceinline__ void uz_sum_rows_wide_body(const float* __restrict__ partial, int ld, int rows, int n,
+                                                      float* __restrict__ out0, int n0, float* __restrict__ out1, int block) {
+  constexpr int CQ = 256 / RG;   // column quads per workgroup
+  __shared__ double sh[RG][CQ][4 + 1];
+  const int cq = threadIdx.x % CQ, g = threadIdx.x / CQ;
+  const int e = (block * CQ + cq) * 4;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (e < n) {
+    int r = g;
+    for (; r + 3 * RG < rows; r += 4 * RG) {   // four independent loads in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(r + u * RG) * ld + e);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[0] += (double)v[u].x;
+        s[1] += (double)v[u].y;
+        s[2] += (double)v[u].z;
+        s[3] += (double)v[u].w;
+      }
+    }
+    for (; r < rows; r += RG) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)r * ld + e);
+      s[0] += (double)v.x;
+      s[1] += (double)v.y;
+      s[2] += (double)v.z;
+      s[3] += (double)v.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sh[g][cq][i] = s[i];
+  __syncthreads();
+  if (g == 0 && e < n) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double t = 0.0;
+      for (int r = 0; r < RG; ++r) t += sh[r][cq][i];
+      const int idx = e + i;
+      if (idx < n0) out0[idx] = (float)t;
+      else out1[idx - n0] = (float)t;
+    }
+  }
+}
+// which form uz_sum_rows_f32_ld takes for a buffer: 16 / 4 = the wide form with that many row groups, 0 = the column forms
+static inline int uz_sum_rows_wide_rg(const float* partial, int ld, int rows, int n) {
+  if (rows <= 256 && n >= 16384 && n % 4 == 0 && ld % 4 == 0 && ((uintptr_t)partial & 15) == 0) return rows >= 64 ? 16 : 4;
+  return 0;
+}
 
 // Tuning / ablation switches for in-process A/B measurements (tools/kbench.py).  They exist only in a library
 // built with -DUZ_ABLATE (make ABLATE=1): the shipped libunetzoo_hip.so never reads the environment, its flags are

@@ -267,14 +267,19 @@ class Engine:
         sums of this backward range have been enqueued; ops take `defer=self._rowsum_items`"""
         self._pending_rowsums.append((self._cur_entry, fn))
 
-    def _flush_colsums(self) -> None:
+    def _flush_rowsums(self) -> None:
         if self._pending_rowsums:
             items, self._rowsum_items = self._rowsum_items, []
             after, self._pending_rowsums = self._pending_rowsums, []
             ops.sum_rows_f32_batched(items)
+            cur = self._cur_entry
             for entry, fn in after:
                 self._cur_entry = entry
                 fn()
+            self._cur_entry = cur
+
+    def _flush_colsums(self) -> None:
+        self._flush_rowsums()
         wpend, self._pending_wgrads = self._pending_wgrads, []
         if wpend:
             wouts = []
@@ -1747,6 +1752,7 @@ class Engine:
         ops.cpb_fwd_batched(mods)
         if self.record:
             def bwd():
+                self._flush_rowsums()      # the d(bias) of this range's attentions may still be partial rows
                 live = [m for m in mods if m.get("G") is not None]
                 for m in live:
                     cpb = m["attn"].cpb
@@ -1799,9 +1805,20 @@ class Engine:
                     return
                 dqkv = self.new_act(qkv.N, qkv.H, qkv.W, qkv.C)
                 whole = tuple(attn.tau.shape) == (heads, N, N)
+                # d(bias) and d(tau) leave the kernel as per-workgroup rows; nothing reads their sums before the position
+                # biases' own backward (the last tape entry) and the optimizer: summed with the range's other rows in one
+                # launch (12 launches of 5 us per swin step)
+                late = pre is not None and whole
                 dbias, dtau = ops.winattn_bwd(qkv, tau, bias, o, lse, g, dqkv, heads, ws, shift,
-                                              dtau=self._dst(attn.tau) if whole else None, scale=attn.scale)
+                                              dtau=self._dst(attn.tau) if whole else None, scale=attn.scale,
+                                              defer=self._rowsum_items if late else None)
                 qkv.add_grad(dqkv)
+                if late:
+                    def give():
+                        self._give_grad(attn.tau, dtau)
+                        pre["G"] = dbias.view(heads, N * N)     # differentiated with all the others (position_biases)
+                    self._after_rowsums(give)
+                    return
                 if not whole:                                                   # window clipped to the map size
                     full = torch.zeros_like(attn.tau)
                     full[:, :N, :N] = dtau

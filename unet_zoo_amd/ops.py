@@ -1042,8 +1042,11 @@ def winattn_fwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, heads
 
 
 def winattn_bwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, lse: torch.Tensor, dout: Act, dqkv: Act,
-                heads: int, ws: int, shift: int, dtau: Optional[torch.Tensor] = None, scale: Optional[float] = None):
-    """returns (dbias, dtau) as (heads, N, N) fp32; dtau is written into the given tensor when passed"""
+                heads: int, ws: int, shift: int, dtau: Optional[torch.Tensor] = None, scale: Optional[float] = None,
+                defer: Optional[list] = None):
+    """returns (dbias, dtau) as (heads, N, N) fp32; dtau is written into the given tensor when passed.
+    defer: a list -> the row sums that finish dbias / dtau are appended to it instead of launched (sum_rows_f32_batched):
+    the two tensors are valid once the caller has flushed the list"""
     lib = L.load()
     d = _attn_desc(qkv, heads, ws, shift, tau.shape[1], out.ld, scale)
     rows = L.check_count(lib.uz_winattn_bwd_rows(byref(d)), "uz_winattn_bwd_rows")
@@ -1057,7 +1060,7 @@ def winattn_bwd(qkv: Act, tau: torch.Tensor, bias: torch.Tensor, out: Act, lse: 
     if dtau is None:
         dtau = torch.empty((heads, N, N), dtype=torch.float32, device=qkv.buf.device)
     assert dtau.shape == (heads, N, N)
-    sum_rows_f32(part, rows, dbias, dtau)
+    sum_rows_f32(part, rows, dbias, dtau, defer=defer)
     return dbias, dtau
 
 
