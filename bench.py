@@ -211,7 +211,7 @@ def cpu_baseline(batch: int, hw: int, steps: int, model_name: str = "unet", thre
             "sample": f"{model_name} train step on CPU fp32, B={batch} 3x{hw}x{hw}, 1 warm-up + {steps} timed steps, median"}
 
 
-def torch_rocm_baseline(batch: int, hw: int, steps: int, model_name: str = "unet"):
+def torch_rocm_baseline(batch: int, hw: int, steps: int, model_name: str = "unet", both: bool = True):
     """The SAME training step through stock PyTorch-ROCm on the same GPU (MIOpen / rocBLAS kernels, eager launches): the
     oracle's restatement of the reference graph (torch.nn.functional calls with the reference's own parameters) moved to
     the device -- (a) as the reference runs it (fp32, NCHW; scripts/train.py has neither autocast nor channels_last) and
@@ -220,7 +220,8 @@ def torch_rocm_baseline(batch: int, hw: int, steps: int, model_name: str = "unet
     from oracle import torch_ref
     out = {}
     dev = torch.device("cuda")
-    for key, amp, cl in (("as_reference_fp32_nchw", False, False), ("bf16_autocast_channels_last", True, True)):
+    modes = (("as_reference_fp32_nchw", False, False), ("bf16_autocast_channels_last", True, True))
+    for key, amp, cl in (modes if both else modes[1:]):
         torch.manual_seed(0)
         m, kw = make_model(model_name, hw)
         sd = m.state_dict()
@@ -342,8 +343,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-baseline", action="store_true",
-                    help="also time the same step through stock PyTorch-ROCm ops on this GPU (oracle graph on the device; "
-                         "MIOpen's first-use search makes this take minutes) -> \"torch_rocm_baseline\" in the line")
+                    help="time the same step through stock PyTorch-ROCm ops on this GPU in BOTH forms (fp32 NCHW as the reference "
+                         "runs, and bf16 autocast + channels_last); the default line carries the second, faster one only "
+                         "(MIOpen's first-use search: ~75 s) -> \"torch_rocm_baseline\" in the line")
+    ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=None,
                     help="batch of the CPU baseline (default: the configuration's own batch, capped at 16 -- unet B=16: "
                          "~6 s per step on the 16 host threads of a one-GPU box)")
@@ -638,8 +641,11 @@ def main():
             # (8 threads, to compare with the survey's anchors: a quarter of the batch keeps the default run short)
             cb["value_8_threads"] = cpu_baseline(max(cpu_b // 4, 1), args.size, 1, args.model, threads=8)["value"]
             line["cpu_baseline"] = cb
-        if world == 1 and args.torch_baseline:
-            line["torch_rocm_baseline"] = torch_rocm_baseline(args.batch, args.size, 10, args.model)
+        if world == 1 and not distributed and (args.torch_baseline or not (args.no_torch_baseline or args.no_cpu_baseline)):
+            try:
+                line["torch_rocm_baseline"] = torch_rocm_baseline(args.batch, args.size, 10, args.model, both=args.torch_baseline)
+            except Exception as e:      # noqa: BLE001  (a yardstick must not cost the line)
+                line["torch_rocm_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
