@@ -10,8 +10,10 @@ import torch
 import unet_zoo_amd
 from unet_zoo_amd.engine import Engine
 
-VARIANTS = [("finalize in consumer", dict(fuse_bn_finalize=True, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
-            ("fold BN apply (xf)", dict(fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+VARIANTS = [("reversed + bwd passes alternate", dict(BN_BWD_ALTERNATE=True, reverse_element_passes=True, fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+            ("element passes reversed", dict(BN_BWD_ALTERNATE=False, reverse_element_passes=True, fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+            ("finalize in consumer", dict(reverse_element_passes=False, fuse_bn_finalize=True, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
+            ("fold BN apply (xf)", dict(reverse_element_passes=False, fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
             ("fused conv + convT", dict(fold_bn_apply=False, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
             ("fused conv only", dict(fuse_bn_reduce=True, fuse_bn_reduce_convt=False)),
             ("two-pass everywhere", dict(fuse_bn_reduce=False, fuse_bn_reduce_convt=False))]
@@ -21,6 +23,9 @@ def build(attrs, model_name, B, S):
     for k, v in attrs.items():
         if k == "UZ_TUNE":       # plan switches of the ablation build (UNET_ZOO_AMD_LIB=.../libunetzoo_hip_ablate.so): the
             os.environ["UZ_TUNE"] = str(v)     # plans are taken at capture time, so a captured step keeps its variant
+        elif k == "BN_BWD_ALTERNATE":
+            from unet_zoo_amd import ops as _ops
+            _ops.BN_BWD_ALTERNATE = v
         else:
             setattr(Engine, k, v)
     torch.manual_seed(0)

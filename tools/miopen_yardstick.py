@@ -55,8 +55,17 @@ def main():
         h_f = timeit(lambda: ops.conv_igemm(xa, wp, None, ya, ntaps=9, want_stats=True))
         h_d = timeit(lambda: ops.conv_igemm(ga, wd, None, dxa, ntaps=9))
         h_w = timeit(lambda: ops.wgrad(ga, xa, (co, ci, 3, 3), ntaps=9, out=dw))
+        # the plain matrix product of the same size through the vendor's GEMM library (hipBLASLt / rocBLAS behind
+        # torch.matmul): [P, 9 Cin] x [9 Cin, Cout] with the im2col matrix GIVEN -- what the matrix cores deliver on this
+        # arithmetic shape on this box when nothing but a GEMM has to be done (no halo gather, no statistics)
+        P = B * hw * hw
+        am = torch.randn(P, 9 * ci, device=DEV, dtype=dt)
+        bm = torch.randn(9 * ci, co, device=DEV, dtype=dt)
+        g_f = timeit(lambda: torch.matmul(am, bm))
+        del am, bm
         print(f"{ci:4d} -> {co:<4d} @ {hw:3d}x{hw:<3d} {gf * 1e3:5.0f} GF | {v_f:8.1f} {v_d:8.1f} {v_w:8.1f}  | {h_f:8.1f} {h_d:8.1f} {h_w:8.1f}"
-              f"   (vendor {gf / v_f * 1e6:6.0f}, here {gf / h_f * 1e6:6.0f} TFLOP/s)", flush=True)
+              f"   (vendor {gf / v_f * 1e6:6.0f}, here {gf / h_f * 1e6:6.0f} TFLOP/s; vendor GEMM on the given im2col matrix"
+              f" {g_f:6.1f} us = {gf / g_f * 1e6:6.0f} TFLOP/s)", flush=True)
 
 
 if __name__ == "__main__":

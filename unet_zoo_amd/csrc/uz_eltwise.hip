@@ -255,12 +255,14 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
   constexpr int VEC = ElemTraits<T>::VEC;
   const int CC = C / VEC;
   const bool relu = !(pool_ceil & 2);   // bit 1 of the flag word: BatchNorm WITHOUT the ReLU (resunet's skip branch)
+  const bool rev = (pool_ceil & 4) != 0;   // bit 2: walk the tensor from its END (the part its producer wrote last)
   pool_ceil &= 1;
   const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
   const int Hp = pool_ceil ? Ho : H >> 1, Wp = pool_ceil ? Wo : W >> 1;
   const long long total = POOL ? (long long)N * Ho * Wo * CC : (long long)N * H * W * CC;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx0 < total;
+       idx0 += (long long)gridDim.x * blockDim.x) {
+    const long long idx = rev ? total - 1 - idx0 : idx0;
     const int cc = (int)(idx % CC);
     const long long u = idx / CC;
     const int c0 = cc * VEC;
@@ -412,13 +414,18 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
   for (int i = 0; i < VEC; ++i) S0[i] = S1[i] = 0.f;
 
   const long long ustride = (long long)gridDim.x * blockDim.y;
-  for (long long u = (long long)blockIdx.x * blockDim.y + threadIdx.y; u < units && cok;
-       u += (POOL ? 1 : NPIX) * ustride) {
+  // bit 2 of the flag word: walk the units from the END -- the part of y / g the producing kernel wrote last and the
+  // Infinity Cache still holds (sums are per workgroup and fixed-order either way; the walk changes WHICH units a
+  // workgroup sums, so the partial rows -- not the totals' determinism -- differ between the two walks)
+  const bool rev = (a.pool_ceil & 4) != 0;
+  for (long long u0 = (long long)blockIdx.x * blockDim.y + threadIdx.y; u0 < units && cok;
+       u0 += (POOL ? 1 : NPIX) * ustride) {
     size_t pix[NPIX];   // pixel of slot k; slots outside the map / past the end read a clamped pixel and are zeroed
     bool in[NPIX];
     size_t gpoff = 0;
     bool has_pool = false;
     if constexpr (POOL) {
+      const long long u = rev ? units - 1 - u0 : u0;
       const int wo = (int)(u % Wo);
       const long long t = u / Wo;
       const int ho = (int)(t % Ho);
@@ -434,9 +441,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
     } else {
 #pragma unroll
       for (int k = 0; k < NPIX; ++k) {
-        const long long q = u + k * ustride;
+        const long long q = u0 + k * ustride;
         in[k] = q < units;
-        pix[k] = (size_t)(in[k] ? q : units - 1);
+        pix[k] = (size_t)(in[k] ? (rev ? units - 1 - q : q) : units - 1);
       }
     }
 #ifndef UZ_BN_BRANCHY
@@ -1187,7 +1194,7 @@ static int bn_relu_apply_t(const void* y, int ldy, const float* scale, const flo
   } else {
     const long long total = (long long)N * H * W * (C / VEC);
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, s,
-                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 2, BnFin{});
+                       (const T*)y, ldy, scale, shift, N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 6, BnFin{});
   }
   UZ_LAUNCH_CHECK("uz_bn_relu_apply");
   return UZ_OK;
@@ -1213,7 +1220,7 @@ extern "C" int uz_bn_relu_add_apply(int dtype, const void* y, int ldy, const flo
   UZ_REQUIRE(ldy % vec == 0 && lda % vec == 0 && ldy >= C && lda >= C, "uz_bn_relu_apply: bad ld");
   if (res != nullptr) UZ_REQUIRE(ldr % vec == 0 && ldr >= C, "uz_bn_relu_apply: bad ldr");
   if (pooled != nullptr) {
-    UZ_REQUIRE(pool_ceil || (H >= 2 && W >= 2), "uz_bn_relu_apply: floor-mode pool of a %dx%d map is empty", H, W);
+    UZ_REQUIRE((pool_ceil & 1) || (H >= 2 && W >= 2), "uz_bn_relu_apply: floor-mode pool of a %dx%d map is empty", H, W);
     UZ_REQUIRE(ldp % vec == 0 && ldp >= C, "uz_bn_relu_apply: bad ldp");
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1237,7 +1244,7 @@ static int bn_relu_apply_fin_t(const void* y, int ldy, const BnFin& fin, int N, 
                        H, W, C, (T*)act, lda, (T*)pooled, ldp, (const T*)res, ldr, pool_ceil, fin);
   else
     hipLaunchKernelGGL((bn_relu_apply_kernel<T, false, true>), dim3(grid), dim3(256), 0, s, (const T*)y, ldy, fin.vec, fin.vec + C,
-                       N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 2, fin);
+                       N, H, W, C, (T*)act, lda, (T*)nullptr, 0, (const T*)res, ldr, pool_ceil & 6, fin);
   UZ_LAUNCH_CHECK("uz_bn_relu_add_apply_fin");
   return UZ_OK;
 }
@@ -1255,7 +1262,7 @@ extern "C" int uz_bn_relu_add_apply_fin(int dtype, const void* y, int ldy, const
   UZ_REQUIRE(ldy % vecw == 0 && lda % vecw == 0 && ldy >= C && lda >= C, "uz_bn_relu_add_apply_fin: bad ld");
   if (res != nullptr) UZ_REQUIRE(ldr % vecw == 0 && ldr >= C, "uz_bn_relu_add_apply_fin: bad ldr");
   if (pooled != nullptr) {
-    UZ_REQUIRE(pool_ceil || (H >= 2 && W >= 2), "uz_bn_relu_add_apply_fin: floor-mode pool of a %dx%d map is empty", H, W);
+    UZ_REQUIRE((pool_ceil & 1) || (H >= 2 && W >= 2), "uz_bn_relu_add_apply_fin: floor-mode pool of a %dx%d map is empty", H, W);
     UZ_REQUIRE(ldp % vecw == 0 && ldp >= C, "uz_bn_relu_add_apply_fin: bad ldp");
   }
   BnFin fin{};

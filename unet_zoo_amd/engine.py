@@ -154,6 +154,10 @@ class Engine:
     # costs more than the ~2 us of launch gap it removes.  Kept as a tested switch (tests/test_bn_fin_gpu.py).
     fuse_bn_finalize = False
     FIN_FLAGS = 4096
+    # the BatchNorm element passes walk their tensors from the END: the convolution in front wrote its output ascending, its
+    # last ~100 MB are still in the Infinity Cache; the pass then ends at the low addresses, where the next (ascending)
+    # convolution starts reading (class-level: tools/ab_step.py times both ways)
+    reverse_element_passes = True
 
     def __init__(self, dtype: torch.dtype, device: torch.device, training: bool, record: bool,
                  grad_sink: Optional[Callable[[nn.Parameter, torch.Tensor], None]] = None,
@@ -428,7 +432,8 @@ class Engine:
                 vec = ops.bn_relu_apply_fin(y, stats, y.P, bn.weight.detach(), bn.bias.detach(), bn.eps, mom, bn.running_mean,
                                             bn.running_var, fin, act, pooled, residual, pool_ceil, relu=relu)
             else:
-                ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu)
+                ops.bn_relu_apply(y, vec[0], vec[1], act, pooled, residual, pool_ceil, relu=relu,
+                                  reverse=self.reverse_element_passes)
         if self.record and self.training and relu and pooled is None and residual is None and stat_repeat == 1:
             act.bn_src = (y, vec)      # what a sole reader's input-gradient kernel needs (see sole_reader)
 
@@ -461,7 +466,8 @@ class Engine:
                 # g0 came from a sole reader's input-gradient kernel with the reduction already done in its epilogue
                 parts = getattr(g0, "bn_partials", None) if (g1 is None and gp is None and residual is None) else None
                 ops.bn_relu_bwd(y, vec, g0, g1, gp, self._bn_sums(Cout), dy, dgamma, dbeta, pool_ceil, relu=relu,
-                                partials=parts, frozen=frozen, fin_flag=None if frozen else self._fin_flag())
+                                partials=parts, frozen=frozen, fin_flag=None if frozen else self._fin_flag(),
+                                reverse=self.reverse_element_passes)
                 self._give_grad(bn.weight, dgamma)
                 self._give_grad(bn.bias, dbeta)
                 if conv.bias is not None:

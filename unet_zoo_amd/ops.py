@@ -519,9 +519,11 @@ def bn_eval_scale(gamma, beta, running_mean, running_var, eps: float):
 
 def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
                   pooled: Optional[Act] = None, res: Optional[Act] = None, pool_ceil: bool = False,
-                  relu: bool = True) -> None:
+                  relu: bool = True, reverse: bool = False) -> None:
     """act = relu(scale*y + shift) [+ res]; pooled = maxpool2x2(act) (floor or ceil output size);
-    relu=False: plain BatchNorm (no pool)"""
+    relu=False: plain BatchNorm (no pool).  reverse: the pass walks the tensor from its END -- the part the producing kernel
+    wrote last and the 256 MB Infinity Cache still holds (tools/mall_order_probe.py: 46 -> 39 us after a convolution at
+    64 channels x 1 M pixels, 65 us on a cold tensor); same values either way"""
     if pooled is not None:
         want = ((y.H + 1) // 2, (y.W + 1) // 2) if pool_ceil else (y.H // 2, y.W // 2)
         assert (pooled.H, pooled.W) == want, (pooled.H, pooled.W, want)
@@ -533,8 +535,8 @@ def bn_relu_apply(y: Act, scale: torch.Tensor, shift: torch.Tensor, act: Act,
                                          res.ptr() if res is not None else None,
                                          res.ld if res is not None else 0, act.ptr(), act.ld,
                                          pooled.ptr() if pooled is not None else None,
-                                         pooled.ld if pooled is not None else 0, int(pool_ceil) | (0 if relu else 2),
-                                         L.stream_ptr()),
+                                         pooled.ld if pooled is not None else 0,
+                                         int(pool_ceil) | (0 if relu else 2) | (4 if reverse else 0), L.stream_ptr()),
                 "uz_bn_relu_add_apply")
 
 
@@ -560,11 +562,14 @@ def bn_relu_apply_fin(y: Act, stats: torch.Tensor, count: int, gamma, beta, eps:
     return vec
 
 
+BN_BWD_ALTERNATE = True
+
+
 def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 gpool: Optional[Act], sums: torch.Tensor, dy: Act, dgamma: torch.Tensor,
                 dbeta: torch.Tensor, pool_ceil: bool = False, relu: bool = True,
                 partials: Optional[torch.Tensor] = None, frozen: bool = False,
-                fin_flag: Optional[torch.Tensor] = None) -> None:
+                fin_flag: Optional[torch.Tensor] = None, reverse: bool = False) -> None:
     """Two-pass backward of BN(train)+ReLU(+pool); `sums` is a float64 (2, C) scratch; relu=False: the
     forward was a plain BatchNorm.  partials: the rows of the first pass as left by the convolution that produced g0
     (conv_igemm(bnred=...)): only their fixed-order sum is launched instead of the reduction pass.
@@ -573,9 +578,15 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
     dy = scale * g * mask without the two batch-correction terms -- the same kernels with the sums zeroed between the
     passes; dgamma = sum g*mask*xhat and dbeta = sum g*mask are the first pass's results as they are."""
     lib = L.load()
-    d = L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
-                    g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
-                    gpool.ld if gpool is not None else 0, dy.ld, int(pool_ceil) | (0 if relu else 2))
+    def desc(rev):
+        return L.BnBwdDesc(L.dtype_code(y.dtype), y.N, y.H, y.W, y.C, y.ld,
+                           g0.ld if g0 is not None else 0, g1.ld if g1 is not None else 0,
+                           gpool.ld if gpool is not None else 0, dy.ld,
+                           int(pool_ceil) | (0 if relu else 2) | (4 if rev else 0))   # bit 2: walk from the end (see bn_relu_apply)
+    d = desc(reverse)
+    # the apply pass after a reduce pass of its own starts where that pass ENDED (the opposite walk): what the reduce pass read
+    # last is what the Infinity Cache holds (class-level switch for tools/ab_step.py)
+    d_apply = desc(reverse != (partials is None and BN_BWD_ALTERNATE))
     args = (y.ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
             g0.ptr() if g0 is not None else None, g1.ptr() if g1 is not None else None,
             gpool.ptr() if gpool is not None else None)
@@ -596,7 +607,7 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
             with _Timed("bn_relu_bwd_reduce", 0.0, es * y.P * y.C * (1 + nsrc)):
                 L.check(lib.uz_bn_relu_bwd_reduce_rows(byref(d), *args, pptr, s), "uz_bn_relu_bwd_reduce_rows")
         with _Timed("bn_relu_bwd_apply", 0.0, es * y.P * y.C * (2 + nsrc)):
-            L.check(lib.uz_bn_relu_bwd_apply_fin(byref(d), *args, pptr, rows, sums.data_ptr(), dgamma.data_ptr(),
+            L.check(lib.uz_bn_relu_bwd_apply_fin(byref(d_apply), *args, pptr, rows, sums.data_ptr(), dgamma.data_ptr(),
                                                  dbeta.data_ptr(), fin_flag.data_ptr(), float(y.P), dy.ptr(), s),
                     "uz_bn_relu_bwd_apply_fin")
         return
@@ -614,7 +625,7 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
     if frozen:
         sums.zero_()
     with _Timed("bn_relu_bwd_apply", 0.0, es * y.P * y.C * (2 + nsrc)):
-        L.check(lib.uz_bn_relu_bwd_apply(byref(d), *args, sums.data_ptr(), float(y.P), dy.ptr(), s),
+        L.check(lib.uz_bn_relu_bwd_apply(byref(d_apply), *args, sums.data_ptr(), float(y.P), dy.ptr(), s),
                 "uz_bn_relu_bwd_apply")
 
 
