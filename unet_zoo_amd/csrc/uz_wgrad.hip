@@ -245,22 +245,6 @@ __global__ __launch_bounds__(64 * ZG) void wgrad_reduce_flat_kernel(const float*
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < row) {
     int z = zg;
-#ifndef UZ_RED_NARROW
-    // eight splits' loads in flight per pass, added in the same order as one by one (a pass is one memory round trip: 256
-    // slabs over 16 groups were eight round trips of two loads, ~1 us each, for a 37.7 MB read that takes 5)
-    for (; z + 7 * ZG < split; z += 8 * ZG) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(slab + (size_t)(z + u * ZG) * row + col);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        acc.x += v[u].x;
-        acc.y += v[u].y;
-        acc.z += v[u].z;
-        acc.w += v[u].w;
-      }
-    }
-#endif
     for (; z + ZG < split; z += 2 * ZG) {   // two splits' loads in flight per pass
       const float4 a0 = *reinterpret_cast<const float4*>(slab + (size_t)z * row + col);
       const float4 a1 = *reinterpret_cast<const float4*>(slab + (size_t)(z + ZG) * row + col);
@@ -305,20 +289,6 @@ __global__ __launch_bounds__(64 * ZG) void wgrad_reduce_kernel(const float* __re
   if (e < CiCj) {
     // two splits' loads in flight per pass (same summation order): a pass is one memory round trip
     int z = zg;
-#ifndef UZ_RED_NARROW
-    // four splits' loads in flight per pass (4 NT loads), added in the same order as one by one
-    for (; z + 3 * ZG < split; z += 4 * ZG) {
-      float v[4][NT];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) v[u][t] = slab[((size_t)(z + u * ZG) * NT + t) * CiCj + e];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] += v[u][t];
-    }
-#endif
     for (; z + ZG < split; z += 2 * ZG) {
       float a0[NT], a1[NT];
 #pragma unroll
