@@ -53,11 +53,14 @@ _LOSS_IMPL = "hip"
 # that contains one of its substrings (all epilogue variants of a ping-pong configuration share the `PpCfg<...>` prefix).
 # tests/test_bench_contract.py checks that every entry resolves in the newest committed profiles/r*_pmc_traffic.json.
 PMC_KEYS = {
-    "conv3x3_pp512_bf16": ("PpCfg<16, 32, 4, 2, 1>",),
-    "conv3x3_pp512x64_bf16": ("PpCfg<16, 32, 8, 1, 3>",),
-    "conv3x3_pp256_bf16": ("PpCfg<8, 32, 4, 2, 3>",),
-    "conv3x3_pp256w16_bf16": ("PpCfg<16, 16, 4, 2, 3>",),
-    "wgrad9_bf16_64x64_rowwalk": ("wgrad9_kernel<64,",),
+    # an entry = alternatives; an alternative is a substring, or a tuple of substrings that must ALL occur in the symbol
+    "conv3x3_pp512_bf16": ("PpCfg<16, 32, 4, 2, 1,",),
+    "conv3x3_pp512x64_bf16": ("PpCfg<16, 32, 8, 1, 3, false>",),
+    "conv3x3_pp512x64_bf16_xf": ("PpCfg<16, 32, 8, 1, 3, true>",),
+    "conv3x3_pp256_bf16": ("PpCfg<8, 32, 4, 2, 3,",),
+    "conv3x3_pp256w16_bf16": ("PpCfg<16, 16, 4, 2, 3,",),
+    "wgrad9_bf16_64x64_rowwalk": (("wgrad9_kernel<64,", "false>"),),
+    "wgrad9_bf16_64x64_rowwalk_xf": (("wgrad9_kernel<64,", "true>"),),
     "wgrad3x3_bf16_128x128_3tap": ("wgrad3x3_kernel<128, 128, 1, 3,",),
     "wgrad3x3_bf16_128x128_gather4": ("wgrad3x3_kernel<128, 128, 1, 1,",),
     "wgrad_g4_bf16_128x64_4tap": ("wgrad_g4_kernel<128,",),
@@ -73,7 +76,10 @@ def newest_pmc_file(root: str = None):
 
 def pmc_rows(family: str, pmc_kernels: dict) -> list:
     keys = PMC_KEYS.get(family, ())
-    return [v for k, v in pmc_kernels.items() if any(c in k for c in keys)]
+
+    def hit(sym, alt):
+        return alt in sym if isinstance(alt, str) else all(a in sym for a in alt)
+    return [v for k, v in pmc_kernels.items() if any(hit(k, c) for c in keys)]
 
 
 def torch_criterion(out, mask):

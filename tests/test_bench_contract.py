@@ -56,11 +56,16 @@ def test_every_timed_family_with_a_key_resolves():
 
 def test_pingpong_variants_share_one_key():
     b = _bench()
-    fake = {"void (anonymous namespace)::conv3x3_pp_kernel<(anonymous namespace)::PpCfg<16, 32, 4, 2, 1>, false, false>(x)": 1,
-            "void (anonymous namespace)::conv3x3_pp_kernel<(anonymous namespace)::PpCfg<16, 32, 4, 2, 1>, true, false>(x)": 2,
-            "void (anonymous namespace)::conv3x3_pp_kernel<(anonymous namespace)::PpCfg<16, 32, 8, 1, 3>, false, false>(x)": 3}
+    fake = {"void (anonymous namespace)::conv3x3_pp_kernel<(anonymous namespace)::PpCfg<16, 32, 4, 2, 1, false>, false, false, false>(x)": 1,
+            "void (anonymous namespace)::conv3x3_pp_kernel<(anonymous namespace)::PpCfg<16, 32, 4, 2, 1, false>, true, false, false>(x)": 2,
+            "void (anonymous namespace)::conv3x3_pp_kernel<(anonymous namespace)::PpCfg<16, 32, 8, 1, 3, false>, false, false, false>(x)": 3,
+            "void (anonymous namespace)::conv3x3_pp_kernel<(anonymous namespace)::PpCfg<16, 32, 8, 1, 3, true>, false, false, true>(x)": 4,
+            "void (anonymous namespace)::wgrad9_kernel<64, 64, 0, 4, 1, 1, false>(Wg9Args)": 5,
+            "void (anonymous namespace)::wgrad9_kernel<64, 64, 0, 4, 1, 1, true>(Wg9Args)": 6}
     assert sorted(b.pmc_rows("conv3x3_pp512_bf16", fake)) == [1, 2]
     assert b.pmc_rows("conv3x3_pp512x64_bf16", fake) == [3]
+    assert b.pmc_rows("conv3x3_pp512x64_bf16_xf", fake) == [4]          # the input-transform forms are families of their own
+    assert b.pmc_rows("wgrad9_bf16_64x64_rowwalk", fake) == [5] and b.pmc_rows("wgrad9_bf16_64x64_rowwalk_xf", fake) == [6]
 
 
 def test_cpu_baseline_protocol_defaults():

@@ -24,8 +24,10 @@ plain = json.loads(open("gpurun_out/prof_default_bench_plain.json").read().strip
 fam = plain["roofline"]["kernel"]             # the dominant kernel family of the un-profiled line, by the library's own name
 pats = bm.PMC_KEYS[fam]                       # ... and the kernel symbols that belong to it (bench.py's table)
 rows = []
-for sub in pats:
-    rows += [r for r in c.execute("select start, duration/1000.0 from kernels where name like ? order by start", ("%" + sub + "%",))]
+for alt in pats:                              # a substring, or a tuple of substrings that must all occur
+    subs = (alt,) if isinstance(alt, str) else tuple(alt)
+    rows += [(r[0], r[1]) for r in c.execute("select start, duration/1000.0, name from kernels where name like ? order by start",
+                                             ("%" + subs[0] + "%",)) if all(x in r[2] for x in subs)]
 rows.sort()
 marks = [r[0] for r in c.execute("select start from kernels where name like '%adamw_apply_kernel%' order by start")]
 per_step = len([r for r in rows if marks[-2] < r[0] < marks[-1]])      # launches inside one graph replay
