@@ -353,6 +353,8 @@ def main():
                          "runs, and bf16 autocast + channels_last); the default line carries the second, faster one only "
                          "(MIOpen's first-use search: ~75 s) -> \"torch_rocm_baseline\" in the line")
     ap.add_argument("--no-torch-baseline", action="store_true")
+    ap.add_argument("--torch-baseline-child", default=None, metavar="OUT.json",
+                    help=argparse.SUPPRESS)    # internal: the yardstick's helper process (started before the GPU is touched)
     ap.add_argument("--cpu-batch", type=int, default=None,
                     help="batch of the CPU baseline (default: the configuration's own batch, capped at 16 -- unet B=16: "
                          "~6 s per step on the 16 host threads of a one-GPU box)")
@@ -397,6 +399,57 @@ def main():
         print(f"bench.py: refusing to run with ablation switches set in the environment: {stray}", file=sys.stderr)
         sys.exit(2)
 
+    # ---- the stock-PyTorch yardstick runs in a HELPER process: MIOpen's first-use search takes 60-80 s, and a hang or an abort
+    # in a vendor library must cost the yardstick, not the line.  The helper is started here, BEFORE this process touches the
+    # GPU (a GPU process must not fork + exec on these boxes), waits on its stdin, and is told to go after the timed work.
+    if args.torch_baseline_child:
+        if not sys.stdin.readline().strip():     # "go"; EOF = the parent is gone or skipped the yardstick: do nothing
+            return
+        out = {"error": "no go"}
+        try:
+            out = torch_rocm_baseline(args.batch, args.size, 10, args.model, both=args.torch_baseline)
+        except Exception as e:      # noqa: BLE001
+            out = {"error": repr(e)[:200]}
+        with open(args.torch_baseline_child, "w") as f:
+            json.dump(out, f)
+        return
+    helper = None
+    want_yardstick = args.torch_baseline or not (args.no_torch_baseline or args.no_cpu_baseline)
+    if (want_yardstick and not launch.under_launcher() and (args.gpus in (None, 1)) and not args.force_dist):
+        import subprocess
+        import tempfile
+        helper_out = os.path.join(tempfile.mkdtemp(prefix="uz_bench_"), "torch_baseline.json")
+        helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--torch-baseline-child", helper_out, "--model",
+                                   args.model, "--batch", str(args.batch), "--size", str(args.size)]
+                                  + (["--torch-baseline"] if args.torch_baseline else []),
+                                  stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        _bench_main(args, helper, helper_out if helper is not None else None)
+    finally:
+        if helper is not None and helper.poll() is None:      # not told to go, or still running past its time: this exact PID
+            helper.kill()
+            helper.wait()
+
+
+def _yardstick_from_helper(helper, helper_out, limit_s: float):
+    """tell the helper to go, wait at most limit_s, read what it wrote"""
+    import subprocess
+    try:
+        helper.stdin.write(b"go\n")
+        helper.stdin.flush()
+        helper.wait(timeout=limit_s)
+        return json.load(open(helper_out))
+    except subprocess.TimeoutExpired:
+        helper.kill()
+        helper.wait()
+        return {"error": f"the stock-PyTorch yardstick did not finish within {limit_s:.0f} s (MIOpen's search); killed"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:200]}
+
+
+def _bench_main(args, helper, helper_out):
+    global _LOSS_IMPL
+    _LOSS_IMPL = args.loss
     # ---- ranks: one process per GPU, started BEFORE this process touches the GPU ---------------------------
     if not launch.under_launcher():
         want = 1 if args.gpus is None else args.gpus
@@ -647,11 +700,9 @@ def main():
             # (8 threads, to compare with the survey's anchors: a quarter of the batch keeps the default run short)
             cb["value_8_threads"] = cpu_baseline(max(cpu_b // 4, 1), args.size, 1, args.model, threads=8)["value"]
             line["cpu_baseline"] = cb
-        if world == 1 and not distributed and (args.torch_baseline or not (args.no_torch_baseline or args.no_cpu_baseline)):
-            try:
-                line["torch_rocm_baseline"] = torch_rocm_baseline(args.batch, args.size, 10, args.model, both=args.torch_baseline)
-            except Exception as e:      # noqa: BLE001  (a yardstick must not cost the line)
-                line["torch_rocm_baseline"] = {"error": repr(e)[:200]}
+        if helper is not None:
+            # 75-80 s of search + steps for the bf16 form; both forms (--torch-baseline) twice that and more at 512 x 512
+            line["torch_rocm_baseline"] = _yardstick_from_helper(helper, helper_out, 900.0 if args.torch_baseline else 300.0)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
