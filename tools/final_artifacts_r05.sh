@@ -14,7 +14,7 @@ if [ "$PART" = a ]; then
   cat gpurun_out/${TAG}_roofline_agreement.txt
   bash tools/profile_bench.sh ${TAG}_unet > gpurun_out/pb.log 2>&1
   bash tools/profile_bench.sh ${TAG}_swin_unet_v2_256 --model swin_unet_v2 > gpurun_out/pb2.log 2>&1
-  tail -2 gpurun_out/pb.log gpurun_out/pb2.log
+  tail -n 2 gpurun_out/pb.log; tail -n 2 gpurun_out/pb2.log
 else
   bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_traffic.json --second-steps 0 > gpurun_out/pmc_t.log 2>&1
   tail -3 gpurun_out/pmc_t.log
