@@ -353,3 +353,53 @@ def test_batched_row_sums_equal_the_single_launches_bit_for_bit():
         assert np.array_equal(o0.cpu().numpy(), r0)
         if o1 is not None:
             assert np.array_equal(o1.cpu().numpy(), r1[:n - n0])
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("ws,shift,Nt", [(8, 4, 64), (8, 0, 64), (7, 3, 49)])
+def test_window_attention_backward_follows_the_norm_clamp_of_the_reference(dt, ws, shift, Nt):
+    """swin_unet_v2.py:137-139 divides q k^T by max(|q||k|, 1e-6): a pair under the clamp keeps u / 1e-6 and has no projection
+    term in its gradient.  Rounds 1-4: the bf16 kernel was exact for zero rows only.  Here image 0 has every key at 1e-2 of
+    its size and three queries at 1e-5 -- norm products of ~5e-7, NOT zero -- beside ordinary rows and a zero row; dqkv
+    (whose largest entries are exactly those rows': the clamp's 1e6 factor) against the restatement, which follows the
+    clamp pair by pair (pinned against torch autograd of the reference's formula, tests/test_c_ref.py)."""
+    lib = c_ref.load()
+    g = torch.Generator().manual_seed(7 * ws + shift)
+    B, heads = 2, 3
+    H = W = 2 * ws
+    C, N, P = 32 * heads, ws * ws, B * H * W
+    qkv = rnd((P, 3 * C), torch.float32, g)
+    qkv[:H * W, C:2 * C] *= 1e-2                       # image 0: small keys
+    for t in (3, 17, 40, H * W - 1):
+        qkv[t, :C] *= 1e-5                             # ... and a few tiny (non-zero) queries: |scale q||k| ~ 5e-7
+    qkv[H * W + 5, :C] = 0                             # image 1: a zero query row
+    qkv = qkv.to(dt)
+    nq = qkv[3, :32].float().norm() * 32 ** -0.5
+    nk = qkv[4, C:C + 32].float().norm()
+    assert 0 < nq * nk < 1e-6
+    tau = torch.rand(heads, Nt, Nt, generator=g) * 0.5 + 0.05
+    bias = torch.randn(heads, N, N, generator=g) * 0.3
+    dout = rnd((P, C), dt, g)
+    qa, da = Act(qkv.to(DEV), 0, 3 * C, B, H, W), Act(dout.to(DEV), 0, C, B, H, W)
+    out, dq = ops.new_act(B, H, W, C, dt, DEV), ops.new_act(B, H, W, 3 * C, dt, DEV)
+    lse = ops.winattn_fwd(qa, tau.to(DEV), bias.to(DEV), out, heads, ws, shift)
+    ops.winattn_bwd(qa, tau.to(DEV), bias.to(DEV), out, lse, da, dq, heads, ws, shift)
+    d = L.WinAttnDesc(L.dtype_code(dt), B, H, W, C, heads, ws, shift, Nt, 3 * C, C, 32 ** -0.5)
+    nwin = B * (H // ws) * (W // ws)
+    o_r, l_r = np.zeros(P * C, npdt(dt)), np.zeros(nwin * heads * N, np.float32)
+    qh, th, bh, dh = c_ref.host(qkv), c_ref.host(tau), c_ref.host(bias), c_ref.host(dout)
+    assert lib.uz_winattn_fwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(th), c_ref.ptr(bh), c_ref.ptr(o_r), c_ref.ptr(l_r), None) == 0
+    dq_r, part = np.zeros(P * 3 * C, npdt(dt)), np.zeros(2 * heads * N * N, np.float32)
+    assert lib.uz_winattn_bwd_ref(byref(d), c_ref.ptr(qh), c_ref.ptr(th), c_ref.ptr(bh), c_ref.ptr(o_r), c_ref.ptr(l_r), c_ref.ptr(dh), C,
+                                  c_ref.ptr(dq_r), 3 * C, c_ref.ptr(part), None) == 0
+    got, want = dq.buf.double().cpu(), c_ref.tensor(dq_r, dt).reshape(P, 3 * C).double()
+    tol = 1e-4 if dt == torch.float32 else 3e-2
+    # the tiny queries' gradient rows (d q of image 0's rows 3, 17, 40, last) carry the 1e6 factor: compare them by themselves,
+    # then everything else by itself (a global maximum would let either hide behind the other)
+    tiny = torch.zeros(P, dtype=torch.bool)
+    tiny[[3, 17, 40, H * W - 1]] = True
+    for name, rows, cols in (("dq of the clamped queries", tiny, slice(0, C)), ("dk of image 0", torch.arange(P) < H * W, slice(C, 2 * C)),
+                             ("the rest", ~tiny, slice(0, 3 * C))):
+        a, b = got[rows][:, cols], want[rows][:, cols]
+        err = ((a - b).abs().max() / b.abs().max()).item()
+        assert err <= tol, (name, err, b.abs().max().item())

@@ -32,7 +32,7 @@ def build(attrs, model_name, B, S):
     import bench   # the benchmark's own create_model call (swin: image_size and a window that divides the token maps)
     model = bench.make_model(model_name, S)[0].cuda()
     model.run_dtype = torch.bfloat16
-    step = unet_zoo_amd.GraphedStep(model, "bce_dice", lr=1e-4, weight_decay=1e-2, max_norm=1.0)
+    step = unet_zoo_amd.GraphedStep(model, "bce_dice", lr=1e-4, weight_decay=1e-5, max_norm=1.0)
     x = torch.randn(B, 3, S, S, device="cuda")
     t = (torch.rand(B, 1, S, S, device="cuda") > 0.5).float()
     for _ in range(3):

@@ -1029,15 +1029,20 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   // W = dC / (|q||k|) of its block in LDS as bf16 [key][query], which is the B operand of the dk / dv products,
   // so there is no second element pass.  The projection terms of the two normalisations come from the products
   // themselves: with A_i = sum_j W_ij k_j, sum_j dC_ij c_ij = q_i . A_i (likewise for k), a 32-term dot in
-  // the epilogue instead of six operations per score element.  (A row whose norm product falls under the
-  // reference's 1e-6 clamp keeps the clamped quotient but not its projection-free gradient; exact zero rows
-  // are exact.  The fp32 kernel below follows the clamp to the letter.)
+  // the epilogue instead of six operations per score element.  The reference clamps the norm product at 1e-6
+  // (swin_unet_v2.py:137-139): a clamped pair keeps u / 1e-6 and has NO projection term.  Round 5 follows that to the
+  // letter: a wave whose queries could reach the clamp against this key tile (|scale q| * min |k| < 1e-6, a test of one
+  // multiply per window) takes a slow path that sums W_ij u_ij over its clamped pairs -- per query in a register, per key
+  // by shuffles into sCorrK -- and the epilogues subtract those sums from q_i . A_i / k_j . B_j.  (Rounds 1-4 kept the
+  // projection term for 0 < |q||k| <= 1e-6 and were exact for zero rows only.)
   // Partial dq (over kt) and dk / dv (over qt) of the two waves that share a tile meet in LDS.
   __shared__ __attribute__((aligned(16))) bf16_t sKT[AD * VTS], sGT[AD * VTS], sQT[AD * VTS];
   __shared__ __attribute__((aligned(16))) bf16_t sPW[2 * AN * VTS];   // P, W [key][query]; later the dk / dv hand-over
   __shared__ float sRedQ[2][64 * 17];   // dq hand-over of the kt = 1 waves, [lane][16] (+1 pad)
   __shared__ __attribute__((aligned(16))) float sRk[AN];   // 1 / |k_j|
   __shared__ __attribute__((aligned(16))) int sCnt[AN];
+  __shared__ float sRkMax[2];        // per key tile: max 1 / |k_j| over its non-zero keys
+  __shared__ float sCorrK[2][AN];    // [query tile][key]: sum over the tile's CLAMPED pairs of W_ij u_ij (zero in the fast path)
   // 1 / clip(tau) (negated where the clip is active) and the bias of this head in LANE ORDER: a lane's 16 score elements are
   // the same (query, key) pairs in every window, [table][g4][thread] holds its four values of key group g4 as one 16-byte
   // read that is conflict-free across the wave (the [query][key] table it replaces cost 32 ds_read_b32 per window, each
@@ -1174,11 +1179,16 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
             sQT[d * VTS + iq] = qf[ks][e];
           }
       }
+      if (lh == 0) sCorrK[qt][jk] = 0.f;   // this wave's own region; filled by its slow path only
       if (qt == 0) {
         if (lh == 0) {
           sRk[jk] = rcp(sqrtf(k2));
           sCnt[jk] = tkk.cnt;
         }
+        float rkm = k2 > 0.f ? rcp(sqrtf(k2)) : 0.f;   // zero keys (padding, dead rows) cannot contribute: u = 0
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) rkm = fmaxf(rkm, __shfl_xor(rkm, m));
+        if (lane == 0) sRkMax[kt] = rkm;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1189,6 +1199,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
 
     // ---------------- element pass: column = query iq, rows = keys of tile kt
     f32x16 dq, dk, dv;
+    float corrQ_keep = 0.f;
     {
       f32x16 ut, dt;
 #pragma unroll
@@ -1200,6 +1211,9 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       }
       if (win + (int)gridDim.x < nWin) fetch(win + gridDim.x);
       float w1[16];
+      // could any pair of this wave fall under the clamp?  1 / (|scale q_i| |k_j|) > 1e6 for the smallest non-zero |k| of the tile
+      float corrQ = 0.f;
+      const bool slow = __ballot(rq < INFINITY && rq * sRkMax[kt] > 1e6f) != 0;
       bf16_t* pcol = sP + (32 * kt + 4 * lh) * VTS + iq;
       bf16_t* wcol = sW + (32 * kt + 4 * lh) * VTS + iq;
       // per key group of four: 1 / |k|, the two table entries (and, under the shifted-window mask, the region ids) in one
@@ -1228,6 +1242,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
           const f32x2 pn2 = hp ? (f32x2){pn.z, pn.w} : (f32x2){pn.x, pn.y};
           const f32x2 ut2 = {ut[r], ut[r + 1]}, dt2 = {dt[r], dt[r + 1]};
           f32x2 rden = rq2 * rk2;                                  // 1 / max(|scale q||k|, 1e-6)
+          const bool cx = slow && rden.x > 1e6f, cy = slow && rden.y > 1e6f;
           rden.x = fminf(rden.x, 1e6f);
           rden.y = fminf(rden.y, 1e6f);
           const f32x2 c = (ut2 * sc2) * rden;
@@ -1239,6 +1254,19 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
           accb2[r >> 1] += ds;
           acct2[r >> 1] = __builtin_elementwise_fma(ds, c, acct2[r >> 1]);
           const f32x2 ww = (ds * ti2) * rden;
+          if (slow) {   // wave-uniform; W_ij u_ij of the clamped pairs: per query here, per key across the 32 query lanes
+            float ex = cx ? ww.x * ut2.x : 0.f, ey = cy ? ww.y * ut2.y : 0.f;
+            corrQ += ex + ey;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+              ex += __shfl_xor(ex, m);
+              ey += __shfl_xor(ey, m);
+            }
+            if (l31 == 0) {
+              sCorrK[qt][32 * kt + 4 * lh + jr] = ex;
+              sCorrK[qt][32 * kt + 4 * lh + jr + 1] = ey;
+            }
+          }
           w1[r] = ww.x;
           w1[r + 1] = ww.y;
           pcol[jr * VTS] = (bf16_t)pp.x;
@@ -1262,7 +1290,9 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         float* red = &sRedQ[qt][lane * 17];
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[r] = dq[r];
+        red[16] = corrQ;
       }
+      corrQ_keep = corrQ;
     }
     lds_barrier();   // dq partials visible; every wave is done with P / W
     if (kt == 0 && iq < N) {
@@ -1285,7 +1315,9 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       }
       dot += __shfl_xor(dot, 32);
       q2 += __shfl_xor(q2, 32);
-      const float pr = dot * rcp(fmaxf(q2, 1e-30f));
+      float cq = corrQ_keep + r1[16];          // the clamped pairs of both key tiles ...
+      cq += __shfl_xor(cq, 32);                // ... and both halves of the rows: they have no projection term
+      const float pr = (dot - cq) * rcp(fmaxf(q2, 1e-30f));
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         bf16x4 o4;
@@ -1323,6 +1355,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
       }
       dot += __shfl_xor(dot, 32);
       k2 += __shfl_xor(k2, 32);
+      dot -= a.scale * (sCorrK[0][jk] + sCorrK[1][jk]);   // clamped pairs (both query tiles): no projection term
       const float pr = dot * rcp(fmaxf(k2, 1e-30f));
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {

@@ -702,18 +702,28 @@ int uz_wgrad9_launch(const uz_wgrad_desc* d, const UzWgrad2Plan& p, const void* 
     else if (up) hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 1, 4, 1, 1>), grid, dim3(512), 0, s, a);      \
     else hipLaunchKernelGGL((wgrad9_kernel<BI_, KW_, 0, 4, 1, 1>), grid, dim3(512), 0, s, a);              \
   } while (0)
-  const bool w4 = (a.flags & 0x20000000) != 0;   // ablation build: the 128-wide tile on four waves of 64 x 32
+#ifdef UZ_ABLATE
+  // the measurement build (make ABLATE=1) keeps the forms this round's plan was chosen against: the 128 x 64 tile on eight
+  // do-everything waves (0x10000000) or on four waves of 64 x 32 (+ 0x20000000), the 64 x 64 tile on four do-everything
+  // waves (0x20000000) or on eight waves in two pixel groups (0x2000000).  The shipped library does not instantiate them
+  // (round-4 review: 36 kernels, 2 MB of the .so, that no plan of the shipped build can select).
+  const bool w4 = (a.flags & 0x20000000) != 0;
   if (p.bi == 128) {
     if (p.kw == 64) { if (w4) UZ_W9_LAUNCH1(128, 64, 4); else UZ_W9_LAUNCH1(128, 64, 8); }
     else if (p.kw == 32) { if (w4) UZ_W9_LAUNCH1(128, 32, 4); else UZ_W9_LAUNCH1(128, 32, 8); }
     else { if (w4) UZ_W9_LAUNCH1(128, 16, 4); else UZ_W9_LAUNCH1(128, 16, 8); }
   } else {
-    // ablation build: 0x20000000 four waves that do everything, 0x2000000 eight waves in two pixel groups
     const int form = (a.flags & 0x20000000) ? 1 : ((a.flags & 0x2000000) ? 2 : 0);
     if (p.kw == 64) { if (form == 1) UZ_W9_LAUNCH1(64, 64, 4); else if (form == 2) UZ_W9_LAUNCH2(64, 64, 8, 2); else UZ_W9_LAUNCHL(64, 64); }
     else if (p.kw == 32) { if (form == 1) UZ_W9_LAUNCH1(64, 32, 4); else if (form == 2) UZ_W9_LAUNCH2(64, 32, 8, 2); else UZ_W9_LAUNCHL(64, 32); }
     else { if (form == 1) UZ_W9_LAUNCH1(64, 16, 4); else if (form == 2) UZ_W9_LAUNCH2(64, 16, 8, 2); else UZ_W9_LAUNCHL(64, 16); }
   }
+#else
+  UZ_REQUIRE(p.bi == 64, "uz_wgrad9: the 128 x 64 tile exists in the measurement build only");
+  if (p.kw == 64) UZ_W9_LAUNCHL(64, 64);
+  else if (p.kw == 32) UZ_W9_LAUNCHL(64, 32);
+  else UZ_W9_LAUNCHL(64, 16);
+#endif
 #undef UZ_W9_LAUNCH1
 #undef UZ_W9_LAUNCH2
 #undef UZ_W9_LAUNCHL
