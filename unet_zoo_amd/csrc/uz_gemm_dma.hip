@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
       const int h = rem / a.W, w = rem - h * a.W;
       return ((long long)img * a.Hout + 2 * h + (ab >> 1)) * a.Wout + 2 * w + (ab & 1);
     };
-    // a whole BN tile belongs to one sub-pixel (Co % BN == 0, checked on the host)
+    // fp32 path: a whole BN tile belongs to one sub-pixel (Co % BN == 0, checked on the host); the bf16 path decides per chunk
     const int ab = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 / a.Co : 0;
     const int co0 = (a.store == UZ_STORE_SHUFFLE2X2) ? n0 - ab * a.Co : n0;
     pre = 0;
@@ -325,6 +325,12 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
       static_assert(512 % CPR == 0, "a thread keeps one channel chunk");
       const int cc = tid % CPR;
       const bool cok = n0 + cc * VEC < a.Nout;
+      // this thread's 16-byte channel chunk: its sub-pixel and its channel inside the sub-pixel.  Per chunk, not per tile: a
+      // tile may straddle sub-pixels when Co is not a multiple of BN (PatchExpand with Co = 96: swin_unet_v2.py:343-351)
+      const int nthr = n0 + cc * VEC;
+      const bool shuf = !BNRED && a.store == UZ_STORE_SHUFFLE2X2;   // (the fused-reduction form stores plain only)
+      const int abt = (shuf && cok) ? nthr / a.Co : 0;
+      const int cot = shuf ? nthr - abt * a.Co : nthr;
       // all of a thread's chunks are requested from LDS before the first store (see uz_conv3x3.hip)
       constexpr int NPASS = BM * CPR / 512, RPP = 512 / CPR;
       Vec16<T> vb[NPASS];
@@ -352,8 +358,8 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
         Vec16<T> rb[NPASS];
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
-          const long long orow = out_row(tid / CPR + k * RPP, ab);
-          rb[k] = (orow >= 0 && cok) ? ld16(rg + (size_t)orow * a.ldres + co0 + cc * VEC) : zero16<T>();
+          const long long orow = out_row(tid / CPR + k * RPP, abt);
+          rb[k] = (orow >= 0 && cok) ? ld16(rg + (size_t)orow * a.ldres + cot) : zero16<T>();
         }
 #pragma unroll
         for (int k = 0; k < NPASS; ++k)
@@ -362,9 +368,9 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
       }
 #pragma unroll
       for (int k = 0; k < NPASS; ++k) {
-        const long long orow = out_row(tid / CPR + k * RPP, ab);
+        const long long orow = out_row(tid / CPR + k * RPP, abt);
         if (orow >= 0 && cok) {
-          st16(yg + (size_t)orow * a.ldy + co0 + cc * VEC, vb[k]);
+          st16(yg + (size_t)orow * a.ldy + cot, vb[k]);
           if constexpr (BNRED) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -494,6 +500,7 @@ int uz_gemm_dma_plan(const uz_conv_desc* d, UzGemmPlan* p) {
     if (gath) return 0;
     if (d->Co % 128 == 0) p->bn = 128;
     else if (d->Co % 64 == 0) p->bn = 64;
+    else if (d->dtype == UZ_BF16 && d->Co % vec == 0) p->bn = d->Nout <= 64 ? 64 : 128;   // tiles straddle sub-pixels: per-chunk store
     else return 0;
   }
   const long long M = (long long)d->N * d->H * d->W;
