@@ -29,7 +29,7 @@ class ConvBlock(nn.Module):
 
     def emit(self, eng: Engine, x: Act, *, pool: bool = False, im2col: bool = False):
         s = self.conv
-        mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col)
+        mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col, defer_apply=s[3])   # read through BN + ReLU where the kernels can (Engine.fold_bn_apply)
         return eng.conv_bn_relu(mid, s[3], s[4], pool=pool, sole_reader=True)
 
 

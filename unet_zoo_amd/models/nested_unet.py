@@ -31,7 +31,7 @@ class VGGBlock(nn.Module):
 
     def emit(self, eng: Engine, x: Act, *, out: Optional[Act] = None, pool: bool = False,
              im2col: bool = False) -> Tuple[Act, Optional[Act]]:
-        mid, _ = eng.conv_bn_relu(x, self.conv1, self.bn1, im2col=im2col)
+        mid, _ = eng.conv_bn_relu(x, self.conv1, self.bn1, im2col=im2col, defer_apply=self.conv2)   # Engine.fold_bn_apply
         return eng.conv_bn_relu(mid, self.conv2, self.bn2, out=out, pool=pool, sole_reader=True)
 
 

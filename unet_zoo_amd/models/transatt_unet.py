@@ -42,7 +42,7 @@ class DoubleConvo(nn.Module):
     def emit(self, eng: Engine, x: Act, *, out: Optional[Act] = None, pool: bool = False,
              im2col: bool = False) -> Tuple[Act, Optional[Act]]:
         s = self.double_conv
-        mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col)
+        mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col, defer_apply=s[3])   # Engine.fold_bn_apply
         return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True)
 
 
