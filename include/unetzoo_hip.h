@@ -338,8 +338,9 @@ int uz_bn_relu_add_apply_fin(int dtype, const void* y, int ldy, const float* sta
                              const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                              float* running_var, float* vec, int* flag, int N, int H, int W, int C, const void* res, int ldr,
                              void* act, int lda, void* pooled, int ldp, int pool_ceil, void* stream);
-/* pool_ceil = 1: pooled is (N, ceil(H/2), ceil(W/2), C), border windows clipped (ceil_mode=True, u2net.py:30);
- * pool_ceil = 0: pooled is (N, H/2, W/2, C), an odd last row / column is not pooled (MaxPool2d default). */
+/* pool_ceil bit 0 = 1: pooled is (N, ceil(H/2), ceil(W/2), C), border windows clipped (ceil_mode=True, u2net.py:30);
+ * bit 0 = 0: pooled is (N, H/2, W/2, C), an odd last row / column is not pooled (MaxPool2d default); bit 1: BatchNorm without
+ * the ReLU; bit 2: the pass walks the tensor from its end (see uz_bnbwd_desc.pool_ceil; identical output). */
 
 /* Backward of (BN train -> ReLU [-> MaxPool2d(2,2)]) in two passes.
  * The gradient arriving at the activation is
@@ -356,7 +357,11 @@ typedef struct uz_bnbwd_desc {
   int pool_ceil; /* bit 0: geometry of gpool: 1 = (ceil(H/2), ceil(W/2)) with clipped border windows, 0 = (H/2, W/2);
                   * bit 1: the forward was BatchNorm WITHOUT ReLU (uz_bn_relu_add_apply with the same bit); with unit
                   * scale and zero shift that pair is a stand-alone MaxPool2d(2) of an arbitrary tensor
-                  * (unet_transformer.py:151) */
+                  * (unet_transformer.py:151);
+                  * bit 2: walk the tensors from their END (same values; the part the producing kernel wrote last is what
+                  * the 256 MB Infinity Cache still holds -- a pass after a convolution runs 15 % faster that way; the
+                  * partial rows of pass 1 then belong to other pixel groups, so the fp32 totals differ in the last bits
+                  * between the two walks, each walk being deterministic) */
 } uz_bnbwd_desc;
 /* Statistics of a BatchNorm whose input is not a convolution output (pre-activation blocks, `ResidualConv`,
  * common_layers.py:186-187): per-channel sum and sum of squares of x (P pixels, C channels, row stride ld) as

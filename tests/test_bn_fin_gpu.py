@@ -150,3 +150,45 @@ def test_a_training_step_is_the_same_with_and_without_the_fused_finalize(name):
             assert torch.equal(p1.grad, p2.grad), n1
     for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
         assert torch.equal(b1, b2), n1
+
+
+@pytest.mark.parametrize("dt,N,H,W,C,rows,pool,residual,relu", CASES)
+def test_walking_from_the_end_gives_the_same_values(dt, N, H, W, C, rows, pool, residual, relu):
+    """bit 2 of the passes' flag word (Engine.reverse_element_passes): the apply pass is a pure element pass -- identical bytes;
+    the backward's totals are summed in other pixel groups -- equal to fp32 rounding, dy within one rounding of the tensor type"""
+    g = torch.Generator().manual_seed(C + 7)
+    y, _, gamma, beta = make(dt, N, H, W, C, rows, g)
+    ceil_mode = bool(H % 2 or W % 2)
+    res = None
+    if residual:
+        res = ops.new_act(N, H, W, C, dt, DEV)
+        res.buf.copy_(torch.randn(N * H * W, C, generator=g).to(dt))
+    outs = []
+    for rev in (False, True):
+        act = ops.new_act(N, H, W, C, dt, DEV)
+        pooled = ops.new_act(N, (H + 1) // 2 if ceil_mode else H // 2, (W + 1) // 2 if ceil_mode else W // 2, C, dt, DEV) if pool else None
+        ops.bn_relu_apply(y, gamma, beta, act, pooled, res, ceil_mode, relu=relu, reverse=rev)
+        outs.append((act.buf.clone(), pooled.buf.clone() if pool else None))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if pool:
+        assert torch.equal(outs[0][1], outs[1][1])
+
+    vec = torch.stack([gamma, beta, torch.randn(C, generator=g).to(DEV) * 0.1, (torch.rand(C, generator=g) + 0.5).to(DEV)])
+    g0 = ops.new_act(N, H, W, C, dt, DEV)
+    g0.buf.copy_(torch.randn(N * H * W, C, generator=g).to(dt))
+    gp = None
+    if pool and relu:
+        gp = ops.new_act(N, (H + 1) // 2 if ceil_mode else H // 2, (W + 1) // 2 if ceil_mode else W // 2, C, dt, DEV)
+        gp.buf.copy_(torch.randn(gp.P, C, generator=g).to(dt))
+    res = []
+    for rev in (False, True):
+        sums = torch.zeros(2, C, dtype=torch.float64, device=DEV)
+        dy = ops.new_act(N, H, W, C, dt, DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        ops.bn_relu_bwd(y, vec, g0, None, gp, sums, dy, dg, db, ceil_mode, relu=relu, reverse=rev)
+        torch.cuda.synchronize()
+        res.append((sums.clone(), dy.buf.float().clone(), dg.clone(), db.clone()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-4) and torch.allclose(res[0][3], res[1][3], rtol=1e-5, atol=1e-4)
+    tol = 1e-5 if dt == torch.float32 else 2.0 ** -7
+    assert ((res[0][1] - res[1][1]).abs() <= tol * (res[0][1].abs() + 1e-2 * res[0][1].abs().max())).all()
