@@ -1,5 +1,5 @@
 """fp32 gradient of one model under input perturbations of 1e-7 ... 1e-5: how much of a golden-vector gradient mismatch is
-the network amplifying rounding noise (ReLU masks, max-pool selections) rather than a kernel.  usage: python tools/grad_sensitivity.py"""
+the network amplifying rounding noise (ReLU masks, max-pool selections) rather than a kernel.  usage: python tests/debug/grad_sensitivity.py"""
 import torch, torch.nn.functional as F, sys
 sys.path.insert(0, ".")
 import unet_zoo_amd

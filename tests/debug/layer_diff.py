@@ -1,6 +1,6 @@
 """Debug tool (GPU): per-layer divergence of a model's HIP-engine forward from the oracle (every Conv + BN + ReLU
 output), optionally with the oracle rounding to bf16 at the engine's storage points.
-Usage: python tools/layer_diff.py MODEL H W [bf16|fp32] [key=value ...]   (values are eval'd: res=(16,24))"""
+Usage: python tests/debug/layer_diff.py MODEL H W [bf16|fp32] [key=value ...]   (values are eval'd: res=(16,24))"""
 import sys
 
 import torch

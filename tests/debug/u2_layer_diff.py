@@ -1,5 +1,5 @@
 """Debug tool (GPU): per-layer divergence of the HIP engine's u2net forward from the oracle with the
-same bf16 storage-rounding points.  Usage: python tools/u2_layer_diff.py [u2net|u2netp] [size]"""
+same bf16 storage-rounding points.  Usage: python tests/debug/u2_layer_diff.py [u2net|u2netp] [size]"""
 import sys
 
 import torch

@@ -2,7 +2,7 @@
 same oracle with fp32-rounding-size jitter in front of every storage rounding (J), as tests/test_bf16_yardstick_gpu.py
 builds them.  For every parameter |E - O| / |O|, |J - O| / |O| and the two cosines, in forward order; several jitter seeds
 show how far two correct implementations scatter.
-Usage: python tools/yardstick_by_param.py MODEL H W [seeds]"""
+Usage: python tests/debug/yardstick_by_param.py MODEL H W [seeds]"""
 import sys
 
 import torch

@@ -88,7 +88,7 @@ CASES = [
     ("unet", 64, 64, 3e-2, 1e-2, 0.995, 0.92),
     ("unet", 64, 96, 3e-2, 1e-2, 0.995, 0.92),
     # Attention U-Net: BOTH inputs of every decoder convolution (the gated skip psi * x and the upsampled path) carry
-    # the decoder's error, which therefore grows ~1.25x per layer instead of shrinking (tools/layer_diff.py)
+    # the decoder's error, which therefore grows ~1.25x per layer instead of shrinking (tests/debug/layer_diff.py)
     # Measured: engine vs oracle logits rms 0.083, gradient cosine 0.83, worst parameter 0.76 -- while the oracle against
     # ITSELF with 1e-6 jitter in front of its storage roundings is 0.14 / 0.70 / 0.60: the network, not a kernel
     ("attention_unet", 64, 64, 0.15, 0.15, 0.75, 0.5),

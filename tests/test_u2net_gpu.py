@@ -338,7 +338,7 @@ def test_u2net_bf16_first_stage_tracks_storage_rounded_oracle(name):
     dilated layers, fused pools, bilinear resizes into concat halves, the residual tail) against the
     oracle that rounds to bf16 at the same storage points.  Deeper stages are not comparable in bf16:
     this random-init network amplifies a rounding-level perturbation 10^4 x by the last layer (measured
-    in fp32: 9e-8 -> 1e-3, tools/u2_layer_diff.py), so two correct bf16 evaluations decorrelate."""
+    in fp32: 9e-8 -> 1e-3, tests/debug/u2_layer_diff.py), so two correct bf16 evaluations decorrelate."""
     from unet_zoo_amd.engine import Engine
     torch.manual_seed(3)
     m = unet_zoo_amd.create_model(name)

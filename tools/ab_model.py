@@ -3,13 +3,20 @@ the plans are made, i.e. at capture).   python tools/ab_model.py MODEL SIZE BATC
 import os
 import sys
 import time
+
+
+def _synthetic_batch(B, C, H, W, seed=1):
+    """randn image, rand > 0.5 mask, one generator (the fixture protocol; tools/ do not import the oracle)"""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, C, H, W, generator=g), (torch.rand(B, 1, H, W, generator=g) > 0.5).float()
+
+
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("UNET_ZOO_AMD_LIB", os.path.join(_ROOT, "unet_zoo_amd", "libunetzoo_hip_ablate.so"))
 import torch
 sys.path.insert(0, _ROOT)
 import unet_zoo_amd
 from unet_zoo_amd import ops
-from oracle import torch_ref
 
 
 def main():
@@ -21,7 +28,7 @@ def main():
         if a.startswith("--steps="):
             steps = int(a.split("=")[1])
     dev = torch.device("cuda", 0)
-    x, mask = torch_ref.synthetic_batch(batch, 3, size, size, seed=5)
+    x, mask = _synthetic_batch(batch, 3, size, size, seed=5)
     x, mask = x.to(dev), mask.to(dev)
     res = {}
     for rep in range(2):

@@ -5,12 +5,19 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import unet_zoo_amd
 from unet_zoo_amd import ops
-from oracle import torch_ref
+
+
+
+def _synthetic_batch(B, C, H, W, seed=1):
+    """randn image, rand > 0.5 mask, one generator (the fixture protocol; tools/ do not import the oracle)"""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, C, H, W, generator=g), (torch.rand(B, 1, H, W, generator=g) > 0.5).float()
+
 
 DEV = "cuda"
 torch.manual_seed(0)
 m = unet_zoo_amd.create_model("unet").to(DEV).train()
-x, _ = torch_ref.synthetic_batch(16, 3, 256, 256, seed=2)
+x, _ = _synthetic_batch(16, 3, 256, 256, seed=2)
 x = x.to(DEV)
 log = []
 orig = ops.conv_igemm
