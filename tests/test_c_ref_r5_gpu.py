@@ -403,3 +403,30 @@ def test_window_attention_backward_follows_the_norm_clamp_of_the_reference(dt, w
         a, b = got[rows][:, cols], want[rows][:, cols]
         err = ((a - b).abs().max() / b.abs().max()).item()
         assert err <= tol, (name, err, b.abs().max().item())
+
+
+@pytest.mark.parametrize("Co,Ci,bias_res", [(96, 192, False), (40, 64, True), (24, 32, False), (64, 64, True)])
+def test_pixel_shuffle_store_with_a_sub_pixel_boundary_inside_a_tile(Co, Ci, bias_res):
+    """uz_conv_igemm with UZ_STORE_SHUFFLE2X2 where Co is a multiple of 8 but not of the kernel's 64 / 128-channel tile
+    (PatchExpand with Co = 96, swin_unet_v2.py:343-351: it ran on the round-1 kernel until the LDS-DMA GEMM learned to decide
+    the sub-pixel per 16-byte chunk): the kernel family is asserted, the result held against the restatement; with bias and
+    the residual form (uz_conv_igemm_res) where given"""
+    ref = c_ref.load()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(Co)
+    N, H, W = 2, 24, 40
+    x = rnd((N * H * W, Ci), dt, g)
+    wt = rnd((Ci, Co, 2, 2), torch.float32, g, 0.2)
+    bias = torch.randn(Co, generator=g) if bias_res else None
+    xa = Act(dev(x), 0, Ci, N, H, W)
+    wpt = ops.pack_weights(dev(wt), L.PACK_CONVT_FWD, dt)
+    d = L.ConvDesc(L.dtype_code(dt), N, H, W, H, W, Ci, Ci, 4 * Co, Co, 1, L.TAPS_CONV, 1, L.STORE_SHUFFLE2X2, Co, 0, 0)
+    assert ops.conv_kernel_name(d).startswith("gemm_dma"), ops.conv_kernel_name(d)
+    yt = ops.new_act(N, 2 * H, 2 * W, Co, dt, DEV)
+    b4 = bias.repeat(4) if bias is not None else None          # the GEMM's bias: one value per (sub-pixel, channel) column
+    ops.conv_igemm(xa, wpt, dev(b4) if b4 is not None else None, yt, ntaps=1, store_mode=L.STORE_SHUFFLE2X2, nout=4 * Co, co=Co)
+    yr = np.zeros(N * 4 * H * W * Co, np.uint16)
+    xh, wh = c_ref.host(x), c_ref.host(wpt)
+    bh = c_ref.host(b4) if b4 is not None else None
+    assert ref.uz_conv_igemm_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(wh), c_ref.ptr(bh), c_ref.ptr(yr), None, None) == 0
+    agree(yt.buf, c_ref.tensor(yr, dt).reshape(-1, Co), dt, f"convT forward, Co = {Co}")
