@@ -408,6 +408,13 @@ def main():
         out = {"error": "no go"}
         try:
             out = torch_rocm_baseline(args.batch, args.size, 10, args.model, both=args.torch_baseline)
+            if (args.model, args.size, args.batch) == ("unet", 256, 16) and args.second_steps > 0:
+                # the second headline's model through the same stock ops (no MIOpen search to speak of: ~10 s)
+                try:
+                    out["second_headline_swin_unet_v2"] = torch_rocm_baseline(16, 256, 10, "swin_unet_v2", both=False)[
+                        "bf16_autocast_channels_last"]
+                except Exception as e:      # noqa: BLE001
+                    out["second_headline_swin_unet_v2"] = {"error": repr(e)[:200]}
         except Exception as e:      # noqa: BLE001
             out = {"error": repr(e)[:200]}
         with open(args.torch_baseline_child, "w") as f:
@@ -420,7 +427,8 @@ def main():
         import tempfile
         helper_out = os.path.join(tempfile.mkdtemp(prefix="uz_bench_"), "torch_baseline.json")
         helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--torch-baseline-child", helper_out, "--model",
-                                   args.model, "--batch", str(args.batch), "--size", str(args.size)]
+                                   args.model, "--batch", str(args.batch), "--size", str(args.size), "--second-steps",
+                                   str(args.second_steps)]
                                   + (["--torch-baseline"] if args.torch_baseline else []),
                                   stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     try:
