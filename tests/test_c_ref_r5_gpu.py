@@ -430,3 +430,43 @@ def test_pixel_shuffle_store_with_a_sub_pixel_boundary_inside_a_tile(Co, Ci, bia
     bh = c_ref.host(b4) if b4 is not None else None
     assert ref.uz_conv_igemm_ref(byref(d), c_ref.ptr(xh), c_ref.ptr(wh), c_ref.ptr(bh), c_ref.ptr(yr), None, None) == 0
     agree(yt.buf, c_ref.tensor(yr, dt).reshape(-1, Co), dt, f"convT forward, Co = {Co}")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_batched_weight_packing_of_transposed_convolutions_equals_the_single_calls(dt):
+    """uz_pack_weights_batched: the ConvTranspose2d(k2, s2) fast paths (row permutation for the input-gradient layout, LDS
+    transpose with permuted destination rows for the forward layout) against uz_pack_weights' element-wise gather and the C
+    restatement, bit for bit; odd channel counts and tails of the 64 x 64 tiles included; mixed with other items in one launch"""
+    import ctypes
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(90)
+    shapes = [(1024, 512), (128, 64), (96, 40), (8, 8), (72, 100)]
+    ws = [dev(torch.randn(ci, co, 2, 2, generator=g)) for ci, co in shapes]
+    lin = dev(torch.randn(48, 80, generator=g))                # a one-tap item between them (its own fast path)
+    items, outs, begin = [], [], 0
+    for w, (ci, co) in zip(ws, shapes):
+        for mode, shape in ((L.PACK_CONVT_FWD, (4 * co, ci)), (L.PACK_CONVT_DGRAD, (ci, 4 * co))):
+            dst = torch.full(shape, 7.0, dtype=dt, device=DEV)
+            items.append(L.PackItem(w.data_ptr(), dst.data_ptr(), begin, mode, co, ci, 4, 0, 0))
+            outs.append((w, mode, dst))
+            begin += dst.numel()
+    dl = torch.full((48, 80), 7.0, dtype=dt, device=DEV)
+    items.insert(3, L.PackItem(lin.data_ptr(), dl.data_ptr(), 0, L.PACK_CONV_FWD, 48, 80, 1, 0, 0))
+    begin = 0
+    arr = (L.PackItem * len(items))()
+    for i, it in enumerate(items):                             # `begin` is the prefix sum over the items in launch order
+        it.begin = begin
+        arr[i] = it
+        begin += (48 * 80) if i == 3 else outs[i if i < 3 else i - 1][2].numel()
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    ok(lib.uz_pack_weights_batched(L.dtype_code(dt), tab.data_ptr(), len(items), begin, None))
+    torch.cuda.synchronize()
+    for w, mode, dst in outs:
+        single = ops.pack_weights(w, mode, dt)
+        assert torch.equal(dst, single), (tuple(w.shape), mode)
+        ci, co = w.shape[0], w.shape[1]
+        r = np.zeros(dst.numel(), npdt(dt))
+        wh = c_ref.host(w)
+        assert ref.uz_pack_weights_ref(L.dtype_code(dt), mode, c_ref.ptr(wh), co, ci, 4, 0, c_ref.ptr(r), None) == 0
+        assert torch.equal(dst.cpu(), c_ref.tensor(r, dt).reshape(dst.shape))
+    assert torch.equal(dl, ops.pack_weights(lin.view(48, 80, 1, 1), L.PACK_CONV_FWD, dt).view(48, 80))

@@ -1027,6 +1027,41 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const uz_pack
     }
     return;
   }
+  // ConvTranspose2d k2 s2 (T = 4 taps, w[ci][co][t]; unet's four up-convolutions, 2.8 M parameters, both layouts per step): the
+  // source is a [Ci][4 Co] matrix with column j = 4 co + t.  The element-wise gather below (64-bit divisions per element) ran
+  // them at 0.3 TB/s; these two paths are 32-bit and coalesced on the wide side.
+  if (it.T == 4 && it.mode == UZ_PACK_CONVT_DGRAD && count == 4LL * it.Co * it.Ci) {
+    // dst[ci][t Co + co]: a row is the source row with (co, t) -> (t, co)
+    const int rowlen = 4 * it.Co;
+    for (int ci = blockIdx.x; ci < it.Ci; ci += gridDim.x) {
+      const float* __restrict__ srow = src + (size_t)ci * rowlen;
+      T* __restrict__ drow = dst + (size_t)ci * rowlen;
+      for (int k = threadIdx.x; k < rowlen; k += 256) {
+        const int t = k / it.Co, co = k - t * it.Co;
+        drow[k] = (T)srow[4 * co + t];
+      }
+    }
+    return;
+  }
+  if (it.T == 4 && it.mode == UZ_PACK_CONVT_FWD && count == 4LL * it.Co * it.Ci) {
+    // dst[t Co + co][ci]: the transpose of the source matrix with destination row perm(j) = (j & 3) Co + (j >> 2)
+    const int R = it.Ci, Cc = 4 * it.Co;
+    __shared__ float tile4[64][65];
+    const int tr = (R + 63) / 64, tc = (Cc + 63) / 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+      const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+      __syncthreads();
+      for (int r = ty; r < 64; r += 4)
+        tile4[r][tx] = (r0 + r < R && c0 + tx < Cc) ? src[(size_t)(r0 + r) * Cc + c0 + tx] : 0.f;
+      __syncthreads();
+      for (int c = ty; c < 64; c += 4) {
+        const int j = c0 + c;
+        if (j < Cc && r0 + tx < R) dst[(size_t)((j & 3) * it.Co + (j >> 2)) * R + r0 + tx] = (T)tile4[tx][c];
+      }
+    }
+    return;
+  }
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < count;
        idx += (long long)gridDim.x * blockDim.x)
     dst[idx] = (T)pack_element(it.mode, it.src, it.Co, it.Ci, it.T, it.Kpad, idx);
@@ -1729,7 +1764,10 @@ extern "C" int uz_pack_weights_batched(int dtype, const uz_pack_item* items_devi
   UZ_REQUIRE(items_device && n_items > 0 && total_elements > 0, "uz_pack_weights_batched: bad args");
   hipStream_t s = (hipStream_t)stream;
   UZ_REQUIRE(n_items <= 65535, "uz_pack_weights_batched: too many items");
-  const dim3 grid(128, n_items);
+  // workgroups per item: the host does not see the items' sizes (the table lives in device memory).  Few items (unet: 12, the
+  // largest a 1024 x 512 ConvTranspose of 2 M elements) want the chip per item: 128 -> 512 took the launch from 44 to 18 us;
+  // many items (swin_unet_v2: 77 Linear weights) pay for the empty workgroups instead: 40 -> 54 us at 512.
+  const dim3 grid(n_items <= 16 ? 512 : (n_items <= 40 ? 256 : 128), n_items);
   if (dtype == UZ_BF16)
     hipLaunchKernelGGL((pack_weights_batched_kernel<bf16_t>), grid, dim3(256), 0, s, items_device, n_items, total_elements);
   else
