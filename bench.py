@@ -59,6 +59,7 @@ PMC_KEYS = {
     "conv3x3_pp512x64_bf16_xf": ("PpCfg<16, 32, 8, 1, 3, true>",),
     "conv3x3_pp256_bf16": ("PpCfg<8, 32, 4, 2, 3,",),
     "conv3x3_pp256w16_bf16": ("PpCfg<16, 16, 4, 2, 3,",),
+    "conv3x3_pp128w16_bf16": ("PpCfg<8, 16, 4, 2, 3,",),
     "wgrad9_bf16_64x64_rowwalk": (("wgrad9_kernel<64,", "false>"),),
     "wgrad9_bf16_64x64_rowwalk_xf": (("wgrad9_kernel<64,", "true>"),),
     "wgrad3x3_bf16_128x128_3tap": ("wgrad3x3_kernel<128, 128, 1, 3,",),

@@ -47,18 +47,21 @@ CASES = [
     ("pp512x64", 3, 128, 256, 128, 64, 0, False),  # 64 output channels: eight waves along the pixels, phases of one tap row
     ("pp512x64", 2, 120, 250, 64, 40, 32, False),  # ragged, channel tail, window; one tile per workgroup
     ("pp512x64", 9, 128, 256, 32, 64, 0, False),   # 576 tiles: up to three per workgroup, one slab per tile
-    ("pp256", 2, 40, 72, 128, 256, 0, False),      # 8 x 32 patches, ragged both ways, two N tiles
-    ("pp256", 1, 32, 32, 64, 128, 0, False),       # four tiles
+    ("pp256", 6, 40, 72, 128, 256, 0, False),      # 8 x 32 patches, ragged both ways, two N tiles
+    ("pp128w16", 2, 40, 72, 128, 256, 0, False),   # the same maps, 60 tiles: 8 x 16 patches (ragged both ways) so that 120 CUs work, not 60
+    ("pp128w16", 1, 32, 32, 64, 128, 0, False),    # eight half tiles
     ("pp256", 16, 32, 32, 256, 512, 0, False),     # unet level 4 at batch 16: one tile per workgroup, eight slabs
-    ("pp256", 2, 48, 64, 32, 128, 0, True),        # upsampled input, one slab
+    ("pp128w16", 2, 48, 64, 32, 128, 0, True),     # upsampled input, one slab
+    ("pp256", 12, 48, 64, 32, 128, 0, True),       # upsampled input, one slab, 288 tiles
     ("pp256", 40, 32, 32, 96, 512, 64, False),     # 160 tiles x 4 N tiles: the grid is capped at 64 workgroups per N tile, 2-3 tiles each
-    ("pp256w16", 4, 16, 16, 256, 384, 0, False),   # one 16 x 16 map per tile
-    ("pp256w16", 3, 12, 14, 128, 136, 0, False),   # ragged 16 x 16 patches, channel tail
+    ("pp128w16", 4, 16, 16, 256, 384, 0, False),   # half a 16 x 16 map per tile
+    ("pp128w16", 3, 12, 14, 128, 136, 0, False),   # ragged 8 x 16 patches, channel tail
+    ("pp256w16", 70, 12, 14, 128, 136, 0, False),  # ragged 16 x 16 patches, channel tail (140 tiles)
     ("pp256w16", 70, 16, 16, 64, 512, 0, False),   # 70 x 4 tiles: the grid is capped at 64 workgroups per N tile
     # split-K (few tiles, many channel slabs: the slabs of a tile are dealt to several workgroups, fp32 partial tiles + a
     # fixed-order reduce pass with bias and statistics)
     ("pp256w16", 16, 16, 16, 1024, 512, 0, False),  # unet's 1024 -> 512 at 16 x 16, B = 16: 64 tiles, 32 slabs -> 4 ranges of 8
-    ("pp256w16", 16, 16, 16, 512, 1024, 0, False),  # 128 tiles: more than a quarter of the CUs -> not split
+    ("pp128w16", 16, 16, 16, 512, 1024, 0, False),  # 128 whole-map tiles: more than a quarter of the CUs -> not split, 256 half tiles
     ("pp256", 2, 32, 32, 512, 256, 32, False),      # 16 tiles -> 4 ranges of 4 slabs; input window of a NaN-poisoned buffer
     ("pp256w16", 2, 12, 14, 544, 136, 0, False),    # ragged patches, channel tail, 17 slabs -> ranges of 5 + 5 + 5 + 2
     ("pp256", 1, 32, 64, 1024, 128, 0, True),       # upsampled input, 32 slabs -> 8 ranges
@@ -158,8 +161,10 @@ def test_pp_conv3x3_exact_on_small_integers():
     (3, 128, 256, 64, 128),     # pp512, one tile per workgroup
     (6, 112, 224, 128, 136),    # pp512, two tiles for some, ragged, channel tail
     (3, 128, 256, 64, 64),      # pp512x64
-    (16, 32, 32, 128, 128),     # pp256
-    (5, 16, 16, 256, 256),      # pp256w16
+    (36, 32, 32, 128, 128),     # pp256
+    (70, 16, 16, 64, 256),      # pp256w16
+    (16, 32, 32, 128, 128),     # pp128w16 on 32-wide maps
+    (5, 16, 16, 256, 256),      # pp128w16 on 16-wide maps
 ])
 def test_pp_bn_backward_reduction_in_the_input_gradient_epilogue(N, H, W, C, Cn):
     """uz_conv_igemm_bnred on the ping-pong kernel: the gradient must be bit-identical to the plain launch, the
@@ -200,7 +205,9 @@ def test_pp_plan_picks_a_configuration_per_problem():
     16-wide maps, the 64-channel configuration for 64 output channels; everything else stays on the other kernels"""
     assert kernel_of(16, 128, 128, 128, 128, 128, 128) == "conv3x3_pp512_bf16"        # unet level 2 at batch 16
     assert kernel_of(16, 32, 32, 512, 512, 512, 512) == "conv3x3_pp256_bf16"          # level 4: 128 tiles of 512 pixels would idle half the CUs
-    assert kernel_of(16, 16, 16, 1024, 1024, 1024, 1024) == "conv3x3_pp256w16_bf16"   # level 5
+    assert kernel_of(16, 16, 16, 1024, 1024, 1024, 1024) == "conv3x3_pp128w16_bf16"   # level 5: 128 whole maps would idle half the CUs
+    assert kernel_of(32, 16, 16, 1024, 1024, 1024, 1024) == "conv3x3_pp256w16_bf16"   # twice the batch: one map per tile
+    assert kernel_of(16, 32, 32, 512, 512, 256, 256) == "conv3x3_pp128w16_bf16"       # the input gradient of level 4's first convolution
     assert kernel_of(16, 256, 256, 128, 128, 64, 64) == "conv3x3_pp512x64_bf16"       # decoder level 1
     assert not kernel_of(1, 32, 32, 64, 64, 64, 64).startswith("conv3x3_pp")          # 64 channels, two tiles
     assert not kernel_of(2, 64, 64, 16, 16, 128, 128).startswith("conv3x3_pp")        # 16 input channels (u2net)

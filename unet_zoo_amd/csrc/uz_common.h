@@ -188,7 +188,8 @@ int uz_direct_launch(const uz_conv_desc* d, const UzDirectPlan& p, const void* x
 enum { UZ_PP_512 = 0,      // 16 x 32 pixels x 128 channels
        UZ_PP_512X64 = 1,   // 16 x 32 pixels x 64 channels
        UZ_PP_256 = 2,      // 8 x 32 pixels x 128 channels
-       UZ_PP_256W16 = 3 }; // 16 x 16 pixels x 128 channels
+       UZ_PP_256W16 = 3,   // 16 x 16 pixels x 128 channels
+       UZ_PP_128W16 = 4 }; // 8 x 16 pixels x 128 channels
 struct UzPpPlan {
   int cfg, bn, th_n, tw_n, ntiles, tiles_n, grid_m;
   int ksplit, cps;   // split-K over the channel slabs (only with a workspace): ksplit ranges of cps slabs

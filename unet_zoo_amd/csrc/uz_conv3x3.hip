@@ -945,7 +945,7 @@ int uz_direct_plan(const uz_conv_desc* d, UzDirectPlan* p) {
   {
     UzPpPlan pp;   // third generation (uz_conv3x3_pp.hip): bf16, input channels in multiples of 32
     if (uz_pp_plan(d, &pp)) {
-      p->tw = pp.cfg == UZ_PP_256W16 ? 16 : 32;
+      p->tw = (pp.cfg == UZ_PP_256W16 || pp.cfg == UZ_PP_128W16) ? 16 : 32;
       p->bn = pp.bn;
       p->bres = 3;
       p->ppcfg = pp.cfg;

@@ -822,6 +822,7 @@ typedef PpCfg<16, 32, 8, 1, 3> Cfg512x64;
 typedef PpCfg<16, 32, 8, 1, 3, true> Cfg512x64X;   // the XF instantiation's deal of the halo pieces
 typedef PpCfg<8, 32, 4, 2, 3> Cfg256;
 typedef PpCfg<16, 16, 4, 2, 3> Cfg256w16;
+typedef PpCfg<8, 16, 4, 2, 3> Cfg128w16;
 
 }  // namespace
 
@@ -858,7 +859,16 @@ int uz_pp_plan(const uz_conv_desc* d, UzPpPlan* p) {
     if (tiles(16, 32) >= UZ_NUM_CU / 2 && !(uz_tune_flags() & 0x10000000)) cfg = UZ_PP_512X64;
   }
   if (cfg < 0) return 0;
-  const int th = cfg == UZ_PP_256 ? 8 : 16, tw = cfg == UZ_PP_256W16 ? 16 : 32, bn = cfg == UZ_PP_512X64 ? 64 : 128;
+  // 128-pixel tiles (8 x 16) where 256-pixel ones leave at least half of the CUs without a tile and the split-K plan below
+  // (a quarter) does not apply: unet's 16 x 16 maps at B = 16, 512 -> 1024 50.1 -> 41.8 us, 1024 -> 1024 92.2 -> 76.2 us
+  // (bit-identical: an output's K order does not depend on its tile; profiles/r05_pp128_probe.txt).  Twice the weight
+  // fragments per MFMA -- which idle CUs pay for, full ones would not.
+  if ((cfg == UZ_PP_256 || cfg == UZ_PP_256W16) && !(uz_tune_flags() & 0x4)) {
+    const long long tot = (cfg == UZ_PP_256 ? tiles(8, 32) : tiles(16, 16)) * ((d->Nout + 127) / 128);
+    const bool splits = tot * 4 <= UZ_NUM_CU_HW && d->Cin / KU >= 16;
+    if (tot * 2 <= UZ_NUM_CU_HW && !splits) cfg = UZ_PP_128W16;
+  }
+  const int th = (cfg == UZ_PP_256 || cfg == UZ_PP_128W16) ? 8 : 16, tw = (cfg == UZ_PP_256W16 || cfg == UZ_PP_128W16) ? 16 : 32, bn = cfg == UZ_PP_512X64 ? 64 : 128;
   p->cfg = cfg;
   p->bn = bn;
   p->th_n = (d->H + th - 1) / th;
@@ -964,6 +974,7 @@ int uz_pp_launch(const uz_conv_desc* d, const UzPpPlan& p, const void* x, const 
     case UZ_PP_512X64: UZ_PP_GO(Cfg512x64); break;
     case UZ_PP_256: UZ_PP_GO(Cfg256); break;
     case UZ_PP_256W16: UZ_PP_GO(Cfg256w16); break;
+    case UZ_PP_128W16: UZ_PP_GO(Cfg128w16); break;
     default: UZ_REQUIRE(false, "uz_conv_igemm(direct3x3 ping-pong): bad configuration %d", p.cfg);
   }
 #undef UZ_PP_GO

@@ -500,8 +500,8 @@ extern "C" int uz_conv_igemm_kernel_name(const uz_conv_desc* d, int with_workspa
   UzGemmPlan gp;
   if (uz_direct_plan(d, &dp)) {
     const char* up = d->taps_mode == UZ_TAPS_CONV_UP2 ? "_up2" : "";
-    static const char* const ppn[4] = {"pp512", "pp512x64", "pp256", "pp256w16"};
-    if (dp.bres == 3) snprintf(name, sizeof(name), "conv3x3_%s_%s%s%s", ppn[dp.ppcfg & 3], dt, up, (dp.ksplit > 1 && with_workspace) ? "_splitk" : "");
+    static const char* const ppn[8] = {"pp512", "pp512x64", "pp256", "pp256w16", "pp128w16", "?", "?", "?"};
+    if (dp.bres == 3) snprintf(name, sizeof(name), "conv3x3_%s_%s%s%s", ppn[dp.ppcfg & 7], dt, up, (dp.ksplit > 1 && with_workspace) ? "_splitk" : "");
     else if (dp.bres == 2) snprintf(name, sizeof(name), "conv3x3_res64_%s%s", dt, up);
     else snprintf(name, sizeof(name), "conv3x3_direct_%s_bn%d%s%s", dt, dp.bn, dp.bres == 1 ? "_resident" : "", up);
   } else if (uz_gemm_dma_plan(d, &gp)) {
