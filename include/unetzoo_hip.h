@@ -396,6 +396,12 @@ int uz_bn_bwd_finalize(const float* partial, int rows, int C, double* sums, floa
  *   out[n, k, h, w] = b[k] + sum_c x[p, c] * w[k, c],  k < Kout <= 8 */
 int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w,
                    const float* b, int Kout, float* out_nchw, void* stream);
+/* uz_outconv_fwd on the RAW output y of the convolution in front, read through that layer's BatchNorm + ReLU (bf16):
+ *   x[p, c] = bf16(max(fma(y[p, c], scale[c], shift[c]), 0))   -- the value uz_bn_relu_apply() would have stored --
+ * so the normalised activation of the last decoder block (DoubleConv's second half, common_layers.py:31-33, feeding OutConv,
+ * :125) is never written down; its backward is uz_outconv_bwd_bnred(x = NULL). */
+int uz_outconv_fwd_xf(int dtype, const void* y, int ldy, int N, int HW, int C, const float* scale, const float* shift,
+                      const float* w, const float* b, int Kout, float* out_nchw, void* stream);
 /* dx[p,c] = sum_k g[n,k,hw] * w[k,c];  dw[k,c] = sum_p g*x;  db[k] = sum_p g.
  * Two kernels (per-workgroup partial rows in `workspace`, then a fixed-order sum): deterministic. */
 long long uz_outconv_bwd_workspace_bytes(int dtype, int N, int HW, int C, int Kout);
@@ -404,7 +410,8 @@ int uz_outconv_bwd(int dtype, const void* x, int ldx, int N, int HW, int C, cons
                    void* stream);
 /* uz_outconv_bwd with the first pass of a BatchNorm backward in the same pass over the pixels (bf16): x = relu(bn(bn_y))
  * feeds only this head, so the gradient dx it writes is the whole gradient of that activation; bn_partial receives
- * [uz_outconv_bwd_rows()][2][C] partial rows for uz_bn_bwd_finalize() (see uz_conv_igemm_bnred). */
+ * [uz_outconv_bwd_rows()][2][C] partial rows for uz_bn_bwd_finalize() (see uz_conv_igemm_bnred).  x == NULL: the
+ * activation was never written down (uz_outconv_fwd_xf); the kernel forms it from bn_y, scale, shift (ldx unused). */
 int uz_outconv_bwd_rows(int dtype, int N, int HW, int C);
 int uz_outconv_bwd_bnred(int dtype, const void* x, int ldx, int N, int HW, int C, const float* w, int Kout,
                          const float* g_nchw, void* dx, int lddx, float* dw, float* db, void* workspace,

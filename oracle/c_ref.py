@@ -27,7 +27,7 @@ REF_NAMES = (
     "uz_conv_igemm_xf", "uz_wgrad_xf", "uz_bn_relu_add_apply", "uz_pool_grad_combine", "uz_resize_bilinear_bwd", "uz_bilinear_bwd",
     "uz_bce_dice_workspace_bytes", "uz_bce_dice", "uz_dropout", "uz_chanscale_relu", "uz_patchify", "uz_im2col3x3_nchw",
     "uz_sum_rows_f32_ld", "uz_sum_rows_f32", "uz_resample2", "uz_attn_bwd_psi", "uz_attn_bwd_reduce", "uz_attn_bwd_apply",
-    "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd",
+    "uz_sra_fwd", "uz_sra_bwd_workspace_bytes", "uz_sra_bwd", "uz_outconv_fwd_xf",
 )
 
 

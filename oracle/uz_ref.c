@@ -331,6 +331,28 @@ int uz_outconv_fwd_ref(int dtype, const void* x, int ldx, int N, int HW, int C, 
 }
 UZ_SAME_SIGNATURE(uz_outconv_fwd);
 
+/* the head on the RAW output of the last convolution, read through BatchNorm + ReLU (common_layers.py:31-33 then :125): the
+ * activation is the value uz_bn_relu_apply would have stored -- fp32 fma, max with 0, rounded to bf16 -- then the head as above */
+int uz_outconv_fwd_xf_ref(int dtype, const void* y, int ldy, int N, int HW, int C, const float* scale, const float* shift,
+                          const float* w, const float* b, int Kout, float* out_nchw, void* stream) {
+  (void)stream;
+  if (dtype != UZ_BF16) return UZ_ENOTIMPL;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < Kout; ++k)
+      for (int q = 0; q < HW; ++q) {
+        double acc = b ? b[k] : 0.0;
+        for (int c = 0; c < C; ++c) {
+          const float raw = (float)ld(dtype, y, ((long long)n * HW + q) * ldy + c);
+          float a = fmaf(raw, scale[c], shift[c]);
+          a = a > 0.f ? a : 0.f;
+          acc += (double)bf16_to_f32(f32_to_bf16(a)) * w[(long long)k * C + c];
+        }
+        out_nchw[((long long)n * Kout + k) * HW + q] = (float)acc;
+      }
+  return UZ_OK;
+}
+UZ_SAME_SIGNATURE(uz_outconv_fwd_xf);
+
 /* ---- dense token attention (unet_transformer.py:126-137, :200-213; transatt_unet.py:41-49, :91-107) ------------------ */
 int uz_gemm_nt_ref(const uz_gemm_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y, void* stream) {
   (void)stream;

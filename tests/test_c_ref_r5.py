@@ -344,3 +344,32 @@ def test_spatial_reduction_attention_restatement(dt, blocks):
         for got, want, what in ((dq, want_dq, "dq"), (dkv, tkv.grad, "dkv")):
             got = c_ref.tensor(got, dt).reshape(want.shape).double()
             assert ((got - want).abs().max() / want.abs().max()).item() < 2e-2, what
+
+
+def test_head_reads_the_last_block_through_batchnorm_relu():
+    """uz_outconv_fwd_xf_ref: OutConv on relu(bn(y)) with y the RAW output of the last decoder convolution
+    (common_layers.py:31-33, then :125), the activation rounded to bf16 as the stand-alone pass stores it"""
+    lib = c_ref.load()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(57)
+    N, C, H, W, K = 2, 24, 5, 7, 3
+    y = rnd((N, C, H, W), dt, g)
+    w, b = torch.randn(K, C, generator=g) * 0.3, torch.randn(K, generator=g)
+    scale = (torch.rand(C, generator=g) + 0.5) * torch.where(torch.rand(C, generator=g) < 0.3, -1.0, 1.0)
+    shift = torch.randn(C, generator=g) * 0.5
+    a = activation(y, scale, shift, dt)
+    ref = F.conv2d(a.double(), w.double().view(K, C, 1, 1), b.double())
+    out = np.zeros(N * K * H * W, np.float32)
+    yh, sch, shh, wh, bh = c_ref.host(nhwc(y)), c_ref.host(scale), c_ref.host(shift), c_ref.host(w), c_ref.host(b)
+    assert lib.uz_outconv_fwd_xf_ref(L.dtype_code(dt), c_ref.ptr(yh), C, N, H * W, C, c_ref.ptr(sch), c_ref.ptr(shh), c_ref.ptr(wh),
+                                     c_ref.ptr(bh), K, c_ref.ptr(out), None) == 0
+    got = torch.from_numpy(out).reshape(N, K, H, W).double()
+    # fma against multiply-then-add before the bf16 rounding: an element may land on the neighbouring bf16 number
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-3
+    # and it is the plain head on the stored activation
+    plain = np.zeros(N * K * H * W, np.float32)
+    ah = c_ref.host(nhwc(a))
+    assert lib.uz_outconv_fwd_ref(L.dtype_code(dt), c_ref.ptr(ah), C, N, H * W, C, c_ref.ptr(wh), c_ref.ptr(bh), K, c_ref.ptr(plain), None) == 0
+    assert ((torch.from_numpy(plain).double().reshape(N, K, H, W) - got).abs().max() / ref.abs().max()).item() < 2e-3
+    assert lib.uz_outconv_fwd_xf_ref(L.dtype_code(torch.float32), c_ref.ptr(yh), C, N, H * W, C, c_ref.ptr(sch), c_ref.ptr(shh),
+                                     c_ref.ptr(wh), c_ref.ptr(bh), K, c_ref.ptr(out), None) != 0      # bf16 only, as the kernel

@@ -470,3 +470,40 @@ def test_batched_weight_packing_of_transposed_convolutions_equals_the_single_cal
         assert ref.uz_pack_weights_ref(L.dtype_code(dt), mode, c_ref.ptr(wh), co, ci, 4, 0, c_ref.ptr(r), None) == 0
         assert torch.equal(dst.cpu(), c_ref.tensor(r, dt).reshape(dst.shape))
     assert torch.equal(dl, ops.pack_weights(lin.view(48, 80, 1, 1), L.PACK_CONV_FWD, dt).view(48, 80))
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 32, 48, 64, 1), (3, 17, 19, 40, 3), (1, 8, 8, 512, 8)])
+def test_head_through_batchnorm_relu_against_the_c_restatement_and_the_two_pass_form(N, H, W, C, K):
+    """uz_outconv_fwd_xf against its restatement and, bit for bit, against uz_bn_relu_apply + uz_outconv_fwd; then
+    uz_outconv_bwd_bnred with x = NULL (the activation formed from the raw tensor) bit for bit against the same call with
+    the stored activation: dx, dW, db and the BatchNorm-backward partial rows"""
+    dt = torch.bfloat16
+    lib, ref = L.load(), c_ref.load()
+    g = torch.Generator().manual_seed(83)
+    y = rnd((N * H * W, C), dt, g)
+    w, b = torch.randn(K, C, generator=g) * 0.3, torch.randn(K, generator=g)
+    scale = (torch.rand(C, generator=g) + 0.5) * torch.where(torch.rand(C, generator=g) < 0.3, -1.0, 1.0)
+    shift = torch.randn(C, generator=g) * 0.5
+    mean, invstd = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    ya = Act(dev(y), 0, C, N, H, W)
+    sc, sh = dev(scale), dev(shift)
+    got = ops.outconv_fwd(ya, dev(w), dev(b), xform=(sc, sh))
+    out = np.zeros(N * K * H * W, np.float32)
+    yh, sch, shh, wh, bh = c_ref.host(y), c_ref.host(scale), c_ref.host(shift), c_ref.host(w), c_ref.host(b)
+    assert ref.uz_outconv_fwd_xf_ref(L.dtype_code(dt), c_ref.ptr(yh), C, N, H * W, C, c_ref.ptr(sch), c_ref.ptr(shh), c_ref.ptr(wh),
+                                     c_ref.ptr(bh), K, c_ref.ptr(out), None) == 0
+    want = torch.from_numpy(out).reshape(N, K, H, W)
+    assert ((got.cpu().double() - want.double()).abs().max() / want.abs().max()).item() < 1e-5     # fp32 sum order over C terms
+    act = ops.new_act(N, H, W, C, dt, DEV)
+    ops.bn_relu_apply(ya, sc, sh, act, None, None, False)
+    assert torch.equal(got, ops.outconv_fwd(act, dev(w), dev(b)))
+
+    gl = dev(torch.randn(N, K, H, W, generator=g))
+    vec = (sc, sh, dev(mean), dev(invstd))
+    res = []
+    for lazy in (False, True):
+        dx = ops.new_act(N, H, W, C, dt, DEV)
+        dw, db = ops.outconv_bwd(act, dev(w), gl, dx, bnred=(ya, vec), lazy=lazy)
+        res.append((dx.buf.clone(), dw.clone(), db.clone(), dx.bn_partials.clone()))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)

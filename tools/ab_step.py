@@ -10,13 +10,16 @@ import torch
 import unet_zoo_amd
 from unet_zoo_amd.engine import Engine
 
-VARIANTS = [("reversed + bwd passes alternate", dict(BN_BWD_ALTERNATE=True, reverse_element_passes=True, fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
-            ("element passes reversed", dict(BN_BWD_ALTERNATE=False, reverse_element_passes=True, fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
-            ("finalize in consumer", dict(reverse_element_passes=False, fuse_bn_finalize=True, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
-            ("fold BN apply (xf)", dict(reverse_element_passes=False, fuse_bn_finalize=False, fold_bn_apply=True, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
-            ("fused conv + convT", dict(fold_bn_apply=False, fuse_bn_reduce=True, fuse_bn_reduce_convt=True)),
-            ("fused conv only", dict(fuse_bn_reduce=True, fuse_bn_reduce_convt=False)),
-            ("two-pass everywhere", dict(fuse_bn_reduce=False, fuse_bn_reduce_convt=False))]
+_ON = dict(BN_BWD_ALTERNATE=True, reverse_element_passes=True, fuse_bn_finalize=False, fold_bn_apply=True, fold_bn_apply_head=True,
+           fuse_bn_reduce=True, fuse_bn_reduce_convt=True)
+VARIANTS = [("shipped", dict(_ON)),
+            ("head: apply pass kept", dict(_ON, fold_bn_apply_head=False)),
+            ("bwd passes not alternating", dict(_ON, BN_BWD_ALTERNATE=False)),
+            ("element passes ascending", dict(_ON, BN_BWD_ALTERNATE=False, reverse_element_passes=False)),
+            ("finalize in consumer", dict(_ON, fuse_bn_finalize=True)),
+            ("no fold of BN apply (xf)", dict(_ON, fold_bn_apply=False, fold_bn_apply_head=False)),
+            ("fused conv only", dict(_ON, fold_bn_apply=False, fold_bn_apply_head=False, fuse_bn_reduce_convt=False)),
+            ("two-pass everywhere", dict(_ON, fold_bn_apply=False, fold_bn_apply_head=False, fuse_bn_reduce=False, fuse_bn_reduce_convt=False))]
 
 
 def build(attrs, model_name, B, S):
@@ -64,9 +67,9 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / a.steps * 1e3
             best[name] = min(best[name], ms)
-            print(f"round {r} {name:24s} {ms:7.3f} ms/step", flush=True)
+            print(f"round {r} {name:30s} {ms:7.3f} ms/step", flush=True)
     for name, ms in best.items():
-        print(f"best  {name:24s} {ms:7.3f} ms/step")
+        print(f"best  {name:30s} {ms:7.3f} ms/step")
 
 
 main()

@@ -28,7 +28,7 @@ EXPORTS = (
     "uz_wgrad_split", "uz_wgrad_workspace_bytes", "uz_wgrad", "uz_wgrad_kernel_name", "uz_wgrad_phase", "uz_wgrad_xf_supported", "uz_wgrad_xf", "uz_conv3x3_first_supported", "uz_conv3x3_first_rows", "uz_conv3x3_first_fwd",
     "uz_conv3x3_first_wgrad_workspace_bytes", "uz_conv3x3_first_wgrad", "uz_pack_weights", "uz_pack_weights_batched", "uz_pack_conv3x3_batched", "uz_im2col3x3_nchw", "uz_bn_finalize",
     "uz_bn_eval_scale", "uz_bn_relu_apply", "uz_bn_relu_bwd_workspace_bytes", "uz_bn_relu_bwd_reduce", "uz_bn_relu_bwd_apply",
-    "uz_outconv_fwd", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_outconv_bwd_rows", "uz_outconv_bwd_bnred",
+    "uz_outconv_fwd", "uz_outconv_fwd_xf", "uz_outconv_bwd_workspace_bytes", "uz_outconv_bwd", "uz_outconv_bwd_rows", "uz_outconv_bwd_bnred",
     "uz_colsum",
     "uz_attn_grid", "uz_attn_psi_fwd", "uz_attn_gate_fwd", "uz_attn_bwd_psi", "uz_attn_bwd_reduce",
     "uz_attn_bwd_apply", "uz_sum_rows", "uz_sum_rows_f32", "uz_sum2x2",
@@ -212,6 +212,7 @@ def load():
     lib.uz_bn_relu_bwd_apply.argtypes = [POINTER(BnBwdDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                          c_double, vp, vp]
     lib.uz_outconv_fwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, ip, vp, vp]
+    lib.uz_outconv_fwd_xf.argtypes = [ip, vp, ip, ip, ip, ip, vp, vp, vp, vp, ip, vp, vp]
     lib.uz_outconv_bwd_workspace_bytes.argtypes = [ip, ip, ip, ip, ip]
     lib.uz_outconv_bwd.argtypes = [ip, vp, ip, ip, ip, ip, vp, ip, vp, vp, ip, vp, vp, vp, vp]
     lib.uz_outconv_bwd_rows.argtypes = [ip, ip, ip, ip]

@@ -608,11 +608,16 @@ __host__ __device__ inline int lanes_per_pixel(int chunks) {  // power of two >=
   return l;
 }
 
-template <typename T, int KOUT>
+// XF: x holds the RAW output of the convolution in front; the head reads it through that layer's BatchNorm + ReLU,
+// a = T(max(fma(x, scale, shift), 0)) -- the value uz_bn_relu_apply would have stored -- so that the normalised tensor of
+// the last decoder block never exists (uz_outconv_fwd_xf)
+template <typename T, int KOUT, bool XF = false>
 __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ x, int ldx, int N,
                                                           int HW, int C, const float* __restrict__ w,
                                                           const float* __restrict__ b,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out,
+                                                          const float* __restrict__ xf_scale = nullptr,
+                                                          const float* __restrict__ xf_shift = nullptr) {
   constexpr int VEC = ElemTraits<T>::VEC;
   const int LPP = lanes_per_pixel(C / VEC);  // power of two >= C/VEC, <= 64; lanes >= C/VEC carry zeros
   const int ppb = blockDim.x / LPP;
@@ -624,11 +629,23 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ 
   for (int k = 0; k < KOUT; ++k)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) wr[k][i] = live ? w[k * C + sub * VEC + i] : 0.f;
+  float xsc[VEC], xsh[VEC];
+  if constexpr (XF) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      xsc[i] = live ? xf_scale[sub * VEC + i] : 0.f;
+      xsh[i] = live ? xf_shift[sub * VEC + i] : 0.f;
+    }
+  }
   for (int p0 = blockIdx.x * ppb; p0 < P; p0 += gridDim.x * ppb) {
     const int p = p0 + pl;
     float v[VEC];
     if (p < P && live) {
       load_f(x + (size_t)p * ldx + sub * VEC, v);
+      if constexpr (XF) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = (float)(T)fmaxf(fmaf(v[i], xsc[i], xsh[i]), 0.f);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) v[i] = 0.f;
@@ -698,8 +715,17 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
       pp[u] = p < P ? p : -1;
       if (pp[u] >= 0) {
         if (live) {
-          load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
-          if constexpr (BNRED) load_f(bn_y + (size_t)p * ld_bny + sub * VEC, yv[u]);
+          if constexpr (BNRED) {
+            load_f(bn_y + (size_t)p * ld_bny + sub * VEC, yv[u]);
+            if (x != nullptr) {
+              load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
+            } else {   // the activation was never written down (uz_outconv_fwd_xf): the value the apply pass would have stored
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) v[u][i] = (float)(T)fmaxf(fmaf(yv[u][i], bsc[i], bsh[i]), 0.f);
+            }
+          } else {
+            load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
@@ -1511,11 +1537,27 @@ extern "C" int uz_outconv_fwd(int dtype, const void* x, int ldx, int N, int HW, 
   const int grid = grid_for(((long long)N * HW + ppb - 1) / ppb, 1);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UZ_BF16) {
-    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_fwd_kernel<bf16_t, KOUT>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, b, out_nchw))
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_fwd_kernel<bf16_t, KOUT>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, N, HW, C, w, b, out_nchw, (const float*)nullptr, (const float*)nullptr))
   } else {
-    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_fwd_kernel<float, KOUT>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, b, out_nchw))
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_fwd_kernel<float, KOUT>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, N, HW, C, w, b, out_nchw, (const float*)nullptr, (const float*)nullptr))
   }
   UZ_LAUNCH_CHECK("uz_outconv_fwd");
+  return UZ_OK;
+}
+
+extern "C" int uz_outconv_fwd_xf(int dtype, const void* y, int ldy, int N, int HW, int C, const float* scale,
+                                 const float* shift, const float* w, const float* b, int Kout, float* out_nchw,
+                                 void* stream) {
+  UZ_REQUIRE(dtype == UZ_BF16, "uz_outconv_fwd_xf: bf16 only");
+  UZ_REQUIRE(y && scale && shift && w && b && out_nchw, "uz_outconv_fwd_xf: null pointer");
+  UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_fwd_xf: Kout=%d (max %d)", Kout, OUTCONV_MAXK);
+  UZ_REQUIRE(C % 8 == 0 && C / 8 <= 64, "uz_outconv_fwd_xf: C=%d unsupported", C);
+  UZ_REQUIRE(ldy % 8 == 0 && ldy >= C && N > 0 && HW > 0 && (long long)N * HW < (1LL << 31), "uz_outconv_fwd_xf: bad shape");
+  const int ppb = 256 / lanes_per_pixel(C / 8);
+  const int grid = grid_for(((long long)N * HW + ppb - 1) / ppb, 1);
+  hipStream_t s = (hipStream_t)stream;
+  UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_fwd_kernel<bf16_t, KOUT, true>), dim3(grid), dim3(256), 0, s, (const bf16_t*)y, ldy, N, HW, C, w, b, out_nchw, scale, shift))
+  UZ_LAUNCH_CHECK("uz_outconv_fwd_xf");
   return UZ_OK;
 }
 
@@ -1547,12 +1589,13 @@ extern "C" int uz_outconv_bwd_bnred(int dtype, const void* x, int ldx, int N, in
                                     const float* shift, const float* mean, const float* invstd, float* bn_partial,
                                     void* stream) {
   UZ_REQUIRE(dtype == UZ_BF16, "uz_outconv_bwd_bnred: bf16 only");
-  UZ_REQUIRE(x && w && g_nchw && dw && db && workspace && dx && bn_y && scale && shift && mean && invstd && bn_partial,
+  // x == NULL: the activation was never written down (uz_outconv_fwd_xf); the kernel forms it from bn_y
+  UZ_REQUIRE(w && g_nchw && dw && db && workspace && dx && bn_y && scale && shift && mean && invstd && bn_partial,
              "uz_outconv_bwd_bnred: null pointer");
   UZ_REQUIRE(Kout >= 1 && Kout <= OUTCONV_MAXK, "uz_outconv_bwd_bnred: Kout=%d", Kout);
   UZ_REQUIRE(C % 8 == 0 && C / 8 <= 64, "uz_outconv_bwd_bnred: C=%d unsupported", C);
-  UZ_REQUIRE(ldx % 8 == 0 && ldx >= C && lddx % 8 == 0 && lddx >= C && ld_bny % 8 == 0 && ld_bny >= C && N > 0 && HW > 0 &&
-                 (long long)N * HW < (1LL << 31), "uz_outconv_bwd_bnred: bad shape");
+  UZ_REQUIRE((x == nullptr || (ldx % 8 == 0 && ldx >= C)) && lddx % 8 == 0 && lddx >= C && ld_bny % 8 == 0 && ld_bny >= C && N > 0 &&
+                 HW > 0 && (long long)N * HW < (1LL << 31), "uz_outconv_bwd_bnred: bad shape");
   const int g = outconv_bwd_grid(dtype, N, HW, C);
   float* part = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;

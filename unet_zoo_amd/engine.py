@@ -146,6 +146,10 @@ class Engine:
     # its weight gradient read the first one's raw output through it (uz_conv_igemm_xf / uz_wgrad_xf), where both kernels
     # take the shape; the normalised middle tensor then never exists (class-level: tools/ab_step.py times both ways)
     fold_bn_apply = True
+    # ... and the same for the LAST decoder block in front of the 1x1 head (OutConv): the head's forward reads the raw tensor
+    # through the map (uz_outconv_fwd_xf), its backward needs the raw tensor only (uz_outconv_bwd_bnred with x = NULL) --
+    # one full-resolution apply pass and one full-resolution read fewer per step
+    fold_bn_apply_head = True
     # the BatchNorm finalize launches (forward: statistics -> scale / shift; backward: partial rows -> totals) riding in the
     # launch of the element pass that consumes them (uz_bn_relu_add_apply_fin, uz_bn_relu_bwd_apply_fin; 36 launches of
     # ~5 us per unet step, 448 per u2net step).  OFF: measured slower (round 5, tools/ab_step.py, same box: unet 6.654 vs
@@ -405,6 +409,13 @@ class Engine:
             c2 = defer_apply.out_channels
             lazy = (ops.conv_xform_supported(y, c2, c2)
                     and ops.wgrad_xform_shapes_supported(N, H, W, c2, c2, Cout, y.ld, self.dtype))
+        elif (defer_apply is not None and self.fold_bn_apply and self.fold_bn_apply_head and out is None and not pool
+                and residual is None and relu and stat_repeat == 1 and defer_apply.kernel_size == (1, 1)
+                and defer_apply.in_channels == Cout and (self.training or not self.record)):
+            # the reader is the 1x1 head (out_conv): its forward reads the raw tensor through the map, its backward takes the
+            # gradient AND this BatchNorm's first backward pass from the raw tensor alone (uz_outconv_bwd_bnred, x = NULL) --
+            # which needs batch statistics on the tape (training), or no tape at all
+            lazy = self.fuse_bn_reduce_convt and ops.outconv_xform_supported(y, defer_apply.out_channels)
         # the finalize inside the apply pass's launch: training statistics, an apply pass to ride in
         fin = self._fin_flag() if (self.training and not lazy and stat_repeat == 1) else None
         vec = None
@@ -1957,15 +1968,17 @@ class Engine:
         K = conv.out_channels
         w = conv.weight.detach().reshape(K, x.C)
         b = conv.bias.detach() if conv.bias is not None else torch.zeros(K, device=self.device)
-        logits = ops.outconv_fwd(x, w, b)
+        xf = getattr(x, "lazy", None)      # x is the raw output of a convolution (conv_bn_relu(defer_apply=this head))
+        assert xf is None or sole_reader, "a lazy activation goes to the head it was deferred for"
+        logits = ops.outconv_fwd(x, w, b, xform=xf)
         if self.record:
             def bwd(g_logits: torch.Tensor):
-                dx = self.new_act(x.N, x.H, x.W, x.C) if x.needs_grad else None
+                dx = self.new_act(x.N, x.H, x.W, x.C) if (x.needs_grad or xf is not None) else None
                 dwt = self._dst(conv.weight)
                 dbt = self._dst(conv.bias) if conv.bias is not None else None
-                src = getattr(x, "bn_src", None) if (sole_reader and self.fuse_bn_reduce_convt) else None
+                src = getattr(x, "bn_src", None) if (sole_reader and (self.fuse_bn_reduce_convt or xf is not None)) else None
                 dw, db = ops.outconv_bwd(x, w, g_logits.contiguous().float(), dx,
-                                         dwt.view(K, x.C) if dwt is not None else None, dbt, bnred=src)
+                                         dwt.view(K, x.C) if dwt is not None else None, dbt, bnred=src, lazy=xf is not None)
                 self._give_grad(conv.weight, dwt if dwt is not None else dw.reshape(conv.weight.shape))
                 if conv.bias is not None:
                     self._give_grad(conv.bias, db)

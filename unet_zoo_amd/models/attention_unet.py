@@ -8,6 +8,8 @@ unused exactly as in the reference (attention_unet.py:43).
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn as nn
 
@@ -27,10 +29,11 @@ class ConvBlock(nn.Module):
             nn.Conv2d(ch_out, ch_out, kernel_size=3, stride=1, padding=1, bias=True),
             nn.BatchNorm2d(ch_out), nn.ReLU(inplace=True))
 
-    def emit(self, eng: Engine, x: Act, *, pool: bool = False, im2col: bool = False):
+    def emit(self, eng: Engine, x: Act, *, pool: bool = False, im2col: bool = False, head: Optional[nn.Conv2d] = None):
         s = self.conv
         mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col, defer_apply=s[3])   # read through BN + ReLU where the kernels can (Engine.fold_bn_apply)
-        return eng.conv_bn_relu(mid, s[3], s[4], pool=pool, sole_reader=True)
+        # head: the 1x1 convolution that alone reads this block's output (the same for the output, Engine.fold_bn_apply_head)
+        return eng.conv_bn_relu(mid, s[3], s[4], pool=pool, sole_reader=True, defer_apply=head)
 
 
 class UpConvBlock(nn.Module):
@@ -114,5 +117,5 @@ class AttentionUNet(HipModule):
             full, (gated_slot, up_slot) = eng.new_cat(N, skip.H, skip.W, (c, c))   # cat((gated_skip, d), 1)
             d = up.emit(eng, cur, up_slot)
             att.emit(eng, d, skip, gated_slot)
-            cur, _ = conv.emit(eng, full)
+            cur, _ = conv.emit(eng, full, head=self.conv_1x1 if lvl == 0 else None)
         return (eng.out_conv(cur, self.conv_1x1, sole_reader=True),)

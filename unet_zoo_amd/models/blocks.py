@@ -30,11 +30,12 @@ class DoubleConv(nn.Module):
         self.conv_op = _conv_bn_relu_x2(in_channels, out_channels)
 
     def emit(self, eng: Engine, x: Act, *, out: Optional[Act] = None, pool: bool = False,
-             im2col: bool = False) -> Tuple[Act, Optional[Act]]:
+             im2col: bool = False, head: Optional[nn.Conv2d] = None) -> Tuple[Act, Optional[Act]]:
         s = self.conv_op
         # the middle tensor has one reader: where the kernels can, it is never written down (Engine.fold_bn_apply)
         mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col, defer_apply=s[3])
-        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True)
+        # head = the 1x1 convolution that is the ONLY reader of this block's output (OutConv): the same for the output
+        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True, defer_apply=head)
 
 
 class DownSample(nn.Module):
@@ -59,11 +60,11 @@ class UpSample_UNet(nn.Module):
         self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
         self.conv = DoubleConv(in_channels, out_channels)
 
-    def emit(self, eng: Engine, x: Act, cat_full: Act, up_slot: Act) -> Act:
+    def emit(self, eng: Engine, x: Act, cat_full: Act, up_slot: Act, head: Optional[nn.Conv2d] = None) -> Act:
         # odd skip sizes: the transposed convolution lands top-left, the remaining row / column is the
         # reference's F.pad zeros (common_layers.py:110-113); handled inside conv_transpose2x2
         eng.conv_transpose2x2(x, self.up, up_slot, sole_reader=True)
-        act, _ = self.conv.emit(eng, cat_full)
+        act, _ = self.conv.emit(eng, cat_full, head=head)
         return act
 
 

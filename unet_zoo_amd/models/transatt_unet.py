@@ -40,10 +40,11 @@ class DoubleConvo(nn.Module):
             nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1), nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
 
     def emit(self, eng: Engine, x: Act, *, out: Optional[Act] = None, pool: bool = False,
-             im2col: bool = False) -> Tuple[Act, Optional[Act]]:
+             im2col: bool = False, head: Optional[nn.Conv2d] = None) -> Tuple[Act, Optional[Act]]:
         s = self.double_conv
         mid, _ = eng.conv_bn_relu(x, s[0], s[1], im2col=im2col, defer_apply=s[3])   # Engine.fold_bn_apply
-        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True)
+        # head: the 1x1 convolution that alone reads this block's output (Engine.fold_bn_apply_head)
+        return eng.conv_bn_relu(mid, s[3], s[4], out=out, pool=pool, sole_reader=True, defer_apply=head)
 
 
 class Down(nn.Module):
@@ -71,12 +72,12 @@ class Up(nn.Module):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConvo(in_channels, out_channels)
 
-    def emit(self, eng: Engine, x1: Act, cat_full: Act, up_slot: Act) -> Act:
+    def emit(self, eng: Engine, x1: Act, cat_full: Act, up_slot: Act, head: Optional[nn.Conv2d] = None) -> Act:
         if self.bilinear:
             eng.resize_bilinear(x1, up_slot, align_corners=True)
         else:
             eng.conv_transpose2x2(x1, self.up, up_slot)
-        act, _ = self.conv.emit(eng, cat_full)
+        act, _ = self.conv.emit(eng, cat_full, head=head)
         return act
 
 
@@ -187,5 +188,5 @@ class TransAttUNet(HipModule):
         cur = fused
         for lvl in (3, 2, 1, 0):
             full, up_slot = cats[lvl]
-            cur = ups[lvl].emit(eng, cur, full, up_slot)
+            cur = ups[lvl].emit(eng, cur, full, up_slot, head=self.outc.conv if lvl == 0 else None)
         return (self.outc.emit(eng, cur),)

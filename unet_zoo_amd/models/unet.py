@@ -58,5 +58,6 @@ class UNet(HipModule):
         cur, _ = self.bottle_neck.emit(eng, cur)
         for lvl in (3, 2, 1, 0):
             full, up_slot = cats[lvl]
-            cur = ups[lvl].emit(eng, cur, full, up_slot)
+            # the last block's output feeds the head only: where the kernels can, it is never written down either
+            cur = ups[lvl].emit(eng, cur, full, up_slot, head=self.out.conv if lvl == 0 else None)
         return (self.out.emit(eng, cur),)

@@ -629,10 +629,22 @@ def bn_relu_bwd(y: Act, vec: torch.Tensor, g0: Optional[Act], g1: Optional[Act],
                 "uz_bn_relu_bwd_apply")
 
 
-def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def outconv_xform_supported(x: Act, K: int) -> bool:
+    """uz_outconv_fwd_xf / uz_outconv_bwd_bnred(x = NULL) take this raw activation (bf16, <= 512 channels, <= 8 classes)"""
+    return x.dtype == torch.bfloat16 and x.C % 8 == 0 and x.C // 8 <= 64 and 1 <= K <= 8 and x.ld % 8 == 0
+
+
+def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor, xform: Optional[tuple] = None) -> torch.Tensor:
+    """xform = (scale, shift): x is the RAW output of the convolution in front, read through its BatchNorm + ReLU"""
     lib = L.load()
     K = w.shape[0]
     out = torch.empty((x.N, K, x.H, x.W), dtype=torch.float32, device=x.buf.device)
+    if xform is not None:
+        assert outconv_xform_supported(x, K)
+        L.check(lib.uz_outconv_fwd_xf(L.dtype_code(x.dtype), x.ptr(), x.ld, x.N, x.H * x.W, x.C, xform[0].data_ptr(),
+                                      xform[1].data_ptr(), w.data_ptr(), b.data_ptr(), K, out.data_ptr(), L.stream_ptr()),
+                "uz_outconv_fwd_xf")
+        return out
     L.check(lib.uz_outconv_fwd(L.dtype_code(x.dtype), x.ptr(), x.ld, x.N, x.H * x.W, x.C,
                                w.data_ptr(), b.data_ptr(), K, out.data_ptr(), L.stream_ptr()),
             "uz_outconv_fwd")
@@ -641,9 +653,11 @@ def outconv_fwd(x: Act, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act],
                 dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
-                bnred: Optional[tuple] = None):
+                bnred: Optional[tuple] = None, lazy: bool = False):
     """bnred = (bn_y, vec): x = relu(bn(bn_y)) is read by this head only; the BatchNorm-backward sums of dx are taken in
-    the same pass (uz_outconv_bwd_bnred) and their partial rows left in dx.bn_partials (bf16 only; else ignored)"""
+    the same pass (uz_outconv_bwd_bnred) and their partial rows left in dx.bn_partials (bf16 only; else ignored).
+    lazy: x was never written down (outconv_fwd(xform=...)): x is only a shape here, the kernel forms the activation from
+    bn_y (bnred and dx are then required)"""
     lib = L.load()
     K = w.shape[0]
     assert g.dtype == torch.float32 and g.is_contiguous() and g.shape == (x.N, K, x.H, x.W)
@@ -656,11 +670,14 @@ def outconv_bwd(x: Act, w: torch.Tensor, g: torch.Tensor, dx: Optional[Act],
     wsb = L.check_count(lib.uz_outconv_bwd_workspace_bytes(code, x.N, x.H * x.W, x.C, K),
                         "uz_outconv_bwd_workspace_bytes")
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    if lazy:
+        assert bnred is not None and dx is not None and x.dtype == torch.bfloat16 and (bnred[0].P, bnred[0].C) == (x.P, x.C), \
+            "a head on a lazy activation takes its backward through uz_outconv_bwd_bnred"
     if bnred is not None and dx is not None and x.dtype == torch.bfloat16 and (bnred[0].P, bnred[0].C) == (x.P, x.C):
         bn_y, vec4 = bnred
         rows = L.check_count(lib.uz_outconv_bwd_rows(code, x.N, x.H * x.W, x.C), "uz_outconv_bwd_rows")
         part = torch.empty((rows, 2, x.C), dtype=torch.float32, device=dev)
-        L.check(lib.uz_outconv_bwd_bnred(code, x.ptr(), x.ld, x.N, x.H * x.W, x.C, w.data_ptr(), K, g.data_ptr(),
+        L.check(lib.uz_outconv_bwd_bnred(code, None if lazy else x.ptr(), x.ld, x.N, x.H * x.W, x.C, w.data_ptr(), K, g.data_ptr(),
                                          dx.ptr(), dx.ld, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), bn_y.ptr(), bn_y.ld,
                                          vec4[0].data_ptr(), vec4[1].data_ptr(), vec4[2].data_ptr(), vec4[3].data_ptr(),
                                          part.data_ptr(), L.stream_ptr()), "uz_outconv_bwd_bnred")
