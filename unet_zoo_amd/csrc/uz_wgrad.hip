@@ -593,12 +593,54 @@ struct MultiPlan {
   UzWgrad2Plan* p2 = nullptr;
   long long* ws_off = nullptr;    // byte offset of problem i's slabs in the workspace
   long long ws_total = 0;
+  int* order = nullptr;           // the shared problems in launch order: tile shape, then longest pixel list first
+  int* launch_of = nullptr;       // order[k] goes into shared launch launch_of[k]
+  int n_shared = 0;
   ~MultiPlan() {
     delete[] together;
     delete[] p2;
     delete[] ws_off;
+    delete[] order;
+    delete[] launch_of;
   }
 };
+
+// Finish time (in K-steps) of one shared launch under in-order dispatch of its workgroups to UZ_NUM_CU one-workgroup CUs:
+// problem k of the launch contributes tiles x ceil(units / T) workgroups of ~min(units, T) steps + FIX (pipeline fill and the
+// 64 KB slab store, in step units).
+long long multi_makespan(const UzWgrad2Plan* p2, const int* idx, int n, long long T) {
+  constexpr int FIX = 6;
+  constexpr int NCU = UZ_NUM_CU_HW;   // the hardware's count, not the reserve-adjusted one: the chosen splits (summation orders) must not depend on that setting
+  long long cu[NCU];
+  for (int c = 0; c < NCU; ++c) cu[c] = 0;
+  // a binary min-heap over the CUs' free times (all equal at the start: any array is a heap)
+  auto sift = [&](int i) {
+    for (;;) {
+      int l = 2 * i + 1, r = l + 1, m = i;
+      if (l < NCU && cu[l] < cu[m]) m = l;
+      if (r < NCU && cu[r] < cu[m]) m = r;
+      if (m == i) return;
+      const long long t = cu[i];
+      cu[i] = cu[m];
+      cu[m] = t;
+      i = m;
+    }
+  };
+  long long end = 0;
+  for (int k = 0; k < n; ++k) {
+    const UzWgrad2Plan& p = p2[idx[k]];
+    long long upb = p.units < T ? p.units : T;
+    const long long split = (p.units + upb - 1) / upb;
+    upb = (p.units + split - 1) / split;
+    const long long wgs = (long long)p.tiles_i * p.tiles_j * ((p.units + upb - 1) / upb);
+    for (long long w = 0; w < wgs; ++w) {
+      cu[0] += upb + FIX;
+      if (cu[0] > end) end = cu[0];
+      sift(0);
+    }
+  }
+  return end;
+}
 }  // namespace
 
 static int multi_plan(const uz_wgrad_item* items, int n, MultiPlan* mp) {
@@ -618,8 +660,49 @@ static int multi_plan(const uz_wgrad_item* items, int n, MultiPlan* mp) {
   }
   // K-steps (64 pixels each) per workgroup: long enough to carry the pipeline fill and the 64 KB slab store, short
   // enough that the whole set is several rounds of workgroups
-  long long T = steps / (4LL * UZ_NUM_CU);
-  T = T < 8 ? 8 : (T > 64 ? 64 : T);
+  long long Tmax = steps / (4LL * UZ_NUM_CU);
+  Tmax = Tmax < 8 ? 8 : (Tmax > 64 ? 64 : Tmax);
+  // Launch order: per tile shape, the problems with the longest pixel lists first (stable), so that a launch ends on its
+  // SHORT workgroups (a backward range hands the full-resolution layers over last: the last round of a launch was a few
+  // 64-step workgroups on an otherwise idle chip).  Then, per launch, the T <= Tmax whose in-order dispatch finishes first:
+  // swin_unet_v2 B = 16 256 x 256: 1046 + 318 workgroups = 4.09 + 1.24 rounds of 64 steps.  Results do not depend on the
+  // order (every problem has its own slabs); T changes a problem's split, i.e. its fixed summation order.
+  mp->order = new int[n];
+  mp->launch_of = new int[n];
+  int ns = 0;
+  for (int big = 0; big < 2; ++big) {
+    const int beg = ns;
+    for (int i = 0; i < n; ++i)
+      if (mp->together[i] && mp->p2[i].big == big) mp->order[ns++] = i;
+    for (int a = beg + 1; a < ns; ++a) {   // insertion sort: stable, n <= 4096 and mostly a few dozen
+      const int v = mp->order[a];
+      int b = a;
+      for (; b > beg && mp->p2[mp->order[b - 1]].units < mp->p2[v].units; --b) mp->order[b] = mp->order[b - 1];
+      mp->order[b] = v;
+    }
+  }
+  mp->n_shared = ns;
+  long long* Tof = new long long[n];
+  {
+    const int cap = uz_wgrad3x3_multi_max();
+    int launch = 0;
+    for (int beg = 0; beg < ns;) {
+      int end = beg;
+      while (end < ns && end - beg < cap && mp->p2[mp->order[end]].big == mp->p2[mp->order[beg]].big) ++end;
+      long long bestT = Tmax, best = -1;
+      const bool search = !(uz_tune_flags() & 0x8);
+      for (long long T = Tmax; T >= (search ? (Tmax + 1) / 2 : Tmax) && T >= 8; T -= 2) {
+        const long long m = multi_makespan(mp->p2, mp->order + beg, end - beg, T);
+        if (best < 0 || m < best) best = m, bestT = T;
+      }
+      for (int k = beg; k < end; ++k) {
+        Tof[mp->order[k]] = bestT;
+        mp->launch_of[k] = launch;
+      }
+      ++launch;
+      beg = end;
+    }
+  }
   long long off = 0;
   for (int i = 0; i < n; ++i) {
     const uz_wgrad_desc* d = &items[i].desc;
@@ -627,6 +710,7 @@ static int multi_plan(const uz_wgrad_item* items, int n, MultiPlan* mp) {
     long long bytes;
     if (mp->together[i]) {
       UzWgrad2Plan& p = mp->p2[i];
+      const long long T = Tof[i];
       long long upb = p.units < T ? p.units : T;
       const long long split = (p.units + upb - 1) / upb;
       upb = (p.units + split - 1) / split;
@@ -639,6 +723,7 @@ static int multi_plan(const uz_wgrad_item* items, int n, MultiPlan* mp) {
     }
     off += (bytes + 255) & ~255LL;
   }
+  delete[] Tof;
   mp->ws_total = off;
   return UZ_OK;
 }
@@ -664,21 +749,20 @@ extern "C" int uz_wgrad_multi(const uz_wgrad_item* items, int n, void* workspace
       if (r != UZ_OK) return r;
     }
   }
-  const int cap = uz_wgrad3x3_multi_max();
-  for (int big = 0; big < 2; ++big) {
+  {
     UzWgradMultiItem grp[64];
     int g = 0;
-    for (int i = 0; i <= n; ++i) {
-      const bool take = i < n && mp.together[i] && mp.p2[i].big == big;
-      // a problem that is not split writes its one "slab" where the result belongs
-      if (take)
-        grp[g++] = UzWgradMultiItem{&items[i].desc, mp.p2[i], items[i].L, items[i].R,
-                                    mp.p2[i].nslabs == 1 ? items[i].out : reinterpret_cast<float*>(ws + mp.ws_off[i])};
-      if (g == cap || (i == n && g > 0)) {
+    for (int k = 0; k <= mp.n_shared; ++k) {
+      if (g > 0 && (k == mp.n_shared || mp.launch_of[k] != mp.launch_of[k - 1])) {
         const int r = uz_wgrad3x3_multi_launch(grp, g, s);
         if (r != UZ_OK) return r;
         g = 0;
       }
+      if (k == mp.n_shared) break;
+      const int i = mp.order[k];
+      // a problem that is not split writes its one "slab" where the result belongs
+      grp[g++] = UzWgradMultiItem{&items[i].desc, mp.p2[i], items[i].L, items[i].R,
+                                  mp.p2[i].nslabs == 1 ? items[i].out : reinterpret_cast<float*>(ws + mp.ws_off[i])};
     }
   }
   bool vec4 = true;   // 16-byte stores need aligned destinations (a gradient may be a view into a flat buffer)
