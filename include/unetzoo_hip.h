@@ -535,6 +535,8 @@ typedef struct uz_ln_desc {
   int act; /* 0: none; 1: exact GELU applied to the result (MixFFN_skip's act(norm1(.)), missformer.py:206;
               no residual / image scale; backward through uz_layernorm_act_bwd) */
 } uz_ln_desc;
+/* (every entry of this family: gamma / beta are read with 16-byte loads, stats -- (mean, rstd) pairs -- with 8-byte accesses:
+ * 16- / 8-byte aligned pointers) */
 int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float* gamma, const float* beta,
                      const void* res, const float* image_scale, void* y, float* stats, void* stream);
 int uz_layernorm_bwd_rows(const uz_ln_desc* d); /* rows of `partial`; <0 on error */

@@ -302,21 +302,33 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(
       const int img = (int)(t / Ho);
       const size_t p00 = ((size_t)img * H + 2 * ho) * W + 2 * wo;
       float m[VEC];
+      // the four taps' loads are issued together, UNCONDITIONALLY (a clipped tap reads tap 0's address and is dropped by a
+      // select): a load inside `if (tap inside)` is followed by s_waitcnt vmcnt(0) at the block's end (hipcc 7.2), which ran
+      // the taps one memory round trip after the other
+      bool ok[4];
+      size_t pp[4];
+      Vec16<T> vr[4], rr[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (2 * ho + (k >> 1) >= H || 2 * wo + (k & 1) >= W) continue;  // clipped window (tap 0 is always inside)
-        const size_t p = p00 + (k >> 1) * W + (k & 1);
-        float v[VEC], r[VEC];
-        load_f(y + p * ldy + c0, v);
-        if (res != nullptr) load_f(res + p * ldr + c0, r);
+        ok[k] = 2 * ho + (k >> 1) < H && 2 * wo + (k & 1) < W;   // clipped window (tap 0 is always inside)
+        pp[k] = p00 + (k >> 1) * W + (k & 1);
+        // the dummy address is PIXEL 0 (of the tensor), not tap 0: a dummy the compiler can prove equal to an address it
+        // has already loaded is turned back into `if (differs) load` (with its wait); the same for a missing residual -- a
+        // load under `if (res != nullptr)`, uniform as that is, gets the wait too
+        vr[k] = ld16(ok[k] ? y + pp[k] * ldy + c0 : y + c0);
+        rr[k] = ld16(res != nullptr && ok[k] ? res + pp[k] * ldr + c0 : y + c0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          v[i] = fmaf(v[i], sc[i], sh[i]);
+          v[i] = fmaf((float)vr[k].v[i], sc[i], sh[i]);
           if (relu) v[i] = fmaxf(v[i], 0.f);
-          if (res != nullptr) v[i] = (float)(T)(v[i] + r[i]);  // the pool sees the stored value
-          m[i] = (k == 0) ? v[i] : fmaxf(m[i], v[i]);
+          if (res != nullptr) v[i] = (float)(T)(v[i] + (float)rr[k].v[i]);  // the pool sees the stored value
+          m[i] = (k == 0) ? v[i] : (ok[k] ? fmaxf(m[i], v[i]) : m[i]);
         }
-        store_f(act + p * lda + c0, v);
+        if (ok[k]) store_f(act + pp[k] * lda + c0, v);
       }
       if (ho < Hp && wo < Wp) store_f(pooled + (((size_t)img * Hp + ho) * Wp + wo) * ldp + c0, m);
     }
@@ -449,13 +461,23 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
 #ifndef UZ_BN_BRANCHY
     // every load of the iteration is issued before the first use: a branch per slot put an s_waitcnt vmcnt(0)
     // behind each slot's loads and the four slots ran one memory latency after the other
-    Vec16<T> yr[NPIX], g0r[NPIX], g1r[NPIX];
+    Vec16<T> yr[NPIX], g0r[NPIX], g1r[NPIX], gpr;
 #pragma unroll
     for (int k = 0; k < NPIX; ++k) {
       yr[k] = ld16(y + pix[k] * a.ldy + c0);
-      if (g0 != nullptr) g0r[k] = ld16(g0 + pix[k] * a.ldg0 + c0);
-      if (g1 != nullptr) g1r[k] = ld16(g1 + pix[k] * a.ldg1 + c0);
+      if constexpr (POOL) {
+        // (the pooled loop is not unswitched on the two pointers, and a load under `if (g != nullptr)`, uniform as that is,
+        // is waited for at the block's end: a missing gradient reads pixel 0 of y instead -- a cached line -- and is dropped)
+        g0r[k] = ld16(g0 != nullptr ? g0 + pix[k] * a.ldg0 + c0 : y + c0);
+        g1r[k] = ld16(g1 != nullptr ? g1 + pix[k] * a.ldg1 + c0 : y + c0);
+      } else {
+        if (g0 != nullptr) g0r[k] = ld16(g0 + pix[k] * a.ldg0 + c0);
+        if (g1 != nullptr) g1r[k] = ld16(g1 + pix[k] * a.ldg1 + c0);
+      }
     }
+    // ... the pool's gradient among them (a window without a pooled pixel reads element 0 and does not use it): as a load
+    // behind `if (has_pool)` it was a second memory round trip per window, after the first had been waited for
+    if constexpr (POOL) gpr = ld16(gp != nullptr ? gp + (has_pool ? gpoff : 0) + c0 : y + c0);
     float yv[NPIX][VEC], gv[NPIX][VEC];
 #pragma unroll
     for (int k = 0; k < NPIX; ++k)
@@ -494,7 +516,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const BnBwdArgs a) {
     if constexpr (POOL) {
       if (gp != nullptr && has_pool) {
         float gpv[VEC];
+#ifndef UZ_BN_BRANCHY
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gpv[i] = (float)gpr.v[i];
+#else
         load_f(gp + gpoff + c0, gpv);
+#endif
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           float best = fmaf(yv[0][i], sc[i], sh[i]);
@@ -665,7 +692,8 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const T* __restrict__ 
 
 // BNRED: x = relu(bn(bn_y)) has no other reader: the two sums of that BatchNorm's backward over this workgroup's pixels
 // (of dz = dx * [scale * bn_y + shift > 0], dx as stored) go to bnpart[blockIdx.x][2][C] (uz_outconv_bwd_bnred)
-template <typename T, int KOUT, bool BNRED = false>
+// XNULL (with BNRED): x was never written down (uz_outconv_fwd_xf): the activation is formed from bn_y
+template <typename T, int KOUT, bool BNRED = false, bool XNULL = false>
 __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ x, int ldx, int N,
                                                           int HW, int C, const float* __restrict__ w,
                                                           const float* __restrict__ g,
@@ -710,35 +738,37 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const T* __restrict__ 
     float v[UNR][VEC], gk[UNR][KOUT], yv[UNR][VEC];
     int pp[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {   // all loads first: UNR pixels in flight
+    for (int u = 0; u < UNR; ++u) {   // all loads first: UNR pixels in flight.  UNCONDITIONAL loads (a lane out of range
+      // reads pixel 0 / chunk 0 and is zeroed by a select): a load inside `if (in range)` ends in s_waitcnt vmcnt(0) at the
+      // block's end (hipcc 7.2) and the UNR pixels came one memory round trip after the other
       const int p = p0 + u * ppb + pl;
-      pp[u] = p < P ? p : -1;
-      if (pp[u] >= 0) {
-        if (live) {
-          if constexpr (BNRED) {
-            load_f(bn_y + (size_t)p * ld_bny + sub * VEC, yv[u]);
-            if (x != nullptr) {
-              load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
-            } else {   // the activation was never written down (uz_outconv_fwd_xf): the value the apply pass would have stored
+      const bool inp = p < P, ok = inp && live;
+      pp[u] = inp ? p : -1;
+      const size_t pc = ok ? (size_t)p : 0;
+      const int cs = ok ? sub * VEC : 0;
+      Vec16<T> xr, yr;
+      if constexpr (BNRED) yr = ld16(bn_y + pc * ld_bny + cs);
+      if constexpr (!XNULL) xr = ld16(x + pc * ldx + cs);
+      const int pg = inp ? p : 0;
+      const int img = (KOUT == 1) ? 0 : pg / HW;  // KOUT == 1: NCHW index == pixel index
+      const int hw = pg - img * HW;
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) v[u][i] = (float)(T)fmaxf(fmaf(yv[u][i], bsc[i], bsh[i]), 0.f);
-            }
-          } else {
-            load_f(x + (size_t)p * ldx + sub * VEC, v[u]);
-          }
+      for (int k = 0; k < KOUT; ++k) {
+        const float gq = g[((size_t)img * KOUT + k) * HW + hw];
+        gk[u][k] = inp ? gq : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        if constexpr (BNRED) {
+          yv[u][i] = (float)yr.v[i];
+          // XNULL: the activation was never written down (uz_outconv_fwd_xf): the value the apply pass would have stored
+          float xv;
+          if constexpr (XNULL) xv = (float)(T)fmaxf(fmaf(yv[u][i], bsc[i], bsh[i]), 0.f);
+          else xv = (float)xr.v[i];
+          v[u][i] = ok ? xv : 0.f;
         } else {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+          v[u][i] = ok ? (float)xr.v[i] : 0.f;
         }
-        const int img = (KOUT == 1) ? 0 : p / HW;  // KOUT == 1: NCHW index == pixel index
-        const int hw = p - img * HW;
-#pragma unroll
-        for (int k = 0; k < KOUT; ++k) gk[u][k] = g[((size_t)img * KOUT + k) * HW + hw];
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
-#pragma unroll
-        for (int k = 0; k < KOUT; ++k) gk[u][k] = 0.f;
       }
     }
 #pragma unroll
@@ -1599,9 +1629,15 @@ extern "C" int uz_outconv_bwd_bnred(int dtype, const void* x, int ldx, int N, in
   const int g = outconv_bwd_grid(dtype, N, HW, C);
   float* part = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT, true>), dim3((unsigned)g), dim3(256), 0, s,
-                                          (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, part,
-                                          (const bf16_t*)bn_y, ld_bny, scale, shift, mean, invstd, bn_partial))
+  if (x != nullptr) {
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT, true>), dim3((unsigned)g), dim3(256), 0, s,
+                                            (const bf16_t*)x, ldx, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, part,
+                                            (const bf16_t*)bn_y, ld_bny, scale, shift, mean, invstd, bn_partial))
+  } else {
+    UZ_KOUT_SWITCH(Kout, hipLaunchKernelGGL((outconv_bwd_kernel<bf16_t, KOUT, true, true>), dim3((unsigned)g), dim3(256), 0, s,
+                                            (const bf16_t*)nullptr, 0, N, HW, C, w, g_nchw, (bf16_t*)dx, lddx, part,
+                                            (const bf16_t*)bn_y, ld_bny, scale, shift, mean, invstd, bn_partial))
+  }
   UZ_LAUNCH_CHECK("uz_outconv_bwd_bnred");
   const int ne = Kout * (C + 1);
   hipLaunchKernelGGL(outconv_bwd_finalize_kernel, dim3(uz_cdiv(ne, 32)), dim3(1024), 0, s, part, g, Kout, C, dw, db);

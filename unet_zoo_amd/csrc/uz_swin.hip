@@ -199,16 +199,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
   const int ld2 = BWD ? a.ldg : a.ldr;
   float gam[MAXIT][VEC], bet[MAXIT][VEC], ag[MAXIT][VEC], ab[MAXIT][VEC];
   int dpix[MAXIT], cch[MAXIT];
+  // Every load of this kernel is UNCONDITIONAL: an out-of-range lane reads a valid dummy address and its value is replaced
+  // by a select.  Loads inside `if (in range)` blocks made hipcc 7.2 close every block with s_waitcnt vmcnt(0): the three
+  // chunks of a token (and the 48 gamma / beta words before them) arrived one memory round trip after the other, which
+  // is what a launch on a 1.5 MB tensor spent its 10 us on (tools/ln_bench.py under rocprofv3: see DESIGN 3b).
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int cc = sub + lpt * it;
     ln_chunk(a, cc * VEC, &dpix[it], &cch[it]);
+    const bool in = cc < CC;
+    const int c0 = in ? cc * VEC : 0;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      gam[it][e] = cc < CC ? a.gamma[cc * VEC + e] : 0.f;
-      bet[it][e] = ((!BWD || ACT) && cc < CC) ? a.beta[cc * VEC + e] : 0.f;
-      ag[it][e] = ab[it][e] = 0.f;
+    for (int e = 0; e < VEC; e += 4) {
+      const float4 gq = *reinterpret_cast<const float4*>(a.gamma + c0 + e);
+      const float4 bq = (!BWD || ACT) ? *reinterpret_cast<const float4*>(a.beta + c0 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gam[it][e] = in ? gq.x : 0.f, gam[it][e + 1] = in ? gq.y : 0.f, gam[it][e + 2] = in ? gq.z : 0.f, gam[it][e + 3] = in ? gq.w : 0.f;
+      bet[it][e] = in ? bq.x : 0.f, bet[it][e + 1] = in ? bq.y : 0.f, bet[it][e + 2] = in ? bq.z : 0.f, bet[it][e + 3] = in ? bq.w : 0.f;
     }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ag[it][e] = ab[it][e] = 0.f;
   }
   const float invC = 1.f / (float)a.C;
   const int tpb = 4 * tpw * U;  // tokens per workgroup pass
@@ -217,28 +226,36 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
     TokPos pos[U];
     bool tok[U];    // whole lane groups go idle together; shuffles below stay inside a group
     uint4 xr[U][MAXIT], sr[U][MAXIT];
-    float mean[U], rstd[U];
+    float mean[U], rstd[U], fsc[U];
+    const bool has2 = BWD || second != nullptr;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       t[u] = t0 + (u * 4 + wave) * tpw + grp;
       tok[u] = t[u] < P;
-      pos[u] = ln_tok(a, tok[u] ? t[u] : 0);
+      const int tc = tok[u] ? t[u] : 0;
+      pos[u] = ln_tok(a, tc);
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int cc = sub + lpt * it;
-        if (cc < CC && tok[u]) {
-          xr[u][it] = *reinterpret_cast<const uint4*>(x + ln_off(pos[u], dpix[it], cch[it], a.ldx));
-          if (BWD || second != nullptr) sr[u][it] = *reinterpret_cast<const uint4*>(second + (size_t)t[u] * ld2 + cc * VEC);
-          else sr[u][it] = make_uint4(0, 0, 0, 0);
-        } else {
-          xr[u][it] = sr[u][it] = make_uint4(0, 0, 0, 0);
-        }
+        const bool ok = cc < CC && tok[u], ok2 = ok && has2;
+        const T* px = ok ? x + ln_off(pos[u], dpix[it], cch[it], a.ldx) : x;
+        const T* ps = ok2 ? second + (size_t)tc * ld2 + cc * VEC : x;
+        const uint4 rx = *reinterpret_cast<const uint4*>(px), rs = *reinterpret_cast<const uint4*>(ps);
+        xr[u][it].x = ok ? rx.x : 0u, xr[u][it].y = ok ? rx.y : 0u, xr[u][it].z = ok ? rx.z : 0u, xr[u][it].w = ok ? rx.w : 0u;
+        sr[u][it].x = ok2 ? rs.x : 0u, sr[u][it].y = ok2 ? rs.y : 0u, sr[u][it].z = ok2 ? rs.z : 0u, sr[u][it].w = ok2 ? rs.w : 0u;
       }
       if constexpr (BWD) {
-        mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
-        rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
+        const float2 ms = *reinterpret_cast<const float2*>(a.stats + (size_t)tc * 2);
+        mean[u] = tok[u] ? ms.x : 0.f;
+        rstd[u] = tok[u] ? ms.y : 0.f;
       }
+      // the per-image factor (stochastic depth) with the operands, not after the reductions
+      const float* pf = a.sb != nullptr ? a.sb + pos[u].img : a.gamma;
+      const float fv = *pf;
+      fsc[u] = a.sb != nullptr ? fv : 1.f;
     }
+    (void)zero4;
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -271,11 +288,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
             }
           }
         const float rs = rsqrtf(group_sum(q, lpt) * invC + a.eps);
-        if (sub == 0 && tok[u]) {
-          a.stats[(size_t)t[u] * 2] = mu;
-          a.stats[(size_t)t[u] * 2 + 1] = rs;
-        }
-        const float f = a.sb != nullptr ? a.sb[pos[u].img] : 1.f;
+        const float f = fsc[u];
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
           const int cc = sub + lpt * it;
@@ -291,13 +304,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
             store_f(y + (size_t)t[u] * a.ldy + cc * VEC, o);
           }
         }
+        // (after the outputs: the block's join waits for the stores in front of it)
+        if (sub == 0 && tok[u]) *reinterpret_cast<float2*>(a.stats + (size_t)t[u] * 2) = make_float2(mu, rs);
       }
     } else {
       T* __restrict__ dx = static_cast<T*>(a.dx);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         __builtin_amdgcn_sched_barrier(0);   // one token at a time: the packed loads stay packed until here
-        const float f = a.sb != nullptr ? a.sb[pos[u].img] : 1.f;
+        const float f = fsc[u];
         float xh[MAXIT][VEC], gv[MAXIT][VEC];
         float s1 = 0.f, s2 = 0.f;  // sum of g*gamma, sum of g*gamma*xhat
 #pragma unroll
@@ -426,18 +441,24 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const LnHeadArgs h, int lp
       const int tc = tok[u] ? t[u] : 0;
       pos[u] = ln_tok(a, tc);
       rem[u] = tc - pos[u].img * HW;
+      // unconditional loads (a dummy address for lanes out of range, then a select): see layernorm_kernel
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
         const int cc = sub + lpt * it;
-        xr[u][it] = (cc < CC && tok[u]) ? *reinterpret_cast<const uint4*>(x + ln_off(pos[u], 0, cc * VEC, a.ldx))
-                                        : make_uint4(0, 0, 0, 0);
+        const bool ok = cc < CC && tok[u];
+        const uint4 rx = *reinterpret_cast<const uint4*>(ok ? x + ln_off(pos[u], 0, cc * VEC, a.ldx) : x);
+        xr[u][it].x = ok ? rx.x : 0u, xr[u][it].y = ok ? rx.y : 0u, xr[u][it].z = ok ? rx.z : 0u, xr[u][it].w = ok ? rx.w : 0u;
       }
       if constexpr (BWD) {
-        mean[u] = tok[u] ? a.stats[(size_t)t[u] * 2] : 0.f;
-        rstd[u] = tok[u] ? a.stats[(size_t)t[u] * 2 + 1] : 0.f;
+        const float2 ms = *reinterpret_cast<const float2*>(a.stats + (size_t)tc * 2);
+        mean[u] = tok[u] ? ms.x : 0.f;
+        rstd[u] = tok[u] ? ms.y : 0.f;
 #pragma unroll
-        for (int k = 0; k < KT; ++k)
-          dl[u][k] = (tok[u] && k < K) ? h.dlogits[((size_t)pos[u].img * K + k) * HW + rem[u]] : 0.f;
+        for (int k = 0; k < KT; ++k) {
+          const bool okk = tok[u] && k < K;
+          const float dv = h.dlogits[okk ? ((size_t)pos[u].img * K + k) * HW + rem[u] : 0];
+          dl[u][k] = okk ? dv : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -2163,6 +2184,8 @@ extern "C" int uz_layernorm_fwd(const uz_ln_desc* d, const void* x, const float*
   if (rc != UZ_OK) return rc;
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(x && gamma && beta && y && stats, "uz_layernorm_fwd: null pointer");
+  UZ_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)stats & 7) == 0,
+             "uz_layernorm_fwd: gamma / beta must be 16-byte aligned, stats 8-byte aligned");
   UZ_REQUIRE(d->ldy % vec == 0 && d->ldy >= d->C, "uz_layernorm_fwd: bad ldy");
   if (res) UZ_REQUIRE(d->ldr % vec == 0 && d->ldr >= d->C, "uz_layernorm_fwd: bad ldr");
   LnArgs a{};
@@ -2191,6 +2214,8 @@ static int ln_bwd_common(const char* fn, const uz_ln_desc* d, const void* x, con
   if (rc != UZ_OK) return rc;
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(x && gamma && stats && g && dx && partial, "%s: null pointer", fn);
+  UZ_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 && ((uintptr_t)stats & 7) == 0,
+             "%s: gamma / beta must be 16-byte aligned, stats 8-byte aligned", fn);
   UZ_REQUIRE(d->ldg % vec == 0 && d->ldg >= d->C && d->lddx % vec == 0, "%s: bad ldg / lddx", fn);
   LnArgs a{};
   a.x = x; a.g = g; a.dx = dx; a.gamma = gamma; a.beta = beta; a.sb = image_scale; a.stats = const_cast<float*>(stats);
@@ -2293,6 +2318,7 @@ extern "C" int uz_ln_head_bwd(const uz_ln_desc* d, const void* x, const float* g
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(x && gamma && beta && w && stats && dlogits && dx && dgamma && dbeta && dw && workspace,
              "uz_ln_head_bwd: null pointer");
+  UZ_REQUIRE(((uintptr_t)stats & 7) == 0, "uz_ln_head_bwd: stats must be 8-byte aligned");
   UZ_REQUIRE(d->lddx % vec == 0, "uz_ln_head_bwd: bad lddx");
   LnHeadArgs h{};
   ln_head_args(d, &h);
