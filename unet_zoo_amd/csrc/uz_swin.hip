@@ -411,17 +411,28 @@ __global__ __launch_bounds__(256) void ln_head_kernel(const LnHeadArgs h, int lp
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
       const int cc = sub + lpt * it;
+      const bool in = cc < CC && k < K;
+      // unconditional 16-byte loads (chunk 0 of class 0 for a lane out of range, then a select): as `in ? w[...] : 0` these
+      // were 3 x 8 x 3 dword loads, each waited for before the next was issued (see layernorm_kernel)
+      const int co = in ? cc * VEC : 0;
+      const size_t wo = in ? (size_t)k * a.C + cc * VEC : 0;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const bool in = cc < CC && k < K;
-        const float wv = in ? h.w[(size_t)k * a.C + cc * VEC + e] : 0.f;
-        wg[k][it][e] = in ? wv * a.gamma[cc * VEC + e] : 0.f;
-        S[k][it][e] = 0.f;
-        c0 += in ? wv * a.beta[cc * VEC + e] : 0.f;
-        c1 += wg[k][it][e];
+      for (int e = 0; e < VEC; e += 4) {
+        const float4 wq = *reinterpret_cast<const float4*>(h.w + wo + e);
+        const float4 gq = *reinterpret_cast<const float4*>(a.gamma + co + e);
+        const float4 bq = *reinterpret_cast<const float4*>(a.beta + co + e);
+        const float wv[4] = {wq.x, wq.y, wq.z, wq.w}, gv[4] = {gq.x, gq.y, gq.z, gq.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wg[k][it][e + q] = in ? wv[q] * gv[q] : 0.f;
+          S[k][it][e + q] = 0.f;
+          c0 += in ? wv[q] * bv[q] : 0.f;
+          c1 += wg[k][it][e + q];
+        }
       }
     }
-    cst[k] = group_sum(c0, lpt) + ((h.b != nullptr && k < K) ? h.b[k] : 0.f);
+    const float bk = h.b != nullptr ? h.b[k < K ? k : 0] : 0.f;
+    cst[k] = group_sum(c0, lpt) + ((h.b != nullptr && k < K) ? bk : 0.f);
     swg[k] = group_sum(c1, lpt);
     D[k] = 0.f;
   }
@@ -1100,8 +1111,21 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
     for (int i = 0; i < 16; ++i) {
       const int e = tid + 256 * i, r = e >> 6, c = e & 63;
       const bool in = r < N && c < N && !(UZ_KFLAGS(a) & 0x10000);
-      tv[i] = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
-      bv[i] = in ? a.bias[((size_t)h * N + r) * N + c] : ((r < N && c < N) ? 0.f : -1e30f);   // padding: exp() = 0, no test
+      // (unconditional loads -- entry (0, 0) for a lane outside the window -- then a select: under `in ? ... :` every load
+      // was waited for before the next was issued, the "16 serialized round trips" again)
+      tv[i] = a.tau[in ? ((size_t)h * a.Nt + r) * a.Nt + c : 0];
+      bv[i] = a.bias[in ? ((size_t)h * N + r) * N + c : 0];
+    }
+    // (the loaded values are made opaque before the selects: a value that is only used when `in` holds is otherwise turned back
+    // into a load under a branch)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(tv[i]), "+v"(bv[i]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+      const bool in = r < N && c < N && !(UZ_KFLAGS(a) & 0x10000);
+      tv[i] = in ? tv[i] : 1.f;
+      bv[i] = in ? bv[i] : ((r < N && c < N) ? 0.f : -1e30f);   // padding: exp() = 0, no test
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1126,37 +1150,34 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   WinTok ntq = {0, -1}, ntk = {0, -1};
   bf16x8 nq[2], ng[2], no[2], nk[2], nv[2];
   float nlse = 0.f;
+  // UNCONDITIONAL loads (a lane beyond the window -- 7 x 7 windows -- reads token 0 of its window and is zeroed by a select):
+  // as loads under `if (iq < N)` each group ended in s_waitcnt vmcnt(0) (hipcc 7.2) and the "prefetch" waited for its own data
+  // in the middle of the current window -- the kernel ran one memory round trip per window behind its own design.
   auto fetch = [&](int win) {
-    ntq = {0, -1};
-    ntk = {0, -1};
-    nlse = 0.f;
+    const bool qin = iq < N, kin = jk < N;
+    const WinTok tq0 = win_token(a, win, qin ? iq : 0), tk0 = win_token(a, win, kin ? jk : 0);
+    const bf16_t* row = qkv + (size_t)tq0.tok * a.ldq + h * AD + 8 * lh;
+    const bf16_t* grow = dout + (size_t)tq0.tok * a.lddo + h * AD + 8 * lh;
+    const bf16_t* orow = out + (size_t)tq0.tok * a.ldo + h * AD + 8 * lh;
+    const bf16_t* rowk = qkv + (size_t)tk0.tok * a.ldq + a.C + h * AD + 8 * lh;
+    // the RAW loaded registers are kept; the zeroing of lanes beyond the window happens where they are consumed, one window
+    // later (a select here would wait for the data at once)
+    nlse = a.lse[((size_t)win * a.heads + h) * N + (qin ? iq : 0)];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) nq[ks][e] = ng[ks][e] = no[ks][e] = nk[ks][e] = nv[ks][e] = (bf16_t)0.f;
-    if (iq < N) {
-      ntq = win_token(a, win, iq);
-      const bf16_t* row = qkv + (size_t)ntq.tok * a.ldq + h * AD + 8 * lh;
-      const bf16_t* grow = dout + (size_t)ntq.tok * a.lddo + h * AD + 8 * lh;
-      const bf16_t* orow = out + (size_t)ntq.tok * a.ldo + h * AD + 8 * lh;
-      nlse = a.lse[((size_t)win * a.heads + h) * N + iq];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        nq[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
-        ng[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks);
-        no[ks] = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
-      }
+    for (int ks = 0; ks < 2; ++ks) {
+      nq[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+      ng[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks);
+      no[ks] = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
+      nk[ks] = *reinterpret_cast<const bf16x8*>(rowk + 16 * ks);
+      nv[ks] = *reinterpret_cast<const bf16x8*>(rowk + a.C + 16 * ks);
     }
-    if (jk < N) {
-      ntk = win_token(a, win, jk);
-      const bf16_t* row = qkv + (size_t)ntk.tok * a.ldq + a.C + h * AD + 8 * lh;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        nk[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
-        nv[ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
-      }
-    }
+    ntq = qin ? tq0 : WinTok{0, -1};
+    ntk = kin ? tk0 : WinTok{0, -1};
   };
+  const bool qin = iq < N, kin = jk < N;
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (bf16_t)0.f;
   if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
 
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
@@ -1165,15 +1186,16 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
     const WinTok tq = ntq, tkk = ntk;
     bf16x8 qf[2], gf[2], kf[2], vf[2];
     float rq = 0.f, Di = 0.f;
-    const float lse = nlse;
+    const float lse = qin ? nlse : 0.f;
     {
       float q2 = 0.f, k2 = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = nq[ks];
-        gf[ks] = ng[ks];
-        kf[ks] = nk[ks];
-        vf[ks] = nv[ks];
+        qf[ks] = qin ? nq[ks] : zero8;
+        gf[ks] = qin ? ng[ks] : zero8;
+        kf[ks] = kin ? nk[ks] : zero8;
+        vf[ks] = kin ? nv[ks] : zero8;
+        no[ks] = qin ? no[ks] : zero8;
         // |q|^2, |k|^2 and dO . O on bf16 pairs (v_dot2c_f32_bf16: fp32 products and sums), 12 instructions instead of ~130
         const bf16x2* qp = reinterpret_cast<const bf16x2*>(&qf[ks]);
         const bf16x2* kp = reinterpret_cast<const bf16x2*>(&kf[ks]);
@@ -1230,7 +1252,10 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ut, 0, 0, 0);
         dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], gf[ks], dt, 0, 0, 0);
       }
-      if (win + (int)gridDim.x < nWin) fetch(win + gridDim.x);
+      {   // (unconditionally: a workgroup's last window fetches itself again rather than putting the loads under a branch)
+        const int nxt = win + (int)gridDim.x;
+        fetch(nxt < nWin ? nxt : win);
+      }
       float w1[16];
       // could any pair of this wave fall under the clamp?  1 / (|scale q_i| |k_j|) > 1e6 for the smallest non-zero |k| of the tile
       float corrQ = 0.f;
@@ -1443,8 +1468,21 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
     for (int i = 0; i < 16; ++i) {
       const int e = tid + 256 * i, r = e >> 6, c = e & 63;
       const bool in = r < N && c < N;
-      tv[i] = in ? a.tau[((size_t)h * a.Nt + r) * a.Nt + c] : 1.f;
-      bv[i] = in ? a.bias[((size_t)h * N + r) * N + c] : -1e30f;
+      // unconditional loads (entry (0, 0) for a lane outside the window, then a select): as `in ? table[...] : pad` every
+      // load was waited for before the next was issued
+      tv[i] = a.tau[in ? ((size_t)h * a.Nt + r) * a.Nt + c : 0];
+      bv[i] = a.bias[in ? ((size_t)h * N + r) * N + c : 0];
+    }
+    // (the loaded values are made opaque before the selects: a value that is only used when `in` holds is otherwise turned back
+    // into a load under a branch)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(tv[i]), "+v"(bv[i]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, r = e >> 6, c = e & 63;
+      const bool in = r < N && c < N;
+      tv[i] = in ? tv[i] : 1.f;
+      bv[i] = in ? bv[i] : -1e30f;
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1470,29 +1508,29 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
 
   WinTok ntq = {0, -1}, ntk = {0, -1};
   bf16x8 nq[2], nk[2], nv[2];
+  // The next window's operands, requested while this one is computed.  UNCONDITIONAL loads: a lane beyond the window (7 x 7
+  // windows) reads token 0 of its window and is zeroed by a select -- as loads under `if (iq < N)` each group was closed by
+  // s_waitcnt vmcnt(0) (hipcc 7.2) and the prefetch waited for its own data in the middle of the current window.
   auto fetch = [&](int win) {
-    ntq = {0, -1};
-    ntk = {0, -1};
+    const bool qin = iq < N, kin = jk < N;
+    const WinTok tq0 = win_token(a, win, qin ? iq : 0), tk0 = win_token(a, win, kin ? jk : 0);
+    const bf16_t* rowq = qkv + (size_t)tq0.tok * a.ldq + h * AD + 8 * lh;
+    const bf16_t* rowk = qkv + (size_t)tk0.tok * a.ldq + a.C + h * AD + 8 * lh;
+    // the RAW loaded registers are kept; lanes beyond the window are zeroed where the registers are consumed, one window
+    // later (a select here would wait for the data at once)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) nq[ks][e] = nk[ks][e] = nv[ks][e] = (bf16_t)0.f;
-    if (iq < N) {
-      ntq = win_token(a, win, iq);
-      const bf16_t* row = qkv + (size_t)ntq.tok * a.ldq + h * AD + 8 * lh;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) nq[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+    for (int ks = 0; ks < 2; ++ks) {
+      nq[ks] = *reinterpret_cast<const bf16x8*>(rowq + 16 * ks);
+      nk[ks] = *reinterpret_cast<const bf16x8*>(rowk + 16 * ks);
+      nv[ks] = *reinterpret_cast<const bf16x8*>(rowk + a.C + 16 * ks);
     }
-    if (jk < N) {
-      ntk = win_token(a, win, jk);
-      const bf16_t* row = qkv + (size_t)ntk.tok * a.ldq + a.C + h * AD + 8 * lh;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        nk[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
-        nv[ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
-      }
-    }
+    ntq = qin ? tq0 : WinTok{0, -1};
+    ntk = kin ? tk0 : WinTok{0, -1};
   };
+  const bool qin = iq < N, kin = jk < N;
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (bf16_t)0.f;
   if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
 
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
@@ -1504,8 +1542,8 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
       float q2 = 0.f, k2 = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = nq[ks];
-        kf[ks] = nk[ks];
+        qf[ks] = qin ? nq[ks] : zero8;
+        kf[ks] = kin ? nk[ks] : zero8;
         const bf16x2* qp = reinterpret_cast<const bf16x2*>(&qf[ks]);
         const bf16x2* kp = reinterpret_cast<const bf16x2*>(&kf[ks]);
 #pragma unroll
@@ -1525,7 +1563,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sVT[(16 * ks + 8 * lh + e) * VTS + jk] = nv[ks][e];
+          for (int e = 0; e < 8; ++e) sVT[(16 * ks + 8 * lh + e) * VTS + jk] = kin ? nv[ks][e] : (bf16_t)0.f;
       }
     }
     lds_barrier();
@@ -1534,7 +1572,10 @@ __global__ __launch_bounds__(256) void winattn_fwd_mfma2_kernel(const AttnArgs a
     for (int r = 0; r < 16; ++r) ut[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ut, 0, 0, 0);
-    if (win + (int)gridDim.x < nWin) fetch(win + gridDim.x);
+    {   // (unconditionally: the last window of a workgroup fetches itself again rather than putting the loads under a branch)
+      const int nxt = win + (int)gridDim.x;
+      fetch(nxt < nWin ? nxt : win);
+    }
     float sv[16], mx = -3.0e38f;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {   // key group of four: one 16-byte read per operand, 16 independent element chains
@@ -2295,6 +2336,8 @@ extern "C" int uz_ln_head_fwd(const uz_ln_desc* d, const void* x, const float* g
   const int rc = ln_head_check("uz_ln_head_fwd", d, K);
   if (rc != UZ_OK) return rc;
   UZ_REQUIRE(x && gamma && beta && w && logits && stats, "uz_ln_head_fwd: null pointer");
+  UZ_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w) & 15) == 0 && ((uintptr_t)stats & 7) == 0,
+             "uz_ln_head_fwd: gamma / beta / w must be 16-byte aligned, stats 8-byte aligned");
   LnHeadArgs h{};
   ln_head_args(d, &h);
   h.ln.x = x; h.ln.gamma = gamma; h.ln.beta = beta; h.ln.stats = stats;
@@ -2318,7 +2361,8 @@ extern "C" int uz_ln_head_bwd(const uz_ln_desc* d, const void* x, const float* g
   const int vec = d->dtype == UZ_BF16 ? 8 : 4;
   UZ_REQUIRE(x && gamma && beta && w && stats && dlogits && dx && dgamma && dbeta && dw && workspace,
              "uz_ln_head_bwd: null pointer");
-  UZ_REQUIRE(((uintptr_t)stats & 7) == 0, "uz_ln_head_bwd: stats must be 8-byte aligned");
+  UZ_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w) & 15) == 0 && ((uintptr_t)stats & 7) == 0,
+             "uz_ln_head_bwd: gamma / beta / w must be 16-byte aligned, stats 8-byte aligned");
   UZ_REQUIRE(d->lddx % vec == 0, "uz_ln_head_bwd: bad lddx");
   LnHeadArgs h{};
   ln_head_args(d, &h);
