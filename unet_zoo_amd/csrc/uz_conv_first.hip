@@ -39,27 +39,32 @@ __device__ __forceinline__ float round_bf16(float v) { return (float)(bf16_t)v; 
 // halo tile of image `img` at (h0, w0): sx[c][PH][PW] fp32 (bf16-rounded values), zero outside the image.  Register-staged
 // in two halves so that a persistent workgroup fetches its NEXT tile (four independent loads per thread, one round trip)
 // while it computes the current one.
-__device__ __forceinline__ void halo_fetch(const CfArgs& a, float (&h)[4], int tile, int tid) {
+// The loads are UNCONDITIONAL (element 0 of the tensor for a halo position outside the image) and their RAW values are kept;
+// bit j of the returned mask says whether h[j] is real, and halo_store() -- one tile later -- zeroes the rest.  As loads
+// under `if (inside)` each was followed by s_waitcnt vmcnt(0) (hipcc 7.2): four round trips, waited for on the spot, where
+// the design wants one that lands during the current tile.
+__device__ __forceinline__ unsigned halo_fetch(const CfArgs& a, float (&h)[4], int tile, int tid) {
   const int per = a.th_n * a.tw_n;
   const int img = tile / per, rem = tile - img * per;
   const int h0 = (rem / a.tw_n) * TH, w0 = (rem % a.tw_n) * TW;
   const int n = a.C * PH * PW;
+  unsigned mask = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int idx = tid + 256 * j;
     const int c = idx / (PH * PW), r2 = idx - c * (PH * PW);
     const int r = r2 / PW, col = r2 - r * PW;
     const int gh = h0 - 1 + r, gw = w0 - 1 + col;
-    float v = 0.f;
-    if (idx < n && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W)
-      v = a.x[(((size_t)img * a.C + c) * a.H + gh) * a.W + gw];
-    h[j] = v;
+    const bool ok = idx < n && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+    h[j] = a.x[ok ? (((size_t)img * a.C + c) * a.H + gh) * a.W + gw : 0];
+    mask |= ok ? 1u << j : 0u;
   }
+  return mask;
 }
-__device__ __forceinline__ void halo_store(float* sx, const float (&h)[4], int tid, int n) {
+__device__ __forceinline__ void halo_store(float* sx, const float (&h)[4], unsigned mask, int tid, int n) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    if (tid + 256 * j < n) sx[tid + 256 * j] = round_bf16(h[j]);
+    if (tid + 256 * j < n) sx[tid + 256 * j] = (mask >> j & 1u) ? round_bf16(h[j]) : 0.f;
 }
 static_assert(3 * PH * PW <= 4 * 256, "four halo elements per thread");
 
@@ -77,11 +82,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const CfArgs a) {
   const int per = a.th_n * a.tw_n;
   const int K = a.C * 9;
   float hreg[4];
-  if ((int)blockIdx.x < a.ntiles) halo_fetch(a, hreg, blockIdx.x, tid);
+  unsigned hmask = 0;
+  if ((int)blockIdx.x < a.ntiles) hmask = halo_fetch(a, hreg, blockIdx.x, tid);
   if (tid < 64) sbias[tid] = (a.bias != nullptr && tid < a.Cout) ? a.bias[tid] : 0.f;
 
   // weights as the row operand: lane (co = 32 t + lane % 32, K block b) holds w[co][16 kh + 8 b + i], zero beyond K
   bf16x8 wfr[CT][2];
+  float wraw[CT][2][8];
 #pragma unroll
   for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -89,7 +96,22 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const CfArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = 16 * kh + 8 * b + i, co = 32 * t + px;
-        wfr[t][kh][i] = (bf16_t)((k < K && co < a.Cout) ? a.w[(size_t)co * K + k] : 0.f);
+        wraw[t][kh][i] = a.w[(k < K && co < a.Cout) ? (size_t)co * K + k : 0];   // unconditional loads, all in flight ...
+      }
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(wraw[t][kh][i]));   // ... opaque, so that the selects below cannot pull them back under a branch
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 16 * kh + 8 * b + i, co = 32 * t + px;
+        wfr[t][kh][i] = (bf16_t)((k < K && co < a.Cout) ? wraw[t][kh][i] : 0.f);
       }
   // this lane's 16 patch offsets (floats): k -> (c, ty, tx) -> (c PH + ty) PW + tx, plus its pixel column
   int koff[2][8];
@@ -116,9 +138,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const CfArgs a) {
     const int img = tile / per, rem = tile - img * per;
     const int h0 = (rem / a.tw_n) * TH, w0 = (rem % a.tw_n) * TW;
     __syncthreads();   // the previous tile's halo is consumed
-    halo_store(sx, hreg, tid, a.C * PH * PW);
+    halo_store(sx, hreg, hmask, tid, a.C * PH * PW);
     __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles) halo_fetch(a, hreg, tile + gridDim.x, tid);   // in flight during this tile's rows
+    {   // the next tile, in flight during this tile's rows (unconditionally: the last tile fetches itself again -- a load under
+        // a branch is waited for where the branch ends)
+      const int nxt = tile + (int)gridDim.x;
+      hmask = halo_fetch(a, hreg, nxt < a.ntiles ? nxt : tile, tid);
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int row = 2 * wave + rr, gh = h0 + row;
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const CfArgs a) {
   constexpr int NDY = TH * TW * CPP / 256;          // dy chunks per thread and tile (8 or 4)
   float hreg[4];
   f32x4 dreg[NDY];
+  unsigned hmask = 0, dmask = 0;
   auto dy_fetch = [&](int tile) __attribute__((always_inline)) {
     const int img = tile / per, rem = tile - img * per;
     const int h0 = (rem / a.tw_n) * TH, w0 = (rem % a.tw_n) * TW;
@@ -233,20 +260,20 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const CfArgs a) {
       const int idx = tid + 256 * j;
       const int p = idx / CPP, ch = idx % CPP;
       const int r = p / TW, c = p % TW, gh = h0 + r, gw = w0 + c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gh < a.H && gw < a.W && ch * 8 < a.Cout)
-        v = *reinterpret_cast<const f32x4*>(dyg + (((size_t)img * a.H + gh) * a.W + gw) * a.ldy + ch * 8);
-      dreg[j] = v;
+      // unconditional (pixel 0 for a chunk outside the image / beyond the channels), RAW; zeroed where it is stored to LDS
+      const bool ok = gh < a.H && gw < a.W && ch * 8 < a.Cout;
+      dreg[j] = *reinterpret_cast<const f32x4*>(ok ? dyg + (((size_t)img * a.H + gh) * a.W + gw) * a.ldy + ch * 8 : dyg);
+      dmask |= ok ? 1u << j : 0u;
     }
   };
   if ((int)blockIdx.x < a.ntiles) {
-    halo_fetch(a, hreg, blockIdx.x, tid);
+    hmask = halo_fetch(a, hreg, blockIdx.x, tid);
     dy_fetch(blockIdx.x);
   }
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     __syncthreads();   // the previous tile is consumed
-    halo_store(sx, hreg, tid, a.C * PH * PW);
+    halo_store(sx, hreg, hmask, tid, a.C * PH * PW);
     // dy tile, pixel-major [row][col][channel]; 64-byte granule swizzle on the way in
 #pragma unroll
     for (int j = 0; j < NDY; ++j) {
@@ -254,12 +281,15 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const CfArgs a) {
       const int p = idx / CPP, ch = idx % CPP;
       const int gran = ch >> 2, sw = (p >> 1) & 1;
       const int pg = (CT == 2) ? (gran ^ sw) : gran;   // (one granule per pixel at CT = 1: nothing to swizzle)
-      *reinterpret_cast<f32x4*>(sdy + p * RB + pg * 64 + (ch & 3) * 16) = dreg[j];
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(sdy + p * RB + pg * 64 + (ch & 3) * 16) = (dmask >> j & 1u) ? dreg[j] : z4;
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles) {   // the next tile streams in while this one is multiplied
-      halo_fetch(a, hreg, tile + gridDim.x, tid);
-      dy_fetch(tile + gridDim.x);
+    {   // the next tile streams in while this one is multiplied (unconditionally: the last tile fetches itself again)
+      const int nxt = tile + (int)gridDim.x, ft = nxt < a.ntiles ? nxt : tile;
+      hmask = halo_fetch(a, hreg, ft, tid);
+      dmask = 0;
+      dy_fetch(ft);
     }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
