@@ -68,6 +68,12 @@ constexpr unsigned OOB = 0x80000000u;
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// keeps a 16-byte load unconditional: the loaded registers pass through an empty asm, so the optimiser cannot conclude that the
+// value is needed on one path only and move the load under that path's branch (where hipcc 7.2 ends the block with vmcnt(0))
+template <typename T> __device__ __forceinline__ void pin16(Vec16<T>& v) {
+  unsigned* r = reinterpret_cast<unsigned*>(&v);
+  asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
 
 // BM x BN tile per workgroup, NST stages of one 128-byte K slab each in the LDS ring (NST - 1 in flight).
 // (256, 3) is the throughput shape.  A GEMM whose 256-row tiling leaves most CUs idle (the 16x16 and 8x8
@@ -343,9 +349,14 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
         const T* by = static_cast<const T*>(a.bn_y);
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
+          // unconditional (element 0 for a row outside the image / a chunk beyond the channels: such a chunk is never used):
+          // as `ok ? load : 0` every pass's load was waited for -- with the next tile's LDS-DMA stages in front of it --
+          // before the next pass's was issued
           const long long orow = out_row(tid / CPR + k * RPP, 0);
-          yb[k] = (orow >= 0 && cok) ? ld16(by + (size_t)orow * a.ld_bny + n0 + cc * VEC) : zero16<T>();
+          yb[k] = ld16(by + ((orow >= 0 && cok) ? (size_t)orow * a.ld_bny + n0 + cc * VEC : 0));
         }
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) pin16(yb[k]);   // (opaque: a value used only under `ok` is otherwise loaded under a branch again)
         const int ch0 = cok ? n0 + cc * VEC : 0;
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) {
@@ -359,8 +370,10 @@ __global__ __launch_bounds__(512, (NST == 2 ? 2 : 1)) void gemm_dma_kernel(const
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
           const long long orow = out_row(tid / CPR + k * RPP, abt);
-          rb[k] = (orow >= 0 && cok) ? ld16(rg + (size_t)orow * a.ldres + cot) : zero16<T>();
+          rb[k] = ld16(rg + ((orow >= 0 && cok) ? (size_t)orow * a.ldres + cot : 0));   // (unconditional, as above; the sum of a chunk that is not stored is not used)
         }
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) pin16(rb[k]);
 #pragma unroll
         for (int k = 0; k < NPASS; ++k)
 #pragma unroll
