@@ -38,12 +38,31 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   const int cl = threadIdx.x % EW, g = threadIdx.x / EW;
   const int c = blockIdx.x * EW + cl;
   double a1 = 0.0, a2 = 0.0;
-  if (c < C) {
-    for (int r = g; r < grid_m; r += NG) {
-      a1 += (double)part[((size_t)r * 2 + 0) * C + c];
-      a2 += (double)part[((size_t)r * 2 + 1) * C + c];
+  const int cq = c < C ? c : 0;
+  // the tail's operands, requested before the reduction (they were three dependent round trips behind `if (g == 0)`, in a
+  // kernel that is nothing but latency); unconditional, made opaque below so that they stay in front
+  float gmv = gamma[cq], btv = beta[cq];
+  float rmv = (running_mean != nullptr ? running_mean : gamma)[cq], rvv = (running_var != nullptr ? running_var : gamma)[cq];
+  // four row groups per trip, unconditional loads (row 0 past the end, dropped by the select), added in the same order as one
+  // group per trip: the sums are bit-identical, the dependent round trips a quarter
+  for (int r = g; r < grid_m; r += 4 * NG) {
+    float p1[4], p2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = r + k * NG < grid_m ? r + k * NG : 0;
+      p1[k] = part[((size_t)rr * 2 + 0) * C + cq];
+      p2[k] = part[((size_t)rr * 2 + 1) * C + cq];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(p1[k]), "+v"(p2[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (r + k * NG < grid_m && c < C) {
+        a1 += (double)p1[k];
+        a2 += (double)p2[k];
+      }
   }
+  asm volatile("" : "+v"(gmv), "+v"(btv), "+v"(rmv), "+v"(rvv));
   sh[0][g][cl] = a1;
   sh[1][g][cl] = a2;
   __syncthreads();
@@ -63,15 +82,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     double var = t2 / count - m * m;
     if (var < 0.0) var = 0.0;
     const double istd = 1.0 / sqrt(var + (double)eps);
-    const float sc = (float)((double)gamma[c] * istd);
+    const float sc = (float)((double)gmv * istd);
     scale[c] = sc;
-    shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * istd);
+    shift[c] = (float)((double)btv - m * (double)gmv * istd);
     mean[c] = (float)m;
     invstd[c] = (float)istd;
     if (running_mean != nullptr) {
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
-      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)rmv + (double)momentum * m);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)rvv + (double)momentum * unbiased);
     }
   }
 }
@@ -594,11 +613,24 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   const int cl = threadIdx.x % EW, g = threadIdx.x / EW;
   const int c = blockIdx.x * EW + cl;
   double a1 = 0.0, a2 = 0.0;
-  if (c < C) {
-    for (int r = g; r < rows; r += NG) {
-      a1 += (double)part[((size_t)r * 2 + 0) * C + c];
-      a2 += (double)part[((size_t)r * 2 + 1) * C + c];
+  const int cq = c < C ? c : 0;
+  // four row groups per trip, unconditional loads, same order of additions (see bn_finalize_kernel)
+  for (int r = g; r < rows; r += 4 * NG) {
+    float p1[4], p2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = r + k * NG < rows ? r + k * NG : 0;
+      p1[k] = part[((size_t)rr * 2 + 0) * C + cq];
+      p2[k] = part[((size_t)rr * 2 + 1) * C + cq];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(p1[k]), "+v"(p2[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (r + k * NG < rows && c < C) {
+        a1 += (double)p1[k];
+        a2 += (double)p2[k];
+      }
   }
   sh[0][g][cl] = a1;
   sh[1][g][cl] = a2;
@@ -1075,8 +1107,23 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const uz_pack
     for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
       const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
       __syncthreads();
-      for (int r = ty; r < 64; r += 4)
-        tile[r][tx] = (r0 + r < R && c0 + tx < Cc) ? src[(size_t)(r0 + r) * Cc + c0 + tx] : 0.f;
+      {   // the 16 loads of a thread unconditional and in flight together (element 0 outside the matrix, dropped by the select;
+          // the values pass through an empty asm so that the select cannot pull the loads back under a branch): as
+          // `inside ? src[...] : 0` each was waited for before the next was issued
+        float tv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int r = ty + 4 * k;
+          tv[k] = src[(r0 + r < R && c0 + tx < Cc) ? (size_t)(r0 + r) * Cc + c0 + tx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(tv[k]));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int r = ty + 4 * k;
+          tile[r][tx] = (r0 + r < R && c0 + tx < Cc) ? tv[k] : 0.f;
+        }
+      }
       __syncthreads();
       for (int c = ty; c < 64; c += 4)
         if (c0 + c < Cc && r0 + tx < R) dst[(size_t)(c0 + c) * R + r0 + tx] = (T)tile[tx][c];
@@ -1108,8 +1155,21 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const uz_pack
     for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
       const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
       __syncthreads();
-      for (int r = ty; r < 64; r += 4)
-        tile4[r][tx] = (r0 + r < R && c0 + tx < Cc) ? src[(size_t)(r0 + r) * Cc + c0 + tx] : 0.f;
+      {   // (unconditional loads, as in the one-tap transpose above)
+        float tv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int r = ty + 4 * k;
+          tv[k] = src[(r0 + r < R && c0 + tx < Cc) ? (size_t)(r0 + r) * Cc + c0 + tx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(tv[k]));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int r = ty + 4 * k;
+          tile4[r][tx] = (r0 + r < R && c0 + tx < Cc) ? tv[k] : 0.f;
+        }
+      }
       __syncthreads();
       for (int c = ty; c < 64; c += 4) {
         const int j = c0 + c;
