@@ -241,6 +241,11 @@ __global__ __launch_bounds__(256) void resample2_kernel(const T* __restrict__ sr
 // (g0, g1; either may be null) and through MaxPool2d(2,2) (gp; routed to the FIRST maximum of each
 // window in (0,0),(0,1),(1,0),(1,1) order, the element ATen records).
 // ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void rsu_pin16(Vec16<T>& v) {   // see pin16 in uz_gemm_dma.hip
+  unsigned* r = reinterpret_cast<unsigned*>(&v);
+  asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
+
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void grad_combine_kernel(int N, int H, int W, int C, const T* __restrict__ act,
                                                            int lda, const T* __restrict__ g0, int ld0,
@@ -277,15 +282,31 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(int N, int H, int W, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) in[k] = 2 * ho + (k >> 1) < H && 2 * wo + (k & 1) < W;
       const bool has_pool = ho < Hp && wo < Wp;
-      if (has_pool) {
-        load_f(gp + (((size_t)img * Hp + ho) * Wp + wo) * ldp + c0, gv);
-      } else {
+      // every load of the window UNCONDITIONAL and in flight together (pixel 0 of `act` for a clipped tap / a missing operand,
+      // dropped by a select; the registers pass through an empty asm so that the selects cannot pull the loads back under
+      // branches): as loads under `if (in[k])` / `if (g != nullptr)` the thirteen of them came one round trip after the other
+      Vec16<T> gpr, ar[4], g0r[4], g1r[4];
+      gpr = ld16(has_pool ? gp + (((size_t)img * Hp + ho) * Wp + wo) * ldp + c0 : act + c0);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) gv[i] = 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const size_t p = p00 + (k >> 1) * W + (k & 1);
+        ar[k] = ld16(in[k] ? act + p * lda + c0 : act + c0);
+        g0r[k] = ld16(in[k] && g0 != nullptr ? g0 + p * ld0 + c0 : act + c0);
+        g1r[k] = ld16(in[k] && g1 != nullptr ? g1 + p * ld1 + c0 : act + c0);
+      }
+      rsu_pin16(gpr);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rsu_pin16(ar[k]);
+        rsu_pin16(g0r[k]);
+        rsu_pin16(g1r[k]);
       }
 #pragma unroll
+      for (int i = 0; i < VEC; ++i) gv[i] = has_pool ? (float)gpr.v[i] : 0.f;
+#pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (in[k]) load_f(act + (p00 + (k >> 1) * W + (k & 1)) * lda + c0, av[k]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) av[k][i] = (float)ar[k].v[i];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         best[i] = 0;
@@ -305,15 +326,14 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(int N, int H, int W, 
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s[i] = best[i] == k ? gv[i] : 0.f;
         if (g0 != nullptr) {
-          load_f(g0 + p * ld0 + c0, v);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) s[i] += v[i];
+          for (int i = 0; i < VEC; ++i) s[i] += (float)g0r[k].v[i];
         }
         if (g1 != nullptr) {
-          load_f(g1 + p * ld1 + c0, v);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) s[i] += v[i];
+          for (int i = 0; i < VEC; ++i) s[i] += (float)g1r[k].v[i];
         }
+        (void)v;
         store_f(out + p * ldo + c0, s);
       }
     }

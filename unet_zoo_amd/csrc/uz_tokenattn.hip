@@ -602,13 +602,34 @@ __global__ __launch_bounds__(1024) void chanattn_probs_kernel(const float* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* pl = scores + ((long long)b * H + h) * C * KV;
   const int n = C * KV;
+  // the plane passes: eight UNCONDITIONAL loads of a thread in flight (element 0 past the end, dropped by the select; values made
+  // opaque so that the select cannot pull the loads back under a branch), added in the same order as one load per trip -- these
+  // loops were 30 dependent L2 round trips per pass, and a load under `if (in range)` is waited for where the block ends
   float t = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) t += pl[i];
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = pl[i0 + k * 1024 < n ? i0 + k * 1024 : 0];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(v[k]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * 1024 < n) t += v[k];
+  }
   const float mean = block_sum(t, red) * scale / (float)n;
   t = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) {
-    const float d = pl[i] * scale - mean;
-    t += d * d;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = pl[i0 + k * 1024 < n ? i0 + k * 1024 : 0];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(v[k]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * 1024 < n) {
+        const float d = v[k] * scale - mean;
+        t += d * d;
+      }
   }
   const float rstd = rsqrtf(block_sum(t, red) / (float)n + eps);
   const float invH = 1.f / (float)H;
@@ -617,11 +638,24 @@ __global__ __launch_bounds__(1024) void chanattn_probs_kernel(const float* __res
   // one row: normalised scores and probabilities of this lane's RPT elements
   auto row = [&](int c, float (&sh)[RPT], float (&p)[RPT]) {
     float mx = -INFINITY;
+    if constexpr (RPT <= 4 || !BWD) {
 #pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-      const int kv = u * 64 + lane;
-      sh[u] = kv < KV ? (pl[(long long)c * KV + kv] * scale - mean) * rstd : -INFINITY;
-      mx = fmaxf(mx, sh[u]);
+      for (int u = 0; u < RPT; ++u) sh[u] = pl[(long long)c * KV + (u * 64 + lane < KV ? u * 64 + lane : 0)];   // (unconditional, in flight together)
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) asm volatile("" : "+v"(sh[u]));
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int kv = u * 64 + lane;
+        sh[u] = kv < KV ? (sh[u] * scale - mean) * rstd : -INFINITY;
+        mx = fmaxf(mx, sh[u]);
+      }
+    } else {   // (the backward at 16 elements per lane and 1024 threads: the batched form spills)
+#pragma unroll
+      for (int u = 0; u < RPT; ++u) {
+        const int kv = u * 64 + lane;
+        sh[u] = kv < KV ? (pl[(long long)c * KV + kv] * scale - mean) * rstd : -INFINITY;
+        mx = fmaxf(mx, sh[u]);
+      }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -662,11 +696,24 @@ __global__ __launch_bounds__(1024) void chanattn_probs_kernel(const float* __res
     for (int c = wave; c < C; c += 16) {
       float sh[RPT], p[RPT], g[RPT], dot = 0.f;
       row(c, sh, p);
+      if constexpr (RPT <= 4) {
 #pragma unroll
-      for (int u = 0; u < RPT; ++u) {
-        const int kv = u * 64 + lane;
-        g[u] = kv < KV ? dp[(long long)c * HK + kv] * invH : 0.f;
-        dot += p[u] * g[u];
+        for (int u = 0; u < RPT; ++u) g[u] = dp[(long long)c * HK + (u * 64 + lane < KV ? u * 64 + lane : 0)];   // (unconditional, in flight together)
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) asm volatile("" : "+v"(g[u]));
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+          const int kv = u * 64 + lane;
+          g[u] = kv < KV ? g[u] * invH : 0.f;
+          dot += p[u] * g[u];
+        }
+      } else {   // (16 elements per lane at 1024 threads: the batched form spills)
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+          const int kv = u * 64 + lane;
+          g[u] = kv < KV ? dp[(long long)c * HK + kv] * invH : 0.f;
+          dot += p[u] * g[u];
+        }
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
@@ -686,11 +733,24 @@ __global__ __launch_bounds__(1024) void chanattn_probs_kernel(const float* __res
     for (int c = wave; c < C; c += 16) {
       float sh[RPT], p[RPT], g[RPT], dot = 0.f;
       row(c, sh, p);
+      if constexpr (RPT <= 4) {
 #pragma unroll
-      for (int u = 0; u < RPT; ++u) {
-        const int kv = u * 64 + lane;
-        g[u] = kv < KV ? dp[(long long)c * HK + kv] * invH : 0.f;
-        dot += p[u] * g[u];
+        for (int u = 0; u < RPT; ++u) g[u] = dp[(long long)c * HK + (u * 64 + lane < KV ? u * 64 + lane : 0)];   // (unconditional, in flight together)
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) asm volatile("" : "+v"(g[u]));
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+          const int kv = u * 64 + lane;
+          g[u] = kv < KV ? g[u] * invH : 0.f;
+          dot += p[u] * g[u];
+        }
+      } else {   // (16 elements per lane at 1024 threads: the batched form spills)
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+          const int kv = u * 64 + lane;
+          g[u] = kv < KV ? dp[(long long)c * HK + kv] * invH : 0.f;
+          dot += p[u] * g[u];
+        }
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
