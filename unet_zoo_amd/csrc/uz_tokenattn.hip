@@ -29,6 +29,14 @@ template <typename T> __device__ __forceinline__ float uz_exp(float x) {
 //   apply   : s <- exp(scale * s - m[col]) / Z[col], elementwise
 constexpr int SM_SLICE = 512;   // rows per stats workgroup
 
+// keeps a 16-byte load unconditional (see pin16 in uz_gemm_dma.hip): the loaded registers pass through an empty asm, so a value
+// that is only used on one path is not loaded under that path's branch -- where hipcc 7.2 ends the block with s_waitcnt vmcnt(0)
+// and the loads of an unrolled group come one memory round trip after the other
+template <typename T> __device__ __forceinline__ void ta_pin16(Vec16<T>& v) {
+  unsigned* r = reinterpret_cast<unsigned*>(&v);
+  asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_cols_stats_kernel(const T* s, int ld, long long sb, int rows, int cols, float scale,
                                                                  float* part) {   // part[b][slice][2][cols]
@@ -46,8 +54,10 @@ __global__ __launch_bounds__(256) void softmax_cols_stats_kernel(const T* s, int
     for (int r = r_beg + rg; r < r_end; r += 64) {
       Vec16<T> v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        v[u] = (r + 16 * u < r_end) ? ld16(base + (long long)(r + 16 * u) * ld + c0) : zero16<T>();
+      for (int u = 0; u < 4; ++u)   // (unconditional: the slice's first row past its end; such a row enters as -inf below)
+        v[u] = ld16(base + (long long)(r + 16 * u < r_end ? r + 16 * u : r_beg) * ld + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ta_pin16(v[u]);
       // one rescale of the running sum per group of four rows: 5 exponentials per 4 elements instead of 8
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -125,8 +135,9 @@ __global__ __launch_bounds__(256) void softmax_cols_apply_kernel(T* s, int ld, l
   for (int r = 0; r < nr; r += 4) {
     Vec16<T> v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (r + u < nr) v[u] = ld16(p + (long long)(r + u) * ld);
+    for (int u = 0; u < 4; ++u) v[u] = ld16(p + (long long)(r + u < nr ? r + u : 0) * ld);   // (unconditional: row 0 past the end, not stored)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ta_pin16(v[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (r + u < nr) {
@@ -201,12 +212,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* a, T* s, int
     Vec16<T> v[RPT], w[RPT];
     float red = BWD ? 0.f : -INFINITY;
 #pragma unroll
+    for (int u = 0; u < RPT; ++u) {   // (unconditional loads, all in flight: chunk 0 of the row for a lane beyond the columns)
+      const int c = (u * 64 + lane) * VEC;
+      v[u] = ld16(s + off + (c < cols ? c : 0));
+      if constexpr (BWD) w[u] = ld16(a + off + (c < cols ? c : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      ta_pin16(v[u]);
+      if constexpr (BWD) ta_pin16(w[u]);
+    }
+#pragma unroll
     for (int u = 0; u < RPT; ++u) {
       const int c = (u * 64 + lane) * VEC;
       if (c < cols) {
-        v[u] = ld16(s + off + c);
         if constexpr (BWD) {
-          w[u] = ld16(a + off + c);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) red = fmaf(tof(v[u].v[e]), tof(w[u].v[e]), red);
         } else {
