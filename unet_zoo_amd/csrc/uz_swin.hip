@@ -1150,34 +1150,41 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
   WinTok ntq = {0, -1}, ntk = {0, -1};
   bf16x8 nq[2], ng[2], no[2], nk[2], nv[2];
   float nlse = 0.f;
-  // UNCONDITIONAL loads (a lane beyond the window -- 7 x 7 windows -- reads token 0 of its window and is zeroed by a select):
-  // as loads under `if (iq < N)` each group ended in s_waitcnt vmcnt(0) (hipcc 7.2) and the "prefetch" waited for its own data
-  // in the middle of the current window -- the kernel ran one memory round trip per window behind its own design.
+  // (The forward kernel's fetch is unconditional, DESIGN 3h.  Here that form measured SLOWER -- 52.8 -> 58.9 us on the 64 x 64
+  // token map -- the loop's top then waits with the previous window's dq / dk / dv stores behind the prefetched loads; the
+  // conditional form waits for its loads right here, before those stores are issued, and the second resident workgroup of the
+  // CU covers the round trip.)
   auto fetch = [&](int win) {
-    const bool qin = iq < N, kin = jk < N;
-    const WinTok tq0 = win_token(a, win, qin ? iq : 0), tk0 = win_token(a, win, kin ? jk : 0);
-    const bf16_t* row = qkv + (size_t)tq0.tok * a.ldq + h * AD + 8 * lh;
-    const bf16_t* grow = dout + (size_t)tq0.tok * a.lddo + h * AD + 8 * lh;
-    const bf16_t* orow = out + (size_t)tq0.tok * a.ldo + h * AD + 8 * lh;
-    const bf16_t* rowk = qkv + (size_t)tk0.tok * a.ldq + a.C + h * AD + 8 * lh;
-    // the RAW loaded registers are kept; the zeroing of lanes beyond the window happens where they are consumed, one window
-    // later (a select here would wait for the data at once)
-    nlse = a.lse[((size_t)win * a.heads + h) * N + (qin ? iq : 0)];
+    ntq = {0, -1};
+    ntk = {0, -1};
+    nlse = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      nq[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
-      ng[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks);
-      no[ks] = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
-      nk[ks] = *reinterpret_cast<const bf16x8*>(rowk + 16 * ks);
-      nv[ks] = *reinterpret_cast<const bf16x8*>(rowk + a.C + 16 * ks);
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) nq[ks][e] = ng[ks][e] = no[ks][e] = nk[ks][e] = nv[ks][e] = (bf16_t)0.f;
+    if (iq < N) {
+      ntq = win_token(a, win, iq);
+      const bf16_t* row = qkv + (size_t)ntq.tok * a.ldq + h * AD + 8 * lh;
+      const bf16_t* grow = dout + (size_t)ntq.tok * a.lddo + h * AD + 8 * lh;
+      const bf16_t* orow = out + (size_t)ntq.tok * a.ldo + h * AD + 8 * lh;
+      nlse = a.lse[((size_t)win * a.heads + h) * N + iq];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        nq[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+        ng[ks] = *reinterpret_cast<const bf16x8*>(grow + 16 * ks);
+        no[ks] = *reinterpret_cast<const bf16x8*>(orow + 16 * ks);
+      }
     }
-    ntq = qin ? tq0 : WinTok{0, -1};
-    ntk = kin ? tk0 : WinTok{0, -1};
-  };
-  const bool qin = iq < N, kin = jk < N;
-  bf16x8 zero8;
+    if (jk < N) {
+      ntk = win_token(a, win, jk);
+      const bf16_t* row = qkv + (size_t)ntk.tok * a.ldq + a.C + h * AD + 8 * lh;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) zero8[e] = (bf16_t)0.f;
+      for (int ks = 0; ks < 2; ++ks) {
+        nk[ks] = *reinterpret_cast<const bf16x8*>(row + 16 * ks);
+        nv[ks] = *reinterpret_cast<const bf16x8*>(row + a.C + 16 * ks);
+      }
+    }
+  };
   if ((int)blockIdx.x < nWin) fetch(blockIdx.x);
 
   for (int win = blockIdx.x; win < nWin; win += gridDim.x) {
@@ -1186,16 +1193,15 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
     const WinTok tq = ntq, tkk = ntk;
     bf16x8 qf[2], gf[2], kf[2], vf[2];
     float rq = 0.f, Di = 0.f;
-    const float lse = qin ? nlse : 0.f;
+    const float lse = nlse;
     {
       float q2 = 0.f, k2 = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = qin ? nq[ks] : zero8;
-        gf[ks] = qin ? ng[ks] : zero8;
-        kf[ks] = kin ? nk[ks] : zero8;
-        vf[ks] = kin ? nv[ks] : zero8;
-        no[ks] = qin ? no[ks] : zero8;
+        qf[ks] = nq[ks];
+        gf[ks] = ng[ks];
+        kf[ks] = nk[ks];
+        vf[ks] = nv[ks];
         // |q|^2, |k|^2 and dO . O on bf16 pairs (v_dot2c_f32_bf16: fp32 products and sums), 12 instructions instead of ~130
         const bf16x2* qp = reinterpret_cast<const bf16x2*>(&qf[ks]);
         const bf16x2* kp = reinterpret_cast<const bf16x2*>(&kf[ks]);
@@ -1252,10 +1258,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_mfma_kernel(const AttnArgs
         ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ut, 0, 0, 0);
         dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], gf[ks], dt, 0, 0, 0);
       }
-      {   // (unconditionally: a workgroup's last window fetches itself again rather than putting the loads under a branch)
-        const int nxt = win + (int)gridDim.x;
-        fetch(nxt < nWin ? nxt : win);
-      }
+      if (win + (int)gridDim.x < nWin) fetch(win + gridDim.x);
       float w1[16];
       // could any pair of this wave fall under the clamp?  1 / (|scale q_i| |k_j|) > 1e6 for the smallest non-zero |k| of the tile
       float corrQ = 0.f;
