@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(int N, int H, int W, 
       for (int k = 0; k < 4; ++k) {
         if (!in[k]) continue;
         const size_t p = p00 + (k >> 1) * W + (k & 1);
-        float s[VEC], v[VEC];
+        float s[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s[i] = best[i] == k ? gv[i] : 0.f;
         if (g0 != nullptr) {
@@ -333,7 +333,6 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(int N, int H, int W, 
 #pragma unroll
           for (int i = 0; i < VEC; ++i) s[i] += (float)g1r[k].v[i];
         }
-        (void)v;
         store_f(out + p * ldo + c0, s);
       }
     }

@@ -228,7 +228,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
     uint4 xr[U][MAXIT], sr[U][MAXIT];
     float mean[U], rstd[U], fsc[U];
     const bool has2 = BWD || second != nullptr;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       t[u] = t0 + (u * 4 + wave) * tpw + grp;
@@ -255,7 +254,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a, int lpt)
       const float fv = *pf;
       fsc[u] = a.sb != nullptr ? fv : 1.f;
     }
-    (void)zero4;
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
