@@ -4,6 +4,7 @@
     python tools/kres.py                      every .hip of unet_zoo_amd/csrc (four compiles at a time)
     python tools/kres.py uz_gemm_dma.hip ...  the named files
     python tools/kres.py --spills             only kernels with a spill or scratch
+    python tools/kres.py --loads              kernels whose loads are waited for one by one (load -> s_waitcnt vmcnt(0) -> load)
 
 hipcc cross-compiles gfx950 without a GPU (`--cuda-device-only -S`); the numbers are the `amdhsa.kernels` entries of the
 emitted assembly (`.vgpr_count` includes the accumulator registers, `.vgpr_spill_count`, `.private_segment_fixed_size` =
@@ -58,6 +59,34 @@ def parse_asm(text):
     return [k for k in kernels if "name" in k]
 
 
+def load_wait_points(text):
+    """{kernel symbol: (points, loads)}: `points` = places where a global / buffer load is followed within 25 instructions by
+    `s_waitcnt vmcnt(0)` with more loads still to come -- the signature of loads that run one memory round trip after the
+    other (hipcc 7.2 closes a block that contains a load with that wait, so `if (in range) v = *p;` serialises an
+    unrolled group of loads and a prefetch waits for its own data).  LDS-DMA loads (`... lds`) are not counted."""
+    lines = text.split("\n")
+    out, cur, start = {}, None, 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur, start = m.group(1), i
+        elif l.startswith(".Lfunc_end") and cur is not None:
+            body = [x for x in lines[start:i] if x.startswith("\t") and not x.startswith("\t.") and not x.startswith("\t;")]
+            ev = []
+            for j, x in enumerate(body):
+                if re.search(r"\b(global_load|buffer_load|flat_load)", x) and " lds" not in x:
+                    ev.append((j, "L"))
+                elif re.search(r"s_waitcnt.*vmcnt\(0\)", x):
+                    ev.append((j, "W"))
+            pts = 0
+            for k, (j, t) in enumerate(ev):
+                if t == "W" and k > 0 and ev[k - 1][1] == "L" and j - ev[k - 1][0] <= 25 and any(t2 == "L" for _, t2 in ev[k + 1:]):
+                    pts += 1
+            out[cur] = (pts, sum(1 for _, t in ev if t == "L"))
+            cur = None
+    return out
+
+
 def compile_one(path, extra=()):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -65,7 +94,11 @@ def compile_one(path, extra=()):
         if r.returncode != 0:
             raise RuntimeError(f"{path}: hipcc failed\n{r.stderr[-2000:]}")
         with open(out) as f:
-            ks = parse_asm(f.read())
+            text = f.read()
+        ks = parse_asm(text)
+        lw = load_wait_points(text)
+    for k in ks:
+        k["load_wait_points"], k["loads"] = lw.get(k["name"], (0, 0))
     names = demangle([k["name"] for k in ks])
     for k, n in zip(ks, names):
         k["demangled"] = n
@@ -92,6 +125,11 @@ def main(argv):
     only_spills = "--spills" in argv
     files = [a for a in argv if not a.startswith("--")]
     ks = collect(files)
+    if "--loads" in argv:     # kernels whose loads are waited for one by one, worst first
+        for k in sorted(ks, key=lambda k: -k["load_wait_points"]):
+            if k["load_wait_points"] >= 2:
+                print(f"{k['load_wait_points']:3d} load -> vmcnt(0) -> load points / {k['loads']:3d} loads  {k['file']:18s} {short(k['demangled'])}")
+        return 0
     bad = 0
     for k in ks:
         sp = k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)
