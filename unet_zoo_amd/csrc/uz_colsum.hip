@@ -33,7 +33,15 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const CsBatch b, fl
   constexpr int VEC = ElemTraits<T>::VEC;
   __shared__ __attribute__((aligned(16))) float red[256 * VEC];
   int i = 0;
-  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
+  {   // blk0 is increasing: binary search (a linear walk is one dependent scalar load from the argument segment per item)
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)blockIdx.x >= b.it[mid].blk0) lo = mid;
+      else hi = mid;
+    }
+    i = lo;
+  }
   const CsItem& it = b.it[i];
   const int local = blockIdx.x - it.blk0;
   const int bx = local % it.gx, by = local / it.gx;
@@ -76,13 +84,33 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(const CsBatch b, fl
 __global__ __launch_bounds__(1024) void colsum_batched_finalize_kernel(const CsBatch b, const float* __restrict__ ws) {
   __shared__ double sh[32][33];
   int i = 0;
-  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].fin0) ++i;
+  {   // fin0 is increasing: binary search (a linear walk is one dependent scalar load from the argument segment per item)
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)blockIdx.x >= b.it[mid].fin0) lo = mid;
+      else hi = mid;
+    }
+    i = lo;
+  }
   const CsItem& it = b.it[i];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int c = (blockIdx.x - it.fin0) * 32 + el;
   double s = 0.0;
-  if (c < it.C)
-    for (int r = g; r < it.gx; r += 32) s += (double)ws[(size_t)it.ws0 + (size_t)r * it.C + c];
+  {   // eight rows per trip, unconditional loads (row 0 / column 0 out of range, dropped), same order of additions
+    const bool in = c < it.C;
+    const float* base = ws + (size_t)it.ws0 + (in ? c : 0);
+    for (int r = g; r < it.gx; r += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + u * 32 < it.gx ? r + u * 32 : 0) * it.C];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (in && r + u * 32 < it.gx) s += (double)v[u];
+    }
+  }
   sh[g][el] = s;
   __syncthreads();
   if (g == 0 && c < it.C) {
@@ -159,13 +187,33 @@ struct SrBatch {
 __global__ __launch_bounds__(1024) void sum_rows_batched_kernel(const SrBatch b) {
   __shared__ double sh[32][33];
   int i = 0;
-  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
+  {   // blk0 is increasing: binary search (see colsum_batched_finalize_kernel)
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)blockIdx.x >= b.it[mid].blk0) lo = mid;
+      else hi = mid;
+    }
+    i = lo;
+  }
   const SrItem& it = b.it[i];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int e = (blockIdx.x - it.blk0) * 32 + el;
   double s = 0.0;
-  if (e < it.n)
-    for (int r = g; r < it.rows; r += 32) s += (double)it.partial[(size_t)r * it.n + e];
+  {   // eight rows per trip, unconditional loads, same order of additions
+    const bool in = e < it.n;
+    const float* base = it.partial + (in ? e : 0);
+    for (int r = g; r < it.rows; r += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + u * 32 < it.rows ? r + u * 32 : 0) * it.n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (in && r + u * 32 < it.rows) s += (double)v[u];
+    }
+  }
   sh[g][el] = s;
   __syncthreads();
   if (g == 0 && e < it.n) {
@@ -179,7 +227,15 @@ __global__ __launch_bounds__(1024) void sum_rows_batched_kernel(const SrBatch b)
 template <int RG>
 __global__ __launch_bounds__(256) void sum_rows_wide_batched_kernel(const SrBatch b) {
   int i = 0;
-  while (i + 1 < b.n && (int)blockIdx.x >= b.it[i + 1].blk0) ++i;
+  {   // blk0 is increasing: binary search (a linear walk is one dependent scalar load from the argument segment per item)
+    int lo = 0, hi = b.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)blockIdx.x >= b.it[mid].blk0) lo = mid;
+      else hi = mid;
+    }
+    i = lo;
+  }
   const SrItem& it = b.it[i];
   uz_sum_rows_wide_body<RG>(it.partial, it.n, it.rows, it.n, it.out0, it.n0, it.out1, (int)blockIdx.x - it.blk0);
 }

@@ -598,12 +598,12 @@ __global__ __launch_bounds__(1024) void ln_head_finalize_kernel(const float* __r
     const int col = k < K ? k * C + c : K * C + el;
     const bool in = k < K ? c < C : el < K;
     double s = 0.0;
-    // eight rows per trip, unconditional loads (row g / column 0 out of range, dropped below), added in the same order as one row
+    // eight rows per trip, unconditional loads (row 0 / column 0 out of range, dropped below), added in the same order as one row
     // per trip: this loop was rows / 128 dependent round trips per pass
     for (int r = g; r < rows; r += 8 * 128) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + u * 128 < rows ? r + u * 128 : g) * n + (in ? col : 0)];
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(r + u * 128 < rows ? r + u * 128 : 0) * n + (in ? col : 0)];
 #pragma unroll
       for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
 #pragma unroll

@@ -446,7 +446,15 @@ static_assert(sizeof(WgMulti) <= 4096, "kernel arguments");
 template <int BI, int BJ, int WI, int WJ, int TG>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_multi_kernel(const WgMulti m) {
   int i = 0;
-  while (i + 1 < m.n && (int)blockIdx.x >= m.first[i + 1]) ++i;
+  {   // first[] is increasing: binary search (a linear walk is one dependent scalar load from the argument segment per problem)
+    int lo = 0, hi = m.n;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int)blockIdx.x >= m.first[mid]) lo = mid;
+      else hi = mid;
+    }
+    i = lo;
+  }
   const int tiles = m.tiles[i], n = m.first[i + 1] - m.first[i];
   int local = blockIdx.x - m.first[i];
   // The tiles of one pixel range read the same dy / x pixels: put them on one XCD (workgroup ids 8 apart share an L2) and
