@@ -289,8 +289,20 @@ __global__ __launch_bounds__(1024) void sum_rows_f32_kernel(const float* __restr
   const int el = threadIdx.x % EW, g = threadIdx.x / EW;
   const int e = blockIdx.x * EW + el;
   double s = 0.0;
-  if (e < n)
-    for (int r = g; r < rows; r += NG) s += (double)partial[(size_t)r * ld + e];
+  {   // eight rows per trip, unconditional loads, same order of additions
+    const bool in = e < n;
+    const float* base = partial + (in ? e : 0);
+    for (int r = g; r < rows; r += 8 * NG) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + u * NG < rows ? r + u * NG : 0) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (in && r + u * NG < rows) s += (double)v[u];
+    }
+  }
   sh[g][el] = s;
   __syncthreads();
   if (g == 0 && e < n) {

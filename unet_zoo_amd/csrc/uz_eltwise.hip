@@ -885,8 +885,20 @@ __global__ __launch_bounds__(1024) void outconv_bwd_finalize_kernel(const float*
   const int ne = Kout * (C + 1);
   const int e = blockIdx.x * 32 + el;
   double s = 0.0;
-  if (e < ne)
-    for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * ne + e];
+  {   // eight rows per trip, unconditional loads (row 0 / element 0 out of range, dropped), same order of additions
+    const bool in = e < ne;
+    const float* base = partial + (in ? e : 0);
+    for (int r = g; r < rows; r += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + u * 32 < rows ? r + u * 32 : 0) * ne];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (in && r + u * 32 < rows) s += (double)v[u];
+    }
+  }
   sh[g][el] = s;
   __syncthreads();
 #pragma unroll
@@ -1005,8 +1017,20 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + el;
   double s = 0.0;
-  if (c < C)
-    for (int r = g; r < rows; r += 32) s += (double)partial[(size_t)r * C + c];
+  {   // eight rows per trip, unconditional loads, same order of additions
+    const bool in = c < C;
+    const float* base = partial + (in ? c : 0);
+    for (int r = g; r < rows; r += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + u * 32 < rows ? r + u * 32 : 0) * C];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (in && r + u * 32 < rows) s += (double)v[u];
+    }
+  }
   sh[g][el] = s;
   __syncthreads();
   if (g == 0 && c < C) {

@@ -2102,7 +2102,16 @@ __global__ __launch_bounds__(256) void cpb_bwd_finalize_kernel(const CpbBatch b,
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < nmain) {
     float t = 0.f;
-    for (int r = 0; r < rows; ++r) t += main_ws[(size_t)r * nmain + e];
+    for (int r = 0; r < rows; r += 8) {   // eight rows per trip, unconditional loads, same order of additions
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = main_ws[(size_t)(r + u < rows ? r + u : 0) * nmain + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r + u < rows) t += v[u];
+    }
     const int j = e / hidden, k = e - j * hidden;
     if (j < heads) m.dw2[j * hidden + k] = t;
     else if (j == heads) m.dw1[2 * k] = t;
