@@ -365,13 +365,8 @@ __global__ __launch_bounds__(256) void side_taps_kernel(const T* __restrict__ x,
     const int p = p0 + pl;
     float v[CH][VEC];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      if (p < P) {
-        load_f(x + (size_t)p * ldx + (sub + j * LPP) * VEC, v[j]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
-      }
+    for (int j = 0; j < CH; ++j) {   // unconditional loads (pixel 0 past the end: its sums are not stored), DESIGN 3h
+      load_f(x + (size_t)(p < P ? p : 0) * ldx + (sub + j * LPP) * VEC, v[j]);
     }
     const int img = p / HW, hw = p - img * HW;
 #pragma unroll
@@ -438,21 +433,31 @@ __global__ __launch_bounds__(256) void side_bwd_kernel(const T* __restrict__ x, 
     const int img = ok ? p / HW : 0, hw = ok ? p - img * HW : 0;
     const int h = hw / W, ww0 = hw - h * W;
 #pragma unroll
+    // unconditional loads, all in flight (pixel 0 / tap position 0 out of range, dropped by the selects below; the tap values
+    // pass through an empty asm so that the selects cannot pull the loads back under branches): DESIGN 3h
     for (int j = 0; j < CH; ++j) {
-      if (ok) {
-        load_f(x + (size_t)p * ldx + (sub + j * LPP) * VEC, v[j]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
-      }
+      load_f(x + (size_t)(ok ? p : 0) * ldx + (sub + j * LPP) * VEC, v[j]);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) d[j][i] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int hh = h - (k / 3 - 1), ww = ww0 - (k % 3 - 1);  // dt[q][tap] = dy[q - off(tap)]
-      gk[k] = (ok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
-                  ? g[(size_t)img * g_img + hh * W + ww] : 0.f;
+      const bool in = ok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+      gk[k] = g[in ? (size_t)img * g_img + hh * W + ww : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(gk[k]));
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int hh = h - (k / 3 - 1), ww = ww0 - (k % 3 - 1);
+      gk[k] = (ok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? gk[k] : 0.f;
       ab[k] += gk[k];
 #pragma unroll
       for (int j = 0; j < CH; ++j)
